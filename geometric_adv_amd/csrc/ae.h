@@ -1,0 +1,45 @@
+// Device-side description of the victim auto-encoder (internal to libgeoadv.so).
+#pragma once
+#include "common.h"
+
+namespace geoadv {
+
+constexpr int ENC_L = GEOADV_ENC_LAYERS;   // 5 per-point layers
+constexpr int ENC_ROWS = 64;               // points per workgroup tile
+
+// Packed weight fragments for v_mfma_f32_32x32x2_f32.  For a layer computing out[r][n] =
+// sum_k in[r][k] * W[k][n] (K = fan-in, a multiple of 8; N padded to a multiple of 32):
+//   packed[((cb * K/8 + t) * 64 + lane) * 4 + u] = W[8t + 4*(lane>>5) + u][32cb + (lane&31)]
+// so one wave fetches the B operands of four consecutive MFMA k-steps for column block cb with a
+// single coalesced 1 KiB global_load_dwordx4.
+struct PackedLayer {
+    const float *w;   // packed fragments (device)
+    int K, N;         // fan-in, (padded) fan-out
+};
+
+struct DeviceAE {
+    int n_points, bneck;
+    int enc_dims[ENC_L + 1];
+    int dec_dims[GEOADV_DEC_LAYERS + 1];
+    // encoder: layer 0 (fan-in 3) stays un-packed, [3][C1] row-major, plus its transpose use
+    const float *w0;               // [3][C1]
+    PackedLayer enc_fwd[ENC_L];    // [1..4] used: in[r][C_i] -> [C_{i+1}]
+    PackedLayer enc_bwd[ENC_L];    // [1..4] used: W_i^T : [C_{i+1}] -> [C_i]
+    const float *scale[ENC_L];     // BN folded: h = max(a*scale + shift, 0), a = x@W (no bias)
+    const float *shift[ENC_L];     // shift = b*scale + (beta - mean*scale)
+    // decoder
+    const float *v0, *c0;          // [bneck][256], [256]
+    const float *v1, *c1;          // [256][256], [256]
+    const float *v0t, *v1t;        // transposes for the backward pass: [256][bneck], [256][256]
+    PackedLayer dec2_fwd;          // V2: K = 256 -> N = 3*n_points (padded to 32)
+    PackedLayer dec2_bwd;          // V2^T: K = 3*n_points (padded to 8) -> N = 256
+    const float *c2;               // [3*n_points]
+};
+
+}  // namespace geoadv
+
+struct geoadv_ae {
+    geoadv::DeviceAE d;
+    void *arena;       // one device allocation holding everything above
+    size_t arena_bytes;
+};

@@ -1,0 +1,324 @@
+// Chamfer nearest-neighbour distance (NnDistance / NnDistanceGrad) for gfx950.
+//
+// Replaces NmDistanceKernelLauncher / NmDistanceGradKernelLauncher
+// (external/structural_losses/tf_nndistance.cpp:168,208; kernels tf_nndistance_g.cu:5-157).
+// Results reproduce the reference CPU op bit for bit (tf_nndistance.cpp:21-43, 126-163):
+//   d = ((dx*dx) + (dy*dy)) + (dz*dz) in fp32 with every operation rounded on its own (this
+//   file is compiled with -ffp-contract=off and carries the pragma below), strict '<' so the
+//   lowest target index wins ties, and a CPU-ordered (deterministic) gradient accumulation.
+//
+// Forward layout: one workgroup = 4 waves x 64 lanes; every lane keeps R query points in
+// registers; the target cloud is staged into LDS as three SoA planes (x[], y[], z[]) and read
+// back with wave-uniform (broadcast) ds_read_b128; wave w scans the w-th quarter of each stage.
+// The argmin is tracked per CHUNK of 8 targets (one v_min per pair, one compare per chunk) and
+// the winning chunk is re-scanned at the end for the first index whose distance equals the
+// minimum -- exact, and ~25 % fewer VALU instructions than compare+select per pair.
+// The kernel is VALU-issue bound (8 unfusable fp32 ops + 1 min per pair); HBM traffic is the
+// 20*B*(N+M) algorithmic bytes.
+#include "common.h"
+#include <limits.h>
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+namespace geoadv {
+
+struct ChamferScan {
+    const float *query;   // [b, nq, 3]
+    const float *target;  // [b, nt, 3]
+    float *dist;          // [b, nq]
+    int *idx;             // [b, nq]
+    int nq, nt;
+};
+struct ChamferArgs {
+    ChamferScan s[4];
+};
+
+constexpr int CH_THREADS = 256;
+constexpr int CH_WAVES = CH_THREADS / kWave;
+constexpr int CH_CHUNK = 8;        // targets per argmin chunk
+constexpr int CH_STAGE = 4096;     // targets per LDS stage: 3 planes x 16 KB
+
+__device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, float qy, float qz) {
+    const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return (xx + yy) + zz;
+}
+
+template <int R>
+__global__ __launch_bounds__(CH_THREADS) void chamfer_scan_kernel(ChamferArgs args) {
+    const ChamferScan sc = args.s[blockIdx.z];
+    const int nq = sc.nq, nt = sc.nt;
+    const int q0 = blockIdx.x * (kWave * R);
+    if (q0 >= nq) return;
+    const int c = blockIdx.y;
+    const float *Q = sc.query + (size_t)c * nq * 3;
+    const float *T = sc.target + (size_t)c * nt * 3;
+
+    __shared__ __attribute__((aligned(16))) float sx[CH_STAGE];
+    __shared__ __attribute__((aligned(16))) float sy[CH_STAGE];
+    __shared__ __attribute__((aligned(16))) float sz[CH_STAGE];
+    __shared__ float mdist[CH_WAVES][kWave * R];
+    __shared__ int midx[CH_WAVES][kWave * R];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+
+    float qx[R], qy[R], qz[R], best[R];
+    int bestk[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int qi = q0 + r * kWave + lane;
+        qi = qi < nq ? qi : nq - 1;
+        qx[r] = Q[3 * qi];
+        qy[r] = Q[3 * qi + 1];
+        qz[r] = Q[3 * qi + 2];
+        best[r] = INFINITY;
+        bestk[r] = -1;
+    }
+
+    for (int t0 = 0; t0 < nt; t0 += CH_STAGE) {
+        const int cnt = min(CH_STAGE, nt - t0);
+        const int cntp = (cnt + CH_CHUNK - 1) / CH_CHUNK * CH_CHUNK;
+        __syncthreads();   // the previous stage has been consumed
+        for (int e = threadIdx.x; e < cntp; e += CH_THREADS) {
+            float x = INFINITY, y = INFINITY, z = INFINITY;   // padding: distance +inf, never wins
+            if (e < cnt) {
+                x = T[3 * (size_t)(t0 + e)];
+                y = T[3 * (size_t)(t0 + e) + 1];
+                z = T[3 * (size_t)(t0 + e) + 2];
+            }
+            sx[e] = x; sy[e] = y; sz[e] = z;
+        }
+        __syncthreads();
+        const int nchunks = cntp / CH_CHUNK;
+        const int cbeg = nchunks * wave / CH_WAVES, cend = nchunks * (wave + 1) / CH_WAVES;
+        if (cbeg < cend) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (bestk[r] < 0) bestk[r] = t0 + cbeg * CH_CHUNK;
+        }
+        for (int ch = cbeg; ch < cend; ++ch) {
+            const int k0 = ch * CH_CHUNK;
+            float tx[CH_CHUNK], ty[CH_CHUNK], tz[CH_CHUNK];
+#pragma unroll
+            for (int v = 0; v < CH_CHUNK / 4; ++v) {
+                const float4 a = *reinterpret_cast<const float4 *>(&sx[k0 + 4 * v]);
+                const float4 bb = *reinterpret_cast<const float4 *>(&sy[k0 + 4 * v]);
+                const float4 cc = *reinterpret_cast<const float4 *>(&sz[k0 + 4 * v]);
+                tx[4 * v] = a.x; tx[4 * v + 1] = a.y; tx[4 * v + 2] = a.z; tx[4 * v + 3] = a.w;
+                ty[4 * v] = bb.x; ty[4 * v + 1] = bb.y; ty[4 * v + 2] = bb.z; ty[4 * v + 3] = bb.w;
+                tz[4 * v] = cc.x; tz[4 * v + 1] = cc.y; tz[4 * v + 2] = cc.z; tz[4 * v + 3] = cc.w;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float cm = sqdist(tx[0], ty[0], tz[0], qx[r], qy[r], qz[r]);
+#pragma unroll
+                for (int u = 1; u < CH_CHUNK; ++u)
+                    cm = fminf(cm, sqdist(tx[u], ty[u], tz[u], qx[r], qy[r], qz[r]));
+                if (cm < best[r]) {       // strict: an equal later chunk never replaces an earlier one
+                    best[r] = cm;
+                    bestk[r] = t0 + k0;
+                }
+            }
+        }
+    }
+
+    // Re-scan the winning chunk of every query for the first index attaining the minimum.
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int found = INT_MAX;
+        if (bestk[r] >= 0) {
+            found = bestk[r];
+            bool hit = false;
+            for (int u = 0; u < CH_CHUNK; ++u) {
+                const int k = bestk[r] + u;
+                if (k < nt) {
+                    const float d = sqdist(T[3 * (size_t)k], T[3 * (size_t)k + 1], T[3 * (size_t)k + 2], qx[r], qy[r], qz[r]);
+                    if (!hit && d == best[r]) { hit = true; found = k; }
+                }
+            }
+        }
+        mdist[wave][r * kWave + lane] = best[r];
+        midx[wave][r * kWave + lane] = found;
+    }
+    __syncthreads();
+    for (int qq = threadIdx.x; qq < kWave * R; qq += CH_THREADS) {
+        float d = mdist[0][qq];
+        int k = midx[0][qq];
+#pragma unroll
+        for (int w = 1; w < CH_WAVES; ++w) {
+            const float dw = mdist[w][qq];
+            const int kw = midx[w][qq];
+            if (dw < d || (dw == d && kw < k)) { d = dw; k = kw; }
+        }
+        if (q0 + qq < nq) {
+            sc.dist[(size_t)c * nq + q0 + qq] = d;
+            sc.idx[(size_t)c * nq + q0 + qq] = k;
+        }
+    }
+}
+
+// m == 0: the reference CPU loop leaves best = 0, besti = 0 (tf_nndistance.cpp:27-28,39-40).
+__global__ void chamfer_fill_empty_kernel(float *dist, int *idx, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { dist[i] = 0.f; idx[i] = 0; }
+}
+
+int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t stream) {
+    if (b <= 0) return GEOADV_OK;
+    ChamferArgs args;
+    int live = 0, maxq = 0;
+    for (int i = 0; i < nscan; ++i) {
+        const ChamferScan &s = scans[i];
+        if (s.nq <= 0) continue;
+        if (s.nt <= 0) {
+            const size_t count = (size_t)b * s.nq;
+            chamfer_fill_empty_kernel<<<(unsigned)((count + 255) / 256), 256, 0, stream>>>(s.dist, s.idx, count);
+            GA_LAUNCH_CHECK();
+            continue;
+        }
+        args.s[live++] = s;
+        maxq = s.nq > maxq ? s.nq : maxq;
+    }
+    if (!live) return GEOADV_OK;
+    // Pick the register blocking so that the grid still fills 256 CUs x 4 workgroups.
+    auto groups = [&](int R) { return (long)cdiv(maxq, kWave * R) * b * live; };
+    dim3 block(CH_THREADS);
+    if (groups(4) >= 768) {
+        chamfer_scan_kernel<4><<<dim3(cdiv(maxq, kWave * 4), b, live), block, 0, stream>>>(args);
+    } else if (groups(2) >= 768) {
+        chamfer_scan_kernel<2><<<dim3(cdiv(maxq, kWave * 2), b, live), block, 0, stream>>>(args);
+    } else {
+        chamfer_scan_kernel<1><<<dim3(cdiv(maxq, kWave), b, live), block, 0, stream>>>(args);
+    }
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Gradient.  One workgroup per (cloud, output side).  For the output side "own" (n_own points)
+// every point j receives its own term g*(p_j - q_match[j]) and the scatter terms of all points
+// k of the other side with match_other[k] == j.  The reference CPU op applies them in a fixed
+// order (tf_nndistance.cpp:130-163): for grad_xyz1 own term first, then scatter terms in
+// ascending k; for grad_xyz2 scatter terms (ascending j) first, then the own term.  We get the
+// ascending order by sorting the keys (match_other[k] << 16 | k) in LDS (bitonic) and walking the
+// segment of equal high halves; arithmetic is the CPU's, so the result is bit-identical.
+// ------------------------------------------------------------------------------------------
+constexpr int CG_THREADS = 512;
+
+template <bool OWN_FIRST>
+__device__ void chamfer_grad_side(int n_own, const float *own, const float *gd_own, const int *match_own,
+                                  int n_oth, const float *oth, const float *gd_oth, const int *match_oth,
+                                  float *gout, unsigned *keys, int P) {
+    for (int i = threadIdx.x; i < P; i += CG_THREADS)
+        keys[i] = i < n_oth ? (((unsigned)match_oth[i] << 16) | (unsigned)i) : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += CG_THREADS) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned a = keys[i], bkey = keys[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > bkey) == up) { keys[i] = bkey; keys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int j = threadIdx.x; j < n_own; j += CG_THREADS) {
+        const float px = own[3 * j], py = own[3 * j + 1], pz = own[3 * j + 2];
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        const int mj = match_own[j];
+        const float g = gd_own[j] * 2;
+        const float ox = g * (px - oth[3 * mj]), oy = g * (py - oth[3 * mj + 1]), oz = g * (pz - oth[3 * mj + 2]);
+        if (OWN_FIRST) { ax += ox; ay += oy; az += oz; }
+        // lower bound of (j << 16) in the sorted keys
+        const unsigned want = (unsigned)j << 16;
+        int lo = 0, hi = P;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        for (; lo < P && (keys[lo] >> 16) == (unsigned)j; ++lo) {
+            const int k = keys[lo] & 0xFFFF;
+            const float gk = gd_oth[k] * 2;
+            // other point k matched our point j: it subtracts gk*(q_k - p_j) from us
+            ax -= gk * (oth[3 * k] - px);
+            ay -= gk * (oth[3 * k + 1] - py);
+            az -= gk * (oth[3 * k + 2] - pz);
+        }
+        if (!OWN_FIRST) { ax += ox; ay += oy; az += oz; }
+        gout[3 * j] = ax; gout[3 * j + 1] = ay; gout[3 * j + 2] = az;
+    }
+}
+
+__global__ __launch_bounds__(CG_THREADS) void chamfer_grad_kernel(
+    int n, const float *xyz1, int m, const float *xyz2, const float *gd1, const int *idx1,
+    const float *gd2, const int *idx2, float *g1, float *g2, int P1, int P2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned keys[];
+    const int c = blockIdx.x;
+    const float *p = xyz1 + (size_t)c * n * 3, *q = xyz2 + (size_t)c * m * 3;
+    if (blockIdx.y == 0) {
+        if (g1)
+            chamfer_grad_side<true>(n, p, gd1 + (size_t)c * n, idx1 + (size_t)c * n, m, q, gd2 + (size_t)c * m,
+                                    idx2 + (size_t)c * m, g1 + (size_t)c * n * 3, keys, P2);
+    } else {
+        if (g2)
+            chamfer_grad_side<false>(m, q, gd2 + (size_t)c * m, idx2 + (size_t)c * m, n, p, gd1 + (size_t)c * n,
+                                     idx1 + (size_t)c * n, g2 + (size_t)c * m * 3, keys, P1);
+    }
+}
+
+static int pow2_at_least(int v) {
+    int p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int launch_chamfer_grad(int b, int n, const float *xyz1, int m, const float *xyz2, const float *gd1,
+                        const int *idx1, const float *gd2, const int *idx2, float *g1, float *g2,
+                        hipStream_t stream) {
+    if (b <= 0 || (n <= 0 && m <= 0)) return GEOADV_OK;
+    GA_REQUIRE(n <= 32768 && m <= 32768, "nn_distance_grad supports at most 32768 points per cloud (got n=%d m=%d)", n, m);
+    if (n == 0 || m == 0) {   // nothing matches anything: both gradients are zero
+        if (g1 && n) GA_HIP(hipMemsetAsync(g1, 0, sizeof(float) * (size_t)b * n * 3, stream));
+        if (g2 && m) GA_HIP(hipMemsetAsync(g2, 0, sizeof(float) * (size_t)b * m * 3, stream));
+        return GEOADV_OK;
+    }
+    const int P1 = pow2_at_least(n), P2 = pow2_at_least(m);
+    const size_t lds = sizeof(unsigned) * (size_t)(P1 > P2 ? P1 : P2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        attr_set = true;
+    }
+    chamfer_grad_kernel<<<dim3(b, g2 ? 2 : 1), CG_THREADS, lds, stream>>>(n, xyz1, m, xyz2, gd1, idx1, gd2, idx2,
+                                                                         g1, g2, P1, P2);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+}  // namespace geoadv
+
+using namespace geoadv;
+
+extern "C" int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1,
+                                  int *idx1, float *dist2, int *idx2, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 0 && m >= 0, "nn_distance: negative dimension (b=%d n=%d m=%d)", b, n, m);
+    GA_REQUIRE(b <= 65535, "nn_distance: batch %d exceeds 65535", b);
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE((n == 0 || (xyz1 && dist1 && idx1)) && (m == 0 || (xyz2 && dist2 && idx2)), "nn_distance: null pointer");
+    ChamferScan scans[2] = {{xyz1, xyz2, dist1, idx1, n, m}, {xyz2, xyz1, dist2, idx2, m, n}};
+    return launch_chamfer_scans(scans, 2, b, as_stream(stream));
+}
+
+extern "C" int geoadv_nn_distance_grad(int b, int n, const float *xyz1, int m, const float *xyz2,
+                                       const float *grad_dist1, const int *idx1, const float *grad_dist2,
+                                       const int *idx2, float *grad_xyz1, float *grad_xyz2, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 0 && m >= 0, "nn_distance_grad: negative dimension");
+    GA_REQUIRE(b <= 65535, "nn_distance_grad: batch %d exceeds 65535", b);
+    return launch_chamfer_grad(b, n, xyz1, m, xyz2, grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2,
+                               as_stream(stream));
+}

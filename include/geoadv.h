@@ -1,0 +1,223 @@
+/*
+ * geoadv.h -- C ABI of libgeoadv.so, the MI355X (gfx950) implementation of the geometric
+ * adversarial attack hot path of itailang/geometric_adv.
+ *
+ * This header is the drop-in boundary.  Every entry point below replaces one native launcher
+ * (or one session-level Python method) of the reference; the reference file:line is cited at
+ * each declaration.  Conventions, all entry points:
+ *   - plain C linkage, plain pointers and ints; no torch / TF types,
+ *   - every data pointer is a DEVICE pointer (HBM) unless the parameter name starts with host_,
+ *   - row-major contiguous fp32 / int32 tensors in the reference's layouts,
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only ENQUEUE
+ *     work (no allocation, no host synchronisation) unless stated otherwise, so they are
+ *     capturable into a hipGraph,
+ *   - return value: 0 on success, non-zero on error; geoadv_last_error() gives the message
+ *     (thread-local).  Shape violations that the reference reports through OP_REQUIRES /
+ *     errors::InvalidArgument (tf_nndistance.cpp:51-58, tf_grouping.cpp:70-74) return
+ *     GEOADV_EINVAL here,
+ *   - the caller owns every buffer; the library owns only what lives behind the opaque
+ *     geoadv_ae / geoadv_attack handles.
+ */
+#ifndef GEOADV_H
+#define GEOADV_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOADV_OK      0
+#define GEOADV_EINVAL  1   /* bad shape / argument                      */
+#define GEOADV_EHIP    2   /* a HIP runtime call or kernel launch failed */
+#define GEOADV_ENOMEM  3
+
+int         geoadv_version(void);                /* 1000*major + minor */
+const char *geoadv_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Structural losses: external/structural_losses
+ * ---------------------------------------------------------------------------------------- */
+
+/* NmDistanceKernelLauncher(b,n,xyz,m,xyz2,result,result_i,result2,result2_i)
+ * (tf_nndistance.cpp:168, kernel tf_nndistance_g.cu:5-131).  dist1[b,n], idx1[b,n] = squared
+ * distance / index of the nearest xyz2 point for every xyz1 point; dist2/idx2 the converse.
+ * Results are bit-identical to the reference CPU op (tf_nndistance.cpp:21-43): unfused fp32
+ * arithmetic, lowest index on ties.  n == 0 or m == 0 is accepted (m == 0 gives dist 0 / idx 0,
+ * like the CPU loop). */
+int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
+                       float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
+
+/* NmDistanceGradKernelLauncher(b,n,xyz1,m,xyz2,grad_dist1,idx1,grad_dist2,idx2,grad_xyz1,grad_xyz2)
+ * (tf_nndistance.cpp:208, kernel tf_nndistance_g.cu:132-157).  Outputs are fully overwritten
+ * (the reference memsets them).  Unlike the reference GPU kernel (float atomicAdd) the
+ * accumulation order is the CPU op's (tf_nndistance.cpp:126-163), so results are deterministic
+ * and bit-identical to it.  Requires n, m <= 32768. */
+int geoadv_nn_distance_grad(int b, int n, const float *xyz1, int m, const float *xyz2,
+                            const float *grad_dist1, const int *idx1,
+                            const float *grad_dist2, const int *idx2,
+                            float *grad_xyz1, float *grad_xyz2, void *stream);
+
+/* approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp) (tf_approxmatch.cpp:141, kernel
+ * tf_approxmatch_g.cu:1-181).  match is (b,m,n) like the reference GPU op: match[b,l,k] couples
+ * xyz2 point l with xyz1 point k.  temp: scratch of geoadv_approx_match_temp_floats(b,n,m) floats
+ * (the reference allocates b*(n+m)*2, tf_approxmatch.cpp:168).  The level schedule is the CPU
+ * op's (11 levels, tf_approxmatch.cpp:31). */
+size_t geoadv_approx_match_temp_floats(int b, int n, int m);
+int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2,
+                        float *match, float *temp, void *stream);
+/* matchcostLauncher (tf_approxmatch.cpp:142; tf_approxmatch_g.cu:183-227): out[b]. */
+int geoadv_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2,
+                      const float *match, float *out, void *stream);
+/* matchcostgradLauncher (tf_approxmatch.cpp:143; tf_approxmatch_g.cu:229-295). */
+int geoadv_match_cost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
+                           const float *match, float *grad1, float *grad2, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouping: external/grouping
+ * ---------------------------------------------------------------------------------------- */
+
+/* queryBallPointLauncher(b,n,m,radius,nsample,xyz1,xyz2,idx,pts_cnt) (tf_grouping.cpp:66;
+ * tf_grouping_g.cu:3-36,125-128). */
+int geoadv_query_ball_point(int b, int n, int m, float radius, int nsample,
+                            const float *xyz1, const float *xyz2, int *idx, int *pts_cnt, void *stream);
+/* selectionSortLauncher(b,n,m,k,dist,outi,out) (tf_grouping.cpp:108; tf_grouping_g.cu:83-131).
+ * dist, outi, out are (b,m,n).  The first k entries of every row equal the reference's; the
+ * remaining n-k entries hold the unselected elements in the reference's (swap) order too. */
+int geoadv_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream);
+/* groupPointLauncher(b,n,c,m,nsample,points,idx,out) (tf_grouping.cpp:142; tf_grouping_g.cu:40-57). */
+int geoadv_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
+                       float *out, void *stream);
+/* groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points) (tf_grouping.cpp:173;
+ * tf_grouping_g.cu:61-78).  grad_points is zeroed here (the reference op memsets it,
+ * tf_grouping.cpp:204) and accumulated in a fixed order (no float atomics). */
+int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                            float *grad_points, void *stream);
+/* knn_point(k, xyz1, xyz2) (tf_grouping.py:48-75) fused: squared distances + the k smallest per
+ * query in the order SelectionSort produces (incl. its swap tie rule), without the (b,m,n)
+ * matrix or the two tiled (b,m,n,3) operands.  val, idx are (b,m,k).  1 <= k <= 64. */
+int geoadv_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2,
+                     float *val, int *idx, void *stream);
+/* defender/get_knn_dists_per_point.py:78-81 fused: knn_point(k+1, pc, pc), drop the first column,
+ * gather, euclidean distance.  out is (b,n,k). */
+int geoadv_knn_dists(int b, int n, int k, const float *pc, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Victim auto-encoder: src/encoders_decoders.py:19-147 with the architecture of
+ * src/ae_templates.py:11-39 (5 x [conv1d k=1, BN(inference), ReLU], max over points,
+ * FC-ReLU, FC-ReLU, FC).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct geoadv_ae geoadv_ae;
+
+#define GEOADV_ENC_LAYERS 5
+#define GEOADV_DEC_LAYERS 3
+
+/* Host-side description of the weights, in the reference's variable layout
+ * (adversary_autoencoder.py:42-51 restores exactly these variables):
+ *   enc_w[i]  : [C_i, C_{i+1}]   (tflearn conv_1d W[1,1,Cin,Cout] squeezed), enc_b[i] : [C_{i+1}]
+ *   bn_*[i]   : [C_{i+1}]         gamma, beta, moving_mean, moving_variance (eps = 1e-5)
+ *   dec_w[k]  : [D_k, D_{k+1}], dec_b[k] : [D_{k+1}]
+ * enc_dims = {3, 64, 128, 128, 256, bneck}; dec_dims = {bneck, 256, 256, 3*n_points}.
+ * This build supports the template's widths (every C_i, i>=1, a multiple of 32; bneck = 128). */
+typedef struct geoadv_ae_weights {
+    int n_points;
+    int enc_dims[GEOADV_ENC_LAYERS + 1];
+    int dec_dims[GEOADV_DEC_LAYERS + 1];
+    const float *enc_w[GEOADV_ENC_LAYERS], *enc_b[GEOADV_ENC_LAYERS];
+    const float *bn_gamma[GEOADV_ENC_LAYERS], *bn_beta[GEOADV_ENC_LAYERS];
+    const float *bn_mean[GEOADV_ENC_LAYERS], *bn_var[GEOADV_ENC_LAYERS];
+    const float *dec_w[GEOADV_DEC_LAYERS], *dec_b[GEOADV_DEC_LAYERS];
+} geoadv_ae_weights;
+
+/* Uploads (and re-packs for MFMA) the HOST weights.  Allocates device memory; synchronous. */
+int  geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *host_weights);
+void geoadv_ae_destroy(geoadv_ae *ae);
+
+/* AdversaryAutoEncoder.reconstruct / AutoEncoder.transform (adversary_autoencoder.py:75-91):
+ * pc[b,n,3] -> latent[b,bneck] (may be NULL) and recon[b,n,3] (may be NULL).
+ * workspace: geoadv_ae_workspace_bytes(ae,b) bytes of device scratch. */
+size_t geoadv_ae_workspace_bytes(const geoadv_ae *ae, int b);
+int geoadv_ae_forward(const geoadv_ae *ae, int b, const float *pc, float *latent, float *recon,
+                      void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The attack loop: AdvAE (src/adv_ae.py:30-251) + Adversary (src/adversary.py:9-57).
+ * One handle = one batch slot of `batch` clouds with device-resident state
+ * (pert, Adam m/v/beta powers, best-so-far outputs).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct geoadv_attack geoadv_attack;
+
+#define GEOADV_LOSS_ADV_CHAMFER 0   /* loss_adv_type 'chamfer' (output space), adv_ae.py:88   */
+#define GEOADV_LOSS_ADV_LATENT  1   /* loss_adv_type 'latent',  adv_ae.py:85-86,107-116      */
+#define GEOADV_LOSS_DIST_CHAMFER 0  /* loss_dist_type 'chamfer', adv_ae.py:98-102            */
+#define GEOADV_LOSS_DIST_PERT    1  /* loss_dist_type 'pert',    adv_ae.py:93-97             */
+
+typedef struct geoadv_attack_config {
+    int   batch;                    /* conf.batch_size                                        */
+    int   loss_adv_type;            /* GEOADV_LOSS_ADV_*                                      */
+    int   loss_dist_type;           /* GEOADV_LOSS_DIST_*                                     */
+    float max_point_pert_weight;    /* conf.max_point_pert_weight (adv_ae.py:94-95)           */
+    float max_point_dist_weight;    /* conf.max_point_dist_weight (adv_ae.py:99-100)          */
+    float learning_rate;            /* conf.learning_rate (adv_ae.py:146,152)                 */
+    float emd_weight;               /* build-defined: loss_adv += emd_weight*match_cost/N; 0 = off */
+} geoadv_attack_config;
+
+int  geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, const geoadv_attack_config *cfg);
+void geoadv_attack_destroy(geoadv_attack *at);
+
+/* feed_dict of adv_ae.py:202,213: x = source_pc[B,N,3], gt = target_pc[B,N,3],
+ * target_z = target_latent[B,bneck], dist_weight[B].  Device pointers, copied into the handle. */
+int geoadv_attack_set_inputs(geoadv_attack *at, const float *source_pc, const float *target_pc,
+                             const float *target_latent, const float *dist_weight, void *stream);
+/* Adversary.init_pert (adversary.py:27-28): pert <- init[B,N,3] (device).  Also resets the
+ * best-so-far bookkeeping of _attack_one_batch (adv_ae.py:197-200).  The Adam slots and beta
+ * powers are NOT reset (they are never re-initialised in the reference, adv_ae.py:74) unless
+ * reset_optimizer != 0. */
+int geoadv_attack_init_pert(geoadv_attack *at, const float *init_pert, int reset_optimizer, void *stream);
+
+/* Runs `iterations` iterations of the hot loop (adv_ae.py:216-246): each is one Adam step on
+ * pert followed by the evaluation of the per-cloud metrics of the UPDATED pert; iterations whose
+ * 1-based global index is >= thresh take part in the keep-best update (strict '<' on the target
+ * reconstruction error).  Everything stays on the device; nothing is synchronised.
+ * `first_iteration` is the 0-based index of the first iteration of this call within the current
+ * dist-weight run (so a 500-iteration attack may be issued as several calls).
+ * metrics_hist: optional device buffer [iterations, 6, B] receiving, per iteration,
+ *   loss_adv, loss_dist, loss_pert, loss_max (or max_dist), input_dist, loss_ae  (adv_ae.py:219-221). */
+int geoadv_attack_run(geoadv_attack *at, int first_iteration, int iterations, int thresh,
+                      float *metrics_hist, void *stream);
+
+/* Results of the keep-best bookkeeping (adv_ae.py:238-249), device -> caller device buffers:
+ * metrics[B,5] = loss_adv, loss_dist, source_chamfer_dist, target_nre, target_recon_error
+ * (target_nre = target_recon_error / target_ae_loss_ref[b]), adv[B,N,3], recon[B,N,3]. */
+int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_loss_ref,
+                           float *metrics, float *adv, float *recon, void *stream);
+
+/* Introspection for tests: copies of the current device state (any pointer may be NULL).
+ * pert/adv/recon/grad [B,N,3]; latent [B,bneck]; idx_* [B,N] of the last forward:
+ * idx_r1/idx_r2 = nn_distance(recon, gt) indices, idx_a1/idx_a2 = nn_distance(adv, x) indices. */
+int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, float *recon, float *latent,
+                       float *grad, int *idx_r1, int *idx_r2, int *idx_a1, int *idx_a2, void *stream);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * enable != 0: every geoadv_attack_run iteration brackets its kernels with events (a small
+ * fixed pool is recycled).  geoadv_attack_profile_read synchronises the stream and returns, for
+ * kernel class `which` (GEOADV_PROF_*), the number of launches timed and their total ms. */
+#define GEOADV_PROF_ENCODER_FWD 0
+#define GEOADV_PROF_DECODER_FWD 1
+#define GEOADV_PROF_CHAMFER_FWD 2
+#define GEOADV_PROF_LOSS_GRAD   3
+#define GEOADV_PROF_DECODER_BWD 4
+#define GEOADV_PROF_ENCODER_BWD 5
+#define GEOADV_PROF_ADAM        6
+#define GEOADV_PROF_COUNT       7
+int geoadv_attack_profile(geoadv_attack *at, int enable);
+int geoadv_attack_profile_read(geoadv_attack *at, int which, int *launches, float *total_ms);
+
+/* Micro-benchmarks used by bench.py / DESIGN.md to calibrate the rooflines on the box
+ * (not part of the reference's surface).  Returns elapsed ms of `iters` repetitions. */
+int geoadv_microbench(int which, int iters, float *ms, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOADV_H */

@@ -1,0 +1,31 @@
+"""CPU: the C-ABI library loads and exports every symbol include/geoadv.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "geoadv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(geoadv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    names = _declared()
+    for must in ["geoadv_nn_distance", "geoadv_nn_distance_grad", "geoadv_approx_match", "geoadv_match_cost",
+                 "geoadv_match_cost_grad", "geoadv_selection_sort", "geoadv_group_point", "geoadv_group_point_grad",
+                 "geoadv_query_ball_point", "geoadv_knn_point", "geoadv_attack_run"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from geometric_adv_amd import _lib
+    import __graft_entry__
+    if not os.path.exists(_lib.LIB_PATH):
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _declared() if not hasattr(lib, n)]
+    assert not missing, "libgeoadv.so lacks: %s" % missing
+    assert lib.geoadv_version() >= 1

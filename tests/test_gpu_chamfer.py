@@ -1,0 +1,128 @@
+"""GPU parity: nn_distance / nn_distance_grad through the C ABI vs the golden vectors (reference
+CPU functions) and vs the oracle on seeded inputs.  Bit-exact: indices AND float outputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_nn_distance_golden(dev, golden_nn):
+    from geometric_adv_amd import ops
+    g = golden_nn
+    for name in g["cases"]:
+        d1, i1, d2, i2 = ops.nn_distance(_t(g[f"{name}_xyz1"], dev), _t(g[f"{name}_xyz2"], dev))
+        assert np.array_equal(i1.cpu().numpy(), g[f"{name}_idx1"]), name
+        assert np.array_equal(i2.cpu().numpy(), g[f"{name}_idx2"]), name
+        assert np.array_equal(_bits(d1.cpu().numpy()), _bits(g[f"{name}_dist1"])), name
+        assert np.array_equal(_bits(d2.cpu().numpy()), _bits(g[f"{name}_dist2"])), name
+
+
+def test_nn_distance_grad_golden(dev, golden_nn):
+    from geometric_adv_amd import ops
+    g = golden_nn
+    for name in g["cases"]:
+        g1, g2 = ops.nn_distance_grad(_t(g[f"{name}_xyz1"], dev), _t(g[f"{name}_xyz2"], dev),
+                                      _t(g[f"{name}_gd1"], dev), _t(g[f"{name}_idx1"], dev),
+                                      _t(g[f"{name}_gd2"], dev), _t(g[f"{name}_idx2"], dev))
+        assert np.array_equal(_bits(g1.cpu().numpy()), _bits(g[f"{name}_gxyz1"])), name
+        assert np.array_equal(_bits(g2.cpu().numpy()), _bits(g[f"{name}_gxyz2"])), name
+
+
+@pytest.mark.parametrize("b,n,m", [(4, 2048, 2048), (2, 4500, 777), (3, 100, 5000), (1, 8192, 8192), (70, 33, 65)])
+def test_nn_distance_vs_oracle(dev, oracle, b, n, m):
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x1, x2 = cloud(100 + n, b, n), cloud(200 + m, b, m)
+    # near-coincident clouds (the adv-vs-source regime): plenty of near ties
+    if n == m:
+        x2 = (x1 + np.float32(1e-4) * cloud(7, b, n)).astype(np.float32)
+    want = oracle.nn_distance(x1, x2)
+    got = ops.nn_distance(_t(x1, dev), _t(x2, dev))
+    for w, gt, what in zip(want, got, ["dist1", "idx1", "dist2", "idx2"]):
+        gt = gt.cpu().numpy()
+        if w.dtype == np.int32:
+            assert np.array_equal(gt, w), what
+        else:
+            assert np.array_equal(_bits(gt), _bits(w)), what
+    rng = np.random.default_rng(1)
+    gd1 = rng.standard_normal((b, n)).astype(np.float32)
+    gd2 = rng.standard_normal((b, m)).astype(np.float32)
+    wg1, wg2 = oracle.nn_distance_grad(x1, x2, gd1, want[1], gd2, want[3])
+    g1, g2 = ops.nn_distance_grad(_t(x1, dev), _t(x2, dev), _t(gd1, dev), got[1], _t(gd2, dev), got[3])
+    assert np.array_equal(_bits(g1.cpu().numpy()), _bits(wg1))
+    assert np.array_equal(_bits(g2.cpu().numpy()), _bits(wg2))
+
+
+def test_nn_distance_full_size_properties(dev):
+    """Config-2 size (B=32, N=2048): size-independent properties instead of a CPU re-run:
+    a cloud against itself gives idx = identity / dist = 0; against a permuted copy gives the
+    inverse permutation; results do not depend on the batch a cloud sits in."""
+    import torch
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x = _t(cloud(3, 32, 2048), dev)
+    d1, i1, d2, i2 = ops.nn_distance(x, x)
+    ar = torch.arange(2048, device=dev, dtype=torch.int32).expand(32, -1)
+    assert torch.equal(i1, ar) and torch.equal(i2, ar)
+    assert not d1.any() and not d2.any()
+    perm = torch.randperm(2048, device=dev)
+    y = x[:, perm].contiguous()
+    d1, i1, d2, i2 = ops.nn_distance(x, y)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(2048, device=dev)
+    assert torch.equal(i1.long(), inv.expand(32, -1))
+    assert torch.equal(i2.long(), perm.expand(32, -1))
+    z = _t(cloud(4, 32, 2048), dev)
+    full = ops.nn_distance(x, z)
+    part = ops.nn_distance(x[5:7].contiguous(), z[5:7].contiguous())
+    for a, b_ in zip(full, part):
+        assert torch.equal(a[5:7], b_)
+
+
+def test_nn_distance_edge_cases(dev):
+    import torch
+    from geometric_adv_amd import ops
+    e = torch.empty((2, 0, 3), device=dev)
+    x = torch.rand((2, 5, 3), device=dev)
+    d1, i1, d2, i2 = ops.nn_distance(x, e)          # no targets: the CPU loop leaves 0 / 0
+    assert d1.shape == (2, 5) and not d1.any() and not i1.any() and d2.shape == (2, 0)
+    d1, i1, d2, i2 = ops.nn_distance(torch.empty((0, 4, 3), device=dev), torch.empty((0, 4, 3), device=dev))
+    assert d1.shape == (0, 4)
+    with pytest.raises(ValueError):
+        ops.nn_distance(torch.rand((2, 5, 2), device=dev), x)
+    with pytest.raises(ValueError):
+        ops.nn_distance(torch.rand((3, 5, 3), device=dev), x)
+    with pytest.raises(ValueError):
+        ops.nn_distance(torch.rand((2, 5, 3)), torch.rand((2, 5, 3)))   # CPU tensors: no CPU path
+
+
+def test_nn_distance_autograd(dev):
+    """The registered gradient (tf_nndistance.py:35-41) through torch autograd."""
+    import torch
+    from geometric_adv_amd import ops
+    a = torch.rand((2, 50, 3), device=dev, requires_grad=True)
+    b_ = torch.rand((2, 60, 3), device=dev, requires_grad=True)
+    d1, i1, d2, i2 = ops.nn_distance_autograd(a, b_)
+    (d1.mean(1) + d2.mean(1)).sum().backward()
+    # same thing with torch's own ops on the gathered pairs
+    a2 = a.detach().clone().requires_grad_(True); b2 = b_.detach().clone().requires_grad_(True)
+    p1 = ((a2 - torch.gather(b2, 1, i1.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    p2 = ((b2 - torch.gather(a2, 1, i2.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    (p1.mean(1) + p2.mean(1)).sum().backward()
+    torch.testing.assert_close(a.grad, a2.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(b_.grad, b2.grad, rtol=1e-5, atol=1e-7)
