@@ -1,0 +1,211 @@
+"""AdvAE: the geometric adversarial attack on a point-cloud auto-encoder (src/adv_ae.py:25-251).
+
+Same constructor / attack() contract as the reference class; the TF graph + session are replaced
+by a device-resident loop in libgeoadv.so (geoadv_attack_*): one fused forward per iteration,
+sparse encoder backward, CPU-ordered Chamfer gradients, TF-1.13-form Adam on the perturbation.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .adversary import init_pert_value
+from .autoencoder import PointNetAE
+
+
+class Configuration:
+    """The fields AdvAE reads from the reference's pickled Configuration (src/autoencoder.py:19-82,
+    patched in attacker/run_attack.py:84-107).  Plain attributes; `weights` replaces
+    ae_dir/ae_restore_epoch (a dict or .npz keyed by TF variable names, see weights.py)."""
+
+    def __init__(self, batch_size, n_points, weights, loss="chamfer", loss_adv_type="chamfer",
+                 loss_dist_type="chamfer", dist_weight_list=(1.0,), max_point_pert_weight=0.0,
+                 max_point_dist_weight=0.0, num_iterations=500, num_iterations_thresh=400,
+                 learning_rate=0.01, ae_name="autoencoder", emd_weight=0.0, verbose=False):
+        self.batch_size = int(batch_size)
+        self.n_input = [int(n_points), 3]
+        self.n_output = [int(n_points), 3]
+        self.weights = weights
+        self.loss = loss
+        self.loss_adv_type = loss_adv_type
+        self.loss_dist_type = loss_dist_type
+        self.dist_weight_list = list(dist_weight_list)
+        self.max_point_pert_weight = float(max_point_pert_weight)
+        self.max_point_dist_weight = float(max_point_dist_weight)
+        self.num_iterations = int(num_iterations)
+        self.num_iterations_thresh = int(num_iterations_thresh)
+        self.learning_rate = float(learning_rate)
+        self.ae_name = ae_name
+        self.emd_weight = float(emd_weight)
+        self.verbose = verbose
+
+
+class _AttackConfig(C.Structure):
+    _fields_ = [("batch", C.c_int), ("loss_adv_type", C.c_int), ("loss_dist_type", C.c_int),
+                ("max_point_pert_weight", C.c_float), ("max_point_dist_weight", C.c_float),
+                ("learning_rate", C.c_float), ("emd_weight", C.c_float)]
+
+
+PROF_NAMES = ["encoder_fwd", "decoder_fwd", "chamfer_fwd", "loss_grad", "decoder_bwd", "encoder_bwd", "adam"]
+
+
+class AdvAE:
+    def __init__(self, adversary_name, configuration, device=None, ae=None):
+        c = configuration
+        self.configuration = c
+        self.name = adversary_name
+        if c.loss != "chamfer":
+            raise ValueError("loss=%r: AdvAE as shipped only builds with loss='chamfer' (adv_ae.py:124 fails for 'emd')" % c.loss)
+        if c.loss_adv_type not in ("chamfer", "latent"):
+            raise ValueError("loss_adv_type must be 'latent' or 'chamfer' (run_attack.py:49)")
+        if c.loss_dist_type not in ("pert", "chamfer"):
+            raise ValueError("loss_dist_type must be 'pert' or 'chamfer' (run_attack.py:50)")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.ae = ae if ae is not None else PointNetAE(c.weights, c.n_input[0], c.ae_name, self.device)
+        self.n = c.n_input[0]
+        self.B = c.batch_size
+        cfg = _AttackConfig(self.B, 1 if c.loss_adv_type == "latent" else 0, 1 if c.loss_dist_type == "pert" else 0,
+                            c.max_point_pert_weight, c.max_point_dist_weight, c.learning_rate, c.emd_weight)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_attack_create(C.byref(self._h), self.ae.handle, C.byref(cfg)), "attack_create")
+        self.last_history = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                _lib.lib().geoadv_attack_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- low-level device API (used by bench.py and the tests) ---------------------------
+    def _dev(self, a, shape=None):
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float32))
+        t = t.to(self.device, dtype=torch.float32).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t
+
+    def set_inputs(self, source_pc, target_pc, target_latent, dist_weight):
+        B, n = self.B, self.n
+        x = self._dev(source_pc, (B, n, 3)); gt = self._dev(target_pc, (B, n, 3))
+        tz = None if target_latent is None else self._dev(target_latent, (B, 128))
+        w = self._dev(np.ones(B, np.float32) * dist_weight if np.isscalar(dist_weight) else dist_weight, (B,))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_attack_set_inputs(self._h, _lib.ptr(x), _lib.ptr(gt), _lib.ptr(tz), _lib.ptr(w),
+                                                           _lib.stream_handle()), "attack_set_inputs")
+
+    def init_pert(self, init=None, reset_optimizer=False):
+        """Adversary.init_pert (adversary.py:27-28).  Adam's slots are NOT reset by default: the
+        reference initialises them once per graph (adv_ae.py:74) and never again."""
+        if init is None:
+            init = init_pert_value(self.B, self.n)
+        p = self._dev(init, (self.B, self.n, 3))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_attack_init_pert(self._h, _lib.ptr(p), int(bool(reset_optimizer)),
+                                                          _lib.stream_handle()), "attack_init_pert")
+
+    def run(self, first_iteration, iterations, thresh, history=None):
+        """Enqueue `iterations` attack iterations (no host sync).  history: optional GPU tensor
+        [iterations, 6, B] receiving loss_adv, loss_dist, loss_pert, loss_max, input_dist, loss_ae."""
+        if history is not None and tuple(history.shape) != (iterations, 6, self.B):
+            raise ValueError("history must be of shape (iterations, 6, batch)")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_attack_run(self._h, int(first_iteration), int(iterations), int(thresh),
+                                                    _lib.ptr(history), _lib.stream_handle()), "attack_run")
+
+    def get_best(self, target_ae_loss_ref):
+        B, n = self.B, self.n
+        ref = self._dev(target_ae_loss_ref, (B,))
+        metrics = torch.empty((B, 5), dtype=torch.float32, device=self.device)
+        adv = torch.empty((B, n, 3), dtype=torch.float32, device=self.device)
+        recon = torch.empty((B, n, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_attack_get_best(self._h, _lib.ptr(ref), _lib.ptr(metrics), _lib.ptr(adv),
+                                                         _lib.ptr(recon), _lib.stream_handle()), "attack_get_best")
+        return metrics, adv, recon
+
+    def peek(self):
+        """Current device state (test introspection): dict of GPU tensors."""
+        B, n, dev = self.B, self.n, self.device
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        i = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        out = dict(pert=f(B, n, 3), adv=f(B, n, 3), recon=f(B, n, 3), latent=f(B, 128), grad=f(B, n, 3),
+                   idx_r1=i(B, n), idx_r2=i(B, n), idx_a1=i(B, n), idx_a2=i(B, n))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().geoadv_attack_peek(self._h, *[_lib.ptr(out[k]) for k in
+                       ("pert", "adv", "recon", "latent", "grad", "idx_r1", "idx_r2", "idx_a1", "idx_a2")],
+                       _lib.stream_handle()), "attack_peek")
+        return out
+
+    def profile(self, enable):
+        _lib.check(_lib.lib().geoadv_attack_profile(self._h, int(bool(enable))), "attack_profile")
+
+    def profile_read(self):
+        """{kernel class: (launches, total_ms)} measured with HIP events on the launch stream."""
+        out = {}
+        for k, name in enumerate(PROF_NAMES):
+            n_, ms = C.c_int(0), C.c_float(0)
+            _lib.check(_lib.lib().geoadv_attack_profile_read(self._h, k, C.byref(n_), C.byref(ms)), "attack_profile_read")
+            out[name] = (n_.value, ms.value)
+        return out
+
+    # ---- the reference's public surface ----------------------------------------------------
+    def reconstruct(self, X, GT=None, compute_loss=True):
+        return self.ae.reconstruct(X, GT, compute_loss)
+
+    def attack(self, source_pc, target_latent, target_pc, target_ae_loss_ref, configuration=None, log_file=None):
+        """adv_ae.py:155-189.  Returns (adversarial_metrics [W,n,5], adversarial_pc_input [W,n,N,3],
+        adversarial_pc_recon [W,n,N,3]) as numpy arrays, W = len(dist_weight_list)."""
+        c = configuration if configuration is not None else self.configuration
+        n_examples = len(source_pc)
+        batch_size = c.batch_size
+        assert n_examples % batch_size == 0, \
+            'The number of examples (%d) should be divided by the batch size (%d)' % (n_examples, batch_size)
+        n_batches = n_examples // batch_size
+        metrics, pcs_in, pcs_rec = [], [], []
+        for i in range(n_batches):
+            start_time = time.time()
+            s, e = i * batch_size, (i + 1) * batch_size
+            m_, a_, r_ = self._attack_one_batch(source_pc[s:e], None if target_latent is None else target_latent[s:e],
+                                                target_pc[s:e], target_ae_loss_ref[s:e], log_file)
+            metrics.append(m_); pcs_in.append(a_); pcs_rec.append(r_)
+            duration = time.time() - start_time
+            print("Batch: %04d out of %04d, attack time (minutes): %.4f" % (i + 1, n_batches, duration / 60.0))
+            if log_file is not None:
+                log_file.write('Batch %04d\tDuration %.4f\n' % (i + 1, duration / 60.0))
+        return np.concatenate(metrics, axis=1), np.concatenate(pcs_in, axis=1), np.concatenate(pcs_rec, axis=1)
+
+    def _attack_one_batch(self, source_pc, target_latent, target_pc, target_ae_loss_ref, log_file=None, init_pert=None):
+        """adv_ae.py:191-251."""
+        c = self.configuration
+        W = len(c.dist_weight_list)
+        B, n = self.B, self.n
+        metrics_all = np.zeros((W, B, 5), np.float32)
+        adv_all = np.zeros((W, B, n, 3), np.float32)
+        rec_all = np.zeros((W, B, n, 3), np.float32)
+        hist = torch.empty((c.num_iterations, 6, B), dtype=torch.float32, device=self.device)
+        self.last_history = []
+        for i, dist_weight in enumerate(c.dist_weight_list):
+            self.set_inputs(source_pc, target_pc, target_latent, float(dist_weight))
+            self.init_pert(init_pert)
+            self.run(0, c.num_iterations, c.num_iterations_thresh, hist)
+            m_, a_, r_ = self.get_best(target_ae_loss_ref)
+            h = hist.cpu().numpy()                                   # the only host sync of the run
+            self.last_history.append(h)
+            step = (c.num_iterations // 10) or 1
+            for it in range(c.num_iterations):
+                if (it + 1) % step == 0:
+                    la, ld, lp, lm = (h[it, k].mean() for k in range(4))
+                    loss = (h[it, 0] + dist_weight * h[it, 1]).mean()
+                    if c.verbose:
+                        print("Weight {} of {}, Iteration {} of {}, loss={} loss_adv={} loss_dist={} loss_pert={} loss_max={}"
+                              .format(i + 1, W, it + 1, c.num_iterations, loss, la, ld, lp, lm))
+                    if log_file is not None:
+                        log_file.write('Dist weight %.4f\tIteration %.04d\tloss: %.4f\tloss_adv: %.4f\tloss_dist: %.4f\t'
+                                       'loss_pert: %.4f\tloss_max: %.4f\n' % (dist_weight, it + 1, loss, la, ld, lp, lm))
+            metrics_all[i] = m_.cpu().numpy(); adv_all[i] = a_.cpu().numpy(); rec_all[i] = r_.cpu().numpy()
+        return metrics_all, adv_all, rec_all

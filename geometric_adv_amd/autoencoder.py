@@ -1,0 +1,113 @@
+"""Host-side handle of the victim auto-encoder (forward only).
+
+Mirrors what the attack path uses of src/adversary_autoencoder.py (restore_ae_model :42-51,
+reconstruct :75-91, get_latent_vectors) and src/autoencoder.py (get_loss_per_pc :150-168): the
+weights are uploaded once into libgeoadv.so (geoadv_ae_create packs them for MFMA) and every call
+runs the fused gfx950 kernels.  Training the AE is out of scope.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops, weights as W
+
+
+class _AEWeights(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("enc_dims", C.c_int * 6), ("dec_dims", C.c_int * 4),
+                ("enc_w", C.c_void_p * 5), ("enc_b", C.c_void_p * 5),
+                ("bn_gamma", C.c_void_p * 5), ("bn_beta", C.c_void_p * 5),
+                ("bn_mean", C.c_void_p * 5), ("bn_var", C.c_void_p * 5),
+                ("dec_w", C.c_void_p * 3), ("dec_b", C.c_void_p * 3)]
+
+
+class PointNetAE:
+    """PointNet-style encoder + FC decoder with frozen weights on one GPU."""
+
+    def __init__(self, weights, n_points, ae_name=W.AE_NAME, device=None):
+        """weights: dict of TF-variable-name -> array (see weights.py) or a path to such an .npz."""
+        if isinstance(weights, str):
+            weights = W.load_npz(weights)
+        self.n_points = int(n_points)
+        self.bneck = 128
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self._canon = W.canonical(weights, self.n_points, ae_name)     # keeps the host arrays alive
+        hw = _AEWeights()
+        hw.n_points = self.n_points
+        hw.enc_dims[:] = W.enc_dims()
+        hw.dec_dims[:] = W.dec_dims(self.n_points)
+        for i in range(5):
+            hw.enc_w[i] = self._canon["enc_w"][i].ctypes.data
+            hw.enc_b[i] = self._canon["enc_b"][i].ctypes.data
+            hw.bn_gamma[i] = self._canon["gamma"][i].ctypes.data
+            hw.bn_beta[i] = self._canon["beta"][i].ctypes.data
+            hw.bn_mean[i] = self._canon["mean"][i].ctypes.data
+            hw.bn_var[i] = self._canon["var"][i].ctypes.data
+        for k in range(3):
+            hw.dec_w[k] = self._canon["dec_w"][k].ctypes.data
+            hw.dec_b[k] = self._canon["dec_b"][k].ctypes.data
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_ae_create(C.byref(self._h), C.byref(hw)), "ae_create")
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                _lib.lib().geoadv_ae_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _as_dev(self, a):
+        t = torch.as_tensor(np.asarray(a, dtype=np.float32)) if not isinstance(a, torch.Tensor) else a
+        t = t.to(self.device, dtype=torch.float32).contiguous()
+        if t.dim() != 3 or t.shape[1] != self.n_points or t.shape[2] != 3:
+            raise ValueError("point clouds must be of shape (batch, %d, 3); got %s" % (self.n_points, tuple(t.shape)))
+        return t
+
+    def forward(self, pc, want_recon=True):
+        """pc (b,n,3) -> (recon (b,n,3) or None, latent (b,128)) as GPU tensors."""
+        pc = self._as_dev(pc)
+        b = pc.shape[0]
+        latent = torch.empty((b, self.bneck), dtype=torch.float32, device=self.device)
+        recon = torch.empty((b, self.n_points, 3), dtype=torch.float32, device=self.device) if want_recon else None
+        with torch.cuda.device(self.device):
+            need = _lib.lib().geoadv_ae_workspace_bytes(self._h, b)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            st = _lib.lib().geoadv_ae_forward(self._h, b, _lib.ptr(pc), _lib.ptr(latent), _lib.ptr(recon),
+                                              _lib.ptr(self._ws), _lib.stream_handle())
+        _lib.check(st, "ae_forward")
+        return recon, latent
+
+    # -- the reference's method names -----------------------------------------------------
+    def reconstruct(self, X, GT=None, compute_loss=True):
+        """adversary_autoencoder.py:75-91: returns (reconstructions, mean Chamfer loss or None) as numpy."""
+        recon, _ = self.forward(X)
+        loss = None
+        if compute_loss:
+            gt = self._as_dev(X if GT is None else GT)
+            loss = float(self.loss_per_pc_tensor(recon, gt).mean().item())
+        return recon.cpu().numpy(), loss
+
+    def transform(self, X):
+        """Latent codes (autoencoder.py: transform / get_latent_vectors) as numpy."""
+        _, z = self.forward(X, want_recon=False)
+        return z.cpu().numpy()
+
+    get_latent_vectors = transform
+
+    def loss_per_pc_tensor(self, recon, gt):
+        d1, _, d2, _ = ops.nn_distance(recon, gt)
+        return d1.mean(1) + d2.mean(1)                      # pointnet_ae.py:75-79 / adv_ae.py:120-121
+
+    def get_loss_per_pc(self, feed_data, orig_data=None):
+        """autoencoder.py:150-168: per-cloud Chamfer reconstruction error as numpy."""
+        recon, _ = self.forward(feed_data)
+        gt = self._as_dev(feed_data if orig_data is None else orig_data)
+        return self.loss_per_pc_tensor(recon, gt).cpu().numpy()

@@ -1,0 +1,195 @@
+// geoadv_ae: device-resident, MFMA-packed weights of the victim auto-encoder + plain forward
+// (AdversaryAutoEncoder.restore_ae_model / reconstruct, src/adversary_autoencoder.py:42-51,75-91).
+#include "ae.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace geoadv {
+
+int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
+                       int *parg, int *pcnt, hipStream_t stream);
+int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
+                         int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
+int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
+int encoder_tiles(int n);
+
+static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// B[k][n] for k < K, n < N taken from src through `at(k, n)`; zero padded to (Kp, Np).
+template <class F>
+static void pack_fragments(std::vector<float> &dst, size_t off, int K, int N, int Kp, int Np, F at) {
+    const int kg = Kp / 8;
+    for (int cb = 0; cb < Np / 32; ++cb)
+        for (int t = 0; t < kg; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 8 * t + 4 * (lane >> 5) + u, n = 32 * cb + (lane & 31);
+                    dst[off + (((size_t)cb * kg + t) * 64 + lane) * 4 + u] = (k < K && n < N) ? at(k, n) : 0.f;
+                }
+}
+
+struct ForwardScratch {
+    float *pmax; int *parg; int *pcnt;   // [b][tiles][128]
+    float *z; int *crit; int *zcnt;      // [b][128]
+    int *dense;                          // [b]
+    float *d1, *d2;                      // [b][256]
+    size_t bytes;
+};
+
+ForwardScratch carve_forward_scratch(void *base, int b, int n_points) {
+    ForwardScratch s;
+    const size_t tiles = encoder_tiles(n_points);
+    char *p = static_cast<char *>(base);
+    auto take = [&](size_t bytes) { char *q = p; p += rup(bytes, 256); return q; };
+    s.pmax = reinterpret_cast<float *>(take(sizeof(float) * b * tiles * 128));
+    s.parg = reinterpret_cast<int *>(take(sizeof(int) * b * tiles * 128));
+    s.pcnt = reinterpret_cast<int *>(take(sizeof(int) * b * tiles * 128));
+    s.z = reinterpret_cast<float *>(take(sizeof(float) * b * 128));
+    s.crit = reinterpret_cast<int *>(take(sizeof(int) * b * 128));
+    s.zcnt = reinterpret_cast<int *>(take(sizeof(int) * b * 128));
+    s.dense = reinterpret_cast<int *>(take(sizeof(int) * b));
+    s.d1 = reinterpret_cast<float *>(take(sizeof(float) * b * 256));
+    s.d2 = reinterpret_cast<float *>(take(sizeof(float) * b * 256));
+    s.bytes = (size_t)(p - static_cast<char *>(base));
+    return s;
+}
+
+int run_forward(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, const ForwardScratch &s,
+                float *recon, hipStream_t stream) {
+    if (int st = launch_encoder_fwd(A, b, x, pert, adv_out, s.pmax, s.parg, s.pcnt, stream)) return st;
+    if (int st = launch_latent_decode(A, b, s.pmax, s.parg, s.pcnt, s.z, s.crit, s.zcnt, s.dense,
+                                      recon ? s.d1 : nullptr, s.d2, stream)) return st;
+    if (recon)
+        if (int st = launch_decoder_fc2(A, b, s.d2, recon, stream)) return st;
+    return GEOADV_OK;
+}
+
+}  // namespace geoadv
+
+using namespace geoadv;
+
+extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
+    GA_REQUIRE(out && hw, "ae_create: null argument");
+    static const int want_enc[ENC_L + 1] = {3, 64, 128, 128, 256, 128};
+    for (int i = 0; i <= ENC_L; ++i)
+        GA_REQUIRE(hw->enc_dims[i] == want_enc[i],
+                   "ae_create: encoder widths must be 3,64,128,128,256,128 (src/ae_templates.py:22); got %d at %d",
+                   hw->enc_dims[i], i);
+    const int n = hw->n_points;
+    GA_REQUIRE(n >= 1 && n <= 32768, "ae_create: n_points %d out of range [1, 32768]", n);
+    GA_REQUIRE(hw->dec_dims[0] == 128 && hw->dec_dims[1] == 256 && hw->dec_dims[2] == 256 && hw->dec_dims[3] == 3 * n,
+               "ae_create: decoder widths must be 128,256,256,3*n_points (src/ae_templates.py:29)");
+    for (int i = 0; i < ENC_L; ++i)
+        GA_REQUIRE(hw->enc_w[i] && hw->enc_b[i] && hw->bn_gamma[i] && hw->bn_beta[i] && hw->bn_mean[i] && hw->bn_var[i],
+                   "ae_create: null encoder weight pointer at layer %d", i);
+    for (int k = 0; k < GEOADV_DEC_LAYERS; ++k)
+        GA_REQUIRE(hw->dec_w[k] && hw->dec_b[k], "ae_create: null decoder weight pointer at layer %d", k);
+
+    const int *C = hw->enc_dims;
+    const int n3 = 3 * n, n3p32 = (int)rup(n3, 32), n3p8 = (int)rup(n3, 8);
+    // arena layout (floats)
+    std::vector<float> host;
+    auto reserve = [&](size_t count) { size_t off = rup(host.size(), 64); host.resize(off + count, 0.f); return off; };
+    size_t o_w0 = reserve(3 * C[1]);
+    size_t o_fwd[ENC_L] = {0}, o_bwd[ENC_L] = {0}, o_scale[ENC_L], o_shift[ENC_L];
+    for (int i = 1; i < ENC_L; ++i) {
+        o_fwd[i] = reserve((size_t)C[i] * C[i + 1]);
+        o_bwd[i] = reserve((size_t)C[i] * C[i + 1]);
+    }
+    for (int i = 0; i < ENC_L; ++i) { o_scale[i] = reserve(C[i + 1]); o_shift[i] = reserve(C[i + 1]); }
+    size_t o_v0 = reserve(128 * 256), o_c0 = reserve(256), o_v1 = reserve(256 * 256), o_c1 = reserve(256);
+    size_t o_v0t = reserve(256 * 128), o_v1t = reserve(256 * 256);
+    size_t o_d2f = reserve((size_t)256 * n3p32), o_d2b = reserve((size_t)n3p8 * 256), o_c2 = reserve(n3);
+
+    memcpy(&host[o_w0], hw->enc_w[0], sizeof(float) * 3 * C[1]);
+    for (int i = 1; i < ENC_L; ++i) {
+        const float *W = hw->enc_w[i];
+        const int K = C[i], N = C[i + 1];
+        pack_fragments(host, o_fwd[i], K, N, K, N, [&](int k, int nn) { return W[(size_t)k * N + nn]; });
+        // transposed product: B[k][nn] = W[nn][k], K' = N, N' = K
+        pack_fragments(host, o_bwd[i], N, K, N, (int)rup(K, 32), [&](int k, int nn) { return W[(size_t)nn * N + k]; });
+    }
+    for (int i = 0; i < ENC_L; ++i)
+        for (int c = 0; c < C[i + 1]; ++c) {
+            // tf.nn.batch_normalization, inference branch: inv = gamma * rsqrt(var + eps);
+            // y = a * inv + (beta - mean * inv) with a = x@W + b  ==>  y = (x@W) * inv + (b*inv + beta - mean*inv)
+            const float inv = hw->bn_gamma[i][c] * (1.0f / sqrtf(hw->bn_var[i][c] + 1e-5f));
+            host[o_scale[i] + c] = inv;
+            host[o_shift[i] + c] = hw->enc_b[i][c] * inv + (hw->bn_beta[i][c] - hw->bn_mean[i][c] * inv);
+        }
+    memcpy(&host[o_v0], hw->dec_w[0], sizeof(float) * 128 * 256);
+    memcpy(&host[o_c0], hw->dec_b[0], sizeof(float) * 256);
+    memcpy(&host[o_v1], hw->dec_w[1], sizeof(float) * 256 * 256);
+    memcpy(&host[o_c1], hw->dec_b[1], sizeof(float) * 256);
+    for (int k = 0; k < 128; ++k)
+        for (int t = 0; t < 256; ++t) host[o_v0t + (size_t)t * 128 + k] = hw->dec_w[0][(size_t)k * 256 + t];
+    for (int k = 0; k < 256; ++k)
+        for (int t = 0; t < 256; ++t) host[o_v1t + (size_t)t * 256 + k] = hw->dec_w[1][(size_t)k * 256 + t];
+    {
+        const float *V2 = hw->dec_w[2];
+        pack_fragments(host, o_d2f, 256, n3, 256, n3p32, [&](int k, int nn) { return V2[(size_t)k * n3 + nn]; });
+        pack_fragments(host, o_d2b, n3, 256, n3p8, 256, [&](int k, int nn) { return V2[(size_t)nn * n3 + k]; });
+    }
+    memcpy(&host[o_c2], hw->dec_b[2], sizeof(float) * n3);
+
+    geoadv_ae *ae = new geoadv_ae();
+    ae->arena_bytes = sizeof(float) * host.size();
+    if (hipMalloc(&ae->arena, ae->arena_bytes) != hipSuccess) {
+        delete ae;
+        set_error("ae_create: hipMalloc of %zu bytes failed", sizeof(float) * host.size());
+        return GEOADV_ENOMEM;
+    }
+    hipError_t e = hipMemcpy(ae->arena, host.data(), ae->arena_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(ae->arena);
+        delete ae;
+        set_error("ae_create: upload failed: %s", hipGetErrorString(e));
+        return GEOADV_EHIP;
+    }
+    const float *base = static_cast<const float *>(ae->arena);
+    DeviceAE &d = ae->d;
+    d.n_points = n;
+    d.bneck = 128;
+    memcpy(d.enc_dims, hw->enc_dims, sizeof(d.enc_dims));
+    memcpy(d.dec_dims, hw->dec_dims, sizeof(d.dec_dims));
+    d.w0 = base + o_w0;
+    for (int i = 0; i < ENC_L; ++i) {
+        d.enc_fwd[i] = PackedLayer{i ? base + o_fwd[i] : nullptr, C[i], C[i + 1]};
+        d.enc_bwd[i] = PackedLayer{i ? base + o_bwd[i] : nullptr, C[i + 1], (int)rup(C[i], 32)};
+        d.scale[i] = base + o_scale[i];
+        d.shift[i] = base + o_shift[i];
+    }
+    d.v0 = base + o_v0; d.c0 = base + o_c0; d.v1 = base + o_v1; d.c1 = base + o_c1;
+    d.v0t = base + o_v0t; d.v1t = base + o_v1t;
+    d.dec2_fwd = PackedLayer{base + o_d2f, 256, n3p32};
+    d.dec2_bwd = PackedLayer{base + o_d2b, n3p8, 256};
+    d.c2 = base + o_c2;
+    *out = ae;
+    return GEOADV_OK;
+}
+
+extern "C" void geoadv_ae_destroy(geoadv_ae *ae) {
+    if (!ae) return;
+    (void)hipFree(ae->arena);
+    delete ae;
+}
+
+extern "C" size_t geoadv_ae_workspace_bytes(const geoadv_ae *ae, int b) {
+    if (!ae || b <= 0) return 256;
+    return carve_forward_scratch(nullptr, b, ae->d.n_points).bytes + 256;
+}
+
+extern "C" int geoadv_ae_forward(const geoadv_ae *ae, int b, const float *pc, float *latent, float *recon,
+                                 void *workspace, void *stream) {
+    GA_REQUIRE(ae && b >= 0, "ae_forward: bad arguments");
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(pc && workspace, "ae_forward: null pointer");
+    GA_REQUIRE(b <= 65535, "ae_forward: batch %d exceeds 65535", b);
+    hipStream_t st = as_stream(stream);
+    void *aligned = reinterpret_cast<void *>(rup(reinterpret_cast<size_t>(workspace), 256));
+    ForwardScratch s = carve_forward_scratch(aligned, b, ae->d.n_points);
+    if (int rc = run_forward(ae->d, b, pc, nullptr, nullptr, s, recon, st)) return rc;
+    if (latent) GA_HIP(hipMemcpyAsync(latent, s.z, sizeof(float) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
+    return GEOADV_OK;
+}

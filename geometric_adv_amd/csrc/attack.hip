@@ -1,0 +1,607 @@
+// The attack loop of AdvAE (src/adv_ae.py:191-251) + Adversary (src/adversary.py) on one GPU:
+// device-resident state, one forward per iteration, no host synchronisation inside the loop.
+//
+// Reference schedule per iteration (adv_ae.py:216-246): sess.run(attack_op) = forward(pert) ->
+// backward -> Adam, then a SECOND full forward to evaluate the metrics of the updated pert (and a
+// third/fourth run for adv / reconstruct once iteration+1 >= thresh).  Here an iteration is
+//   backward (from the cached forward) -> Adam -> forward(pert_new) -> metrics + keep-best,
+// i.e. exactly one forward per iteration (plus one after init_pert); the observable outputs are
+// index-aligned with the reference (metrics of iteration k describe the state after k+1 updates).
+#include "ae.h"
+#include <limits.h>
+#include <math.h>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace geoadv {
+
+// ---- from the other translation units ------------------------------------------------------
+struct ChamferScan { const float *query; const float *target; float *dist; int *idx; int nq, nt; };
+int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t stream);
+struct ForwardScratch {
+    float *pmax; int *parg; int *pcnt; float *z; int *crit; int *zcnt; int *dense; float *d1, *d2; size_t bytes;
+};
+ForwardScratch carve_forward_scratch(void *base, int b, int n_points);
+int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
+                       int *parg, int *pcnt, hipStream_t stream);
+int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
+                         int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
+int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
+int launch_decoder_bwd(const DeviceAE &A, int b, const float *g_recon, const float *d1, const float *d2, float *partial,
+                       float *dz, hipStream_t stream);
+int decoder_bwd_chunks(const DeviceAE &A);
+int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *crit_rows, const float *z,
+                       const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// Per-cloud losses + metrics history + keep-best.  grid = clouds, 256 threads.
+// ------------------------------------------------------------------------------------------
+struct LossArgs {
+    int n;                         // points per cloud (n_input == n_output)
+    int loss_adv_type, loss_dist_type;
+    float mp_pert_w, mp_dist_w;
+    const float *r1, *r2, *a1, *a2;   // [B][n] squared NN distances (recon->gt, gt->recon, adv->x, x->adv)
+    const float *pert;                // [B][n][3]
+    const float *z, *tz;              // [B][128]
+    const float *w;                   // [B] dist_weight
+    float *losses;                    // [8][B]: loss_adv, loss_dist, loss_pert, loss_max|max_dist, input_dist, loss_ae, loss_max(pert), max_dist
+    int *jstar;                       // [B] argmax_j a1 (first), [B] argmax_n |pert_n|^2 (first)
+    float *dz_latent;                 // [B][128] d loss_adv / d z in latent mode (else untouched)
+    float *hist;                      // [6][B] slot of this iteration or null
+    int keep;                         // 1: take part in the keep-best update
+    float *best_err;                  // [B]
+    float *best_metrics;              // [B][4]
+    const float *adv, *recon;         // [B][n][3]
+    float *best_adv, *best_recon;     // [B][n][3]
+};
+
+__device__ __forceinline__ float block_sum(float v, float *sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    const float r = sh[0];
+    __syncthreads();
+    return r;
+}
+// max with the lowest index on ties
+__device__ __forceinline__ void block_argmax(float &v, int &i, float *sh, int *shi) {
+    const int t = threadIdx.x;
+    sh[t] = v; shi[t] = i;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            const float o = sh[t + s]; const int oi = shi[t + s];
+            if (o > sh[t] || (o == sh[t] && oi < shi[t])) { sh[t] = o; shi[t] = oi; }
+        }
+        __syncthreads();
+    }
+    v = sh[0]; i = shi[0];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void loss_metrics_kernel(LossArgs a) {
+    __shared__ float sh[256];
+    __shared__ int shi[256];
+    __shared__ int take;
+    const int b = blockIdx.x, t = threadIdx.x, n = a.n, B = gridDim.x;
+    const size_t o = (size_t)b * n;
+    float s1 = 0, s2 = 0, s3 = 0, s4 = 0, sp = 0;
+    float ma = -1.f, mp = -1.f;
+    int ja = INT_MAX, jp = INT_MAX;
+    for (int j = t; j < n; j += 256) {
+        s1 += a.r1[o + j]; s2 += a.r2[o + j];
+        const float d = a.a1[o + j];
+        s3 += d; s4 += a.a2[o + j];
+        if (d > ma) { ma = d; ja = j; }
+        const float px = a.pert[(o + j) * 3], py = a.pert[(o + j) * 3 + 1], pz = a.pert[(o + j) * 3 + 2];
+        const float p2 = (px * px + py * py) + pz * pz;
+        sp += p2;
+        if (p2 > mp) { mp = p2; jp = j; }
+    }
+    const float inv_n = 1.0f / (float)n;
+    const float loss_ae = block_sum(s1, sh) * inv_n + block_sum(s2, sh) * inv_n;      // adv_ae.py:121
+    const float input_dist = block_sum(s3, sh) * inv_n + block_sum(s4, sh) * inv_n;   // adv_ae.py:132
+    const float pert_sq = block_sum(sp, sh);
+    block_argmax(ma, ja, sh, shi);                                                     // adv_ae.py:133
+    block_argmax(mp, jp, sh, shi);                                                     // adversary.py:44
+    const float loss_pert = sqrtf(pert_sq), loss_max = sqrtf(mp);                      // adversary.py:47,50
+    float loss_adv = loss_ae;
+    if (a.loss_adv_type == GEOADV_LOSS_ADV_LATENT) {                                   // adv_ae.py:107-116
+        float d = 0.f;
+        if (t < 128) { d = a.z[(size_t)b * 128 + t] - a.tz[(size_t)b * 128 + t]; }
+        const float nsq = block_sum(d * d, sh);
+        loss_adv = sqrtf(nsq);
+        if (t < 128) a.dz_latent[(size_t)b * 128 + t] = d / loss_adv;
+    }
+    float loss_dist;
+    if (a.loss_dist_type == GEOADV_LOSS_DIST_PERT)
+        loss_dist = a.mp_pert_w > 0.f ? loss_pert + a.mp_pert_w * loss_max : loss_pert;   // adv_ae.py:93-97
+    else
+        loss_dist = a.mp_dist_w > 0.f ? input_dist + a.mp_dist_w * ma : input_dist;       // adv_ae.py:98-102
+    const float fourth = a.loss_dist_type == GEOADV_LOSS_DIST_PERT ? loss_max : ma;       // adv_ae.py:204-207
+    if (t == 0) {
+        a.losses[0 * B + b] = loss_adv; a.losses[1 * B + b] = loss_dist; a.losses[2 * B + b] = loss_pert;
+        a.losses[3 * B + b] = fourth;   a.losses[4 * B + b] = input_dist; a.losses[5 * B + b] = loss_ae;
+        a.losses[6 * B + b] = loss_max; a.losses[7 * B + b] = ma;
+        a.jstar[b] = ja; a.jstar[B + b] = jp;
+        if (a.hist) {
+            a.hist[0 * B + b] = loss_adv; a.hist[1 * B + b] = loss_dist; a.hist[2 * B + b] = loss_pert;
+            a.hist[3 * B + b] = fourth;   a.hist[4 * B + b] = input_dist; a.hist[5 * B + b] = loss_ae;
+        }
+        int tk = 0;
+        if (a.keep && loss_ae < a.best_err[b]) {                                          // adv_ae.py:239 (strict)
+            tk = 1;
+            a.best_err[b] = loss_ae;
+            a.best_metrics[b * 4 + 0] = loss_adv; a.best_metrics[b * 4 + 1] = loss_dist;
+            a.best_metrics[b * 4 + 2] = input_dist; a.best_metrics[b * 4 + 3] = loss_ae;   // nre = this / ref, at read-out
+        }
+        take = tk;
+    }
+    __syncthreads();
+    if (take) {
+        const size_t base = o * 3;
+        for (int e = t; e < 3 * n; e += 256) {
+            a.best_adv[base + e] = a.adv[base + e];
+            a.best_recon[base + e] = a.recon[base + e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Chamfer gradient w.r.t. the FIRST cloud only, with per-cloud constant upstream gradients
+// (mean over points => 1/n, times dist_weight for the source-distance term) -- the two uses the
+// attack has (adv_ae.py:120-121,131-133 differentiated by adv_ae.py:153).  Same CPU-ordered
+// accumulation as chamfer.hip (tf_nndistance.cpp:130-163): own term, then scatter terms in
+// ascending index.  grid = (clouds, problems).
+// ------------------------------------------------------------------------------------------
+struct CGradProblem {
+    const float *p, *q;          // [B][n][3] own / other cloud
+    const int *idx1, *idx2;      // [B][n] own->other matches, other->own matches
+    float *g;                    // [B][n][3]
+    const float *w;              // [B] or null: upstream factor (dist_weight)
+    const int *jstar;            // [B] or null: point receiving the extra max-term
+    float extra_w;               // max_point_dist_weight (0 = none)
+};
+struct CGradArgs { CGradProblem pr[2]; int n, P; };
+constexpr int CGA_THREADS = 512;
+
+__global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned keys[];
+    const CGradProblem pr = a.pr[blockIdx.y];
+    const int b = blockIdx.x, n = a.n, P = a.P;
+    const float *p = pr.p + (size_t)b * n * 3, *q = pr.q + (size_t)b * n * 3;
+    const int *i1 = pr.idx1 + (size_t)b * n, *i2 = pr.idx2 + (size_t)b * n;
+    float *g = pr.g + (size_t)b * n * 3;
+    const float wb = pr.w ? pr.w[b] : 1.0f;
+    const float gd = wb * (1.0f / (float)n);
+    const int js = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
+    for (int i = threadIdx.x; i < P; i += CGA_THREADS)
+        keys[i] = i < n ? (((unsigned)i2[i] << 16) | (unsigned)i) : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += CGA_THREADS) {
+                const int pp = i ^ j;
+                if (pp > i) {
+                    const unsigned x = keys[i], y = keys[pp];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[pp] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    const float g2 = gd * 2;
+    for (int j = threadIdx.x; j < n; j += CGA_THREADS) {
+        const float px = p[3 * j], py = p[3 * j + 1], pz = p[3 * j + 2];
+        const int mj = i1[j];
+        const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        ax += gown * (px - q[3 * mj]); ay += gown * (py - q[3 * mj + 1]); az += gown * (pz - q[3 * mj + 2]);
+        const unsigned want = (unsigned)j << 16;
+        int lo = 0, hi = P;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        for (; lo < P && (keys[lo] >> 16) == (unsigned)j; ++lo) {
+            const int k = keys[lo] & 0xFFFF;
+            ax -= g2 * (q[3 * k] - px); ay -= g2 * (q[3 * k + 1] - py); az -= g2 * (q[3 * k + 2] - pz);
+        }
+        g[3 * j] = ax; g[3 * j + 1] = ay; g[3 * j + 2] = az;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam on pert (tf.train.AdamOptimizer defaults, TF 1.13 ApplyAdam form; adv_ae.py:152-153).
+// g = g_enc + g_dist, g_dist either the Chamfer source-distance gradient (buffer) or the
+// perturbation-norm gradient computed here.
+// ------------------------------------------------------------------------------------------
+struct AdamArgs {
+    int n, B;
+    float *pert, *m, *v;
+    const float *g_enc, *g_dist;     // g_dist null in 'pert' mode
+    const float *w, *losses;         // [B], [8][B]
+    const int *jstar;                // [2][B]
+    int loss_dist_type;
+    float mp_pert_w;
+    float alpha, one_minus_b1, one_minus_b2, eps;
+    float *grad_out;                 // optional copy of g (tests)
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    const size_t per = (size_t)a.n * 3;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= per * a.B) return;
+    const int b = (int)(e / per);
+    float g = a.g_enc[e];
+    if (a.loss_dist_type == GEOADV_LOSS_DIST_PERT) {
+        const float p = a.pert[e];
+        const float wb = a.w[b];
+        float gp = wb * (p / a.losses[2 * a.B + b]);                   // d sqrt(sum pert^2) = pert / norm
+        if (a.mp_pert_w > 0.f) {
+            const int pt = (int)((e % per) / 3);
+            if (pt == a.jstar[a.B + b]) gp += wb * a.mp_pert_w * (p / a.losses[6 * a.B + b]);
+        }
+        g += gp;
+    } else {
+        g += a.g_dist[e];
+    }
+    if (a.grad_out) a.grad_out[e] = g;
+    float m = a.m[e], v = a.v[e];
+    m += (g - m) * a.one_minus_b1;
+    v += (g * g - v) * a.one_minus_b2;
+    a.m[e] = m; a.v[e] = v;
+    a.pert[e] -= (m * a.alpha) / (sqrtf(v) + a.eps);
+}
+
+__global__ void fill_kernel(float *p, float v, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+// metrics[B][5] = loss_adv, loss_dist, source_chamfer_dist, target_nre, target_recon_error
+__global__ void best_metrics_kernel(int B, const float *best_metrics, const float *best_err, const float *ref, float *out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    out[b * 5 + 0] = best_metrics[b * 4 + 0];
+    out[b * 5 + 1] = best_metrics[b * 4 + 1];
+    out[b * 5 + 2] = best_metrics[b * 4 + 2];
+    out[b * 5 + 3] = best_metrics[b * 4 + 3] / ref[b];          // adv_ae.py:241
+    out[b * 5 + 4] = best_err[b];                                // adv_ae.py:249
+}
+
+}  // namespace geoadv
+
+using namespace geoadv;
+
+struct geoadv_attack {
+    const geoadv_ae *ae;
+    geoadv_attack_config cfg;
+    int B, n;
+    void *arena; size_t arena_bytes;
+    // device state
+    float *x, *gt, *tz, *w;
+    float *pert, *m, *v;
+    float *adv, *recon, *g_recon, *g_dist, *g_enc, *grad_last;
+    float *r1, *r2, *a1, *a2; int *ir1, *ir2, *ia1, *ia2;
+    ForwardScratch fs;
+    float *dz, *dec_partial;
+    float *losses; int *jstar;
+    float *best_err, *best_metrics, *best_adv, *best_recon;
+    // host state
+    float beta1_pow, beta2_pow;
+    bool fwd_valid;
+    // profiling
+    bool prof;
+    std::vector<hipEvent_t> ev;      // pool
+    int ev_used;
+    struct Mark { int which, e0, e1; };
+    std::vector<Mark> marks;
+    double prof_ms[GEOADV_PROF_COUNT];
+    int prof_n[GEOADV_PROF_COUNT];
+    hipStream_t prof_stream;
+};
+
+namespace {
+
+inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int prof_flush(geoadv_attack *at) {
+    if (at->marks.empty()) return GEOADV_OK;
+    GA_HIP(hipStreamSynchronize(at->prof_stream));
+    for (const auto &mk : at->marks) {
+        float ms = 0;
+        GA_HIP(hipEventElapsedTime(&ms, at->ev[mk.e0], at->ev[mk.e1]));
+        at->prof_ms[mk.which] += ms;
+        at->prof_n[mk.which] += 1;
+    }
+    at->marks.clear();
+    at->ev_used = 0;
+    return GEOADV_OK;
+}
+
+struct ProfScope {
+    geoadv_attack *at; int which; int e0; hipStream_t st; bool on;
+    ProfScope(geoadv_attack *a, int w, hipStream_t s) : at(a), which(w), e0(-1), st(s), on(a->prof) {
+        if (!on) return;
+        if (at->ev_used + 2 > (int)at->ev.size()) prof_flush(at);
+        e0 = at->ev_used++;
+        (void)hipEventRecord(at->ev[e0], st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        const int e1 = at->ev_used++;
+        (void)hipEventRecord(at->ev[e1], st);
+        at->marks.push_back({which, e0, e1});
+    }
+};
+
+
+// forward(pert): encoder -> latent/decoder -> both Chamfer problems -> per-cloud losses (+ metrics / keep-best)
+int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
+    const DeviceAE &A = at->ae->d;
+    const int B = at->B, n = at->n;
+    {
+        ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st);
+        if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, at->adv, at->fs.pmax, at->fs.parg, at->fs.pcnt, st)) return rc;
+    }
+    {
+        ProfScope ps(at, GEOADV_PROF_DECODER_FWD, st);
+        if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
+                                          at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
+        if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
+    }
+    {
+        ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
+        ChamferScan sc[4] = {{at->recon, at->gt, at->r1, at->ir1, n, n}, {at->gt, at->recon, at->r2, at->ir2, n, n},
+                             {at->adv, at->x, at->a1, at->ia1, n, n},   {at->x, at->adv, at->a2, at->ia2, n, n}};
+        if (int rc = launch_chamfer_scans(sc, 4, B, st)) return rc;
+    }
+    {
+        ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
+        LossArgs la;
+        la.n = n; la.loss_adv_type = at->cfg.loss_adv_type; la.loss_dist_type = at->cfg.loss_dist_type;
+        la.mp_pert_w = at->cfg.max_point_pert_weight; la.mp_dist_w = at->cfg.max_point_dist_weight;
+        la.r1 = at->r1; la.r2 = at->r2; la.a1 = at->a1; la.a2 = at->a2; la.pert = at->pert;
+        la.z = at->fs.z; la.tz = at->tz; la.w = at->w; la.losses = at->losses; la.jstar = at->jstar;
+        la.dz_latent = at->dz; la.hist = hist_slot; la.keep = keep; la.best_err = at->best_err;
+        la.best_metrics = at->best_metrics; la.adv = at->adv; la.recon = at->recon;
+        la.best_adv = at->best_adv; la.best_recon = at->best_recon;
+        loss_metrics_kernel<<<B, 256, 0, st>>>(la);
+        GA_LAUNCH_CHECK();
+    }
+    at->fwd_valid = true;
+    return GEOADV_OK;
+}
+
+int pow2_ge(int v) { int p = 2; while (p < v) p <<= 1; return p; }
+
+// backward from the cached forward + Adam
+int do_step(geoadv_attack *at, hipStream_t st) {
+    const DeviceAE &A = at->ae->d;
+    const int B = at->B, n = at->n;
+    const bool adv_chamfer = at->cfg.loss_adv_type == GEOADV_LOSS_ADV_CHAMFER;
+    const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
+    {
+        ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
+        CGradArgs ca;
+        int np = 0;
+        if (adv_chamfer) ca.pr[np++] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
+        if (dist_chamfer)
+            ca.pr[np++] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar,
+                                       at->cfg.max_point_dist_weight};
+        if (np) {
+            ca.n = n; ca.P = pow2_ge(n);
+            chamfer_grad_attack_kernel<<<dim3(B, np), CGA_THREADS, sizeof(unsigned) * ca.P, st>>>(ca);
+            GA_LAUNCH_CHECK();
+        }
+    }
+    if (adv_chamfer) {
+        ProfScope ps(at, GEOADV_PROF_DECODER_BWD, st);
+        if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st)) return rc;
+    }
+    {
+        ProfScope ps(at, GEOADV_PROF_ENCODER_BWD, st);
+        GA_HIP(hipMemsetAsync(at->g_enc, 0, sizeof(float) * (size_t)B * n * 3, st));
+        if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, st))
+            return rc;
+    }
+    {
+        ProfScope ps(at, GEOADV_PROF_ADAM, st);
+        AdamArgs aa;
+        aa.n = n; aa.B = B; aa.pert = at->pert; aa.m = at->m; aa.v = at->v; aa.g_enc = at->g_enc;
+        aa.g_dist = dist_chamfer ? at->g_dist : nullptr; aa.w = at->w; aa.losses = at->losses; aa.jstar = at->jstar;
+        aa.loss_dist_type = at->cfg.loss_dist_type; aa.mp_pert_w = at->cfg.max_point_pert_weight;
+        const float beta1 = 0.9f, beta2 = 0.999f;
+        aa.alpha = at->cfg.learning_rate * sqrtf(1.0f - at->beta2_pow) / (1.0f - at->beta1_pow);
+        aa.one_minus_b1 = 1.0f - beta1; aa.one_minus_b2 = 1.0f - beta2; aa.eps = 1e-8f;
+        aa.grad_out = at->grad_last;
+        const size_t total = (size_t)B * n * 3;
+        adam_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(aa);
+        GA_LAUNCH_CHECK();
+        at->beta1_pow *= beta1;
+        at->beta2_pow *= beta2;
+    }
+    at->fwd_valid = false;
+    return GEOADV_OK;
+}
+
+}  // namespace
+
+extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, const geoadv_attack_config *cfg) {
+    GA_REQUIRE(out && ae && cfg, "attack_create: null argument");
+    GA_REQUIRE(cfg->batch >= 1 && cfg->batch <= 65535, "attack_create: batch %d out of range", cfg->batch);
+    GA_REQUIRE(cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER || cfg->loss_adv_type == GEOADV_LOSS_ADV_LATENT,
+               "attack_create: unknown loss_adv_type %d", cfg->loss_adv_type);
+    GA_REQUIRE(cfg->loss_dist_type == GEOADV_LOSS_DIST_CHAMFER || cfg->loss_dist_type == GEOADV_LOSS_DIST_PERT,
+               "attack_create: unknown loss_dist_type %d", cfg->loss_dist_type);
+    GA_REQUIRE(cfg->emd_weight == 0.f, "attack_create: emd_weight is not supported by this build yet");
+    geoadv_attack *at = new geoadv_attack();
+    at->ae = ae; at->cfg = *cfg; at->B = cfg->batch; at->n = ae->d.n_points;
+    const size_t B = at->B, n = at->n, bn3 = B * n * 3, bn = B * n;
+    const int chunks = decoder_bwd_chunks(ae->d);
+    const size_t fs_bytes = carve_forward_scratch(nullptr, at->B, at->n).bytes;
+    size_t total = 0;
+    auto need = [&](size_t bytes) { total += rup(bytes, 256); };
+    for (int i = 0; i < 2; ++i) need(4 * bn3);            // x, gt
+    need(4 * B * 128); need(4 * B);                       // tz, w
+    for (int i = 0; i < 3; ++i) need(4 * bn3);            // pert, m, v
+    for (int i = 0; i < 6; ++i) need(4 * bn3);            // adv, recon, g_recon, g_dist, g_enc, grad_last
+    for (int i = 0; i < 8; ++i) need(4 * bn);             // r1 r2 a1 a2 + 4 idx
+    need(fs_bytes);
+    need(4 * B * 128); need(4 * (size_t)chunks * B * 256);
+    need(4 * 8 * B); need(4 * 2 * B);
+    need(4 * B); need(4 * B * 4); need(4 * bn3); need(4 * bn3);
+    at->arena_bytes = total;
+    if (hipMalloc(&at->arena, total) != hipSuccess) {
+        delete at;
+        set_error("attack_create: hipMalloc of %zu bytes failed", total);
+        return GEOADV_ENOMEM;
+    }
+    (void)hipMemset(at->arena, 0, total);
+    char *p = static_cast<char *>(at->arena);
+    auto take = [&](size_t bytes) { char *q = p; p += rup(bytes, 256); return q; };
+    auto F = [&](size_t bytes) { return reinterpret_cast<float *>(take(bytes)); };
+    auto I = [&](size_t bytes) { return reinterpret_cast<int *>(take(bytes)); };
+    at->x = F(4 * bn3); at->gt = F(4 * bn3); at->tz = F(4 * B * 128); at->w = F(4 * B);
+    at->pert = F(4 * bn3); at->m = F(4 * bn3); at->v = F(4 * bn3);
+    at->adv = F(4 * bn3); at->recon = F(4 * bn3); at->g_recon = F(4 * bn3); at->g_dist = F(4 * bn3);
+    at->g_enc = F(4 * bn3); at->grad_last = F(4 * bn3);
+    at->r1 = F(4 * bn); at->r2 = F(4 * bn); at->a1 = F(4 * bn); at->a2 = F(4 * bn);
+    at->ir1 = I(4 * bn); at->ir2 = I(4 * bn); at->ia1 = I(4 * bn); at->ia2 = I(4 * bn);
+    at->fs = carve_forward_scratch(take(fs_bytes), at->B, at->n);
+    at->dz = F(4 * B * 128); at->dec_partial = F(4 * (size_t)chunks * B * 256);
+    at->losses = F(4 * 8 * B); at->jstar = I(4 * 2 * B);
+    at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
+    at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
+    at->fwd_valid = false;
+    at->prof = false; at->ev_used = 0; at->prof_stream = nullptr;
+    for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        attr = true;
+    }
+    *out = at;
+    return GEOADV_OK;
+}
+
+extern "C" void geoadv_attack_destroy(geoadv_attack *at) {
+    if (!at) return;
+    for (auto e : at->ev) (void)hipEventDestroy(e);
+    (void)hipFree(at->arena);
+    delete at;
+}
+
+extern "C" int geoadv_attack_set_inputs(geoadv_attack *at, const float *source_pc, const float *target_pc,
+                                        const float *target_latent, const float *dist_weight, void *stream) {
+    GA_REQUIRE(at && source_pc && target_pc && dist_weight, "attack_set_inputs: null argument");
+    GA_REQUIRE(target_latent || at->cfg.loss_adv_type != GEOADV_LOSS_ADV_LATENT,
+               "attack_set_inputs: target_latent is required for loss_adv_type 'latent'");
+    hipStream_t st = as_stream(stream);
+    const size_t bn3 = (size_t)at->B * at->n * 3;
+    GA_HIP(hipMemcpyAsync(at->x, source_pc, 4 * bn3, hipMemcpyDeviceToDevice, st));
+    GA_HIP(hipMemcpyAsync(at->gt, target_pc, 4 * bn3, hipMemcpyDeviceToDevice, st));
+    if (target_latent) GA_HIP(hipMemcpyAsync(at->tz, target_latent, 4 * (size_t)at->B * 128, hipMemcpyDeviceToDevice, st));
+    GA_HIP(hipMemcpyAsync(at->w, dist_weight, 4 * (size_t)at->B, hipMemcpyDeviceToDevice, st));
+    at->fwd_valid = false;
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_init_pert(geoadv_attack *at, const float *init_pert, int reset_optimizer, void *stream) {
+    GA_REQUIRE(at && init_pert, "attack_init_pert: null argument");
+    hipStream_t st = as_stream(stream);
+    const size_t bn3 = (size_t)at->B * at->n * 3;
+    GA_HIP(hipMemcpyAsync(at->pert, init_pert, 4 * bn3, hipMemcpyDeviceToDevice, st));
+    if (reset_optimizer) {
+        GA_HIP(hipMemsetAsync(at->m, 0, 4 * bn3, st));
+        GA_HIP(hipMemsetAsync(at->v, 0, 4 * bn3, st));
+        at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;
+    }
+    // adv_ae.py:197-200: best error 1e10, metrics / clouds zero
+    fill_kernel<<<(at->B + 255) / 256, 256, 0, st>>>(at->best_err, 1e10f, (size_t)at->B);
+    GA_LAUNCH_CHECK();
+    GA_HIP(hipMemsetAsync(at->best_metrics, 0, 4 * (size_t)at->B * 4, st));
+    GA_HIP(hipMemsetAsync(at->best_adv, 0, 4 * bn3, st));
+    GA_HIP(hipMemsetAsync(at->best_recon, 0, 4 * bn3, st));
+    at->fwd_valid = false;
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_run(geoadv_attack *at, int first_iteration, int iterations, int thresh,
+                                 float *metrics_hist, void *stream) {
+    GA_REQUIRE(at && first_iteration >= 0 && iterations >= 0, "attack_run: bad arguments");
+    hipStream_t st = as_stream(stream);
+    at->prof_stream = st;
+    if (iterations == 0) return GEOADV_OK;
+    if (!at->fwd_valid)
+        if (int rc = do_forward(at, nullptr, 0, st)) return rc;
+    for (int i = 0; i < iterations; ++i) {
+        if (int rc = do_step(at, st)) return rc;
+        const int it = first_iteration + i;                       // 0-based index within the dist-weight run
+        const int keep = (it + 1) >= thresh ? 1 : 0;              // adv_ae.py:234
+        float *slot = metrics_hist ? metrics_hist + (size_t)i * 6 * at->B : nullptr;
+        if (int rc = do_forward(at, slot, keep, st)) return rc;
+    }
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_loss_ref, float *metrics, float *adv,
+                                      float *recon, void *stream) {
+    GA_REQUIRE(at, "attack_get_best: null handle");
+    hipStream_t st = as_stream(stream);
+    const size_t bn3 = (size_t)at->B * at->n * 3;
+    if (metrics) {
+        GA_REQUIRE(target_ae_loss_ref, "attack_get_best: target_ae_loss_ref is required for the metrics");
+        best_metrics_kernel<<<(at->B + 63) / 64, 64, 0, st>>>(at->B, at->best_metrics, at->best_err, target_ae_loss_ref, metrics);
+        GA_LAUNCH_CHECK();
+    }
+    if (adv) GA_HIP(hipMemcpyAsync(adv, at->best_adv, 4 * bn3, hipMemcpyDeviceToDevice, st));
+    if (recon) GA_HIP(hipMemcpyAsync(recon, at->best_recon, 4 * bn3, hipMemcpyDeviceToDevice, st));
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, float *recon, float *latent, float *grad,
+                                  int *idx_r1, int *idx_r2, int *idx_a1, int *idx_a2, void *stream) {
+    GA_REQUIRE(at, "attack_peek: null handle");
+    hipStream_t st = as_stream(stream);
+    const size_t bn3 = 4 * (size_t)at->B * at->n * 3, bn = 4 * (size_t)at->B * at->n;
+    if (!at->fwd_valid && (adv || recon || latent || idx_r1 || idx_r2 || idx_a1 || idx_a2))
+        if (int rc = do_forward(at, nullptr, 0, st)) return rc;
+    if (pert) GA_HIP(hipMemcpyAsync(pert, at->pert, bn3, hipMemcpyDeviceToDevice, st));
+    if (adv) GA_HIP(hipMemcpyAsync(adv, at->adv, bn3, hipMemcpyDeviceToDevice, st));
+    if (recon) GA_HIP(hipMemcpyAsync(recon, at->recon, bn3, hipMemcpyDeviceToDevice, st));
+    if (latent) GA_HIP(hipMemcpyAsync(latent, at->fs.z, 4 * (size_t)at->B * 128, hipMemcpyDeviceToDevice, st));
+    if (grad) GA_HIP(hipMemcpyAsync(grad, at->grad_last, bn3, hipMemcpyDeviceToDevice, st));
+    if (idx_r1) GA_HIP(hipMemcpyAsync(idx_r1, at->ir1, bn, hipMemcpyDeviceToDevice, st));
+    if (idx_r2) GA_HIP(hipMemcpyAsync(idx_r2, at->ir2, bn, hipMemcpyDeviceToDevice, st));
+    if (idx_a1) GA_HIP(hipMemcpyAsync(idx_a1, at->ia1, bn, hipMemcpyDeviceToDevice, st));
+    if (idx_a2) GA_HIP(hipMemcpyAsync(idx_a2, at->ia2, bn, hipMemcpyDeviceToDevice, st));
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_profile(geoadv_attack *at, int enable) {
+    GA_REQUIRE(at, "attack_profile: null handle");
+    if (enable && at->ev.empty()) {
+        at->ev.resize(4096);
+        for (auto &e : at->ev) GA_HIP(hipEventCreate(&e));
+    }
+    if (!enable && at->prof) { if (int rc = prof_flush(at)) return rc; }
+    at->prof = enable != 0;
+    if (enable) for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_profile_read(geoadv_attack *at, int which, int *launches, float *total_ms) {
+    GA_REQUIRE(at && which >= 0 && which < GEOADV_PROF_COUNT && launches && total_ms, "attack_profile_read: bad arguments");
+    if (int rc = prof_flush(at)) return rc;
+    *launches = at->prof_n[which];
+    *total_ms = (float)at->prof_ms[which];
+    return GEOADV_OK;
+}
