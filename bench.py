@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- attack-iterations/sec of the geometric adversarial attack loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): B = 32 clouds of N = 2048 points per batch, output-space
+attack (loss_adv_type = chamfer, loss_dist_type = chamfer, dist_weight 1.0, lr 0.01), synthetic
+uniform clouds and seeded random-init weights of the reference architecture.  A "step" is one attack
+iteration on one batch: Adam step on pert + the metrics of the updated pert (+ keep-best for the last
+20 % of the run, like thresh 400 of 500).  Multi-GPU: every rank attacks its OWN batch of 32 (the
+reference walks examples in independent batches, adv_ae.py:166-177) -- weak scaling, no data-path
+collective; the final per-cloud loss scalars are all-gathered once (RCCL).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, N = 32, 2048
+ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
+PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def clouds(seed, b, n):
+    rng = np.random.default_rng(seed)
+    return (rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
+
+
+def cpu_baseline(weights, x, gt, iters=5):
+    """The oracle's attack iteration (numpy fp32 GEMMs on all cores + the single-threaded C Chamfer
+    restatement, i.e. the reference's threading: NnDistanceOp::Compute is single-threaded,
+    tf_nndistance.cpp:79-80) in the REFERENCE schedule: step (fwd+bwd+Adam) + a second metrics
+    forward (adv_ae.py:217-221).  Bounded sample: `iters` iterations after one warm-up."""
+    from geometric_adv_amd import weights as W
+    from oracle.attack_model import AEModel, AttackModel
+    from geometric_adv_amd.adversary import init_pert_value
+    model = AEModel(W.canonical(weights, N), N, np.float32)
+    am = AttackModel(model, x, gt, None, np.ones(B, np.float32))
+    am.init_pert(init_pert_value(B, N))
+    am.step(); am.forward()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        am.step()
+        am.forward()
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d iterations of config 2 (B=32, N=2048) after 1 warm-up, reference schedule (2 forwards/iter); "
+                      "numpy fp32 GEMMs on all cores, Chamfer single-threaded C (gcc -O2 -ffp-contract=off)" % iters,
+            "sec_per_iteration": dt / iters}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    from geometric_adv_amd import dist as gdist
+    rank, world, local = gdist.env_rank()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    gdist.init("nccl")
+
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+
+    K, Wm = args.steps, args.warmup
+    weights = W.synthetic_weights(N, seed=7)
+    x = clouds(1000 + 2 + 17 * rank, B, N)            # source batch of this rank
+    gt = clouds(2000 + 2 + 17 * rank, B, N)           # target batch of this rank
+    total = Wm + K
+    thresh = Wm + int(0.8 * K) + 1
+    conf = Configuration(batch_size=B, n_points=N, weights=weights, loss_adv_type="chamfer", loss_dist_type="chamfer",
+                         dist_weight_list=[1.0], num_iterations=total, num_iterations_thresh=thresh, learning_rate=0.01)
+    ae = PointNetAE(weights, N, device=dev)
+    ref = torch.as_tensor(ae.get_loss_per_pc(gt)).to(dev)      # target_ae_loss_ref
+    tz = ae.transform(gt)
+    at = AdvAE("adversary", conf, device=dev, ae=ae)
+    at.set_inputs(x, gt, tz, 1.0)
+    at.init_pert(None, reset_optimizer=True)
+
+    at.run(0, Wm, thresh)                                      # W untimed warm-up steps
+    at.profile(["encoder_fwd", "chamfer_fwd"])                 # HIP events on the launch stream, timed region
+    torch.cuda.synchronize()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    at.run(Wm, K, thresh)                                      # exactly K timed steps, no host sync inside
+    metrics, _, _ = at.get_best(ref)
+    gathered = gdist.all_gather_examples(metrics[None], axis=1)   # final loss scalars only (RCCL for N > 1)
+    torch.cuda.synchronize()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = gdist.max_over_ranks(dt, device=dev)
+    prof = at.profile_read()
+    at.profile(False)
+
+    if rank != 0:
+        return
+    # per-kernel breakdown in a separate, untimed pass
+    at.profile(True)
+    at.run(total, 50, total + 1000)
+    torch.cuda.synchronize()
+    breakdown = {k: (ms / max(n_, 1)) for k, (n_, ms) in at.profile_read().items()}
+    at.profile(False)
+
+    enc_n, enc_ms = prof["encoder_fwd"]
+    enc_avg_ms = enc_ms / max(enc_n, 1)
+    enc_flop = ENC_FLOP_PER_POINT * B * N                       # algorithmic flop per launch
+    enc_tflops = enc_flop / (enc_avg_ms * 1e-3) / 1e12
+    ch_n, ch_ms = prof["chamfer_fwd"]
+    ch_avg_ms = ch_ms / max(ch_n, 1)
+    ch_pairs = 4.0 * B * N * N                                  # 2 problems x 2 directions per launch
+    ch_bytes = 2 * 20.0 * B * (N + N)                           # 20*B*(N+M) per nn_distance call
+    out = {
+        "metric": "attack-iterations/sec (B=32, N=2048) at 1/2/4/8 GPUs; Chamfer rel-err vs ref",
+        "value": world * K / dt, "unit": "attack-iterations/sec", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: B=32 random clouds x N=2048, output-space attack (chamfer/chamfer, "
+                               "dist_weight 1.0, lr 0.01), one batch per GPU", "batch_per_gpu": B, "n_points": N,
+                   "global_batch": B * world, "parallelism": "batches sharded, dp%d, no data-path collective" % world,
+                   "thresh_fraction": 0.8},
+        "roofline": {"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_tflops, "peak": PEAK_MFMA_F32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": enc_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                     "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop},
+        "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_scan_kernel", "avg_launch_ms": ch_avg_ms,
+                             "launches_timed": ch_n, "achieved_Tpair_per_s": ch_pairs / (ch_avg_ms * 1e-3) / 1e12,
+                             "algorithmic_bytes_per_launch": ch_bytes,
+                             "achieved_hbm_GBps": ch_bytes / (ch_avg_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS},
+        "kernel_ms_per_iteration": breakdown,
+        "final_mean_target_recon_error": float(gathered[0, :, 4].mean().item()),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(weights, x, gt, args.cpu_iters)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

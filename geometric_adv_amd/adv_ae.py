@@ -141,8 +141,15 @@ class AdvAE:
                        _lib.stream_handle()), "attack_peek")
         return out
 
-    def profile(self, enable):
-        _lib.check(_lib.lib().geoadv_attack_profile(self._h, int(bool(enable))), "attack_profile")
+    def profile(self, classes):
+        """classes: True/False for all/none, or an iterable of PROF_NAMES to time."""
+        if classes is True:
+            mask = -1
+        elif not classes:
+            mask = 0
+        else:
+            mask = sum(1 << PROF_NAMES.index(c) for c in classes)
+        _lib.check(_lib.lib().geoadv_attack_profile(self._h, int(mask)), "attack_profile")
 
     def profile_read(self):
         """{kernel class: (launches, total_ms)} measured with HIP events on the launch stream."""

@@ -8,6 +8,7 @@
 // i.e. exactly one forward per iteration (plus one after init_pert); the observable outputs are
 // index-aligned with the reference (metrics of iteration k describe the state after k+1 updates).
 #include "ae.h"
+#include "chamfer_grad.h"
 #include <limits.h>
 #include <math.h>
 #include <vector>
@@ -171,49 +172,20 @@ struct CGradArgs { CGradProblem pr[2]; int n, P; };
 constexpr int CGA_THREADS = 512;
 
 __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned keys[];
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     const CGradProblem pr = a.pr[blockIdx.y];
-    const int b = blockIdx.x, n = a.n, P = a.P;
-    const float *p = pr.p + (size_t)b * n * 3, *q = pr.q + (size_t)b * n * 3;
-    const int *i1 = pr.idx1 + (size_t)b * n, *i2 = pr.idx2 + (size_t)b * n;
-    float *g = pr.g + (size_t)b * n * 3;
+    const int b = blockIdx.x, n = a.n;
     const float wb = pr.w ? pr.w[b] : 1.0f;
-    const float gd = wb * (1.0f / (float)n);
-    const int js = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
-    for (int i = threadIdx.x; i < P; i += CGA_THREADS)
-        keys[i] = i < n ? (((unsigned)i2[i] << 16) | (unsigned)i) : 0xFFFFFFFFu;
-    __syncthreads();
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += CGA_THREADS) {
-                const int pp = i ^ j;
-                if (pp > i) {
-                    const unsigned x = keys[i], y = keys[pp];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { keys[i] = y; keys[pp] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    const float g2 = gd * 2;
-    for (int j = threadIdx.x; j < n; j += CGA_THREADS) {
-        const float px = p[3 * j], py = p[3 * j + 1], pz = p[3 * j + 2];
-        const int mj = i1[j];
-        const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
-        float ax = 0.f, ay = 0.f, az = 0.f;
-        ax += gown * (px - q[3 * mj]); ay += gown * (py - q[3 * mj + 1]); az += gown * (pz - q[3 * mj + 2]);
-        const unsigned want = (unsigned)j << 16;
-        int lo = 0, hi = P;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (keys[mid] < want) lo = mid + 1; else hi = mid;
-        }
-        for (; lo < P && (keys[lo] >> 16) == (unsigned)j; ++lo) {
-            const int k = keys[lo] & 0xFFFF;
-            ax -= g2 * (q[3 * k] - px); ay -= g2 * (q[3 * k + 1] - py); az -= g2 * (q[3 * k + 2] - pz);
-        }
-        g[3 * j] = ax; g[3 * j + 1] = ay; g[3 * j + 2] = az;
-    }
+    const float gd = wb * (1.0f / (float)n);          // d(mean over n points)/d dist, times dist_weight
+    GradSide s;
+    s.n_own = n; s.n_oth = n;
+    s.own = pr.p + (size_t)b * n * 3; s.oth = pr.q + (size_t)b * n * 3;
+    s.match_own = pr.idx1 + (size_t)b * n; s.match_oth = pr.idx2 + (size_t)b * n;
+    s.gd_own = nullptr; s.gd_oth = nullptr; s.gd_own_s = gd; s.gd_oth_s = gd;
+    s.jstar = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
+    s.extra = wb * pr.extra_w;                        // max_point_dist_weight * max_j dist1[j] (adv_ae.py:100)
+    s.gout = pr.g + (size_t)b * n * 3;
+    chamfer_grad_side<true, CGA_THREADS>(s, lds, a.P);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -297,7 +269,7 @@ struct geoadv_attack {
     float beta1_pow, beta2_pow;
     bool fwd_valid;
     // profiling
-    bool prof;
+    unsigned prof_mask;
     std::vector<hipEvent_t> ev;      // pool
     int ev_used;
     struct Mark { int which, e0, e1; };
@@ -327,7 +299,7 @@ int prof_flush(geoadv_attack *at) {
 
 struct ProfScope {
     geoadv_attack *at; int which; int e0; hipStream_t st; bool on;
-    ProfScope(geoadv_attack *a, int w, hipStream_t s) : at(a), which(w), e0(-1), st(s), on(a->prof) {
+    ProfScope(geoadv_attack *a, int w, hipStream_t s) : at(a), which(w), e0(-1), st(s), on((a->prof_mask >> w) & 1u) {
         if (!on) return;
         if (at->ev_used + 2 > (int)at->ev.size()) prof_flush(at);
         e0 = at->ev_used++;
@@ -397,7 +369,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
                                        at->cfg.max_point_dist_weight};
         if (np) {
             ca.n = n; ca.P = pow2_ge(n);
-            chamfer_grad_attack_kernel<<<dim3(B, np), CGA_THREADS, sizeof(unsigned) * ca.P, st>>>(ca);
+            chamfer_grad_attack_kernel<<<dim3(B, np), CGA_THREADS, sizeof(unsigned) * (size_t)ca.P * (ca.P <= CG_TERMS_MAX_P ? 4 : 1), st>>>(ca);
             GA_LAUNCH_CHECK();
         }
     }
@@ -480,7 +452,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
     at->fwd_valid = false;
-    at->prof = false; at->ev_used = 0; at->prof_stream = nullptr;
+    at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr;
     for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
     static bool attr = false;
     if (!attr) {
@@ -592,8 +564,8 @@ extern "C" int geoadv_attack_profile(geoadv_attack *at, int enable) {
         at->ev.resize(4096);
         for (auto &e : at->ev) GA_HIP(hipEventCreate(&e));
     }
-    if (!enable && at->prof) { if (int rc = prof_flush(at)) return rc; }
-    at->prof = enable != 0;
+    if (at->prof_mask) { if (int rc = prof_flush(at)) return rc; }
+    at->prof_mask = (unsigned)enable;
     if (enable) for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
     return GEOADV_OK;
 }

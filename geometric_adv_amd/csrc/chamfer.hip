@@ -16,6 +16,7 @@
 // The kernel is VALU-issue bound (8 unfusable fp32 ops + 1 min per pair); HBM traffic is the
 // 20*B*(N+M) algorithmic bytes.
 #include "common.h"
+#include "chamfer_grad.h"
 #include <limits.h>
 #include <math.h>
 
@@ -197,76 +198,32 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
 }
 
 // ------------------------------------------------------------------------------------------
-// Gradient.  One workgroup per (cloud, output side).  For the output side "own" (n_own points)
-// every point j receives its own term g*(p_j - q_match[j]) and the scatter terms of all points
-// k of the other side with match_other[k] == j.  The reference CPU op applies them in a fixed
-// order (tf_nndistance.cpp:130-163): for grad_xyz1 own term first, then scatter terms in
-// ascending k; for grad_xyz2 scatter terms (ascending j) first, then the own term.  We get the
-// ascending order by sorting the keys (match_other[k] << 16 | k) in LDS (bitonic) and walking the
-// segment of equal high halves; arithmetic is the CPU's, so the result is bit-identical.
+// Gradient (NnDistanceGrad).  One workgroup per (cloud, output side); see chamfer_grad.h.
 // ------------------------------------------------------------------------------------------
 constexpr int CG_THREADS = 512;
-
-template <bool OWN_FIRST>
-__device__ void chamfer_grad_side(int n_own, const float *own, const float *gd_own, const int *match_own,
-                                  int n_oth, const float *oth, const float *gd_oth, const int *match_oth,
-                                  float *gout, unsigned *keys, int P) {
-    for (int i = threadIdx.x; i < P; i += CG_THREADS)
-        keys[i] = i < n_oth ? (((unsigned)match_oth[i] << 16) | (unsigned)i) : 0xFFFFFFFFu;
-    __syncthreads();
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += CG_THREADS) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const unsigned a = keys[i], bkey = keys[p];
-                    const bool up = (i & k) == 0;
-                    if ((a > bkey) == up) { keys[i] = bkey; keys[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int j = threadIdx.x; j < n_own; j += CG_THREADS) {
-        const float px = own[3 * j], py = own[3 * j + 1], pz = own[3 * j + 2];
-        float ax = 0.f, ay = 0.f, az = 0.f;
-        const int mj = match_own[j];
-        const float g = gd_own[j] * 2;
-        const float ox = g * (px - oth[3 * mj]), oy = g * (py - oth[3 * mj + 1]), oz = g * (pz - oth[3 * mj + 2]);
-        if (OWN_FIRST) { ax += ox; ay += oy; az += oz; }
-        // lower bound of (j << 16) in the sorted keys
-        const unsigned want = (unsigned)j << 16;
-        int lo = 0, hi = P;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (keys[mid] < want) lo = mid + 1; else hi = mid;
-        }
-        for (; lo < P && (keys[lo] >> 16) == (unsigned)j; ++lo) {
-            const int k = keys[lo] & 0xFFFF;
-            const float gk = gd_oth[k] * 2;
-            // other point k matched our point j: it subtracts gk*(q_k - p_j) from us
-            ax -= gk * (oth[3 * k] - px);
-            ay -= gk * (oth[3 * k + 1] - py);
-            az -= gk * (oth[3 * k + 2] - pz);
-        }
-        if (!OWN_FIRST) { ax += ox; ay += oy; az += oz; }
-        gout[3 * j] = ax; gout[3 * j + 1] = ay; gout[3 * j + 2] = az;
-    }
-}
 
 __global__ __launch_bounds__(CG_THREADS) void chamfer_grad_kernel(
     int n, const float *xyz1, int m, const float *xyz2, const float *gd1, const int *idx1,
     const float *gd2, const int *idx2, float *g1, float *g2, int P1, int P2) {
-    extern __shared__ __attribute__((aligned(16))) unsigned keys[];
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     const int c = blockIdx.x;
     const float *p = xyz1 + (size_t)c * n * 3, *q = xyz2 + (size_t)c * m * 3;
+    GradSide s;
+    s.jstar = -1; s.extra = 0.f; s.gd_own_s = 0.f; s.gd_oth_s = 0.f;
     if (blockIdx.y == 0) {
-        if (g1)
-            chamfer_grad_side<true>(n, p, gd1 + (size_t)c * n, idx1 + (size_t)c * n, m, q, gd2 + (size_t)c * m,
-                                    idx2 + (size_t)c * m, g1 + (size_t)c * n * 3, keys, P2);
+        if (!g1) return;
+        s.n_own = n; s.n_oth = m; s.own = p; s.oth = q;
+        s.match_own = idx1 + (size_t)c * n; s.match_oth = idx2 + (size_t)c * m;
+        s.gd_own = gd1 + (size_t)c * n; s.gd_oth = gd2 + (size_t)c * m;
+        s.gout = g1 + (size_t)c * n * 3;
+        chamfer_grad_side<true, CG_THREADS>(s, lds, P2);
     } else {
-        if (g2)
-            chamfer_grad_side<false>(m, q, gd2 + (size_t)c * m, idx2 + (size_t)c * m, n, p, gd1 + (size_t)c * n,
-                                     idx1 + (size_t)c * n, g2 + (size_t)c * m * 3, keys, P1);
+        if (!g2) return;
+        s.n_own = m; s.n_oth = n; s.own = q; s.oth = p;
+        s.match_own = idx2 + (size_t)c * m; s.match_oth = idx1 + (size_t)c * n;
+        s.gd_own = gd2 + (size_t)c * m; s.gd_oth = gd1 + (size_t)c * n;
+        s.gout = g2 + (size_t)c * m * 3;
+        chamfer_grad_side<false, CG_THREADS>(s, lds, P1);
     }
 }
 
@@ -275,6 +232,7 @@ static int pow2_at_least(int v) {
     while (p < v) p <<= 1;
     return p;
 }
+static size_t grad_lds_bytes(int P) { return sizeof(unsigned) * (size_t)P * (P <= CG_TERMS_MAX_P ? 4 : 1); }
 
 int launch_chamfer_grad(int b, int n, const float *xyz1, int m, const float *xyz2, const float *gd1,
                         const int *idx1, const float *gd2, const int *idx2, float *g1, float *g2,
@@ -287,7 +245,8 @@ int launch_chamfer_grad(int b, int n, const float *xyz1, int m, const float *xyz
         return GEOADV_OK;
     }
     const int P1 = pow2_at_least(n), P2 = pow2_at_least(m);
-    const size_t lds = sizeof(unsigned) * (size_t)(P1 > P2 ? P1 : P2);
+    const size_t l1 = grad_lds_bytes(P1), l2 = grad_lds_bytes(P2);
+    const size_t lds = l1 > l2 ? l1 : l2;
     static bool attr_set = false;
     if (!attr_set) {
         GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_kernel),

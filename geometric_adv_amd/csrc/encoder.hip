@@ -3,17 +3,23 @@
 // Reference semantics: src/encoders_decoders.py:37-72 with the widths of src/ae_templates.py:22
 // (3 -> 64 -> 128 -> 128 -> 256 -> 128): five per-point layers [conv1d k=1 (= x@W + b),
 // batch-norm in inference mode, ReLU], then a max over the points of each cloud.  In the
-// reference that is ~25 TF ops per forward; here it is ONE kernel: a workgroup owns 64 points,
-// keeps their activations in LDS, chains the four wide layers on v_mfma_f32_32x32x2_f32 (exact
-// fp32: the 1e-5 Chamfer tolerance rules out bf16/fp16 operands) and reduces the symmetric
-// max-pool in registers.  Nothing but the points, the weights (L2 resident, pre-packed into MFMA
-// fragment order) and 3*128 words per tile touches HBM -- the kernel is MFMA bound.
+// reference that is ~25 TF ops per forward; here it is ONE kernel: a workgroup owns a tile of
+// points, keeps their activations in LDS, chains the four wide layers on
+// v_mfma_f32_32x32x2_f32 (exact fp32: the 1e-5 Chamfer tolerance rules out bf16/fp16 operands)
+// and reduces the symmetric max-pool in registers.  Nothing but the points, the weights (L2
+// resident, pre-packed into MFMA fragment order) and 3*128 words per tile touches HBM -- the
+// kernel is MFMA bound.
 //
 // Backward-to-input (weights are frozen, var_list = pert only, adv_ae.py:153): the max-pool
 // passes gradient only to the <= 128 "critical" points of a cloud, so the backward kernel
 // re-runs the forward for just those rows (keeping the ReLU masks as bytes in LDS) and chains
 // the transposed layers.  Exact ties in the pool are handled like TF's _MinOrMaxGrad (equal
 // split): a cloud with a tied positive maximum is flagged and processed densely instead.
+//
+// Bit-identity of the recompute: the backward decides "is this row the arg-max" by comparing its
+// recomputed h5 with z, so every forward layer has ONE canonical accumulation order, whatever
+// the tile height or the wave assignment: 128-wide layers sum two independent K-half chains
+// (half0 + half1), the 256-wide layer one chain.
 #include "ae.h"
 #include <limits.h>
 
@@ -21,17 +27,18 @@ namespace geoadv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int ENC_THREADS = 512;
-constexpr int ENC_WAVES = ENC_THREADS / kWave;   // 8
-// LDS activation buffers (row stride = width + 4 floats keeps ds_read_b128 conflict-free)
-constexpr int BUF_P_FLOATS = ENC_ROWS * (256 + 4);
-constexpr int BUF_Q_FLOATS = ENC_ROWS * (128 + 4);
-constexpr int MASK_BYTES = ENC_ROWS * (64 + 128 + 128 + 256);   // ReLU masks of h1..h4 (backward only)
+constexpr int ENC_THREADS = 512;                 // 8 waves
 
-// One k-group (8 k values = 4 MFMA k-steps) at a time; RM row blocks of 32 share each B fragment.
+// accumulator register -> row inside a 32-row block (C/D layout of the 32x32 MFMA shapes)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// One chain over k-groups [t0, t1) (a k-group = 8 k values = 4 MFMA k-steps); RM row blocks of
+// 32 share each B fragment.  A fragments: ds_read_b128 from the LDS activation tile (row stride
+// s_in = width + 4 floats keeps them bank-conflict free); B fragments: one coalesced 1 KiB
+// global_load_dwordx4 per k-group from the packed weights, prefetched one group ahead.
 template <int RM>
-__device__ __forceinline__ void gemm_tile(const float *in, int s_in, int row0, const PackedLayer &L, int cb,
-                                          f32x16 (&acc)[RM]) {
+__device__ __forceinline__ void gemm_chain(const float *in, int s_in, int row0, const PackedLayer &L, int cb, int t0,
+                                           int t1, f32x16 (&acc)[RM]) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5, i = lane & 31;
     const int kg = L.K >> 3;
@@ -39,9 +46,9 @@ __device__ __forceinline__ void gemm_tile(const float *in, int s_in, int row0, c
     const float *ar[RM];
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) ar[rm] = in + (row0 + rm * 32 + i) * s_in + 4 * h;
-    float4 bcur = bp[0];
-    for (int t = 0; t < kg; ++t) {
-        const float4 bnext = bp[(size_t)(t + 1 < kg ? t + 1 : t) * 64];
+    float4 bcur = bp[(size_t)t0 * 64];
+    for (int t = t0; t < t1; ++t) {
+        const float4 bnext = bp[(size_t)(t + 1 < t1 ? t + 1 : t) * 64];
         float4 a[RM];
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) a[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * t);
@@ -56,66 +63,103 @@ __device__ __forceinline__ void gemm_tile(const float *in, int s_in, int row0, c
     }
 }
 
-// accumulator register -> row inside a 32-row block (C/D layout of the 32x32 MFMA shapes)
-__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-
-// Hidden forward layer on a 64-row tile: out = relu(in @ W * scale + shift), optional ReLU mask.
-// NOUT == 128: wave w -> column block w&3, row block w>>2.  NOUT == 256: wave w -> column block w,
-// both row blocks.
-template <int NOUT, bool SAVE_MASK>
-__device__ __forceinline__ void fwd_layer(const float *in, int s_in, float *out, int s_out, const PackedLayer &L,
-                                          const float *scale, const float *shift, unsigned char *mask) {
+// out tile [ROWS][NOUT] = in tile [ROWS][K] @ W, handed element-wise to epi(row, col, value).
+// KC = number of canonical K parts (independent chains summed part0 + part1 + ...); KC == 0
+// picks whatever keeps all 8 waves busy.  Must be called by every wave of the workgroup.
+template <int ROWS, int NOUT, int KC_REQ, class Epi>
+__device__ __forceinline__ void layer_gemm(const float *in, int s_in, const PackedLayer &L, float *scratch, Epi epi) {
+    constexpr int CB = NOUT / 32, RB = ROWS / 32;
+    constexpr bool RM2 = (CB * RB > 8);                      // 64 rows x 256 columns: two row blocks per wave
+    constexpr int UNITS = RM2 ? CB : CB * RB;                // (column block, row block) units handed to waves
+    constexpr int SPARE = 8 / UNITS;                         // waves available per unit
+    constexpr int KC = KC_REQ > 0 ? KC_REQ : SPARE;
+    constexpr int KS = (SPARE >= KC) ? KC : 1;               // K parts computed by different waves, or all by one
+    static_assert(KS == KC || KS == 1, "bad K split");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = lane >> 5, i = lane & 31;
-    if (NOUT == 256) {
-        const int cb = wave;
-        f32x16 acc[2] = {};
-        gemm_tile<2>(in, s_in, 0, L, cb, acc);
-        const int col = cb * 32 + i;
-        const float sc = scale[col], sh = shift[col];
+    const int unit = wave % UNITS, ks = wave / UNITS;
+    const int cb = unit % CB, rb = RM2 ? 0 : unit / CB;
+    const int kg = L.K >> 3;
+    constexpr int RM = RM2 ? 2 : 1;
+    f32x16 acc[RM] = {};
+    if (KS == KC) {
+        if (ks < KS) gemm_chain<RM>(in, s_in, rb * 32, L, cb, ks * kg / KC, (ks + 1) * kg / KC, acc);
+        if (KC > 1) {
+            if (ks > 0 && ks < KS) {
 #pragma unroll
-        for (int rm = 0; rm < 2; ++rm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rm * 32 + acc_row(r, h);
-                const float v = fmaxf(fmaf(acc[rm][r], sc, sh), 0.f);
-                out[row * s_out + col] = v;
-                if (SAVE_MASK) mask[row * NOUT + col] = v > 0.f;
+                for (int r = 0; r < 16; ++r) scratch[(((ks - 1) * UNITS + unit) * 16 + r) * 64 + lane] = acc[0][r];
             }
-    } else {
-        constexpr int CB = NOUT / 32;             // 4 (128 wide) or 2 (64 wide)
-        const int cb = wave % CB, rb = wave / CB;
-        if (rb < 2) {
-            f32x16 acc[1] = {};
-            gemm_tile<1>(in, s_in, rb * 32, L, cb, acc);
-            const int col = cb * 32 + i;
-            const float sc = scale[col], sh = shift[col];
+            __syncthreads();
+            if (ks == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + acc_row(r, h);
-                const float v = fmaxf(fmaf(acc[0][r], sc, sh), 0.f);
-                out[row * s_out + col] = v;
-                if (SAVE_MASK) mask[row * NOUT + col] = v > 0.f;
+                for (int p = 1; p < KC; ++p)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][r] += scratch[(((p - 1) * UNITS + unit) * 16 + r) * 64 + lane];
             }
         }
+    } else if (ks == 0) {   // one wave walks the canonical parts one after the other
+        gemm_chain<RM>(in, s_in, rb * 32, L, cb, 0, kg / KC, acc);
+#pragma unroll
+        for (int p = 1; p < KC; ++p) {
+            f32x16 part[RM] = {};
+            gemm_chain<RM>(in, s_in, rb * 32, L, cb, p * kg / KC, (p + 1) * kg / KC, part);
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) acc[rm] += part[rm];
+        }
+    }
+    if (ks == 0) {
+        const int col = cb * 32 + i;
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi((rb + rm) * 32 + acc_row(r, h), col, acc[rm][r]);
     }
 }
 
-// Layer 0 (fan-in 3) on the VALU: 512 threads = 64 rows x 8 threads, 8 channels each.
-template <bool SAVE_MASK>
-__device__ __forceinline__ void fwd_layer0(const float *pts /*LDS [64][3]*/, float *out, int s_out, const DeviceAE &A,
+constexpr int fwd_kc(int nout) { return nout == 256 ? 1 : 2; }   // the canonical order of a forward layer
+
+template <int ROWS> struct EncLds {
+    static constexpr int P_FLOATS = ROWS * (256 + 4);
+    static constexpr int Q_FLOATS = ROWS * (128 + 4);
+    static constexpr int SCRATCH_FLOATS = ROWS == 32 ? 3 * 2 * 16 * 64 : 16 * 64 * 4;   // K-part hand-off
+    static constexpr int MASK_BYTES = ROWS * (64 + 128 + 128 + 256);
+    static constexpr size_t fwd_bytes = sizeof(float) * (P_FLOATS + Q_FLOATS + SCRATCH_FLOATS + ROWS * 3 + 256) + sizeof(int) * 512;
+    static constexpr size_t bwd_bytes = sizeof(float) * (P_FLOATS + Q_FLOATS + SCRATCH_FLOATS + ROWS * 3) + sizeof(int) * ROWS + MASK_BYTES;
+};
+
+// Hidden forward layer: out = relu(in @ W * scale + shift) (+ ReLU mask bytes for the backward).
+template <int ROWS, int NOUT, bool SAVE_MASK>
+__device__ __forceinline__ void fwd_layer(const float *in, int s_in, float *out, int s_out, const PackedLayer &L,
+                                          const float *scale, const float *shift, unsigned char *mask, float *scratch) {
+    const int i = threadIdx.x & 31;
+    const int wave = threadIdx.x >> 6;
+    constexpr int CB = NOUT / 32;
+    const int col_of_lane = ((wave % ((CB * (ROWS / 32) > 8) ? CB : CB * (ROWS / 32))) % CB) * 32 + i;
+    const float sc = scale[col_of_lane], sh = shift[col_of_lane];
+    layer_gemm<ROWS, NOUT, fwd_kc(NOUT)>(in, s_in, L, scratch, [&](int row, int col, float a) {
+        const float v = fmaxf(fmaf(a, sc, sh), 0.f);
+        out[row * s_out + col] = v;
+        if (SAVE_MASK) mask[row * NOUT + col] = v > 0.f;
+    });
+}
+
+// Layer 0 (fan-in 3) on the VALU: 8 channels per thread.
+template <int ROWS, bool SAVE_MASK>
+__device__ __forceinline__ void fwd_layer0(const float *pts /*LDS [ROWS][3]*/, float *out, int s_out, const DeviceAE &A,
                                            unsigned char *mask) {
-    const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 8;
-    const float x = pts[row * 3], y = pts[row * 3 + 1], z = pts[row * 3 + 2];
     const int C1 = 64;
+    for (int e = threadIdx.x; e < ROWS * 8; e += ENC_THREADS) {
+        const int row = e >> 3, c0 = (e & 7) * 8;
+        const float x = pts[row * 3], y = pts[row * 3 + 1], z = pts[row * 3 + 2];
 #pragma unroll
-    for (int c = c0; c < c0 + 8; ++c) {
-        float a = x * A.w0[c];
-        a = fmaf(y, A.w0[C1 + c], a);
-        a = fmaf(z, A.w0[2 * C1 + c], a);
-        const float v = fmaxf(fmaf(a, A.scale[0][c], A.shift[0][c]), 0.f);
-        out[row * s_out + c] = v;
-        if (SAVE_MASK) mask[row * C1 + c] = v > 0.f;
+        for (int c = c0; c < c0 + 8; ++c) {
+            float a = x * A.w0[c];
+            a = fmaf(y, A.w0[C1 + c], a);
+            a = fmaf(z, A.w0[2 * C1 + c], a);
+            const float v = fmaxf(fmaf(a, A.scale[0][c], A.shift[0][c]), 0.f);
+            out[row * s_out + c] = v;
+            if (SAVE_MASK) mask[row * C1 + c] = v > 0.f;
+        }
     }
 }
 
@@ -123,20 +167,23 @@ __device__ __forceinline__ void fwd_layer0(const float *pts /*LDS [64][3]*/, flo
 // Forward kernel.  grid = (tiles per cloud, clouds).  Outputs per tile and channel: the maximum
 // of h5 over the tile's valid rows, the first row attaining it, and how many rows attain it.
 // ------------------------------------------------------------------------------------------
+template <int ROWS>
 __global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(DeviceAE A, int n, const float *x,
                                                                   const float *pert, float *adv_out, float *pmax,
                                                                   int *parg, int *pcnt) {
+    using LD = EncLds<ROWS>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufP = lds;
-    float *bufQ = lds + BUF_P_FLOATS;
-    float *pts = bufQ + BUF_Q_FLOATS;                 // [64][3]
-    float *redm = pts + ENC_ROWS * 3;                 // [2][128]
+    float *bufQ = bufP + LD::P_FLOATS;
+    float *scratch = bufQ + LD::Q_FLOATS;
+    float *pts = scratch + LD::SCRATCH_FLOATS;        // [ROWS][3]
+    float *redm = pts + ROWS * 3;                     // [2][128]
     int *reda = reinterpret_cast<int *>(redm + 256);  // [2][128]
     int *redc = reda + 256;                           // [2][128]
 
     const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
-    const int n0 = tile * ENC_ROWS;
-    if (threadIdx.x < ENC_ROWS * 3) {
+    const int n0 = tile * ROWS;
+    if (threadIdx.x < ROWS * 3) {
         const int r = threadIdx.x / 3, a = threadIdx.x % 3;
         int p = n0 + r;
         const bool valid = p < n;
@@ -148,49 +195,53 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(DeviceAE A, in
         if (adv_out && valid) adv_out[g] = v;
     }
     __syncthreads();
-    fwd_layer0<false>(pts, bufQ, 68, A, nullptr);
+    fwd_layer0<ROWS, false>(pts, bufQ, 68, A, nullptr);
     __syncthreads();
-    fwd_layer<128, false>(bufQ, 68, bufP, 132, A.enc_fwd[1], A.scale[1], A.shift[1], nullptr);
+    fwd_layer<ROWS, 128, false>(bufQ, 68, bufP, 132, A.enc_fwd[1], A.scale[1], A.shift[1], nullptr, scratch);
     __syncthreads();
-    fwd_layer<128, false>(bufP, 132, bufQ, 132, A.enc_fwd[2], A.scale[2], A.shift[2], nullptr);
+    fwd_layer<ROWS, 128, false>(bufP, 132, bufQ, 132, A.enc_fwd[2], A.scale[2], A.shift[2], nullptr, scratch);
     __syncthreads();
-    fwd_layer<256, false>(bufQ, 132, bufP, 260, A.enc_fwd[3], A.scale[3], A.shift[3], nullptr);
+    fwd_layer<ROWS, 256, false>(bufQ, 132, bufP, 260, A.enc_fwd[3], A.scale[3], A.shift[3], nullptr, scratch);
     __syncthreads();
 
-    // layer 4 + symmetric max-pool straight from the accumulators
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int h = lane >> 5, i = lane & 31;
-    const int cb = wave & 3, rb = wave >> 2;
-    f32x16 acc[1] = {};
-    gemm_tile<1>(bufP, 260, rb * 32, A.enc_fwd[4], cb, acc);
-    const int col = cb * 32 + i;
-    const float sc = A.scale[4][col], sh = A.shift[4][col];
+    // layer 4 + symmetric max-pool straight from the accumulators: every lane owns one column and
+    // 16 rows per row block (ascending), so the running (max, first row, count) stays in registers.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
     float mx = -1.f;
-    int arg = INT_MAX, cnt = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = rb * 32 + acc_row(r, h);
-        const float v = fmaxf(fmaf(acc[0][r], sc, sh), 0.f);
+    int arg = INT_MAX, cnt = 0, mycol = 0, myrb = 0;
+    {
+        constexpr int UNITS = 4 * (ROWS / 32);
+        const int unit = wave % UNITS;
+        mycol = (unit % 4) * 32 + (lane & 31);
+        myrb = unit / 4;
+    }
+    const float sc = A.scale[4][mycol], sh = A.shift[4][mycol];
+    layer_gemm<ROWS, 128, fwd_kc(128)>(bufP, 260, A.enc_fwd[4], scratch, [&](int row, int col, float a) {
+        const float v = fmaxf(fmaf(a, sc, sh), 0.f);
         if (n0 + row < n) {
             if (v > mx) { mx = v; arg = n0 + row; cnt = 1; }
             else if (v == mx) cnt++;
         }
-    }
+    });
     {   // the two lane halves hold interleaved rows of the same column
         const float m2 = __shfl_xor(mx, 32);
         const int a2 = __shfl_xor(arg, 32), c2 = __shfl_xor(cnt, 32);
         if (m2 > mx) { mx = m2; arg = a2; cnt = c2; }
         else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += c2; }
     }
-    if (h == 0) { redm[rb * 128 + col] = mx; reda[rb * 128 + col] = arg; redc[rb * 128 + col] = cnt; }
+    constexpr int OWNERS = 4 * (ROWS / 32);           // waves that own an output unit of layer 4
+    if (wave < OWNERS && h == 0) { redm[myrb * 128 + mycol] = mx; reda[myrb * 128 + mycol] = arg; redc[myrb * 128 + mycol] = cnt; }
     __syncthreads();
     if (threadIdx.x < 128) {
         const int c = threadIdx.x;
         float m = redm[c];
         int a = reda[c], k = redc[c];
-        const float m2 = redm[128 + c];
-        if (m2 > m) { m = m2; a = reda[128 + c]; k = redc[128 + c]; }
-        else if (m2 == m) { k += redc[128 + c]; }       // rows of block 1 are higher: arg stays
+        if (ROWS == 64) {
+            const float m2 = redm[128 + c];
+            if (m2 > m) { m = m2; a = reda[128 + c]; k = redc[128 + c]; }
+            else if (m2 == m) { k += redc[128 + c]; }   // rows of block 1 are higher: arg stays
+        }
         const size_t o = ((size_t)b * tiles + tile) * 128 + c;
         pmax[o] = m; parg[o] = a; pcnt[o] = k;
     }
@@ -198,10 +249,11 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(DeviceAE A, in
 
 // ------------------------------------------------------------------------------------------
 // Backward kernel over a list of rows.  grid = (row tiles, clouds).  rows: [b][rows_per_cloud]
-// point indices (duplicates allowed: every listed row is written with the same value).  A cloud
-// takes part only if dense_flag[b] == want_dense (the sparse list launch skips flagged clouds,
-// the dense launch skips the others).  g_enc[b][row][3] = d loss / d adv through the encoder.
+// point indices (duplicates allowed: every listed row is written with the same value), or null
+// for "all points".  A cloud takes part only if dense_flag[b] == want_dense (the sparse launch
+// skips flagged clouds, the dense launch the others).  g_enc[b][row][3] = dL/d adv via the encoder.
 // ------------------------------------------------------------------------------------------
+template <int ROWS>
 __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(DeviceAE A, int n, const float *adv,
                                                                   const int *rows, int rows_per_cloud,
                                                                   const float *z, const int *zcnt, const float *dz,
@@ -209,18 +261,20 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(DeviceAE A, in
                                                                   float *g_enc) {
     const int b = blockIdx.y;
     if ((dense_flag[b] != 0) != (want_dense != 0)) return;
+    using LD = EncLds<ROWS>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufP = lds;
-    float *bufQ = lds + BUF_P_FLOATS;
-    float *pts = bufQ + BUF_Q_FLOATS;                              // [64][3]
-    int *rowid = reinterpret_cast<int *>(pts + ENC_ROWS * 3);      // [64]
-    unsigned char *m1 = reinterpret_cast<unsigned char *>(rowid + ENC_ROWS);
-    unsigned char *m2 = m1 + ENC_ROWS * 64;
-    unsigned char *m3 = m2 + ENC_ROWS * 128;
-    unsigned char *m4 = m3 + ENC_ROWS * 128;
+    float *bufQ = bufP + LD::P_FLOATS;
+    float *scratch = bufQ + LD::Q_FLOATS;
+    float *pts = scratch + LD::SCRATCH_FLOATS;                     // [ROWS][3]
+    int *rowid = reinterpret_cast<int *>(pts + ROWS * 3);          // [ROWS]
+    unsigned char *m1 = reinterpret_cast<unsigned char *>(rowid + ROWS);
+    unsigned char *m2 = m1 + ROWS * 64;
+    unsigned char *m3 = m2 + ROWS * 128;
+    unsigned char *m4 = m3 + ROWS * 128;
 
-    const int r0 = blockIdx.x * ENC_ROWS;
-    if (threadIdx.x < ENC_ROWS) {
+    const int r0 = blockIdx.x * ROWS;
+    if (threadIdx.x < ROWS) {
         int rr = r0 + threadIdx.x;
         int p;
         if (rows) { rr = rr < rows_per_cloud ? rr : rows_per_cloud - 1; p = rows[(size_t)b * rows_per_cloud + rr]; }
@@ -228,100 +282,72 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(DeviceAE A, in
         rowid[threadIdx.x] = p;
     }
     __syncthreads();
-    if (threadIdx.x < ENC_ROWS * 3) {
+    if (threadIdx.x < ROWS * 3) {
         const int r = threadIdx.x / 3, a = threadIdx.x % 3;
         pts[threadIdx.x] = adv[((size_t)b * n + rowid[r]) * 3 + a];
     }
     __syncthreads();
-    // forward recompute (bit-identical to the forward kernel: same instruction sequence per row)
-    fwd_layer0<true>(pts, bufQ, 68, A, m1);
+    // forward recompute, bit-identical to the forward kernel (canonical accumulation order)
+    fwd_layer0<ROWS, true>(pts, bufQ, 68, A, m1);
     __syncthreads();
-    fwd_layer<128, true>(bufQ, 68, bufP, 132, A.enc_fwd[1], A.scale[1], A.shift[1], m2);
+    fwd_layer<ROWS, 128, true>(bufQ, 68, bufP, 132, A.enc_fwd[1], A.scale[1], A.shift[1], m2, scratch);
     __syncthreads();
-    fwd_layer<128, true>(bufP, 132, bufQ, 132, A.enc_fwd[2], A.scale[2], A.shift[2], m3);
+    fwd_layer<ROWS, 128, true>(bufP, 132, bufQ, 132, A.enc_fwd[2], A.scale[2], A.shift[2], m3, scratch);
     __syncthreads();
-    fwd_layer<256, true>(bufQ, 132, bufP, 260, A.enc_fwd[3], A.scale[3], A.shift[3], m4);
+    fwd_layer<ROWS, 256, true>(bufQ, 132, bufP, 260, A.enc_fwd[3], A.scale[3], A.shift[3], m4, scratch);
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int h = lane >> 5, i = lane & 31;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {   // layer 4 forward -> da4 = dz/cnt * [h5 == z, z > 0] * scale4   into bufQ (128 wide)
-        const int cb = wave & 3, rb = wave >> 2;
-        f32x16 acc[1] = {};
-        gemm_tile<1>(bufP, 260, rb * 32, A.enc_fwd[4], cb, acc);
-        const int col = cb * 32 + i;
+        constexpr int UNITS = 4 * (ROWS / 32);
+        const int col = ((wave % UNITS) % 4) * 32 + (lane & 31);
         const float sc = A.scale[4][col], sh = A.shift[4][col];
         const float zc = z[(size_t)b * 128 + col];
         const int kc = zcnt[(size_t)b * 128 + col];
         const float gz = (kc > 1 ? (1.0f / (float)kc) : 1.0f) * dz[(size_t)b * 128 + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rb * 32 + acc_row(r, h);
-            const float v = fmaxf(fmaf(acc[0][r], sc, sh), 0.f);
-            bufQ[row * 132 + col] = (v == zc && v > 0.f) ? gz * sc : 0.f;
-        }
+        layer_gemm<ROWS, 128, fwd_kc(128)>(bufP, 260, A.enc_fwd[4], scratch, [&](int row, int c, float a) {
+            const float v = fmaxf(fmaf(a, sc, sh), 0.f);
+            bufQ[row * 132 + c] = (v == zc && v > 0.f) ? gz * sc : 0.f;
+        });
     }
     __syncthreads();
     // dh4 = da4 @ W4^T (128 -> 256); da3 = dh4 * mask4 * scale3   into bufP (256 wide)
     {
-        const int cb = wave;
-        f32x16 acc[2] = {};
-        gemm_tile<2>(bufQ, 132, 0, A.enc_bwd[4], cb, acc);
-        const int col = cb * 32 + i;
+        const int col = (wave % 8) * 32 + (lane & 31);
         const float sc = A.scale[3][col];
-#pragma unroll
-        for (int rm = 0; rm < 2; ++rm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rm * 32 + acc_row(r, h);
-                bufP[row * 260 + col] = m4[row * 256 + col] ? acc[rm][r] * sc : 0.f;
-            }
+        layer_gemm<ROWS, 256, 0>(bufQ, 132, A.enc_bwd[4], scratch,
+                                 [&](int row, int c, float a) { bufP[row * 260 + c] = m4[row * 256 + c] ? a * sc : 0.f; });
     }
     __syncthreads();
     // dh3 = da3 @ W3^T (256 -> 128); da2 = dh3 * mask3 * scale2   into bufQ
     {
-        const int cb = wave & 3, rb = wave >> 2;
-        f32x16 acc[1] = {};
-        gemm_tile<1>(bufP, 260, rb * 32, A.enc_bwd[3], cb, acc);
-        const int col = cb * 32 + i;
+        constexpr int UNITS = 4 * (ROWS / 32);
+        const int col = ((wave % UNITS) % 4) * 32 + (lane & 31);
         const float sc = A.scale[2][col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rb * 32 + acc_row(r, h);
-            bufQ[row * 132 + col] = m3[row * 128 + col] ? acc[0][r] * sc : 0.f;
-        }
+        layer_gemm<ROWS, 128, 0>(bufP, 260, A.enc_bwd[3], scratch,
+                                 [&](int row, int c, float a) { bufQ[row * 132 + c] = m3[row * 128 + c] ? a * sc : 0.f; });
     }
     __syncthreads();
     // dh2 = da2 @ W2^T (128 -> 128); da1 = dh2 * mask2 * scale1   into bufP (stride 132)
     {
-        const int cb = wave & 3, rb = wave >> 2;
-        f32x16 acc[1] = {};
-        gemm_tile<1>(bufQ, 132, rb * 32, A.enc_bwd[2], cb, acc);
-        const int col = cb * 32 + i;
+        constexpr int UNITS = 4 * (ROWS / 32);
+        const int col = ((wave % UNITS) % 4) * 32 + (lane & 31);
         const float sc = A.scale[1][col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rb * 32 + acc_row(r, h);
-            bufP[row * 132 + col] = m2[row * 128 + col] ? acc[0][r] * sc : 0.f;
-        }
+        layer_gemm<ROWS, 128, 0>(bufQ, 132, A.enc_bwd[2], scratch,
+                                 [&](int row, int c, float a) { bufP[row * 132 + c] = m2[row * 128 + c] ? a * sc : 0.f; });
     }
     __syncthreads();
-    // dh1 = da1 @ W1^T (128 -> 64); da0 = dh1 * mask1 * scale0   into bufQ (stride 68); 4 waves
-    if (wave < 4) {
-        const int cb = wave & 1, rb = wave >> 1;
-        f32x16 acc[1] = {};
-        gemm_tile<1>(bufP, 132, rb * 32, A.enc_bwd[1], cb, acc);
-        const int col = cb * 32 + i;
+    // dh1 = da1 @ W1^T (128 -> 64); da0 = dh1 * mask1 * scale0   into bufQ (stride 68)
+    {
+        constexpr int UNITS = 2 * (ROWS / 32);
+        const int col = ((wave % UNITS) % 2) * 32 + (lane & 31);
         const float sc = A.scale[0][col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rb * 32 + acc_row(r, h);
-            bufQ[row * 68 + col] = m1[row * 64 + col] ? acc[0][r] * sc : 0.f;
-        }
+        layer_gemm<ROWS, 64, 0>(bufP, 132, A.enc_bwd[1], scratch,
+                                [&](int row, int c, float a) { bufQ[row * 68 + c] = m1[row * 64 + c] ? a * sc : 0.f; });
     }
     __syncthreads();
     // dh0 = da0 @ W0^T (64 -> 3) on the VALU
-    if (threadIdx.x < ENC_ROWS * 3) {
+    if (threadIdx.x < ROWS * 3) {
         const int r = threadIdx.x / 3, a = threadIdx.x % 3;
         float s = 0.f;
 #pragma unroll 8
@@ -331,30 +357,31 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(DeviceAE A, in
     }
 }
 
-size_t encoder_fwd_lds_bytes() { return sizeof(float) * (BUF_P_FLOATS + BUF_Q_FLOATS + ENC_ROWS * 3 + 256) + sizeof(int) * 512; }
-size_t encoder_bwd_lds_bytes() {
-    return sizeof(float) * (BUF_P_FLOATS + BUF_Q_FLOATS + ENC_ROWS * 3) + sizeof(int) * ENC_ROWS + MASK_BYTES;
-}
+constexpr int FWD_ROWS = 64;
+constexpr int BWD_SPARSE_ROWS = 32;
+constexpr int BWD_DENSE_ROWS = 64;
 
 static int set_lds_attr_once() {
     static bool done = false;
     if (done) return GEOADV_OK;
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)encoder_fwd_lds_bytes()));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)encoder_bwd_lds_bytes()));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<FWD_ROWS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<FWD_ROWS>::fwd_bytes));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_SPARSE_ROWS>::bwd_bytes));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_DENSE_ROWS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_DENSE_ROWS>::bwd_bytes));
     done = true;
     return GEOADV_OK;
 }
 
-int encoder_tiles(int n) { return cdiv(n, ENC_ROWS); }
+int encoder_tiles(int n) { return cdiv(n, FWD_ROWS); }
 
 // pmax/parg/pcnt: [b][tiles][128]
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
                        int *parg, int *pcnt, hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
-    encoder_fwd_kernel<<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, encoder_fwd_lds_bytes(), stream>>>(
+    encoder_fwd_kernel<FWD_ROWS><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<FWD_ROWS>::fwd_bytes, stream>>>(
         A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
@@ -367,10 +394,10 @@ int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *cr
                        const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
-    encoder_bwd_kernel<<<dim3(128 / ENC_ROWS, b), ENC_THREADS, encoder_bwd_lds_bytes(), stream>>>(
+    encoder_bwd_kernel<BWD_SPARSE_ROWS><<<dim3(128 / BWD_SPARSE_ROWS, b), ENC_THREADS, EncLds<BWD_SPARSE_ROWS>::bwd_bytes, stream>>>(
         A, A.n_points, adv, crit_rows, 128, z, zcnt, dz, dense_flag, 0, g_enc);
     GA_LAUNCH_CHECK();
-    encoder_bwd_kernel<<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, encoder_bwd_lds_bytes(), stream>>>(
+    encoder_bwd_kernel<BWD_DENSE_ROWS><<<dim3(cdiv(A.n_points, BWD_DENSE_ROWS), b), ENC_THREADS, EncLds<BWD_DENSE_ROWS>::bwd_bytes, stream>>>(
         A, A.n_points, adv, nullptr, 0, z, zcnt, dz, dense_flag, 1, g_enc);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;

@@ -1,0 +1,103 @@
+"""Multi-GPU: one process per GPU, batches sharded across ranks, RCCL only for the result gather.
+
+The attack has no cross-example coupling (the loss is a sum over the batch, adv_ae.py:105; pert
+and the Adam slots are per example; weights are frozen), and AdvAE.attack already walks the
+examples in independent batches of batch_size (adv_ae.py:166-177).  So ranks take disjoint
+contiguous runs of BATCHES, run them with no communication at all, and all-gather only the final
+per-cloud metric scalars (5 floats per cloud and dist weight) -- KB-sized, latency-bound, the xGMI
+link bandwidth is irrelevant.  Clouds are gathered to rank 0 only on request.
+
+Backend: 'nccl' (= RCCL on ROCm) on GPUs, 'gloo' for the CPU tests of this module.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    """(rank, world_size, local_rank) from the torchrun environment (1-process defaults)."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the environment if WORLD_SIZE > 1.  Returns (rank, world, local_rank)."""
+    rank, world, local = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batches(n_batches, rank, world):
+    """Contiguous split of range(n_batches); the first n_batches % world ranks get one extra."""
+    q, r = divmod(n_batches, world)
+    start = rank * q + min(rank, r)
+    return range(start, start + q + (1 if rank < r else 0))
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_gather_examples(local, counts=None, axis=1):
+    """all-gather a tensor whose `axis` is the example axis, concatenated in rank order.
+    Ranks may hold different numbers of examples (pads to the maximum, trims after)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n_local = torch.tensor([local.shape[axis]], dtype=torch.int64, device=local.device)
+    ns = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(ns, n_local)
+    ns = [int(t.item()) for t in ns]
+    cap = max(ns)
+    loc = local.movedim(axis, 0).contiguous()
+    if loc.shape[0] < cap:
+        pad = torch.zeros((cap - loc.shape[0],) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device)
+        loc = torch.cat([loc, pad], 0)
+    parts = [torch.empty_like(loc) for _ in range(world)]
+    dist.all_gather(parts, loc)
+    out = torch.cat([p[:k] for p, k in zip(parts, ns)], 0)
+    return out.movedim(0, axis).contiguous()
+
+
+def attack_sharded(adv_ae, source_pc, target_latent, target_pc, target_ae_loss_ref, gather_clouds=False, device=None):
+    """AdvAE.attack over all examples with the batches sharded across ranks.
+
+    Every rank passes the FULL arrays (n_examples must divide by batch_size, adv_ae.py:162).
+    Returns (metrics [W, n_examples, 5] on every rank, adv, recon): adv/recon cover all examples
+    when gather_clouds else only this rank's (with `local_slice` giving their position)."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    c = adv_ae.configuration
+    n_examples = len(source_pc)
+    assert n_examples % c.batch_size == 0, \
+        'The number of examples (%d) should be divided by the batch size (%d)' % (n_examples, c.batch_size)
+    mine = shard_batches(n_examples // c.batch_size, rank, world)
+    lo, hi = mine.start * c.batch_size, mine.stop * c.batch_size
+    W = len(c.dist_weight_list)
+    if hi > lo:
+        m_, a_, r_ = adv_ae.attack(source_pc[lo:hi], None if target_latent is None else target_latent[lo:hi],
+                                   target_pc[lo:hi], target_ae_loss_ref[lo:hi], c)
+    else:
+        n = c.n_input[0]
+        m_, a_, r_ = np.zeros((W, 0, 5), np.float32), np.zeros((W, 0, n, 3), np.float32), np.zeros((W, 0, n, 3), np.float32)
+    dev = device if device is not None else (adv_ae.device if getattr(adv_ae, "device", None) is not None else "cpu")
+    metrics = all_gather_examples(torch.as_tensor(m_).to(dev)).cpu().numpy()
+    if gather_clouds:
+        a_ = all_gather_examples(torch.as_tensor(a_).to(dev)).cpu().numpy()
+        r_ = all_gather_examples(torch.as_tensor(r_).to(dev)).cpu().numpy()
+    return metrics, a_, r_, slice(lo, hi)

@@ -199,8 +199,9 @@ int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, float *recon,
                        float *grad, int *idx_r1, int *idx_r2, int *idx_a1, int *idx_a2, void *stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
- * enable != 0: every geoadv_attack_run iteration brackets its kernels with events (a small
- * fixed pool is recycled).  geoadv_attack_profile_read synchronises the stream and returns, for
+ * enable is a bit mask of GEOADV_PROF_* classes (bit k = class k, -1 = all, 0 = off; enabling resets
+ * the totals): every geoadv_attack_run iteration brackets the selected kernels with events (a fixed
+ * pool is recycled; when it runs dry the stream is synchronised once).  geoadv_attack_profile_read synchronises the stream and returns, for
  * kernel class `which` (GEOADV_PROF_*), the number of launches timed and their total ms. */
 #define GEOADV_PROF_ENCODER_FWD 0
 #define GEOADV_PROF_DECODER_FWD 1
