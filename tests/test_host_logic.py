@@ -1,0 +1,103 @@
+"""CPU: host-side logic of the package (no GPU, no compute calls through the C ABI)."""
+import numpy as np
+import pytest
+
+
+def test_weights_roundtrip_and_validation(tmp_path):
+    from geometric_adv_amd import weights as W
+    w = W.synthetic_weights(256)
+    assert sorted(w) == sorted(W.variable_names())
+    assert w["autoencoder/encoder_conv_layer_0/W"].shape == (1, 1, 3, 64)          # tflearn conv_1d filter shape
+    assert w["autoencoder/decoder_fc_2/W"].shape == (256, 768)
+    p = str(tmp_path / "ae.npz")
+    W.save_npz(p, w)
+    w2 = W.load_npz(p)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+    c = W.canonical(w2, 256)
+    assert c["enc_w"][3].shape == (128, 256) and c["dec_w"][2].shape == (256, 768)
+    bad = dict(w); del bad["autoencoder/decoder_fc_1/b"]
+    with pytest.raises(KeyError):
+        W.canonical(bad, 256)
+    with pytest.raises(ValueError):
+        W.canonical(w, 128)                                                        # decoder sized for 256 points
+
+
+def test_init_pert_is_truncated_normal():
+    from geometric_adv_amd.adversary import init_pert_value, get_pert_loss_np
+    p = init_pert_value(4, 512)
+    assert p.shape == (4, 512, 3) and p.dtype == np.float32
+    assert np.abs(p).max() <= 2e-7 + 1e-12 and 0.5e-7 < p.std() < 1.1e-7           # sigma 1e-7, cut at 2 sigma
+    assert np.array_equal(p, init_pert_value(4, 512))                              # seed 55 => reproducible
+    lp, lm = get_pert_loss_np(p)
+    np.testing.assert_allclose(lp, np.sqrt((p.astype(np.float64) ** 2).sum((1, 2))), rtol=1e-5)
+    np.testing.assert_allclose(lm, np.sqrt((p.astype(np.float64) ** 2).sum(2).max(1)), rtol=1e-5)
+
+
+def test_ops_reject_cpu_tensors_and_bad_shapes():
+    """There is no CPU path: CPU tensors are an error, like a wrong rank (tf_nndistance.cpp:51-58)."""
+    import torch
+    from geometric_adv_amd import ops
+    with pytest.raises(ValueError, match="no CPU path"):
+        ops.nn_distance(torch.rand(2, 5, 3), torch.rand(2, 5, 3))
+    with pytest.raises(ValueError):
+        ops.nn_distance(torch.rand(5, 3), torch.rand(2, 5, 3))
+    with pytest.raises(TypeError):
+        ops.nn_distance(np.zeros((2, 5, 3), np.float32), np.zeros((2, 5, 3), np.float32))
+
+
+def test_configuration_validation():
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    conf = Configuration(batch_size=2, n_points=64, weights={}, loss="emd")
+    with pytest.raises(ValueError, match="chamfer"):
+        AdvAE("adversary", conf)
+    conf = Configuration(batch_size=2, n_points=64, weights={}, loss_adv_type="bogus")
+    with pytest.raises(ValueError):
+        AdvAE("adversary", conf)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from geometric_adv_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.GeoAdvError, match="not built"):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under geometric_adv_amd/ may reference it,
+    except smoke_attack.py which exists only for __graft_entry__.smoke()."""
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geometric_adv_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) and f != "smoke_attack.py":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("oracle of record", ""), os.path.join(dirpath, f)
+
+
+def test_attack_model_gradient_matches_finite_differences():
+    """The numpy model's hand-written backward (Appendix A) against central differences, fp64."""
+    from geometric_adv_amd import weights as W
+    from oracle.attack_model import AEModel, AttackModel
+    from conftest import cloud
+    n, b = 64, 2
+    w = W.randomized_weights(n)
+    m = AEModel(W.canonical(w, n), n)
+    x, gt = cloud(1, b, n), cloud(2, b, n)
+    tz = m.encode(gt)
+    rng = np.random.default_rng(0)
+    for adv_t, dist_t in [("chamfer", "chamfer"), ("latent", "pert")]:
+        am = AttackModel(m, x, gt, tz, np.array([1.0, 3.0]), adv_t, dist_t)
+        am.init_pert(1e-2 * rng.standard_normal((b, n, 3)))
+        f = am.forward()
+        g = am.gradient(f)
+        d = rng.standard_normal(am.pert.shape)
+        eps = 1e-6
+        p0 = am.pert.copy()
+        vals = []
+        for sgn in (+1, -1):
+            am.pert = p0 + sgn * eps * d
+            fs = am.forward(idx_override=f["idx"])
+            vals.append((fs["loss_adv"] + am.w * fs["loss_dist"]).sum())
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        np.testing.assert_allclose((g * d).sum(), fd, rtol=2e-3)
