@@ -1,0 +1,278 @@
+// Grouping ops (external/grouping) for gfx950: QueryBallPoint, SelectionSort, GroupPoint(+Grad)
+// and the fused k-NN the defense uses (tf_grouping.py:48-75, defender/get_knn_dists_per_point.py:78-81).
+//
+// The reference materialises a dense (b,m,n) distance matrix plus two tiled (b,m,n,3) operands
+// (1.7 GB at b=100, n=2048) and then lets ONE THREAD per row run k passes of "find the first
+// minimum of [s,n), swap it into s" (tf_grouping_g.cu:83-123).  Here a wave owns a row: the row
+// lives in LDS (values + indices), distances are computed straight into it, and every pass is a
+// wave-wide lexicographic (value, position) arg-min followed by the same swap -- so the result,
+// including the reference's peculiar order among equal distances, is identical, and nothing of
+// size n*m ever touches HBM in the fused form.
+#include "common.h"
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+namespace geoadv {
+
+constexpr int ROW_MAX_N = 16384;          // a row (float + int per entry) must fit in LDS: 128 KB
+
+// k passes of the reference's partial selection sort on an LDS row.  val/idx: [n].  One wave.
+__device__ __forceinline__ void wave_selection_sort(float *val, int *idx, int n, int k) {
+    const int lane = threadIdx.x & 63;
+    for (int s = 0; s < k && s < n; ++s) {
+        // first minimum of positions [s, n): start with position s, replace only on strict '<'
+        // => lexicographic min of (value, position)
+        float bv = INFINITY;
+        int bp = 0x7fffffff;
+        for (int t = s + lane; t < n; t += 64) {
+            const float v = val[t];
+            if (v < bv) { bv = v; bp = t; }     // per lane ascending t: first min kept
+        }
+        // a lane whose values are all NaN / that saw nothing keeps (inf, maxint)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int op = __shfl_xor(bp, off);
+            if (ov < bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+        }
+        // (bv, bp) = the first position of [s, n) attaining the minimum, exactly what the reference's
+        // scan "min = s; if (p[t] < p[min]) min = t" finds; nothing comparable (all NaN) keeps s.
+        const int mn = bp == 0x7fffffff ? s : bp;
+        if (mn != s) {
+            if (lane == 0) {
+                const float tv = val[mn]; val[mn] = val[s]; val[s] = tv;
+                const int ti = idx[mn]; idx[mn] = idx[s]; idx[s] = ti;
+            }
+        }
+        __syncthreads();                          // block = one wave: orders the swap before the next pass
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SelectionSort op: dist (b,m,n) -> outi (b,m,n), out (b,m,n).  grid = rows, block = 64.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void selection_sort_kernel(int n, int k, size_t rows, const float *dist, int *outi,
+                                                            float *out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *val = lds;
+    int *idx = reinterpret_cast<int *>(lds + n);
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float *src = dist + row * n;
+        for (int t = threadIdx.x; t < n; t += 64) { val[t] = src[t]; idx[t] = t; }
+        __syncthreads();
+        wave_selection_sort(val, idx, n, k);
+        for (int t = threadIdx.x; t < n; t += 64) { out[row * n + t] = val[t]; outi[row * n + t] = idx[t]; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused knn_point: for query q of cloud c, row[p] = sum_c (xyz1[p,c]-xyz2[q,c])^2 (left to right,
+// tf_grouping.py:68), then the selection sort; val/idx (b,m,k).  grid = (query groups, b), block = 64.
+// MODE 0: write val/idx.  MODE 1 (defender): drop column 0 and write the euclidean distances to the
+// remaining k-1 neighbours, recomputed from the gathered points as the reference graph does
+// (get_knn_dists_per_point.py:79-81: grouped - centre, sqrt(reduce_sum(deltas**2))).
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void knn_kernel(int n, int m, int k, int qper, const float *xyz1, const float *xyz2,
+                                                 float *val_out, int *idx_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *val = lds;
+    int *idx = reinterpret_cast<int *>(lds + n);
+    const int c = blockIdx.y;
+    const float *data = xyz1 + (size_t)c * n * 3;
+    const float *qry = xyz2 + (size_t)c * m * 3;
+    const int q_end = min(m, (int)(blockIdx.x + 1) * qper);
+    for (int q = blockIdx.x * qper; q < q_end; ++q) {
+        const float qx = qry[3 * q], qy = qry[3 * q + 1], qz = qry[3 * q + 2];
+        for (int t = threadIdx.x; t < n; t += 64) {
+            const float dx = data[3 * t] - qx, dy = data[3 * t + 1] - qy, dz = data[3 * t + 2] - qz;
+            val[t] = (dx * dx + dy * dy) + dz * dz;
+            idx[t] = t;
+        }
+        __syncthreads();
+        wave_selection_sort(val, idx, n, k);
+        if (MODE == 0) {
+            for (int s = threadIdx.x; s < k; s += 64) {
+                val_out[((size_t)c * m + q) * k + s] = val[s];
+                idx_out[((size_t)c * m + q) * k + s] = idx[s];
+            }
+        } else {
+            for (int s = threadIdx.x; s + 1 < k; s += 64) {
+                const int nb = idx[s + 1];
+                const float dx = data[3 * nb] - qx, dy = data[3 * nb + 1] - qy, dz = data[3 * nb + 2] - qz;
+                val_out[((size_t)c * m + q) * (k - 1) + s] = sqrtf((dx * dx + dy * dy) + dz * dz);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// QueryBallPoint (tf_grouping_g.cu:3-36): the FIRST nsample dataset points with
+// max(sqrt(d2), 1e-20) < radius, padded with the first hit; pts_cnt = number found.
+// One wave per query: 64 candidates at a time, ballot + prefix count keep the ascending order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void query_ball_kernel(int n, int m, float radius, int nsample, const float *xyz1,
+                                                        const float *xyz2, int *idx, int *pts_cnt) {
+    const int c = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
+    const float *data = xyz1 + (size_t)c * n * 3;
+    const float *qp = xyz2 + ((size_t)c * m + q) * 3;
+    int *row = idx + ((size_t)c * m + q) * nsample;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    int cnt = 0, first = -1;
+    for (int t0 = 0; t0 < n && cnt < nsample; t0 += 64) {
+        const int t = t0 + lane;
+        bool hit = false;
+        if (t < n) {
+            const float dx = qx - data[3 * t], dy = qy - data[3 * t + 1], dz = qz - data[3 * t + 2];
+            float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+            d = d < 1e-20f ? 1e-20f : d;
+            hit = d < radius;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            const int before = __popcll(mask & ((1ull << lane) - 1ull));
+            if (first < 0) first = t0 + __ffsll((long long)mask) - 1;
+            if (hit && cnt + before < nsample) row[cnt + before] = t;
+            cnt += __popcll(mask);
+        }
+    }
+    cnt = cnt < nsample ? cnt : nsample;
+    if (first >= 0)
+        for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;   // pad with the first hit
+    if (pts_cnt && lane == 0) pts_cnt[(size_t)c * m + q] = cnt;
+}
+
+// GroupPoint gather (tf_grouping_g.cu:40-57): out[b,j,k,:] = points[b, idx[b,j,k], :]
+__global__ void group_point_kernel(int n, int cch, size_t per_cloud, size_t total, const float *points, const int *idx,
+                                   float *out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;    // over (b, j, k, channel)
+    if (e >= total) return;
+    const size_t entry = e / cch;
+    const int ch = (int)(e % cch);
+    const size_t cloud = entry / per_cloud;
+    out[e] = points[(cloud * n + idx[entry]) * cch + ch];
+}
+
+// GroupPointGrad (tf_grouping_g.cu:61-78) without float atomics: thread (point, channel) walks the
+// cloud's entries in ascending order -- the CPU twin's accumulation order
+// (test/query_ball_point.cpp:70-84) -- with the index list staged through LDS.
+__global__ __launch_bounds__(256) void group_point_grad_kernel(int n, int cch, int entries, const float *grad_out,
+                                                               const int *idx, float *grad_points) {
+    __shared__ int sidx[1024];
+    const int c = blockIdx.y;
+    const int pc = blockIdx.x * 256 + threadIdx.x;     // (point, channel) pair of this cloud
+    const int p = pc / cch, ch = pc % cch;
+    const bool live = pc < n * cch;
+    float acc = 0.f;
+    for (int e0 = 0; e0 < entries; e0 += 1024) {
+        const int cnt = min(1024, entries - e0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += 256) sidx[e] = idx[(size_t)c * entries + e0 + e];
+        __syncthreads();
+        if (live)
+            for (int e = 0; e < cnt; ++e)
+                if (sidx[e] == p) acc += grad_out[((size_t)c * entries + e0 + e) * cch + ch];
+    }
+    if (live) grad_points[((size_t)c * n + p) * cch + ch] = acc;
+}
+
+}  // namespace geoadv
+
+using namespace geoadv;
+
+static int row_lds_attr() {
+    static bool done = false;
+    if (done) return GEOADV_OK;
+    const int cap = ROW_MAX_N * 8;
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(selection_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    done = true;
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 0 && m >= 0, "selection_sort: negative dimension");
+    GA_REQUIRE(k > 0, "SelectionSort expects positive k");                         // tf_grouping.cpp:112-113
+    GA_REQUIRE(n <= ROW_MAX_N, "selection_sort: rows longer than %d are not supported (n=%d)", ROW_MAX_N, n);
+    const size_t rows = (size_t)b * m;
+    if (rows == 0 || n == 0) return GEOADV_OK;
+    GA_REQUIRE(dist && outi && out, "selection_sort: null pointer");
+    if (int rc = row_lds_attr()) return rc;
+    const unsigned grid = (unsigned)(rows < 65535u * 16u ? rows : 65535u * 16u);
+    selection_sort_kernel<<<grid, 64, (size_t)n * 8, as_stream(stream)>>>(n, k, rows, dist, outi, out);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+static int launch_knn(int mode, int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                      hipStream_t st) {
+    if (int rc = row_lds_attr()) return rc;
+    // enough workgroups to fill the chip, a few queries each to amortise the launch
+    int qper = 1;
+    while ((long)cdiv(m, qper) * b > 16384 && qper < 16) qper *= 2;
+    dim3 grid(cdiv(m, qper), b);
+    if (mode == 0) knn_kernel<0><<<grid, 64, (size_t)n * 8, st>>>(n, m, k, qper, xyz1, xyz2, val, idx);
+    else knn_kernel<1><<<grid, 64, (size_t)n * 8, st>>>(n, m, k, qper, xyz1, xyz2, val, idx);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                                void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 1 && m >= 0, "knn_point: bad dimensions (b=%d n=%d m=%d)", b, n, m);
+    GA_REQUIRE(k >= 1 && k <= n, "knn_point: k=%d must be in [1, n=%d]", k, n);
+    GA_REQUIRE(n <= ROW_MAX_N, "knn_point: more than %d dataset points per cloud are not supported (n=%d)", ROW_MAX_N, n);
+    GA_REQUIRE(b <= 65535, "knn_point: batch %d exceeds 65535", b);
+    if (b == 0 || m == 0) return GEOADV_OK;
+    GA_REQUIRE(xyz1 && xyz2 && val && idx, "knn_point: null pointer");
+    return launch_knn(0, b, n, m, k, xyz1, xyz2, val, idx, as_stream(stream));
+}
+
+extern "C" int geoadv_knn_dists(int b, int n, int k, const float *pc, float *out, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 2, "knn_dists: bad dimensions (b=%d n=%d)", b, n);
+    GA_REQUIRE(k >= 1 && k + 1 <= n, "knn_dists: k=%d must be in [1, n-1=%d]", k, n - 1);
+    GA_REQUIRE(n <= ROW_MAX_N, "knn_dists: more than %d points per cloud are not supported (n=%d)", ROW_MAX_N, n);
+    GA_REQUIRE(b <= 65535, "knn_dists: batch %d exceeds 65535", b);
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(pc && out, "knn_dists: null pointer");
+    return launch_knn(1, b, n, n, k + 1, pc, pc, out, nullptr, as_stream(stream));
+}
+
+extern "C" int geoadv_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                       const float *xyz2, int *idx, int *pts_cnt, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 0 && m >= 0, "query_ball_point: negative dimension");
+    GA_REQUIRE(radius > 0.f, "QueryBallPoint expects positive radius");           // tf_grouping.cpp:70-71
+    GA_REQUIRE(nsample > 0, "QueryBallPoint expects positive nsample");           // tf_grouping.cpp:73-74
+    GA_REQUIRE(b <= 65535, "query_ball_point: batch %d exceeds 65535", b);
+    if (b == 0 || m == 0) return GEOADV_OK;
+    GA_REQUIRE(xyz1 && xyz2 && idx, "query_ball_point: null pointer");
+    query_ball_kernel<<<dim3(m, b), 64, 0, as_stream(stream)>>>(n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
+                                  float *out, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 0 && nsample >= 0, "group_point: negative dimension");
+    const size_t per_cloud = (size_t)m * nsample, total = (size_t)b * per_cloud * c;
+    if (total == 0) return GEOADV_OK;
+    GA_REQUIRE(points && idx && out, "group_point: null pointer");
+    group_point_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(n, c, per_cloud, total, points, idx, out);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                                       float *grad_points, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 0 && nsample >= 0, "group_point_grad: negative dimension");
+    GA_REQUIRE(b <= 65535, "group_point_grad: batch %d exceeds 65535", b);
+    if ((size_t)b * n * c == 0) return GEOADV_OK;
+    GA_REQUIRE(grad_points && (m * nsample == 0 || (grad_out && idx)), "group_point_grad: null pointer");
+    group_point_grad_kernel<<<dim3(cdiv(n * c, 256), b), 256, 0, as_stream(stream)>>>(n, c, m * nsample, grad_out, idx, grad_points);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}

@@ -114,3 +114,94 @@ def microbench(which, iters=2000):
     st = _lib.lib().geoadv_microbench(int(which), int(iters), C.byref(ms), _lib.stream_handle())
     _lib.check(st, "microbench")
     return ms.value
+
+
+# ---------------------------------------------------------------------------------------------
+# external/grouping/tf_grouping.py
+# ---------------------------------------------------------------------------------------------
+def _call(name, *args):
+    st = getattr(_lib.lib(), name)(*args, _lib.stream_handle())
+    _lib.check(st, name.replace("geoadv_", ""))
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    """tf_grouping.py:8-20.  xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries ->
+    idx (b,m,nsample) int32 (first nsample points within radius, padded with the first hit),
+    pts_cnt (b,m) int32."""
+    xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "QueryBallPoint")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = torch.zeros((b, m, int(nsample)), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.zeros((b, m), dtype=torch.int32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _call("geoadv_query_ball_point", b, n, m, C.c_float(radius), int(nsample), _lib.ptr(xyz1), _lib.ptr(xyz2),
+              _lib.ptr(idx), _lib.ptr(cnt))
+    return idx, cnt
+
+
+def select_top_k(k, dist):
+    """tf_grouping.py:22-31.  dist (b,m,n) -> idx (b,m,n) int32, dist_out (b,m,n); the first k
+    entries of every row are the k smallest in ascending order (the reference's swap order)."""
+    dist = _f32(dist, "dist", 3)
+    b, m, n = dist.shape
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty_like(dist)
+    with torch.cuda.device(dist.device):
+        _call("geoadv_selection_sort", b, n, m, int(k), _lib.ptr(dist), _lib.ptr(outi), _lib.ptr(out))
+    return outi, out
+
+
+def group_point(points, idx):
+    """tf_grouping.py:33-41.  points (b,n,c), idx (b,m,nsample) -> out (b,m,nsample,c)."""
+    points = _f32(points, "points", 3)
+    b, n, c = points.shape
+    if idx.dim() != 3 or idx.shape[0] != b:
+        raise ValueError("GroupPoint expects idx of shape (batch, npoint, nsample)")
+    idx = _i32(idx, "idx", idx.shape)
+    m, ns = idx.shape[1], idx.shape[2]
+    out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _call("geoadv_group_point", b, n, c, m, ns, _lib.ptr(points), _lib.ptr(idx), _lib.ptr(out))
+    return out
+
+
+def group_point_grad(points, idx, grad_out):
+    """The GroupPointGrad op behind tf_grouping.py:42-46 -> grad_points (b,n,c)."""
+    points = _f32(points, "points", 3)
+    b, n, c = points.shape
+    idx = _i32(idx, "idx", idx.shape)
+    m, ns = idx.shape[1], idx.shape[2]
+    grad_out = _f32(grad_out, "grad_out", 4)
+    if tuple(grad_out.shape) != (b, m, ns, c):
+        raise ValueError("GroupPointGrad expects grad_out of shape (batch, npoint, nsample, channel)")
+    gp = torch.empty_like(points)
+    with torch.cuda.device(points.device):
+        _call("geoadv_group_point_grad", b, n, c, m, ns, _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(gp))
+    return gp
+
+
+def knn_point(k, xyz1, xyz2):
+    """tf_grouping.py:48-75.  xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries -> val (b,m,k) squared
+    distances ascending, idx (b,m,k) int32 -- fused (no (b,m,n) matrix), same order among equal
+    distances as the reference's SelectionSort."""
+    xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "knn_point")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    val = torch.empty((b, m, int(k)), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, m, int(k)), dtype=torch.int32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _call("geoadv_knn_point", b, n, m, int(k), _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(val), _lib.ptr(idx))
+    return val, idx
+
+
+def knn_dists(pc, num_knn):
+    """The graph of defender/get_knn_dists_per_point.py:78-81 fused: distances (not squared) from
+    every point to its num_knn nearest neighbours, self dropped.  pc (b,n,3) -> (b,n,num_knn)."""
+    pc = _f32(pc, "pc", 3)
+    if pc.shape[2] != 3:
+        raise ValueError("knn_dists only accepts 3d point sets")
+    b, n, _ = pc.shape
+    out = torch.empty((b, n, int(num_knn)), dtype=torch.float32, device=pc.device)
+    with torch.cuda.device(pc.device):
+        _call("geoadv_knn_dists", b, n, int(num_knn), _lib.ptr(pc), _lib.ptr(out))
+    return out

@@ -1,0 +1,120 @@
+"""GPU parity of the grouping ops against the golden vectors (reference CPU twins) and the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def test_selection_sort_golden(golden_grouping):
+    from geometric_adv_amd import ops
+    g = golden_grouping
+    for name in ["kat", "rnd", "tie", "full", "swap"]:
+        k = int(g[f"{name}_k"])
+        idx, val = ops.select_top_k(k, _t(g[f"{name}_dist"]))
+        assert np.array_equal(idx.cpu().numpy(), g[f"{name}_idx"]), name      # ALL n entries, not just the first k
+        assert np.array_equal(val.cpu().numpy(), g[f"{name}_val"]), name
+
+
+def test_query_ball_and_group_point_golden(golden_grouping):
+    from geometric_adv_amd import ops
+    g = golden_grouping
+    idx, cnt = ops.query_ball_point(float(g["qb_radius"]), int(g["qb_nsample"]), _t(g["qb_xyz1"]), _t(g["qb_xyz2"]))
+    assert np.array_equal(idx.cpu().numpy(), g["qb_idx"])
+    out = ops.group_point(_t(g["gp_points"]), _t(g["qb_idx"]))
+    assert np.array_equal(out.cpu().numpy(), g["gp_out"])
+    gp = ops.group_point_grad(_t(g["gp_points"]), _t(g["qb_idx"]), _t(g["gp_grad_out"]))
+    assert np.array_equal(gp.cpu().numpy(), g["gp_grad_points"])            # same accumulation order => same bits
+
+
+def test_query_ball_vs_oracle_sparse_hits(oracle):
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x1, x2 = cloud(1, 3, 300) + 0.5, cloud(2, 3, 50) + 0.5
+    for radius, ns in [(0.05, 4), (0.2, 16), (2.0, 7)]:
+        want_idx, want_cnt = oracle.query_ball_point(radius, ns, x1, x2)
+        idx, cnt = ops.query_ball_point(radius, ns, _t(x1), _t(x2))
+        cnt = cnt.cpu().numpy()
+        assert np.array_equal(cnt, want_cnt)
+        hit = want_cnt > 0                                                  # rows without any hit are left untouched by both
+        assert np.array_equal(idx.cpu().numpy()[hit], want_idx[hit])
+
+
+@pytest.mark.parametrize("b,n,m,k", [(2, 200, 77, 9), (1, 2048, 64, 9), (3, 64, 64, 64), (2, 500, 10, 1)])
+def test_knn_point_vs_oracle(oracle, b, n, m, k):
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x1, x2 = cloud(10 + n, b, n), cloud(20 + m, b, m)
+    want_val, want_idx = oracle.knn_point(k, x1, x2)
+    val, idx = ops.knn_point(k, _t(x1), _t(x2))
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert np.array_equal(val.cpu().numpy(), want_val)
+
+
+def test_knn_point_exact_ties_follow_the_swap_rule(oracle):
+    """Lattice clouds: many exactly equal distances; the order among them is the reference's."""
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(3)
+    x = (rng.integers(-2, 3, size=(2, 150, 3)) * 0.25).astype(np.float32)
+    want_val, want_idx = oracle.knn_point(9, x, x)
+    val, idx = ops.knn_point(9, _t(x), _t(x))
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert np.array_equal(val.cpu().numpy(), want_val)
+
+
+def test_knn_dists_vs_oracle_and_defense(oracle):
+    from geometric_adv_amd import ops, weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.defense import defend_surface, get_outlier_pc_inlier_pc
+    from conftest import cloud
+    n = 256
+    pc = cloud(5, 6, n)
+    got = ops.knn_dists(_t(pc), 8).cpu().numpy()
+    assert np.array_equal(got, oracle.knn_dists(pc, 8))
+    # a defended cloud: push 10 points far off the surface -> they are the outliers
+    adv = pc.copy()
+    adv[:, :10] += 3.0 * (np.arange(10, dtype=np.float32)[None, :, None] + 1)      # each far from everything else
+    ae = PointNetAE(W.synthetic_weights(n), n)
+    out = defend_surface(ae, adv, pc, knn_dist_thresh=0.5)
+    assert (out["outlier_num"] == 10).all()
+    assert np.array_equal(out["outlier_idx"][:, :10], np.tile(np.arange(10, dtype=np.int16), (6, 1)))
+    assert np.array_equal(out["defended_pc"][:, :n - 10], adv[:, 10:])
+    assert np.array_equal(out["defended_pc"][:, n - 10:], np.repeat(adv[:, -1:], 10, axis=1))   # last inlier duplicated
+    assert out["recon_error_vs_source"].shape == (6,)
+    # host-side packing against a direct restatement on one cloud
+    score = out["knn_dists"][:, :, :2].mean(2)
+    _, _, _, inl = get_outlier_pc_inlier_pc(adv, score, 0.5)
+    assert np.array_equal(inl, out["defended_pc"])
+
+
+def test_knn_full_size_properties():
+    """Config-3 size (n = 2048): properties instead of a CPU re-run -- the self distance is 0 and
+    comes first, columns ascend, and the result is invariant to where in the batch a cloud sits."""
+    import torch
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    pc = _t(cloud(9, 16, 2048))
+    val, idx = ops.knn_point(9, pc, pc)
+    ar = torch.arange(2048, device="cuda:0", dtype=torch.int32).expand(16, -1)
+    assert torch.equal(idx[:, :, 0], ar) and not val[:, :, 0].any()
+    assert (val[:, :, 1:] >= val[:, :, :-1]).all()
+    v2, i2 = ops.knn_point(9, pc[3:5].contiguous(), pc[3:5].contiguous())
+    assert torch.equal(v2, val[3:5]) and torch.equal(i2, idx[3:5])
+    d = ops.knn_dists(pc, 8)
+    torch.testing.assert_close(d, val[:, :, 1:].sqrt(), rtol=1e-6, atol=0)
+
+
+def test_grouping_argument_errors():
+    import torch
+    from geometric_adv_amd import ops
+    x = torch.rand((2, 10, 3), device="cuda:0")
+    with pytest.raises(ValueError):
+        ops.query_ball_point(-1.0, 4, x, x)
+    with pytest.raises(ValueError):
+        ops.select_top_k(0, torch.rand((2, 3, 5), device="cuda:0"))
+    with pytest.raises(ValueError):
+        ops.knn_point(11, x, x)
