@@ -205,3 +205,72 @@ def knn_dists(pc, num_knn):
     with torch.cuda.device(pc.device):
         _call("geoadv_knn_dists", b, n, int(num_knn), _lib.ptr(pc), _lib.ptr(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# external/structural_losses/tf_approxmatch.py
+# ---------------------------------------------------------------------------------------------
+def approx_match(xyz1, xyz2):
+    """tf_approxmatch.py:10-18.  xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n): match[b,l,k] is the
+    soft assignment between xyz2 point l and xyz1 point k (the reference GPU op's layout; the CPU
+    op writes the transpose into the same declared shape).  Level schedule of the CPU op."""
+    xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "ApproxMatch")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    match = torch.empty((b, m, n), dtype=torch.float32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        nf = _lib.lib().geoadv_approx_match_temp_floats(b, n, m)
+        temp = torch.empty(int(nf), dtype=torch.float32, device=xyz1.device)
+        _call("geoadv_approx_match", b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(temp))
+    return match
+
+
+def _match_args(xyz1, xyz2, match, op):
+    xyz1, xyz2 = _xyz_pair(xyz1, xyz2, op)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    match = _f32(match, "match", 3)
+    if tuple(match.shape) != (b, m, n):
+        raise ValueError("%s expects (batch_size,#query,#dataset) match shape" % op)      # tf_approxmatch.cpp
+    return xyz1, xyz2, match, b, n, m
+
+
+def match_cost(xyz1, xyz2, match):
+    """tf_approxmatch.py:21-32 -> cost (b,): sum over pairs of match * euclidean distance."""
+    xyz1, xyz2, match, b, n, m = _match_args(xyz1, xyz2, match, "MatchCost")
+    cost = torch.empty((b,), dtype=torch.float32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _call("geoadv_match_cost", b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(cost))
+    return cost
+
+
+def match_cost_grad(xyz1, xyz2, match):
+    """The MatchCostGrad op behind tf_approxmatch.py:38-50 -> (grad1 (b,n,3), grad2 (b,m,3)),
+    before the scaling by the upstream grad_cost[b]."""
+    xyz1, xyz2, match, b, n, m = _match_args(xyz1, xyz2, match, "MatchCostGrad")
+    g1 = torch.empty_like(xyz1)
+    g2 = torch.empty_like(xyz2)
+    with torch.cuda.device(xyz1.device):
+        _call("geoadv_match_cost_grad", b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(g1), _lib.ptr(g2))
+    return g1, g2
+
+
+class _MatchCostFn(torch.autograd.Function):
+    """@tf.RegisterGradient('MatchCost') (tf_approxmatch.py:38-50): grads scaled by grad_cost[b],
+    no gradient w.r.t. match (ApproxMatch is registered NoGradient, :19)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, match):
+        ctx.save_for_backward(xyz1, xyz2, match)
+        return match_cost(xyz1, xyz2, match)
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        xyz1, xyz2, match = ctx.saved_tensors
+        g1, g2 = match_cost_grad(xyz1, xyz2, match)
+        gc = grad_cost.reshape(-1, 1, 1)
+        return g1 * gc, g2 * gc, None
+
+
+def match_cost_autograd(xyz1, xyz2, match):
+    return _MatchCostFn.apply(xyz1, xyz2, match)

@@ -1,0 +1,85 @@
+"""GPU parity of approx-EMD against the golden vectors (reference CPU functions,
+tf_approxmatch.cpp:23-140).  Tolerances: the GPU path uses the CPU op's level schedule and double
+bookkeeping; the only arithmetic differences are the device expf (<= 1-2 ulp vs glibc) and the
+factorised normalisation, so match agrees to ~1e-6 (the reference's own CPU-vs-GPU check allows
+1e-2, approxmatch.cpp:222)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def test_approx_match_and_cost_golden(golden_emd):
+    from geometric_adv_amd import ops
+    g = golden_emd
+    for name in g["cases"]:
+        x1, x2 = g[f"{name}_xyz1"], g[f"{name}_xyz2"]
+        want = g[f"{name}_match_nm"]                                    # CPU layout (b, n, m)
+        match = ops.approx_match(_t(x1), _t(x2))                        # (b, m, n)
+        got = match.cpu().numpy().transpose(0, 2, 1)
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=name)
+        cost = ops.match_cost(_t(x1), _t(x2), match).cpu().numpy()
+        np.testing.assert_allclose(cost, g[f"{name}_cost"], rtol=1e-5, err_msg=name)
+        # cost / grad kernels in isolation: feed them the REFERENCE's match
+        mref = _t(np.ascontiguousarray(want.transpose(0, 2, 1)))
+        cost = ops.match_cost(_t(x1), _t(x2), mref).cpu().numpy()
+        np.testing.assert_allclose(cost, g[f"{name}_cost"], rtol=2e-7, err_msg=name)
+        g1, g2 = ops.match_cost_grad(_t(x1), _t(x2), mref)
+        assert np.array_equal(g1.cpu().numpy(), g[f"{name}_grad1"]), name          # same order => same bits
+        np.testing.assert_allclose(g2.cpu().numpy(), g[f"{name}_grad2"], rtol=1e-5, atol=1e-6, err_msg=name)
+
+
+def test_approx_match_vs_oracle_medium(oracle):
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x1, x2 = cloud(1, 2, 512), cloud(2, 2, 384)
+    want = oracle.approx_match(x1, x2)
+    got = ops.approx_match(_t(x1), _t(x2)).cpu().numpy().transpose(0, 2, 1)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_approx_match_is_a_transport_plan_full_size():
+    """n = m = 2048: properties instead of a CPU re-run (the CPU op needs minutes per cloud)."""
+    import torch
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x1, x2 = _t(cloud(3, 2, 2048)), _t(cloud(4, 2, 2048))
+    match = ops.approx_match(x1, x2).double()
+    assert (match >= 0).all()
+    assert (match.sum(1) <= 1 + 1e-4).all() and (match.sum(2) <= 1 + 1e-4).all()
+    torch.testing.assert_close(match.sum((1, 2)), torch.full((2,), 2048.0, dtype=torch.float64, device="cuda:0"), rtol=2e-2, atol=0)
+    # identical clouds: the plan is (close to) the identity and the cost (close to) zero
+    m2 = ops.approx_match(x1, x1)
+    diag = torch.diagonal(m2, dim1=1, dim2=2)              # a few near-coincident pairs legitimately share mass
+    assert (diag > 0.45).all() and diag.mean() > 0.99
+    assert (ops.match_cost(x1, x1, m2) < 1e-2).all()
+
+
+def test_match_cost_autograd_scales_by_upstream(golden_emd):
+    import torch
+    from geometric_adv_amd import ops
+    g = golden_emd
+    x1 = _t(g["a_xyz1"]).requires_grad_(True)
+    x2 = _t(g["a_xyz2"]).requires_grad_(True)
+    match = ops.approx_match(x1.detach(), x2.detach())
+    cost = ops.match_cost_autograd(x1, x2, match)
+    up = torch.tensor([2.0, -0.5], device="cuda:0")
+    (cost * up).sum().backward()
+    g1, g2 = ops.match_cost_grad(x1.detach(), x2.detach(), match)
+    torch.testing.assert_close(x1.grad, g1 * up.view(-1, 1, 1))
+    torch.testing.assert_close(x2.grad, g2 * up.view(-1, 1, 1))
+
+
+def test_emd_argument_errors():
+    import torch
+    from geometric_adv_amd import ops
+    x = torch.rand((2, 10, 3), device="cuda:0")
+    with pytest.raises(ValueError):
+        ops.match_cost(x, x, torch.rand((2, 10, 9), device="cuda:0"))
+    with pytest.raises(ValueError):
+        ops.approx_match(x, torch.rand((3, 10, 3), device="cuda:0"))
