@@ -5,7 +5,6 @@
 namespace geoadv {
 
 constexpr int ENC_L = GEOADV_ENC_LAYERS;   // 5 per-point layers
-constexpr int ENC_ROWS = 64;               // points per workgroup tile
 
 // Packed weight fragments for v_mfma_f32_32x32x2_f32.  For a layer computing out[r][n] =
 // sum_k in[r][k] * W[k][n] (K = fan-in, a multiple of 8; N padded to a multiple of 32):

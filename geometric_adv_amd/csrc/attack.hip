@@ -57,65 +57,85 @@ struct LossArgs {
     float *best_adv, *best_recon;     // [B][n][3]
 };
 
-__device__ __forceinline__ float block_sum(float v, float *sh) {
-    const int t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (t < s) sh[t] += sh[t + s];
-        __syncthreads();
-    }
-    const float r = sh[0];
-    __syncthreads();
-    return r;
+// One pass for everything: 5 sums and 2 (max, lowest index) pairs per thread, reduced across the
+// wave with shuffles and across the 4 waves through LDS -- two barriers instead of ~60.
+struct CloudRed { float s1, s2, s3, s4, sp, ma, mp; int ja, jp; };
+
+__device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
-// max with the lowest index on ties
-__device__ __forceinline__ void block_argmax(float &v, int &i, float *sh, int *shi) {
-    const int t = threadIdx.x;
-    sh[t] = v; shi[t] = i;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (t < s) {
-            const float o = sh[t + s]; const int oi = shi[t + s];
-            if (o > sh[t] || (o == sh[t] && oi < shi[t])) { sh[t] = o; shi[t] = oi; }
-        }
-        __syncthreads();
+
+__device__ __forceinline__ CloudRed block_reduce(CloudRed r, float (*shf)[8], int (*shi)[2]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r.s1 += __shfl_xor(r.s1, off); r.s2 += __shfl_xor(r.s2, off); r.s3 += __shfl_xor(r.s3, off);
+        r.s4 += __shfl_xor(r.s4, off); r.sp += __shfl_xor(r.sp, off);
+        argmax_merge(r.ma, r.ja, __shfl_xor(r.ma, off), __shfl_xor(r.ja, off));
+        argmax_merge(r.mp, r.jp, __shfl_xor(r.mp, off), __shfl_xor(r.jp, off));
     }
-    v = sh[0]; i = shi[0];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        shf[wave][0] = r.s1; shf[wave][1] = r.s2; shf[wave][2] = r.s3; shf[wave][3] = r.s4; shf[wave][4] = r.sp;
+        shf[wave][5] = r.ma; shf[wave][6] = r.mp; shi[wave][0] = r.ja; shi[wave][1] = r.jp;
+    }
     __syncthreads();
+    CloudRed t;
+    t.s1 = ((shf[0][0] + shf[1][0]) + shf[2][0]) + shf[3][0];
+    t.s2 = ((shf[0][1] + shf[1][1]) + shf[2][1]) + shf[3][1];
+    t.s3 = ((shf[0][2] + shf[1][2]) + shf[2][2]) + shf[3][2];
+    t.s4 = ((shf[0][3] + shf[1][3]) + shf[2][3]) + shf[3][3];
+    t.sp = ((shf[0][4] + shf[1][4]) + shf[2][4]) + shf[3][4];
+    t.ma = shf[0][5]; t.ja = shi[0][0]; t.mp = shf[0][6]; t.jp = shi[0][1];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        argmax_merge(t.ma, t.ja, shf[w][5], shi[w][0]);
+        argmax_merge(t.mp, t.jp, shf[w][6], shi[w][1]);
+    }
+    return t;
+}
+
+__device__ __forceinline__ float wave4_sum128(float v, float *sh2) {   // sum over threads 0..127 (others pass 0)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) sh2[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh2[0] + sh2[1];
 }
 
 __global__ __launch_bounds__(256) void loss_metrics_kernel(LossArgs a) {
-    __shared__ float sh[256];
-    __shared__ int shi[256];
+    __shared__ float shf[4][8];
+    __shared__ int shi[4][2];
+    __shared__ float sh2[4];
     __shared__ int take;
     const int b = blockIdx.x, t = threadIdx.x, n = a.n, B = gridDim.x;
     const size_t o = (size_t)b * n;
-    float s1 = 0, s2 = 0, s3 = 0, s4 = 0, sp = 0;
-    float ma = -1.f, mp = -1.f;
-    int ja = INT_MAX, jp = INT_MAX;
+    CloudRed r;
+    r.s1 = r.s2 = r.s3 = r.s4 = r.sp = 0.f;
+    r.ma = r.mp = -1.f;
+    r.ja = r.jp = INT_MAX;
     for (int j = t; j < n; j += 256) {
-        s1 += a.r1[o + j]; s2 += a.r2[o + j];
+        r.s1 += a.r1[o + j]; r.s2 += a.r2[o + j];
         const float d = a.a1[o + j];
-        s3 += d; s4 += a.a2[o + j];
-        if (d > ma) { ma = d; ja = j; }
+        r.s3 += d; r.s4 += a.a2[o + j];
+        if (d > r.ma) { r.ma = d; r.ja = j; }
         const float px = a.pert[(o + j) * 3], py = a.pert[(o + j) * 3 + 1], pz = a.pert[(o + j) * 3 + 2];
         const float p2 = (px * px + py * py) + pz * pz;
-        sp += p2;
-        if (p2 > mp) { mp = p2; jp = j; }
+        r.sp += p2;
+        if (p2 > r.mp) { r.mp = p2; r.jp = j; }
     }
+    r = block_reduce(r, shf, shi);
+    float ma = r.ma, mp = r.mp;
+    const int ja = r.ja, jp = r.jp;
     const float inv_n = 1.0f / (float)n;
-    const float loss_ae = block_sum(s1, sh) * inv_n + block_sum(s2, sh) * inv_n;      // adv_ae.py:121
-    const float input_dist = block_sum(s3, sh) * inv_n + block_sum(s4, sh) * inv_n;   // adv_ae.py:132
-    const float pert_sq = block_sum(sp, sh);
-    block_argmax(ma, ja, sh, shi);                                                     // adv_ae.py:133
-    block_argmax(mp, jp, sh, shi);                                                     // adversary.py:44
+    const float loss_ae = r.s1 * inv_n + r.s2 * inv_n;                                 // adv_ae.py:121
+    const float input_dist = r.s3 * inv_n + r.s4 * inv_n;                              // adv_ae.py:132, max :133
+    const float pert_sq = r.sp;                                                        // adversary.py:41-44
     const float loss_pert = sqrtf(pert_sq), loss_max = sqrtf(mp);                      // adversary.py:47,50
     float loss_adv = loss_ae;
     if (a.loss_adv_type == GEOADV_LOSS_ADV_LATENT) {                                   // adv_ae.py:107-116
         float d = 0.f;
         if (t < 128) { d = a.z[(size_t)b * 128 + t] - a.tz[(size_t)b * 128 + t]; }
-        const float nsq = block_sum(d * d, sh);
+        const float nsq = wave4_sum128(d * d, sh2);
         loss_adv = sqrtf(nsq);
         if (t < 128) a.dz_latent[(size_t)b * 128 + t] = d / loss_adv;
     }

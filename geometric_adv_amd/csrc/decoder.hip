@@ -11,32 +11,72 @@
 
 namespace geoadv {
 
+int encoder_tiles(int n);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int acc_row16(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------------------------------
-// Pool reduce + FC0 + FC1.  grid = clouds, 256 threads.
+// Pool reduce + FC0 + FC1.  grid = clouds, 1024 threads (the work per cloud is tiny, so it is
+// spread over 16 waves and every thread issues all its loads before it starts summing).
 //   z[b][c]     = max over tiles (encoders_decoders.py:72: reduce_max over the point axis)
 //   crit[b][c]  = lowest point index attaining it; zcnt[b][c] = number of points attaining it
 //   dense[b]    = 1 if some channel has a positive maximum attained more than once (exact tie)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void latent_decode_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
-                                                            const int *pcnt, float *z, int *crit, int *zcnt,
-                                                            int *dense, float *d1, float *d2) {
+constexpr int LD_THREADS = 1024;
+
+// out[o] (o < 256) = sum_k in[k] * Wt[k][256 + ...]: K split over 4 thread groups, partials in LDS,
+// summed in a fixed order by the first 256 threads.
+template <int K>
+__device__ __forceinline__ float fc256_split4(const float *in_lds, const float *W /*[K][256]*/, float (*part)[256]) {
+    const int t = threadIdx.x, o = t & 255, ks = t >> 8;
+    constexpr int PER = K / 4;
+    float w[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) w[k] = W[(size_t)(ks * PER + k) * 256 + o];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) s = fmaf(in_lds[ks * PER + k], w[k], s);
+    part[ks][o] = s;
+    __syncthreads();
+    return ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];     // meaningful for t < 256
+}
+
+__global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
+                                                                   const int *pcnt, float *z, int *crit, int *zcnt,
+                                                                   int *dense, float *d1, float *d2) {
+    __shared__ float gm[8][128];
+    __shared__ int ga[8][128], gk[8][128];
     __shared__ float zs[128];
     __shared__ float hs[256];
+    __shared__ float part[4][256];
     __shared__ int tie;
     const int b = blockIdx.x, t = threadIdx.x;
     if (t == 0) tie = 0;
-    __syncthreads();
-    if (t < 128) {
+    {   // 8 contiguous tile groups x 128 channels; ascending tiles inside a group, groups merged in order
+        const int c = t & 127, g = t >> 7;
+        const int tb = tiles * g / 8, te = tiles * (g + 1) / 8;
         float m = -1.f;
         int a = INT_MAX, k = 0;
-        for (int tl = 0; tl < tiles; ++tl) {
-            const size_t o = ((size_t)b * tiles + tl) * 128 + t;
+#pragma unroll 4
+        for (int tl = tb; tl < te; ++tl) {
+            const size_t o = ((size_t)b * tiles + tl) * 128 + c;
             const float pm = pmax[o];
-            if (pm > m) { m = pm; a = parg[o]; k = pcnt[o]; }
-            else if (pm == m) k += pcnt[o];
+            const int pa = parg[o], pk = pcnt[o];
+            if (pm > m) { m = pm; a = pa; k = pk; }
+            else if (pm == m) k += pk;
+        }
+        gm[g][c] = m; ga[g][c] = a; gk[g][c] = k;
+    }
+    __syncthreads();
+    if (t < 128) {
+        float m = gm[0][t];
+        int a = ga[0][t], k = gk[0][t];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) {
+            const float pm = gm[g][t];
+            if (pm > m) { m = pm; a = ga[g][t]; k = gk[g][t]; }
+            else if (pm == m) k += gk[g][t];
         }
         zs[t] = m;
         z[(size_t)b * 128 + t] = m;
@@ -48,18 +88,17 @@ __global__ __launch_bounds__(256) void latent_decode_kernel(DeviceAE A, int tile
     if (t == 0) dense[b] = tie;
     if (!d1) return;
     {   // FC0 + ReLU: 128 -> 256
-        float s = 0.f;
-        for (int k = 0; k < 128; ++k) s = fmaf(zs[k], A.v0[k * 256 + t], s);
-        s = fmaxf(s + A.c0[t], 0.f);
-        hs[t] = s;
-        d1[(size_t)b * 256 + t] = s;
+        const float s = fc256_split4<128>(zs, A.v0, part);
+        if (t < 256) {
+            const float v = fmaxf(s + A.c0[t], 0.f);
+            hs[t] = v;
+            d1[(size_t)b * 256 + t] = v;
+        }
     }
     __syncthreads();
     {   // FC1 + ReLU: 256 -> 256
-        float s = 0.f;
-        for (int k = 0; k < 256; ++k) s = fmaf(hs[k], A.v1[k * 256 + t], s);
-        s = fmaxf(s + A.c1[t], 0.f);
-        d2[(size_t)b * 256 + t] = s;
+        const float s = fc256_split4<256>(hs, A.v1, part);
+        if (t < 256) d2[(size_t)b * 256 + t] = fmaxf(s + A.c1[t], 0.f);
     }
 }
 
@@ -80,14 +119,22 @@ __global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch,
     const float *ap = d2 + (size_t)arow * 256 + 4 * h;
     const float4 *bp = reinterpret_cast<const float4 *>(L.w) + (size_t)cb * kg * 64 + lane;
     f32x16 acc = {};
-#pragma unroll 2
-    for (int t = wave * per; t < (wave + 1) * per; ++t) {
-        const float4 a = *reinterpret_cast<const float4 *>(ap + 8 * t);
-        const float4 w = bp[(size_t)t * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+    // K = 256 = 32 k-groups, 8 per wave: request all 16 operand fragments first, then run the MFMAs
+    float4 av[8], wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int t = wave * per + (u < per ? u : per - 1);
+        av[u] = *reinterpret_cast<const float4 *>(ap + 8 * t);
+        wv[u] = bp[(size_t)t * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u < per) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, wv[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, wv[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, wv[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, wv[u].w, acc, 0, 0, 0);
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -111,7 +158,7 @@ __global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch,
 // FC2 backward: partial[ch][b][256] = g_out[b][k-chunk] @ V2^T.  grid = (k chunks of 128, row
 // blocks of 32), 512 threads = 8 waves = the 8 column blocks of the 256 outputs.
 // ------------------------------------------------------------------------------------------
-constexpr int DB_KC = 128;
+constexpr int DB_KC = 64;
 
 __global__ __launch_bounds__(512) void decoder_fc2_bwd_kernel(DeviceAE A, int batch, const float *g_out, float *partial) {
     __shared__ __attribute__((aligned(16))) float as[32 * (DB_KC + 4)];
@@ -134,13 +181,19 @@ __global__ __launch_bounds__(512) void decoder_fc2_bwd_kernel(DeviceAE A, int ba
     const float4 *bp = reinterpret_cast<const float4 *>(L.w) + ((size_t)cb * kg_total + t0) * 64 + lane;
     const float *ap = as + i * (DB_KC + 4) + 4 * h;
     f32x16 acc = {};
-    for (int t = 0; t < nt; ++t) {
-        const float4 a = *reinterpret_cast<const float4 *>(ap + 8 * t);
-        const float4 w = bp[(size_t)t * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+    constexpr int NT = DB_KC >> 3;              // 8 k-groups: all B fragments requested up front (issued before the
+    float4 wv[NT];                              // barrier above would be even better; they do not depend on LDS)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wv[t] = bp[(size_t)(t < nt ? t : nt - 1) * 64];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < nt) {
+            const float4 a = *reinterpret_cast<const float4 *>(ap + 8 * t);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[t].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[t].w, acc, 0, 0, 0);
+        }
     }
     const int col = cb * 32 + i;
 #pragma unroll
@@ -151,31 +204,55 @@ __global__ __launch_bounds__(512) void decoder_fc2_bwd_kernel(DeviceAE A, int ba
 }
 
 // dd2 = sum of partials, masked by d2 > 0; dd1 = dd2 @ V1^T masked by d1 > 0; dz = dd1 @ V0^T.
-// grid = clouds, 256 threads.  TF ReluGrad masks by the layer OUTPUT being > 0.
-__global__ __launch_bounds__(256) void decoder_bwd_tail_kernel(DeviceAE A, int batch, int chunks, const float *partial,
-                                                               const float *d1, const float *d2, float *dz) {
+// grid = clouds, 1024 threads.  TF ReluGrad masks by the layer OUTPUT being > 0.
+__global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A, int batch, int chunks, const float *partial,
+                                                                     const float *d1, const float *d2, float *dz) {
     __shared__ float g2[256];
     __shared__ float g1[256];
-    const int b = blockIdx.x, t = threadIdx.x;
-    float s = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) s += partial[((size_t)ch * batch + b) * 256 + t];
-    g2[t] = d2[(size_t)b * 256 + t] > 0.f ? s : 0.f;
+    __shared__ float part[8][256];
+    const int b = blockIdx.x, t = threadIdx.x, o = t & 255, ks = t >> 8;
+    {   // split-K partials: 4 contiguous chunk groups, ascending inside, merged in order
+        const int cb = chunks * ks / 4, ce = chunks * (ks + 1) / 4;
+        float s = 0.f;
+#pragma unroll 8
+        for (int ch = cb; ch < ce; ++ch) s += partial[((size_t)ch * batch + b) * 256 + o];
+        part[ks][o] = s;
+    }
     __syncthreads();
-    s = 0.f;
-    for (int k = 0; k < 256; ++k) s = fmaf(g2[k], A.v1t[k * 256 + t], s);
-    g1[t] = d1[(size_t)b * 256 + t] > 0.f ? s : 0.f;
+    if (t < 256) {
+        const float s = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+        g2[t] = d2[(size_t)b * 256 + t] > 0.f ? s : 0.f;
+    }
     __syncthreads();
-    if (t < 128) {
-        s = 0.f;
-        for (int k = 0; k < 256; ++k) s = fmaf(g1[k], A.v0t[k * 128 + t], s);
-        dz[(size_t)b * 128 + t] = s;
+    {
+        const float s = fc256_split4<256>(g2, A.v1t, part);
+        __syncthreads();
+        if (t < 256) g1[t] = d1[(size_t)b * 256 + t] > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    {   // dz: 128 outputs x 8 K-slices of 32
+        const int c = t & 127, k8 = t >> 7;
+        float w[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) w[k] = A.v0t[(size_t)(k8 * 32 + k) * 128 + c];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s = fmaf(g1[k8 * 32 + k], w[k], s);
+        part[k8][c] = s;
+        __syncthreads();
+        if (t < 128) {
+            float r = part[0][t];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) r += part[q][t];
+            dz[(size_t)b * 128 + t] = r;
+        }
     }
 }
 
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
-    latent_decode_kernel<<<b, 256, 0, stream>>>(A, cdiv(A.n_points, ENC_ROWS), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
+    latent_decode_kernel<<<b, LD_THREADS, 0, stream>>>(A, encoder_tiles(A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -195,7 +272,7 @@ int launch_decoder_bwd(const DeviceAE &A, int b, const float *g_recon, const flo
     const int chunks = decoder_bwd_chunks(A);
     decoder_fc2_bwd_kernel<<<dim3(chunks, cdiv(b, 32)), 512, 0, stream>>>(A, b, g_recon, partial);
     GA_LAUNCH_CHECK();
-    decoder_bwd_tail_kernel<<<b, 256, 0, stream>>>(A, b, chunks, partial, d1, d2, dz);
+    decoder_bwd_tail_kernel<<<b, LD_THREADS, 0, stream>>>(A, b, chunks, partial, d1, d2, dz);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

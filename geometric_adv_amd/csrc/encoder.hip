@@ -22,6 +22,7 @@
 // (half0 + half1), the 256-wide layer one chain.
 #include "ae.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace geoadv {
 
@@ -37,6 +38,22 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 // s_in = width + 4 floats keeps them bank-conflict free); B fragments: one coalesced 1 KiB
 // global_load_dwordx4 per k-group from the packed weights, prefetched one group ahead.
 template <int RM>
+__device__ __forceinline__ void mfma_group(const float4 (&a)[RM], const float4 &b, f32x16 (&acc)[RM]) {
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+        acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].x, b.x, acc[rm], 0, 0, 0);
+        acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].y, b.y, acc[rm], 0, 0, 0);
+        acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].z, b.z, acc[rm], 0, 0, 0);
+        acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].w, b.w, acc[rm], 0, 0, 0);
+    }
+}
+
+// Chain lengths (t1 - t0) are multiples of 4 for every layer of the template architecture.
+// Software pipeline: a wave consumes one 1 KiB B fragment per ~512 cycles (two waves share a
+// SIMD's MFMA pipe) while an L2 hit takes ~800 cycles under load, so B fragments run through a
+// 4-slot register ring (4 loads in flight); A fragments (LDS, ~130 cycles) are fetched one
+// k-group ahead.
+template <int RM>
 __device__ __forceinline__ void gemm_chain(const float *in, int s_in, int row0, const PackedLayer &L, int cb, int t0,
                                            int t1, f32x16 (&acc)[RM]) {
     const int lane = threadIdx.x & 63;
@@ -46,20 +63,30 @@ __device__ __forceinline__ void gemm_chain(const float *in, int s_in, int row0, 
     const float *ar[RM];
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) ar[rm] = in + (row0 + rm * 32 + i) * s_in + 4 * h;
-    float4 bcur = bp[(size_t)t0 * 64];
-    for (int t = t0; t < t1; ++t) {
-        const float4 bnext = bp[(size_t)(t + 1 < t1 ? t + 1 : t) * 64];
-        float4 a[RM];
+    float4 b0 = bp[(size_t)t0 * 64], b1 = bp[(size_t)(t0 + 1) * 64], b2 = bp[(size_t)(t0 + 2) * 64], b3 = bp[(size_t)(t0 + 3) * 64];
+    float4 a0[RM], a1[RM];
 #pragma unroll
-        for (int rm = 0; rm < RM; ++rm) a[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * t);
+    for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * t0);
+    for (int t = t0; t < t1; t += 4) {
+        const bool more = t + 4 < t1;
 #pragma unroll
-        for (int rm = 0; rm < RM; ++rm) {
-            acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].x, bcur.x, acc[rm], 0, 0, 0);
-            acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].y, bcur.y, acc[rm], 0, 0, 0);
-            acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].z, bcur.z, acc[rm], 0, 0, 0);
-            acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].w, bcur.w, acc[rm], 0, 0, 0);
+        for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 1));
+        mfma_group<RM>(a0, b0, acc);
+        if (more) b0 = bp[(size_t)(t + 4) * 64];
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 2));
+        mfma_group<RM>(a1, b1, acc);
+        if (more) b1 = bp[(size_t)(t + 5) * 64];
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 3));
+        mfma_group<RM>(a0, b2, acc);
+        if (more) b2 = bp[(size_t)(t + 6) * 64];
+        if (more) {
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 4));
         }
-        bcur = bnext;
+        mfma_group<RM>(a1, b3, acc);
+        if (more) b3 = bp[(size_t)(t + 7) * 64];
     }
 }
 
@@ -123,7 +150,8 @@ template <int ROWS> struct EncLds {
     static constexpr int Q_FLOATS = ROWS * (128 + 4);
     static constexpr int SCRATCH_FLOATS = ROWS == 32 ? 3 * 2 * 16 * 64 : 16 * 64 * 4;   // K-part hand-off
     static constexpr int MASK_BYTES = ROWS * (64 + 128 + 128 + 256);
-    static constexpr size_t fwd_bytes = sizeof(float) * (P_FLOATS + Q_FLOATS + SCRATCH_FLOATS + ROWS * 3 + 256) + sizeof(int) * 512;
+    static constexpr int FWD_SCRATCH_FLOATS = ROWS == 32 ? 4 * 16 * 64 : 0;                 // 128-wide layers: 4 units x 1 hand-off
+    static constexpr size_t fwd_bytes = sizeof(float) * (P_FLOATS + Q_FLOATS + FWD_SCRATCH_FLOATS + ROWS * 3 + 256) + sizeof(int) * 512;
     static constexpr size_t bwd_bytes = sizeof(float) * (P_FLOATS + Q_FLOATS + SCRATCH_FLOATS + ROWS * 3) + sizeof(int) * ROWS + MASK_BYTES;
 };
 
@@ -176,7 +204,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(DeviceAE A, in
     float *bufP = lds;
     float *bufQ = bufP + LD::P_FLOATS;
     float *scratch = bufQ + LD::Q_FLOATS;
-    float *pts = scratch + LD::SCRATCH_FLOATS;        // [ROWS][3]
+    float *pts = scratch + LD::FWD_SCRATCH_FLOATS;    // [ROWS][3]
     float *redm = pts + ROWS * 3;                     // [2][128]
     int *reda = reinterpret_cast<int *>(redm + 256);  // [2][128]
     int *redc = reda + 256;                           // [2][128]
@@ -357,15 +385,16 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(DeviceAE A, in
     }
 }
 
-constexpr int FWD_ROWS = 64;
 constexpr int BWD_SPARSE_ROWS = 32;
 constexpr int BWD_DENSE_ROWS = 64;
 
 static int set_lds_attr_once() {
     static bool done = false;
     if (done) return GEOADV_OK;
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<FWD_ROWS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<FWD_ROWS>::fwd_bytes));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<64>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::fwd_bytes));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<32>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<32>::fwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_SPARSE_ROWS>::bwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_DENSE_ROWS>),
@@ -374,15 +403,29 @@ static int set_lds_attr_once() {
     return GEOADV_OK;
 }
 
-int encoder_tiles(int n) { return cdiv(n, FWD_ROWS); }
+// Forward tile height: 32 rows -> 2 workgroups per CU (67 KB of LDS each), 64 rows -> 1 per CU.
+int encoder_fwd_rows() {
+    static int rows = 0;
+    if (!rows) {
+        const char *e = getenv("GEOADV_FWD_ROWS");
+        rows = (e && atoi(e) == 64) ? 64 : 32;
+        if (e && atoi(e) != 64 && atoi(e) != 32) rows = 32;
+    }
+    return rows;
+}
+int encoder_tiles(int n) { return cdiv(n, encoder_fwd_rows()); }
 
 // pmax/parg/pcnt: [b][tiles][128]
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
                        int *parg, int *pcnt, hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
-    encoder_fwd_kernel<FWD_ROWS><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<FWD_ROWS>::fwd_bytes, stream>>>(
-        A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
+    if (encoder_fwd_rows() == 64)
+        encoder_fwd_kernel<64><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<64>::fwd_bytes, stream>>>(
+            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
+    else
+        encoder_fwd_kernel<32><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<32>::fwd_bytes, stream>>>(
+            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
