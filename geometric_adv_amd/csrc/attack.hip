@@ -11,6 +11,7 @@
 #include "chamfer_grad.h"
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -208,6 +209,50 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradA
     chamfer_grad_side<true, CGA_THREADS>(s, lds, a.P);
 }
 
+// Fast variant for the loop (n*24 B of LDS must fit): instead of sorting, every scatter term is
+// added to its target point as a 64-bit FIXED-POINT number (2^-44 resolution) with LDS integer
+// atomics.  Integer addition commutes, so the result is independent of the arrival order --
+// deterministic run to run like the sorted form -- and the sum is exact to 6e-14 absolute (tighter
+// than the CPU op's sequential fp32 sum, from which it differs by normal fp32 rounding only).
+// The bit-exact-vs-CPU sorted form stays behind the public NnDistanceGrad op (chamfer.hip).
+constexpr double CG_FX = 17592186044416.0;          // 2^44
+constexpr int CG_FX_MAX_N = 5000;                   // 3 * 8 B * n <= 120 KB
+
+__global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(lds);     // [n][3]
+    const CGradProblem pr = a.pr[blockIdx.y];
+    const int b = blockIdx.x, n = a.n;
+    const float wb = pr.w ? pr.w[b] : 1.0f;
+    const float gd = wb * (1.0f / (float)n);
+    const float g2 = gd * 2;
+    const float *p = pr.p + (size_t)b * n * 3, *q = pr.q + (size_t)b * n * 3;
+    const int *i1 = pr.idx1 + (size_t)b * n, *i2 = pr.idx2 + (size_t)b * n;
+    const int js = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
+    for (int e = threadIdx.x; e < 3 * n; e += CGA_THREADS) acc[e] = 0ull;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += CGA_THREADS) {
+        const int j = i2[k];                          // other point k matched our point j
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = g2 * (q[3 * k + c] - p[3 * j + c]);
+            const long long f = __double2ll_rn((double)t * CG_FX);
+            atomicAdd(&acc[3 * j + c], (unsigned long long)f);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += CGA_THREADS) {
+        const int mj = i1[j];
+        const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float own = gown * (p[3 * j + c] - q[3 * mj + c]);
+            const float sc = (float)((double)(long long)acc[3 * j + c] * (1.0 / CG_FX));
+            pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Adam on pert (tf.train.AdamOptimizer defaults, TF 1.13 ApplyAdam form; adv_ae.py:152-153).
 // g = g_enc + g_dist, g_dist either the Chamfer source-distance gradient (buffer) or the
@@ -216,13 +261,16 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradA
 struct AdamArgs {
     int n, B;
     float *pert, *m, *v;
-    const float *g_enc, *g_dist;     // g_dist null in 'pert' mode
+    float *g_enc;                    // read, then zeroed for the next iteration's sparse scatter
+    const float *g_dist;             // null in 'pert' mode
     const float *w, *losses;         // [B], [8][B]
     const int *jstar;                // [2][B]
     int loss_dist_type;
     float mp_pert_w;
     float alpha, one_minus_b1, one_minus_b2, eps;
     float *grad_out;                 // optional copy of g (tests)
+    const float *x;                  // source clouds
+    float *adv_out;                  // adv = x + pert_new, ready for the next forward (Adversary.attack, adversary.py:35)
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
@@ -231,6 +279,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     if (e >= per * a.B) return;
     const int b = (int)(e / per);
     float g = a.g_enc[e];
+    a.g_enc[e] = 0.f;
     if (a.loss_dist_type == GEOADV_LOSS_DIST_PERT) {
         const float p = a.pert[e];
         const float wb = a.w[b];
@@ -248,7 +297,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     m += (g - m) * a.one_minus_b1;
     v += (g * g - v) * a.one_minus_b2;
     a.m[e] = m; a.v[e] = v;
-    a.pert[e] -= (m * a.alpha) / (sqrtf(v) + a.eps);
+    const float pnew = a.pert[e] - (m * a.alpha) / (sqrtf(v) + a.eps);
+    a.pert[e] = pnew;
+    a.adv_out[e] = a.x[e] + pnew;
 }
 
 __global__ void fill_kernel(float *p, float v, size_t count) {
@@ -288,6 +339,11 @@ struct geoadv_attack {
     // host state
     float beta1_pow, beta2_pow;
     bool fwd_valid;
+    bool adv_valid;                  // adv == x + pert already (written by the Adam kernel)
+    bool overlap;                    // second stream in use
+    bool overlap_fwd;                // also run the Chamfer(adv, x) SCANS beside the encoder (measured: slower, off)
+    hipStream_t s2;
+    hipEvent_t ev_fork, ev_scan, ev_loss, ev_gdist;
     // profiling
     unsigned prof_mask;
     std::vector<hipEvent_t> ev;      // pool
@@ -306,6 +362,7 @@ inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 int prof_flush(geoadv_attack *at) {
     if (at->marks.empty()) return GEOADV_OK;
     GA_HIP(hipStreamSynchronize(at->prof_stream));
+    if (at->s2) GA_HIP(hipStreamSynchronize(at->s2));
     for (const auto &mk : at->marks) {
         float ms = 0;
         GA_HIP(hipEventElapsedTime(&ms, at->ev[mk.e0], at->ev[mk.e1]));
@@ -334,13 +391,30 @@ struct ProfScope {
 };
 
 
-// forward(pert): encoder -> latent/decoder -> both Chamfer problems -> per-cloud losses (+ metrics / keep-best)
+// forward(pert): encoder -> latent/decoder -> both Chamfer problems -> per-cloud losses (+ metrics / keep-best).
+// With `overlap`, Chamfer(adv, x) -- VALU bound, and independent of the network -- runs on the second
+// stream while the MFMA-bound encoder/decoder run on the main one; both kinds of workgroup fit on one
+// CU (104 KB + 2 x 24 KB of LDS) and use different pipes.
 int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     const DeviceAE &A = at->ae->d;
     const int B = at->B, n = at->n;
+    const bool split = at->overlap && at->overlap_fwd && at->adv_valid;
+    const ChamferScan sc_recon[2] = {{at->recon, at->gt, at->r1, at->ir1, n, n}, {at->gt, at->recon, at->r2, at->ir2, n, n}};
+    const ChamferScan sc_adv[2] = {{at->adv, at->x, at->a1, at->ia1, n, n}, {at->x, at->adv, at->a2, at->ia2, n, n}};
+    if (split) {
+        GA_HIP(hipEventRecord(at->ev_fork, st));
+        GA_HIP(hipStreamWaitEvent(at->s2, at->ev_fork, 0));
+        {
+            ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, at->s2);
+            if (int rc = launch_chamfer_scans(sc_adv, 2, B, at->s2)) return rc;
+        }
+        GA_HIP(hipEventRecord(at->ev_scan, at->s2));
+    }
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st);
-        if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, at->adv, at->fs.pmax, at->fs.parg, at->fs.pcnt, st)) return rc;
+        if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, at->adv_valid ? nullptr : at->adv, at->fs.pmax, at->fs.parg,
+                                        at->fs.pcnt, st)) return rc;
+        at->adv_valid = true;
     }
     {
         ProfScope ps(at, GEOADV_PROF_DECODER_FWD, st);
@@ -350,10 +424,14 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     }
     {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
-        ChamferScan sc[4] = {{at->recon, at->gt, at->r1, at->ir1, n, n}, {at->gt, at->recon, at->r2, at->ir2, n, n},
-                             {at->adv, at->x, at->a1, at->ia1, n, n},   {at->x, at->adv, at->a2, at->ia2, n, n}};
-        if (int rc = launch_chamfer_scans(sc, 4, B, st)) return rc;
+        if (split) {
+            if (int rc = launch_chamfer_scans(sc_recon, 2, B, st)) return rc;
+        } else {
+            const ChamferScan all[4] = {sc_recon[0], sc_recon[1], sc_adv[0], sc_adv[1]};
+            if (int rc = launch_chamfer_scans(all, 4, B, st)) return rc;
+        }
     }
+    if (split) GA_HIP(hipStreamWaitEvent(st, at->ev_scan, 0));
     {
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
         LossArgs la;
@@ -367,11 +445,26 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         loss_metrics_kernel<<<B, 256, 0, st>>>(la);
         GA_LAUNCH_CHECK();
     }
+    if (at->overlap) GA_HIP(hipEventRecord(at->ev_loss, st));
     at->fwd_valid = true;
     return GEOADV_OK;
 }
 
 int pow2_ge(int v) { int p = 2; while (p < v) p <<= 1; return p; }
+
+int launch_cgrad(const CGradProblem *pr, int np, int B, int n, hipStream_t st) {
+    CGradArgs ca;
+    for (int i = 0; i < np; ++i) ca.pr[i] = pr[i];
+    ca.n = n; ca.P = pow2_ge(n);
+    if (n <= CG_FX_MAX_N) {
+        chamfer_grad_attack_fx_kernel<<<dim3(B, np), CGA_THREADS, sizeof(unsigned long long) * 3 * (size_t)n, st>>>(ca);
+        GA_LAUNCH_CHECK();
+        return GEOADV_OK;
+    }
+    chamfer_grad_attack_kernel<<<dim3(B, np), CGA_THREADS, sizeof(unsigned) * (size_t)ca.P * (ca.P <= CG_TERMS_MAX_P ? 4 : 1), st>>>(ca);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
 
 // backward from the cached forward + Adam
 int do_step(geoadv_attack *at, hipStream_t st) {
@@ -379,19 +472,25 @@ int do_step(geoadv_attack *at, hipStream_t st) {
     const int B = at->B, n = at->n;
     const bool adv_chamfer = at->cfg.loss_adv_type == GEOADV_LOSS_ADV_CHAMFER;
     const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
+    const CGradProblem p_recon{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
+    const CGradProblem p_dist{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, at->cfg.max_point_dist_weight};
+    const bool split = at->overlap && dist_chamfer;
+    if (split) {   // the source-distance gradient does not depend on the network: second stream
+        GA_HIP(hipStreamWaitEvent(at->s2, at->ev_loss, 0));
+        {
+            ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, at->s2);
+            if (int rc = launch_cgrad(&p_dist, 1, B, n, at->s2)) return rc;
+        }
+        GA_HIP(hipEventRecord(at->ev_gdist, at->s2));
+    }
     {
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
-        CGradArgs ca;
+        CGradProblem pr[2];
         int np = 0;
-        if (adv_chamfer) ca.pr[np++] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
-        if (dist_chamfer)
-            ca.pr[np++] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar,
-                                       at->cfg.max_point_dist_weight};
-        if (np) {
-            ca.n = n; ca.P = pow2_ge(n);
-            chamfer_grad_attack_kernel<<<dim3(B, np), CGA_THREADS, sizeof(unsigned) * (size_t)ca.P * (ca.P <= CG_TERMS_MAX_P ? 4 : 1), st>>>(ca);
-            GA_LAUNCH_CHECK();
-        }
+        if (adv_chamfer) pr[np++] = p_recon;
+        if (dist_chamfer && !split) pr[np++] = p_dist;
+        if (np)
+            if (int rc = launch_cgrad(pr, np, B, n, st)) return rc;
     }
     if (adv_chamfer) {
         ProfScope ps(at, GEOADV_PROF_DECODER_BWD, st);
@@ -399,10 +498,10 @@ int do_step(geoadv_attack *at, hipStream_t st) {
     }
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_BWD, st);
-        GA_HIP(hipMemsetAsync(at->g_enc, 0, sizeof(float) * (size_t)B * n * 3, st));
         if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, st))
             return rc;
     }
+    if (split) GA_HIP(hipStreamWaitEvent(st, at->ev_gdist, 0));
     {
         ProfScope ps(at, GEOADV_PROF_ADAM, st);
         AdamArgs aa;
@@ -412,7 +511,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
         const float beta1 = 0.9f, beta2 = 0.999f;
         aa.alpha = at->cfg.learning_rate * sqrtf(1.0f - at->beta2_pow) / (1.0f - at->beta1_pow);
         aa.one_minus_b1 = 1.0f - beta1; aa.one_minus_b2 = 1.0f - beta2; aa.eps = 1e-8f;
-        aa.grad_out = at->grad_last;
+        aa.grad_out = at->grad_last; aa.x = at->x; aa.adv_out = at->adv;
         const size_t total = (size_t)B * n * 3;
         adam_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(aa);
         GA_LAUNCH_CHECK();
@@ -420,6 +519,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
         at->beta2_pow *= beta2;
     }
     at->fwd_valid = false;
+    at->adv_valid = true;
     return GEOADV_OK;
 }
 
@@ -471,13 +571,36 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->losses = F(4 * 8 * B); at->jstar = I(4 * 2 * B);
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
-    at->fwd_valid = false;
+    at->fwd_valid = false; at->adv_valid = false;
     at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr;
+    {
+        // GEOADV_OVERLAP (experiment switch): 0 (default) = single stream; 2 = the source-distance
+        // gradient runs on a second stream beside the decoder/encoder backward; 1 = additionally the
+        // Chamfer(adv, x) scans beside the encoder forward.  Measured on MI355X (B=32, N=2048): both are
+        // SLOWER than one stream -- mode 1: 2451 vs 2794 it/s (the 24 KB Chamfer workgroups fragment the
+        // LDS the 104 KB encoder workgroups need: encoder 113 -> 176 us); mode 2: 2630 vs 2790 it/s
+        // (event hand-offs cost more than the small kernels they hide).
+        const char *e = getenv("GEOADV_OVERLAP");
+        const int mode = e ? atoi(e) : 0;
+        at->overlap = mode != 0;
+        at->overlap_fwd = mode == 1;
+    }
+    at->s2 = nullptr;
+    if (at->overlap) {
+        bool ok = hipStreamCreateWithFlags(&at->s2, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&at->ev_fork, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&at->ev_scan, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&at->ev_loss, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&at->ev_gdist, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { at->overlap = false; at->s2 = nullptr; }
+    }
     for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_fx_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N);
         attr = true;
     }
     *out = at;
@@ -487,6 +610,12 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
 extern "C" void geoadv_attack_destroy(geoadv_attack *at) {
     if (!at) return;
     for (auto e : at->ev) (void)hipEventDestroy(e);
+    if (at->s2) {
+        (void)hipStreamSynchronize(at->s2);
+        (void)hipEventDestroy(at->ev_fork); (void)hipEventDestroy(at->ev_scan);
+        (void)hipEventDestroy(at->ev_loss); (void)hipEventDestroy(at->ev_gdist);
+        (void)hipStreamDestroy(at->s2);
+    }
     (void)hipFree(at->arena);
     delete at;
 }
@@ -502,7 +631,7 @@ extern "C" int geoadv_attack_set_inputs(geoadv_attack *at, const float *source_p
     GA_HIP(hipMemcpyAsync(at->gt, target_pc, 4 * bn3, hipMemcpyDeviceToDevice, st));
     if (target_latent) GA_HIP(hipMemcpyAsync(at->tz, target_latent, 4 * (size_t)at->B * 128, hipMemcpyDeviceToDevice, st));
     GA_HIP(hipMemcpyAsync(at->w, dist_weight, 4 * (size_t)at->B, hipMemcpyDeviceToDevice, st));
-    at->fwd_valid = false;
+    at->fwd_valid = false; at->adv_valid = false;
     return GEOADV_OK;
 }
 
@@ -522,7 +651,7 @@ extern "C" int geoadv_attack_init_pert(geoadv_attack *at, const float *init_pert
     GA_HIP(hipMemsetAsync(at->best_metrics, 0, 4 * (size_t)at->B * 4, st));
     GA_HIP(hipMemsetAsync(at->best_adv, 0, 4 * bn3, st));
     GA_HIP(hipMemsetAsync(at->best_recon, 0, 4 * bn3, st));
-    at->fwd_valid = false;
+    at->fwd_valid = false; at->adv_valid = false;
     return GEOADV_OK;
 }
 

@@ -38,7 +38,8 @@ struct ChamferArgs {
 constexpr int CH_THREADS = 256;
 constexpr int CH_WAVES = CH_THREADS / kWave;
 constexpr int CH_CHUNK = 8;        // targets per argmin chunk
-constexpr int CH_STAGE = 4096;     // targets per LDS stage: 3 planes x 16 KB
+constexpr int CH_STAGE = 2048;     // targets per LDS stage: 3 planes x 8 KB (24 KB per workgroup, so that two
+                                   // workgroups fit next to an encoder workgroup on one CU)
 
 __device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, float qy, float qz) {
     const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
@@ -56,11 +57,12 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_scan_kernel(ChamferArgs ar
     const float *Q = sc.query + (size_t)c * nq * 3;
     const float *T = sc.target + (size_t)c * nt * 3;
 
-    __shared__ __attribute__((aligned(16))) float sx[CH_STAGE];
-    __shared__ __attribute__((aligned(16))) float sy[CH_STAGE];
-    __shared__ __attribute__((aligned(16))) float sz[CH_STAGE];
-    __shared__ float mdist[CH_WAVES][kWave * R];
-    __shared__ int midx[CH_WAVES][kWave * R];
+    __shared__ __attribute__((aligned(16))) float stage[3 * CH_STAGE];
+    float *sx = stage, *sy = stage + CH_STAGE, *sz = stage + 2 * CH_STAGE;
+    // the wave-merge arrays alias the stage planes (dead after the last scan)
+    float (*mdist)[kWave * R] = reinterpret_cast<float (*)[kWave * R]>(stage);
+    int (*midx)[kWave * R] = reinterpret_cast<int (*)[kWave * R]>(stage + CH_WAVES * kWave * R);
+    static_assert(2 * CH_WAVES * kWave * R <= 3 * CH_STAGE, "merge arrays must fit in the stage buffer");
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_scan_kernel(ChamferArgs ar
     }
 
     // Re-scan the winning chunk of every query for the first index attaining the minimum.
+    __syncthreads();   // every wave is done with the stage planes: they become the merge arrays
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int found = INT_MAX;
