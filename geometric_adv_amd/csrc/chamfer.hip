@@ -33,6 +33,7 @@ struct ChamferScan {
 };
 struct ChamferArgs {
     ChamferScan s[4];
+    int tiles, clouds, scans;   // 1-D grid decomposition (XCD aware, see the kernel)
 };
 
 constexpr int CH_THREADS = 256;
@@ -49,11 +50,18 @@ __device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, 
 
 template <int R>
 __global__ __launch_bounds__(CH_THREADS) void chamfer_scan_kernel(ChamferArgs args) {
-    const ChamferScan sc = args.s[blockIdx.z];
+    // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so all query tiles of one (scan, cloud) group -- which stream the same target cloud -- are
+    // given the same `blockIdx % 8`: the cloud is then fetched into ONE L2 instead of eight.
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int group = (slot / args.tiles) * 8 + xcd, tile = slot % args.tiles;
+    if (group >= args.clouds * args.scans) return;
+    const ChamferScan sc = args.s[group / args.clouds];
     const int nq = sc.nq, nt = sc.nt;
-    const int q0 = blockIdx.x * (kWave * R);
+    const int q0 = tile * (kWave * R);
     if (q0 >= nq) return;
-    const int c = blockIdx.y;
+    const int c = group % args.clouds;
     const float *Q = sc.query + (size_t)c * nq * 3;
     const float *T = sc.target + (size_t)c * nt * 3;
 
@@ -189,12 +197,20 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
     // Pick the register blocking so that the grid still fills 256 CUs x 4 workgroups.
     auto groups = [&](int R) { return (long)cdiv(maxq, kWave * R) * b * live; };
     dim3 block(CH_THREADS);
+    args.clouds = b; args.scans = live;
+    auto grid = [&](int R) {
+        args.tiles = cdiv(maxq, kWave * R);
+        return dim3((unsigned)(args.tiles * 8 * cdiv(b * live, 8)));
+    };
     if (groups(4) >= 768) {
-        chamfer_scan_kernel<4><<<dim3(cdiv(maxq, kWave * 4), b, live), block, 0, stream>>>(args);
+        const dim3 g = grid(4);
+        chamfer_scan_kernel<4><<<g, block, 0, stream>>>(args);
     } else if (groups(2) >= 768) {
-        chamfer_scan_kernel<2><<<dim3(cdiv(maxq, kWave * 2), b, live), block, 0, stream>>>(args);
+        const dim3 g = grid(2);
+        chamfer_scan_kernel<2><<<g, block, 0, stream>>>(args);
     } else {
-        chamfer_scan_kernel<1><<<dim3(cdiv(maxq, kWave), b, live), block, 0, stream>>>(args);
+        const dim3 g = grid(1);
+        chamfer_scan_kernel<1><<<g, block, 0, stream>>>(args);
     }
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
