@@ -77,7 +77,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    gdist.init("nccl")
+    backend = "nccl"
+    try:
+        gdist.init("nccl")                       # RCCL over xGMI
+        if world > 1:
+            gdist.barrier()
+    except Exception as e:                       # keep the scaling run alive if RCCL cannot come up
+        sys.stderr.write("bench.py: RCCL init failed (%s); falling back to gloo for the KB-sized gather\n" % e)
+        backend = "gloo"
+        import torch.distributed as tdist
+        if tdist.is_initialized():
+            tdist.destroy_process_group()
+        gdist.init("gloo")
 
     from geometric_adv_amd import weights as W
     from geometric_adv_amd.adv_ae import AdvAE, Configuration
@@ -106,12 +117,12 @@ def main():
     t0 = time.perf_counter()
     at.run(Wm, K, thresh)                                      # exactly K timed steps, no host sync inside
     metrics, _, _ = at.get_best(ref)
-    gathered = gdist.all_gather_examples(metrics[None], axis=1)   # final loss scalars only (RCCL for N > 1)
+    gathered = gdist.all_gather_examples(metrics[None] if backend == "nccl" else metrics[None].cpu(), axis=1)   # final loss scalars only
     torch.cuda.synchronize()
     gdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = gdist.max_over_ranks(dt, device=dev)
+    dt = gdist.max_over_ranks(dt, device=dev if backend == "nccl" else "cpu")
     prof = at.profile_read()
     at.profile(False)
 
@@ -140,6 +151,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: B=32 random clouds x N=2048, output-space attack (chamfer/chamfer, "
                                "dist_weight 1.0, lr 0.01), one batch per GPU", "batch_per_gpu": B, "n_points": N,
                    "global_batch": B * world, "parallelism": "batches sharded, dp%d, no data-path collective" % world,
+                   "collective_backend": backend if world > 1 else "none",
                    "thresh_fraction": 0.8},
         "roofline": {"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_tflops, "peak": PEAK_MFMA_F32_TFLOPS,
                      "unit": "TFLOP/s", "frac": enc_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": None,

@@ -89,7 +89,8 @@ class AttackModel:
     """One batch of the attack in numpy; state layout as the reference's graph variables."""
 
     def __init__(self, model, x, gt, tz, w, loss_adv_type="chamfer", loss_dist_type="chamfer",
-                 lr=0.01, max_point_pert_weight=0.0, max_point_dist_weight=0.0):
+                 lr=0.01, max_point_pert_weight=0.0, max_point_dist_weight=0.0, fp32_state=True):
+        self.fp32_state = fp32_state          # False: pure fp64 (finite-difference checks of the backward)
         self.m_ = model
         self.dt = model.dt
         self.x = np.asarray(x, np.float32)
@@ -112,8 +113,15 @@ class AttackModel:
         plus intermediates.  idx_override = (iR1,iR2,iA1,iA2) pins the matches (so that a gradient
         check is not derailed by a legitimately flipped near-tie)."""
         M = self.m_
-        adv = (self.x.astype(self.dt) + self.pert)
-        adv32 = adv.astype(np.float32)
+        # adv is an fp32 tensor in the reference (placeholder x + variable pert, adversary.py:35): form it
+        # with ONE fp32 addition; with pert ~ 1e-7 against coordinates ~ 0.3 that rounding is a 10 % effect
+        # on (adv - x), which an fp64 sum would hide
+        if self.fp32_state:
+            adv32 = (self.x + self.pert.astype(np.float32)).astype(np.float32)
+            adv = adv32.astype(self.dt)
+        else:
+            adv = self.x.astype(self.dt) + self.pert
+            adv32 = adv.astype(np.float32)
         z, hs = M.encode(adv, keep=True)
         recon, d1, d2 = M.decode(z, keep=True)
         recon32 = recon.astype(np.float32)
@@ -188,6 +196,10 @@ class AttackModel:
         self.m += (g - self.m) * omb1
         self.v += (g * g - self.v) * omb2
         self.pert -= (self.m * alpha) / (np.sqrt(self.v) + eps)
+        # pert and the Adam slots are fp32 variables in the reference graph
+        if self.fp32_state:
+            self.m = self.m.astype(f32).astype(dt); self.v = self.v.astype(f32).astype(dt)
+            self.pert = self.pert.astype(f32).astype(dt)
         self.b1p = np.float32(self.b1p * np.float32(0.9))
         self.b2p = np.float32(self.b2p * np.float32(0.999))
 

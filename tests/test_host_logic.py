@@ -87,7 +87,7 @@ def test_attack_model_gradient_matches_finite_differences():
     tz = m.encode(gt)
     rng = np.random.default_rng(0)
     for adv_t, dist_t in [("chamfer", "chamfer"), ("latent", "pert")]:
-        am = AttackModel(m, x, gt, tz, np.array([1.0, 3.0]), adv_t, dist_t)
+        am = AttackModel(m, x, gt, tz, np.array([1.0, 3.0]), adv_t, dist_t, fp32_state=False)
         am.init_pert(1e-2 * rng.standard_normal((b, n, 3)))
         f = am.forward()
         g = am.gradient(f)
