@@ -47,6 +47,8 @@ struct LossArgs {
     const float *pert;                // [B][n][3]
     const float *z, *tz;              // [B][128]
     const float *w;                   // [B] dist_weight
+    const float *emd_cost;            // [B] match_cost(recon, gt) or null
+    float emd_weight;                 // loss_adv += emd_weight * emd_cost / n  (build-defined)
     float *losses;                    // [8][B]: loss_adv, loss_dist, loss_pert, loss_max|max_dist, input_dist, loss_ae, loss_max(pert), max_dist
     int *jstar;                       // [B] argmax_j a1 (first), [B] argmax_n |pert_n|^2 (first)
     float *dz_latent;                 // [B][128] d loss_adv / d z in latent mode (else untouched)
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void loss_metrics_kernel(LossArgs a) {
     const float pert_sq = r.sp;                                                        // adversary.py:41-44
     const float loss_pert = sqrtf(pert_sq), loss_max = sqrtf(mp);                      // adversary.py:47,50
     float loss_adv = loss_ae;
+    if (a.emd_cost) loss_adv = loss_ae + a.emd_weight * (a.emd_cost[b] * inv_n);
     if (a.loss_adv_type == GEOADV_LOSS_ADV_LATENT) {                                   // adv_ae.py:107-116
         float d = 0.f;
         if (t < 128) { d = a.z[(size_t)b * 128 + t] - a.tz[(size_t)b * 128 + t]; }
@@ -302,6 +305,11 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     a.adv_out[e] = a.x[e] + pnew;
 }
 
+__global__ void axpy_kernel(float *y, const float *x, float a, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) y[i] = fmaf(a, x[i], y[i]);
+}
+
 __global__ void fill_kernel(float *p, float v, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) p[i] = v;
@@ -336,6 +344,7 @@ struct geoadv_attack {
     float *dz, *dec_partial;
     float *losses; int *jstar;
     float *best_err, *best_metrics, *best_adv, *best_recon;
+    float *emd_match, *emd_temp, *emd_cost, *emd_g1, *emd_g2;   // only when cfg.emd_weight > 0
     // host state
     float beta1_pow, beta2_pow;
     bool fwd_valid;
@@ -431,6 +440,11 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
             if (int rc = launch_chamfer_scans(all, 4, B, st)) return rc;
         }
     }
+    if (at->emd_match) {   // approx_match is NoGradient (tf_approxmatch.py:19): the plan is recomputed every forward
+        ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
+        if (int rc = geoadv_approx_match(B, n, n, at->recon, at->gt, at->emd_match, at->emd_temp, st)) return rc;
+        if (int rc = geoadv_match_cost(B, n, n, at->recon, at->gt, at->emd_match, at->emd_cost, st)) return rc;
+    }
     if (split) GA_HIP(hipStreamWaitEvent(st, at->ev_scan, 0));
     {
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
@@ -439,6 +453,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         la.mp_pert_w = at->cfg.max_point_pert_weight; la.mp_dist_w = at->cfg.max_point_dist_weight;
         la.r1 = at->r1; la.r2 = at->r2; la.a1 = at->a1; la.a2 = at->a2; la.pert = at->pert;
         la.z = at->fs.z; la.tz = at->tz; la.w = at->w; la.losses = at->losses; la.jstar = at->jstar;
+        la.emd_cost = at->emd_match ? at->emd_cost : nullptr; la.emd_weight = at->cfg.emd_weight;
         la.dz_latent = at->dz; la.hist = hist_slot; la.keep = keep; la.best_err = at->best_err;
         la.best_metrics = at->best_metrics; la.adv = at->adv; la.recon = at->recon;
         la.best_adv = at->best_adv; la.best_recon = at->best_recon;
@@ -492,6 +507,13 @@ int do_step(geoadv_attack *at, hipStream_t st) {
         if (np)
             if (int rc = launch_cgrad(pr, np, B, n, st)) return rc;
     }
+    if (adv_chamfer && at->emd_match) {   // d(emd_weight * cost / n)/d recon, match held constant
+        ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
+        if (int rc = geoadv_match_cost_grad(B, n, n, at->recon, at->gt, at->emd_match, at->emd_g1, at->emd_g2, st)) return rc;
+        const size_t total = (size_t)B * n * 3;
+        axpy_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(at->g_recon, at->emd_g1, at->cfg.emd_weight / (float)n, total);
+        GA_LAUNCH_CHECK();
+    }
     if (adv_chamfer) {
         ProfScope ps(at, GEOADV_PROF_DECODER_BWD, st);
         if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st)) return rc;
@@ -532,7 +554,9 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
                "attack_create: unknown loss_adv_type %d", cfg->loss_adv_type);
     GA_REQUIRE(cfg->loss_dist_type == GEOADV_LOSS_DIST_CHAMFER || cfg->loss_dist_type == GEOADV_LOSS_DIST_PERT,
                "attack_create: unknown loss_dist_type %d", cfg->loss_dist_type);
-    GA_REQUIRE(cfg->emd_weight == 0.f, "attack_create: emd_weight is not supported by this build yet");
+    GA_REQUIRE(cfg->emd_weight >= 0.f, "attack_create: emd_weight must be >= 0");
+    GA_REQUIRE(cfg->emd_weight == 0.f || cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER,
+               "attack_create: emd_weight needs the output-space attack (loss_adv_type chamfer)");
     geoadv_attack *at = new geoadv_attack();
     at->ae = ae; at->cfg = *cfg; at->B = cfg->batch; at->n = ae->d.n_points;
     const size_t B = at->B, n = at->n, bn3 = B * n * 3, bn = B * n;
@@ -549,6 +573,9 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * B * 128); need(4 * (size_t)chunks * B * 256);
     need(4 * 8 * B); need(4 * 2 * B);
     need(4 * B); need(4 * B * 4); need(4 * bn3); need(4 * bn3);
+    const bool emd = cfg->emd_weight > 0.f;
+    const size_t emd_temp_f = emd ? geoadv_approx_match_temp_floats(at->B, at->n, at->n) : 0;
+    if (emd) { need(4 * B * n * n); need(4 * emd_temp_f + 8); need(4 * B); need(4 * bn3); need(4 * bn3); }
     at->arena_bytes = total;
     if (hipMalloc(&at->arena, total) != hipSuccess) {
         delete at;
@@ -570,6 +597,11 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->dz = F(4 * B * 128); at->dec_partial = F(4 * (size_t)chunks * B * 256);
     at->losses = F(4 * 8 * B); at->jstar = I(4 * 2 * B);
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
+    at->emd_match = at->emd_temp = at->emd_cost = at->emd_g1 = at->emd_g2 = nullptr;
+    if (emd) {
+        at->emd_match = F(4 * B * n * n); at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B);
+        at->emd_g1 = F(4 * bn3); at->emd_g2 = F(4 * bn3);
+    }
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
     at->fwd_valid = false; at->adv_valid = false;
     at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr;

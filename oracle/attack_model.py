@@ -89,7 +89,9 @@ class AttackModel:
     """One batch of the attack in numpy; state layout as the reference's graph variables."""
 
     def __init__(self, model, x, gt, tz, w, loss_adv_type="chamfer", loss_dist_type="chamfer",
-                 lr=0.01, max_point_pert_weight=0.0, max_point_dist_weight=0.0, fp32_state=True):
+                 lr=0.01, max_point_pert_weight=0.0, max_point_dist_weight=0.0, fp32_state=True,
+                 emd_weight=0.0):
+        self.emd_weight = emd_weight          # build-defined: loss_adv += emd_weight * match_cost(recon, gt) / N
         self.fp32_state = fp32_state          # False: pure fp64 (finite-difference checks of the backward)
         self.m_ = model
         self.dt = model.dt
@@ -139,15 +141,20 @@ class AttackModel:
         max_dist = A1.max(1)
         p2 = (self.pert ** 2).sum(-1)
         loss_pert, loss_max = np.sqrt(p2.sum(1)), np.sqrt(p2.max(1))
+        match = None
         if self.adv_type == "latent":
             loss_adv = np.sqrt(((z - self.tz) ** 2).sum(1))
         else:
             loss_adv = loss_ae
+            if self.emd_weight > 0:
+                match = _o().approx_match(recon32, self.gt)                 # (b, n, m), no gradient (tf_approxmatch.py:19)
+                cost = _o().match_cost(recon32, self.gt, match)
+                loss_adv = loss_ae + self.emd_weight * cost.astype(self.dt) / self.x.shape[1]
         if self.dist_type == "pert":
             loss_dist = loss_pert + (self.mppw * loss_max if self.mppw > 0 else 0)
         else:
             loss_dist = input_dist + (self.mpdw * max_dist if self.mpdw > 0 else 0)
-        return dict(adv=adv, recon=recon, z=z, hs=hs, d1=d1, d2=d2, idx=(iR1, iR2, iA1, iA2), A1=A1,
+        return dict(match=match, adv=adv, recon=recon, z=z, hs=hs, d1=d1, d2=d2, idx=(iR1, iR2, iA1, iA2), A1=A1,
                     loss_ae=loss_ae, input_dist=input_dist, max_dist=max_dist, loss_pert=loss_pert,
                     loss_max=loss_max, loss_adv=loss_adv, loss_dist=loss_dist, p2=p2)
 
@@ -170,6 +177,9 @@ class AttackModel:
             dz = (f["z"] - self.tz) / f["loss_adv"][:, None]
         else:
             g_recon = self._chamfer_grad_first(f["recon"], self.gt.astype(self.dt), iR1, iR2, one / N, one / N)
+            if self.emd_weight > 0:
+                g1, _ = _o().match_cost_grad(f["recon"].astype(np.float32), self.gt, f["match"])
+                g_recon = g_recon + (self.emd_weight / N) * g1.astype(self.dt)
             dz = M.decoder_backward(g_recon, f["d1"], f["d2"])
         g = M.encoder_backward(dz, f["z"], f["hs"])
         if self.dist_type == "pert":

@@ -235,3 +235,35 @@ def test_attack_api_shapes_and_progress(setup):
     assert (metrics[:, :, 4] < before[None, :]).all()
     with pytest.raises(AssertionError):
         at.attack(x[:3], tz[:3], gt[:3], ref[:3], conf)                 # 3 % 2 != 0 (adv_ae.py:162)
+
+
+def test_emd_combined_loss_step(setup):
+    """configs[3]: Chamfer + EMD combined adversarial loss (build-defined: loss_adv = chamfer +
+    emd_weight * match_cost(recon, gt) / N, match held constant in the backward like the reference's
+    NoGradient registration): loss value and gradient of one iteration against the model."""
+    import torch
+    from oracle.attack_model import AttackModel
+    w, ae, model = setup
+    b = 2
+    x, gt = _clouds(71, b)
+    at = _mk_attack(w, ae, b, "chamfer", "chamfer", emd_weight=0.5)
+    at.set_inputs(x, gt, None, 1.0)
+    p0 = (1e-3 * np.random.default_rng(2).standard_normal((b, N, 3))).astype(np.float32)
+    at.init_pert(p0, reset_optimizer=True)
+    am = AttackModel(model, x, gt, None, np.ones(b), emd_weight=0.5)
+    am.init_pert(p0)
+    s = {k: v.cpu().numpy() for k, v in at.peek().items()}
+    f = am.forward(idx_override=(s["idx_r1"], s["idx_r2"], s["idx_a1"], s["idx_a2"]))
+    g = am.gradient(f)
+    hist = torch.empty((1, 6, b), device=ae.device)
+    at.run(0, 1, 1, hist)
+    got = at.peek()["grad"].cpu().numpy()
+    sc = np.abs(g).reshape(b, -1).max(1)[:, None, None]
+    np.testing.assert_allclose(got / sc, g / sc, atol=2e-4)
+    # metrics of the updated state: loss_adv includes the EMD term, loss_ae (the keep-best key) does not
+    am.pert = at.peek()["pert"].cpu().numpy().astype(np.float64)
+    f2 = am.forward()
+    h = hist.cpu().numpy()[0]
+    np.testing.assert_allclose(h[5], f2["loss_ae"], rtol=1e-5)
+    np.testing.assert_allclose(h[0], f2["loss_adv"], rtol=2e-5)
+    assert (h[0] > h[5]).all()
