@@ -19,6 +19,7 @@
 #include "chamfer_grad.h"
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -48,8 +49,10 @@ __device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, 
     return (xx + yy) + zz;
 }
 
+// __launch_bounds__(256, 4): at most 128 VGPRs, so 4 workgroups (16 waves) fit per CU and the 1024
+// workgroups of the B = 32, N = 2048 attack step are all resident at once (no partial second round).
 template <int R>
-__global__ __launch_bounds__(CH_THREADS) void chamfer_scan_kernel(ChamferArgs args) {
+__global__ __launch_bounds__(CH_THREADS, 4) void chamfer_scan_kernel(ChamferArgs args) {
     // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own
     // L2), so all query tiles of one (scan, cloud) group -- which stream the same target cloud -- are
     // given the same `blockIdx % 8`: the cloud is then fetched into ONE L2 instead of eight.
@@ -202,10 +205,12 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
         args.tiles = cdiv(maxq, kWave * R);
         return dim3((unsigned)(args.tiles * 8 * cdiv(b * live, 8)));
     };
-    if (groups(4) >= 768) {
+    static int force_r = -1;
+    if (force_r < 0) { const char *e = getenv("GEOADV_CHAMFER_R"); force_r = e ? atoi(e) : 0; }
+    if (force_r == 4 || (!force_r && groups(4) >= 768)) {
         const dim3 g = grid(4);
         chamfer_scan_kernel<4><<<g, block, 0, stream>>>(args);
-    } else if (groups(2) >= 768) {
+    } else if (force_r == 2 || (!force_r && groups(2) >= 768)) {
         const dim3 g = grid(2);
         chamfer_scan_kernel<2><<<g, block, 0, stream>>>(args);
     } else {
