@@ -37,6 +37,14 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 // 32 share each B fragment.  A fragments: ds_read_b128 from the LDS activation tile (row stride
 // s_in = width + 4 floats keeps them bank-conflict free); B fragments: one coalesced 1 KiB
 // global_load_dwordx4 per k-group from the packed weights, prefetched one group ahead.
+// A ring refill; the sched_barrier after each call keeps it between the MFMA groups (a volatile load would be
+// followed by vmcnt(0); without the barrier the scheduler clusters all four refills at the loop end).
+__device__ __forceinline__ float4 ld_pinned(const float4 *p) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 t = *reinterpret_cast<const v4 *>(p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 template <int RM>
 __device__ __forceinline__ void mfma_group(const float4 (&a)[RM], const float4 &b, f32x16 (&acc)[RM]) {
 #pragma unroll
@@ -68,25 +76,33 @@ __device__ __forceinline__ void gemm_chain(const float *in, int s_in, int row0, 
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * t0);
     for (int t = t0; t < t1; t += 4) {
-        const bool more = t + 4 < t1;
+        // refills are unconditional (clamped index; the last iteration re-reads its own fragments): a branch
+        // around a load makes the compiler drain the ring with vmcnt(0) every four k-groups
+        const int tn = t + 4 < t1 ? t + 4 : t;
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 1));
+        __builtin_amdgcn_sched_barrier(0);           // A prefetch stays ahead of the MFMA group
         mfma_group<RM>(a0, b0, acc);
-        if (more) b0 = bp[(size_t)(t + 4) * 64];
+        b0 = ld_pinned(bp + (size_t)tn * 64);
+        __builtin_amdgcn_sched_barrier(0);           // pin the refill between the MFMA groups
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 2));
+        __builtin_amdgcn_sched_barrier(0);
         mfma_group<RM>(a1, b1, acc);
-        if (more) b1 = bp[(size_t)(t + 5) * 64];
+        b1 = ld_pinned(bp + (size_t)(tn + 1) * 64);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 3));
+        __builtin_amdgcn_sched_barrier(0);
         mfma_group<RM>(a0, b2, acc);
-        if (more) b2 = bp[(size_t)(t + 6) * 64];
-        if (more) {
+        b2 = ld_pinned(bp + (size_t)(tn + 2) * 64);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 4));
-        }
+        for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * tn);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_group<RM>(a1, b3, acc);
-        if (more) b3 = bp[(size_t)(t + 7) * 64];
+        b3 = ld_pinned(bp + (size_t)(tn + 3) * 64);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -276,6 +292,201 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(DeviceAE A, in
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward kernel, two-buffer form (default).  Same arithmetic and the same canonical accumulation
+// order as encoder_fwd_kernel<64>, but the 256-wide h4 is never held whole: layer 3 is computed in
+// two column halves and each half is consumed at once by the matching K-half of layer 4 (whose
+// canonical order IS "K-half 0 + K-half 1").  Two 64 x 132 buffers (67.6 KB) instead of 100 KB, so
+// TWO workgroups share a CU and one's epilogues / barriers / first-operand latencies hide under
+// the other's MFMAs.
+// ------------------------------------------------------------------------------------------
+constexpr int FWD2_BUF_FLOATS = 64 * 132;
+constexpr size_t FWD2_LDS_BYTES = sizeof(float) * (2 * FWD2_BUF_FLOATS + 64 * 3 + 256) + sizeof(int) * 512;
+
+// B-fragment ring carried ACROSS chains: while the last four k-groups of a chain run, the freed
+// slots are refilled with the first four fragments of the NEXT chain (weights do not depend on the
+// activations, so the request may cross the epilogue and the barrier).  Without it every chain start
+// exposes one L2 round trip (~900 cycles, 8 chains per tile = 13 % of the tile).
+struct BRing { float4 b[4]; };
+__device__ __forceinline__ void ring_fill(BRing &r, const float4 *bp) { r.b[0] = bp[0]; r.b[1] = bp[64]; r.b[2] = bp[128]; r.b[3] = bp[192]; }
+
+// nt k-groups (multiple of 4) starting at fragment pointer bp (lane offset included); A rows from `ar`
+// (lane's row, +4*h applied), first A k-group index at0.  ring holds fragments 0..3 of this chain on entry
+// and fragments 0..3 of the chain at bp_next on exit (if bp_next).
+__device__ __forceinline__ void chain_ring(const float *ar, int at0, const float4 *bp, int nt, BRing &ring,
+                                           const float4 *bp_next, f32x16 (&acc)[1]) {
+    float4 a0[1], a1[1];
+    a0[0] = *reinterpret_cast<const float4 *>(ar + 8 * at0);
+    for (int t = 0; t < nt; t += 4) {
+        // every refill is UNCONDITIONAL (a clamped, always valid address): with a branch around a load the
+        // compiler can no longer count outstanding loads and degrades the s_waitcnt vmcnt(3) below to
+        // vmcnt(2)/(1)/(0), i.e. it drains the ring every four k-groups
+        const bool more = t + 4 < nt;
+        const float4 *src = more ? bp + (size_t)(t + 4) * 64 : (bp_next ? bp_next : bp);
+        a1[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + t + 1));
+        __builtin_amdgcn_sched_barrier(0);       // the next A fragment is requested BEFORE this group's MFMAs issue
+        mfma_group<1>(a0, ring.b[0], acc);
+        ring.b[0] = ld_pinned(src + 0);
+        __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
+        a0[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + t + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<1>(a1, ring.b[1], acc);
+        ring.b[1] = ld_pinned(src + 64);
+        __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
+        a1[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + t + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<1>(a0, ring.b[2], acc);
+        ring.b[2] = ld_pinned(src + 128);
+        __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
+        a0[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + (more ? t + 4 : t)));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<1>(a1, ring.b[3], acc);
+        ring.b[3] = ld_pinned(src + 192);
+        __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A, int n, const float *x, const float *pert,
+                                                                     float *adv_out, float *pmax, int *parg, int *pcnt) {
+    constexpr int ROWS = 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *bufA = lds;
+    float *bufB = bufA + FWD2_BUF_FLOATS;
+    float *pts = bufB + FWD2_BUF_FLOATS;              // [64][3]
+    float *redm = pts + ROWS * 3;                     // [2][128]
+    int *reda = reinterpret_cast<int *>(redm + 256);
+    int *redc = reda + 256;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    const int cb = wave & 3, rb = wave >> 2;          // this wave's (column block, row block) unit in every 128-wide product
+    // fragment bases of this wave's eight chains
+    const int kg1 = A.enc_fwd[1].K >> 3, kg2 = A.enc_fwd[2].K >> 3, kg3 = A.enc_fwd[3].K >> 3, kg4 = A.enc_fwd[4].K >> 3;
+    const float4 *w1 = reinterpret_cast<const float4 *>(A.enc_fwd[1].w) + (size_t)cb * kg1 * 64 + lane;
+    const float4 *w2 = reinterpret_cast<const float4 *>(A.enc_fwd[2].w) + (size_t)cb * kg2 * 64 + lane;
+    const float4 *w3a = reinterpret_cast<const float4 *>(A.enc_fwd[3].w) + (size_t)cb * kg3 * 64 + lane;
+    const float4 *w3b = reinterpret_cast<const float4 *>(A.enc_fwd[3].w) + (size_t)(4 + cb) * kg3 * 64 + lane;
+    const float4 *w4 = reinterpret_cast<const float4 *>(A.enc_fwd[4].w) + (size_t)cb * kg4 * 64 + lane;
+    BRing ring;
+    ring_fill(ring, w1);                              // in flight during the point load and layer 0
+    // every per-lane constant is requested up front too (a load at its point of use costs an exposed
+    // L2 round trip per epilogue): BN scale/shift of this lane's column in layers 1-4 ...
+    const int ccol = cb * 32 + i;
+    const float sc1 = A.scale[1][ccol], sh1 = A.shift[1][ccol], sc2 = A.scale[2][ccol], sh2 = A.shift[2][ccol];
+    const float sc3a = A.scale[3][ccol], sh3a = A.shift[3][ccol], sc3b = A.scale[3][128 + ccol], sh3b = A.shift[3][128 + ccol];
+    const float sc4 = A.scale[4][ccol], sh4 = A.shift[4][ccol];
+    // ... and the 8 channels of layer 0 this thread computes (row = tid/8, channels 8*(tid%8) ..)
+    float l0w[3][8], l0s[8], l0t[8];
+    {
+        const int c0 = (threadIdx.x & 7) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            l0w[0][c] = A.w0[c0 + c]; l0w[1][c] = A.w0[64 + c0 + c]; l0w[2][c] = A.w0[128 + c0 + c];
+            l0s[c] = A.scale[0][c0 + c]; l0t[c] = A.shift[0][c0 + c];
+        }
+    }
+
+    const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
+    const int n0 = tile * ROWS;
+    if (threadIdx.x < ROWS * 3) {
+        const int r = threadIdx.x / 3, a = threadIdx.x % 3;
+        int p = n0 + r;
+        const bool valid = p < n;
+        p = valid ? p : n - 1;
+        const size_t g = ((size_t)b * n + p) * 3 + a;
+        float v = x[g];
+        if (pert) v += pert[g];
+        pts[threadIdx.x] = v;
+        if (adv_out && valid) adv_out[g] = v;
+    }
+    __syncthreads();
+    {   // layer 0 (fan-in 3) on the VALU, same arithmetic as fwd_layer0
+        const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 8;
+        const float px = pts[row * 3], py = pts[row * 3 + 1], pz = pts[row * 3 + 2];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a = px * l0w[0][c];
+            a = fmaf(py, l0w[1][c], a);
+            a = fmaf(pz, l0w[2][c], a);
+            bufA[row * 68 + c0 + c] = fmaxf(fmaf(a, l0s[c], l0t[c]), 0.f);
+        }
+    }
+    __syncthreads();
+
+    const int orow = rb * 32;                         // accumulator rows of this wave: orow + acc_row(r, h)
+    // ---- layer 1: 64 -> 128, canonical K halves (4 + 4 k-groups) ----
+    {
+        const float *ar = bufA + (orow + i) * 68 + 4 * h;
+        f32x16 acc[1] = {}, part[1] = {};
+        chain_ring(ar, 0, w1, kg1 / 2, ring, w1 + (size_t)(kg1 / 2) * 64, acc);
+        chain_ring(ar, kg1 / 2, w1 + (size_t)(kg1 / 2) * 64, kg1 / 2, ring, w2, part);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bufB[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r] + part[0][r], sc1, sh1), 0.f);
+    }
+    __syncthreads();
+    // ---- layer 2: 128 -> 128, canonical K halves (8 + 8) ----
+    {
+        const float *ar = bufB + (orow + i) * 132 + 4 * h;
+        f32x16 acc[1] = {}, part[1] = {};
+        chain_ring(ar, 0, w2, kg2 / 2, ring, w2 + (size_t)(kg2 / 2) * 64, acc);
+        chain_ring(ar, kg2 / 2, w2 + (size_t)(kg2 / 2) * 64, kg2 / 2, ring, w3a, part);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bufA[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r] + part[0][r], sc2, sh2), 0.f);
+    }
+    __syncthreads();
+    // ---- layers 3 + 4 interleaved by halves: h4[:, 128*half ..] feeds K-half `half` of layer 4 ----
+    f32x16 acc4[2][1] = {};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        {
+            const float *ar = bufA + (orow + i) * 132 + 4 * h;
+            f32x16 acc[1] = {};
+            chain_ring(ar, 0, half ? w3b : w3a, kg3, ring, w4 + (size_t)(kg4 / 2) * half * 64, acc);   // one full-K chain
+            const float sc = half ? sc3b : sc3a, sh = half ? sh3b : sh3a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bufB[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r], sc, sh), 0.f);
+        }
+        __syncthreads();
+        {
+            const float *ar = bufB + (orow + i) * 132 + 4 * h;
+            chain_ring(ar, 0, w4 + (size_t)(kg4 / 2) * half * 64, kg4 / 2, ring, half ? nullptr : w3b, acc4[half]);
+        }
+        if (half == 0) __syncthreads();               // bufB is rewritten by the second half of layer 3
+    }
+    // canonical combination: part0 + part1, then BN + ReLU and the max-pool from the registers
+    const int col = ccol;
+    float mx = -1.f;
+    int arg = INT_MAX, cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = orow + acc_row(r, h);
+        const float a = acc4[0][0][r] + acc4[1][0][r];
+        const float v = fmaxf(fmaf(a, sc4, sh4), 0.f);
+        if (n0 + row < n) {
+            if (v > mx) { mx = v; arg = n0 + row; cnt = 1; }
+            else if (v == mx) cnt++;
+        }
+    }
+    {
+        const float m2 = __shfl_xor(mx, 32);
+        const int a2 = __shfl_xor(arg, 32), c2 = __shfl_xor(cnt, 32);
+        if (m2 > mx) { mx = m2; arg = a2; cnt = c2; }
+        else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += c2; }
+    }
+    if (h == 0) { redm[rb * 128 + col] = mx; reda[rb * 128 + col] = arg; redc[rb * 128 + col] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        float m = redm[c];
+        int a = reda[c], k = redc[c];
+        const float m2 = redm[128 + c];
+        if (m2 > m) { m = m2; a = reda[128 + c]; k = redc[128 + c]; }
+        else if (m2 == m) { k += redc[128 + c]; }
+        const size_t o = ((size_t)b * tiles + tile) * 128 + c;
+        pmax[o] = m; parg[o] = a; pcnt[o] = k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Backward kernel over a list of rows.  grid = (row tiles, clouds).  rows: [b][rows_per_cloud]
 // point indices (duplicates allowed: every listed row is written with the same value), or null
 // for "all points".  A cloud takes part only if dense_flag[b] == want_dense (the sparse launch
@@ -395,6 +606,8 @@ static int set_lds_attr_once() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::fwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<32>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<32>::fwd_bytes));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_SPARSE_ROWS>::bwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_DENSE_ROWS>),
@@ -403,16 +616,17 @@ static int set_lds_attr_once() {
     return GEOADV_OK;
 }
 
-// Forward tile height: 64 rows (1 workgroup per CU, default) or 32 rows (2 per CU); measured on
-// MI355X at B=32, N=2048: 64 is ~5 % faster end to end.  GEOADV_FWD_ROWS=32 selects the other.
-int encoder_fwd_rows() {
-    static int rows = 0;
-    if (!rows) {
+// Forward kernel selection (GEOADV_FWD_ROWS): unset/"2buf" = two-buffer 64-row form (2 workgroups per CU,
+// default); "64" = single-pass 64-row form (1 per CU); "32" = 32-row form (2 per CU, K split over waves).
+static int fwd_variant() {          // 0: two-buffer, 64, 32
+    static int v = -1;
+    if (v < 0) {
         const char *e = getenv("GEOADV_FWD_ROWS");
-        rows = (e && atoi(e) == 32) ? 32 : 64;
+        v = !e ? 0 : (atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : 0));
     }
-    return rows;
+    return v;
 }
+int encoder_fwd_rows() { return fwd_variant() == 32 ? 32 : 64; }
 int encoder_tiles(int n) { return cdiv(n, encoder_fwd_rows()); }
 
 // pmax/parg/pcnt: [b][tiles][128]
@@ -420,7 +634,10 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
                        int *parg, int *pcnt, hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
-    if (encoder_fwd_rows() == 64)
+    if (fwd_variant() == 0)
+        encoder_fwd2_kernel<<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
+            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
+    else if (fwd_variant() == 64)
         encoder_fwd_kernel<64><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<64>::fwd_bytes, stream>>>(
             A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
     else
