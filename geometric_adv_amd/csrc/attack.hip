@@ -21,6 +21,9 @@ namespace geoadv {
 // ---- from the other translation units ------------------------------------------------------
 struct ChamferScan { const float *query; const float *target; float *dist; int *idx; int nq, nt; };
 int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t stream);
+struct ChamferPair { const float *p, *q; float *dist1; int *idx1; float *dist2; int *idx2; };
+size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
+int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
 struct ForwardScratch {
     float *pmax; int *parg; int *pcnt; float *z; int *crit; int *zcnt; int *dense; float *d1, *d2; size_t bytes;
 };
@@ -345,6 +348,8 @@ struct geoadv_attack {
     float *losses; int *jstar;
     float *best_err, *best_metrics, *best_adv, *best_recon;
     float *emd_match, *emd_temp, *emd_cost, *emd_g1, *emd_g2;   // only when cfg.emd_weight > 0
+    float *sym_ws;                   // column-minimum partials of the symmetric Chamfer kernel
+    bool chamfer_sym;
     // host state
     float beta1_pow, beta2_pow;
     bool fwd_valid;
@@ -435,6 +440,10 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
         if (split) {
             if (int rc = launch_chamfer_scans(sc_recon, 2, B, st)) return rc;
+        } else if (at->chamfer_sym) {   // one distance evaluation per pair serves both directions
+            const ChamferPair pairs[2] = {{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2},
+                                          {at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2}};
+            if (int rc = launch_chamfer_sym(pairs, 2, B, n, n, at->sym_ws, st)) return rc;
         } else {
             const ChamferScan all[4] = {sc_recon[0], sc_recon[1], sc_adv[0], sc_adv[1]};
             if (int rc = launch_chamfer_scans(all, 4, B, st)) return rc;
@@ -573,6 +582,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * B * 128); need(4 * (size_t)chunks * B * 256);
     need(4 * 8 * B); need(4 * 2 * B);
     need(4 * B); need(4 * B * 4); need(4 * bn3); need(4 * bn3);
+    const size_t sym_floats = chamfer_sym_workspace_floats(2, at->B, at->n, at->n);
+    need(4 * sym_floats);
     const bool emd = cfg->emd_weight > 0.f;
     const size_t emd_temp_f = emd ? geoadv_approx_match_temp_floats(at->B, at->n, at->n) : 0;
     if (emd) { need(4 * B * n * n); need(4 * emd_temp_f + 8); need(4 * B); need(4 * bn3); need(4 * bn3); }
@@ -597,6 +608,11 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->dz = F(4 * B * 128); at->dec_partial = F(4 * (size_t)chunks * B * 256);
     at->losses = F(4 * 8 * B); at->jstar = I(4 * 2 * B);
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
+    at->sym_ws = F(4 * sym_floats);
+    {
+        const char *e = getenv("GEOADV_CHAMFER_SYM");
+        at->chamfer_sym = !(e && e[0] == '0');
+    }
     at->emd_match = at->emd_temp = at->emd_cost = at->emd_g1 = at->emd_g2 = nullptr;
     if (emd) {
         at->emd_match = F(4 * B * n * n); at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B);

@@ -1,0 +1,305 @@
+// Symmetric Chamfer for the attack loop: ONE evaluation of every pair distance serves both
+// directions of nn_distance (note 4): d(P_j, Q_k) = ((dx*dx)+(dy*dy))+(dz*dz) is
+// bit-identical whichever cloud is the "query" (the differences only change sign), so the row minima
+// (dist1/idx1) and the column minima (dist2/idx2) of the same distance matrix are exactly what the two
+// scans of the reference op produce (tf_nndistance.cpp:79-80).  Still brute force -- all n*m distances are
+// evaluated, none is skipped -- but 8 VALU ops per pair are now spent once instead of twice.
+//
+// Kernel 1 (chamfer_sym_kernel): as chamfer_scan_kernel, a workgroup of 4 waves owns 64*R rows (P points,
+// R per lane, in registers); wave w scans the w-th quarter of the columns (Q points, LDS-staged SoA planes,
+// broadcast reads).  Row minima: running min per chunk of 8 columns + re-scan of the winning chunk, as
+// before.  Column minima: every lane reduces its R rows in registers (v_min3), then the 64 lanes of the
+// wave are reduced through a 4 KB LDS transpose per 16 columns (16 ds_write_b32 + 4 ds_read_b128 + 2
+// shuffles per lane: ~8 % on top of the distance arithmetic; a DPP butterfly per column would cost 19 %).
+// Each column is visited by exactly one wave of the workgroup, so the reduced value IS the column's
+// minimum over this row tile; it goes to colpart[tile][k].
+// Kernel 2 (chamfer_sym_finish_kernel): per column, minimum over the row tiles and the LOWEST tile
+// attaining it; then only that tile's 64*R rows are re-evaluated to find the lowest row index with
+// d == minimum (exactly the reference's tie rule): 1/8 of a scan at n = 2048.
+#include "common.h"
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+
+#pragma clang fp contract(off)
+
+namespace geoadv {
+
+struct ChamferPair {
+    const float *p, *q;        // [b][n][3] rows, [b][m][3] columns
+    float *dist1; int *idx1;   // [b][n]  row minima  (nn_distance outputs 0,1)
+    float *dist2; int *idx2;   // [b][m]  column minima (outputs 2,3)
+};
+struct ChamferSymArgs {
+    ChamferPair pr[2];
+    int n, m, tiles, clouds, pairs, csplit;
+    float *colpart;            // [pairs][clouds][tiles][m]
+    float *rowpart_d;          // [pairs][clouds][csplit][n]   row minima per column slice
+    int *rowpart_i;
+};
+
+constexpr int CS_THREADS = 512;               // 8 waves share one row tile and split the columns 8 ways
+constexpr int CS_WAVES = 8;
+constexpr int CS_R = 4;                      // rows per lane
+constexpr int CS_ROWS = kWave * CS_R;        // 256 rows per workgroup
+constexpr int CS_CHUNK = 8;                  // columns per arg-min chunk
+constexpr int CS_ROUND = 16;                 // columns per transpose round
+constexpr int CS_STAGE = 2048;               // columns per LDS stage
+constexpr int CS_TSTRIDE = 68;               // floats per column in the transpose buffer (64 lanes + pad)
+
+__device__ __forceinline__ float sqdist_s(float tx, float ty, float tz, float qx, float qy, float qz) {
+    const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return (xx + yy) + zz;
+}
+
+__global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymArgs a) {
+    constexpr int R = CS_R;
+    const int lin = blockIdx.x;                            // XCD-aware mapping, see chamfer_scan_kernel
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int per = a.tiles * a.csplit;                    // workgroups per (pair, cloud) group
+    const int group = (slot / per) * 8 + xcd, sub = slot % per;
+    if (group >= a.clouds * a.pairs) return;
+    const int tile = sub % a.tiles, cs = sub / a.tiles;    // row tile, column slice
+    const int pi = group / a.clouds, c = group % a.clouds;
+    const ChamferPair pr = a.pr[pi];
+    const int n = a.n, m = a.m;
+    const int q0 = tile * CS_ROWS;
+    // this workgroup's columns: [mbeg, mend), slices aligned to the transpose round
+    const int mround = (m + CS_ROUND - 1) / CS_ROUND;
+    const int mbeg = min(m, (mround * cs / a.csplit) * CS_ROUND), mend = min(m, (mround * (cs + 1) / a.csplit) * CS_ROUND);
+    const float *P = pr.p + (size_t)c * n * 3;
+    const float *Q = pr.q + (size_t)c * m * 3;
+    float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * a.tiles + tile) * m;
+
+    __shared__ __attribute__((aligned(16))) float stage[3 * CS_STAGE];
+    __shared__ __attribute__((aligned(16))) float tbuf[CS_WAVES][CS_ROUND * CS_TSTRIDE];
+    float *sx = stage, *sy = stage + CS_STAGE, *sz = stage + 2 * CS_STAGE;
+    static_assert(2 * CS_WAVES * CS_ROWS <= 3 * CS_STAGE, "merge arrays must fit in the stage buffer");
+    float (*mdist)[CS_ROWS] = reinterpret_cast<float (*)[CS_ROWS]>(stage);
+    int (*midx)[CS_ROWS] = reinterpret_cast<int (*)[CS_ROWS]>(stage + CS_WAVES * CS_ROWS);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float px[R], py[R], pz[R], best[R];
+    int bestk[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int j = q0 + r * kWave + lane;
+        j = j < n ? j : n - 1;                             // padding rows repeat the last row: same distances,
+        px[r] = P[3 * j]; py[r] = P[3 * j + 1]; pz[r] = P[3 * j + 2];   // so the column minima are unaffected
+        best[r] = INFINITY; bestk[r] = -1;
+    }
+    float *tb = tbuf[wave];
+    for (int t0 = mbeg; t0 < mend; t0 += CS_STAGE) {
+        const int cnt = min(CS_STAGE, mend - t0);
+        const int cntp = (cnt + CS_ROUND - 1) / CS_ROUND * CS_ROUND;
+        __syncthreads();
+        for (int e = threadIdx.x; e < cntp; e += CS_THREADS) {
+            float x = INFINITY, y = INFINITY, z = INFINITY;
+            if (e < cnt) { x = Q[3 * (size_t)(t0 + e)]; y = Q[3 * (size_t)(t0 + e) + 1]; z = Q[3 * (size_t)(t0 + e) + 2]; }
+            sx[e] = x; sy[e] = y; sz[e] = z;
+        }
+        __syncthreads();
+        const int nrounds = cntp / CS_ROUND;
+        const int rbeg = nrounds * wave / CS_WAVES, rend = nrounds * (wave + 1) / CS_WAVES;
+        if (rbeg < rend) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (bestk[r] < 0) bestk[r] = t0 + rbeg * CS_ROUND;
+        }
+        for (int rd = rbeg; rd < rend; ++rd) {
+            const int k0 = rd * CS_ROUND;
+            float colp[CS_ROUND];
+#pragma unroll
+            for (int hf = 0; hf < CS_ROUND / CS_CHUNK; ++hf) {
+                float tx[CS_CHUNK], ty[CS_CHUNK], tz[CS_CHUNK];
+#pragma unroll
+                for (int v = 0; v < CS_CHUNK / 4; ++v) {
+                    const float4 xa = *reinterpret_cast<const float4 *>(&sx[k0 + hf * CS_CHUNK + 4 * v]);
+                    const float4 ya = *reinterpret_cast<const float4 *>(&sy[k0 + hf * CS_CHUNK + 4 * v]);
+                    const float4 za = *reinterpret_cast<const float4 *>(&sz[k0 + hf * CS_CHUNK + 4 * v]);
+                    tx[4 * v] = xa.x; tx[4 * v + 1] = xa.y; tx[4 * v + 2] = xa.z; tx[4 * v + 3] = xa.w;
+                    ty[4 * v] = ya.x; ty[4 * v + 1] = ya.y; ty[4 * v + 2] = ya.z; ty[4 * v + 3] = ya.w;
+                    tz[4 * v] = za.x; tz[4 * v + 1] = za.y; tz[4 * v + 2] = za.z; tz[4 * v + 3] = za.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float cm = INFINITY;
+#pragma unroll
+                    for (int u = 0; u < CS_CHUNK; ++u) {
+                        const float d = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]);
+                        cm = fminf(cm, d);
+                        colp[hf * CS_CHUNK + u] = r == 0 ? d : fminf(colp[hf * CS_CHUNK + u], d);
+                    }
+                    if (cm < best[r]) { best[r] = cm; bestk[r] = t0 + k0 + hf * CS_CHUNK; }
+                }
+            }
+            // 64-lane reduction of the 16 column partials through LDS: [column][lane] -> 4 lanes per column
+#pragma unroll
+            for (int u = 0; u < CS_ROUND; ++u) tb[u * CS_TSTRIDE + lane] = colp[u];
+            __builtin_amdgcn_wave_barrier();
+            {
+                const int col = lane >> 2, quarter = lane & 3;
+                const float4 *src = reinterpret_cast<const float4 *>(tb + col * CS_TSTRIDE + quarter * 16);
+                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                float mn = fminf(fminf(fminf(v0.x, v0.y), fminf(v0.z, v0.w)), fminf(fminf(v1.x, v1.y), fminf(v1.z, v1.w)));
+                mn = fminf(mn, fminf(fminf(fminf(v2.x, v2.y), fminf(v2.z, v2.w)), fminf(fminf(v3.x, v3.y), fminf(v3.z, v3.w))));
+                mn = fminf(mn, __shfl_xor(mn, 1));
+                mn = fminf(mn, __shfl_xor(mn, 2));
+                const int k = t0 + k0 + col;
+                if (quarter == 0 && k < mend) colpart[k] = mn;
+            }
+            __builtin_amdgcn_wave_barrier();              // the buffer is rewritten by the next round
+        }
+    }
+    // row minima: first index attaining the minimum inside the winning chunk, then merge the 4 waves
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int found = INT_MAX;
+        if (bestk[r] >= 0) {
+            found = bestk[r];
+            bool hit = false;
+            for (int u = 0; u < CS_CHUNK; ++u) {
+                const int k = bestk[r] + u;
+                if (k < mend) {
+                    const float d = sqdist_s(Q[3 * (size_t)k], Q[3 * (size_t)k + 1], Q[3 * (size_t)k + 2], px[r], py[r], pz[r]);
+                    if (!hit && d == best[r]) { hit = true; found = k; }
+                }
+            }
+        }
+        mdist[wave][r * kWave + lane] = best[r];
+        midx[wave][r * kWave + lane] = found;
+    }
+    __syncthreads();
+    for (int qq = threadIdx.x; qq < CS_ROWS; qq += CS_THREADS) {
+        float d = mdist[0][qq];
+        int k = midx[0][qq];
+#pragma unroll
+        for (int w = 1; w < CS_WAVES; ++w) {
+            const float dw = mdist[w][qq];
+            const int kw = midx[w][qq];
+            if (dw < d || (dw == d && kw < k)) { d = dw; k = kw; }
+        }
+        if (q0 + qq < n) {
+            if (a.csplit == 1) {
+                pr.dist1[(size_t)c * n + q0 + qq] = d;
+                pr.idx1[(size_t)c * n + q0 + qq] = k;
+            } else {   // merged over the column slices by the finish kernel
+                const size_t o = (((size_t)pi * a.clouds + c) * a.csplit + cs) * n + q0 + qq;
+                a.rowpart_d[o] = d;
+                a.rowpart_i[o] = k;
+            }
+        }
+    }
+}
+
+// grid = (column slices, clouds * pairs).  Every workgroup takes an equal slice of COLUMNS (so the work is
+// balanced even when all column minima fall into one row tile, which is what a collapsed reconstruction
+// produces) and keeps the whole row cloud in LDS as SoA planes, one padded segment per row tile.  Thread =
+// one column: minimum over the row tiles + lowest tile attaining it, then that tile's rows are
+// re-evaluated in ascending order for the first one with d == minimum.
+constexpr int CF_THREADS = 256;
+constexpr int CF_COLS = CF_THREADS;                   // columns per workgroup (one per thread)
+constexpr int CF_SEG = CS_ROWS + 4;                   // floats per tile segment: 16-B aligned, and the pad staggers the banks
+
+__global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferSymArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles = a.tiles;
+    float *rx = lds, *ry = lds + tiles * CF_SEG, *rz = lds + 2 * tiles * CF_SEG;
+    const int group = blockIdx.y;
+    const int pi = group / a.clouds, c = group % a.clouds;
+    const ChamferPair pr = a.pr[pi];
+    const int n = a.n, m = a.m;
+    const float *P = pr.p + (size_t)c * n * 3;
+    const float *Q = pr.q + (size_t)c * m * 3;
+    const float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * tiles) * m;
+    for (int e = threadIdx.x; e < tiles * CS_ROWS; e += CF_THREADS) {
+        const int o = (e / CS_ROWS) * CF_SEG + (e % CS_ROWS);
+        const int src = e < n ? e : n - 1;
+        rx[o] = P[3 * (size_t)src]; ry[o] = P[3 * (size_t)src + 1]; rz[o] = P[3 * (size_t)src + 2];
+    }
+    __syncthreads();
+    if (a.csplit > 1) {   // row minima: lexicographic (distance, index) minimum over the column slices
+        for (int j = blockIdx.x * CF_COLS + threadIdx.x; j < n; j += gridDim.x * CF_COLS) {
+            const size_t o = ((size_t)pi * a.clouds + c) * a.csplit * n + j;
+            float d = a.rowpart_d[o];
+            int i = a.rowpart_i[o];
+            for (int s = 1; s < a.csplit; ++s) {
+                const float ds = a.rowpart_d[o + (size_t)s * n];
+                const int is = a.rowpart_i[o + (size_t)s * n];
+                if (ds < d || (ds == d && is < i)) { d = ds; i = is; }
+            }
+            pr.dist1[(size_t)c * n + j] = d;
+            pr.idx1[(size_t)c * n + j] = i;
+        }
+    }
+    const int k = blockIdx.x * CF_COLS + threadIdx.x;
+    if (k >= m) return;
+    float v = colpart[k];
+    int bt = 0;
+    for (int t = 1; t < tiles; ++t) {
+        const float w = colpart[(size_t)t * m + k];
+        if (w < v) { v = w; bt = t; }                     // strict: the lowest tile wins ties
+    }
+    const float qx = Q[3 * (size_t)k], qy = Q[3 * (size_t)k + 1], qz = Q[3 * (size_t)k + 2];
+    const int q0 = bt * CS_ROWS;
+    const int nrows = min(CS_ROWS, n - q0);
+    const float *sx = rx + bt * CF_SEG, *sy = ry + bt * CF_SEG, *sz = rz + bt * CF_SEG;
+    // descending, four rows per step (one ds_read_b128 per plane): the last hit kept is the lowest row.
+    // Rows beyond nrows inside the last 4-group are padding (never equal to v unless they duplicate a real
+    // row, and a lower real row then wins anyway) -- they are masked explicitly all the same.
+    int found = nrows;
+    for (int j4 = ((nrows + 3) >> 2) - 1; j4 >= 0; --j4) {
+        const float4 xa = *reinterpret_cast<const float4 *>(sx + 4 * j4);
+        const float4 ya = *reinterpret_cast<const float4 *>(sy + 4 * j4);
+        const float4 za = *reinterpret_cast<const float4 *>(sz + 4 * j4);
+        const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
+        const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
+        const int j = 4 * j4;
+        found = (d3 == v && j + 3 < nrows) ? j + 3 : found;
+        found = (d2 == v && j + 2 < nrows) ? j + 2 : found;
+        found = (d1 == v && j + 1 < nrows) ? j + 1 : found;
+        found = d0 == v ? j : found;
+    }
+    if (found == nrows) found = 0;                        // only if v is NaN-tainted (out of contract)
+    pr.dist2[(size_t)c * m + k] = v;
+    pr.idx2[(size_t)c * m + k] = q0 + found;
+}
+
+constexpr int CS_MAX_SPLIT = 4;
+size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
+    return (size_t)pairs * b * cdiv(n, CS_ROWS) * m + 2 * (size_t)pairs * b * CS_MAX_SPLIT * n + 64;
+}
+
+// pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
+int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream) {
+    if (b <= 0 || np <= 0) return GEOADV_OK;
+    ChamferSymArgs a;
+    for (int i = 0; i < np; ++i) a.pr[i] = pairs[i];
+    a.n = n; a.m = m; a.tiles = cdiv(n, CS_ROWS); a.clouds = b; a.pairs = np; a.colpart = workspace;
+    // column slices so that the grid fills the chip (4 workgroups per CU resident): 1, 2 or 4
+    static int force_split = -1;
+    if (force_split < 0) { const char *e = getenv("GEOADV_SYM_SPLIT"); force_split = e ? atoi(e) : 0; }
+    a.csplit = 1;
+    while (a.csplit < CS_MAX_SPLIT && (long)a.tiles * a.csplit * b * np < 256 && m / (a.csplit * 2) >= 256) a.csplit *= 2;   // measured: slicing only pays when the grid would not even cover the CUs
+    if (force_split == 1 || force_split == 2 || force_split == 4) a.csplit = force_split;
+    a.rowpart_d = workspace + (size_t)np * b * a.tiles * m;
+    a.rowpart_i = reinterpret_cast<int *>(a.rowpart_d + (size_t)np * b * CS_MAX_SPLIT * n);
+    static bool attr = false;
+    if (!attr) {
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_finish_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr = true;
+    }
+    const unsigned grid = (unsigned)(a.tiles * a.csplit * 8 * cdiv(b * np, 8));
+    chamfer_sym_kernel<<<grid, CS_THREADS, 0, stream>>>(a);
+    GA_LAUNCH_CHECK();
+    const size_t lds = sizeof(float) * 3 * (size_t)a.tiles * CF_SEG;
+    GA_REQUIRE(lds <= 150 * 1024, "chamfer_sym: too many rows (%d)", n);
+    chamfer_sym_finish_kernel<<<dim3(cdiv(m, CF_COLS), b * np), CF_THREADS, lds, stream>>>(a);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+}  // namespace geoadv
