@@ -29,6 +29,30 @@ B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+PMC_HBM_FILE = os.path.join(ROOT, "profiles", "r01_v6_pmc_hbm.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SQ_FILE = os.path.join(ROOT, "profiles", "r01_v5_pmc_sq.json")       # rocprofv3 --pmc SQ_* pass
+
+
+def pmc_traffic_bytes():
+    """HBM-side bytes per encoder launch from the committed PMC passes (separate --pmc runs, guide recipe):
+    FETCH_SIZE is in KiB and under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM),
+    WRITE_SIZE is exact.  Returns (bytes, note) or (None, reason)."""
+    try:
+        d = json.load(open(PMC_HBM_FILE))
+        k = [v for name, v in d.items() if "encoder_fwd" in name][0]
+        fetch, write = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
+        return (2.0 * fetch + write) * 1024.0, "profiles/r01_v6_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
+    except Exception as e:          # pragma: no cover
+        return None, "no PMC profile: %s" % e
+
+
+def pmc_mfma_util():
+    try:
+        d = json.load(open(PMC_SQ_FILE))
+        k = [v for name, v in d.items() if "encoder_fwd" in name][0]
+        return k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (k["GRBM_GUI_ACTIVE"] / 8.0)
+    except Exception:               # pragma: no cover
+        return None
 
 
 def clouds(seed, b, n):
@@ -139,9 +163,10 @@ def main():
     enc_avg_ms = enc_ms / max(enc_n, 1)
     enc_flop = ENC_FLOP_PER_POINT * B * N                       # algorithmic flop per launch
     enc_tflops = enc_flop / (enc_avg_ms * 1e-3) / 1e12
+    traffic, traffic_note = pmc_traffic_bytes()
     ch_n, ch_ms = prof["chamfer_fwd"]
     ch_avg_ms = ch_ms / max(ch_n, 1)
-    ch_pairs = 4.0 * B * N * N                                  # 2 problems x 2 directions per launch
+    ch_pairs = 4.0 * B * N * N                                  # 2 problems x 2 directions of nn_distance per step
     ch_bytes = 2 * 20.0 * B * (N + N)                           # 20*B*(N+M) per nn_distance call
     out = {
         "metric": "attack-iterations/sec (B=32, N=2048) at 1/2/4/8 GPUs; Chamfer rel-err vs ref",
@@ -153,10 +178,12 @@ def main():
                    "global_batch": B * world, "parallelism": "batches sharded, dp%d, no data-path collective" % world,
                    "collective_backend": backend if world > 1 else "none",
                    "thresh_fraction": 0.8},
-        "roofline": {"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_tflops, "peak": PEAK_MFMA_F32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": enc_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "kernel": "encoder_fwd2_kernel", "achieved": enc_tflops, "peak": PEAK_MFMA_F32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": enc_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                     "mfma_pipe_utilisation_pmc": pmc_mfma_util(),
                      "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop},
-        "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_scan_kernel", "avg_launch_ms": ch_avg_ms,
+        "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel (both directions of both "
+                                                         "problems from one distance evaluation per pair)", "avg_launch_ms": ch_avg_ms,
                              "launches_timed": ch_n, "achieved_Tpair_per_s": ch_pairs / (ch_avg_ms * 1e-3) / 1e12,
                              "algorithmic_bytes_per_launch": ch_bytes,
                              "achieved_hbm_GBps": ch_bytes / (ch_avg_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS},
