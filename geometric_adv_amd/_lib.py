@@ -23,7 +23,7 @@ def lib():
                 "g.build()'` or `make -C geometric_adv_amd/csrc` (needs hipcc, --offload-arch=gfx950)." % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
         _lib.geoadv_last_error.restype = C.c_char_p
-        for name in ("geoadv_approx_match_temp_floats", "geoadv_ae_workspace_bytes"):
+        for name in ("geoadv_approx_match_temp_floats", "geoadv_ae_workspace_bytes", "geoadv_chamfer_matrix_workspace_floats"):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

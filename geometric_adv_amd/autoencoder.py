@@ -85,6 +85,23 @@ class PointNetAE:
         _lib.check(st, "ae_forward")
         return recon, latent
 
+    def max_and_argmax(self, pc):
+        """(max_val (b,128), max_idx (b,128) int32) of the last encoder layer over the points of each cloud:
+        what src/ae_utils.py:19-20 computes with np.max / np.argmax from get_pre_symmetry_data
+        (autoencoder.py:309-319), without ever materialising the (b, n, 128) pre-symmetry tensor."""
+        pc = self._as_dev(pc)
+        b = pc.shape[0]
+        latent = torch.empty((b, self.bneck), dtype=torch.float32, device=self.device)
+        idx = torch.empty((b, self.bneck), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            need = _lib.lib().geoadv_ae_workspace_bytes(self._h, b)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            st = _lib.lib().geoadv_ae_critical(self._h, b, _lib.ptr(pc), _lib.ptr(latent), _lib.ptr(idx),
+                                               _lib.ptr(self._ws), _lib.stream_handle())
+        _lib.check(st, "ae_critical")
+        return latent, idx
+
     # -- the reference's method names -----------------------------------------------------
     def reconstruct(self, X, GT=None, compute_loss=True):
         """adversary_autoencoder.py:75-91: returns (reconstructions, mean Chamfer loss or None) as numpy."""

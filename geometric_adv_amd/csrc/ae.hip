@@ -193,3 +193,18 @@ extern "C" int geoadv_ae_forward(const geoadv_ae *ae, int b, const float *pc, fl
     if (latent) GA_HIP(hipMemcpyAsync(latent, s.z, sizeof(float) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
     return GEOADV_OK;
 }
+
+extern "C" int geoadv_ae_critical(const geoadv_ae *ae, int b, const float *pc, float *latent, int *arg_idx,
+                                  void *workspace, void *stream) {
+    GA_REQUIRE(ae && b >= 0, "ae_critical: bad arguments");
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(pc && workspace, "ae_critical: null pointer");
+    GA_REQUIRE(b <= 65535, "ae_critical: batch %d exceeds 65535", b);
+    hipStream_t st = as_stream(stream);
+    void *aligned = reinterpret_cast<void *>(rup(reinterpret_cast<size_t>(workspace), 256));
+    ForwardScratch s = carve_forward_scratch(aligned, b, ae->d.n_points);
+    if (int rc = run_forward(ae->d, b, pc, nullptr, nullptr, s, nullptr, st)) return rc;
+    if (latent) GA_HIP(hipMemcpyAsync(latent, s.z, sizeof(float) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
+    if (arg_idx) GA_HIP(hipMemcpyAsync(arg_idx, s.crit, sizeof(int) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
+    return GEOADV_OK;
+}

@@ -33,6 +33,7 @@ struct ChamferPair {
 struct ChamferSymArgs {
     ChamferPair pr[2];
     int n, m, tiles, clouds, pairs, csplit;
+    int pair_base, q_clouds;   // q_clouds > 0: cloud c is the pair (P cloud (pair_base+c)/q_clouds, Q cloud (pair_base+c)%q_clouds)
     float *colpart;            // [pairs][clouds][tiles][m]
     float *rowpart_d;          // [pairs][clouds][csplit][n]   row minima per column slice
     int *rowpart_i;
@@ -68,8 +69,10 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     // this workgroup's columns: [mbeg, mend), slices aligned to the transpose round
     const int mround = (m + CS_ROUND - 1) / CS_ROUND;
     const int mbeg = min(m, (mround * cs / a.csplit) * CS_ROUND), mend = min(m, (mround * (cs + 1) / a.csplit) * CS_ROUND);
-    const float *P = pr.p + (size_t)c * n * 3;
-    const float *Q = pr.q + (size_t)c * m * 3;
+    const int cp = a.q_clouds > 0 ? (a.pair_base + c) / a.q_clouds : c;
+    const int cq = a.q_clouds > 0 ? (a.pair_base + c) % a.q_clouds : c;
+    const float *P = pr.p + (size_t)cp * n * 3;
+    const float *Q = pr.q + (size_t)cq * m * 3;
     float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * a.tiles + tile) * m;
 
     __shared__ __attribute__((aligned(16))) float stage[3 * CS_STAGE];
@@ -211,8 +214,10 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
     const int pi = group / a.clouds, c = group % a.clouds;
     const ChamferPair pr = a.pr[pi];
     const int n = a.n, m = a.m;
-    const float *P = pr.p + (size_t)c * n * 3;
-    const float *Q = pr.q + (size_t)c * m * 3;
+    const int cp = a.q_clouds > 0 ? (a.pair_base + c) / a.q_clouds : c;
+    const int cq = a.q_clouds > 0 ? (a.pair_base + c) % a.q_clouds : c;
+    const float *P = pr.p + (size_t)cp * n * 3;
+    const float *Q = pr.q + (size_t)cq * m * 3;
     const float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * tiles) * m;
     for (int e = threadIdx.x; e < tiles * CS_ROWS; e += CF_THREADS) {
         const int o = (e / CS_ROWS) * CF_SEG + (e % CS_ROWS);
@@ -273,9 +278,17 @@ size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
 }
 
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
+int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
+                          int q_clouds, hipStream_t stream);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream) {
+    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, stream);
+}
+
+int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
+                          int q_clouds, hipStream_t stream) {
     if (b <= 0 || np <= 0) return GEOADV_OK;
     ChamferSymArgs a;
+    a.pair_base = pair_base; a.q_clouds = q_clouds;
     for (int i = 0; i < np; ++i) a.pr[i] = pairs[i];
     a.n = n; a.m = m; a.tiles = cdiv(n, CS_ROWS); a.clouds = b; a.pairs = np; a.colpart = workspace;
     // column slices so that the grid fills the chip (4 workgroups per CU resident): 1, 2 or 4
@@ -302,4 +315,61 @@ int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, fl
     return GEOADV_OK;
 }
 
+
+// out[pair] = mean(dist1[pair]) + mean(dist2[pair])  (chamfer_dist of prepare_indices_for_attack.py:113-114)
+__global__ __launch_bounds__(256) void chamfer_pair_mean_kernel(int n, int m, const float *d1, const float *d2, float *out) {
+    __shared__ float sh[8];
+    const int c = blockIdx.x, t = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = t; j < n; j += 256) s1 += d1[(size_t)c * n + j];
+    for (int k = t; k < m; k += 256) s2 += d2[(size_t)c * m + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if ((t & 63) == 0) { sh[t >> 6] = s1; sh[4 + (t >> 6)] = s2; }
+    __syncthreads();
+    if (t == 0) {
+        const float a = ((sh[0] + sh[1]) + sh[2]) + sh[3], b = ((sh[4] + sh[5]) + sh[6]) + sh[7];
+        out[c] = a * (1.0f / (float)n) + b * (1.0f / (float)m);
+    }
+}
+
 }  // namespace geoadv
+
+using namespace geoadv;
+
+// Per-pair scratch of geoadv_chamfer_matrix, in floats.
+static size_t matrix_floats_per_pair(int n, int m) {
+    return (size_t)2 * (n + m) + chamfer_sym_workspace_floats(1, 1, n, m) + 64;
+}
+
+extern "C" size_t geoadv_chamfer_matrix_workspace_floats(int na, int nb, int n, int m) {
+    if (na <= 0 || nb <= 0 || n <= 0 || m <= 0) return 256;
+    const size_t pairs = (size_t)na * nb;
+    const size_t chunk = pairs < 8192 ? pairs : 8192;
+    return chunk * matrix_floats_per_pair(n, m) + 256;
+}
+
+extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *A, const float *B, float *out,
+                                     float *workspace, size_t workspace_floats, void *stream) {
+    GA_REQUIRE(na >= 0 && nb >= 0 && n >= 1 && m >= 1, "chamfer_matrix: bad dimensions (na=%d nb=%d n=%d m=%d)", na, nb, n, m);
+    if (na == 0 || nb == 0) return GEOADV_OK;
+    GA_REQUIRE(A && B && out && workspace, "chamfer_matrix: null pointer");
+    const size_t per = matrix_floats_per_pair(n, m);
+    GA_REQUIRE(workspace_floats >= per + 256, "chamfer_matrix: workspace too small (%zu floats, need >= %zu)", workspace_floats, per + 256);
+    size_t chunk = (workspace_floats - 256) / per;
+    if (chunk > 32768) chunk = 32768;
+    hipStream_t st = as_stream(stream);
+    const size_t pairs = (size_t)na * nb;
+    for (size_t base = 0; base < pairs; base += chunk) {
+        const int cnt = (int)((pairs - base) < chunk ? (pairs - base) : chunk);
+        float *d1 = workspace, *d2 = d1 + (size_t)cnt * n;
+        int *i1 = reinterpret_cast<int *>(d2 + (size_t)cnt * m), *i2 = i1 + (size_t)cnt * n;
+        float *ws = reinterpret_cast<float *>(i2 + (size_t)cnt * m);
+        const ChamferPair pr{A, B, d1, i1, d2, i2};
+        GA_REQUIRE(base <= 0x7fffffff, "chamfer_matrix: too many pairs");
+        if (int rc = launch_chamfer_sym_ex(&pr, 1, cnt, n, m, ws, (int)base, nb, st)) return rc;
+        chamfer_pair_mean_kernel<<<cnt, 256, 0, st>>>(n, m, d1, d2, out + base);
+        GA_LAUNCH_CHECK();
+    }
+    return GEOADV_OK;
+}

@@ -274,3 +274,29 @@ class _MatchCostFn(torch.autograd.Function):
 
 def match_cost_autograd(xyz1, xyz2, match):
     return _MatchCostFn.apply(xyz1, xyz2, match)
+
+
+# ---------------------------------------------------------------------------------------------
+# attacker/prepare_indices_for_attack.py
+# ---------------------------------------------------------------------------------------------
+def chamfer_dist_matrix(pcs_a, pcs_b, max_workspace_bytes=2 << 30):
+    """All-pairs Chamfer distance: out[i, j] = mean(dist1) + mean(dist2) of nn_distance(pcs_a[i], pcs_b[j])
+    (the `chamfer_dist` tensor of prepare_indices_for_attack.py:113-114 for every pair), computed without
+    tiling the clouds.  pcs_a (na,n,3), pcs_b (nb,m,3) GPU tensors -> (na, nb)."""
+    a = _f32(pcs_a, "pcs_a", 3)
+    b = _f32(pcs_b, "pcs_b", 3)
+    if a.shape[2] != 3 or b.shape[2] != 3:
+        raise ValueError("chamfer_dist_matrix only accepts 3d point sets")
+    na, n, _ = a.shape
+    nb, m, _ = b.shape
+    out = torch.empty((na, nb), dtype=torch.float32, device=a.device)
+    if na == 0 or nb == 0:
+        return out
+    with torch.cuda.device(a.device):
+        want = _lib.lib().geoadv_chamfer_matrix_workspace_floats(na, nb, n, m)
+        nfl = int(min(want, max(max_workspace_bytes // 4, _lib.lib().geoadv_chamfer_matrix_workspace_floats(1, 1, n, m))))
+        ws = torch.empty(nfl, dtype=torch.float32, device=a.device)
+        st = _lib.lib().geoadv_chamfer_matrix(na, nb, n, m, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(ws),
+                                              C.c_size_t(nfl), _lib.stream_handle())
+    _lib.check(st, "chamfer_matrix")
+    return out

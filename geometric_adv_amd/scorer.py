@@ -1,0 +1,45 @@
+"""Bulk Chamfer scorer (attacker/prepare_indices_for_attack.py:104-164): the all-pairs Chamfer
+distance matrix over a set of clouds, from which the attack's target candidates are ranked.
+
+The reference fills `chamfer_dist_mat[:, start:start+size]` with one process per 100-column slice (44 launches,
+runner_indices_for_attack.sh:11-15), 10 x 10 tiled pairs per sess.run.  Here one call computes a slice with the
+pair-indexed symmetric kernel (no tiled copies); slices shard over GPUs exactly like the reference's processes.
+"""
+import numpy as np
+import torch
+
+from . import dist as gdist
+from . import ops
+
+
+def get_chamfer_dist_mat_slice(point_clouds, pc_start_idx, pc_batch_size, device="cuda:0", row_chunk=512):
+    """chamfer_dist_mat_curr of prepare_indices_for_attack.py:116-139: shape (num_all, num_curr), entry [i, j] =
+    Chamfer(source = point_clouds[start + j], target = point_clouds[i])."""
+    pcs = np.ascontiguousarray(point_clouds, dtype=np.float32)
+    cur = torch.as_tensor(pcs[pc_start_idx:pc_start_idx + pc_batch_size]).to(device)
+    out = np.empty((len(pcs), cur.shape[0]), np.float32)
+    for r0 in range(0, len(pcs), row_chunk):
+        rows = torch.as_tensor(pcs[r0:r0 + row_chunk]).to(device)
+        # nn_distance(source, target): source = current cloud j, target = cloud i  ->  pair (j, i)
+        out[r0:r0 + row_chunk] = ops.chamfer_dist_matrix(cur, rows).T.cpu().numpy()
+    return out
+
+
+def sort_dist_mat_rows(dist_mat):
+    """Ascending neighbour order per row (the argsort at the heart of sort_dist_mat, :167-190, without the per-class
+    bookkeeping that needs the data set's labels)."""
+    return np.argsort(dist_mat, axis=1).astype(np.int16 if dist_mat.shape[1] < 32768 else np.int32)
+
+
+def get_chamfer_dist_mat_sharded(point_clouds, device=None, col_chunk=100):
+    """Full (num_all, num_all) matrix with the column slices dealt out over the ranks (one process per GPU) and
+    all-gathered -- the only collective, once, at the end."""
+    rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if torch.distributed.is_initialized() else (0, 1)
+    n_all = len(point_clouds)
+    slices = list(range(0, n_all, col_chunk))
+    mine = gdist.shard_batches(len(slices), rank, world)
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    cols = [get_chamfer_dist_mat_slice(point_clouds, slices[k], col_chunk, dev) for k in mine]
+    local = np.concatenate(cols, axis=1) if cols else np.zeros((n_all, 0), np.float32)
+    full = gdist.all_gather_examples(torch.as_tensor(local).to(dev), axis=1)
+    return full.cpu().numpy()

@@ -58,6 +58,15 @@ int geoadv_nn_distance_grad(int b, int n, const float *xyz1, int m, const float 
                             const float *grad_dist2, const int *idx2,
                             float *grad_xyz1, float *grad_xyz2, void *stream);
 
+/* Bulk Chamfer scorer: the graph of attacker/prepare_indices_for_attack.py:110-114 evaluated for
+ * EVERY pair of clouds, out[i*nb + j] = mean_p dist1 + mean_q dist2 of nn_distance(A[i], B[j]), without the
+ * np.tile'd (na, nb, n, 3) copies the script feeds in 10 x 10 batches (:121-139).  A (na,n,3), B (nb,m,3).
+ * workspace: geoadv_chamfer_matrix_workspace_floats(na,nb,n,m) floats (any larger or smaller size >= one pair's
+ * worth works: pairs are processed in chunks that fit). */
+size_t geoadv_chamfer_matrix_workspace_floats(int na, int nb, int n, int m);
+int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *A, const float *B, float *out,
+                          float *workspace, size_t workspace_floats, void *stream);
+
 /* approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp) (tf_approxmatch.cpp:141, kernel
  * tf_approxmatch_g.cu:1-181).  match is (b,m,n) like the reference GPU op: match[b,l,k] couples
  * xyz2 point l with xyz1 point k.  temp: scratch of geoadv_approx_match_temp_floats(b,n,m) floats
@@ -137,6 +146,11 @@ void geoadv_ae_destroy(geoadv_ae *ae);
  * pc[b,n,3] -> latent[b,bneck] (may be NULL) and recon[b,n,3] (may be NULL).
  * workspace: geoadv_ae_workspace_bytes(ae,b) bytes of device scratch. */
 size_t geoadv_ae_workspace_bytes(const geoadv_ae *ae, int b);
+/* Encoder only, with the arg-max of the symmetric pool (what src/ae_utils.py:19-20 derives from
+ * get_pre_symmetry_data): latent[b,bneck] = max over points of the last encoder layer, arg_idx[b,bneck] = the
+ * LOWEST point index attaining it (np.argmax semantics).  Same workspace as geoadv_ae_forward. */
+int geoadv_ae_critical(const geoadv_ae *ae, int b, const float *pc, float *latent, int *arg_idx,
+                       void *workspace, void *stream);
 int geoadv_ae_forward(const geoadv_ae *ae, int b, const float *pc, float *latent, float *recon,
                       void *workspace, void *stream);
 

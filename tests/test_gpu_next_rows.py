@@ -1,0 +1,107 @@
+"""GPU: the SURVEY 8(f) rows built so far -- f-1 bulk Chamfer scorer, f-3 critical-points defense."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("na,nb,n,m", [(3, 5, 300, 300), (2, 2, 1024, 1024), (4, 3, 130, 517), (1, 7, 2048, 2048)])
+def test_chamfer_matrix_vs_oracle(oracle, na, nb, n, m):
+    """Every entry equals mean(dist1) + mean(dist2) of the pinned oracle's nn_distance on that pair (sums in
+    float64 on the oracle side; the kernel sums fp32 in a fixed order => 1e-6 relative)."""
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    a, b = cloud(1, na, n), cloud(2, nb, m)
+    got = ops.chamfer_dist_matrix(_t(a), _t(b)).cpu().numpy()
+    want = np.empty((na, nb))
+    for i in range(na):
+        d1, _, d2, _ = oracle.nn_distance(np.repeat(a[i:i + 1], nb, 0), b)
+        want[i] = d1.mean(1, dtype=np.float64) + d2.mean(1, dtype=np.float64)
+    np.testing.assert_allclose(got, want, rtol=2e-6)
+
+
+def test_chamfer_matrix_chunking_and_symmetry():
+    """A workspace that only fits a few pairs gives the same bits as one that fits all; the matrix of a set against
+    itself is symmetric with a zero diagonal (both directions of one pair are the same distances)."""
+    import torch
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    pcs = _t(cloud(3, 12, 512))
+    full = ops.chamfer_dist_matrix(pcs, pcs)
+    small = ops.chamfer_dist_matrix(pcs, pcs, max_workspace_bytes=4 * 3 * 200000)
+    assert torch.equal(full, small)
+    assert torch.equal(full, full.T) and not torch.diagonal(full).any()
+
+
+def test_scorer_slice_orientation(oracle):
+    from geometric_adv_amd.scorer import get_chamfer_dist_mat_slice, sort_dist_mat_rows
+    from conftest import cloud
+    pcs = cloud(5, 9, 256)
+    sl = get_chamfer_dist_mat_slice(pcs, 2, 4, row_chunk=5)
+    assert sl.shape == (9, 4)
+    d1, _, d2, _ = oracle.nn_distance(pcs[3:4], pcs[7:8])             # source = current cloud 2+1, target = cloud 7
+    np.testing.assert_allclose(sl[7, 1], d1.mean() + d2.mean(), rtol=2e-6)
+    order = sort_dist_mat_rows(sl.T)
+    assert order.shape == (4, 9) and (order[:, 0] == np.arange(2, 6)).all()        # a cloud is its own nearest neighbour
+
+
+def test_critical_points_match_pre_symmetry_argmax():
+    """f-3: (max, argmax) from the fused encoder == np.max / np.argmax of the model's pre-symmetry activations
+    (src/ae_utils.py:19-20), and the host-side bookkeeping reproduces ae_utils' outputs."""
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.defense import get_critical_points
+    from oracle.attack_model import AEModel
+    from conftest import cloud
+    n = 512
+    w = W.randomized_weights(n, seed=11)
+    ae = PointNetAE(w, n)
+    model = AEModel(W.canonical(w, n), n)
+    pcs = cloud(7, 5, n)
+    mv, mi = ae.max_and_argmax(pcs)
+    mv, mi = mv.cpu().numpy(), mi.cpu().numpy()
+    _, hs = model.encode(pcs, keep=True)
+    pre = hs[-1]                                                       # (b, n, 128) pre-symmetry data
+    np.testing.assert_allclose(mv, pre.max(1), atol=2e-6)
+    want_idx = pre.argmax(1)
+    top2 = np.sort(pre, axis=1)[:, -2:, :]
+    live = pre.max(1) > 0                                              # channels that are 0 for a whole cloud carry no critical point
+    clear = ((top2[:, 1] - top2[:, 0]) > 1e-5) & live                  # ... and skip near ties (fp32 vs fp64 may pick either)
+    assert clear.sum() > 0.9 * live.sum() and live.mean() > 0.3
+    assert np.array_equal(mv > 0, live)
+    assert np.array_equal(mi[clear], want_idx[clear])
+    # reference bookkeeping on the model's tensor vs ours on (max, argmax)
+    cp, ci, cn = get_critical_points(pcs, mv, mi)
+    for i in range(len(pcs)):
+        nz = mi[i][mv[i] > 0]
+        u, c = np.unique(nz, return_counts=True)
+        assert cn[i] == len(u) and set(ci[i, :cn[i]].tolist()) == set(u.tolist())
+        assert np.array_equal(cp[i, :cn[i]], pcs[i][ci[i, :cn[i]]])
+        assert (np.diff(c[np.argsort(c)[::-1]]) <= 0).all()
+
+
+def test_critical_cloud_reconstructs_identically_and_defense_runs():
+    """The reference's own sanity check (run_defense_critical.py:186-189): the reconstruction of the critical points
+    alone equals the reconstruction of the full cloud, exactly."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.defense import defend_critical
+    from conftest import cloud
+    n = 1024
+    ae = PointNetAE(W.randomized_weights(n, seed=12), n)
+    adv, src = cloud(8, 6, n), cloud(9, 6, n)
+    out = defend_critical(ae, adv, src)
+    r_full, z_full = ae.forward(adv)
+    r_crit, z_crit = ae.forward(out["critical_pc"])
+    assert torch.equal(z_full, z_crit) and torch.equal(r_full, r_crit)
+    assert (out["critical_num"] > 0).all() and (out["critical_num"] <= 128).all()
+    for k in range(len(adv)):                                          # defended = the complement, padded with its last point
+        keep = np.setdiff1d(np.arange(n), out["critical_idx"][k, :out["critical_num"][k]])
+        assert np.array_equal(out["defended_pc"][k, :len(keep)], adv[k][keep])
+    assert out["recon_error_vs_source"].shape == (6,) and np.isfinite(out["recon_error_vs_source"]).all()
