@@ -1,0 +1,112 @@
+"""attacker/run_attack.py on MI355X: same flags, same input files (looked up by base name in
+<ae_folder>/eval), same outputs per shape class (adversarial_metrics.npy [W,n,5], adversarial_pc_input.npy,
+adversarial_pc_recon.npy, dist_weight.npy, attack_stats.txt).
+
+Differences forced by the environment: the victim's weights come from <ae_folder>/weights.npz (TF variable names,
+see weights.py) instead of a TF1 checkpoint, and the class list of the pickled Configuration (conf.class_names,
+which needs tflearn to unpickle) is passed with --class_names (default: all of pc_classes).  Multi-GPU: launch with
+torchrun; every rank attacks a contiguous run of batches and the metrics are all-gathered (dist.attack_sharded).
+
+    python -m geometric_adv_amd.run_attack --ae_folder log/autoencoder_victim --batch_size 10 ...
+"""
+import argparse
+import os
+import os.path as osp
+
+import numpy as np
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--learning_rate', type=float, default=0.01)
+    p.add_argument('--loss_dist_type', type=str, default='chamfer')
+    p.add_argument('--loss_adv_type', type=str, default='chamfer')
+    p.add_argument('--dist_weight_list', nargs='+', default=[1.0])
+    p.add_argument('--max_point_pert_weight', type=float, default=0.0)
+    p.add_argument('--max_point_dist_weight', type=float, default=0.0)
+    p.add_argument('--num_iterations', type=int, default=500)
+    p.add_argument('--num_iterations_thresh', type=int, default=400)
+    p.add_argument('--batch_size', type=int, default=10)
+    p.add_argument('--ae_folder', type=str, default='log/autoencoder_victim')
+    p.add_argument('--attack_pc_idx', type=str, default='log/autoencoder_victim/eval/sel_idx_rand_100_test_set_13l.npy')
+    p.add_argument('--target_pc_idx_type', type=str, default='chamfer_nn_complete')
+    p.add_argument('--num_pc_for_attack', type=int, default=25)
+    p.add_argument('--num_pc_for_target', type=int, default=5)
+    p.add_argument('--correct_pred_only', type=int, default=0)
+    p.add_argument('--output_folder_name', type=str, default='attack_res')
+    p.add_argument('--top_dir', type=str, default='.', help='root that --ae_folder / --attack_pc_idx are relative to')
+    p.add_argument('--class_names', nargs='+', default=None, help='classes to attack / target [default: all]')
+    return p
+
+
+def main(argv=None):
+    flags = build_parser().parse_args(argv)
+    assert flags.loss_dist_type in ['pert', 'chamfer'], 'wrong loss_dist_type: %s' % flags.loss_dist_type
+    assert flags.loss_adv_type in ['latent', 'chamfer'], 'wrong loss_adv_type: %s' % flags.loss_adv_type
+    assert flags.num_iterations_thresh <= flags.num_iterations, \
+        'num_iterations_thresh (%d) should be smaller or equal to num_iterations (%d)' % (flags.num_iterations_thresh, flags.num_iterations)
+    assert flags.target_pc_idx_type in ['latent_nn', 'chamfer_nn_complete'], 'wrong target_pc_idx_type: %s' % flags.target_pc_idx_type
+
+    from . import dist as gdist
+    from .adv_ae import AdvAE, Configuration
+    from .attack_data import create_dir, load_data, prepare_data_for_attack
+
+    rank, world, local = gdist.init()
+    data_path = osp.join(flags.top_dir, flags.ae_folder, 'eval')
+    files = [f for f in os.listdir(data_path) if osp.isfile(osp.join(data_path, f))]
+    output_path = create_dir(osp.join(data_path, flags.output_folder_name))
+
+    point_clouds, latent_vectors, pc_classes, slice_idx, ae_loss = load_data(
+        data_path, files, ['point_clouds_test_set', 'latent_vectors_test_set', 'pc_classes', 'slice_idx_test_set', 'ae_loss_test_set'])
+    assert np.all(ae_loss > 0), 'Note: not all autoencoder loss values are larger than 0 as they should!'
+    nn_idx_dict = {'latent_nn': 'latent_nn_idx_test_set', 'chamfer_nn_complete': 'chamfer_nn_idx_complete_test_set'}
+    nn_idx = load_data(data_path, files, [nn_idx_dict[flags.target_pc_idx_type]])
+    correct_pred = None
+    if flags.correct_pred_only:
+        pc_labels, pc_pred_labels = load_data(data_path, files, ['pc_label_test_set', 'pc_pred_labels_test_set'])
+        correct_pred = (pc_labels == pc_pred_labels)
+    attack_pc_idx = np.load(osp.join(flags.top_dir, flags.attack_pc_idx))[:, :flags.num_pc_for_attack]
+
+    classes = list(flags.class_names) if flags.class_names else [str(c) for c in pc_classes]
+    conf = Configuration(batch_size=flags.batch_size, n_points=point_clouds.shape[1],
+                         weights=osp.join(flags.top_dir, flags.ae_folder, 'weights.npz'),
+                         loss_adv_type=flags.loss_adv_type, loss_dist_type=flags.loss_dist_type,
+                         dist_weight_list=[float(w) for w in flags.dist_weight_list],
+                         max_point_pert_weight=flags.max_point_pert_weight, max_point_dist_weight=flags.max_point_dist_weight,
+                         num_iterations=flags.num_iterations, num_iterations_thresh=flags.num_iterations_thresh,
+                         learning_rate=flags.learning_rate)
+    import torch
+    dev = torch.device("cuda", local)
+    ae = None
+    for i in range(len(pc_classes)):
+        name = str(pc_classes[i])
+        if name not in classes:
+            continue
+        adv = AdvAE('adversary', conf, device=dev, ae=ae)              # one graph per class in the reference (Adam state restarts)
+        ae = adv.ae
+        save_dir = create_dir(osp.join(output_path, name))
+        prep = lambda data: prepare_data_for_attack(pc_classes, [pc_classes[i]], classes, data, slice_idx, attack_pc_idx,
+                                                     flags.num_pc_for_target, nn_idx, correct_pred)
+        source_pc, target_pc = prep(point_clouds)
+        _, target_latent = prep(latent_vectors)
+        _, target_ae_loss_ref = prep(ae_loss)
+        target_ae_loss_ref = target_ae_loss_ref.reshape(-1)
+        fout = open(osp.join(save_dir, 'attack_stats.txt'), 'a', 1) if rank == 0 else None
+        if fout:
+            fout.write('Train flags: %s\n' % flags)
+        if world > 1:
+            metrics, pc_in, pc_rec, _ = gdist.attack_sharded(adv, source_pc, target_latent, target_pc, target_ae_loss_ref,
+                                                             gather_clouds=True)
+        else:
+            metrics, pc_in, pc_rec = adv.attack(source_pc, target_latent, target_pc, target_ae_loss_ref, conf, log_file=fout)
+        if fout:
+            fout.close()
+        if rank == 0:
+            np.save(osp.join(save_dir, 'adversarial_metrics'), metrics)
+            np.save(osp.join(save_dir, 'adversarial_pc_input'), pc_in)
+            np.save(osp.join(save_dir, 'adversarial_pc_recon'), pc_rec)
+            np.save(osp.join(save_dir, 'dist_weight'), np.array(conf.dist_weight_list))
+
+
+if __name__ == '__main__':
+    main()

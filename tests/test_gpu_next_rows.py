@@ -105,3 +105,58 @@ def test_critical_cloud_reconstructs_identically_and_defense_runs():
         keep = np.setdiff1d(np.arange(n), out["critical_idx"][k, :out["critical_num"][k]])
         assert np.array_equal(out["defended_pc"][k, :len(keep)], adv[k][keep])
     assert out["recon_error_vs_source"].shape == (6,) and np.isfinite(out["recon_error_vs_source"]).all()
+
+
+def test_run_attack_cli_end_to_end(tmp_path):
+    """f-2: the on-disk contract of attacker/run_attack.py on a synthetic eval folder -- same input file names,
+    same flags, same per-class outputs; the saved metrics equal a direct AdvAE.attack on the same pairs."""
+    import os
+    from geometric_adv_amd import run_attack, weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.attack_data import prepare_data_for_attack
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from conftest import cloud
+    n = 128
+    sizes = [4, 5, 4]
+    slice_idx = np.concatenate([[0], np.cumsum(sizes)])
+    pcs = cloud(17, int(slice_idx[-1]), n)
+    w = W.synthetic_weights(n)
+    top = tmp_path
+    ev = top / "log" / "ae" / "eval"
+    os.makedirs(ev)
+    W.save_npz(str(top / "log" / "ae" / "weights.npz"), w)
+    ae = PointNetAE(w, n)
+    latent, loss = ae.transform(pcs), ae.get_loss_per_pc(pcs)
+    rng = np.random.default_rng(0)
+    nn_idx = np.zeros((len(pcs), len(pcs)), np.int16)
+    for s in range(len(pcs)):
+        for t in range(3):
+            nn_idx[s, slice_idx[t]:slice_idx[t + 1]] = rng.permutation(sizes[t])
+    classes = np.array(["chair", "table", "car"])
+    attack_idx = np.stack([rng.permutation(4)[:2] for _ in sizes])
+    np.save(ev / "point_clouds_test_set_3l.npy", pcs); np.save(ev / "latent_vectors_test_set_3l.npy", latent)
+    np.save(ev / "pc_classes_3l.npy", classes); np.save(ev / "slice_idx_test_set_3l.npy", slice_idx)
+    np.save(ev / "ae_loss_test_set_3l.npy", loss); np.save(ev / "chamfer_nn_idx_complete_test_set_3l.npy", nn_idx)
+    np.save(ev / "sel_idx.npy", attack_idx)
+    args = ["--top_dir", str(top), "--ae_folder", "log/ae", "--attack_pc_idx", "log/ae/eval/sel_idx.npy", "--batch_size", "2",
+            "--num_iterations", "12", "--num_iterations_thresh", "8", "--num_pc_for_attack", "2", "--num_pc_for_target", "1",
+            "--dist_weight_list", "0.5", "2.0", "--class_names", "chair", "car"]
+    run_attack.main(args)
+    out = ev / "attack_res"
+    assert sorted(os.listdir(out)) == ["car", "chair"]
+    for cls in ("chair", "car"):
+        m = np.load(out / cls / "adversarial_metrics.npy")
+        a = np.load(out / cls / "adversarial_pc_input.npy")
+        r = np.load(out / cls / "adversarial_pc_recon.npy")
+        assert m.shape == (2, 2, 5) and a.shape == (2, 2, n, 3) and r.shape == (2, 2, n, 3)      # 2 sources x 1 other class x 1 target
+        assert np.array_equal(np.load(out / cls / "dist_weight.npy"), [0.5, 2.0])
+        assert "Dist weight" in open(out / cls / "attack_stats.txt").read()
+    # same numbers as the library call on the same pairs (a fresh AdvAE = fresh Adam state, like one graph per class)
+    conf = Configuration(batch_size=2, n_points=n, weights=w, dist_weight_list=[0.5, 2.0], num_iterations=12, num_iterations_thresh=8)
+    src, tgt = prepare_data_for_attack(classes, ["chair"], ["chair", "car"], pcs, slice_idx, attack_idx, 1, nn_idx, None)
+    _, tl = prepare_data_for_attack(classes, ["chair"], ["chair", "car"], latent, slice_idx, attack_idx, 1, nn_idx, None)
+    _, tr = prepare_data_for_attack(classes, ["chair"], ["chair", "car"], loss, slice_idx, attack_idx, 1, nn_idx, None)
+    assert len(src) == 2
+    m2, a2, r2 = AdvAE("adversary", conf).attack(src, tl, tgt, tr.reshape(-1), conf)
+    assert np.array_equal(m2, np.load(out / "chair" / "adversarial_metrics.npy"))
+    assert np.array_equal(a2, np.load(out / "chair" / "adversarial_pc_input.npy"))

@@ -1,0 +1,59 @@
+"""CPU: the host-side numpy bookkeeping (attack_data.py, defense.py) against golden vectors produced by the
+reference's own function bodies (oracle/make_golden_host.py)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(GOLDEN, "host_logic.npz"))
+
+
+def test_prepare_data_for_attack(g):
+    from geometric_adv_amd.attack_data import prepare_data_for_attack
+    classes, sl, idx, nn = g["prep_classes"], g["prep_slice_idx"], g["prep_attack_idx"], g["prep_nn_idx"]
+    for name, key in [("pc", "prep_pcs"), ("lat", "prep_lat"), ("loss", "prep_loss")]:
+        for cp_name, cp in [("all", None), ("correct", g["prep_correct"])]:
+            src, tgt = prepare_data_for_attack(classes, ["table"], list(classes), g[key], sl, idx, 2, nn, cp)
+            assert np.array_equal(src, g[f"prep_{name}_{cp_name}_src"]), (name, cp_name)
+            assert np.array_equal(tgt, g[f"prep_{name}_{cp_name}_tgt"]), (name, cp_name)
+    src, tgt = prepare_data_for_attack(classes, list(classes), ["chair", "car"], g["prep_pcs"], sl, idx, 3, nn, None)
+    assert np.array_equal(src, g["prep_multi_src"]) and np.array_equal(tgt, g["prep_multi_tgt"])
+
+
+def test_get_quantity_at_index(g):
+    from geometric_adv_amd.attack_data import get_quantity_at_index
+    assert np.array_equal(get_quantity_at_index([g["gq_quantity"]], g["gq_index"]), g["gq_out"])
+
+
+def test_outlier_inlier_packing(g):
+    from geometric_adv_amd.defense import get_outlier_pc_inlier_pc
+    o_pc, o_idx, o_num, i_pc = get_outlier_pc_inlier_pc(g["out_pc"], g["out_knn"], float(g["out_thresh"]))
+    assert np.array_equal(o_pc, g["out_outlier_pc"]) and np.array_equal(o_idx, g["out_outlier_idx"])
+    assert np.array_equal(o_num, g["out_outlier_num"]) and np.array_equal(i_pc, g["out_inlier_pc"])
+    assert o_idx.dtype == np.int16 and o_num.dtype == np.int16
+
+
+def test_critical_points_bookkeeping(g):
+    from geometric_adv_amd.defense import get_critical_pc_non_critical_pc
+    pre = g["crit_pre"]
+    cp, ci, cn, crit_pc, non = get_critical_pc_non_critical_pc(g["crit_in_pc"], pre.max(1), pre.argmax(1))
+    assert np.array_equal(cn, g["crit_num"]) and np.array_equal(ci, g["crit_idx"])
+    assert np.array_equal(cp, g["crit_points"]) and np.array_equal(crit_pc, g["crit_pc"])
+    assert np.array_equal(non, g["crit_noncrit_pc"])
+
+
+def test_load_data_by_basename(tmp_path):
+    from geometric_adv_amd.attack_data import load_data
+    np.save(tmp_path / "point_clouds_test_set_13l.npy", np.arange(6).reshape(2, 3))
+    np.save(tmp_path / "ae_loss_test_set_13l.npy", np.ones(2))
+    files = sorted(os.listdir(tmp_path))
+    a, b = load_data(str(tmp_path), files, ["point_clouds_test_set", "ae_loss_test_set"])
+    assert a.shape == (2, 3) and b.shape == (2,)
+    assert load_data(str(tmp_path), files, ["ae_loss"]).shape == (2,)
+    with pytest.raises(IndexError):
+        load_data(str(tmp_path), files, ["missing"])
