@@ -13,6 +13,8 @@ int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int 
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
 int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
 int encoder_tiles(int n);
+int launch_encoder_fwd_stamped(const DeviceAE &A, int b, const float *x, float *pmax, int *parg, int *pcnt,
+                               unsigned long long *stamps, hipStream_t stream);
 
 static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -207,4 +209,13 @@ extern "C" int geoadv_ae_critical(const geoadv_ae *ae, int b, const float *pc, f
     if (latent) GA_HIP(hipMemcpyAsync(latent, s.z, sizeof(float) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
     if (arg_idx) GA_HIP(hipMemcpyAsync(arg_idx, s.crit, sizeof(int) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
     return GEOADV_OK;
+}
+
+// Diagnostic only (tools/encoder_phases.py): phase stamps of the forward kernel, stamps[b][n/64][12] (device, u64).
+extern "C" int geoadv_debug_encoder_stamps(const geoadv_ae *ae, int b, const float *pc, void *workspace,
+                                           unsigned long long *stamps, void *stream) {
+    GA_REQUIRE(ae && b > 0 && pc && workspace && stamps, "debug_encoder_stamps: bad arguments");
+    void *aligned = reinterpret_cast<void *>(rup(reinterpret_cast<size_t>(workspace), 256));
+    ForwardScratch s = carve_forward_scratch(aligned, b, ae->d.n_points);
+    return launch_encoder_fwd_stamped(ae->d, b, pc, s.pmax, s.parg, s.pcnt, stamps, as_stream(stream));
 }

@@ -345,8 +345,16 @@ __device__ __forceinline__ void chain_ring(const float *ar, int at0, const float
     }
 }
 
+template <bool STAMP>
 __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A, int n, const float *x, const float *pert,
-                                                                     float *adv_out, float *pmax, int *parg, int *pcnt) {
+                                                                     float *adv_out, float *pmax, int *parg, int *pcnt,
+                                                                     unsigned long long *stamps) {
+    // STAMP: diagnostic build only (geoadv_debug_encoder_stamps): wave 0 of every workgroup records s_memtime at the
+    // phase boundaries into its own buffer; no output depends on them.
+    auto stamp = [&](int k) {
+        if (STAMP && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     constexpr int ROWS = 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds;
@@ -411,6 +419,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         }
     }
     __syncthreads();
+    stamp(1);
 
     const int orow = rb * 32;                         // accumulator rows of this wave: orow + acc_row(r, h)
     // ---- layer 1: 64 -> 128, canonical K halves (4 + 4 k-groups) ----
@@ -423,6 +432,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         for (int r = 0; r < 16; ++r) bufB[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r] + part[0][r], sc1, sh1), 0.f);
     }
     __syncthreads();
+    stamp(2);
     // ---- layer 2: 128 -> 128, canonical K halves (8 + 8) ----
     {
         const float *ar = bufB + (orow + i) * 132 + 4 * h;
@@ -433,6 +443,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         for (int r = 0; r < 16; ++r) bufA[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r] + part[0][r], sc2, sh2), 0.f);
     }
     __syncthreads();
+    stamp(3);
     // ---- layers 3 + 4 interleaved by halves: h4[:, 128*half ..] feeds K-half `half` of layer 4 ----
     f32x16 acc4[2][1] = {};
 #pragma unroll
@@ -446,11 +457,13 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
             for (int r = 0; r < 16; ++r) bufB[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r], sc, sh), 0.f);
         }
         __syncthreads();
+        stamp(4 + 2 * half);
         {
             const float *ar = bufB + (orow + i) * 132 + 4 * h;
             chain_ring(ar, 0, w4 + (size_t)(kg4 / 2) * half * 64, kg4 / 2, ring, half ? nullptr : w3b, acc4[half]);
         }
         if (half == 0) __syncthreads();               // bufB is rewritten by the second half of layer 3
+        stamp(5 + 2 * half);
     }
     // canonical combination: part0 + part1, then BN + ReLU and the max-pool from the registers
     const int col = ccol;
@@ -484,6 +497,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         const size_t o = ((size_t)b * tiles + tile) * 128 + c;
         pmax[o] = m; parg[o] = a; pcnt[o] = k;
     }
+    stamp(8);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -606,7 +620,9 @@ static int set_lds_attr_once() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::fwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<32>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<32>::fwd_bytes));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel),
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_SPARSE_ROWS>::bwd_bytes));
@@ -635,8 +651,8 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
     if (fwd_variant() == 0)
-        encoder_fwd2_kernel<<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
-            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
+        encoder_fwd2_kernel<false><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
+            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr);
     else if (fwd_variant() == 64)
         encoder_fwd_kernel<64><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<64>::fwd_bytes, stream>>>(
             A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
@@ -659,6 +675,17 @@ int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *cr
     GA_LAUNCH_CHECK();
     encoder_bwd_kernel<BWD_DENSE_ROWS><<<dim3(cdiv(A.n_points, BWD_DENSE_ROWS), b), ENC_THREADS, EncLds<BWD_DENSE_ROWS>::bwd_bytes, stream>>>(
         A, A.n_points, adv, nullptr, 0, z, zcnt, dz, dense_flag, 1, g_enc);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+
+// Diagnostic (not part of the product path): the two-buffer forward with phase stamps.  stamps: [b][tiles][12] u64.
+int launch_encoder_fwd_stamped(const DeviceAE &A, int b, const float *x, float *pmax, int *parg, int *pcnt,
+                               unsigned long long *stamps, hipStream_t stream) {
+    if (int st = set_lds_attr_once()) return st;
+    encoder_fwd2_kernel<true><<<dim3(cdiv(A.n_points, 64), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
+        A, A.n_points, x, nullptr, nullptr, pmax, parg, pcnt, stamps);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -228,6 +228,11 @@ int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, float *recon,
 int geoadv_attack_profile(geoadv_attack *at, int enable);
 int geoadv_attack_profile_read(geoadv_attack *at, int which, int *launches, float *total_ms);
 
+/* Diagnostic build of the encoder forward with s_memtime stamps at its phase boundaries (tools/encoder_phases.py);
+ * stamps: device buffer of b * ceil(n/64) * 12 uint64.  Not part of the reference's surface. */
+int geoadv_debug_encoder_stamps(const geoadv_ae *ae, int b, const float *pc, void *workspace,
+                                unsigned long long *stamps, void *stream);
+
 /* Micro-benchmarks used by bench.py / DESIGN.md to calibrate the rooflines on the box
  * (not part of the reference's surface).  Returns elapsed ms of `iters` repetitions. */
 int geoadv_microbench(int which, int iters, float *ms, void *stream);
