@@ -93,8 +93,11 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from geometric_adv_amd import dist as gdist
+    from geometric_adv_amd import _lib, dist as gdist
     rank, world, local = gdist.env_rank()
+    if not os.path.exists(_lib.LIB_PATH) and rank == 0:       # clean checkout: build in-tree first (no fallback path exists)
+        import __graft_entry__
+        __graft_entry__.build()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with --nproc-per-node %d" % (args.gpus, args.gpus))
