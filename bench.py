@@ -95,9 +95,15 @@ def main():
     import torch
     from geometric_adv_amd import _lib, dist as gdist
     rank, world, local = gdist.env_rank()
-    if not os.path.exists(_lib.LIB_PATH) and rank == 0:       # clean checkout: build in-tree first (no fallback path exists)
-        import __graft_entry__
-        __graft_entry__.build()
+    if not os.path.exists(_lib.LIB_PATH):                     # clean checkout: build in-tree first (no fallback path exists)
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:                                                 # the other ranks wait for rank 0's build
+            for _ in range(600):
+                if os.path.exists(_lib.LIB_PATH):
+                    break
+                time.sleep(0.5)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with --nproc-per-node %d" % (args.gpus, args.gpus))
