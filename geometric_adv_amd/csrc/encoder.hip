@@ -18,8 +18,8 @@
 //
 // Bit-identity of the recompute: the backward decides "is this row the arg-max" by comparing its
 // recomputed h5 with z, so every forward layer has ONE canonical accumulation order, whatever
-// the tile height or the wave assignment: 128-wide layers sum two independent K-half chains
-// (half0 + half1), the 256-wide layer one chain.
+// the tile height or the wave assignment: layers 1 and 2 sum two independent K-half chains
+// (half0 + half1), layers 3 and 4 run one chain in ascending k.
 #include "ae.h"
 #include <limits.h>
 #include <stdlib.h>
@@ -159,7 +159,8 @@ __device__ __forceinline__ void layer_gemm(const float *in, int s_in, const Pack
     }
 }
 
-constexpr int fwd_kc(int nout) { return nout == 256 ? 1 : 2; }   // the canonical order of a forward layer
+constexpr int fwd_kc(int nout) { return nout == 256 ? 1 : 2; }   // the canonical order of forward layers 1-3
+constexpr int KC_L4 = 1;                                         // layer 4 (K = 256): one chain in ascending k
 
 template <int ROWS> struct EncLds {
     static constexpr int P_FLOATS = ROWS * (256 + 4);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(DeviceAE A, in
         myrb = unit / 4;
     }
     const float sc = A.scale[4][mycol], sh = A.shift[4][mycol];
-    layer_gemm<ROWS, 128, fwd_kc(128)>(bufP, 260, A.enc_fwd[4], scratch, [&](int row, int col, float a) {
+    layer_gemm<ROWS, 128, KC_L4>(bufP, 260, A.enc_fwd[4], scratch, [&](int row, int col, float a) {
         const float v = fmaxf(fmaf(a, sc, sh), 0.f);
         if (n0 + row < n) {
             if (v > mx) { mx = v; arg = n0 + row; cnt = 1; }
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         if (STAMP && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    if (STAMP && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + 9] = __builtin_amdgcn_s_memrealtime();
     constexpr int ROWS = 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     __syncthreads();
     stamp(3);
     // ---- layers 3 + 4 interleaved by halves: h4[:, 128*half ..] feeds K-half `half` of layer 4 ----
-    f32x16 acc4[2][1] = {};
+    f32x16 acc4[1] = {};                              // layer 4: ONE chain over K = 256 (canonical), fed half by half
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         {
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         stamp(4 + 2 * half);
         {
             const float *ar = bufB + (orow + i) * 132 + 4 * h;
-            chain_ring(ar, 0, w4 + (size_t)(kg4 / 2) * half * 64, kg4 / 2, ring, half ? nullptr : w3b, acc4[half]);
+            chain_ring(ar, 0, w4 + (size_t)(kg4 / 2) * half * 64, kg4 / 2, ring, half ? nullptr : w3b, acc4);
         }
         if (half == 0) __syncthreads();               // bufB is rewritten by the second half of layer 3
         stamp(5 + 2 * half);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = orow + acc_row(r, h);
-        const float a = acc4[0][0][r] + acc4[1][0][r];
+        const float a = acc4[0][r];
         const float v = fmaxf(fmaf(a, sc4, sh4), 0.f);
         if (n0 + row < n) {
             if (v > mx) { mx = v; arg = n0 + row; cnt = 1; }
@@ -498,6 +500,220 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         pmax[o] = m; parg[o] = a; pcnt[o] = k;
     }
     stamp(8);
+    if (STAMP && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + 10] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward kernel, ROW-STATIONARY form.  The per-point MLP has no coupling between points, so a wave that owns
+// 32 points can take them through all five layers on its own: no workgroup barrier anywhere before the pool, the
+// A fragment of a k-group is reused for four column blocks (one ds_read_b128 per 16 MFMAs), and the 256-row
+// workgroups (8 waves) fill the chip in ONE round at B = 32 (256 workgroups = 256 CUs) instead of two lockstep
+// rounds of 64-row tiles.  All waves consume the same weight fragments in the same order, so the weights are
+// pre-packed into one linear stream (DeviceAE::enc_stream) that each wave walks through an 8-deep register ring.
+// LDS per wave: its activations [32][<=128] fp32, updated in place layer after layer (16 KB, XOR-swizzled instead
+// of padded so that 8 waves fit), plus a [32][32] scratch (4 KB) through which the 256-wide h4 passes 32 columns
+// at a time straight into layer 4 -- h4 is never materialised.  8 x 20 KB = all 160 KB of the CU.
+// Accumulation orders are the canonical ones (layers 1/2: K-half 0 + K-half 1; layers 3/4: one chain), so the sparse
+// backward's recompute stays bit-identical.
+// ------------------------------------------------------------------------------------------
+constexpr int F3_THREADS = 512;
+constexpr int F3_ROWS = 256;                                   // per workgroup (32 per wave)
+constexpr int F3_WAVE_FLOATS = 32 * 128 + 32 * 32;             // activations + h4 scratch
+constexpr size_t F3_LDS_BYTES = sizeof(float) * 8 * F3_WAVE_FLOATS;
+
+__device__ __forceinline__ int swz128(int row, int col) { return row * 128 + ((((col >> 2) ^ (row & 31)) << 2) | (col & 3)); }
+__device__ __forceinline__ int swz64(int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); }
+__device__ __forceinline__ int swz32(int row, int col) { return row * 32 + ((((col >> 2) ^ ((row >> 1) & 7)) << 2) | (col & 3)); }
+
+__global__ __launch_bounds__(F3_THREADS, 2) void encoder_fwd3_kernel(DeviceAE A, int n, const float *x, const float *pert,
+                                                                    float *adv_out, float *pmax, int *parg, int *pcnt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    float *hbuf = lds + wave * F3_WAVE_FLOATS;                 // [32][64 or 128], swizzled
+    float *cbuf = hbuf + 32 * 128;                             // [32][32], swizzled
+    const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
+    const int n0 = tile * F3_ROWS + wave * 32;                 // first point of this wave
+
+    // the weight stream: fragment j is 64 x float4 at stream + 64 j; ring q[] always holds fragments pos .. pos+3
+    const float4 *stream = reinterpret_cast<const float4 *>(A.enc_stream) + lane;
+    float4 q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = stream[(size_t)j * 64];
+    int pos = 0;
+#define F3_CONSUME(slot, avec, accv)                                                        \
+    do {                                                                                    \
+        accv = __builtin_amdgcn_mfma_f32_32x32x2f32((avec).x, q[slot].x, accv, 0, 0, 0);    \
+        accv = __builtin_amdgcn_mfma_f32_32x32x2f32((avec).y, q[slot].y, accv, 0, 0, 0);    \
+        accv = __builtin_amdgcn_mfma_f32_32x32x2f32((avec).z, q[slot].z, accv, 0, 0, 0);    \
+        accv = __builtin_amdgcn_mfma_f32_32x32x2f32((avec).w, q[slot].w, accv, 0, 0, 0);    \
+        q[slot] = stream[(size_t)(pos + 4 + (slot)) * 64];                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
+
+    // ---- points of this wave (lanes 0..31: one row each) and layer 0 (lane = channel, loop over the 32 rows) ----
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (h == 0) {
+        int p = n0 + i;
+        const bool valid = p < n;
+        p = valid ? p : n - 1;
+        const size_t g = ((size_t)b * n + p) * 3;
+        px = x[g]; py = x[g + 1]; pz = x[g + 2];
+        if (pert) { px += pert[g]; py += pert[g + 1]; pz += pert[g + 2]; }
+        if (adv_out && valid) { adv_out[g] = px; adv_out[g + 1] = py; adv_out[g + 2] = pz; }
+    }
+    {
+        const float wx = A.w0[lane], wy = A.w0[64 + lane], wz = A.w0[128 + lane];
+        const float s0 = A.scale[0][lane], t0 = A.shift[0][lane];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const float rx = __shfl(px, r), ry = __shfl(py, r), rz = __shfl(pz, r);
+            float a = rx * wx;
+            a = fmaf(ry, wy, a);
+            a = fmaf(rz, wz, a);
+            hbuf[swz64(r, lane)] = fmaxf(fmaf(a, s0, t0), 0.f);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // A fragment of k-group t for this lane's row: logical columns 8t + 4h .. +3
+#define F3_A64(t) (*reinterpret_cast<const float4 *>(hbuf + i * 64 + ((((2 * (t) + h) ^ (i & 15))) << 2)))
+#define F3_A128(t) (*reinterpret_cast<const float4 *>(hbuf + i * 128 + ((((2 * (t) + h) ^ (i & 31))) << 2)))
+#define F3_AC(t) (*reinterpret_cast<const float4 *>(cbuf + i * 32 + ((((2 * (t) + h) ^ ((i >> 1) & 7))) << 2)))
+
+    // ---- layer 1: 64 -> 128 ----
+    {
+        f32x16 acc[2][4] = {};
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {               // 2 k-groups (8 fragments) per ring turn
+                const float4 a0 = F3_A64(4 * half + 2 * t2), a1 = F3_A64(4 * half + 2 * t2 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                F3_CONSUME(0, a0, acc[half][0]); F3_CONSUME(1, a0, acc[half][1]); F3_CONSUME(2, a0, acc[half][2]); F3_CONSUME(3, a0, acc[half][3]);
+                pos += 4;
+                F3_CONSUME(0, a1, acc[half][0]); F3_CONSUME(1, a1, acc[half][1]); F3_CONSUME(2, a1, acc[half][2]); F3_CONSUME(3, a1, acc[half][3]);
+                pos += 4;
+            }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int col = cb * 32 + i;
+            const float sc = A.scale[1][col], sh = A.shift[1][col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hbuf[swz128(acc_row(r, h), col)] = fmaxf(fmaf(acc[0][cb][r] + acc[1][cb][r], sc, sh), 0.f);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 2: 128 -> 128 (in place) ----
+    {
+        f32x16 acc[2][4] = {};
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            for (int t2 = 0; t2 < 4; ++t2) {
+                const float4 a0 = F3_A128(8 * half + 2 * t2), a1 = F3_A128(8 * half + 2 * t2 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                F3_CONSUME(0, a0, acc[half][0]); F3_CONSUME(1, a0, acc[half][1]); F3_CONSUME(2, a0, acc[half][2]); F3_CONSUME(3, a0, acc[half][3]);
+                pos += 4;
+                F3_CONSUME(0, a1, acc[half][0]); F3_CONSUME(1, a1, acc[half][1]); F3_CONSUME(2, a1, acc[half][2]); F3_CONSUME(3, a1, acc[half][3]);
+                pos += 4;
+            }
+        __builtin_amdgcn_wave_barrier();                  // every A fragment of h2 has been read: overwrite in place
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int col = cb * 32 + i;
+            const float sc = A.scale[2][col], sh = A.shift[2][col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hbuf[swz128(acc_row(r, h), col)] = fmaxf(fmaf(acc[0][cb][r] + acc[1][cb][r], sc, sh), 0.f);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- layers 3 + 4: h4 passes through cbuf 32 columns at a time ----
+    f32x16 acc4[4] = {};                              // layer 4: one chain per column block over all of K (canonical)
+    for (int c = 0; c < 8; ++c) {
+        f32x16 acc3 = {};
+        for (int t4 = 0; t4 < 4; ++t4) {                  // 4 k-groups (4 fragments) per ring turn
+            const float4 a0 = F3_A128(4 * t4), a1 = F3_A128(4 * t4 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            F3_CONSUME(0, a0, acc3);
+            const float4 a2 = F3_A128(4 * t4 + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            F3_CONSUME(1, a1, acc3);
+            const float4 a3 = F3_A128(4 * t4 + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            F3_CONSUME(2, a2, acc3);
+            F3_CONSUME(3, a3, acc3);
+            pos += 4;
+        }
+        {
+            const int col = c * 32 + i;
+            const float sc = A.scale[3][col], sh = A.shift[3][col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cbuf[swz32(acc_row(r, h), i)] = fmaxf(fmaf(acc3[r], sc, sh), 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const float4 a0 = F3_AC(2 * t2), a1 = F3_AC(2 * t2 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            F3_CONSUME(0, a0, acc4[0]); F3_CONSUME(1, a0, acc4[1]); F3_CONSUME(2, a0, acc4[2]); F3_CONSUME(3, a0, acc4[3]);
+            pos += 4;
+            F3_CONSUME(0, a1, acc4[0]); F3_CONSUME(1, a1, acc4[1]); F3_CONSUME(2, a1, acc4[2]); F3_CONSUME(3, a1, acc4[3]);
+            pos += 4;
+        }
+        __builtin_amdgcn_wave_barrier();                  // cbuf is rewritten by the next chunk
+    }
+#undef F3_CONSUME
+#undef F3_A64
+#undef F3_A128
+#undef F3_AC
+    // ---- pool: this wave's 32 rows per column, then the 8 waves of the workgroup in row order ----
+    float wm[4]; int wa[4], wc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int col = cb * 32 + i;
+        const float sc = A.scale[4][col], sh = A.shift[4][col];
+        float mx = -1.f;
+        int arg = INT_MAX, cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, h);
+            const float v = fmaxf(fmaf(acc4[cb][r], sc, sh), 0.f);
+            if (n0 + row < n) {
+                if (v > mx) { mx = v; arg = n0 + row; cnt = 1; }
+                else if (v == mx) cnt++;
+            }
+        }
+        const float m2 = __shfl_xor(mx, 32);
+        const int a2 = __shfl_xor(arg, 32), c2 = __shfl_xor(cnt, 32);
+        if (m2 > mx) { mx = m2; arg = a2; cnt = c2; }
+        else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += c2; }
+        wm[cb] = mx; wa[cb] = arg; wc[cb] = cnt;
+    }
+    __syncthreads();                                       // all waves are done with their LDS regions
+    float *redm = lds;                                     // [8][128]
+    int *reda = reinterpret_cast<int *>(lds + 1024), *redc = reda + 1024;
+    if (h == 0) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            redm[wave * 128 + cb * 32 + i] = wm[cb]; reda[wave * 128 + cb * 32 + i] = wa[cb]; redc[wave * 128 + cb * 32 + i] = wc[cb];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cidx = threadIdx.x;
+        float m = redm[cidx];
+        int a = reda[cidx], k = redc[cidx];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float m2 = redm[w * 128 + cidx];
+            if (m2 > m) { m = m2; a = reda[w * 128 + cidx]; k = redc[w * 128 + cidx]; }
+            else if (m2 == m) k += redc[w * 128 + cidx];    // later waves hold higher rows: arg stays
+        }
+        const size_t o = ((size_t)b * tiles + tile) * 128 + cidx;
+        pmax[o] = m; parg[o] = a; pcnt[o] = k;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -554,7 +770,7 @@ __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const
         const float zc = z[(size_t)b * 128 + col];
         const int kc = zcnt[(size_t)b * 128 + col];
         const float gz = (kc > 1 ? (1.0f / (float)kc) : 1.0f) * dz[(size_t)b * 128 + col];
-        layer_gemm<ROWS, 128, fwd_kc(128)>(bufP, 260, A.enc_fwd[4], scratch, [&](int row, int c, float a) {
+        layer_gemm<ROWS, 128, KC_L4>(bufP, 260, A.enc_fwd[4], scratch, [&](int row, int c, float a) {
             const float v = fmaxf(fmaf(a, sc, sh), 0.f);
             bufQ[row * 132 + c] = (v == zc && v > 0.f) ? gz * sc : 0.f;
         });
@@ -649,6 +865,8 @@ static int set_lds_attr_once() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::fwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<32>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<32>::fwd_bytes));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)F3_LDS_BYTES));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<true>),
@@ -661,17 +879,19 @@ static int set_lds_attr_once() {
     return GEOADV_OK;
 }
 
-// Forward kernel selection (GEOADV_FWD_ROWS): unset/"2buf" = two-buffer 64-row form (2 workgroups per CU,
+// Forward kernel selection (GEOADV_FWD_ROWS): "256" = row-stationary form (encoder_fwd3_kernel; measured equal to the
+// default at B=32: 102.6 vs 101.5 us -- interleaving its MFMAs over the four independent accumulators made it SLOWER,
+// 111 us); unset/"2buf" = two-buffer 64-row form (2 workgroups per CU,
 // default); "64" = single-pass 64-row form (1 per CU); "32" = 32-row form (2 per CU, K split over waves).
-static int fwd_variant() {          // 0: two-buffer, 64, 32
+static int fwd_variant() {          // 3: row-stationary (256 rows), 0: two-buffer (64), 64, 32
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("GEOADV_FWD_ROWS");
-        v = !e ? 0 : (atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : 0));
+        v = !e ? 0 : (atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : (atoi(e) == 256 ? 3 : 0)));
     }
     return v;
 }
-int encoder_fwd_rows() { return fwd_variant() == 32 ? 32 : 64; }
+int encoder_fwd_rows() { return fwd_variant() == 3 ? F3_ROWS : (fwd_variant() == 32 ? 32 : 64); }
 int encoder_tiles(int n) { return cdiv(n, encoder_fwd_rows()); }
 
 // pmax/parg/pcnt: [b][tiles][128]
@@ -679,7 +899,10 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
                        int *parg, int *pcnt, hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
-    if (fwd_variant() == 0)
+    if (fwd_variant() == 3)
+        encoder_fwd3_kernel<<<dim3(encoder_tiles(A.n_points), b), F3_THREADS, F3_LDS_BYTES, stream>>>(
+            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
+    else if (fwd_variant() == 0)
         encoder_fwd2_kernel<false><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
             A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr);
     else if (fwd_variant() == 64)
