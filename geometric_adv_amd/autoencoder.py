@@ -25,9 +25,10 @@ class PointNetAE:
     """PointNet-style encoder + FC decoder with frozen weights on one GPU."""
 
     def __init__(self, weights, n_points, ae_name=W.AE_NAME, device=None):
-        """weights: dict of TF-variable-name -> array (see weights.py) or a path to such an .npz."""
+        """weights: dict of TF-variable-name -> array (see weights.py), or a path to such an .npz, or a
+        TF V2 checkpoint prefix like '<ae_dir>/models.ckpt-500' (read without TensorFlow, tf_checkpoint.py)."""
         if isinstance(weights, str):
-            weights = W.load_npz(weights)
+            weights = W.load(weights, ae_name)
         self.n_points = int(n_points)
         self.bneck = 128
         self.device = torch.device(device if device is not None else "cuda:0")

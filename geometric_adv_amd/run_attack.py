@@ -2,8 +2,9 @@
 <ae_folder>/eval), same outputs per shape class (adversarial_metrics.npy [W,n,5], adversarial_pc_input.npy,
 adversarial_pc_recon.npy, dist_weight.npy, attack_stats.txt).
 
-Differences forced by the environment: the victim's weights come from <ae_folder>/weights.npz (TF variable names,
-see weights.py) instead of a TF1 checkpoint, and the class list of the pickled Configuration (conf.class_names,
+Differences forced by the environment: the victim's weights are read from <ae_folder>/models.ckpt-<restore_epoch>
+by a TF-free reader of the V2 checkpoint format (tf_checkpoint.py; <ae_folder>/weights.npz with the same variable
+names is the fallback), and the class list of the pickled Configuration (conf.class_names,
 which needs tflearn to unpickle) is passed with --class_names (default: all of pc_classes).  Multi-GPU: launch with
 torchrun; every rank attacks a contiguous run of batches and the metrics are all-gathered (dist.attack_sharded).
 
@@ -28,6 +29,7 @@ def build_parser():
     p.add_argument('--num_iterations_thresh', type=int, default=400)
     p.add_argument('--batch_size', type=int, default=10)
     p.add_argument('--ae_folder', type=str, default='log/autoencoder_victim')
+    p.add_argument('--restore_epoch', type=int, default=500, help='Restore epoch of a trained autoencoder [default: 500]')
     p.add_argument('--attack_pc_idx', type=str, default='log/autoencoder_victim/eval/sel_idx_rand_100_test_set_13l.npy')
     p.add_argument('--target_pc_idx_type', type=str, default='chamfer_nn_complete')
     p.add_argument('--num_pc_for_attack', type=int, default=25)
@@ -37,6 +39,13 @@ def build_parser():
     p.add_argument('--top_dir', type=str, default='.', help='root that --ae_folder / --attack_pc_idx are relative to')
     p.add_argument('--class_names', nargs='+', default=None, help='classes to attack / target [default: all]')
     return p
+
+
+def victim_weights_path(ae_dir, restore_epoch):
+    """<ae_dir>/models.ckpt-<epoch> (the TF V2 checkpoint the reference restores, adversary_autoencoder.py:48 --
+    read without TensorFlow by tf_checkpoint.py) when it exists, else <ae_dir>/weights.npz."""
+    prefix = osp.join(ae_dir, 'models.ckpt-%d' % int(restore_epoch))
+    return prefix if osp.exists(prefix + '.index') else osp.join(ae_dir, 'weights.npz')
 
 
 def main(argv=None):
@@ -69,7 +78,7 @@ def main(argv=None):
 
     classes = list(flags.class_names) if flags.class_names else [str(c) for c in pc_classes]
     conf = Configuration(batch_size=flags.batch_size, n_points=point_clouds.shape[1],
-                         weights=osp.join(flags.top_dir, flags.ae_folder, 'weights.npz'),
+                         weights=victim_weights_path(osp.join(flags.top_dir, flags.ae_folder), flags.restore_epoch),
                          loss_adv_type=flags.loss_adv_type, loss_dist_type=flags.loss_dist_type,
                          dist_weight_list=[float(w) for w in flags.dist_weight_list],
                          max_point_pert_weight=flags.max_point_pert_weight, max_point_dist_weight=flags.max_point_dist_weight,

@@ -81,6 +81,22 @@ def load_npz(path):
         return {k.replace("__", "/"): z[k] for k in z.files}
 
 
+def load(path, ae_name=AE_NAME, restore_epoch=None):
+    """Victim weights from wherever they live: an .npz (save_npz), a TF V2 checkpoint prefix
+    ('.../models.ckpt-500', i.e. the argument of saver.restore in adversary_autoencoder.py:48), or a model
+    directory plus `restore_epoch` (conf.ae_dir / conf.ae_restore_epoch, adv_ae.py:76)."""
+    import os
+    from . import tf_checkpoint
+    if restore_epoch is not None:
+        return tf_checkpoint.restore_ae_weights(path, restore_epoch, ae_name)
+    if path.endswith(".npz"):
+        return load_npz(path)
+    if os.path.exists(path + ".index"):
+        wanted = set(variable_names(ae_name))
+        return tf_checkpoint.load_checkpoint(path, lambda n: n in wanted)
+    raise FileNotFoundError("%s is neither an .npz nor a TF V2 checkpoint prefix" % path)
+
+
 def canonical(weights, n_points, ae_name=AE_NAME):
     """Validate and reshape to what geoadv_ae_create takes: lists of contiguous float32 arrays."""
     ed, dd = enc_dims(), dec_dims(n_points)

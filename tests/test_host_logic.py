@@ -101,3 +101,55 @@ def test_attack_model_gradient_matches_finite_differences():
             vals.append((fs["loss_adv"] + am.w * fs["loss_dist"]).sum())
         fd = (vals[0] - vals[1]) / (2 * eps)
         np.testing.assert_allclose((g * d).sum(), fd, rtol=2e-3)
+
+
+# ---------------------------------------------------------------- TF V2 checkpoint reader
+def test_crc32c_known_answers():
+    from geometric_adv_amd import tf_checkpoint as T
+    assert T.crc32c(b"123456789") == 0xE3069283                       # the CRC-32C check value
+    assert T.crc32c(bytes(32)) == 0x8A9136AA                          # RFC 3720 B.4
+    assert T.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    rng = np.random.default_rng(5)
+    for n in (16384, 70001, (1 << 20) + 77):                          # lockstep/vectorised path == scalar recurrence
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert T.crc32c(b) == T._crc_scalar(b, 0xFFFFFFFF) ^ 0xFFFFFFFF
+    assert T.unmask_crc(T.mask_crc(0xDEADBEEF)) == 0xDEADBEEF
+
+
+def test_tf_checkpoint_round_trip(tmp_path):
+    from geometric_adv_amd import tf_checkpoint as T, weights as W
+    w = W.randomized_weights(256)
+    extra = dict(w)
+    extra["autoencoder/encoder_conv_layer_0/W/Adam"] = np.zeros((1, 1, 3, 64), np.float32)    # optimizer slots are skipped
+    extra["beta1_power"] = np.array(0.5, np.float32)
+    extra["global_step"] = np.array(500, np.int64)
+    prefix = str(tmp_path / "models.ckpt-500")
+    T.write_checkpoint(prefix, extra, block_size=512)                 # several data blocks -> index block is exercised
+    names = dict(T.list_variables(prefix))
+    assert names["global_step"] == () and names["autoencoder/decoder_fc_2/W"] == (256, 768)
+    got = T.restore_ae_weights(str(tmp_path), 500)
+    assert set(got) == set(W.variable_names())
+    for k in got:
+        assert got[k].dtype == w[k].dtype and np.array_equal(got[k], w[k])
+    assert np.array_equal(W.load(prefix)["autoencoder/decoder_fc_0/b"], w["autoencoder/decoder_fc_0/b"])
+    assert T.load_checkpoint(prefix)["global_step"] == 500
+    # corruption is detected: flip one byte of a tensor, then one of the index
+    data = T.shard_path(prefix, 0, 1)
+    raw = bytearray(open(data, "rb").read()); raw[100] ^= 1; open(data, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        T.load_checkpoint(prefix)
+    raw[100] ^= 1; open(data, "wb").write(bytes(raw))
+    idx = bytearray(open(prefix + ".index", "rb").read()); idx[10] ^= 1; open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(ValueError, match="checksum"):
+        T.read_index(prefix)
+    with pytest.raises(ValueError, match="magic"):
+        open(prefix + ".index", "wb").write(bytes(idx[:-1]) + b"\x00")
+        T.read_index(prefix)
+
+
+def test_tf_checkpoint_snappy_block():
+    from geometric_adv_amd import tf_checkpoint as T
+    # literal "abcd", copy(offset 4, len 8) via a 1-byte-offset tag, literal "xyz"  -> "abcdabcdabcdxyz"
+    comp = bytes([15, (4 - 1) << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4]) + bytes([(3 - 1) << 2]) + b"xyz"
+    assert T._snappy_decompress(comp) == b"abcdabcdabcdxyz"
