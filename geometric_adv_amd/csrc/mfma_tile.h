@@ -1,0 +1,150 @@
+// MFMA tile helpers shared by the encoder kernels (encoder.hip) and the training kernels (train.hip):
+// fragment loads, the B-fragment register ring, and layer_gemm = [ROWS x K] LDS tile @ packed weights.
+#pragma once
+#include "ae.h"
+
+namespace geoadv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ENC_THREADS = 512;                 // 8 waves
+
+// accumulator register -> row inside a 32-row block (C/D layout of the 32x32 MFMA shapes)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// One chain over k-groups [t0, t1) (a k-group = 8 k values = 4 MFMA k-steps); RM row blocks of
+// 32 share each B fragment.  A fragments: ds_read_b128 from the LDS activation tile (row stride
+// s_in = width + 4 floats keeps them bank-conflict free); B fragments: one coalesced 1 KiB
+// global_load_dwordx4 per k-group from the packed weights, prefetched one group ahead.
+// A ring refill; the sched_barrier after each call keeps it between the MFMA groups (a volatile load would be
+// followed by vmcnt(0); without the barrier the scheduler clusters all four refills at the loop end).
+__device__ __forceinline__ float4 ld_pinned(const float4 *p) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 t = *reinterpret_cast<const v4 *>(p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
+template <int RM>
+__device__ __forceinline__ void mfma_group(const float4 (&a)[RM], const float4 &b, f32x16 (&acc)[RM]) {
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+        acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].x, b.x, acc[rm], 0, 0, 0);
+        acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].y, b.y, acc[rm], 0, 0, 0);
+        acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].z, b.z, acc[rm], 0, 0, 0);
+        acc[rm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm].w, b.w, acc[rm], 0, 0, 0);
+    }
+}
+
+// Chain lengths (t1 - t0) are multiples of 4 for every layer of the template architecture.
+// Software pipeline: a wave consumes one 1 KiB B fragment per ~512 cycles (two waves share a
+// SIMD's MFMA pipe) while an L2 hit takes ~800 cycles under load, so B fragments run through a
+// 4-slot register ring (4 loads in flight); A fragments (LDS, ~130 cycles) are fetched one
+// k-group ahead.
+template <int RM>
+__device__ __forceinline__ void gemm_chain(const float *in, int s_in, int row0, const PackedLayer &L, int cb, int t0,
+                                           int t1, f32x16 (&acc)[RM]) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5, i = lane & 31;
+    const int kg = L.K >> 3;
+    const float4 *bp = reinterpret_cast<const float4 *>(L.w) + (size_t)cb * kg * 64 + lane;
+    const float *ar[RM];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) ar[rm] = in + (row0 + rm * 32 + i) * s_in + 4 * h;
+    float4 b0 = bp[(size_t)t0 * 64], b1 = bp[(size_t)(t0 + 1) * 64], b2 = bp[(size_t)(t0 + 2) * 64], b3 = bp[(size_t)(t0 + 3) * 64];
+    float4 a0[RM], a1[RM];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * t0);
+    for (int t = t0; t < t1; t += 4) {
+        // refills are unconditional (clamped index; the last iteration re-reads its own fragments): a branch
+        // around a load makes the compiler drain the ring with vmcnt(0) every four k-groups
+        const int tn = t + 4 < t1 ? t + 4 : t;
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 1));
+        __builtin_amdgcn_sched_barrier(0);           // A prefetch stays ahead of the MFMA group
+        mfma_group<RM>(a0, b0, acc);
+        b0 = ld_pinned(bp + (size_t)tn * 64);
+        __builtin_amdgcn_sched_barrier(0);           // pin the refill between the MFMA groups
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<RM>(a1, b1, acc);
+        b1 = ld_pinned(bp + (size_t)(tn + 1) * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<RM>(a0, b2, acc);
+        b2 = ld_pinned(bp + (size_t)(tn + 2) * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * tn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<RM>(a1, b3, acc);
+        b3 = ld_pinned(bp + (size_t)(tn + 3) * 64);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// out tile [ROWS][NOUT] = in tile [ROWS][K] @ W, handed element-wise to epi(row, col, value).
+// KC = number of canonical K parts (independent chains summed part0 + part1 + ...); KC == 0
+// picks whatever keeps all 8 waves busy.  Must be called by every wave of the workgroup.
+template <int ROWS, int NOUT, int KC_REQ, class Epi>
+__device__ __forceinline__ void layer_gemm(const float *in, int s_in, const PackedLayer &L, float *scratch, Epi epi) {
+    constexpr int CB = NOUT / 32, RB = ROWS / 32;
+    constexpr bool RM2 = (CB * RB > 8);                      // 64 rows x 256 columns: two row blocks per wave
+    constexpr int UNITS = RM2 ? CB : CB * RB;                // (column block, row block) units handed to waves
+    constexpr int SPARE = 8 / UNITS;                         // waves available per unit
+    constexpr int KC = KC_REQ > 0 ? KC_REQ : SPARE;
+    constexpr int KS = (SPARE >= KC) ? KC : 1;               // K parts computed by different waves, or all by one
+    static_assert(KS == KC || KS == 1, "bad K split");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = lane >> 5, i = lane & 31;
+    const int unit = wave % UNITS, ks = wave / UNITS;
+    const int cb = unit % CB, rb = RM2 ? 0 : unit / CB;
+    const int kg = L.K >> 3;
+    constexpr int RM = RM2 ? 2 : 1;
+    f32x16 acc[RM] = {};
+    if (KS == KC) {
+        if (ks < KS) gemm_chain<RM>(in, s_in, rb * 32, L, cb, ks * kg / KC, (ks + 1) * kg / KC, acc);
+        if (KC > 1) {
+            if (ks > 0 && ks < KS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scratch[(((ks - 1) * UNITS + unit) * 16 + r) * 64 + lane] = acc[0][r];
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int p = 1; p < KC; ++p)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][r] += scratch[(((p - 1) * UNITS + unit) * 16 + r) * 64 + lane];
+            }
+        }
+    } else if (ks == 0) {   // one wave walks the canonical parts one after the other
+        gemm_chain<RM>(in, s_in, rb * 32, L, cb, 0, kg / KC, acc);
+#pragma unroll
+        for (int p = 1; p < KC; ++p) {
+            f32x16 part[RM] = {};
+            gemm_chain<RM>(in, s_in, rb * 32, L, cb, p * kg / KC, (p + 1) * kg / KC, part);
+#pragma unroll
+            for (int rm = 0; rm < RM; ++rm) acc[rm] += part[rm];
+        }
+    }
+    if (ks == 0) {
+        const int col = cb * 32 + i;
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi((rb + rm) * 32 + acc_row(r, h), col, acc[rm][r]);
+    }
+}
+
+// The output column layer_gemm<ROWS, NOUT, *> hands to the calling lane's epilogue (constant per lane).
+template <int ROWS, int NOUT>
+__device__ __forceinline__ int layer_gemm_lane_col() {
+    constexpr int CB = NOUT / 32, RB = ROWS / 32;
+    constexpr int UNITS = (CB * RB > 8) ? CB : CB * RB;
+    const int wave = threadIdx.x >> 6;
+    return ((wave % UNITS) % CB) * 32 + (threadIdx.x & 31);
+}
+
+}  // namespace geoadv

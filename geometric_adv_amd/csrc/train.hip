@@ -1,0 +1,1000 @@
+// One TRAINING step of the victim auto-encoder on gfx950.
+//
+// Reference: PointNetAutoEncoder (src/pointnet_ae.py:71-99: loss = reduce_mean(dist1) + reduce_mean(dist2) of
+// nn_distance(x_reconstr, gt), AdamOptimizer(lr).minimize(loss)) driven by AutoEncoder.partial_fit
+// (src/autoencoder.py:105-125, tflearn is_training(True)), architecture src/ae_templates.py:22-33, defaults
+// default_train_params (:43-51: batch 50, lr 0.0005).  In training mode tflearn's batch_normalization uses the
+// statistics of the batch (tf.nn.moments over all B*N rows) and differentiates through them, so -- unlike the
+// attack path -- a layer cannot start before the previous one has finished on EVERY row.  The step is therefore
+// layer-by-layer with the pre-BN activations a_i kept in HBM (288 MB at B = 50; the card has 288 GB), and every
+// kernel fuses what the dependency structure allows:
+//   forward layer i   : h_i = relu(a_{i-1} * s + t) formed while loading the tile, [64 x C_i] @ W_i on
+//                       v_mfma_f32_32x32x2_f32, a_i stored, per-tile (sum a, sum a^2) for the batch statistics;
+//   backward layer i  : da_i from (dy_i, a_i) on load; dW_i += h_i^T @ da_i accumulated in registers across the
+//                       tiles of a persistent workgroup (MFMA, both operands from LDS); dy_{i-1} =
+//                       (da_i @ W_i^T) * [h_i > 0] (MFMA, packed W_i^T) with the per-tile sums the BN backward
+//                       of layer i-1 needs, all in ONE kernel per layer.
+// All reductions run in a fixed order (per-tile partials, then a double-precision pass), so a step is
+// deterministic.  Parity: oracle/train_model.py (numpy fp64; unpinned against TF, see there).
+#include "ae.h"
+#include "mfma_tile.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace geoadv {
+
+constexpr int TR_THREADS = 512;
+constexpr int TR_ROWS = 64;
+constexpr float BN_EPS = 1e-5f;
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float *in;             // a_{i-1} [R][CIN]   (x [R][3] for layer 0)
+    const float *pscale, *pshift;   // BN(batch) of the previous layer folded: h = relu(a * s + t)
+    PackedLayer W;               // packed W_i (layers >= 1);  layer 0: W.w = canonical [3][64]
+    const float *bias;           // b_i
+    float *out;                  // a_i [R][COUT]
+    float2 *psum;                // [tiles][COUT] (sum a, sum a^2) over the 64 rows of the tile
+};
+
+__global__ __launch_bounds__(TR_THREADS) void train_fwd0_kernel(FwdArgs A) {
+    // layer 0 (fan-in 3) on the VALU: thread = (column, group of 8 rows)
+    __shared__ float pts[TR_ROWS * 3];
+    __shared__ float2 red[8][64];
+    const size_t row0 = (size_t)blockIdx.x * TR_ROWS;
+    if (threadIdx.x < TR_ROWS * 3) pts[threadIdx.x] = A.in[row0 * 3 + threadIdx.x];
+    __syncthreads();
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const float w0 = A.W.w[c], w1 = A.W.w[64 + c], w2 = A.W.w[128 + c], b = A.bias[c];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = g * 8 + r;
+        const float a = fmaf(pts[row * 3 + 2], w2, fmaf(pts[row * 3 + 1], w1, pts[row * 3] * w0)) + b;
+        A.out[(row0 + row) * 64 + c] = a;
+        s1 += a;
+        s2 = fmaf(a, a, s2);
+    }
+    red[g][c] = make_float2(s1, s2);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float2 t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { t.x += red[k][c].x; t.y += red[k][c].y; }
+        A.psum[(size_t)blockIdx.x * 64 + c] = t;
+    }
+}
+
+// h tile = relu(a * s + t) -> LDS [64][C + 4]
+template <int C>
+__device__ __forceinline__ void load_activated_tile(const float *a, size_t row0, const float *scale, const float *shift,
+                                                    float *lds) {
+    constexpr int Q = C / 4;                          // float4 per row; divides TR_THREADS
+    const int c4 = threadIdx.x % Q, r0 = threadIdx.x / Q;
+    const float4 s = reinterpret_cast<const float4 *>(scale)[c4], t = reinterpret_cast<const float4 *>(shift)[c4];
+#pragma unroll
+    for (int r = r0; r < TR_ROWS; r += TR_THREADS / Q) {
+        const float4 v = reinterpret_cast<const float4 *>(a + (row0 + r) * C)[c4];
+        float4 h;
+        h.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f); h.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
+        h.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f); h.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+        *reinterpret_cast<float4 *>(lds + r * (C + 4) + 4 * c4) = h;
+    }
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(TR_THREADS) void train_fwd_kernel(FwdArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    float *tile = lds;                                   // [64][CIN + 4]
+    float2 *red = reinterpret_cast<float2 *>(lds + TR_ROWS * (CIN + 4));   // [2][COUT]
+    const size_t row0 = (size_t)blockIdx.x * TR_ROWS;
+    load_activated_tile<CIN>(A.in, row0, A.pscale, A.pshift, tile);
+    __syncthreads();
+    const int col = layer_gemm_lane_col<TR_ROWS, COUT>();
+    const float b = A.bias[col];
+    float s1 = 0.f, s2 = 0.f;
+    int rb_seen = 0;
+    layer_gemm<TR_ROWS, COUT, 1>(tile, CIN + 4, A.W, nullptr, [&](int row, int c, float v) {
+        const float a = v + b;
+        A.out[(row0 + row) * COUT + c] = a;
+        s1 += a;
+        s2 = fmaf(a, a, s2);
+        rb_seen = row >> 5;
+    });
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    constexpr bool BOTH = (COUT / 32) * 2 > 8;            // one wave covers both row blocks (COUT = 256)
+    if (BOTH) {
+        if ((threadIdx.x & 63) < 32) A.psum[(size_t)blockIdx.x * COUT + col] = make_float2(s1, s2);
+    } else {
+        if ((threadIdx.x & 63) < 32) red[rb_seen * COUT + col] = make_float2(s1, s2);
+        __syncthreads();
+        if (threadIdx.x < COUT) {
+            const float2 p = red[threadIdx.x], q = red[COUT + threadIdx.x];
+            A.psum[(size_t)blockIdx.x * COUT + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
+        }
+    }
+}
+
+// Batch statistics of one layer from the per-tile partials (fixed order, double), the folded BN constants,
+// and tflearn's moving-average update (assign_moving_average, zero_debias=False).
+struct BnArgs {
+    const float2 *psum; int tiles; int C; double inv_rows;
+    const float *gamma, *beta;
+    float *mean, *inv_std, *scale, *shift;    // batch mean, rsqrt(var + eps), gamma * inv_std, beta - mean * scale
+    float *mov_mean, *mov_var; float one_minus_decay;
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnArgs A) {
+    __shared__ double r1[8][32], r2[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = g; t < A.tiles; t += 8) {
+        const float2 p = A.psum[(size_t)t * A.C + c];
+        s1 += p.x; s2 += p.y;
+    }
+    r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
+    __syncthreads();
+    if (g == 0) {
+        for (int k = 1; k < 8; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
+        const double mean = s1 * A.inv_rows;
+        double var = s2 * A.inv_rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float istd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+        const float sc = A.gamma[c] * istd;
+        A.mean[c] = (float)mean; A.inv_std[c] = istd; A.scale[c] = sc;
+        A.shift[c] = A.beta[c] - (float)mean * sc;
+        A.mov_mean[c] -= (A.mov_mean[c] - (float)mean) * A.one_minus_decay;
+        A.mov_var[c] -= (A.mov_var[c] - (float)var) * A.one_minus_decay;
+    }
+}
+
+// Symmetric max-pool of h5 = relu(a4 * s + t) over the points of each cloud: values are >= 0, so the integer
+// order of their bit patterns is their order and atomicMax (order independent) is exact.  Second pass: number of
+// rows attaining the maximum (TF's _MinOrMaxGrad splits the gradient equally among them).
+struct PoolArgs { const float *a4; const float *scale, *shift; int n_points; int *zbits; int *cnt; };
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void train_pool_kernel(PoolArgs A) {
+    __shared__ int red[8][128];
+    const size_t row0 = (size_t)blockIdx.x * TR_ROWS;
+    const int cloud = (int)(row0 / A.n_points);
+    const int c4 = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const float4 s = reinterpret_cast<const float4 *>(A.scale)[c4], t = reinterpret_cast<const float4 *>(A.shift)[c4];
+    int4 z = make_int4(0, 0, 0, 0);
+    if (COUNT) z = reinterpret_cast<const int4 *>(A.zbits + cloud * 128)[c4];
+    int4 m = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float4 v = reinterpret_cast<const float4 *>(A.a4 + (row0 + g * 8 + r) * 128)[c4];
+        const int hx = __float_as_int(fmaxf(fmaf(v.x, s.x, t.x), 0.f)), hy = __float_as_int(fmaxf(fmaf(v.y, s.y, t.y), 0.f));
+        const int hz = __float_as_int(fmaxf(fmaf(v.z, s.z, t.z), 0.f)), hw = __float_as_int(fmaxf(fmaf(v.w, s.w, t.w), 0.f));
+        if (COUNT) { m.x += hx == z.x; m.y += hy == z.y; m.z += hz == z.z; m.w += hw == z.w; }
+        else { m.x = max(m.x, hx); m.y = max(m.y, hy); m.z = max(m.z, hz); m.w = max(m.w, hw); }
+    }
+    *reinterpret_cast<int4 *>(&red[g][4 * c4]) = m;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        int v = red[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v = COUNT ? v + red[k][threadIdx.x] : max(v, red[k][threadIdx.x]);
+        if (COUNT) { if (v) atomicAdd(A.cnt + cloud * 128 + threadIdx.x, v); }
+        else atomicMax(A.zbits + cloud * 128 + threadIdx.x, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder (B rows only: VALU)
+// ------------------------------------------------------------------------------------------------
+// out[b][n] = act(in[b][:] @ W[:, n] + bias[n]); grid = B, block = NOUT (256)
+template <int K, bool RELU>
+__global__ __launch_bounds__(256) void fc_fwd_kernel(const float *in, const float *W, const float *bias, float *out, int nout) {
+    __shared__ float x[K];
+    if (threadIdx.x < K) x[threadIdx.x] = in[(size_t)blockIdx.x * K + threadIdx.x];
+    __syncthreads();
+    const int n = threadIdx.x;
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < K; k += 2) {
+        acc0 = fmaf(x[k], W[(size_t)k * nout + n], acc0);
+        acc1 = fmaf(x[k + 1], W[(size_t)(k + 1) * nout + n], acc1);
+    }
+    const float v = acc0 + acc1 + bias[n];
+    out[(size_t)blockIdx.x * nout + n] = RELU ? fmaxf(v, 0.f) : v;
+}
+
+// recon[b][n] = d2[b][:] @ V2[:, n] + c2[n]; grid = (ceil(n3/128), ceil(B/16)), block 128
+__global__ __launch_bounds__(128) void fc_out_fwd_kernel(const float *d2, const float *V2, const float *c2, float *out, int batch, int n3) {
+    __shared__ __align__(16) float x[16][256];
+    const int b0 = blockIdx.y * 16;
+    for (int e = threadIdx.x; e < 16 * 256; e += 128) {
+        const int bb = e >> 8;
+        x[bb][e & 255] = b0 + bb < batch ? d2[(size_t)(b0 + bb) * 256 + (e & 255)] : 0.f;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 128 + threadIdx.x;
+    if (n >= n3) return;
+    float acc[16] = {};
+    for (int k = 0; k < 256; k += 4) {
+        const float w0 = V2[(size_t)k * n3 + n], w1 = V2[(size_t)(k + 1) * n3 + n];
+        const float w2 = V2[(size_t)(k + 2) * n3 + n], w3 = V2[(size_t)(k + 3) * n3 + n];
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) {
+            const float4 xv = *reinterpret_cast<const float4 *>(&x[bb][k]);
+            acc[bb] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[bb]))));
+        }
+    }
+    const float c = c2[n];
+#pragma unroll
+    for (int bb = 0; bb < 16; ++bb)
+        if (b0 + bb < batch) out[(size_t)(b0 + bb) * n3 + n] = acc[bb] + c;
+}
+
+// loss = (sum dist1 + sum dist2) / (B * N): tf.reduce_mean over all elements of each direction (pointnet_ae.py:77)
+__global__ __launch_bounds__(1024) void chamfer_loss_kernel(const float *d1, const float *d2, size_t count, double inv, float *loss) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (size_t e = threadIdx.x; e < count; e += 1024) s += (double)d1[e] + (double)d2[e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * inv);
+}
+
+__global__ void fill_f32_kernel(float *p, float v, size_t count) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) p[e] = v;
+}
+
+// dV2[k][n] = sum_b d2[b][k] * g[b][n]; dc2[n] = sum_b g[b][n].  grid = (ceil(n3/128), 256/32), block 128
+__global__ __launch_bounds__(128) void fc_out_bwd_w_kernel(const float *d2, const float *g, float *dV2, float *dc2, int batch, int n3) {
+    extern __shared__ __align__(16) float xs[];            // [batch][32]
+    const int k0 = blockIdx.y * 32;
+    for (int e = threadIdx.x; e < batch * 32; e += 128) xs[e] = d2[(size_t)(e >> 5) * 256 + k0 + (e & 31)];
+    __syncthreads();
+    const int n = blockIdx.x * 128 + threadIdx.x;
+    if (n >= n3) return;
+    float acc[32] = {};
+    float gs = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const float gv = g[(size_t)b * n3 + n];
+        gs += gv;
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 4) {
+            const float4 xv = *reinterpret_cast<const float4 *>(&xs[b * 32 + kk]);
+            acc[kk] = fmaf(xv.x, gv, acc[kk]); acc[kk + 1] = fmaf(xv.y, gv, acc[kk + 1]);
+            acc[kk + 2] = fmaf(xv.z, gv, acc[kk + 2]); acc[kk + 3] = fmaf(xv.w, gv, acc[kk + 3]);
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) dV2[(size_t)(k0 + kk) * n3 + n] = acc[kk];
+    if (blockIdx.y == 0) dc2[n] = gs;
+}
+
+// dd2[b][k] = [d2[b][k] > 0] * sum_n g[b][n] * V2[k][n]; grid = (256/4, ceil(B/8)), block 256
+__global__ __launch_bounds__(256) void fc_out_bwd_x_kernel(const float *g, const float *V2, const float *d2, float *dd2, int batch, int n3) {
+    __shared__ float red[4][32];
+    const int k0 = blockIdx.x * 4, b0 = blockIdx.y * 8;
+    float acc[4][8] = {};
+    for (int n = threadIdx.x; n < n3; n += 256) {
+        float w[4], gv[8];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) w[kk] = V2[(size_t)(k0 + kk) * n3 + n];
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) gv[bb] = b0 + bb < batch ? g[(size_t)(b0 + bb) * n3 + n] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) acc[kk][bb] = fmaf(w[kk], gv[bb], acc[kk][bb]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            float v = acc[kk][bb];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) red[wave][kk * 8 + bb] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int kk = threadIdx.x >> 3, bb = threadIdx.x & 7;
+        if (b0 + bb < batch) {
+            const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            const size_t o = (size_t)(b0 + bb) * 256 + k0 + kk;
+            dd2[o] = d2[o] > 0.f ? v : 0.f;
+        }
+    }
+}
+
+// Small dense layer backward: dW[k][n] = sum_b in[b][k] * dout[b][n] (grid.x = k), db[n] = sum_b dout[b][n]
+__global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float *in, const float *dout, float *dW, float *db, int batch, int K) {
+    const int k = blockIdx.x, n = threadIdx.x;
+    float acc = 0.f, s = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const float d = dout[(size_t)b * 256 + n];
+        acc = fmaf(in[(size_t)b * K + k], d, acc);
+        s += d;
+    }
+    dW[(size_t)k * 256 + n] = acc;
+    if (k == 0) db[n] = s;
+}
+
+// din[b][k] = mask * sum_n dout[b][n] * W[k][n]; grid = B, block = K threads (one wave-strided row each)
+template <bool MASK>
+__global__ __launch_bounds__(256) void fc_bwd_x_kernel(const float *dout, const float *W, const float *act_in, float *din, int K) {
+    __shared__ __align__(16) float d[256];
+    d[threadIdx.x] = dout[(size_t)blockIdx.x * 256 + threadIdx.x];
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    const float4 *w = reinterpret_cast<const float4 *>(W + (size_t)k * 256);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+    for (int n4 = 0; n4 < 64; n4 += 2) {
+        const float4 w0 = w[n4], w1 = w[n4 + 1];
+        const float4 d0 = *reinterpret_cast<const float4 *>(&d[4 * n4]), d1 = *reinterpret_cast<const float4 *>(&d[4 * n4 + 4]);
+        a0 = fmaf(w0.w, d0.w, fmaf(w0.z, d0.z, fmaf(w0.y, d0.y, fmaf(w0.x, d0.x, a0))));
+        a1 = fmaf(w1.w, d1.w, fmaf(w1.z, d1.z, fmaf(w1.y, d1.y, fmaf(w1.x, d1.x, a1))));
+    }
+    const float v = a0 + a1;
+    const size_t o = (size_t)blockIdx.x * K + k;
+    din[o] = (!MASK || act_in[o] > 0.f) ? v : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder backward
+// ------------------------------------------------------------------------------------------------
+// Gradient entering layer 4's BN output: dy4[r][c] = [h5 > 0 and h5 == z] * dz[b][c] / cnt[b][c]   (max-pool
+// gradient with TF's equal split, then ReluGrad), stored densely, plus the per-tile sums of the BN backward.
+struct PoolBwdArgs {
+    const float *a4; const float *scale, *shift, *mean, *inv_std; int n_points;
+    const int *zbits, *cnt; const float *dz;
+    float *dy; float2 *qsum;
+};
+
+__global__ __launch_bounds__(256) void train_pool_bwd_kernel(PoolBwdArgs A) {
+    __shared__ float2 red[8][128];
+    const size_t row0 = (size_t)blockIdx.x * TR_ROWS;
+    const int cloud = (int)(row0 / A.n_points);
+    const int c4 = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const float4 s = reinterpret_cast<const float4 *>(A.scale)[c4], t = reinterpret_cast<const float4 *>(A.shift)[c4];
+    const float4 mu = reinterpret_cast<const float4 *>(A.mean)[c4], is = reinterpret_cast<const float4 *>(A.inv_std)[c4];
+    const int4 z = reinterpret_cast<const int4 *>(A.zbits + cloud * 128)[c4];
+    const int4 cn = reinterpret_cast<const int4 *>(A.cnt + cloud * 128)[c4];
+    const float4 dz = reinterpret_cast<const float4 *>(A.dz + cloud * 128)[c4];
+    const float gx = z.x > 0 ? dz.x / (float)cn.x : 0.f, gy = z.y > 0 ? dz.y / (float)cn.y : 0.f;
+    const float gz = z.z > 0 ? dz.z / (float)cn.z : 0.f, gw = z.w > 0 ? dz.w / (float)cn.w : 0.f;
+    float q1[4] = {}, q2[4] = {};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const size_t row = row0 + g * 8 + r;
+        const float4 v = reinterpret_cast<const float4 *>(A.a4 + row * 128)[c4];
+        float4 dy;
+        dy.x = __float_as_int(fmaxf(fmaf(v.x, s.x, t.x), 0.f)) == z.x ? gx : 0.f;
+        dy.y = __float_as_int(fmaxf(fmaf(v.y, s.y, t.y), 0.f)) == z.y ? gy : 0.f;
+        dy.z = __float_as_int(fmaxf(fmaf(v.z, s.z, t.z), 0.f)) == z.z ? gz : 0.f;
+        dy.w = __float_as_int(fmaxf(fmaf(v.w, s.w, t.w), 0.f)) == z.w ? gw : 0.f;
+        reinterpret_cast<float4 *>(A.dy + row * 128)[c4] = dy;
+        q1[0] += dy.x; q1[1] += dy.y; q1[2] += dy.z; q1[3] += dy.w;
+        q2[0] = fmaf(dy.x, (v.x - mu.x) * is.x, q2[0]); q2[1] = fmaf(dy.y, (v.y - mu.y) * is.y, q2[1]);
+        q2[2] = fmaf(dy.z, (v.z - mu.z) * is.z, q2[2]); q2[3] = fmaf(dy.w, (v.w - mu.w) * is.w, q2[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) red[g][4 * c4 + u] = make_float2(q1[u], q2[u]);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float2 v = red[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { v.x += red[k][threadIdx.x].x; v.y += red[k][threadIdx.x].y; }
+        A.qsum[(size_t)blockIdx.x * 128 + threadIdx.x] = v;
+    }
+}
+
+// d beta = sum dy, d gamma = sum dy * xhat (double, fixed order); m1 = d beta / R, m2 = d gamma / R
+struct BnBwdArgs { const float2 *qsum; int tiles; int C; double inv_rows; float *dbeta, *dgamma, *m1, *m2; };
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs A) {
+    __shared__ double r1[8][32], r2[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = g; t < A.tiles; t += 8) {
+        const float2 p = A.qsum[(size_t)t * A.C + c];
+        s1 += p.x; s2 += p.y;
+    }
+    r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
+    __syncthreads();
+    if (g == 0) {
+        for (int k = 1; k < 8; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
+        A.dbeta[c] = (float)s1; A.dgamma[c] = (float)s2;
+        A.m1[c] = (float)(s1 * A.inv_rows); A.m2[c] = (float)(s2 * A.inv_rows);
+    }
+}
+
+struct BwdArgs {
+    int tiles;
+    const float *dy;                 // [R][COUT]  gradient w.r.t. the BN output of this layer (ReLU mask applied)
+    const float *a;                  // [R][COUT]  pre-BN activations of this layer
+    const float *mean, *inv_std, *gamma, *m1, *m2;     // [COUT]
+    const float *aprev;              // [R][CIN]   pre-BN activations of the previous layer (x for layer 0)
+    const float *pscale, *pshift, *pmean, *pinv_std;   // [CIN] previous layer's BN (batch)
+    PackedLayer WT;                  // packed W_i^T: K = COUT, N = CIN
+    float *dy_out;                   // [R][CIN]
+    float2 *qsum_out;                // [tiles][CIN]
+    float *dw_partial;               // [grid][CIN][COUT]
+    float *db_partial;               // [grid][COUT]
+};
+
+// da tile = gamma * inv_std * (dy - m1 - xhat * m2), xhat = (a - mean) * inv_std -> LDS [64][C + 4]; returns this
+// thread's column sums (bias gradient; mathematically zero behind a BN, kept because TF computes it)
+template <int C>
+__device__ __forceinline__ void load_da_tile(const BwdArgs &A, size_t row0, const float *cc /*LDS [5][C]*/, float *lds, float4 &dbacc) {
+    constexpr int Q = C / 4;
+    const int c4 = threadIdx.x % Q, r0 = threadIdx.x / Q;
+    const float4 mu = reinterpret_cast<const float4 *>(cc)[c4], is = reinterpret_cast<const float4 *>(cc + C)[c4];
+    const float4 gi = reinterpret_cast<const float4 *>(cc + 2 * C)[c4];
+    const float4 m1 = reinterpret_cast<const float4 *>(cc + 3 * C)[c4], m2 = reinterpret_cast<const float4 *>(cc + 4 * C)[c4];
+#pragma unroll
+    for (int r = r0; r < TR_ROWS; r += TR_THREADS / Q) {
+        const float4 d = reinterpret_cast<const float4 *>(A.dy + (row0 + r) * C)[c4];
+        const float4 a = reinterpret_cast<const float4 *>(A.a + (row0 + r) * C)[c4];
+        float4 o;
+        o.x = gi.x * ((d.x - m1.x) - (a.x - mu.x) * is.x * m2.x); o.y = gi.y * ((d.y - m1.y) - (a.y - mu.y) * is.y * m2.y);
+        o.z = gi.z * ((d.z - m1.z) - (a.z - mu.z) * is.z * m2.z); o.w = gi.w * ((d.w - m1.w) - (a.w - mu.w) * is.w * m2.w);
+        *reinterpret_cast<float4 *>(lds + r * (C + 4) + 4 * c4) = o;
+        dbacc.x += o.x; dbacc.y += o.y; dbacc.z += o.z; dbacc.w += o.w;
+    }
+}
+
+template <int CIN, int COUT> struct BwdShape {
+    static constexpr int MB = CIN / 32, NB = COUT / 32;
+    static constexpr int MBW = (MB * NB >= 32) ? 2 : 1;                 // blocks of dW per wave: MBW x NBW
+    static constexpr int NBW = (MB * NB >= 16) ? 2 : 1;
+    static constexpr int WCOLS = NB / NBW;                                // waves along the COUT axis
+    static_assert((MB / MBW) * (NB / NBW) == 8, "dW blocks must map onto 8 waves");
+    static constexpr int DA_FLOATS = TR_ROWS * (COUT + 4), H_FLOATS = TR_ROWS * (CIN + 4);
+    static constexpr int SCRATCH_FLOATS = (CIN == 64) ? 4 * 16 * 64 : 0;  // K-part hand-off of layer_gemm<64, 64, 2>
+    static constexpr int CC_FLOATS = 5 * COUT;
+    static constexpr int RED_FLOATS = 2 * 2 * CIN + 16 * COUT;            // qsum [2][CIN] float2, db [<=16][COUT]... see kernel
+    static constexpr size_t lds_bytes = sizeof(float) * (DA_FLOATS + H_FLOATS + SCRATCH_FLOATS + CC_FLOATS + RED_FLOATS);
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(TR_THREADS, 1) void train_bwd_kernel(BwdArgs A) {
+    using S = BwdShape<CIN, COUT>;
+    extern __shared__ __align__(16) float lds[];
+    float *da = lds;
+    float *ht = da + S::DA_FLOATS;
+    float *scratch = ht + S::H_FLOATS;
+    float *cc = scratch + S::SCRATCH_FLOATS;
+    float *red = cc + S::CC_FLOATS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hh = lane >> 5, li = lane & 31;
+    for (int e = threadIdx.x; e < COUT; e += TR_THREADS) {
+        cc[e] = A.mean[e]; cc[COUT + e] = A.inv_std[e]; cc[2 * COUT + e] = A.gamma[e] * A.inv_std[e];
+        cc[3 * COUT + e] = A.m1[e]; cc[4 * COUT + e] = A.m2[e];
+    }
+    // previous layer's BN constants of this lane's dy_out column
+    const int ocol = layer_gemm_lane_col<TR_ROWS, CIN>();
+    const float ps = A.pscale[ocol], pt = A.pshift[ocol], pm = A.pmean[ocol], pis = A.pinv_std[ocol];
+    const int mb0 = (wave / S::WCOLS) * S::MBW, nb0 = (wave % S::WCOLS) * S::NBW;
+    f32x16 dw[S::MBW][S::NBW] = {};
+    float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
+        const size_t row0 = (size_t)tile * TR_ROWS;
+        load_da_tile<COUT>(A, row0, cc, da, dbacc);
+        load_activated_tile<CIN>(A.aprev, row0, A.pscale, A.pshift, ht);
+        __syncthreads();
+        // dW += h^T @ da : A operand = h^T (lane: m = channel li of block mb, k = row 2kk + hh), B operand = da
+#pragma unroll 8
+        for (int kk = 0; kk < TR_ROWS / 2; ++kk) {
+            const int row = 2 * kk + hh;
+            float av[S::MBW], bv[S::NBW];
+#pragma unroll
+            for (int m = 0; m < S::MBW; ++m) av[m] = ht[row * (CIN + 4) + (mb0 + m) * 32 + li];
+#pragma unroll
+            for (int n = 0; n < S::NBW; ++n) bv[n] = da[row * (COUT + 4) + (nb0 + n) * 32 + li];
+#pragma unroll
+            for (int m = 0; m < S::MBW; ++m)
+#pragma unroll
+                for (int n = 0; n < S::NBW; ++n)
+                    dw[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], dw[m][n], 0, 0, 0);
+        }
+        // dy_{i-1} = (da @ W^T) * [h > 0], with the sums the BN backward of the previous layer needs
+        float q1 = 0.f, q2 = 0.f;
+        int rb_seen = 0;
+        bool ran = false;
+        layer_gemm<TR_ROWS, CIN, 0>(da, COUT + 4, A.WT, scratch, [&](int row, int c, float v) {
+            const float ap = A.aprev[(row0 + row) * CIN + c];
+            const float dyv = fmaf(ap, ps, pt) > 0.f ? v : 0.f;
+            A.dy_out[(row0 + row) * CIN + c] = dyv;
+            q1 += dyv;
+            q2 = fmaf(dyv, (ap - pm) * pis, q2);
+            rb_seen = row >> 5;
+            ran = true;
+        });
+        q1 += __shfl_xor(q1, 32);
+        q2 += __shfl_xor(q2, 32);
+        constexpr bool BOTH = (CIN / 32) * 2 > 8;
+        float2 *qred = reinterpret_cast<float2 *>(red);              // [2][CIN]
+        if (BOTH) {
+            if (ran && hh == 0) A.qsum_out[(size_t)tile * CIN + ocol] = make_float2(q1, q2);
+            __syncthreads();
+        } else {
+            if (ran && hh == 0) qred[rb_seen * CIN + ocol] = make_float2(q1, q2);
+            __syncthreads();
+            if (threadIdx.x < CIN) {
+                const float2 p = qred[threadIdx.x], q = qred[CIN + threadIdx.x];
+                A.qsum_out[(size_t)tile * CIN + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
+            }
+        }
+    }
+    // weight-gradient partial of this workgroup, canonical [CIN][COUT] layout
+    float *dst = A.dw_partial + (size_t)blockIdx.x * CIN * COUT;
+#pragma unroll
+    for (int m = 0; m < S::MBW; ++m)
+#pragma unroll
+        for (int n = 0; n < S::NBW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dst[(size_t)((mb0 + m) * 32 + acc_row(r, hh)) * COUT + (nb0 + n) * 32 + li] = dw[m][n][r];
+    // bias-gradient partial: threads sharing a float4 column group are summed in a fixed order
+    constexpr int Q = COUT / 4, G = TR_THREADS / Q;
+    float *dbred = red + 4 * CIN;                                   // [G][COUT]
+    __syncthreads();
+    *reinterpret_cast<float4 *>(dbred + (threadIdx.x / Q) * COUT + 4 * (threadIdx.x % Q)) = dbacc;
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+        float s = dbred[threadIdx.x];
+#pragma unroll
+        for (int g = 1; g < G; ++g) s += dbred[g * COUT + threadIdx.x];
+        A.db_partial[(size_t)blockIdx.x * COUT + threadIdx.x] = s;
+    }
+}
+
+// layer 0: dW0[k][c] = sum_r x[r][k] * da0[r][c], db0[c] = sum_r da0[r][c]; persistent, thread = (column, 8-row group)
+__global__ __launch_bounds__(TR_THREADS) void train_bwd0_kernel(BwdArgs A) {
+    __shared__ float pts[TR_ROWS * 3];
+    __shared__ float red[8][4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const float mu = A.mean[c], is = A.inv_std[c], gi = A.gamma[c] * A.inv_std[c], m1 = A.m1[c], m2 = A.m2[c];
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f, sb = 0.f;
+    for (int tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
+        const size_t row0 = (size_t)tile * TR_ROWS;
+        __syncthreads();
+        if (threadIdx.x < TR_ROWS * 3) pts[threadIdx.x] = A.aprev[row0 * 3 + threadIdx.x];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = g * 8 + r;
+            const float d = A.dy[(row0 + row) * 64 + c], a = A.a[(row0 + row) * 64 + c];
+            const float o = gi * ((d - m1) - (a - mu) * is * m2);
+            w0 = fmaf(pts[row * 3], o, w0); w1 = fmaf(pts[row * 3 + 1], o, w1); w2 = fmaf(pts[row * 3 + 2], o, w2);
+            sb += o;
+        }
+    }
+    red[g][0][c] = w0; red[g][1][c] = w1; red[g][2][c] = w2; red[g][3][c] = sb;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int k = threadIdx.x >> 6;
+        float s = red[0][k][c];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) s += red[j][k][c];
+        if (k < 3) A.dw_partial[(size_t)blockIdx.x * 192 + k * 64 + c] = s;
+        else A.db_partial[(size_t)blockIdx.x * 64 + c] = s;
+    }
+}
+
+// out[e] = sum over workgroups (ascending) of partial[w][e]
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float *partial, int parts, size_t count, float *out) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    float s = 0.f;
+    for (int w = 0; w < parts; ++w) s += partial[(size_t)w * count + e];
+    out[e] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer + re-packing
+// ------------------------------------------------------------------------------------------------
+// TF 1.13 ApplyAdam over the flat parameter arena (see attack.hip adam_kernel for the restated form)
+__global__ __launch_bounds__(256) void train_adam_kernel(float *p, float *m, float *v, const float *g, size_t count, float gscale,
+                                                         float lr, float b1p, float b2p) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    const float gv = g[e] * gscale;
+    const float mn = m[e] + (gv - m[e]) * (1.f - 0.9f);
+    const float vn = v[e] + (gv * gv - v[e]) * (1.f - 0.999f);
+    m[e] = mn; v[e] = vn;
+    p[e] -= (mn * alpha) / (sqrtf(vn) + 1e-8f);
+}
+
+// packed[((cb * K/8 + t) * 64 + lane) * 4 + u] = B[8t + 4*(lane>>5) + u][32cb + (lane&31)];
+// B = W [K][N] (transpose == 0) or B[k][n] = W[n][k] with W stored [N][K] (transpose == 1)
+__global__ __launch_bounds__(256) void repack_kernel(const float *W, float *packed, int K, int N, int transpose) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * N) return;
+    const int u = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+    const int kg = K / 8, t = rest % kg, cb = rest / kg;
+    const int k = 8 * t + 4 * (lane >> 5) + u, n = 32 * cb + (lane & 31);
+    packed[e] = transpose ? W[(size_t)n * K + k] : W[(size_t)k * N + n];
+}
+
+}  // namespace geoadv
+
+using namespace geoadv;
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+const int ENC[ENC_L + 1] = {3, 64, 128, 128, 256, 128};
+
+struct Layout {                        // offsets (floats) into the flat parameter / gradient / Adam arenas
+    size_t w[ENC_L], b[ENC_L], gamma[ENC_L], beta[ENC_L], v[3], c[3], count;
+};
+
+Layout make_layout(int n_points) {
+    Layout L;
+    size_t o = 0;
+    auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 3) / 4 * 4; return r; };
+    for (int i = 0; i < ENC_L; ++i) {
+        L.w[i] = take((size_t)ENC[i] * ENC[i + 1]); L.b[i] = take(ENC[i + 1]);
+        L.gamma[i] = take(ENC[i + 1]); L.beta[i] = take(ENC[i + 1]);
+    }
+    const int dd[4] = {128, 256, 256, 3 * n_points};
+    for (int k = 0; k < 3; ++k) { L.v[k] = take((size_t)dd[k] * dd[k + 1]); L.c[k] = take(dd[k + 1]); }
+    L.count = o;
+    return L;
+}
+
+}  // namespace
+
+struct geoadv_trainer {
+    int B, N, R, tiles, n3, grid_bwd;
+    float lr, one_minus_decay;
+    float b1p, b2p;
+    Layout L;
+    char *arena; size_t arena_bytes;
+    // carved from the arena
+    float *params, *grads, *adam_m, *adam_v;
+    float *mov_mean[ENC_L], *mov_var[ENC_L];
+    float *packed_fwd[ENC_L], *packed_bwd[ENC_L];
+    float *bn_mean[ENC_L], *bn_istd[ENC_L], *bn_scale[ENC_L], *bn_shift[ENC_L], *bn_m1[ENC_L], *bn_m2[ENC_L];
+    float *act[ENC_L];                 // a_i [R][C_{i+1}]
+    float *dybuf[2];                   // [R][256] ping-pong
+    float2 *psum, *qsum;               // [tiles][256]
+    int *zbits, *cnt;                  // [B][128]
+    float *d1, *d2, *recon, *g_recon, *g_gt, *gd, *dd2, *dd1, *dz;
+    float *dist1, *dist2; int *idx1, *idx2;
+    float *dw_partial, *db_partial;
+    float *loss;
+};
+
+static int trainer_repack(geoadv_trainer *t, hipStream_t st) {
+    for (int i = 1; i < ENC_L; ++i) {
+        const int K = ENC[i], N = ENC[i + 1], cnt = K * N;
+        repack_kernel<<<cdiv(cnt, 256), 256, 0, st>>>(t->params + t->L.w[i], t->packed_fwd[i], K, N, 0);
+        repack_kernel<<<cdiv(cnt, 256), 256, 0, st>>>(t->params + t->L.w[i], t->packed_bwd[i], N, K, 1);
+    }
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weights *hw, const geoadv_train_config *cfg) {
+    GA_REQUIRE(out && hw && cfg, "trainer_create: null argument");
+    for (int i = 0; i <= ENC_L; ++i)
+        GA_REQUIRE(hw->enc_dims[i] == ENC[i], "trainer_create: encoder widths must be 3,64,128,128,256,128 (src/ae_templates.py:22)");
+    const int n = hw->n_points, B = cfg->batch;
+    GA_REQUIRE(n >= 64 && n % 64 == 0 && n <= 32768, "trainer_create: n_points %d must be a multiple of 64 in [64, 32768]", n);
+    GA_REQUIRE(B >= 1 && B <= 4096, "trainer_create: batch %d out of range [1, 4096]", B);
+    GA_REQUIRE(hw->dec_dims[0] == 128 && hw->dec_dims[1] == 256 && hw->dec_dims[2] == 256 && hw->dec_dims[3] == 3 * n,
+               "trainer_create: decoder widths must be 128,256,256,3*n_points (src/ae_templates.py:29)");
+    GA_REQUIRE(cfg->learning_rate > 0.f && cfg->bn_decay >= 0.f && cfg->bn_decay <= 1.f, "trainer_create: bad learning rate / decay");
+    geoadv_trainer *t = new geoadv_trainer();
+    t->B = B; t->N = n; t->R = B * n; t->tiles = t->R / TR_ROWS; t->n3 = 3 * n;
+    t->lr = cfg->learning_rate; t->one_minus_decay = 1.f - cfg->bn_decay;
+    t->b1p = 0.9f; t->b2p = 0.999f;
+    t->L = make_layout(n);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    t->grid_bwd = t->tiles < cus ? t->tiles : cus;
+    // carve
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) / 256 * 256; return r; };
+    const size_t P = t->L.count;
+    const size_t o_params = take(4 * P), o_grads = take(4 * P), o_m = take(4 * P), o_v = take(4 * P);
+    size_t o_mm[ENC_L], o_mv[ENC_L], o_pf[ENC_L], o_pb[ENC_L], o_bn[ENC_L][6], o_act[ENC_L];
+    for (int i = 0; i < ENC_L; ++i) {
+        o_mm[i] = take(4 * ENC[i + 1]); o_mv[i] = take(4 * ENC[i + 1]);
+        o_pf[i] = take(4 * (size_t)ENC[i] * ENC[i + 1]); o_pb[i] = take(4 * (size_t)ENC[i] * ENC[i + 1]);
+        for (int k = 0; k < 6; ++k) o_bn[i][k] = take(4 * ENC[i + 1]);
+        o_act[i] = take(4 * (size_t)t->R * ENC[i + 1]);
+    }
+    const size_t o_dy0 = take(4 * (size_t)t->R * 256), o_dy1 = take(4 * (size_t)t->R * 256);
+    const size_t o_ps = take(8 * (size_t)t->tiles * 256), o_qs = take(8 * (size_t)t->tiles * 256);
+    const size_t o_z = take(4 * (size_t)B * 128), o_cnt = take(4 * (size_t)B * 128);
+    const size_t o_d1 = take(4 * (size_t)B * 256), o_d2 = take(4 * (size_t)B * 256);
+    const size_t o_rec = take(4 * (size_t)B * t->n3), o_gr = take(4 * (size_t)B * t->n3), o_gg = take(4 * (size_t)B * t->n3);
+    const size_t o_gd = take(4 * (size_t)B * n), o_dd2 = take(4 * (size_t)B * 256), o_dd1 = take(4 * (size_t)B * 256);
+    const size_t o_dz = take(4 * (size_t)B * 128);
+    const size_t o_di1 = take(4 * (size_t)B * n), o_di2 = take(4 * (size_t)B * n), o_i1 = take(4 * (size_t)B * n), o_i2 = take(4 * (size_t)B * n);
+    const size_t o_dwp = take(4 * (size_t)t->grid_bwd * 256 * 128), o_dbp = take(4 * (size_t)t->grid_bwd * 256);
+    const size_t o_loss = take(256);
+    t->arena_bytes = off;
+    if (hipMalloc(reinterpret_cast<void **>(&t->arena), off) != hipSuccess) {
+        set_error("trainer_create: hipMalloc of %zu bytes failed", off);
+        delete t;
+        return GEOADV_ENOMEM;
+    }
+    auto F = [&](size_t o) { return reinterpret_cast<float *>(t->arena + o); };
+    t->params = F(o_params); t->grads = F(o_grads); t->adam_m = F(o_m); t->adam_v = F(o_v);
+    for (int i = 0; i < ENC_L; ++i) {
+        t->mov_mean[i] = F(o_mm[i]); t->mov_var[i] = F(o_mv[i]); t->packed_fwd[i] = F(o_pf[i]); t->packed_bwd[i] = F(o_pb[i]);
+        t->bn_mean[i] = F(o_bn[i][0]); t->bn_istd[i] = F(o_bn[i][1]); t->bn_scale[i] = F(o_bn[i][2]);
+        t->bn_shift[i] = F(o_bn[i][3]); t->bn_m1[i] = F(o_bn[i][4]); t->bn_m2[i] = F(o_bn[i][5]);
+        t->act[i] = F(o_act[i]);
+    }
+    t->dybuf[0] = F(o_dy0); t->dybuf[1] = F(o_dy1);
+    t->psum = reinterpret_cast<float2 *>(F(o_ps)); t->qsum = reinterpret_cast<float2 *>(F(o_qs));
+    t->zbits = reinterpret_cast<int *>(F(o_z)); t->cnt = reinterpret_cast<int *>(F(o_cnt));
+    t->d1 = F(o_d1); t->d2 = F(o_d2); t->recon = F(o_rec); t->g_recon = F(o_gr); t->g_gt = F(o_gg); t->gd = F(o_gd);
+    t->dd2 = F(o_dd2); t->dd1 = F(o_dd1); t->dz = F(o_dz);
+    t->dist1 = F(o_di1); t->dist2 = F(o_di2); t->idx1 = reinterpret_cast<int *>(F(o_i1)); t->idx2 = reinterpret_cast<int *>(F(o_i2));
+    t->dw_partial = F(o_dwp); t->db_partial = F(o_dbp); t->loss = F(o_loss);
+    // upload parameters
+    std::vector<float> host(P, 0.f);
+    const int dd[4] = {128, 256, 256, 3 * n};
+    for (int i = 0; i < ENC_L; ++i) {
+        memcpy(&host[t->L.w[i]], hw->enc_w[i], sizeof(float) * ENC[i] * ENC[i + 1]);
+        memcpy(&host[t->L.b[i]], hw->enc_b[i], sizeof(float) * ENC[i + 1]);
+        memcpy(&host[t->L.gamma[i]], hw->bn_gamma[i], sizeof(float) * ENC[i + 1]);
+        memcpy(&host[t->L.beta[i]], hw->bn_beta[i], sizeof(float) * ENC[i + 1]);
+    }
+    for (int k = 0; k < 3; ++k) {
+        memcpy(&host[t->L.v[k]], hw->dec_w[k], sizeof(float) * (size_t)dd[k] * dd[k + 1]);
+        memcpy(&host[t->L.c[k]], hw->dec_b[k], sizeof(float) * dd[k + 1]);
+    }
+    hipError_t e = hipMemcpy(t->params, host.data(), 4 * P, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(t->adam_m, 0, 4 * P);
+    if (e == hipSuccess) e = hipMemset(t->adam_v, 0, 4 * P);
+    if (e == hipSuccess) e = hipMemset(t->grads, 0, 4 * P);
+    for (int i = 0; i < ENC_L && e == hipSuccess; ++i) {
+        e = hipMemcpy(t->mov_mean[i], hw->bn_mean[i], 4 * ENC[i + 1], hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(t->mov_var[i], hw->bn_var[i], 4 * ENC[i + 1], hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        std::vector<float> gdv((size_t)B * n, 1.0f / ((float)B * (float)n));     // d reduce_mean / d dist
+        e = hipMemcpy(t->gd, gdv.data(), 4 * gdv.size(), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        set_error("trainer_create: upload failed: %s", hipGetErrorString(e));
+        (void)hipFree(t->arena);
+        delete t;
+        return GEOADV_EHIP;
+    }
+    if (int rc = trainer_repack(t, nullptr)) { (void)hipFree(t->arena); delete t; return rc; }
+    GA_HIP(hipDeviceSynchronize());
+    *out = t;
+    return GEOADV_OK;
+}
+
+extern "C" void geoadv_trainer_destroy(geoadv_trainer *t) {
+    if (!t) return;
+    (void)hipFree(t->arena);
+    delete t;
+}
+
+template <int CIN, int COUT>
+static int launch_fwd(geoadv_trainer *t, int i, hipStream_t st) {
+    FwdArgs a;
+    a.in = t->act[i - 1]; a.pscale = t->bn_scale[i - 1]; a.pshift = t->bn_shift[i - 1];
+    a.W = PackedLayer{t->packed_fwd[i], CIN, COUT};
+    a.bias = t->params + t->L.b[i]; a.out = t->act[i]; a.psum = t->psum;
+    const size_t lds = sizeof(float) * (TR_ROWS * (CIN + 4) + 4 * COUT);
+    static bool attr = false;
+    if (!attr) {
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_fwd_kernel<CIN, COUT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    train_fwd_kernel<CIN, COUT><<<t->tiles, TR_THREADS, lds, st>>>(a);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+static int launch_bn(geoadv_trainer *t, int i, hipStream_t st) {
+    BnArgs a;
+    a.psum = t->psum; a.tiles = t->tiles; a.C = ENC[i + 1]; a.inv_rows = 1.0 / (double)t->R;
+    a.gamma = t->params + t->L.gamma[i]; a.beta = t->params + t->L.beta[i];
+    a.mean = t->bn_mean[i]; a.inv_std = t->bn_istd[i]; a.scale = t->bn_scale[i]; a.shift = t->bn_shift[i];
+    a.mov_mean = t->mov_mean[i]; a.mov_var = t->mov_var[i]; a.one_minus_decay = t->one_minus_decay;
+    bn_finalize_kernel<<<ENC[i + 1] / 32, 256, 0, st>>>(a);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+template <int CIN, int COUT>
+static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, hipStream_t st) {
+    using S = BwdShape<CIN, COUT>;
+    BwdArgs a;
+    a.tiles = t->tiles; a.dy = dy; a.a = t->act[i];
+    a.mean = t->bn_mean[i]; a.inv_std = t->bn_istd[i]; a.gamma = t->params + t->L.gamma[i]; a.m1 = t->bn_m1[i]; a.m2 = t->bn_m2[i];
+    a.aprev = t->act[i - 1];
+    a.pscale = t->bn_scale[i - 1]; a.pshift = t->bn_shift[i - 1]; a.pmean = t->bn_mean[i - 1]; a.pinv_std = t->bn_istd[i - 1];
+    a.WT = PackedLayer{t->packed_bwd[i], COUT, CIN};
+    a.dy_out = dy_out; a.qsum_out = t->qsum; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
+    static bool attr = false;
+    if (!attr) {
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_kernel<CIN, COUT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes));
+        attr = true;
+    }
+    train_bwd_kernel<CIN, COUT><<<t->grid_bwd, TR_THREADS, S::lds_bytes, st>>>(a);
+    GA_LAUNCH_CHECK();
+    const size_t cnt = (size_t)CIN * COUT;
+    partial_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(t->dw_partial, t->grid_bwd, cnt, t->grads + t->L.w[i]);
+    partial_reduce_kernel<<<cdiv(COUT, 256), 256, 0, st>>>(t->db_partial, t->grid_bwd, COUT, t->grads + t->L.b[i]);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+static int launch_bn_bwd(geoadv_trainer *t, int i, hipStream_t st) {
+    BnBwdArgs a;
+    a.qsum = t->qsum; a.tiles = t->tiles; a.C = ENC[i + 1]; a.inv_rows = 1.0 / (double)t->R;
+    a.dbeta = t->grads + t->L.beta[i]; a.dgamma = t->grads + t->L.gamma[i]; a.m1 = t->bn_m1[i]; a.m2 = t->bn_m2[i];
+    bn_bwd_finalize_kernel<<<ENC[i + 1] / 32, 256, 0, st>>>(a);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x, const float *gt, float *loss, float *recon,
+                                               void *stream) {
+    GA_REQUIRE(t && x, "trainer_forward_backward: null argument");
+    hipStream_t st = as_stream(stream);
+    if (!gt) gt = x;
+    const int B = t->B, n = t->N, n3 = t->n3;
+    // ---- encoder forward, layer by layer (batch statistics) ----
+    {
+        FwdArgs a;
+        a.in = x; a.pscale = a.pshift = nullptr;
+        a.W = PackedLayer{t->params + t->L.w[0], 3, 64};
+        a.bias = t->params + t->L.b[0]; a.out = t->act[0]; a.psum = t->psum;
+        train_fwd0_kernel<<<t->tiles, TR_THREADS, 0, st>>>(a);
+        GA_LAUNCH_CHECK();
+        if (int rc = launch_bn(t, 0, st)) return rc;
+    }
+    if (int rc = launch_fwd<64, 128>(t, 1, st)) return rc;
+    if (int rc = launch_bn(t, 1, st)) return rc;
+    if (int rc = launch_fwd<128, 128>(t, 2, st)) return rc;
+    if (int rc = launch_bn(t, 2, st)) return rc;
+    if (int rc = launch_fwd<128, 256>(t, 3, st)) return rc;
+    if (int rc = launch_bn(t, 3, st)) return rc;
+    if (int rc = launch_fwd<256, 128>(t, 4, st)) return rc;
+    if (int rc = launch_bn(t, 4, st)) return rc;
+    // ---- symmetric max-pool ----
+    GA_HIP(hipMemsetAsync(t->zbits, 0, sizeof(int) * (size_t)B * 128, st));
+    GA_HIP(hipMemsetAsync(t->cnt, 0, sizeof(int) * (size_t)B * 128, st));
+    PoolArgs pa{t->act[4], t->bn_scale[4], t->bn_shift[4], n, t->zbits, t->cnt};
+    train_pool_kernel<false><<<t->tiles, 256, 0, st>>>(pa);
+    train_pool_kernel<true><<<t->tiles, 256, 0, st>>>(pa);
+    GA_LAUNCH_CHECK();
+    const float *z = reinterpret_cast<const float *>(t->zbits);
+    // ---- decoder forward ----
+    const float *V0 = t->params + t->L.v[0], *V1 = t->params + t->L.v[1], *V2 = t->params + t->L.v[2];
+    fc_fwd_kernel<128, true><<<B, 256, 0, st>>>(z, V0, t->params + t->L.c[0], t->d1, 256);
+    fc_fwd_kernel<256, true><<<B, 256, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2, 256);
+    fc_out_fwd_kernel<<<dim3(cdiv(n3, 128), cdiv(B, 16)), 128, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
+    GA_LAUNCH_CHECK();
+    // ---- Chamfer loss and its gradient w.r.t. the reconstruction ----
+    if (int rc = geoadv_nn_distance(B, n, t->recon, n, gt, t->dist1, t->idx1, t->dist2, t->idx2, stream)) return rc;
+    chamfer_loss_kernel<<<1, 1024, 0, st>>>(t->dist1, t->dist2, (size_t)B * n, 1.0 / ((double)B * n), t->loss);
+    GA_LAUNCH_CHECK();
+    if (int rc = geoadv_nn_distance_grad(B, n, t->recon, n, gt, t->gd, t->idx1, t->gd, t->idx2, t->g_recon, t->g_gt, stream)) return rc;
+    // ---- decoder backward ----
+    fc_out_bwd_w_kernel<<<dim3(cdiv(n3, 128), 8), 128, sizeof(float) * B * 32, st>>>(t->d2, t->g_recon, t->grads + t->L.v[2],
+                                                                                    t->grads + t->L.c[2], B, n3);
+    fc_out_bwd_x_kernel<<<dim3(64, cdiv(B, 8)), 256, 0, st>>>(t->g_recon, V2, t->d2, t->dd2, B, n3);
+    fc_bwd_w_kernel<<<256, 256, 0, st>>>(t->d1, t->dd2, t->grads + t->L.v[1], t->grads + t->L.c[1], B, 256);
+    fc_bwd_x_kernel<true><<<B, 256, 0, st>>>(t->dd2, V1, t->d1, t->dd1, 256);
+    fc_bwd_w_kernel<<<128, 256, 0, st>>>(z, t->dd1, t->grads + t->L.v[0], t->grads + t->L.c[0], B, 128);
+    fc_bwd_x_kernel<false><<<B, 256, 0, st>>>(t->dd1, V0, nullptr, t->dz, 128);
+    GA_LAUNCH_CHECK();
+    // ---- encoder backward ----
+    PoolBwdArgs pb{t->act[4], t->bn_scale[4], t->bn_shift[4], t->bn_mean[4], t->bn_istd[4], n, t->zbits, t->cnt, t->dz,
+                   t->dybuf[0], t->qsum};
+    train_pool_bwd_kernel<<<t->tiles, 256, 0, st>>>(pb);
+    GA_LAUNCH_CHECK();
+    if (int rc = launch_bn_bwd(t, 4, st)) return rc;
+    if (int rc = launch_bwd<256, 128>(t, 4, t->dybuf[0], t->dybuf[1], st)) return rc;
+    if (int rc = launch_bn_bwd(t, 3, st)) return rc;
+    if (int rc = launch_bwd<128, 256>(t, 3, t->dybuf[1], t->dybuf[0], st)) return rc;
+    if (int rc = launch_bn_bwd(t, 2, st)) return rc;
+    if (int rc = launch_bwd<128, 128>(t, 2, t->dybuf[0], t->dybuf[1], st)) return rc;
+    if (int rc = launch_bn_bwd(t, 1, st)) return rc;
+    if (int rc = launch_bwd<64, 128>(t, 1, t->dybuf[1], t->dybuf[0], st)) return rc;
+    if (int rc = launch_bn_bwd(t, 0, st)) return rc;
+    {
+        BwdArgs a = {};
+        a.tiles = t->tiles; a.dy = t->dybuf[0]; a.a = t->act[0];
+        a.mean = t->bn_mean[0]; a.inv_std = t->bn_istd[0]; a.gamma = t->params + t->L.gamma[0]; a.m1 = t->bn_m1[0]; a.m2 = t->bn_m2[0];
+        a.aprev = x; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
+        train_bwd0_kernel<<<t->grid_bwd, TR_THREADS, 0, st>>>(a);
+        partial_reduce_kernel<<<1, 256, 0, st>>>(t->dw_partial, t->grid_bwd, 192, t->grads + t->L.w[0]);
+        partial_reduce_kernel<<<1, 256, 0, st>>>(t->db_partial, t->grid_bwd, 64, t->grads + t->L.b[0]);
+        GA_LAUNCH_CHECK();
+    }
+    if (loss) GA_HIP(hipMemcpyAsync(loss, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (recon) GA_HIP(hipMemcpyAsync(recon, t->recon, sizeof(float) * (size_t)B * n3, hipMemcpyDeviceToDevice, st));
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_trainer_apply(geoadv_trainer *t, float grad_scale, void *stream) {
+    GA_REQUIRE(t, "trainer_apply: null trainer");
+    hipStream_t st = as_stream(stream);
+    const size_t P = t->L.count;
+    train_adam_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(t->params, t->adam_m, t->adam_v, t->grads, P, grad_scale, t->lr,
+                                                                   t->b1p, t->b2p);
+    GA_LAUNCH_CHECK();
+    t->b1p *= 0.9f; t->b2p *= 0.999f;
+    return trainer_repack(t, st);
+}
+
+extern "C" int geoadv_trainer_step(geoadv_trainer *t, const float *x, const float *gt, float *loss, float *recon, void *stream) {
+    if (int rc = geoadv_trainer_forward_backward(t, x, gt, loss, recon, stream)) return rc;
+    return geoadv_trainer_apply(t, 1.0f, stream);
+}
+
+extern "C" int geoadv_trainer_buffers(geoadv_trainer *t, float **params, float **grads, size_t *count) {
+    GA_REQUIRE(t, "trainer_buffers: null trainer");
+    if (params) *params = t->params;
+    if (grads) *grads = t->grads;
+    if (count) *count = t->L.count;
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_trainer_export(geoadv_trainer *t, const geoadv_ae_weights *dst, void *stream) {
+    GA_REQUIRE(t && dst, "trainer_export: null argument");
+    GA_HIP(hipStreamSynchronize(as_stream(stream)));
+    std::vector<float> host(t->L.count);
+    GA_HIP(hipMemcpy(host.data(), t->params, 4 * host.size(), hipMemcpyDeviceToHost));
+    const int dd[4] = {128, 256, 256, t->n3};
+    for (int i = 0; i < ENC_L; ++i) {
+        GA_REQUIRE(dst->enc_w[i] && dst->enc_b[i] && dst->bn_gamma[i] && dst->bn_beta[i] && dst->bn_mean[i] && dst->bn_var[i],
+                   "trainer_export: null destination at encoder layer %d", i);
+        memcpy(const_cast<float *>(dst->enc_w[i]), &host[t->L.w[i]], sizeof(float) * ENC[i] * ENC[i + 1]);
+        memcpy(const_cast<float *>(dst->enc_b[i]), &host[t->L.b[i]], sizeof(float) * ENC[i + 1]);
+        memcpy(const_cast<float *>(dst->bn_gamma[i]), &host[t->L.gamma[i]], sizeof(float) * ENC[i + 1]);
+        memcpy(const_cast<float *>(dst->bn_beta[i]), &host[t->L.beta[i]], sizeof(float) * ENC[i + 1]);
+        GA_HIP(hipMemcpy(const_cast<float *>(dst->bn_mean[i]), t->mov_mean[i], 4 * ENC[i + 1], hipMemcpyDeviceToHost));
+        GA_HIP(hipMemcpy(const_cast<float *>(dst->bn_var[i]), t->mov_var[i], 4 * ENC[i + 1], hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < 3; ++k) {
+        GA_REQUIRE(dst->dec_w[k] && dst->dec_b[k], "trainer_export: null destination at decoder layer %d", k);
+        memcpy(const_cast<float *>(dst->dec_w[k]), &host[t->L.v[k]], sizeof(float) * (size_t)dd[k] * dd[k + 1]);
+        memcpy(const_cast<float *>(dst->dec_b[k]), &host[t->L.c[k]], sizeof(float) * dd[k + 1]);
+    }
+    return GEOADV_OK;
+}
+
+// Offsets (in floats) of every variable inside the flat parameter / gradient buffers, in the order
+// enc_w[5], enc_b[5], bn_gamma[5], bn_beta[5], dec_w[3], dec_b[3]  (26 entries)
+extern "C" int geoadv_trainer_layout(const geoadv_trainer *t, size_t *offsets26) {
+    GA_REQUIRE(t && offsets26, "trainer_layout: null argument");
+    for (int i = 0; i < ENC_L; ++i) {
+        offsets26[i] = t->L.w[i]; offsets26[5 + i] = t->L.b[i]; offsets26[10 + i] = t->L.gamma[i]; offsets26[15 + i] = t->L.beta[i];
+    }
+    for (int k = 0; k < 3; ++k) { offsets26[20 + k] = t->L.v[k]; offsets26[23 + k] = t->L.c[k]; }
+    return GEOADV_OK;
+}

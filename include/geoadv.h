@@ -212,6 +212,41 @@ int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_loss_ref,
 int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, float *recon, float *latent,
                        float *grad, int *idx_r1, int *idx_r2, int *idx_a1, int *idx_a2, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Victim auto-encoder TRAINING step: PointNetAutoEncoder._create_loss / _setup_optimizer
+ * (src/pointnet_ae.py:71-99) driven by AutoEncoder.partial_fit (src/autoencoder.py:105-125) with the
+ * architecture of src/ae_templates.py:22-33: encoder BN in TRAINING mode (tflearn batch_normalization:
+ * batch statistics over all batch*n_points rows, differentiated through; moving averages updated with
+ * `bn_decay`, zero_debias=False), loss = reduce_mean(dist1) + reduce_mean(dist2) of nn_distance(recon, gt),
+ * Adam (TF 1.13 ApplyAdam form, beta1 .9, beta2 .999, eps 1e-8) on every trainable variable.
+ * One handle = one model replica with a fixed batch size; everything is device resident.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct geoadv_trainer geoadv_trainer;
+typedef struct geoadv_train_config {
+    int   batch;            /* conf.batch_size (default_train_params: 50)          */
+    float learning_rate;    /* conf.learning_rate (0.0005)                         */
+    float bn_decay;         /* encoder b_norm_decay (encoders_decoders.py:20: 0.9) */
+} geoadv_train_config;
+
+/* init: HOST weights (the initial variable values; bn_mean / bn_var = the moving averages).  n_points % 64 == 0. */
+int  geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weights *init, const geoadv_train_config *cfg);
+void geoadv_trainer_destroy(geoadv_trainer *t);
+/* partial_fit(X, GT): x, gt device [batch,n,3] (gt NULL = x, the non-denoising case); loss: device float (of the
+ * PRE-update weights, like the fetched `self.loss`), recon: device [batch,n,3] or NULL. */
+int geoadv_trainer_step(geoadv_trainer *t, const float *x, const float *gt, float *loss, float *recon, void *stream);
+/* The two halves of a step, for data-parallel training: forward_backward leaves d loss / d variable in the flat
+ * gradient buffer; the caller sum-all-reduces that buffer over the ranks (RCCL) and calls apply with
+ * grad_scale = 1 / world_size. */
+int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x, const float *gt, float *loss, float *recon, void *stream);
+int geoadv_trainer_apply(geoadv_trainer *t, float grad_scale, void *stream);
+/* Device pointers of the flat parameter / gradient buffers (`count` floats each) and where each variable sits:
+ * offsets26 = enc_w[5], enc_b[5], bn_gamma[5], bn_beta[5], dec_w[3], dec_b[3] (in floats). */
+int geoadv_trainer_buffers(geoadv_trainer *t, float **params, float **grads, size_t *count);
+int geoadv_trainer_layout(const geoadv_trainer *t, size_t *offsets26);
+/* Downloads the current variables (and moving averages) into the HOST buffers `dst` points to -- what
+ * saver.save writes (autoencoder.py:213-215); feed them to geoadv_ae_create to attack the trained model. */
+int geoadv_trainer_export(geoadv_trainer *t, const geoadv_ae_weights *dst, void *stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * enable is a bit mask of GEOADV_PROF_* classes (bit k = class k, -1 = all, 0 = off; enabling resets
  * the totals): every geoadv_attack_run iteration brackets the selected kernels with events (a fixed

@@ -1,0 +1,174 @@
+"""one training step of the victim auto-encoder (csrc/train.hip through the C ABI) against the numpy
+fp64 model oracle/train_model.py (PointNetAutoEncoder._create_loss/_setup_optimizer + partial_fit, tflearn BN in
+training mode).  Tolerances: loss 1e-5 relative (the north star's Chamfer tolerance), gradients 5e-5 of each
+variable's norm (fp32 sums over B*N rows against fp64; measured ~1e-6), weights after one Adam step where the gradient is not
+rounding noise."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _clouds(seed, b, n):
+    rng = np.random.default_rng(seed)
+    return (rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
+
+
+def _setup(n, b, seed=11, lr=0.0005):
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.trainer import PointNetAETrainer
+    from oracle.train_model import TrainModel
+    w = W.randomized_weights(n, seed=seed)
+    tr = PointNetAETrainer(w, n, batch_size=b, learning_rate=lr)
+    tm = TrainModel(W.canonical(w, n), n, lr=lr)
+    return w, tr, tm
+
+
+def _well_conditioned(tm, x, margin=5e-6):
+    """A ReLU input within rounding of 0 (or a near-tie in the max-pool) makes the mask a coin flip between fp32 and
+    fp64 -- one flipped row shifts a gradient by ~1/rows.  With ~1e6 activations per small batch that happens for
+    about one seed in three, so the parity batches are drawn until the fp64 model has no such element."""
+    c = tm.forward(x)
+    for i in range(5):
+        if np.abs(c["xhat"][i] * tm.p["gamma"][i] + tm.p["beta"][i]).min() < margin:
+            return False
+    for d in (c["d1"], c["d2"]):
+        if np.abs(d[d > 0]).min() < margin:
+            return False
+    top = np.sort(c["h5"], axis=1)[:, -2:, :]
+    gap = (top[:, 1] - top[:, 0])[c["z"] > 0]
+    return gap.size == 0 or gap.min() > margin
+
+
+def _batch(tm, b, n, seed, duplicate=False):
+    for s in range(seed, seed + 50):
+        x = _clouds(s, b, n // 2 if duplicate else n)
+        if duplicate:
+            x = np.concatenate([x, x], axis=1)
+            c = tm.forward(x)                                   # ties are the point here; only the ReLUs must be clear
+            if all(np.abs(c["xhat"][i] * tm.p["gamma"][i] + tm.p["beta"][i]).min() >= 5e-6 for i in range(5)):
+                return x
+        elif _well_conditioned(tm, x):
+            return x
+    raise AssertionError("no well-conditioned batch found")
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("n,b", [(128, 4), (256, 3), (64, 1)])
+def test_loss_recon_and_gradients_match_the_oracle(n, b):
+    from oracle.train_model import PARAM_GROUPS
+    w, tr, tm = _setup(n, b)
+    x = _batch(tm, b, n, 3)
+    recon, loss = tr.forward_backward(x)
+    g_gpu = tr.gradients()
+    loss_ref, G, c = tm.loss_and_grads(x)
+    assert abs(float(loss.item()) - loss_ref) <= 1e-5 * abs(loss_ref)
+    assert np.abs(recon.cpu().numpy() - c["recon"]).max() <= 1e-5
+    for k in PARAM_GROUPS:
+        for j in range(len(G[k])):
+            if k == "enc_b":          # exactly zero behind a batch norm: both sides hold rounding noise only
+                scale = np.abs(G["enc_w"][j]).max()
+                assert np.abs(g_gpu[k][j]).max() <= 1e-4 * scale and np.abs(G[k][j]).max() <= 1e-10 * max(scale, 1e-30)
+                continue
+            assert g_gpu[k][j].shape == G[k][j].shape
+            assert _rel(g_gpu[k][j], G[k][j]) <= 5e-5, (k, j, _rel(g_gpu[k][j], G[k][j]))
+
+
+def test_one_adam_step_and_moving_averages():
+    n, b = 128, 4
+    w, tr, tm = _setup(n, b)
+    x = _batch(tm, b, n, 5)
+    _, G, _ = tm.loss_and_grads(x)
+    recon, loss = tr.partial_fit(x)
+    loss_ref, recon_ref = tm.step(x)
+    assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
+    from geometric_adv_amd import weights as W
+    new = W.canonical(tr.export_weights(), n)
+    lr = 0.0005
+    for k in ("enc_w", "gamma", "beta", "dec_w", "dec_b"):
+        for j in range(len(G[k])):
+            solid = np.abs(G[k][j]) > 1e-4 * np.abs(G[k][j]).max()          # Adam's first step is lr * g / (|g| + 3e-7)
+            diff = np.abs(new[k][j].astype(np.float64) - tm.p[k][j])[solid]
+            assert diff.size and diff.max() <= 2e-2 * lr, (k, j, diff.max())
+            moved = np.abs(new[k][j].astype(np.float64) - np.asarray(W.canonical(w, n)[k][j], np.float64))[solid]
+            assert moved.min() > 0.5 * lr                                   # every such variable really moved by ~lr
+    for i in range(5):
+        assert np.allclose(new["mean"][i], tm.p["mean"][i], rtol=1e-5, atol=1e-6)
+        assert np.allclose(new["var"][i], tm.p["var"][i], rtol=1e-4, atol=1e-7)
+
+
+def test_loss_trajectory_tracks_the_oracle():
+    n, b = 128, 4
+    w, tr, tm = _setup(n, b, lr=0.0005)
+    x = _clouds(9, b, n)
+    gpu, ref = [], []
+    for _ in range(12):
+        gpu.append(tr.partial_fit(x, want_recon=False)[1])
+        ref.append(tm.step(x)[0])
+    gpu, ref = np.array(gpu), np.array(ref)
+    assert ref[-1] < 0.7 * ref[0]                                           # it trains
+    assert np.abs(gpu[:4] - ref[:4]).max() <= 1e-4 * ref[0]
+    assert np.abs(gpu - ref).max() <= 2e-2 * ref[0]                         # sign-like Adam updates amplify rounding slowly
+
+
+def test_step_is_deterministic():
+    n, b = 256, 6
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.trainer import PointNetAETrainer
+    w = W.randomized_weights(n, seed=2)
+    x = _clouds(1, b, n)
+    outs = []
+    for _ in range(2):
+        tr = PointNetAETrainer(w, n, batch_size=b)
+        for _ in range(3):
+            tr.partial_fit(x, want_recon=False)
+        tr.forward_backward(x, want_recon=False)
+        torch.cuda.synchronize()
+        outs.append(tr.gradient_buffer().cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_duplicated_points_split_the_pool_gradient():
+    """Exact ties in the max-pool (TF _MinOrMaxGrad equal split): every point appears twice."""
+    n, b = 128, 2
+    w, tr, tm = _setup(n, b)
+    x = _batch(tm, b, n, 4, duplicate=True)
+    tr.forward_backward(x)
+    g_gpu = tr.gradients()
+    _, G, _ = tm.loss_and_grads(x)
+    for k in ("enc_w", "gamma", "beta"):
+        for j in range(5):
+            assert _rel(g_gpu[k][j], G[k][j]) <= 5e-5, (k, j)
+
+
+def test_full_size_step_trains_and_exports():
+    """default_train_params shape (batch 50, 2048 points, lr 0.0005): the loss of a fixed batch falls, and the exported
+    variables drive the inference/attack handle (BN moving averages included)."""
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.trainer import PointNetAETrainer, initial_weights
+    from geometric_adv_amd.autoencoder import PointNetAE
+    n, b = 2048, 50
+    tr = PointNetAETrainer(initial_weights(n, seed=1), n, batch_size=b)
+    x = torch.as_tensor(_clouds(7, b, n)).cuda()
+    losses = [tr.partial_fit(x, want_recon=False)[1] for _ in range(30)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < 0.5 * losses[0]
+    exported = tr.export_weights()
+    assert set(exported) == set(W.variable_names())
+    ae = PointNetAE(exported, n)
+    recon, latent = ae.forward(x[:4])
+    assert torch.isfinite(recon).all() and torch.isfinite(latent).all()
+
+
+def test_bad_shapes_are_rejected():
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.trainer import PointNetAETrainer
+    with pytest.raises(ValueError):
+        PointNetAETrainer(W.synthetic_weights(100), 100, batch_size=2)      # n_points must be a multiple of 64
+    tr = PointNetAETrainer(W.synthetic_weights(64), 64, batch_size=2)
+    with pytest.raises(ValueError):
+        tr.partial_fit(np.zeros((3, 64, 3), np.float32))

@@ -153,3 +153,42 @@ def test_tf_checkpoint_snappy_block():
     # literal "abcd", copy(offset 4, len 8) via a 1-byte-offset tag, literal "xyz"  -> "abcdabcdabcdxyz"
     comp = bytes([15, (4 - 1) << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4]) + bytes([(3 - 1) << 2]) + b"xyz"
     assert T._snappy_decompress(comp) == b"abcdabcdabcdxyz"
+
+
+# ---------------------------------------------------------------- training-step oracle
+def test_train_model_gradients_match_finite_differences():
+    """oracle/train_model.py is unpinned against TF; its backward (BN in training mode, differentiated through the
+    batch statistics; max-pool; Chamfer with pinned matches) is checked against central differences in fp64."""
+    from geometric_adv_amd import weights as W
+    from oracle.train_model import TrainModel, PARAM_GROUPS
+    from oracle.attack_model import _o
+    n, b = 64, 3
+    tm = TrainModel(W.canonical(W.randomized_weights(n, seed=11), n), n)
+    rng = np.random.default_rng(0)
+    x = (rng.random((b, n, 3), dtype=np.float32) - 0.5)
+    loss, G, c = tm.loss_and_grads(x)
+    _, i1, _, i2 = _o().nn_distance(c["recon"].astype(np.float32), x)
+    idx = (i1.astype(np.int64), i2.astype(np.int64))
+
+    def f():
+        return tm.chamfer_loss_fixed(tm.forward(x)["recon"], x.astype(np.float64), *idx)
+
+    assert abs(f() - loss) < 1e-12
+    errs = []
+    for k in PARAM_GROUPS:
+        for j, a in enumerate(tm.p[k]):
+            flat = a.reshape(-1)
+            for t in rng.choice(flat.size, size=min(4, flat.size), replace=False):
+                old, h = flat[t], 1e-8
+                flat[t] = old + h; fp = f(); flat[t] = old - h; fm = f(); flat[t] = old
+                an = G[k][j].reshape(-1)[t]
+                if abs(an) > 1e-4:
+                    errs.append(abs((fp - fm) / (2 * h) - an) / abs(an))
+    errs = np.array(errs)
+    assert len(errs) > 40 and np.median(errs) < 1e-5 and np.percentile(errs, 90) < 1e-3    # a few kinks (ReLU, max) are expected
+    for g in G["enc_b"]:                                  # a bias in front of a batch norm has exactly zero gradient
+        assert np.abs(g).max() < 1e-12
+    l0 = tm.step(x)[0]
+    for _ in range(6):
+        l1 = tm.step(x)[0]
+    assert l1 < 0.5 * l0
