@@ -15,7 +15,7 @@
 //                       (da_i @ W_i^T) * [h_i > 0] (MFMA, packed W_i^T) with the per-tile sums the BN backward
 //                       of layer i-1 needs, all in ONE kernel per layer.
 // All reductions run in a fixed order (per-tile partials, then a double-precision pass), so a step is
-// deterministic.  Parity: oracle/train_model.py (numpy fp64; unpinned against TF, see there).
+// deterministic.  Parity is checked by tests/test_gpu_train.py against a numpy fp64 model of the same step.
 #include "ae.h"
 #include "mfma_tile.h"
 #include <math.h>
