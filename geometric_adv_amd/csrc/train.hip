@@ -128,18 +128,24 @@ struct BnArgs {
     float *mov_mean, *mov_var; float one_minus_decay;
 };
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(BnArgs A) {
-    __shared__ double r1[8][32], r2[8][32];
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(BnArgs A) {
+    __shared__ double r1[32][32], r2[32][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = g; t < A.tiles; t += 8) {
+    int t = g;
+    for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight, summed in ascending tile order
+        const float2 p0 = A.psum[(size_t)t * A.C + c], p1 = A.psum[(size_t)(t + 32) * A.C + c];
+        const float2 p2 = A.psum[(size_t)(t + 64) * A.C + c], p3 = A.psum[(size_t)(t + 96) * A.C + c];
+        s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
+    }
+    for (; t < A.tiles; t += 32) {
         const float2 p = A.psum[(size_t)t * A.C + c];
         s1 += p.x; s2 += p.y;
     }
     r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
     __syncthreads();
     if (g == 0) {
-        for (int k = 1; k < 8; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
+        for (int k = 1; k < 32; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
         const double mean = s1 * A.inv_rows;
         double var = s2 * A.inv_rows - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -206,19 +212,21 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float *in, const floa
     out[(size_t)blockIdx.x * nout + n] = RELU ? fmaxf(v, 0.f) : v;
 }
 
-// recon[b][n] = d2[b][:] @ V2[:, n] + c2[n]; grid = (ceil(n3/128), ceil(B/16)), block 128
-__global__ __launch_bounds__(128) void fc_out_fwd_kernel(const float *d2, const float *V2, const float *c2, float *out, int batch, int n3) {
+// recon[b][n] = d2[b][:] @ V2[:, n] + c2[n]; grid = (ceil(n3/64), ceil(B/16)), block 256 = 64 columns x 4 K slices
+__global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const float *V2, const float *c2, float *out, int batch, int n3) {
     __shared__ __align__(16) float x[16][256];
+    __shared__ float red[3][16][64];
     const int b0 = blockIdx.y * 16;
-    for (int e = threadIdx.x; e < 16 * 256; e += 128) {
+    for (int e = threadIdx.x; e < 16 * 256; e += 256) {
         const int bb = e >> 8;
         x[bb][e & 255] = b0 + bb < batch ? d2[(size_t)(b0 + bb) * 256 + (e & 255)] : 0.f;
     }
     __syncthreads();
-    const int n = blockIdx.x * 128 + threadIdx.x;
-    if (n >= n3) return;
+    const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int n = min(blockIdx.x * 64 + col, n3 - 1);
     float acc[16] = {};
-    for (int k = 0; k < 256; k += 4) {
+#pragma unroll 2
+    for (int k = ks * 64; k < ks * 64 + 64; k += 4) {
         const float w0 = V2[(size_t)k * n3 + n], w1 = V2[(size_t)(k + 1) * n3 + n];
         const float w2 = V2[(size_t)(k + 2) * n3 + n], w3 = V2[(size_t)(k + 3) * n3 + n];
 #pragma unroll
@@ -227,17 +235,39 @@ __global__ __launch_bounds__(128) void fc_out_fwd_kernel(const float *d2, const 
             acc[bb] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[bb]))));
         }
     }
-    const float c = c2[n];
+    if (ks > 0) {
 #pragma unroll
-    for (int bb = 0; bb < 16; ++bb)
-        if (b0 + bb < batch) out[(size_t)(b0 + bb) * n3 + n] = acc[bb] + c;
+        for (int bb = 0; bb < 16; ++bb) red[ks - 1][bb][col] = acc[bb];
+    }
+    __syncthreads();
+    if (ks == 0 && blockIdx.x * 64 + col < n3) {
+        const float c = c2[n];
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb)
+            if (b0 + bb < batch) out[(size_t)(b0 + bb) * n3 + n] = (((acc[bb] + red[0][bb][col]) + red[1][bb][col]) + red[2][bb][col]) + c;
+    }
 }
 
 // loss = (sum dist1 + sum dist2) / (B * N): tf.reduce_mean over all elements of each direction (pointnet_ae.py:77)
 __global__ __launch_bounds__(1024) void chamfer_loss_kernel(const float *d1, const float *d2, size_t count, double inv, float *loss) {
     __shared__ double red[1024];
+    const float4 *a = reinterpret_cast<const float4 *>(d1), *b = reinterpret_cast<const float4 *>(d2);
+    const size_t q = count / 4;                               // count = B * n is a multiple of 64
     double s = 0.0;
-    for (size_t e = threadIdx.x; e < count; e += 1024) s += (double)d1[e] + (double)d2[e];
+    size_t e = threadIdx.x;
+    for (; e + 3072 < q; e += 4096) {
+        float4 u[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { u[k] = a[e + 1024 * k]; v[k] = b[e + 1024 * k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            s += ((double)u[k].x + (double)u[k].y) + ((double)u[k].z + (double)u[k].w) + ((double)v[k].x + (double)v[k].y) +
+                 ((double)v[k].z + (double)v[k].w);
+    }
+    for (; e < q; e += 1024) {
+        const float4 u = a[e], v = b[e];
+        s += ((double)u.x + (double)u.y) + ((double)u.z + (double)u.w) + ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int w = 512; w > 0; w >>= 1) {
@@ -318,6 +348,7 @@ __global__ __launch_bounds__(256) void fc_out_bwd_x_kernel(const float *g, const
 __global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float *in, const float *dout, float *dW, float *db, int batch, int K) {
     const int k = blockIdx.x, n = threadIdx.x;
     float acc = 0.f, s = 0.f;
+#pragma unroll 8
     for (int b = 0; b < batch; ++b) {
         const float d = dout[(size_t)b * 256 + n];
         acc = fmaf(in[(size_t)b * K + k], d, acc);
@@ -401,18 +432,24 @@ __global__ __launch_bounds__(256) void train_pool_bwd_kernel(PoolBwdArgs A) {
 // d beta = sum dy, d gamma = sum dy * xhat (double, fixed order); m1 = d beta / R, m2 = d gamma / R
 struct BnBwdArgs { const float2 *qsum; int tiles; int C; double inv_rows; float *dbeta, *dgamma, *m1, *m2; };
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs A) {
-    __shared__ double r1[8][32], r2[8][32];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs A) {
+    __shared__ double r1[32][32], r2[32][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = g; t < A.tiles; t += 8) {
+    int t = g;
+    for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight, summed in ascending tile order
+        const float2 p0 = A.qsum[(size_t)t * A.C + c], p1 = A.qsum[(size_t)(t + 32) * A.C + c];
+        const float2 p2 = A.qsum[(size_t)(t + 64) * A.C + c], p3 = A.qsum[(size_t)(t + 96) * A.C + c];
+        s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
+    }
+    for (; t < A.tiles; t += 32) {
         const float2 p = A.qsum[(size_t)t * A.C + c];
         s1 += p.x; s2 += p.y;
     }
     r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
     __syncthreads();
     if (g == 0) {
-        for (int k = 1; k < 8; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
+        for (int k = 1; k < 32; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
         A.dbeta[c] = (float)s1; A.dgamma[c] = (float)s2;
         A.m1[c] = (float)(s1 * A.inv_rows); A.m2[c] = (float)(s2 * A.inv_rows);
     }
@@ -593,13 +630,28 @@ __global__ __launch_bounds__(TR_THREADS) void train_bwd0_kernel(BwdArgs A) {
     }
 }
 
-// out[e] = sum over workgroups (ascending) of partial[w][e]
+// out[e] = sum over workgroups of partial[w][e], in a fixed order: four contiguous runs of workgroups summed
+// front to back by four threads, then run0 + run1 + run2 + run3
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float *partial, int parts, size_t count, float *out) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
+    __shared__ float red[4][64];
+    const size_t e = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    const int per = (parts + 3) / 4, w0 = g * per, w1 = min(parts, w0 + per);
     float s = 0.f;
-    for (int w = 0; w < parts; ++w) s += partial[(size_t)w * count + e];
-    out[e] = s;
+    if (e < count) {
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(w + u) * count + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; w < w1; ++w) s += partial[(size_t)w * count + e];
+    }
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && e < count) out[e] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,14 +671,21 @@ __global__ __launch_bounds__(256) void train_adam_kernel(float *p, float *m, flo
 }
 
 // packed[((cb * K/8 + t) * 64 + lane) * 4 + u] = B[8t + 4*(lane>>5) + u][32cb + (lane&31)];
-// B = W [K][N] (transpose == 0) or B[k][n] = W[n][k] with W stored [N][K] (transpose == 1)
-__global__ __launch_bounds__(256) void repack_kernel(const float *W, float *packed, int K, int N, int transpose) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// B = W [K][N] (transpose == 0) or B[k][n] = W[n][k] with W stored [N][K] (transpose == 1).  One launch re-packs
+// the forward and the transposed fragments of the four wide encoder layers.
+struct RepackArgs { const float *W[8]; float *packed[8]; int K[8], N[8], transpose[8], first_block[9]; };
+
+__global__ __launch_bounds__(256) void repack_kernel(RepackArgs A) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) j += (int)blockIdx.x >= A.first_block[k];
+    const int K = A.K[j], N = A.N[j];
+    const int e = ((int)blockIdx.x - A.first_block[j]) * 256 + threadIdx.x;
     if (e >= K * N) return;
     const int u = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
     const int kg = K / 8, t = rest % kg, cb = rest / kg;
     const int k = 8 * t + 4 * (lane >> 5) + u, n = 32 * cb + (lane & 31);
-    packed[e] = transpose ? W[(size_t)n * K + k] : W[(size_t)k * N + n];
+    A.packed[j][e] = A.transpose[j] ? A.W[j][(size_t)n * K + k] : A.W[j][(size_t)k * N + n];
 }
 
 }  // namespace geoadv
@@ -682,11 +741,19 @@ struct geoadv_trainer {
 };
 
 static int trainer_repack(geoadv_trainer *t, hipStream_t st) {
-    for (int i = 1; i < ENC_L; ++i) {
-        const int K = ENC[i], N = ENC[i + 1], cnt = K * N;
-        repack_kernel<<<cdiv(cnt, 256), 256, 0, st>>>(t->params + t->L.w[i], t->packed_fwd[i], K, N, 0);
-        repack_kernel<<<cdiv(cnt, 256), 256, 0, st>>>(t->params + t->L.w[i], t->packed_bwd[i], N, K, 1);
-    }
+    RepackArgs a;
+    int blocks = 0;
+    for (int i = 1; i < ENC_L; ++i)
+        for (int tr = 0; tr < 2; ++tr) {
+            const int j = 2 * (i - 1) + tr;
+            a.W[j] = t->params + t->L.w[i];
+            a.packed[j] = tr ? t->packed_bwd[i] : t->packed_fwd[i];
+            a.K[j] = tr ? ENC[i + 1] : ENC[i]; a.N[j] = tr ? ENC[i] : ENC[i + 1]; a.transpose[j] = tr;
+            a.first_block[j] = blocks;
+            blocks += cdiv(ENC[i] * ENC[i + 1], 256);
+        }
+    a.first_block[8] = blocks;
+    repack_kernel<<<blocks, 256, 0, st>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -820,7 +887,7 @@ static int launch_bn(geoadv_trainer *t, int i, hipStream_t st) {
     a.gamma = t->params + t->L.gamma[i]; a.beta = t->params + t->L.beta[i];
     a.mean = t->bn_mean[i]; a.inv_std = t->bn_istd[i]; a.scale = t->bn_scale[i]; a.shift = t->bn_shift[i];
     a.mov_mean = t->mov_mean[i]; a.mov_var = t->mov_var[i]; a.one_minus_decay = t->one_minus_decay;
-    bn_finalize_kernel<<<ENC[i + 1] / 32, 256, 0, st>>>(a);
+    bn_finalize_kernel<<<ENC[i + 1] / 32, 1024, 0, st>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -844,8 +911,8 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
     train_bwd_kernel<CIN, COUT><<<t->grid_bwd, TR_THREADS, S::lds_bytes, st>>>(a);
     GA_LAUNCH_CHECK();
     const size_t cnt = (size_t)CIN * COUT;
-    partial_reduce_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(t->dw_partial, t->grid_bwd, cnt, t->grads + t->L.w[i]);
-    partial_reduce_kernel<<<cdiv(COUT, 256), 256, 0, st>>>(t->db_partial, t->grid_bwd, COUT, t->grads + t->L.b[i]);
+    partial_reduce_kernel<<<(unsigned)((cnt + 63) / 64), 256, 0, st>>>(t->dw_partial, t->grid_bwd, cnt, t->grads + t->L.w[i]);
+    partial_reduce_kernel<<<cdiv(COUT, 64), 256, 0, st>>>(t->db_partial, t->grid_bwd, COUT, t->grads + t->L.b[i]);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -854,7 +921,7 @@ static int launch_bn_bwd(geoadv_trainer *t, int i, hipStream_t st) {
     BnBwdArgs a;
     a.qsum = t->qsum; a.tiles = t->tiles; a.C = ENC[i + 1]; a.inv_rows = 1.0 / (double)t->R;
     a.dbeta = t->grads + t->L.beta[i]; a.dgamma = t->grads + t->L.gamma[i]; a.m1 = t->bn_m1[i]; a.m2 = t->bn_m2[i];
-    bn_bwd_finalize_kernel<<<ENC[i + 1] / 32, 256, 0, st>>>(a);
+    bn_bwd_finalize_kernel<<<ENC[i + 1] / 32, 1024, 0, st>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -895,7 +962,7 @@ extern "C" int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x
     const float *V0 = t->params + t->L.v[0], *V1 = t->params + t->L.v[1], *V2 = t->params + t->L.v[2];
     fc_fwd_kernel<128, true><<<B, 256, 0, st>>>(z, V0, t->params + t->L.c[0], t->d1, 256);
     fc_fwd_kernel<256, true><<<B, 256, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2, 256);
-    fc_out_fwd_kernel<<<dim3(cdiv(n3, 128), cdiv(B, 16)), 128, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
+    fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
     GA_LAUNCH_CHECK();
     // ---- Chamfer loss and its gradient w.r.t. the reconstruction ----
     if (int rc = geoadv_nn_distance(B, n, t->recon, n, gt, t->dist1, t->idx1, t->dist2, t->idx2, stream)) return rc;
@@ -931,7 +998,7 @@ extern "C" int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x
         a.mean = t->bn_mean[0]; a.inv_std = t->bn_istd[0]; a.gamma = t->params + t->L.gamma[0]; a.m1 = t->bn_m1[0]; a.m2 = t->bn_m2[0];
         a.aprev = x; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
         train_bwd0_kernel<<<t->grid_bwd, TR_THREADS, 0, st>>>(a);
-        partial_reduce_kernel<<<1, 256, 0, st>>>(t->dw_partial, t->grid_bwd, 192, t->grads + t->L.w[0]);
+        partial_reduce_kernel<<<3, 256, 0, st>>>(t->dw_partial, t->grid_bwd, 192, t->grads + t->L.w[0]);
         partial_reduce_kernel<<<1, 256, 0, st>>>(t->db_partial, t->grid_bwd, 64, t->grads + t->L.b[0]);
         GA_LAUNCH_CHECK();
     }
