@@ -556,6 +556,10 @@ int do_step(geoadv_attack *at, hipStream_t st) {
 
 }  // namespace
 
+namespace geoadv {   // the same gradient for the training step (train.hip)
+int launch_chamfer_grad(const CGradProblem *pr, int np, int B, int n, hipStream_t st) { return launch_cgrad(pr, np, B, n, st); }
+}
+
 extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, const geoadv_attack_config *cfg) {
     GA_REQUIRE(out && ae && cfg, "attack_create: null argument");
     GA_REQUIRE(cfg->batch >= 1 && cfg->batch <= 65535, "attack_create: batch %d out of range", cfg->batch);

@@ -19,10 +19,20 @@
 #include "ae.h"
 #include "mfma_tile.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
 namespace geoadv {
+
+// ---- from the other translation units (the Chamfer pieces of the attack loop) ----
+struct ChamferPair { const float *p, *q; float *dist1; int *idx1; float *dist2; int *idx2; };
+size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
+int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
+struct CGradProblem {
+    const float *p, *q; const int *idx1, *idx2; float *g; const float *w; const int *jstar; float extra_w;
+};
+int launch_chamfer_grad(const CGradProblem *pr, int np, int B, int n, hipStream_t st);
 
 constexpr int TR_THREADS = 512;
 constexpr int TR_ROWS = 64;
@@ -69,20 +79,30 @@ __global__ __launch_bounds__(TR_THREADS) void train_fwd0_kernel(FwdArgs A) {
 }
 
 // h tile = relu(a * s + t) -> LDS [64][C + 4]
-template <int C>
+template <int C, int ROWS = TR_ROWS>
 __device__ __forceinline__ void load_activated_tile(const float *a, size_t row0, const float *scale, const float *shift,
                                                     float *lds) {
     constexpr int Q = C / 4;                          // float4 per row; divides TR_THREADS
     const int c4 = threadIdx.x % Q, r0 = threadIdx.x / Q;
     const float4 s = reinterpret_cast<const float4 *>(scale)[c4], t = reinterpret_cast<const float4 *>(shift)[c4];
 #pragma unroll
-    for (int r = r0; r < TR_ROWS; r += TR_THREADS / Q) {
+    for (int r = r0; r < ROWS; r += TR_THREADS / Q) {
         const float4 v = reinterpret_cast<const float4 *>(a + (row0 + r) * C)[c4];
         float4 h;
         h.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f); h.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
         h.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f); h.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
         *reinterpret_cast<float4 *>(lds + r * (C + 4) + 4 * c4) = h;
     }
+}
+
+// raw tile -> LDS [ROWS][C + 4]
+template <int C, int ROWS>
+__device__ __forceinline__ void load_raw_tile(const float *a, size_t row0, float *lds) {
+    constexpr int Q = C / 4;
+    const int c4 = threadIdx.x % Q, r0 = threadIdx.x / Q;
+#pragma unroll
+    for (int r = r0; r < ROWS; r += TR_THREADS / Q)
+        *reinterpret_cast<float4 *>(lds + r * (C + 4) + 4 * c4) = reinterpret_cast<const float4 *>(a + (row0 + r) * C)[c4];
 }
 
 template <int CIN, int COUT>
@@ -467,11 +487,12 @@ struct BwdArgs {
     float2 *qsum_out;                // [tiles][CIN]
     float *dw_partial;               // [grid][CIN][COUT]
     float *db_partial;               // [grid][COUT]
+    int debug_skip;                  // timing experiments only (GEOADV_TRAIN_SKIP): 1 = no dW GEMM, 2 = no dy GEMM, 4 = no tile loads
 };
 
 // da tile = gamma * inv_std * (dy - m1 - xhat * m2), xhat = (a - mean) * inv_std -> LDS [64][C + 4]; returns this
 // thread's column sums (bias gradient; mathematically zero behind a BN, kept because TF computes it)
-template <int C>
+template <int C, int ROWS>
 __device__ __forceinline__ void load_da_tile(const BwdArgs &A, size_t row0, const float *cc /*LDS [5][C]*/, float *lds, float4 &dbacc) {
     constexpr int Q = C / 4;
     const int c4 = threadIdx.x % Q, r0 = threadIdx.x / Q;
@@ -479,7 +500,7 @@ __device__ __forceinline__ void load_da_tile(const BwdArgs &A, size_t row0, cons
     const float4 gi = reinterpret_cast<const float4 *>(cc + 2 * C)[c4];
     const float4 m1 = reinterpret_cast<const float4 *>(cc + 3 * C)[c4], m2 = reinterpret_cast<const float4 *>(cc + 4 * C)[c4];
 #pragma unroll
-    for (int r = r0; r < TR_ROWS; r += TR_THREADS / Q) {
+    for (int r = r0; r < ROWS; r += TR_THREADS / Q) {
         const float4 d = reinterpret_cast<const float4 *>(A.dy + (row0 + r) * C)[c4];
         const float4 a = reinterpret_cast<const float4 *>(A.a + (row0 + r) * C)[c4];
         float4 o;
@@ -490,22 +511,29 @@ __device__ __forceinline__ void load_da_tile(const BwdArgs &A, size_t row0, cons
     }
 }
 
-template <int CIN, int COUT> struct BwdShape {
+// ROWS = 32: two workgroups share a CU (one loads / stores while the other runs its MFMA chains); the tile is one
+// row block high, so every dy_out column lives in exactly one wave.
+constexpr int BWD_ROWS = 64;     // measured: 32-row tiles (two workgroups per CU, 128 VGPRs) are 10-20 % slower
+
+template <int CIN, int COUT, int ROWS> struct BwdShape {
     static constexpr int MB = CIN / 32, NB = COUT / 32;
     static constexpr int MBW = (MB * NB >= 32) ? 2 : 1;                 // blocks of dW per wave: MBW x NBW
     static constexpr int NBW = (MB * NB >= 16) ? 2 : 1;
     static constexpr int WCOLS = NB / NBW;                                // waves along the COUT axis
     static_assert((MB / MBW) * (NB / NBW) == 8, "dW blocks must map onto 8 waves");
-    static constexpr int DA_FLOATS = TR_ROWS * (COUT + 4), H_FLOATS = TR_ROWS * (CIN + 4);
-    static constexpr int SCRATCH_FLOATS = (CIN == 64) ? 4 * 16 * 64 : 0;  // K-part hand-off of layer_gemm<64, 64, 2>
+    static constexpr int DA_FLOATS = ROWS * (COUT + 4), H_FLOATS = ROWS * (CIN + 4);
+    static constexpr int UNITS = (MB * (ROWS / 32) > 8) ? MB : MB * (ROWS / 32);      // of layer_gemm<ROWS, CIN, 0>
+    static constexpr int KC = 8 / UNITS;
+    static constexpr int SCRATCH_FLOATS = (KC - 1) * UNITS * 16 * 64;     // K-part hand-off
     static constexpr int CC_FLOATS = 5 * COUT;
-    static constexpr int RED_FLOATS = 2 * 2 * CIN + 16 * COUT;            // qsum [2][CIN] float2, db [<=16][COUT]... see kernel
+    static constexpr int RED_FLOATS = 4 * CIN;                            // qsum [2][CIN] float2 (64-row tiles)
+    static_assert(DA_FLOATS >= (TR_THREADS / (COUT / 4)) * COUT, "bias-gradient reduction aliases the da tile");
     static constexpr size_t lds_bytes = sizeof(float) * (DA_FLOATS + H_FLOATS + SCRATCH_FLOATS + CC_FLOATS + RED_FLOATS);
 };
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(TR_THREADS, 1) void train_bwd_kernel(BwdArgs A) {
-    using S = BwdShape<CIN, COUT>;
+template <int CIN, int COUT, int ROWS>
+__global__ __launch_bounds__(TR_THREADS, ROWS == 32 ? 4 : 2) void train_bwd_kernel(BwdArgs A) {
+    using S = BwdShape<CIN, COUT, ROWS>;
     extern __shared__ __align__(16) float lds[];
     float *da = lds;
     float *ht = da + S::DA_FLOATS;
@@ -519,24 +547,30 @@ __global__ __launch_bounds__(TR_THREADS, 1) void train_bwd_kernel(BwdArgs A) {
         cc[3 * COUT + e] = A.m1[e]; cc[4 * COUT + e] = A.m2[e];
     }
     // previous layer's BN constants of this lane's dy_out column
-    const int ocol = layer_gemm_lane_col<TR_ROWS, CIN>();
+    const int ocol = layer_gemm_lane_col<ROWS, CIN>();
     const float ps = A.pscale[ocol], pt = A.pshift[ocol], pm = A.pmean[ocol], pis = A.pinv_std[ocol];
     const int mb0 = (wave / S::WCOLS) * S::MBW, nb0 = (wave % S::WCOLS) * S::NBW;
     f32x16 dw[S::MBW][S::NBW] = {};
+    float hs[S::MBW], hsh[S::MBW];                       // previous layer's folded BN of this lane's h columns
+#pragma unroll
+    for (int m = 0; m < S::MBW; ++m) { hs[m] = A.pscale[(mb0 + m) * 32 + li]; hsh[m] = A.pshift[(mb0 + m) * 32 + li]; }
     float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     for (int tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
-        const size_t row0 = (size_t)tile * TR_ROWS;
-        load_da_tile<COUT>(A, row0, cc, da, dbacc);
-        load_activated_tile<CIN>(A.aprev, row0, A.pscale, A.pshift, ht);
+        const size_t row0 = (size_t)tile * ROWS;
+        if (!(A.debug_skip & 4)) {
+            load_da_tile<COUT, ROWS>(A, row0, cc, da, dbacc);
+            load_raw_tile<CIN, ROWS>(A.aprev, row0, ht);          // raw a_{i-1}: activated on the way into the MFMA
+        }
         __syncthreads();
         // dW += h^T @ da : A operand = h^T (lane: m = channel li of block mb, k = row 2kk + hh), B operand = da
+        if (!(A.debug_skip & 1))
 #pragma unroll 8
-        for (int kk = 0; kk < TR_ROWS / 2; ++kk) {
+        for (int kk = 0; kk < ROWS / 2; ++kk) {
             const int row = 2 * kk + hh;
             float av[S::MBW], bv[S::NBW];
 #pragma unroll
-            for (int m = 0; m < S::MBW; ++m) av[m] = ht[row * (CIN + 4) + (mb0 + m) * 32 + li];
+            for (int m = 0; m < S::MBW; ++m) av[m] = fmaxf(fmaf(ht[row * (CIN + 4) + (mb0 + m) * 32 + li], hs[m], hsh[m]), 0.f);
 #pragma unroll
             for (int n = 0; n < S::NBW; ++n) bv[n] = da[row * (COUT + 4) + (nb0 + n) * 32 + li];
 #pragma unroll
@@ -549,20 +583,37 @@ __global__ __launch_bounds__(TR_THREADS, 1) void train_bwd_kernel(BwdArgs A) {
         float q1 = 0.f, q2 = 0.f;
         int rb_seen = 0;
         bool ran = false;
-        layer_gemm<TR_ROWS, CIN, 0>(da, COUT + 4, A.WT, scratch, [&](int row, int c, float v) {
-            const float ap = A.aprev[(row0 + row) * CIN + c];
-            const float dyv = fmaf(ap, ps, pt) > 0.f ? v : 0.f;
-            A.dy_out[(row0 + row) * CIN + c] = dyv;
-            q1 += dyv;
-            q2 = fmaf(dyv, (ap - pm) * pis, q2);
+        // The accumulators are parked first; the a_{i-1} values of this lane come back from the LDS tile (reading them
+        // from global memory between the dy stores costs an L2 round trip per element).
+        constexpr int NV = (CIN / 32) * (ROWS / 32) > 8 ? 32 : 16;
+        float vals[NV], apv[NV];
+        int rows[NV];
+        int cnt = 0;
+        if (!(A.debug_skip & 2))
+        layer_gemm<ROWS, CIN, 0>(da, COUT + 4, A.WT, scratch, [&](int row, int c, float v) {
+            vals[cnt] = v; rows[cnt] = row; ++cnt;
             rb_seen = row >> 5;
             ran = true;
         });
+        if (ran && (A.debug_skip & 8)) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) q1 += vals[j];
+        } else if (ran) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) apv[j] = ht[rows[j] * (CIN + 4) + ocol];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float dyv = fmaf(apv[j], ps, pt) > 0.f ? vals[j] : 0.f;
+                A.dy_out[(row0 + rows[j]) * CIN + ocol] = dyv;
+                q1 += dyv;
+                q2 = fmaf(dyv, (apv[j] - pm) * pis, q2);
+            }
+        }
         q1 += __shfl_xor(q1, 32);
         q2 += __shfl_xor(q2, 32);
-        constexpr bool BOTH = (CIN / 32) * 2 > 8;
+        constexpr bool WHOLE = (ROWS == 32) || (CIN / 32) * 2 > 8;       // one wave holds the whole column of the tile
         float2 *qred = reinterpret_cast<float2 *>(red);              // [2][CIN]
-        if (BOTH) {
+        if (WHOLE) {
             if (ran && hh == 0) A.qsum_out[(size_t)tile * CIN + ocol] = make_float2(q1, q2);
             __syncthreads();
         } else {
@@ -585,7 +636,7 @@ __global__ __launch_bounds__(TR_THREADS, 1) void train_bwd_kernel(BwdArgs A) {
                 dst[(size_t)((mb0 + m) * 32 + acc_row(r, hh)) * COUT + (nb0 + n) * 32 + li] = dw[m][n][r];
     // bias-gradient partial: threads sharing a float4 column group are summed in a fixed order
     constexpr int Q = COUT / 4, G = TR_THREADS / Q;
-    float *dbred = red + 4 * CIN;                                   // [G][COUT]
+    float *dbred = da;                                              // [G][COUT], the tile is no longer needed
     __syncthreads();
     *reinterpret_cast<float4 *>(dbred + (threadIdx.x / Q) * COUT + 4 * (threadIdx.x % Q)) = dbacc;
     __syncthreads();
@@ -734,7 +785,7 @@ struct geoadv_trainer {
     float *dybuf[2];                   // [R][256] ping-pong
     float2 *psum, *qsum;               // [tiles][256]
     int *zbits, *cnt;                  // [B][128]
-    float *d1, *d2, *recon, *g_recon, *g_gt, *gd, *dd2, *dd1, *dz;
+    float *d1, *d2, *recon, *g_recon, *cham_ws, *gd, *dd2, *dd1, *dz;
     float *dist1, *dist2; int *idx1, *idx2;
     float *dw_partial, *db_partial;
     float *loss;
@@ -776,7 +827,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    t->grid_bwd = t->tiles < cus ? t->tiles : cus;
+    t->grid_bwd = cus * (64 / BWD_ROWS);                  // persistent backward workgroups
     // carve
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) / 256 * 256; return r; };
@@ -790,11 +841,12 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
         o_act[i] = take(4 * (size_t)t->R * ENC[i + 1]);
     }
     const size_t o_dy0 = take(4 * (size_t)t->R * 256), o_dy1 = take(4 * (size_t)t->R * 256);
-    const size_t o_ps = take(8 * (size_t)t->tiles * 256), o_qs = take(8 * (size_t)t->tiles * 256);
+    const size_t o_ps = take(8 * (size_t)t->tiles * 256), o_qs = take(8 * (size_t)(t->R / BWD_ROWS) * 256);
     const size_t o_z = take(4 * (size_t)B * 128), o_cnt = take(4 * (size_t)B * 128);
     const size_t o_d1 = take(4 * (size_t)B * 256), o_d2 = take(4 * (size_t)B * 256);
-    const size_t o_rec = take(4 * (size_t)B * t->n3), o_gr = take(4 * (size_t)B * t->n3), o_gg = take(4 * (size_t)B * t->n3);
-    const size_t o_gd = take(4 * (size_t)B * n), o_dd2 = take(4 * (size_t)B * 256), o_dd1 = take(4 * (size_t)B * 256);
+    const size_t o_rec = take(4 * (size_t)B * t->n3), o_gr = take(4 * (size_t)B * t->n3);
+    const size_t o_cws = take(4 * chamfer_sym_workspace_floats(1, B, n, n));
+    const size_t o_gd = take(4 * (size_t)B), o_dd2 = take(4 * (size_t)B * 256), o_dd1 = take(4 * (size_t)B * 256);
     const size_t o_dz = take(4 * (size_t)B * 128);
     const size_t o_di1 = take(4 * (size_t)B * n), o_di2 = take(4 * (size_t)B * n), o_i1 = take(4 * (size_t)B * n), o_i2 = take(4 * (size_t)B * n);
     const size_t o_dwp = take(4 * (size_t)t->grid_bwd * 256 * 128), o_dbp = take(4 * (size_t)t->grid_bwd * 256);
@@ -816,7 +868,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     t->dybuf[0] = F(o_dy0); t->dybuf[1] = F(o_dy1);
     t->psum = reinterpret_cast<float2 *>(F(o_ps)); t->qsum = reinterpret_cast<float2 *>(F(o_qs));
     t->zbits = reinterpret_cast<int *>(F(o_z)); t->cnt = reinterpret_cast<int *>(F(o_cnt));
-    t->d1 = F(o_d1); t->d2 = F(o_d2); t->recon = F(o_rec); t->g_recon = F(o_gr); t->g_gt = F(o_gg); t->gd = F(o_gd);
+    t->d1 = F(o_d1); t->d2 = F(o_d2); t->recon = F(o_rec); t->g_recon = F(o_gr); t->cham_ws = F(o_cws); t->gd = F(o_gd);
     t->dd2 = F(o_dd2); t->dd1 = F(o_dd1); t->dz = F(o_dz);
     t->dist1 = F(o_di1); t->dist2 = F(o_di2); t->idx1 = reinterpret_cast<int *>(F(o_i1)); t->idx2 = reinterpret_cast<int *>(F(o_i2));
     t->dw_partial = F(o_dwp); t->db_partial = F(o_dbp); t->loss = F(o_loss);
@@ -842,7 +894,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
         if (e == hipSuccess) e = hipMemcpy(t->mov_var[i], hw->bn_var[i], 4 * ENC[i + 1], hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) {
-        std::vector<float> gdv((size_t)B * n, 1.0f / ((float)B * (float)n));     // d reduce_mean / d dist
+        std::vector<float> gdv((size_t)B, 1.0f / (float)B);     // d reduce_mean over [B, n] / d dist = (1/B) * (1/n)
         e = hipMemcpy(t->gd, gdv.data(), 4 * gdv.size(), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
@@ -894,32 +946,36 @@ static int launch_bn(geoadv_trainer *t, int i, hipStream_t st) {
 
 template <int CIN, int COUT>
 static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, hipStream_t st) {
-    using S = BwdShape<CIN, COUT>;
+    using S = BwdShape<CIN, COUT, BWD_ROWS>;
     BwdArgs a;
-    a.tiles = t->tiles; a.dy = dy; a.a = t->act[i];
+    a.tiles = t->R / BWD_ROWS; a.dy = dy; a.a = t->act[i];
     a.mean = t->bn_mean[i]; a.inv_std = t->bn_istd[i]; a.gamma = t->params + t->L.gamma[i]; a.m1 = t->bn_m1[i]; a.m2 = t->bn_m2[i];
     a.aprev = t->act[i - 1];
     a.pscale = t->bn_scale[i - 1]; a.pshift = t->bn_shift[i - 1]; a.pmean = t->bn_mean[i - 1]; a.pinv_std = t->bn_istd[i - 1];
     a.WT = PackedLayer{t->packed_bwd[i], COUT, CIN};
     a.dy_out = dy_out; a.qsum_out = t->qsum; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
+    static int skip = -1;
+    if (skip < 0) { const char *e = getenv("GEOADV_TRAIN_SKIP"); skip = e ? atoi(e) : 0; }
+    a.debug_skip = skip;
     static bool attr = false;
     if (!attr) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_kernel<CIN, COUT>),
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_kernel<CIN, COUT, BWD_ROWS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes));
         attr = true;
     }
-    train_bwd_kernel<CIN, COUT><<<t->grid_bwd, TR_THREADS, S::lds_bytes, st>>>(a);
+    const int grid = a.tiles < t->grid_bwd ? a.tiles : t->grid_bwd;
+    train_bwd_kernel<CIN, COUT, BWD_ROWS><<<grid, TR_THREADS, S::lds_bytes, st>>>(a);
     GA_LAUNCH_CHECK();
     const size_t cnt = (size_t)CIN * COUT;
-    partial_reduce_kernel<<<(unsigned)((cnt + 63) / 64), 256, 0, st>>>(t->dw_partial, t->grid_bwd, cnt, t->grads + t->L.w[i]);
-    partial_reduce_kernel<<<cdiv(COUT, 64), 256, 0, st>>>(t->db_partial, t->grid_bwd, COUT, t->grads + t->L.b[i]);
+    partial_reduce_kernel<<<(unsigned)((cnt + 63) / 64), 256, 0, st>>>(t->dw_partial, grid, cnt, t->grads + t->L.w[i]);
+    partial_reduce_kernel<<<cdiv(COUT, 64), 256, 0, st>>>(t->db_partial, grid, COUT, t->grads + t->L.b[i]);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
 
-static int launch_bn_bwd(geoadv_trainer *t, int i, hipStream_t st) {
+static int launch_bn_bwd(geoadv_trainer *t, int i, int partial_rows, hipStream_t st) {
     BnBwdArgs a;
-    a.qsum = t->qsum; a.tiles = t->tiles; a.C = ENC[i + 1]; a.inv_rows = 1.0 / (double)t->R;
+    a.qsum = t->qsum; a.tiles = t->R / partial_rows; a.C = ENC[i + 1]; a.inv_rows = 1.0 / (double)t->R;
     a.dbeta = t->grads + t->L.beta[i]; a.dgamma = t->grads + t->L.gamma[i]; a.m1 = t->bn_m1[i]; a.m2 = t->bn_m2[i];
     bn_bwd_finalize_kernel<<<ENC[i + 1] / 32, 1024, 0, st>>>(a);
     GA_LAUNCH_CHECK();
@@ -965,10 +1021,14 @@ extern "C" int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x
     fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
     GA_LAUNCH_CHECK();
     // ---- Chamfer loss and its gradient w.r.t. the reconstruction ----
-    if (int rc = geoadv_nn_distance(B, n, t->recon, n, gt, t->dist1, t->idx1, t->dist2, t->idx2, stream)) return rc;
+    // one distance evaluation per pair serves both directions (chamfer_sym.hip); dist/idx bit-identical to nn_distance
+    const ChamferPair cp{t->recon, gt, t->dist1, t->idx1, t->dist2, t->idx2};
+    if (int rc = launch_chamfer_sym(&cp, 1, B, n, n, t->cham_ws, st)) return rc;
     chamfer_loss_kernel<<<1, 1024, 0, st>>>(t->dist1, t->dist2, (size_t)B * n, 1.0 / ((double)B * n), t->loss);
     GA_LAUNCH_CHECK();
-    if (int rc = geoadv_nn_distance_grad(B, n, t->recon, n, gt, t->gd, t->idx1, t->gd, t->idx2, t->g_recon, t->g_gt, stream)) return rc;
+    // NnDistanceGrad w.r.t. the reconstruction only (order-independent fixed-point accumulation, attack.hip)
+    const CGradProblem gp{t->recon, gt, t->idx1, t->idx2, t->g_recon, t->gd, nullptr, 0.f};
+    if (int rc = launch_chamfer_grad(&gp, 1, B, n, st)) return rc;
     // ---- decoder backward ----
     fc_out_bwd_w_kernel<<<dim3(cdiv(n3, 128), 8), 128, sizeof(float) * B * 32, st>>>(t->d2, t->g_recon, t->grads + t->L.v[2],
                                                                                     t->grads + t->L.c[2], B, n3);
@@ -983,23 +1043,24 @@ extern "C" int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x
                    t->dybuf[0], t->qsum};
     train_pool_bwd_kernel<<<t->tiles, 256, 0, st>>>(pb);
     GA_LAUNCH_CHECK();
-    if (int rc = launch_bn_bwd(t, 4, st)) return rc;
+    if (int rc = launch_bn_bwd(t, 4, TR_ROWS, st)) return rc;
     if (int rc = launch_bwd<256, 128>(t, 4, t->dybuf[0], t->dybuf[1], st)) return rc;
-    if (int rc = launch_bn_bwd(t, 3, st)) return rc;
+    if (int rc = launch_bn_bwd(t, 3, BWD_ROWS, st)) return rc;
     if (int rc = launch_bwd<128, 256>(t, 3, t->dybuf[1], t->dybuf[0], st)) return rc;
-    if (int rc = launch_bn_bwd(t, 2, st)) return rc;
+    if (int rc = launch_bn_bwd(t, 2, BWD_ROWS, st)) return rc;
     if (int rc = launch_bwd<128, 128>(t, 2, t->dybuf[0], t->dybuf[1], st)) return rc;
-    if (int rc = launch_bn_bwd(t, 1, st)) return rc;
+    if (int rc = launch_bn_bwd(t, 1, BWD_ROWS, st)) return rc;
     if (int rc = launch_bwd<64, 128>(t, 1, t->dybuf[1], t->dybuf[0], st)) return rc;
-    if (int rc = launch_bn_bwd(t, 0, st)) return rc;
+    if (int rc = launch_bn_bwd(t, 0, BWD_ROWS, st)) return rc;
     {
         BwdArgs a = {};
         a.tiles = t->tiles; a.dy = t->dybuf[0]; a.a = t->act[0];
         a.mean = t->bn_mean[0]; a.inv_std = t->bn_istd[0]; a.gamma = t->params + t->L.gamma[0]; a.m1 = t->bn_m1[0]; a.m2 = t->bn_m2[0];
         a.aprev = x; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
-        train_bwd0_kernel<<<t->grid_bwd, TR_THREADS, 0, st>>>(a);
-        partial_reduce_kernel<<<3, 256, 0, st>>>(t->dw_partial, t->grid_bwd, 192, t->grads + t->L.w[0]);
-        partial_reduce_kernel<<<1, 256, 0, st>>>(t->db_partial, t->grid_bwd, 64, t->grads + t->L.b[0]);
+        const int grid0 = t->tiles < t->grid_bwd ? t->tiles : t->grid_bwd;
+        train_bwd0_kernel<<<grid0, TR_THREADS, 0, st>>>(a);
+        partial_reduce_kernel<<<3, 256, 0, st>>>(t->dw_partial, grid0, 192, t->grads + t->L.w[0]);
+        partial_reduce_kernel<<<1, 256, 0, st>>>(t->db_partial, grid0, 64, t->grads + t->L.b[0]);
         GA_LAUNCH_CHECK();
     }
     if (loss) GA_HIP(hipMemcpyAsync(loss, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
