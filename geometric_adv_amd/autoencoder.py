@@ -3,7 +3,7 @@
 Mirrors what the attack path uses of src/adversary_autoencoder.py (restore_ae_model :42-51,
 reconstruct :75-91, get_latent_vectors) and src/autoencoder.py (get_loss_per_pc :150-168): the
 weights are uploaded once into libgeoadv.so (geoadv_ae_create packs them for MFMA) and every call
-runs the fused gfx950 kernels.  Training the AE is out of scope.
+runs the fused gfx950 kernels.  Training lives in trainer.py.
 """
 import ctypes as C
 

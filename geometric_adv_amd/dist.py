@@ -54,6 +54,20 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def all_reduce_sum_(t):
+    """In-place sum over the ranks of a (GPU) tensor: RCCL directly; a gloo group (CPU tests, or several ranks sharing
+    one GPU) stages through host memory."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        h = t.detach().cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
 def all_gather_examples(local, counts=None, axis=1):
     """all-gather a tensor whose `axis` is the example axis, concatenated in rank order.
     Ranks may hold different numbers of examples (pads to the maximum, trims after)."""

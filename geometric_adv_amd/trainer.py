@@ -172,8 +172,11 @@ class PointNetAETrainer:
         sync=False returns the loss as a 1-element GPU tensor without synchronising (throughput loops)."""
         recon, loss = self.forward_backward(X, GT, want_recon)
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            torch.distributed.all_reduce(self.gradient_buffer())
-            self.apply(1.0 / torch.distributed.get_world_size())
+            from .dist import all_reduce_sum_
+            world = torch.distributed.get_world_size()
+            all_reduce_sum_(self.gradient_buffer())                 # one flat buffer: a single collective per step
+            loss = all_reduce_sum_(loss.clone()) / world            # loss of the global batch (mean of equal shards)
+            self.apply(1.0 / world)
         else:
             self.apply(1.0)
         return recon, (float(loss.item()) if sync else loss)
