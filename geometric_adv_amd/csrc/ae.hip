@@ -8,7 +8,7 @@
 namespace geoadv {
 
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, hipStream_t stream);
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream);
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
 int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
@@ -59,7 +59,7 @@ ForwardScratch carve_forward_scratch(void *base, int b, int n_points) {
 
 int run_forward(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, const ForwardScratch &s,
                 float *recon, hipStream_t stream) {
-    if (int st = launch_encoder_fwd(A, b, x, pert, adv_out, s.pmax, s.parg, s.pcnt, stream)) return st;
+    if (int st = launch_encoder_fwd(A, b, x, pert, adv_out, s.pmax, s.parg, s.pcnt, nullptr, stream)) return st;
     if (int st = launch_latent_decode(A, b, s.pmax, s.parg, s.pcnt, s.z, s.crit, s.zcnt, s.dense,
                                       recon ? s.d1 : nullptr, s.d2, stream)) return st;
     if (recon)

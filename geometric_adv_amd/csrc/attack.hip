@@ -29,7 +29,8 @@ struct ForwardScratch {
 };
 ForwardScratch carve_forward_scratch(void *base, int b, int n_points);
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, hipStream_t stream);
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream);
+int encoder_mask_words();
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
 int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
@@ -37,7 +38,8 @@ int launch_decoder_bwd(const DeviceAE &A, int b, const float *g_recon, const flo
                        float *dz, hipStream_t stream);
 int decoder_bwd_chunks(const DeviceAE &A);
 int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *crit_rows, const float *z,
-                       const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, hipStream_t stream);
+                       const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, const unsigned *masks,
+                       hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // Per-cloud losses + metrics history + keep-best.  grid = clouds, 256 threads.
@@ -349,6 +351,7 @@ struct geoadv_attack {
     float *best_err, *best_metrics, *best_adv, *best_recon;
     float *emd_match, *emd_temp, *emd_cost, *emd_g1, *emd_g2;   // only when cfg.emd_weight > 0
     float *sym_ws;                   // column-minimum partials of the symmetric Chamfer kernel
+    unsigned *masks;                 // [B][n][mask words] ReLU masks of the cached forward, or null (backward recomputes)
     bool chamfer_sym;
     // host state
     float beta1_pow, beta2_pow;
@@ -427,7 +430,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st);
         if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, at->adv_valid ? nullptr : at->adv, at->fs.pmax, at->fs.parg,
-                                        at->fs.pcnt, st)) return rc;
+                                        at->fs.pcnt, at->masks, st)) return rc;
         at->adv_valid = true;
     }
     {
@@ -529,7 +532,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
     }
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_BWD, st);
-        if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, st))
+        if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, at->masks, st))
             return rc;
     }
     if (split) GA_HIP(hipStreamWaitEvent(st, at->ev_gdist, 0));
@@ -588,6 +591,9 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * B); need(4 * B * 4); need(4 * bn3); need(4 * bn3);
     const size_t sym_floats = chamfer_sym_workspace_floats(2, at->B, at->n, at->n);
     need(4 * sym_floats);
+    const char *mask_env = getenv("GEOADV_BWD_MASKS");             // "0": backward recomputes the forward (A/B tests)
+    const size_t mask_words = (mask_env && mask_env[0] == '0') ? 0 : (size_t)encoder_mask_words() * bn;   // ReLU masks of the cached forward
+    need(4 * mask_words);
     const bool emd = cfg->emd_weight > 0.f;
     const size_t emd_temp_f = emd ? geoadv_approx_match_temp_floats(at->B, at->n, at->n) : 0;
     if (emd) { need(4 * B * n * n); need(4 * emd_temp_f + 8); need(4 * B); need(4 * bn3); need(4 * bn3); }
@@ -613,6 +619,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->losses = F(4 * 8 * B); at->jstar = I(4 * 2 * B);
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
     at->sym_ws = F(4 * sym_floats);
+    at->masks = mask_words ? reinterpret_cast<unsigned *>(take(4 * mask_words)) : nullptr;
     {
         const char *e = getenv("GEOADV_CHAMFER_SYM");
         at->chamfer_sym = !(e && e[0] == '0');

@@ -170,6 +170,19 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(DeviceAE A, in
 // ------------------------------------------------------------------------------------------
 constexpr int FWD2_BUF_FLOATS = 64 * 132;
 constexpr size_t FWD2_LDS_BYTES = sizeof(float) * (2 * FWD2_BUF_FLOATS + 64 * 3 + 256) + sizeof(int) * 512;
+// ReLU masks of h1..h4 for the sparse backward (which then needs no forward recompute): MASK_WORDS 32-bit words per
+// point, bit c&31 of word OFF_L + (c>>5) = [h_L[c] > 0]; h1: words 0-1, h2: 2-5, h3: 6-9, h4: 10-17.  The h5 mask is
+// implied (the arg-max of a channel with z > 0 is positive).  Staged per tile in LDS, written out coalesced.
+constexpr int MASK_WORDS = 18;
+constexpr int MASK_OFF2 = 2, MASK_OFF3 = 6, MASK_OFF4 = 10;
+constexpr size_t FWD2_LDS_BYTES_MASKS = FWD2_LDS_BYTES + sizeof(unsigned) * 64 * MASK_WORDS;
+
+// lane r (< 16) collects the two mask words of accumulator register r: rows acc_row(r, 0) and acc_row(r, 1)
+#define MASK_COLLECT(r, positive, wl, wh)                                   \
+    do {                                                                    \
+        const unsigned long long bal_ = __ballot(positive);                 \
+        if (lane == (r)) { wl = (unsigned)bal_; wh = (unsigned)(bal_ >> 32); } \
+    } while (0)
 
 // B-fragment ring carried ACROSS chains: while the last four k-groups of a chain run, the freed
 // slots are refilled with the first four fragments of the NEXT chain (weights do not depend on the
@@ -214,10 +227,12 @@ __device__ __forceinline__ void chain_ring(const float *ar, int at0, const float
     }
 }
 
-template <bool STAMP>
+__device__ __forceinline__ int orow_of(int rb) { return rb * 32; }
+
+template <bool STAMP, bool MASKS>
 __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A, int n, const float *x, const float *pert,
                                                                      float *adv_out, float *pmax, int *parg, int *pcnt,
-                                                                     unsigned long long *stamps) {
+                                                                     unsigned long long *stamps, unsigned *masks) {
     // STAMP: diagnostic build only (geoadv_debug_encoder_stamps): wave 0 of every workgroup records s_memtime at the
     // phase boundaries into its own buffer; no output depends on them.
     auto stamp = [&](int k) {
@@ -233,6 +248,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     float *redm = pts + ROWS * 3;                     // [2][128]
     int *reda = reinterpret_cast<int *>(redm + 256);
     int *redc = reda + 256;
+    unsigned *mtile = reinterpret_cast<unsigned *>(redc + 256);   // [64][MASK_WORDS] (MASKS only)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, i = lane & 31;
@@ -280,26 +296,37 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     {   // layer 0 (fan-in 3) on the VALU, same arithmetic as fwd_layer0
         const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 8;
         const float px = pts[row * 3], py = pts[row * 3 + 1], pz = pts[row * 3 + 2];
+        unsigned bits = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             float a = px * l0w[0][c];
             a = fmaf(py, l0w[1][c], a);
             a = fmaf(pz, l0w[2][c], a);
-            bufA[row * 68 + c0 + c] = fmaxf(fmaf(a, l0s[c], l0t[c]), 0.f);
+            const float v = fmaxf(fmaf(a, l0s[c], l0t[c]), 0.f);
+            bufA[row * 68 + c0 + c] = v;
+            if (MASKS) bits |= (v > 0.f ? 1u : 0u) << c;
         }
+        if (MASKS) reinterpret_cast<unsigned char *>(mtile)[row * (4 * MASK_WORDS) + (threadIdx.x & 7)] = (unsigned char)bits;
     }
     __syncthreads();
     stamp(1);
+    const int mrow = orow_of(rb) + (lane & 3) + 8 * ((lane & 15) >> 2);    // lanes 0-15: row acc_row(lane, 0) of this wave's block
 
-    const int orow = rb * 32;                         // accumulator rows of this wave: orow + acc_row(r, h)
+    const int orow = orow_of(rb);                     // accumulator rows of this wave: orow + acc_row(r, h)
     // ---- layer 1: 64 -> 128, canonical K halves (4 + 4 k-groups) ----
     {
         const float *ar = bufA + (orow + i) * 68 + 4 * h;
         f32x16 acc[1] = {}, part[1] = {};
         chain_ring(ar, 0, w1, kg1 / 2, ring, w1 + (size_t)(kg1 / 2) * 64, acc);
         chain_ring(ar, kg1 / 2, w1 + (size_t)(kg1 / 2) * 64, kg1 / 2, ring, w2, part);
+        unsigned wl = 0, wh = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bufB[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r] + part[0][r], sc1, sh1), 0.f);
+        for (int r = 0; r < 16; ++r) {
+            const float v = fmaxf(fmaf(acc[0][r] + part[0][r], sc1, sh1), 0.f);
+            bufB[(orow + acc_row(r, h)) * 132 + ccol] = v;
+            if (MASKS) MASK_COLLECT(r, v > 0.f, wl, wh);
+        }
+        if (MASKS && lane < 16) { mtile[mrow * MASK_WORDS + MASK_OFF2 + cb] = wl; mtile[(mrow + 4) * MASK_WORDS + MASK_OFF2 + cb] = wh; }
     }
     __syncthreads();
     stamp(2);
@@ -309,8 +336,14 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         f32x16 acc[1] = {}, part[1] = {};
         chain_ring(ar, 0, w2, kg2 / 2, ring, w2 + (size_t)(kg2 / 2) * 64, acc);
         chain_ring(ar, kg2 / 2, w2 + (size_t)(kg2 / 2) * 64, kg2 / 2, ring, w3a, part);
+        unsigned wl = 0, wh = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bufA[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r] + part[0][r], sc2, sh2), 0.f);
+        for (int r = 0; r < 16; ++r) {
+            const float v = fmaxf(fmaf(acc[0][r] + part[0][r], sc2, sh2), 0.f);
+            bufA[(orow + acc_row(r, h)) * 132 + ccol] = v;
+            if (MASKS) MASK_COLLECT(r, v > 0.f, wl, wh);
+        }
+        if (MASKS && lane < 16) { mtile[mrow * MASK_WORDS + MASK_OFF3 + cb] = wl; mtile[(mrow + 4) * MASK_WORDS + MASK_OFF3 + cb] = wh; }
     }
     __syncthreads();
     stamp(3);
@@ -323,8 +356,16 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
             f32x16 acc[1] = {};
             chain_ring(ar, 0, half ? w3b : w3a, kg3, ring, w4 + (size_t)(kg4 / 2) * half * 64, acc);   // one full-K chain
             const float sc = half ? sc3b : sc3a, sh = half ? sh3b : sh3a;
+            unsigned wl = 0, wh = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bufB[(orow + acc_row(r, h)) * 132 + ccol] = fmaxf(fmaf(acc[0][r], sc, sh), 0.f);
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaxf(fmaf(acc[0][r], sc, sh), 0.f);
+                bufB[(orow + acc_row(r, h)) * 132 + ccol] = v;
+                if (MASKS) MASK_COLLECT(r, v > 0.f, wl, wh);
+            }
+            if (MASKS && lane < 16) {
+                mtile[mrow * MASK_WORDS + MASK_OFF4 + 4 * half + cb] = wl; mtile[(mrow + 4) * MASK_WORDS + MASK_OFF4 + 4 * half + cb] = wh;
+            }
         }
         __syncthreads();
         stamp(4 + 2 * half);
@@ -366,6 +407,11 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         else if (m2 == m) { k += redc[128 + c]; }
         const size_t o = ((size_t)b * tiles + tile) * 128 + c;
         pmax[o] = m; parg[o] = a; pcnt[o] = k;
+    }
+    if (MASKS) {   // the tile's mask rows are contiguous in HBM (issuing these stores before the last chain is slower:
+        const int live = n - n0 < ROWS ? n - n0 : ROWS;   // they count in vmcnt and stall the fragment ring)
+        unsigned *dst = masks + ((size_t)b * n + n0) * MASK_WORDS;
+        for (int e = threadIdx.x; e < live * MASK_WORDS; e += ENC_THREADS) dst[e] = mtile[e];
     }
     stamp(8);
     if (STAMP && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + 10] = __builtin_amdgcn_s_memrealtime();
@@ -691,6 +737,83 @@ __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const
 }
 
 
+// Sparse backward from the forward's ReLU masks: no recompute.  grid = (128 / 32, batch); a workgroup handles 32 of the
+// cloud's 128 critical rows (slot c = the arg-max row of channel c; a row listed several times is computed several times
+// with the same result).  da4[slot][c] = dz[c] * scale4[c] where that slot's row IS the arg-max of channel c and z > 0
+// (clouds with a tied maximum are flagged and go through the dense, recomputing launch instead).
+constexpr int BWM_ROWS = 32;
+constexpr size_t BWM_LDS_BYTES = sizeof(float) * (BWM_ROWS * 260 + BWM_ROWS * 132 + 3 * 2 * 16 * 64 + 128) +
+                                 sizeof(int) * (BWM_ROWS + 128) + sizeof(unsigned) * BWM_ROWS * MASK_WORDS;
+
+__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_masked_kernel(DeviceAE A, int n, const unsigned *masks, const int *rows,
+                                                                        const float *z, const float *dz, const int *dense_flag,
+                                                                        float *g_enc) {
+    const int b = blockIdx.y;
+    if (dense_flag[b] != 0) return;
+    constexpr int ROWS = BWM_ROWS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *bufP = lds;                                  // [32][260]
+    float *bufQ = bufP + ROWS * 260;                    // [32][132]
+    float *scratch = bufQ + ROWS * 132;                 // K-part hand-off of layer_gemm
+    float *dzs = scratch + 3 * 2 * 16 * 64;             // [128] dz * scale4 where z > 0
+    int *rowid = reinterpret_cast<int *>(dzs + 128);    // [32]
+    int *crit = rowid + ROWS;                           // [128]
+    unsigned *mw = reinterpret_cast<unsigned *>(crit + 128);   // [32][MASK_WORDS]
+    const int r0 = blockIdx.x * ROWS;
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        crit[c] = rows[(size_t)b * 128 + c];
+        dzs[c] = z[(size_t)b * 128 + c] > 0.f ? dz[(size_t)b * 128 + c] * A.scale[4][c] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < ROWS) rowid[threadIdx.x] = crit[r0 + threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < ROWS * MASK_WORDS; e += ENC_THREADS)
+        mw[e] = masks[((size_t)b * n + rowid[e / MASK_WORDS]) * MASK_WORDS + e % MASK_WORDS];
+    for (int e = threadIdx.x; e < ROWS * 128; e += ENC_THREADS) {
+        const int s = e >> 7, c = e & 127;
+        bufQ[s * 132 + c] = crit[c] == rowid[s] ? dzs[c] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto bit = [&](int row, int off, int c) { return (mw[row * MASK_WORDS + off + (c >> 5)] >> (c & 31)) & 1u; };
+    {   // dh4 = da4 @ W4^T (128 -> 256); da3 = dh4 * mask4 * scale3   into bufP
+        const int col = (wave % 8) * 32 + (lane & 31);
+        const float sc = A.scale[3][col];
+        layer_gemm<ROWS, 256, 0>(bufQ, 132, A.enc_bwd[4], scratch,
+                                 [&](int row, int c, float a) { bufP[row * 260 + c] = bit(row, MASK_OFF4, c) ? a * sc : 0.f; });
+    }
+    __syncthreads();
+    {   // dh3 = da3 @ W3^T (256 -> 128); da2 = dh3 * mask3 * scale2   into bufQ
+        const int col = (wave % 4) * 32 + (lane & 31);
+        const float sc = A.scale[2][col];
+        layer_gemm<ROWS, 128, 0>(bufP, 260, A.enc_bwd[3], scratch,
+                                 [&](int row, int c, float a) { bufQ[row * 132 + c] = bit(row, MASK_OFF3, c) ? a * sc : 0.f; });
+    }
+    __syncthreads();
+    {   // dh2 = da2 @ W2^T (128 -> 128); da1 = dh2 * mask2 * scale1   into bufP (stride 132)
+        const int col = (wave % 4) * 32 + (lane & 31);
+        const float sc = A.scale[1][col];
+        layer_gemm<ROWS, 128, 0>(bufQ, 132, A.enc_bwd[2], scratch,
+                                 [&](int row, int c, float a) { bufP[row * 132 + c] = bit(row, MASK_OFF2, c) ? a * sc : 0.f; });
+    }
+    __syncthreads();
+    {   // dh1 = da1 @ W1^T (128 -> 64); da0 = dh1 * mask1 * scale0   into bufQ (stride 68)
+        const int col = (wave % 2) * 32 + (lane & 31);
+        const float sc = A.scale[0][col];
+        layer_gemm<ROWS, 64, 0>(bufP, 132, A.enc_bwd[1], scratch,
+                                [&](int row, int c, float a) { bufQ[row * 68 + c] = bit(row, 0, c) ? a * sc : 0.f; });
+    }
+    __syncthreads();
+    if (threadIdx.x < ROWS * 3) {   // dh0 = da0 @ W0^T (64 -> 3) on the VALU
+        const int r = threadIdx.x / 3, a = threadIdx.x % 3;
+        float s = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) s = fmaf(bufQ[r * 68 + c], A.w0[a * 64 + c], s);
+        g_enc[((size_t)b * n + rowid[r]) * 3 + a] = s;
+    }
+}
+
 // Sparse launch: grid (128 / ROWS, batch): block (tile, b) handles 32 of cloud b's 128 critical rows; flagged clouds
 // (exact tie in the max-pool) are skipped.  Dense launch: grid (n / ROWS, DENSE_SLOTS): the flagged clouds -- almost
 // never any -- are dealt round-robin to the DENSE_SLOTS block rows, which process every point of them; with no flagged
@@ -735,10 +858,14 @@ static int set_lds_attr_once() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<32>::fwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)F3_LDS_BYTES));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false>),
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<true>),
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES_MASKS));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<true, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_masked_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWM_LDS_BYTES));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_SPARSE_ROWS>::bwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_DENSE_ROWS, true>),
@@ -763,16 +890,26 @@ int encoder_fwd_rows() { return fwd_variant() == 3 ? F3_ROWS : (fwd_variant() ==
 int encoder_tiles(int n) { return cdiv(n, encoder_fwd_rows()); }
 
 // pmax/parg/pcnt: [b][tiles][128]
+// Words of ReLU mask per point the default forward can leave for the sparse backward (0: this build's forward variant
+// does not write masks and the backward recomputes).
+int encoder_mask_words() { return fwd_variant() == 0 ? MASK_WORDS : 0; }
+
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, hipStream_t stream) {
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
+    if (masks && fwd_variant() == 0) {
+        encoder_fwd2_kernel<false, true><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES_MASKS, stream>>>(
+            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr, masks);
+        GA_LAUNCH_CHECK();
+        return GEOADV_OK;
+    }
     if (fwd_variant() == 3)
         encoder_fwd3_kernel<<<dim3(encoder_tiles(A.n_points), b), F3_THREADS, F3_LDS_BYTES, stream>>>(
             A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
     else if (fwd_variant() == 0)
-        encoder_fwd2_kernel<false><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
-            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr);
+        encoder_fwd2_kernel<false, false><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
+            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr, nullptr);
     else if (fwd_variant() == 64)
         encoder_fwd_kernel<64><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<64>::fwd_bytes, stream>>>(
             A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
@@ -787,9 +924,14 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
 // does work for flagged clouds (its workgroups exit at once otherwise).  g_enc must be zeroed by
 // the caller (rows that are not critical keep gradient 0).
 int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *crit_rows, const float *z,
-                       const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, hipStream_t stream) {
+                       const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, const unsigned *masks,
+                       hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
+    if (masks && fwd_variant() == 0)
+        encoder_bwd_masked_kernel<<<dim3(128 / BWM_ROWS, b), ENC_THREADS, BWM_LDS_BYTES, stream>>>(A, A.n_points, masks, crit_rows, z, dz,
+                                                                                               dense_flag, g_enc);
+    else
     encoder_bwd_kernel<BWD_SPARSE_ROWS, false><<<dim3(128 / BWD_SPARSE_ROWS, b), ENC_THREADS, EncLds<BWD_SPARSE_ROWS>::bwd_bytes, stream>>>(
         A, A.n_points, b, adv, crit_rows, 128, z, zcnt, dz, dense_flag, g_enc);
     GA_LAUNCH_CHECK();
@@ -804,8 +946,8 @@ int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *cr
 int launch_encoder_fwd_stamped(const DeviceAE &A, int b, const float *x, float *pmax, int *parg, int *pcnt,
                                unsigned long long *stamps, hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
-    encoder_fwd2_kernel<true><<<dim3(cdiv(A.n_points, 64), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
-        A, A.n_points, x, nullptr, nullptr, pmax, parg, pcnt, stamps);
+    encoder_fwd2_kernel<true, false><<<dim3(cdiv(A.n_points, 64), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
+        A, A.n_points, x, nullptr, nullptr, pmax, parg, pcnt, stamps, nullptr);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -267,3 +267,27 @@ def test_emd_combined_loss_step(setup):
     np.testing.assert_allclose(h[5], f2["loss_ae"], rtol=1e-5)
     np.testing.assert_allclose(h[0], f2["loss_adv"], rtol=2e-5)
     assert (h[0] > h[5]).all()
+
+
+@pytest.mark.parametrize("n", [N, 200])
+def test_masked_backward_equals_recomputing_backward(setup, monkeypatch, n):
+    """The sparse encoder backward reads the ReLU masks the forward left behind; with GEOADV_BWD_MASKS=0 it re-runs the
+    forward for the critical rows instead.  Same arithmetic either way: 6 iterations must agree bit for bit (also for a
+    ragged point count, whose last tile is partly empty)."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    w = W.randomized_weights(n)
+    ae = PointNetAE(w, n)
+    b = 3
+    x, gt = _clouds(71, b, n)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GEOADV_BWD_MASKS", flag)
+        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=6, num_iterations_thresh=3), ae=ae)
+        at.set_inputs(x, gt, None, 1.0)
+        at.init_pert(None, reset_optimizer=True)
+        at.run(0, 6, 3)
+        outs.append(at.peek()["pert"].clone())
+    assert outs[0].abs().max() > 0 and torch.equal(outs[0], outs[1])
