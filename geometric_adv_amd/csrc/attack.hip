@@ -24,6 +24,7 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
 struct ChamferPair { const float *p, *q; float *dist1; int *idx1; float *dist2; int *idx2; };
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
+int launch_chamfer_light(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, hipStream_t stream);
 struct ForwardScratch {
     float *pmax; int *parg; int *pcnt; float *z; int *crit; int *zcnt; int *dense; float *d1, *d2; size_t bytes;
 };
@@ -358,7 +359,8 @@ struct geoadv_attack {
     bool fwd_valid;
     bool adv_valid;                  // adv == x + pert already (written by the Adam kernel)
     bool overlap;                    // second stream in use
-    bool overlap_fwd;                // also run the Chamfer(adv, x) SCANS beside the encoder (measured: slower, off)
+    bool overlap_fwd;                // run Chamfer(adv, x) (LDS-free scalar-fed kernel) beside the encoder forward
+    bool overlap_bwd;                // run the source-distance gradient beside the decoder / encoder backward
     hipStream_t s2;
     hipEvent_t ev_fork, ev_scan, ev_loss, ev_gdist;
     // profiling
@@ -423,7 +425,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         GA_HIP(hipStreamWaitEvent(at->s2, at->ev_fork, 0));
         {
             ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, at->s2);
-            if (int rc = launch_chamfer_scans(sc_adv, 2, B, at->s2)) return rc;
+            if (int rc = launch_chamfer_light(at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, B, n, at->s2)) return rc;
         }
         GA_HIP(hipEventRecord(at->ev_scan, at->s2));
     }
@@ -442,7 +444,8 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
         if (split) {
-            if (int rc = launch_chamfer_scans(sc_recon, 2, B, st)) return rc;
+            const ChamferPair pair{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2};
+            if (int rc = launch_chamfer_sym(&pair, 1, B, n, n, at->sym_ws, st)) return rc;
         } else if (at->chamfer_sym) {   // one distance evaluation per pair serves both directions
             const ChamferPair pairs[2] = {{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2},
                                           {at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2}};
@@ -501,7 +504,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
     const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
     const CGradProblem p_recon{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
     const CGradProblem p_dist{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, at->cfg.max_point_dist_weight};
-    const bool split = at->overlap && dist_chamfer;
+    const bool split = at->overlap && at->overlap_bwd && dist_chamfer;
     if (split) {   // the source-distance gradient does not depend on the network: second stream
         GA_HIP(hipStreamWaitEvent(at->s2, at->ev_loss, 0));
         {
@@ -633,16 +636,18 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->fwd_valid = false; at->adv_valid = false;
     at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr;
     {
-        // GEOADV_OVERLAP (experiment switch): 0 (default) = single stream; 2 = the source-distance
-        // gradient runs on a second stream beside the decoder/encoder backward; 1 = additionally the
-        // Chamfer(adv, x) scans beside the encoder forward.  Measured on MI355X (B=32, N=2048): both are
-        // SLOWER than one stream -- mode 1: 2451 vs 2794 it/s (the 24 KB Chamfer workgroups fragment the
-        // LDS the 104 KB encoder workgroups need: encoder 113 -> 176 us); mode 2: 2630 vs 2790 it/s
-        // (event hand-offs cost more than the small kernels they hide).
+        // GEOADV_OVERLAP (experiment switch): 0 (default) = single stream; 2 = the source-distance gradient runs on a
+        // second stream beside the decoder/encoder backward; 3 = Chamfer(adv, x) runs beside the encoder forward; 1 = both.
+        // Measured on MI355X (B=32, N=2048), all SLOWER than one stream: beside the encoder, LDS-staged Chamfer
+        // workgroups fragment the LDS the encoder needs (2451 vs 2794 it/s at the time); the LDS-free, scalar-fed
+        // chamfer_light_kernel (18-61 VGPRs, no LDS: it does co-reside) still stretches the encoder from 104 to 125-139 us
+        // (3355-3375 vs 3815 it/s) -- MFMA and VALU streams on one SIMD are not free of each other; mode 2: 2630 vs
+        // 2790 it/s (event hand-offs cost more than the small kernels they hide).
         const char *e = getenv("GEOADV_OVERLAP");
         const int mode = e ? atoi(e) : 0;
         at->overlap = mode != 0;
-        at->overlap_fwd = mode == 1;
+        at->overlap_fwd = mode == 1 || mode == 3;
+        at->overlap_bwd = mode == 1 || mode == 2;
     }
     at->s2 = nullptr;
     if (at->overlap) {

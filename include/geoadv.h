@@ -48,6 +48,11 @@ const char *geoadv_last_error(void);
 int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
                        float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
 
+/* Same results as geoadv_nn_distance for n == m, from an LDS-free kernel whose targets travel through the scalar
+ * cache (s_load) -- built to run beside the MFMA-bound encoder on the same CUs (the attack loop's second stream). */
+int geoadv_nn_distance_light(int b, int n, const float *xyz1, const float *xyz2,
+                             float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
+
 /* NmDistanceGradKernelLauncher(b,n,xyz1,m,xyz2,grad_dist1,idx1,grad_dist2,idx2,grad_xyz1,grad_xyz2)
  * (tf_nndistance.cpp:208, kernel tf_nndistance_g.cu:132-157).  Outputs are fully overwritten
  * (the reference memsets them).  Unlike the reference GPU kernel (float atomicAdd) the
