@@ -66,7 +66,7 @@ def clouds(seed, b, n):
     return (rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
 
 
-def cpu_baseline(weights, x, gt, iters=5):
+def cpu_baseline(weights, x, gt, iters=5, gpu_clouds=None):
     """The oracle's attack iteration (numpy fp32 GEMMs on all cores + the single-threaded C Chamfer
     restatement, i.e. the reference's threading: NnDistanceOp::Compute is single-threaded,
     tf_nndistance.cpp:79-80) in the REFERENCE schedule: step (fwd+bwd+Adam) + a second metrics
@@ -101,10 +101,41 @@ def cpu_baseline(weights, x, gt, iters=5):
                      "note": "Chamfer restatement with OpenMP over the clouds of the batch (not what the reference does)"}
     except OSError:                 # OpenMP build of the oracle missing
         pass
-    return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": os.cpu_count(), "kind": "port",
+    parity = None
+    if gpu_clouds is not None:      # the oracle as the checker of the metric's second half: Chamfer rel-err and exact indices
+        from geometric_adv_amd import ops
+        import torch
+        p, q = gpu_clouds           # GPU tensors (recon, target) of the attacked batch, first clouds only
+        d1, i1, d2, i2 = [t.cpu().numpy() for t in ops.nn_distance(p, q)]
+        o1, oi1, o2, oi2 = Oracle().nn_distance(p.cpu().numpy(), q.cpu().numpy())
+        loss_gpu = d1.mean(axis=1, dtype=np.float64) + d2.mean(axis=1, dtype=np.float64)
+        loss_ref = o1.mean(axis=1, dtype=np.float64) + o2.mean(axis=1, dtype=np.float64)
+        parity = {"clouds": int(p.shape[0]), "chamfer_loss_rel_err_max": float(np.abs(loss_gpu / loss_ref - 1.0).max()),
+                  "dist_bit_exact": bool(np.array_equal(d1, o1) and np.array_equal(d2, o2)),
+                  "idx_exact": bool(np.array_equal(i1, oi1) and np.array_equal(i2, oi2))}
+    return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": os.cpu_count(), "kind": "port", "parity": parity,
             "sample": "%d iterations of config 2 (B=32, N=2048) after 1 warm-up, reference schedule (2 forwards/iter); "
                       "numpy fp32 GEMMs on all cores, Chamfer single-threaded C (gcc -O2 -ffp-contract=off)" % iters,
             "sec_per_iteration": dt / iters, "all_cores": all_cores}
+
+
+def training_leg(dev, steps=30, batch=50):
+    """AE training steps/s at default_train_params (batch 50 x 2048 points, lr 0.0005), synthetic clouds."""
+    import torch
+    from geometric_adv_amd.trainer import PointNetAETrainer, initial_weights
+    tr = PointNetAETrainer(initial_weights(N, seed=1), N, batch_size=batch, device=dev)
+    xb = torch.as_tensor(clouds(77, batch, N)).to(dev)
+    for _ in range(3):
+        tr.partial_fit(xb, want_recon=False, sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.partial_fit(xb, want_recon=False, sync=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flop = 3 * 2.0 * batch * N * 90304 + 3 * 2.0 * batch * (98304 + 768 * N)
+    return {"steps_per_sec": 1.0 / dt, "ms_per_step": dt * 1e3, "batch": batch, "n_points": N,
+            "frac_of_fp32_mfma_peak_end_to_end": flop / dt / (PEAK_MFMA_F32_TFLOPS * 1e12)}
 
 
 def main():
@@ -223,8 +254,12 @@ def main():
         "kernel_ms_per_iteration": breakdown,
         "final_mean_target_recon_error": float(gathered[0, :, 4].mean().item()),
     }
+    if world == 1:                  # the widened row f-4, measured beside the headline (not part of `value`)
+        out["secondary"] = {"ae_training_step": training_leg(dev)}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(weights, x, gt, args.cpu_iters)
+        _, adv_best, recon_best = at.get_best(ref)
+        out["cpu_baseline"] = cpu_baseline(weights, x, gt, args.cpu_iters,
+                                           gpu_clouds=(recon_best[:4].contiguous(), torch.as_tensor(gt[:4]).to(dev)))
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
 
