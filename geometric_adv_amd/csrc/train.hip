@@ -141,7 +141,11 @@ __global__ __launch_bounds__(TR_THREADS) void train_fwd_kernel(FwdArgs A) {
 
 // Batch statistics of one layer from the per-tile partials (fixed order, double), the folded BN constants,
 // and tflearn's moving-average update (assign_moving_average, zero_debias=False).
+// mode 0: per-tile partials -> statistics in one go (single GPU).  Synchronised batch norm over several ranks splits it:
+// mode 1 = partials -> the two per-channel totals (written to `totals`, which the host all-reduces, and to
+// `local_totals`), mode 2 = all-reduced totals -> statistics, with inv_rows = 1 / (rows of ALL ranks).
 struct BnArgs {
+    int mode; double *totals, *local_totals;
     const float2 *psum; int tiles; int C; double inv_rows;
     const float *gamma, *beta;
     float *mean, *inv_std, *scale, *shift;    // batch mean, rsqrt(var + eps), gamma * inv_std, beta - mean * scale
@@ -152,20 +156,25 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnArgs A) {
     __shared__ double r1[32][32], r2[32][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
     double s1 = 0.0, s2 = 0.0;
-    int t = g;
-    for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight, summed in ascending tile order
-        const float2 p0 = A.psum[(size_t)t * A.C + c], p1 = A.psum[(size_t)(t + 32) * A.C + c];
-        const float2 p2 = A.psum[(size_t)(t + 64) * A.C + c], p3 = A.psum[(size_t)(t + 96) * A.C + c];
-        s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
+    if (A.mode != 2) {
+        int t = g;
+        for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight, summed in ascending tile order
+            const float2 p0 = A.psum[(size_t)t * A.C + c], p1 = A.psum[(size_t)(t + 32) * A.C + c];
+            const float2 p2 = A.psum[(size_t)(t + 64) * A.C + c], p3 = A.psum[(size_t)(t + 96) * A.C + c];
+            s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
+        }
+        for (; t < A.tiles; t += 32) {
+            const float2 p = A.psum[(size_t)t * A.C + c];
+            s1 += p.x; s2 += p.y;
+        }
+        r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
     }
-    for (; t < A.tiles; t += 32) {
-        const float2 p = A.psum[(size_t)t * A.C + c];
-        s1 += p.x; s2 += p.y;
-    }
-    r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
     __syncthreads();
     if (g == 0) {
-        for (int k = 1; k < 32; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
+        if (A.mode != 2) {
+            for (int k = 1; k < 32; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
+            if (A.mode == 1) { A.totals[c] = s1; A.totals[A.C + c] = s2; return; }
+        } else { s1 = A.totals[c]; s2 = A.totals[A.C + c]; }
         const double mean = s1 * A.inv_rows;
         double var = s2 * A.inv_rows - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -450,27 +459,39 @@ __global__ __launch_bounds__(256) void train_pool_bwd_kernel(PoolBwdArgs A) {
 }
 
 // d beta = sum dy, d gamma = sum dy * xhat (double, fixed order); m1 = d beta / R, m2 = d gamma / R
-struct BnBwdArgs { const float2 *qsum; int tiles; int C; double inv_rows; float *dbeta, *dgamma, *m1, *m2; };
+// modes as in BnArgs; d beta / d gamma always hold THIS rank's sums (the gradient all-reduce adds the ranks up), m1 / m2 the
+// means over all ranks' rows
+struct BnBwdArgs { int mode; double *totals, *local_totals; const float2 *qsum; int tiles; int C; double inv_rows; float *dbeta, *dgamma, *m1, *m2; };
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs A) {
     __shared__ double r1[32][32], r2[32][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
     double s1 = 0.0, s2 = 0.0;
-    int t = g;
-    for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight, summed in ascending tile order
-        const float2 p0 = A.qsum[(size_t)t * A.C + c], p1 = A.qsum[(size_t)(t + 32) * A.C + c];
-        const float2 p2 = A.qsum[(size_t)(t + 64) * A.C + c], p3 = A.qsum[(size_t)(t + 96) * A.C + c];
-        s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
+    if (A.mode != 2) {
+        int t = g;
+        for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight, summed in ascending tile order
+            const float2 p0 = A.qsum[(size_t)t * A.C + c], p1 = A.qsum[(size_t)(t + 32) * A.C + c];
+            const float2 p2 = A.qsum[(size_t)(t + 64) * A.C + c], p3 = A.qsum[(size_t)(t + 96) * A.C + c];
+            s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
+        }
+        for (; t < A.tiles; t += 32) {
+            const float2 p = A.qsum[(size_t)t * A.C + c];
+            s1 += p.x; s2 += p.y;
+        }
+        r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
     }
-    for (; t < A.tiles; t += 32) {
-        const float2 p = A.qsum[(size_t)t * A.C + c];
-        s1 += p.x; s2 += p.y;
-    }
-    r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
     __syncthreads();
     if (g == 0) {
-        for (int k = 1; k < 32; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
-        A.dbeta[c] = (float)s1; A.dgamma[c] = (float)s2;
+        double l1, l2;
+        if (A.mode != 2) {
+            for (int k = 1; k < 32; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
+            if (A.mode == 1) {
+                A.totals[c] = s1; A.totals[A.C + c] = s2; A.local_totals[c] = s1; A.local_totals[A.C + c] = s2;
+                return;
+            }
+            l1 = s1; l2 = s2;
+        } else { s1 = A.totals[c]; s2 = A.totals[A.C + c]; l1 = A.local_totals[c]; l2 = A.local_totals[A.C + c]; }
+        A.dbeta[c] = (float)l1; A.dgamma[c] = (float)l2;
         A.m1[c] = (float)(s1 * A.inv_rows); A.m2[c] = (float)(s2 * A.inv_rows);
     }
 }
@@ -789,6 +810,8 @@ struct geoadv_trainer {
     float *dist1, *dist2; int *idx1, *idx2;
     float *dw_partial, *db_partial;
     float *loss;
+    int world;                         // ranks sharing the batch statistics (synchronised BN); 1 = local
+    double *xbuf, *lbuf;               // [10][512] per-phase totals: exchanged (all-reduced by the host) / local copy
 };
 
 static int trainer_repack(geoadv_trainer *t, hipStream_t st) {
@@ -851,6 +874,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     const size_t o_di1 = take(4 * (size_t)B * n), o_di2 = take(4 * (size_t)B * n), o_i1 = take(4 * (size_t)B * n), o_i2 = take(4 * (size_t)B * n);
     const size_t o_dwp = take(4 * (size_t)t->grid_bwd * 256 * 128), o_dbp = take(4 * (size_t)t->grid_bwd * 256);
     const size_t o_loss = take(256);
+    const size_t o_xb = take(8 * 10 * 512), o_lb = take(8 * 10 * 512);
     t->arena_bytes = off;
     if (hipMalloc(reinterpret_cast<void **>(&t->arena), off) != hipSuccess) {
         set_error("trainer_create: hipMalloc of %zu bytes failed", off);
@@ -872,6 +896,8 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     t->dd2 = F(o_dd2); t->dd1 = F(o_dd1); t->dz = F(o_dz);
     t->dist1 = F(o_di1); t->dist2 = F(o_di2); t->idx1 = reinterpret_cast<int *>(F(o_i1)); t->idx2 = reinterpret_cast<int *>(F(o_i2));
     t->dw_partial = F(o_dwp); t->db_partial = F(o_dbp); t->loss = F(o_loss);
+    t->world = 1;
+    t->xbuf = reinterpret_cast<double *>(t->arena + o_xb); t->lbuf = reinterpret_cast<double *>(t->arena + o_lb);
     // upload parameters
     std::vector<float> host(P, 0.f);
     const int dd[4] = {128, 256, 256, 3 * n};
@@ -933,9 +959,12 @@ static int launch_fwd(geoadv_trainer *t, int i, hipStream_t st) {
     return GEOADV_OK;
 }
 
-static int launch_bn(geoadv_trainer *t, int i, hipStream_t st) {
+// mode: 0 = local statistics in one launch, 1 = this rank's totals into exchange slot `slot`, 2 = statistics from the
+// (all-reduced) totals of that slot
+static int launch_bn(geoadv_trainer *t, int i, int mode, int slot, hipStream_t st) {
     BnArgs a;
-    a.psum = t->psum; a.tiles = t->tiles; a.C = ENC[i + 1]; a.inv_rows = 1.0 / (double)t->R;
+    a.mode = mode; a.totals = t->xbuf + 512 * slot; a.local_totals = t->lbuf + 512 * slot;
+    a.psum = t->psum; a.tiles = t->tiles; a.C = ENC[i + 1]; a.inv_rows = 1.0 / ((double)t->R * t->world);
     a.gamma = t->params + t->L.gamma[i]; a.beta = t->params + t->L.beta[i];
     a.mean = t->bn_mean[i]; a.inv_std = t->bn_istd[i]; a.scale = t->bn_scale[i]; a.shift = t->bn_shift[i];
     a.mov_mean = t->mov_mean[i]; a.mov_var = t->mov_var[i]; a.one_minus_decay = t->one_minus_decay;
@@ -973,11 +1002,112 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
     return GEOADV_OK;
 }
 
-static int launch_bn_bwd(geoadv_trainer *t, int i, int partial_rows, hipStream_t st) {
+static int launch_bn_bwd(geoadv_trainer *t, int i, int partial_rows, int mode, int slot, hipStream_t st) {
     BnBwdArgs a;
-    a.qsum = t->qsum; a.tiles = t->R / partial_rows; a.C = ENC[i + 1]; a.inv_rows = 1.0 / (double)t->R;
+    a.mode = mode; a.totals = t->xbuf + 512 * slot; a.local_totals = t->lbuf + 512 * slot;
+    a.qsum = t->qsum; a.tiles = t->R / partial_rows; a.C = ENC[i + 1]; a.inv_rows = 1.0 / ((double)t->R * t->world);
     a.dbeta = t->grads + t->L.beta[i]; a.dgamma = t->grads + t->L.gamma[i]; a.m1 = t->bn_m1[i]; a.m2 = t->bn_m2[i];
     bn_bwd_finalize_kernel<<<ENC[i + 1] / 32, 1024, 0, st>>>(a);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+// One training step = TRAIN_PHASES phases.  Between two phases sits the only cross-row coupling of the encoder: the
+// per-channel batch-norm sums.  With one rank a phase ends by turning its per-tile partials into statistics itself
+// (sync == false); with synchronised BN over several ranks it ends by leaving this rank's totals in exchange slot
+// `phase` (geoadv_trainer_exchange), the host all-reduces them, and the next phase starts from the global totals.
+//   phase 0..4 : forward layer i (+ statistics of layer i)
+//   phase 5    : pool, decoder, Chamfer, decoder backward, pool backward (+ BN-gradient sums of layer 4)
+//   phase 6..9 : backward layer 4..1 (+ BN-gradient sums of the layer below);   phase 10: backward layer 0
+constexpr int TRAIN_PHASES = 11;
+
+static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *gt, bool sync, hipStream_t st) {
+    const int B = t->B, n = t->N, n3 = t->n3;
+    const int end_mode = sync ? 1 : 0;
+    if (phase <= 4) {
+        const int i = phase;
+        if (sync && i > 0)
+            if (int rc = launch_bn(t, i - 1, 2, phase - 1, st)) return rc;
+        int rc = GEOADV_OK;
+        if (i == 0) {
+            FwdArgs a;
+            a.in = x; a.pscale = a.pshift = nullptr;
+            a.W = PackedLayer{t->params + t->L.w[0], 3, 64};
+            a.bias = t->params + t->L.b[0]; a.out = t->act[0]; a.psum = t->psum;
+            train_fwd0_kernel<<<t->tiles, TR_THREADS, 0, st>>>(a);
+            GA_LAUNCH_CHECK();
+        } else if (i == 1) rc = launch_fwd<64, 128>(t, 1, st);
+        else if (i == 2) rc = launch_fwd<128, 128>(t, 2, st);
+        else if (i == 3) rc = launch_fwd<128, 256>(t, 3, st);
+        else rc = launch_fwd<256, 128>(t, 4, st);
+        if (rc) return rc;
+        return launch_bn(t, i, end_mode, phase, st);
+    }
+    if (phase == 5) {
+        if (sync)
+            if (int rc = launch_bn(t, 4, 2, 4, st)) return rc;
+        // ---- symmetric max-pool ----
+        GA_HIP(hipMemsetAsync(t->zbits, 0, sizeof(int) * (size_t)B * 128, st));
+        GA_HIP(hipMemsetAsync(t->cnt, 0, sizeof(int) * (size_t)B * 128, st));
+        PoolArgs pa{t->act[4], t->bn_scale[4], t->bn_shift[4], n, t->zbits, t->cnt};
+        train_pool_kernel<false><<<t->tiles, 256, 0, st>>>(pa);
+        train_pool_kernel<true><<<t->tiles, 256, 0, st>>>(pa);
+        GA_LAUNCH_CHECK();
+        const float *z = reinterpret_cast<const float *>(t->zbits);
+        // ---- decoder forward ----
+        const float *V0 = t->params + t->L.v[0], *V1 = t->params + t->L.v[1], *V2 = t->params + t->L.v[2];
+        fc_fwd_kernel<128, true><<<B, 256, 0, st>>>(z, V0, t->params + t->L.c[0], t->d1, 256);
+        fc_fwd_kernel<256, true><<<B, 256, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2, 256);
+        fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
+        GA_LAUNCH_CHECK();
+        // ---- Chamfer loss and its gradient w.r.t. the reconstruction ----
+        // one distance evaluation per pair serves both directions (chamfer_sym.hip); dist/idx bit-identical to nn_distance
+        const ChamferPair cp{t->recon, gt, t->dist1, t->idx1, t->dist2, t->idx2};
+        if (int rc = launch_chamfer_sym(&cp, 1, B, n, n, t->cham_ws, st)) return rc;
+        // reduce_mean over the batch of ALL ranks: with several ranks the host adds the per-rank values up
+        chamfer_loss_kernel<<<1, 1024, 0, st>>>(t->dist1, t->dist2, (size_t)B * n, 1.0 / ((double)B * t->world * n), t->loss);
+        GA_LAUNCH_CHECK();
+        // NnDistanceGrad w.r.t. the reconstruction only (order-independent fixed-point accumulation, attack.hip)
+        const CGradProblem gp{t->recon, gt, t->idx1, t->idx2, t->g_recon, t->gd, nullptr, 0.f};
+        if (int rc = launch_chamfer_grad(&gp, 1, B, n, st)) return rc;
+        // ---- decoder backward ----
+        fc_out_bwd_w_kernel<<<dim3(cdiv(n3, 128), 8), 128, sizeof(float) * B * 32, st>>>(t->d2, t->g_recon, t->grads + t->L.v[2],
+                                                                                        t->grads + t->L.c[2], B, n3);
+        fc_out_bwd_x_kernel<<<dim3(64, cdiv(B, 8)), 256, 0, st>>>(t->g_recon, V2, t->d2, t->dd2, B, n3);
+        fc_bwd_w_kernel<<<256, 256, 0, st>>>(t->d1, t->dd2, t->grads + t->L.v[1], t->grads + t->L.c[1], B, 256);
+        fc_bwd_x_kernel<true><<<B, 256, 0, st>>>(t->dd2, V1, t->d1, t->dd1, 256);
+        fc_bwd_w_kernel<<<128, 256, 0, st>>>(z, t->dd1, t->grads + t->L.v[0], t->grads + t->L.c[0], B, 128);
+        fc_bwd_x_kernel<false><<<B, 256, 0, st>>>(t->dd1, V0, nullptr, t->dz, 128);
+        GA_LAUNCH_CHECK();
+        // ---- encoder backward starts: pool gradient + ReLU of layer 4 ----
+        PoolBwdArgs pb{t->act[4], t->bn_scale[4], t->bn_shift[4], t->bn_mean[4], t->bn_istd[4], n, t->zbits, t->cnt, t->dz,
+                       t->dybuf[0], t->qsum};
+        train_pool_bwd_kernel<<<t->tiles, 256, 0, st>>>(pb);
+        GA_LAUNCH_CHECK();
+        return launch_bn_bwd(t, 4, TR_ROWS, end_mode, phase, st);
+    }
+    if (phase <= 9) {
+        const int i = 10 - phase;                                  // layer whose backward runs: 4, 3, 2, 1
+        if (sync)
+            if (int rc = launch_bn_bwd(t, i, i == 4 ? TR_ROWS : BWD_ROWS, 2, phase - 1, st)) return rc;
+        int rc;
+        if (i == 4) rc = launch_bwd<256, 128>(t, 4, t->dybuf[0], t->dybuf[1], st);
+        else if (i == 3) rc = launch_bwd<128, 256>(t, 3, t->dybuf[1], t->dybuf[0], st);
+        else if (i == 2) rc = launch_bwd<128, 128>(t, 2, t->dybuf[0], t->dybuf[1], st);
+        else rc = launch_bwd<64, 128>(t, 1, t->dybuf[1], t->dybuf[0], st);
+        if (rc) return rc;
+        return launch_bn_bwd(t, i - 1, BWD_ROWS, end_mode, phase, st);
+    }
+    if (sync)
+        if (int rc = launch_bn_bwd(t, 0, BWD_ROWS, 2, 9, st)) return rc;
+    BwdArgs a = {};
+    a.tiles = t->tiles; a.dy = t->dybuf[0]; a.a = t->act[0];
+    a.mean = t->bn_mean[0]; a.inv_std = t->bn_istd[0]; a.gamma = t->params + t->L.gamma[0]; a.m1 = t->bn_m1[0]; a.m2 = t->bn_m2[0];
+    a.aprev = x; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
+    const int grid0 = t->tiles < t->grid_bwd ? t->tiles : t->grid_bwd;
+    train_bwd0_kernel<<<grid0, TR_THREADS, 0, st>>>(a);
+    partial_reduce_kernel<<<3, 256, 0, st>>>(t->dw_partial, grid0, 192, t->grads + t->L.w[0]);
+    partial_reduce_kernel<<<1, 256, 0, st>>>(t->db_partial, grid0, 64, t->grads + t->L.b[0]);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -985,86 +1115,48 @@ static int launch_bn_bwd(geoadv_trainer *t, int i, int partial_rows, hipStream_t
 extern "C" int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x, const float *gt, float *loss, float *recon,
                                                void *stream) {
     GA_REQUIRE(t && x, "trainer_forward_backward: null argument");
+    GA_REQUIRE(t->world == 1, "trainer_forward_backward: synchronised batch norm is on (world %d): drive the phases", t->world);
     hipStream_t st = as_stream(stream);
     if (!gt) gt = x;
-    const int B = t->B, n = t->N, n3 = t->n3;
-    // ---- encoder forward, layer by layer (batch statistics) ----
-    {
-        FwdArgs a;
-        a.in = x; a.pscale = a.pshift = nullptr;
-        a.W = PackedLayer{t->params + t->L.w[0], 3, 64};
-        a.bias = t->params + t->L.b[0]; a.out = t->act[0]; a.psum = t->psum;
-        train_fwd0_kernel<<<t->tiles, TR_THREADS, 0, st>>>(a);
-        GA_LAUNCH_CHECK();
-        if (int rc = launch_bn(t, 0, st)) return rc;
-    }
-    if (int rc = launch_fwd<64, 128>(t, 1, st)) return rc;
-    if (int rc = launch_bn(t, 1, st)) return rc;
-    if (int rc = launch_fwd<128, 128>(t, 2, st)) return rc;
-    if (int rc = launch_bn(t, 2, st)) return rc;
-    if (int rc = launch_fwd<128, 256>(t, 3, st)) return rc;
-    if (int rc = launch_bn(t, 3, st)) return rc;
-    if (int rc = launch_fwd<256, 128>(t, 4, st)) return rc;
-    if (int rc = launch_bn(t, 4, st)) return rc;
-    // ---- symmetric max-pool ----
-    GA_HIP(hipMemsetAsync(t->zbits, 0, sizeof(int) * (size_t)B * 128, st));
-    GA_HIP(hipMemsetAsync(t->cnt, 0, sizeof(int) * (size_t)B * 128, st));
-    PoolArgs pa{t->act[4], t->bn_scale[4], t->bn_shift[4], n, t->zbits, t->cnt};
-    train_pool_kernel<false><<<t->tiles, 256, 0, st>>>(pa);
-    train_pool_kernel<true><<<t->tiles, 256, 0, st>>>(pa);
-    GA_LAUNCH_CHECK();
-    const float *z = reinterpret_cast<const float *>(t->zbits);
-    // ---- decoder forward ----
-    const float *V0 = t->params + t->L.v[0], *V1 = t->params + t->L.v[1], *V2 = t->params + t->L.v[2];
-    fc_fwd_kernel<128, true><<<B, 256, 0, st>>>(z, V0, t->params + t->L.c[0], t->d1, 256);
-    fc_fwd_kernel<256, true><<<B, 256, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2, 256);
-    fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
-    GA_LAUNCH_CHECK();
-    // ---- Chamfer loss and its gradient w.r.t. the reconstruction ----
-    // one distance evaluation per pair serves both directions (chamfer_sym.hip); dist/idx bit-identical to nn_distance
-    const ChamferPair cp{t->recon, gt, t->dist1, t->idx1, t->dist2, t->idx2};
-    if (int rc = launch_chamfer_sym(&cp, 1, B, n, n, t->cham_ws, st)) return rc;
-    chamfer_loss_kernel<<<1, 1024, 0, st>>>(t->dist1, t->dist2, (size_t)B * n, 1.0 / ((double)B * n), t->loss);
-    GA_LAUNCH_CHECK();
-    // NnDistanceGrad w.r.t. the reconstruction only (order-independent fixed-point accumulation, attack.hip)
-    const CGradProblem gp{t->recon, gt, t->idx1, t->idx2, t->g_recon, t->gd, nullptr, 0.f};
-    if (int rc = launch_chamfer_grad(&gp, 1, B, n, st)) return rc;
-    // ---- decoder backward ----
-    fc_out_bwd_w_kernel<<<dim3(cdiv(n3, 128), 8), 128, sizeof(float) * B * 32, st>>>(t->d2, t->g_recon, t->grads + t->L.v[2],
-                                                                                    t->grads + t->L.c[2], B, n3);
-    fc_out_bwd_x_kernel<<<dim3(64, cdiv(B, 8)), 256, 0, st>>>(t->g_recon, V2, t->d2, t->dd2, B, n3);
-    fc_bwd_w_kernel<<<256, 256, 0, st>>>(t->d1, t->dd2, t->grads + t->L.v[1], t->grads + t->L.c[1], B, 256);
-    fc_bwd_x_kernel<true><<<B, 256, 0, st>>>(t->dd2, V1, t->d1, t->dd1, 256);
-    fc_bwd_w_kernel<<<128, 256, 0, st>>>(z, t->dd1, t->grads + t->L.v[0], t->grads + t->L.c[0], B, 128);
-    fc_bwd_x_kernel<false><<<B, 256, 0, st>>>(t->dd1, V0, nullptr, t->dz, 128);
-    GA_LAUNCH_CHECK();
-    // ---- encoder backward ----
-    PoolBwdArgs pb{t->act[4], t->bn_scale[4], t->bn_shift[4], t->bn_mean[4], t->bn_istd[4], n, t->zbits, t->cnt, t->dz,
-                   t->dybuf[0], t->qsum};
-    train_pool_bwd_kernel<<<t->tiles, 256, 0, st>>>(pb);
-    GA_LAUNCH_CHECK();
-    if (int rc = launch_bn_bwd(t, 4, TR_ROWS, st)) return rc;
-    if (int rc = launch_bwd<256, 128>(t, 4, t->dybuf[0], t->dybuf[1], st)) return rc;
-    if (int rc = launch_bn_bwd(t, 3, BWD_ROWS, st)) return rc;
-    if (int rc = launch_bwd<128, 256>(t, 3, t->dybuf[1], t->dybuf[0], st)) return rc;
-    if (int rc = launch_bn_bwd(t, 2, BWD_ROWS, st)) return rc;
-    if (int rc = launch_bwd<128, 128>(t, 2, t->dybuf[0], t->dybuf[1], st)) return rc;
-    if (int rc = launch_bn_bwd(t, 1, BWD_ROWS, st)) return rc;
-    if (int rc = launch_bwd<64, 128>(t, 1, t->dybuf[1], t->dybuf[0], st)) return rc;
-    if (int rc = launch_bn_bwd(t, 0, BWD_ROWS, st)) return rc;
-    {
-        BwdArgs a = {};
-        a.tiles = t->tiles; a.dy = t->dybuf[0]; a.a = t->act[0];
-        a.mean = t->bn_mean[0]; a.inv_std = t->bn_istd[0]; a.gamma = t->params + t->L.gamma[0]; a.m1 = t->bn_m1[0]; a.m2 = t->bn_m2[0];
-        a.aprev = x; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
-        const int grid0 = t->tiles < t->grid_bwd ? t->tiles : t->grid_bwd;
-        train_bwd0_kernel<<<grid0, TR_THREADS, 0, st>>>(a);
-        partial_reduce_kernel<<<3, 256, 0, st>>>(t->dw_partial, grid0, 192, t->grads + t->L.w[0]);
-        partial_reduce_kernel<<<1, 256, 0, st>>>(t->db_partial, grid0, 64, t->grads + t->L.b[0]);
-        GA_LAUNCH_CHECK();
-    }
+    for (int p = 0; p < TRAIN_PHASES; ++p)
+        if (int rc = run_phase(t, p, x, gt, false, st)) return rc;
     if (loss) GA_HIP(hipMemcpyAsync(loss, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (recon) GA_HIP(hipMemcpyAsync(recon, t->recon, sizeof(float) * (size_t)B * n3, hipMemcpyDeviceToDevice, st));
+    if (recon) GA_HIP(hipMemcpyAsync(recon, t->recon, sizeof(float) * (size_t)t->B * t->n3, hipMemcpyDeviceToDevice, st));
+    return GEOADV_OK;
+}
+
+// ---- synchronised batch norm over `world` ranks: the caller runs the phases and all-reduces the exchange slots ----
+extern "C" int geoadv_trainer_set_world(geoadv_trainer *t, int world) {
+    GA_REQUIRE(t && world >= 1 && world <= 4096, "trainer_set_world: bad arguments");
+    t->world = world;
+    std::vector<float> gdv((size_t)t->B, 1.0f / ((float)t->B * (float)world));      // d reduce_mean over the GLOBAL batch
+    GA_HIP(hipMemcpy(t->gd, gdv.data(), 4 * gdv.size(), hipMemcpyHostToDevice));
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_trainer_num_phases(void) { return TRAIN_PHASES; }
+
+extern "C" int geoadv_trainer_run_phase(geoadv_trainer *t, int phase, const float *x, const float *gt, void *stream) {
+    GA_REQUIRE(t && x && phase >= 0 && phase < TRAIN_PHASES, "trainer_run_phase: bad arguments");
+    return run_phase(t, phase, x, gt ? gt : x, true, as_stream(stream));
+}
+
+// What must be summed over the ranks after `phase` before the next one starts: *count doubles at *buf (device), or 0.
+extern "C" int geoadv_trainer_exchange(geoadv_trainer *t, int phase, double **buf, size_t *count) {
+    GA_REQUIRE(t && buf && count && phase >= 0 && phase < TRAIN_PHASES, "trainer_exchange: bad arguments");
+    *buf = t->xbuf + 512 * (phase < 10 ? phase : 0);
+    if (phase <= 4) *count = 2 * (size_t)ENC[phase + 1];
+    else if (phase <= 9) *count = 2 * (size_t)ENC[10 - phase];            // sums of layer 4, 3, 2, 1, 0
+    else *count = 0;
+    return GEOADV_OK;
+}
+
+// loss (this rank's share of the global mean when world > 1) and reconstruction of the last step
+extern "C" int geoadv_trainer_fetch(geoadv_trainer *t, float *loss, float *recon, void *stream) {
+    GA_REQUIRE(t, "trainer_fetch: null trainer");
+    hipStream_t st = as_stream(stream);
+    if (loss) GA_HIP(hipMemcpyAsync(loss, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (recon) GA_HIP(hipMemcpyAsync(recon, t->recon, sizeof(float) * (size_t)t->B * t->n3, hipMemcpyDeviceToDevice, st));
     return GEOADV_OK;
 }
 

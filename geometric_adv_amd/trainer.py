@@ -6,10 +6,11 @@ Host-side mirror of the training surface of the reference's `PointNetAutoEncoder
 as a TF V2 checkpoint through tf_checkpoint.write_checkpoint).  The arithmetic runs in libgeoadv.so
 (csrc/train.hip); there is no CPU fallback.
 
-Data-parallel training: one process per GPU; each rank runs `forward_backward` on its shard of the batch, the flat
-gradient buffer is sum-all-reduced over RCCL (`torch.distributed`, backend "nccl") and `apply` divides by the world
-size -- the mean of the per-rank losses, i.e. the loss of the global batch.  Encoder batch-norm statistics stay
-per rank (the usual un-synchronised data-parallel BN); with world size 1 the step is exactly the reference's.
+Data-parallel training: one process per GPU; each rank runs the step on its shard of the batch and the flat gradient
+buffer is sum-all-reduced over RCCL (`torch.distributed`, backend "nccl").  With `sync_bn=True` (default) the encoder's
+batch-norm statistics are shared too: the step runs in phases and ten <= 4 KB all-reduces carry the per-channel sums,
+so `world` ranks with `batch_size` clouds each take exactly the reference's step on world * batch_size clouds.
+`sync_bn=False` keeps per-rank statistics (one collective per step).
 """
 import ctypes as C
 import time
@@ -77,7 +78,7 @@ class PointNetAETrainer:
     GROUPS = ("enc_w", "enc_b", "gamma", "beta", "dec_w", "dec_b")
 
     def __init__(self, weights, n_points, batch_size=50, learning_rate=0.0005, bn_decay=0.9, ae_name=W.AE_NAME,
-                 device=None):
+                 device=None, sync_bn=True):
         if isinstance(weights, str):
             weights = W.load(weights, ae_name)
         self.n_points, self.batch_size, self.ae_name = int(n_points), int(batch_size), ae_name
@@ -98,6 +99,8 @@ class PointNetAETrainer:
         self._params_ptr, self._grads_ptr = pp.value, gp.value
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.epoch = 0
+        self.sync_bn = bool(sync_bn)
+        self._world_set = 1
 
     def __del__(self):
         try:
@@ -116,6 +119,39 @@ class PointNetAETrainer:
         a.__cuda_array_interface__ = {"shape": (self._count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
         with torch.cuda.device(self.device):
             return torch.as_tensor(a, device=self.device)
+
+    def _view_f64(self, ptr, count):
+        class _Arr:
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        with torch.cuda.device(self.device):
+            return torch.as_tensor(a, device=self.device)
+
+    def _set_world(self, world):
+        if world != self._world_set:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().geoadv_trainer_set_world(self._h, int(world)), "trainer_set_world")
+            self._world_set = world
+
+    def _step_synchronised(self, x, gt, want_recon, world):
+        """The step in phases, batch-norm sums all-reduced in between (see include/geoadv.h)."""
+        from .dist import all_reduce_sum_
+        L = _lib.lib()
+        self._set_world(world)
+        buf, cnt = C.c_void_p(), C.c_size_t()
+        with torch.cuda.device(self.device):
+            for p in range(L.geoadv_trainer_num_phases()):
+                _lib.check(L.geoadv_trainer_run_phase(self._h, p, _lib.ptr(x), _lib.ptr(gt), _lib.stream_handle()), "trainer_run_phase")
+                _lib.check(L.geoadv_trainer_exchange(self._h, p, C.byref(buf), C.byref(cnt)), "trainer_exchange")
+                if cnt.value:
+                    all_reduce_sum_(self._view_f64(buf.value, int(cnt.value)))
+            recon = torch.empty_like(x) if want_recon else None
+            _lib.check(L.geoadv_trainer_fetch(self._h, _lib.ptr(self._loss), _lib.ptr(recon), _lib.stream_handle()), "trainer_fetch")
+        all_reduce_sum_(self.gradient_buffer())
+        loss = all_reduce_sum_(self._loss.clone())
+        self.apply(1.0)
+        return recon, loss
 
     def gradient_buffer(self):
         return self._view(self._grads_ptr)
@@ -170,10 +206,14 @@ class PointNetAETrainer:
     def partial_fit(self, X, GT=None, want_recon=True, sync=True):
         """AutoEncoder.partial_fit (autoencoder.py:105-125): -> (recon, loss) of the pre-update weights.
         sync=False returns the loss as a 1-element GPU tensor without synchronising (throughput loops)."""
+        world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        if world > 1 and self.sync_bn:
+            recon, loss = self._step_synchronised(self._dev(X), self._dev(GT) if GT is not None else None, want_recon, world)
+            return recon, (float(loss.item()) if sync else loss)
+        self._set_world(1)
         recon, loss = self.forward_backward(X, GT, want_recon)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        if world > 1:
             from .dist import all_reduce_sum_
-            world = torch.distributed.get_world_size()
             all_reduce_sum_(self.gradient_buffer())                 # one flat buffer: a single collective per step
             loss = all_reduce_sum_(loss.clone()) / world            # loss of the global batch (mean of equal shards)
             self.apply(1.0 / world)

@@ -244,6 +244,17 @@ int geoadv_trainer_step(geoadv_trainer *t, const float *x, const float *gt, floa
  * grad_scale = 1 / world_size. */
 int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x, const float *gt, float *loss, float *recon, void *stream);
 int geoadv_trainer_apply(geoadv_trainer *t, float grad_scale, void *stream);
+/* Synchronised batch norm for data-parallel training (so that `world` ranks with `batch` clouds each take EXACTLY the
+ * step of one replica with world * batch clouds): the encoder's only coupling between rows is a pair of per-channel
+ * sums per layer and direction, so the step is cut into geoadv_trainer_num_phases() phases; after phase p the caller
+ * sum-all-reduces the *count doubles geoadv_trainer_exchange(t, p, ...) points at (RCCL; <= 4 KB, latency-bound) and
+ * runs phase p + 1.  After the last phase: all-reduce the flat gradient buffer, geoadv_trainer_apply(t, 1.0f), and add
+ * up the ranks' geoadv_trainer_fetch losses.  geoadv_trainer_set_world(t, world) switches the mode (1 = off). */
+int geoadv_trainer_set_world(geoadv_trainer *t, int world);
+int geoadv_trainer_num_phases(void);
+int geoadv_trainer_run_phase(geoadv_trainer *t, int phase, const float *x, const float *gt, void *stream);
+int geoadv_trainer_exchange(geoadv_trainer *t, int phase, double **buf, size_t *count);
+int geoadv_trainer_fetch(geoadv_trainer *t, float *loss, float *recon, void *stream);
 /* Device pointers of the flat parameter / gradient buffers (`count` floats each) and where each variable sits:
  * offsets26 = enc_w[5], enc_b[5], bn_gamma[5], bn_beta[5], dec_w[3], dec_b[3] (in floats). */
 int geoadv_trainer_buffers(geoadv_trainer *t, float **params, float **grads, size_t *count);

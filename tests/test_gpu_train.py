@@ -186,7 +186,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share the one GPU of the test box
 n, b = 128, 4
 x = np.load(sys.argv[1])
-tr = PointNetAETrainer(W.randomized_weights(n, seed=11), n, batch_size=b // world)
+tr = PointNetAETrainer(W.randomized_weights(n, seed=11), n, batch_size=b // world, sync_bn=False)
 losses = [tr.partial_fit(x[rank * (b // world):(rank + 1) * (b // world)], want_recon=False)[1] for _ in range(3)]
 torch.cuda.synchronize()
 if rank == 0:
@@ -225,6 +225,70 @@ def test_data_parallel_step_equals_summed_shard_gradients(tmp_path):
     assert np.allclose(got["losses"], losses, rtol=1e-6)
     assert np.array_equal(got["params"], reps[0].parameter_buffer().cpu().numpy())
     assert np.array_equal(reps[0].parameter_buffer().cpu().numpy(), reps[1].parameter_buffer().cpu().numpy())
+
+
+_SYNC_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import torch.distributed as dist
+from geometric_adv_amd import weights as W
+from geometric_adv_amd.trainer import PointNetAETrainer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n, b = 128, 4
+x = np.load(sys.argv[1])
+tr = PointNetAETrainer(W.randomized_weights(n, seed=11), n, batch_size=b // world)      # sync_bn=True
+shard = x[rank * (b // world):(rank + 1) * (b // world)]
+tr.apply = lambda scale=1.0: None                     # keep the all-reduced gradients of the first step for inspection
+_, loss1 = tr.partial_fit(shard, want_recon=False)
+grads = tr.gradient_buffer().cpu().numpy().copy()
+del tr.apply
+tr2 = PointNetAETrainer(W.randomized_weights(n, seed=11), n, batch_size=b // world)
+losses = [tr2.partial_fit(shard, want_recon=False)[1] for _ in range(4)]
+w = tr2.export_weights()
+torch.cuda.synchronize()
+if rank == 0:
+    np.savez(sys.argv[2], loss1=loss1, grads=grads, losses=np.array(losses),
+             mean0=w["autoencoder/encoder_conv_layer_0_bnorm/moving_mean"], var3=w["autoencoder/encoder_conv_layer_3_bnorm/moving_variance"])
+dist.destroy_process_group()
+"""
+
+
+def test_synchronised_bn_equals_one_replica_on_the_global_batch(tmp_path):
+    """Two ranks x 2 clouds with the batch-norm sums all-reduced between the phases == one replica on all 4 clouds
+    (the reference's step): loss, every gradient, the loss trajectory and the moving averages."""
+    import subprocess, sys
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.trainer import PointNetAETrainer
+    n, b = 128, 4
+    w0 = W.randomized_weights(n, seed=11)
+    from oracle.train_model import TrainModel
+    x = _batch(TrainModel(W.canonical(w0, n), n), b, n, 31)
+    np.save(tmp_path / "x.npy", x)
+    (tmp_path / "worker.py").write_text(_SYNC_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(tmp_path / "worker.py"), str(tmp_path / "x.npy"), str(tmp_path / "out.npz")]
+    subprocess.run(cmd, check=True, env=env, timeout=300, cwd=os.getcwd())
+    got = np.load(tmp_path / "out.npz")
+    one = PointNetAETrainer(w0, n, batch_size=b)
+    _, loss = one.forward_backward(x, want_recon=False)
+    assert abs(float(got["loss1"]) - float(loss.item())) <= 1e-6 * float(loss.item())
+    ref = one._unflatten(one.gradient_buffer().cpu().numpy())
+    dp = one._unflatten(got["grads"])
+    for k in ref:
+        for j in range(len(ref[k])):
+            if k == "enc_b":
+                continue                                   # rounding noise on both sides (zero behind a batch norm)
+            assert _rel(dp[k][j], ref[k][j].astype(np.float64)) <= 2e-5, (k, j, _rel(dp[k][j], ref[k][j].astype(np.float64)))
+    one2 = PointNetAETrainer(w0, n, batch_size=b)
+    losses = [one2.partial_fit(x, want_recon=False)[1] for _ in range(4)]
+    assert np.allclose(got["losses"], losses, rtol=2e-4)
+    w = one2.export_weights()
+    # the conv bias in front of a batch norm has a zero gradient: Adam turns its rounding noise into +-lr steps, so the
+    # bias -- and with it the moving MEAN -- random-walks by up to 4 * lr on either side; the variance is unaffected
+    assert np.allclose(got["mean0"], w["autoencoder/encoder_conv_layer_0_bnorm/moving_mean"], rtol=0, atol=4 * 0.0005 + 1e-5)
+    assert np.allclose(got["var3"], w["autoencoder/encoder_conv_layer_3_bnorm/moving_variance"], rtol=1e-3, atol=1e-7)
 
 
 def test_train_ae_cli_writes_a_restorable_checkpoint(tmp_path):
