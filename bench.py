@@ -41,6 +41,22 @@ def _encoder_entry(d):
     return d[names[0]]
 
 
+def chamfer_valu(avg_ms):
+    """VALU issue rate of the two Chamfer kernels of one step: wave-level VALU instructions from the committed PMC pass
+    (SQ_INSTS_VALU, profiles/r01_v5_pmc_sq.json) x 64 lanes / the measured time, against the best rate any VALU
+    micro-benchmark sustains on the box (geoadv_microbench, profiles/r01_probe_valu_chamfer_v1.json: 52.1 T lane-instr/s for
+    an alternating v_mul/v_add stream, 32 T for a single instruction type)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_sq.json")))
+        insts = d["chamfer_sym_kernel"]["SQ_INSTS_VALU"] + d["chamfer_sym_finish_kernel"]["SQ_INSTS_VALU"]
+        ceil = json.load(open(os.path.join(ROOT, "profiles", "r01_probe_valu_chamfer_v1.json")))["valu_mul+add"]["Tinstr_lane_per_s"]
+        rate = insts * 64.0 / (avg_ms * 1e-3) / 1e12
+        return {"T_lane_instr_per_s": rate, "measured_ceiling_T_lane_instr_per_s": ceil, "frac_of_measured_ceiling": rate / ceil,
+                "wave_instr_per_step_pmc": insts}
+    except Exception:               # pragma: no cover
+        return None
+
+
 def pmc_traffic_bytes():
     """HBM-side bytes per encoder launch from the committed PMC passes (separate --pmc runs, guide recipe):
     FETCH_SIZE is in KiB and under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM),
@@ -249,6 +265,7 @@ def main():
         "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel (both directions of both "
                                                          "problems from one distance evaluation per pair)", "avg_launch_ms": ch_avg_ms,
                              "launches_timed": ch_n, "achieved_Tpair_per_s": ch_pairs / (ch_avg_ms * 1e-3) / 1e12,
+                             "valu": chamfer_valu(ch_avg_ms),
                              "algorithmic_bytes_per_launch": ch_bytes,
                              "achieved_hbm_GBps": ch_bytes / (ch_avg_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS},
         "kernel_ms_per_iteration": breakdown,
