@@ -130,7 +130,16 @@ def cpu_baseline(weights, x, gt, iters=5, gpu_clouds=None):
         parity = {"clouds": int(p.shape[0]), "chamfer_loss_rel_err_max": float(np.abs(loss_gpu / loss_ref - 1.0).max()),
                   "dist_bit_exact": bool(np.array_equal(d1, o1) and np.array_equal(d2, o2)),
                   "idx_exact": bool(np.array_equal(i1, oi1) and np.array_equal(i2, oi2))}
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": os.cpu_count(), "kind": "port", "parity": parity,
+            "cpu_model": cpu_model, "oracle_flags": "gcc -O2 -ffp-contract=off (oracle/Makefile); numpy %s BLAS" % np.__version__,
             "sample": "%d iterations of config 2 (B=32, N=2048) after 1 warm-up, reference schedule (2 forwards/iter); "
                       "numpy fp32 GEMMs on all cores, Chamfer single-threaded C (gcc -O2 -ffp-contract=off)" % iters,
             "sec_per_iteration": dt / iters, "all_cores": all_cores}
