@@ -111,12 +111,13 @@ __device__ __forceinline__ float wave4_sum128(float v, float *sh2) {   // sum ov
     return sh2[0] + sh2[1];
 }
 
-__global__ __launch_bounds__(256) void loss_metrics_kernel(LossArgs a) {
+// cloud b of B; executed by threads 0..255 of the workgroup (whole waves beyond that may have exited)
+__device__ __forceinline__ void loss_metrics_body(const LossArgs &a, const int b, const int B) {
     __shared__ float shf[4][8];
     __shared__ int shi[4][2];
     __shared__ float sh2[4];
     __shared__ int take;
-    const int b = blockIdx.x, t = threadIdx.x, n = a.n, B = gridDim.x;
+    const int t = threadIdx.x, n = a.n;
     const size_t o = (size_t)b * n;
     CloudRed r;
     r.s1 = r.s2 = r.s3 = r.s4 = r.sp = 0.f;
@@ -183,6 +184,8 @@ __global__ __launch_bounds__(256) void loss_metrics_kernel(LossArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void loss_metrics_kernel(LossArgs a) { loss_metrics_body(a, blockIdx.x, gridDim.x); }
+
 // ------------------------------------------------------------------------------------------
 // Chamfer gradient w.r.t. the FIRST cloud only, with per-cloud constant upstream gradients
 // (mean over points => 1/n, times dist_weight for the source-distance term) -- the two uses the
@@ -227,11 +230,11 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradA
 constexpr double CG_FX = 17592186044416.0;          // 2^44
 constexpr int CG_FX_MAX_N = 5000;                   // 3 * 8 B * n <= 120 KB
 
-__global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGradArgs a) {
+__device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(lds);     // [n][3]
-    const CGradProblem pr = a.pr[blockIdx.y];
-    const int b = blockIdx.x, n = a.n;
+    const CGradProblem pr = a.pr[pi];
+    const int n = a.n;
     const float wb = pr.w ? pr.w[b] : 1.0f;
     const float gd = wb * (1.0f / (float)n);
     const float g2 = gd * 2;
@@ -259,6 +262,19 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGr
             const float sc = (float)((double)(long long)acc[3 * j + c] * (1.0 / CG_FX));
             pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
         }
+    }
+}
+
+__global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGradArgs a) { cgrad_fx_body(a, blockIdx.y, blockIdx.x); }
+
+// The per-cloud losses and the Chamfer gradients read the same NN results and do not depend on each other (unless the
+// max-distance term is on: it needs the arg-max the loss pass finds), so one launch does both: grid = (clouds,
+// 1 + problems); row 0 = losses / metrics / keep-best (its four upper waves leave at once), rows 1.. = gradients.
+__global__ __launch_bounds__(CGA_THREADS) void loss_cgrad_kernel(LossArgs la, CGradArgs ca) {
+    if (blockIdx.y == 0) {
+        if (threadIdx.x < 256) loss_metrics_body(la, blockIdx.x, gridDim.x);
+    } else {
+        cgrad_fx_body(ca, blockIdx.y - 1, blockIdx.x);
     }
 }
 
@@ -352,6 +368,7 @@ struct geoadv_attack {
     float *best_err, *best_metrics, *best_adv, *best_recon;
     float *emd_match, *emd_temp, *emd_cost, *emd_g1, *emd_g2;   // only when cfg.emd_weight > 0
     float *sym_ws;                   // column-minimum partials of the symmetric Chamfer kernel
+    bool cgrad_done;                 // the cached forward's loss launch also produced the Chamfer gradients
     unsigned *masks;                 // [B][n][mask words] ReLU masks of the cached forward, or null (backward recomputes)
     bool chamfer_sym;
     // host state
@@ -472,7 +489,22 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         la.dz_latent = at->dz; la.hist = hist_slot; la.keep = keep; la.best_err = at->best_err;
         la.best_metrics = at->best_metrics; la.adv = at->adv; la.recon = at->recon;
         la.best_adv = at->best_adv; la.best_recon = at->best_recon;
-        loss_metrics_kernel<<<B, 256, 0, st>>>(la);
+        // the Chamfer gradients the next step starts with ride in the same launch (see loss_cgrad_kernel)
+        const bool adv_chamfer = at->cfg.loss_adv_type == GEOADV_LOSS_ADV_CHAMFER;
+        const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
+        const bool max_term = dist_chamfer && at->cfg.max_point_dist_weight > 0.f;   // needs this pass's arg-max first
+        CGradArgs ca;
+        int np = 0;
+        if (adv_chamfer) ca.pr[np++] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
+        if (dist_chamfer) ca.pr[np++] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, 0.f};
+        at->cgrad_done = false;
+        if (np && !max_term && !at->overlap && n <= CG_FX_MAX_N) {
+            ca.n = n; ca.P = 0;
+            loss_cgrad_kernel<<<dim3(B, 1 + np), CGA_THREADS, sizeof(unsigned long long) * 3 * (size_t)n, st>>>(la, ca);
+            at->cgrad_done = true;
+        } else {
+            loss_metrics_kernel<<<B, 256, 0, st>>>(la);
+        }
         GA_LAUNCH_CHECK();
     }
     if (at->overlap) GA_HIP(hipEventRecord(at->ev_loss, st));
@@ -513,7 +545,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
         }
         GA_HIP(hipEventRecord(at->ev_gdist, at->s2));
     }
-    {
+    if (!at->cgrad_done) {   // (normally already produced by the forward's loss launch)
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
         CGradProblem pr[2];
         int np = 0;
@@ -522,6 +554,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
         if (np)
             if (int rc = launch_cgrad(pr, np, B, n, st)) return rc;
     }
+    at->cgrad_done = false;
     if (adv_chamfer && at->emd_match) {   // d(emd_weight * cost / n)/d recon, match held constant
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
         if (int rc = geoadv_match_cost_grad(B, n, n, at->recon, at->gt, at->emd_match, at->emd_g1, at->emd_g2, st)) return rc;
@@ -632,6 +665,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
         at->emd_match = F(4 * B * n * n); at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B);
         at->emd_g1 = F(4 * bn3); at->emd_g2 = F(4 * bn3);
     }
+    at->cgrad_done = false;
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
     at->fwd_valid = false; at->adv_valid = false;
     at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr;
@@ -664,6 +698,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_fx_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(loss_cgrad_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N);
         attr = true;
     }
