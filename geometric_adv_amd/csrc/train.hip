@@ -463,9 +463,9 @@ __global__ __launch_bounds__(256) void train_pool_bwd_kernel(PoolBwdArgs A) {
 // means over all ranks' rows
 struct BnBwdArgs { int mode; double *totals, *local_totals; const float2 *qsum; int tiles; int C; double inv_rows; float *dbeta, *dgamma, *m1, *m2; };
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs A) {
+__device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdArgs &A, const int block) {
     __shared__ double r1[32][32], r2[32][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+    const int c = block * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
     double s1 = 0.0, s2 = 0.0;
     if (A.mode != 2) {
         int t = g;
@@ -495,6 +495,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs A) {
         A.m1[c] = (float)(s1 * A.inv_rows); A.m2[c] = (float)(s2 * A.inv_rows);
     }
 }
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs A) { bn_bwd_finalize_block(A, blockIdx.x); }
 
 struct BwdArgs {
     int tiles;
@@ -703,27 +705,44 @@ __global__ __launch_bounds__(TR_THREADS) void train_bwd0_kernel(BwdArgs A) {
 }
 
 // out[e] = sum over workgroups of partial[w][e], in a fixed order: four contiguous runs of workgroups summed
-// front to back by four threads, then run0 + run1 + run2 + run3
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float *partial, int parts, size_t count, float *out) {
-    __shared__ float red[4][64];
-    const size_t e = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int g = threadIdx.x >> 6;
-    const int per = (parts + 3) / 4, w0 = g * per, w1 = min(parts, w0 + per);
+// front to back by four threads, then run0 + run1 + run2 + run3.  COLS elements per block, 4 * COLS threads.
+struct ReduceArgs { const float *partial; int parts; size_t count; float *out; };
+
+template <int COLS>
+__device__ __forceinline__ void partial_reduce_block(const ReduceArgs &A, const int block) {
+    __shared__ float red[4][COLS];
+    const int col = threadIdx.x % COLS, g = threadIdx.x / COLS;
+    const size_t e = (size_t)block * COLS + col;
+    const int per = (A.parts + 3) / 4, w0 = g * per, w1 = min(A.parts, w0 + per);
     float s = 0.f;
-    if (e < count) {
+    if (e < A.count) {
         int w = w0;
         for (; w + 8 <= w1; w += 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(w + u) * count + e];
+            for (int u = 0; u < 8; ++u) v[u] = A.partial[(size_t)(w + u) * A.count + e];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; w < w1; ++w) s += partial[(size_t)w * count + e];
+        for (; w < w1; ++w) s += A.partial[(size_t)w * A.count + e];
     }
-    red[g][threadIdx.x & 63] = s;
+    red[g][col] = s;
     __syncthreads();
-    if (g == 0 && e < count) out[e] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (g == 0 && e < A.count) A.out[e] = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+}
+
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float *partial, int parts, size_t count, float *out) {
+    partial_reduce_block<64>(ReduceArgs{partial, parts, count, out}, blockIdx.x);
+}
+
+// Everything that follows a backward layer kernel in ONE launch (three tiny dependent-free jobs, each of which would
+// otherwise pay a launch of its own): the BN-gradient sums of the layer below (blocks [0, bn_blocks)), then the
+// reductions of the layer's weight- and bias-gradient partials.
+__global__ __launch_bounds__(1024) void post_layer_kernel(BnBwdArgs bn, int bn_blocks, ReduceArgs dw, int dw_blocks, ReduceArgs db) {
+    const int blk = blockIdx.x;
+    if (blk < bn_blocks) bn_bwd_finalize_block(bn, blk);
+    else if (blk < bn_blocks + dw_blocks) partial_reduce_block<256>(dw, blk - bn_blocks);
+    else partial_reduce_block<256>(db, blk - bn_blocks - dw_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -995,19 +1014,32 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
     const int grid = a.tiles < t->grid_bwd ? a.tiles : t->grid_bwd;
     train_bwd_kernel<CIN, COUT, BWD_ROWS><<<grid, TR_THREADS, S::lds_bytes, st>>>(a);
     GA_LAUNCH_CHECK();
-    const size_t cnt = (size_t)CIN * COUT;
-    partial_reduce_kernel<<<(unsigned)((cnt + 63) / 64), 256, 0, st>>>(t->dw_partial, grid, cnt, t->grads + t->L.w[i]);
-    partial_reduce_kernel<<<cdiv(COUT, 64), 256, 0, st>>>(t->db_partial, grid, COUT, t->grads + t->L.b[i]);
-    GA_LAUNCH_CHECK();
-    return GEOADV_OK;
+    return GEOADV_OK;                                   // its partials are reduced by post_layer (next launch)
 }
 
-static int launch_bn_bwd(geoadv_trainer *t, int i, int partial_rows, int mode, int slot, hipStream_t st) {
+static BnBwdArgs bn_bwd_args(geoadv_trainer *t, int i, int partial_rows, int mode, int slot) {
     BnBwdArgs a;
     a.mode = mode; a.totals = t->xbuf + 512 * slot; a.local_totals = t->lbuf + 512 * slot;
     a.qsum = t->qsum; a.tiles = t->R / partial_rows; a.C = ENC[i + 1]; a.inv_rows = 1.0 / ((double)t->R * t->world);
     a.dbeta = t->grads + t->L.beta[i]; a.dgamma = t->grads + t->L.gamma[i]; a.m1 = t->bn_m1[i]; a.m2 = t->bn_m2[i];
-    bn_bwd_finalize_kernel<<<ENC[i + 1] / 32, 1024, 0, st>>>(a);
+    return a;
+}
+
+static int launch_bn_bwd(geoadv_trainer *t, int i, int partial_rows, int mode, int slot, hipStream_t st) {
+    bn_bwd_finalize_kernel<<<ENC[i + 1] / 32, 1024, 0, st>>>(bn_bwd_args(t, i, partial_rows, mode, slot));
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+// after the backward kernel of layer i (>= 1): BN-gradient sums of layer i - 1 (mode as in BnBwdArgs) + dW_i + db_i
+static int launch_post_layer(geoadv_trainer *t, int i, int mode, int slot, hipStream_t st) {
+    const int parts = (t->R / BWD_ROWS) < t->grid_bwd ? (t->R / BWD_ROWS) : t->grid_bwd;
+    const size_t cnt = (size_t)ENC[i] * ENC[i + 1];
+    const ReduceArgs dw{t->dw_partial, parts, cnt, t->grads + t->L.w[i]};
+    const ReduceArgs db{t->db_partial, parts, (size_t)ENC[i + 1], t->grads + t->L.b[i]};
+    const int bn_blocks = ENC[i] / 32, dw_blocks = (int)((cnt + 255) / 256), db_blocks = cdiv(ENC[i + 1], 256);
+    post_layer_kernel<<<bn_blocks + dw_blocks + db_blocks, 1024, 0, st>>>(bn_bwd_args(t, i - 1, BWD_ROWS, mode, slot), bn_blocks, dw,
+                                                                         dw_blocks, db);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -1096,7 +1128,7 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         else if (i == 2) rc = launch_bwd<128, 128>(t, 2, t->dybuf[0], t->dybuf[1], st);
         else rc = launch_bwd<64, 128>(t, 1, t->dybuf[1], t->dybuf[0], st);
         if (rc) return rc;
-        return launch_bn_bwd(t, i - 1, BWD_ROWS, end_mode, phase, st);
+        return launch_post_layer(t, i, end_mode, phase, st);
     }
     if (sync)
         if (int rc = launch_bn_bwd(t, 0, BWD_ROWS, 2, 9, st)) return rc;
@@ -1106,8 +1138,8 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
     a.aprev = x; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
     const int grid0 = t->tiles < t->grid_bwd ? t->tiles : t->grid_bwd;
     train_bwd0_kernel<<<grid0, TR_THREADS, 0, st>>>(a);
-    partial_reduce_kernel<<<3, 256, 0, st>>>(t->dw_partial, grid0, 192, t->grads + t->L.w[0]);
-    partial_reduce_kernel<<<1, 256, 0, st>>>(t->db_partial, grid0, 64, t->grads + t->L.b[0]);
+    post_layer_kernel<<<2, 1024, 0, st>>>(BnBwdArgs{}, 0, ReduceArgs{t->dw_partial, grid0, 192, t->grads + t->L.w[0]}, 1,
+                                          ReduceArgs{t->db_partial, grid0, 64, t->grads + t->L.b[0]});
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
