@@ -748,9 +748,13 @@ __global__ __launch_bounds__(1024) void post_layer_kernel(BnBwdArgs bn, int bn_b
 // ------------------------------------------------------------------------------------------------
 // optimizer + re-packing
 // ------------------------------------------------------------------------------------------------
-// TF 1.13 ApplyAdam over the flat parameter arena (see attack.hip adam_kernel for the restated form)
+// TF 1.13 ApplyAdam over the flat parameter arena (see attack.hip adam_kernel for the restated form).  An element that
+// belongs to one of the four wide encoder matrices is also written straight into its two MFMA fragment positions
+// (W_i for the forward, W_i^T for the backward), so the step needs no separate re-packing launch.
+struct AdamPack { size_t off[4]; int K[4], N[4]; float *fwd[4], *bwd[4]; };
+
 __global__ __launch_bounds__(256) void train_adam_kernel(float *p, float *m, float *v, const float *g, size_t count, float gscale,
-                                                         float lr, float b1p, float b2p) {
+                                                         float lr, float b1p, float b2p, AdamPack pk) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= count) return;
     const float alpha = lr * sqrtf(1.f - b2p) / (1.f - b1p);
@@ -758,7 +762,19 @@ __global__ __launch_bounds__(256) void train_adam_kernel(float *p, float *m, flo
     const float mn = m[e] + (gv - m[e]) * (1.f - 0.9f);
     const float vn = v[e] + (gv * gv - v[e]) * (1.f - 0.999f);
     m[e] = mn; v[e] = vn;
-    p[e] -= (mn * alpha) / (sqrtf(vn) + 1e-8f);
+    const float pn = p[e] - (mn * alpha) / (sqrtf(vn) + 1e-8f);
+    p[e] = pn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int K = pk.K[j], N = pk.N[j];
+        if (e >= pk.off[j] && e < pk.off[j] + (size_t)K * N) {
+            const int r = (int)(e - pk.off[j]), k = r / N, n = r % N;        // W[k][n]
+            // forward fragments: B[k][n] = W[k][n]
+            pk.fwd[j][((size_t)((n >> 5) * (K >> 3) + (k >> 3)) * 64 + (((k >> 2) & 1) << 5) + (n & 31)) * 4 + (k & 3)] = pn;
+            // backward fragments: B'[k' = n][n' = k] = W[k][n], K' = N, N' = K
+            pk.bwd[j][((size_t)((k >> 5) * (N >> 3) + (n >> 3)) * 64 + (((n >> 2) & 1) << 5) + (k & 31)) * 4 + (n & 3)] = pn;
+        }
+    }
 }
 
 // packed[((cb * K/8 + t) * 64 + lane) * 4 + u] = B[8t + 4*(lane>>5) + u][32cb + (lane&31)];
@@ -1196,11 +1212,16 @@ extern "C" int geoadv_trainer_apply(geoadv_trainer *t, float grad_scale, void *s
     GA_REQUIRE(t, "trainer_apply: null trainer");
     hipStream_t st = as_stream(stream);
     const size_t P = t->L.count;
+    AdamPack pk;
+    for (int i = 1; i < ENC_L; ++i) {
+        pk.off[i - 1] = t->L.w[i]; pk.K[i - 1] = ENC[i]; pk.N[i - 1] = ENC[i + 1];
+        pk.fwd[i - 1] = t->packed_fwd[i]; pk.bwd[i - 1] = t->packed_bwd[i];
+    }
     train_adam_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(t->params, t->adam_m, t->adam_v, t->grads, P, grad_scale, t->lr,
-                                                                   t->b1p, t->b2p);
+                                                                   t->b1p, t->b2p, pk);
     GA_LAUNCH_CHECK();
     t->b1p *= 0.9f; t->b2p *= 0.999f;
-    return trainer_repack(t, st);
+    return GEOADV_OK;
 }
 
 extern "C" int geoadv_trainer_step(geoadv_trainer *t, const float *x, const float *gt, float *loss, float *recon, void *stream) {
