@@ -37,6 +37,7 @@ int launch_chamfer_grad(const CGradProblem *pr, int np, int B, int n, hipStream_
 constexpr int TR_THREADS = 512;
 constexpr int TR_ROWS = 64;
 constexpr float BN_EPS = 1e-5f;
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -277,29 +278,30 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const 
     }
 }
 
-// loss = (sum dist1 + sum dist2) / (B * N): tf.reduce_mean over all elements of each direction (pointnet_ae.py:77)
-__global__ __launch_bounds__(1024) void chamfer_loss_kernel(const float *d1, const float *d2, size_t count, double inv, float *loss) {
-    __shared__ double red[1024];
+// loss = (sum dist1 + sum dist2) / (B * N): tf.reduce_mean over all elements of each direction (pointnet_ae.py:77);
+// one workgroup of 256 threads, fixed summation order
+__device__ __forceinline__ void chamfer_loss_block(const float *d1, const float *d2, size_t count, double inv, float *loss) {
+    __shared__ double red[256];
     const float4 *a = reinterpret_cast<const float4 *>(d1), *b = reinterpret_cast<const float4 *>(d2);
     const size_t q = count / 4;                               // count = B * n is a multiple of 64
     double s = 0.0;
     size_t e = threadIdx.x;
-    for (; e + 3072 < q; e += 4096) {
+    for (; e + 768 < q; e += 1024) {
         float4 u[4], v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { u[k] = a[e + 1024 * k]; v[k] = b[e + 1024 * k]; }
+        for (int k = 0; k < 4; ++k) { u[k] = a[e + 256 * k]; v[k] = b[e + 256 * k]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             s += ((double)u[k].x + (double)u[k].y) + ((double)u[k].z + (double)u[k].w) + ((double)v[k].x + (double)v[k].y) +
                  ((double)v[k].z + (double)v[k].w);
     }
-    for (; e < q; e += 1024) {
+    for (; e < q; e += 256) {
         const float4 u = a[e], v = b[e];
         s += ((double)u.x + (double)u.y) + ((double)u.z + (double)u.w) + ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
     }
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
+    for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
@@ -311,13 +313,15 @@ __global__ void fill_f32_kernel(float *p, float v, size_t count) {
     if (e < count) p[e] = v;
 }
 
-// dV2[k][n] = sum_b d2[b][k] * g[b][n]; dc2[n] = sum_b g[b][n].  grid = (ceil(n3/128), 256/32), block 128
-__global__ __launch_bounds__(128) void fc_out_bwd_w_kernel(const float *d2, const float *g, float *dV2, float *dc2, int batch, int n3) {
+// dV2[k][n] = sum_b d2[b][k] * g[b][n]; dc2[n] = sum_b g[b][n].  Block (bx, by) of (ceil(n3/128), 256/32), 128 threads
+__device__ __forceinline__ void fc_out_bwd_w_block(const float *d2, const float *g, float *dV2, float *dc2, int batch, int n3,
+                                                   const int bx, const int by) {
     extern __shared__ __align__(16) float xs[];            // [batch][32]
-    const int k0 = blockIdx.y * 32;
+    if (threadIdx.x >= 128) return;                         // (whole waves)
+    const int k0 = by * 32;
     for (int e = threadIdx.x; e < batch * 32; e += 128) xs[e] = d2[(size_t)(e >> 5) * 256 + k0 + (e & 31)];
     __syncthreads();
-    const int n = blockIdx.x * 128 + threadIdx.x;
+    const int n = bx * 128 + threadIdx.x;
     if (n >= n3) return;
     float acc[32] = {};
     float gs = 0.f;
@@ -333,13 +337,14 @@ __global__ __launch_bounds__(128) void fc_out_bwd_w_kernel(const float *d2, cons
     }
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) dV2[(size_t)(k0 + kk) * n3 + n] = acc[kk];
-    if (blockIdx.y == 0) dc2[n] = gs;
+    if (by == 0) dc2[n] = gs;
 }
 
-// dd2[b][k] = [d2[b][k] > 0] * sum_n g[b][n] * V2[k][n]; grid = (256/4, ceil(B/8)), block 256
-__global__ __launch_bounds__(256) void fc_out_bwd_x_kernel(const float *g, const float *V2, const float *d2, float *dd2, int batch, int n3) {
+// dd2[b][k] = [d2[b][k] > 0] * sum_n g[b][n] * V2[k][n]; block (bx, by) of (256/4, ceil(B/8)), 256 threads
+__device__ __forceinline__ void fc_out_bwd_x_block(const float *g, const float *V2, const float *d2, float *dd2, int batch, int n3,
+                                                   const int bx, const int by) {
     __shared__ float red[4][32];
-    const int k0 = blockIdx.x * 4, b0 = blockIdx.y * 8;
+    const int k0 = bx * 4, b0 = by * 8;
     float acc[4][8] = {};
     for (int n = threadIdx.x; n < n3; n += 256) {
         float w[4], gv[8];
@@ -373,9 +378,24 @@ __global__ __launch_bounds__(256) void fc_out_bwd_x_kernel(const float *g, const
     }
 }
 
+// The output layer's backward in ONE launch: its weight gradient, its data gradient and the scalar loss all depend
+// only on the Chamfer results, not on each other.  blocks [0, nw): dV2 / dc2, [nw, nw + nx): dd2, last block: loss.
+struct DecOutBwdArgs {
+    const float *d2, *g, *V2; float *dV2, *dc2, *dd2; int batch, n3;
+    const float *dist1, *dist2; size_t count; double inv; float *loss;
+};
+
+__global__ __launch_bounds__(256) void dec_out_bwd_kernel(DecOutBwdArgs A) {
+    const int wx = cdiv_dev(A.n3, 128), nw = wx * 8, nx = 64 * cdiv_dev(A.batch, 8);
+    const int blk = blockIdx.x;
+    if (blk < nw) fc_out_bwd_w_block(A.d2, A.g, A.dV2, A.dc2, A.batch, A.n3, blk % wx, blk / wx);
+    else if (blk < nw + nx) fc_out_bwd_x_block(A.g, A.V2, A.d2, A.dd2, A.batch, A.n3, (blk - nw) % 64, (blk - nw) / 64);
+    else chamfer_loss_block(A.dist1, A.dist2, A.count, A.inv, A.loss);
+}
+
 // Small dense layer backward: dW[k][n] = sum_b in[b][k] * dout[b][n] (grid.x = k), db[n] = sum_b dout[b][n]
-__global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float *in, const float *dout, float *dW, float *db, int batch, int K) {
-    const int k = blockIdx.x, n = threadIdx.x;
+__device__ __forceinline__ void fc_bwd_w_block(const float *in, const float *dout, float *dW, float *db, int batch, int K, const int k) {
+    const int n = threadIdx.x;
     float acc = 0.f, s = 0.f;
 #pragma unroll 8
     for (int b = 0; b < batch; ++b) {
@@ -389,9 +409,9 @@ __global__ __launch_bounds__(256) void fc_bwd_w_kernel(const float *in, const fl
 
 // din[b][k] = mask * sum_n dout[b][n] * W[k][n]; grid = B, block = K threads (one wave-strided row each)
 template <bool MASK>
-__global__ __launch_bounds__(256) void fc_bwd_x_kernel(const float *dout, const float *W, const float *act_in, float *din, int K) {
+__device__ __forceinline__ void fc_bwd_x_block(const float *dout, const float *W, const float *act_in, float *din, int K, const int b) {
     __shared__ __align__(16) float d[256];
-    d[threadIdx.x] = dout[(size_t)blockIdx.x * 256 + threadIdx.x];
+    d[threadIdx.x] = dout[(size_t)b * 256 + threadIdx.x];
     __syncthreads();
     const int k = threadIdx.x;
     if (k >= K) return;
@@ -405,8 +425,16 @@ __global__ __launch_bounds__(256) void fc_bwd_x_kernel(const float *dout, const 
         a1 = fmaf(w1.w, d1.w, fmaf(w1.z, d1.z, fmaf(w1.y, d1.y, fmaf(w1.x, d1.x, a1))));
     }
     const float v = a0 + a1;
-    const size_t o = (size_t)blockIdx.x * K + k;
+    const size_t o = (size_t)b * K + k;
     din[o] = (!MASK || act_in[o] > 0.f) ? v : 0.f;
+}
+
+// weight gradient (blocks [0, K)) and data gradient (blocks [K, K + batch)) of a small dense layer in one launch
+template <bool MASK>
+__global__ __launch_bounds__(256) void fc_bwd_kernel(const float *in, const float *dout, const float *W, float *dW, float *db, float *din,
+                                                     int batch, int K) {
+    if ((int)blockIdx.x < K) fc_bwd_w_block(in, dout, dW, db, batch, K, blockIdx.x);
+    else fc_bwd_x_block<MASK>(dout, W, in, din, K, blockIdx.x - K);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,7 +928,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     }
     const size_t o_dy0 = take(4 * (size_t)t->R * 256), o_dy1 = take(4 * (size_t)t->R * 256);
     const size_t o_ps = take(8 * (size_t)t->tiles * 256), o_qs = take(8 * (size_t)(t->R / BWD_ROWS) * 256);
-    const size_t o_z = take(4 * (size_t)B * 128), o_cnt = take(4 * (size_t)B * 128);
+    const size_t o_z = take(4 * (size_t)B * 128), o_cnt = take(4 * (size_t)B * 128);   // adjacent: B * 512 B is a multiple of 256
     const size_t o_d1 = take(4 * (size_t)B * 256), o_d2 = take(4 * (size_t)B * 256);
     const size_t o_rec = take(4 * (size_t)B * t->n3), o_gr = take(4 * (size_t)B * t->n3);
     const size_t o_cws = take(4 * chamfer_sym_workspace_floats(1, B, n, n));
@@ -1095,8 +1123,7 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         if (sync)
             if (int rc = launch_bn(t, 4, 2, 4, st)) return rc;
         // ---- symmetric max-pool ----
-        GA_HIP(hipMemsetAsync(t->zbits, 0, sizeof(int) * (size_t)B * 128, st));
-        GA_HIP(hipMemsetAsync(t->cnt, 0, sizeof(int) * (size_t)B * 128, st));
+        GA_HIP(hipMemsetAsync(t->zbits, 0, 2 * sizeof(int) * (size_t)B * 128, st));      // zbits and cnt are adjacent
         PoolArgs pa{t->act[4], t->bn_scale[4], t->bn_shift[4], n, t->zbits, t->cnt};
         train_pool_kernel<false><<<t->tiles, 256, 0, st>>>(pa);
         train_pool_kernel<true><<<t->tiles, 256, 0, st>>>(pa);
@@ -1112,20 +1139,18 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         // one distance evaluation per pair serves both directions (chamfer_sym.hip); dist/idx bit-identical to nn_distance
         const ChamferPair cp{t->recon, gt, t->dist1, t->idx1, t->dist2, t->idx2};
         if (int rc = launch_chamfer_sym(&cp, 1, B, n, n, t->cham_ws, st)) return rc;
-        // reduce_mean over the batch of ALL ranks: with several ranks the host adds the per-rank values up
-        chamfer_loss_kernel<<<1, 1024, 0, st>>>(t->dist1, t->dist2, (size_t)B * n, 1.0 / ((double)B * t->world * n), t->loss);
-        GA_LAUNCH_CHECK();
         // NnDistanceGrad w.r.t. the reconstruction only (order-independent fixed-point accumulation, attack.hip)
         const CGradProblem gp{t->recon, gt, t->idx1, t->idx2, t->g_recon, t->gd, nullptr, 0.f};
         if (int rc = launch_chamfer_grad(&gp, 1, B, n, st)) return rc;
-        // ---- decoder backward ----
-        fc_out_bwd_w_kernel<<<dim3(cdiv(n3, 128), 8), 128, sizeof(float) * B * 32, st>>>(t->d2, t->g_recon, t->grads + t->L.v[2],
-                                                                                        t->grads + t->L.c[2], B, n3);
-        fc_out_bwd_x_kernel<<<dim3(64, cdiv(B, 8)), 256, 0, st>>>(t->g_recon, V2, t->d2, t->dd2, B, n3);
-        fc_bwd_w_kernel<<<256, 256, 0, st>>>(t->d1, t->dd2, t->grads + t->L.v[1], t->grads + t->L.c[1], B, 256);
-        fc_bwd_x_kernel<true><<<B, 256, 0, st>>>(t->dd2, V1, t->d1, t->dd1, 256);
-        fc_bwd_w_kernel<<<128, 256, 0, st>>>(z, t->dd1, t->grads + t->L.v[0], t->grads + t->L.c[0], B, 128);
-        fc_bwd_x_kernel<false><<<B, 256, 0, st>>>(t->dd1, V0, nullptr, t->dz, 128);
+        // ---- decoder backward: three launches, each = weight gradient + data gradient of one layer side by side ----
+        DecOutBwdArgs da;
+        da.d2 = t->d2; da.g = t->g_recon; da.V2 = V2; da.dV2 = t->grads + t->L.v[2]; da.dc2 = t->grads + t->L.c[2]; da.dd2 = t->dd2;
+        da.batch = B; da.n3 = n3; da.dist1 = t->dist1; da.dist2 = t->dist2; da.count = (size_t)B * n;
+        da.inv = 1.0 / ((double)B * t->world * n);   // reduce_mean over the batch of ALL ranks (the host adds the ranks up)
+        da.loss = t->loss;
+        dec_out_bwd_kernel<<<cdiv(n3, 128) * 8 + 64 * cdiv(B, 8) + 1, 256, sizeof(float) * B * 32, st>>>(da);
+        fc_bwd_kernel<true><<<256 + B, 256, 0, st>>>(t->d1, t->dd2, V1, t->grads + t->L.v[1], t->grads + t->L.c[1], t->dd1, B, 256);
+        fc_bwd_kernel<false><<<128 + B, 256, 0, st>>>(z, t->dd1, V0, t->grads + t->L.v[0], t->grads + t->L.c[0], t->dz, B, 128);
         GA_LAUNCH_CHECK();
         // ---- encoder backward starts: pool gradient + ReLU of layer 4 ----
         PoolBwdArgs pb{t->act[4], t->bn_scale[4], t->bn_shift[4], t->bn_mean[4], t->bn_istd[4], n, t->zbits, t->cnt, t->dz,
