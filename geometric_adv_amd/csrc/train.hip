@@ -194,9 +194,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnArgs A) {
 struct PoolArgs { const float *a4; const float *scale, *shift; int n_points; int *zbits; int *cnt; };
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void train_pool_kernel(PoolArgs A) {
+__device__ __forceinline__ void train_pool_block(const PoolArgs &A, const int tile) {
     __shared__ int red[8][128];
-    const size_t row0 = (size_t)blockIdx.x * TR_ROWS;
+    const size_t row0 = (size_t)tile * TR_ROWS;
     const int cloud = (int)(row0 / A.n_points);
     const int c4 = threadIdx.x & 31, g = threadIdx.x >> 5;
     const float4 s = reinterpret_cast<const float4 *>(A.scale)[c4], t = reinterpret_cast<const float4 *>(A.shift)[c4];
@@ -222,14 +222,17 @@ __global__ __launch_bounds__(256) void train_pool_kernel(PoolArgs A) {
     }
 }
 
+template <bool COUNT>
+__global__ __launch_bounds__(256) void train_pool_kernel(PoolArgs A) { train_pool_block<COUNT>(A, blockIdx.x); }
+
 // ------------------------------------------------------------------------------------------------
 // decoder (B rows only: VALU)
 // ------------------------------------------------------------------------------------------------
 // out[b][n] = act(in[b][:] @ W[:, n] + bias[n]); grid = B, block = NOUT (256)
 template <int K, bool RELU>
-__global__ __launch_bounds__(256) void fc_fwd_kernel(const float *in, const float *W, const float *bias, float *out, int nout) {
+__device__ __forceinline__ void fc_fwd_block(const float *in, const float *W, const float *bias, float *out, int nout, const int b) {
     __shared__ float x[K];
-    if (threadIdx.x < K) x[threadIdx.x] = in[(size_t)blockIdx.x * K + threadIdx.x];
+    if (threadIdx.x < K) x[threadIdx.x] = in[(size_t)b * K + threadIdx.x];
     __syncthreads();
     const int n = threadIdx.x;
     float acc0 = 0.f, acc1 = 0.f;
@@ -239,7 +242,20 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float *in, const floa
         acc1 = fmaf(x[k + 1], W[(size_t)(k + 1) * nout + n], acc1);
     }
     const float v = acc0 + acc1 + bias[n];
-    out[(size_t)blockIdx.x * nout + n] = RELU ? fmaxf(v, 0.f) : v;
+    out[(size_t)b * nout + n] = RELU ? fmaxf(v, 0.f) : v;
+}
+
+template <int K, bool RELU>
+__global__ __launch_bounds__(256) void fc_fwd_kernel(const float *in, const float *W, const float *bias, float *out, int nout) {
+    fc_fwd_block<K, RELU>(in, W, bias, out, nout, blockIdx.x);
+}
+
+// First decoder layer (blocks [0, batch)) and the tie counts of the max-pool (the remaining blocks, one per tile): both
+// need only the pooled maxima, neither needs the other.
+__global__ __launch_bounds__(256) void fc0_and_pool_count_kernel(const float *z, const float *W, const float *bias, float *out, int batch,
+                                                                 PoolArgs P) {
+    if ((int)blockIdx.x < batch) fc_fwd_block<128, true>(z, W, bias, out, 256, blockIdx.x);
+    else train_pool_block<true>(P, blockIdx.x - batch);
 }
 
 // recon[b][n] = d2[b][:] @ V2[:, n] + c2[n]; grid = (ceil(n3/64), ceil(B/16)), block 256 = 64 columns x 4 K slices
@@ -1126,12 +1142,11 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         GA_HIP(hipMemsetAsync(t->zbits, 0, 2 * sizeof(int) * (size_t)B * 128, st));      // zbits and cnt are adjacent
         PoolArgs pa{t->act[4], t->bn_scale[4], t->bn_shift[4], n, t->zbits, t->cnt};
         train_pool_kernel<false><<<t->tiles, 256, 0, st>>>(pa);
-        train_pool_kernel<true><<<t->tiles, 256, 0, st>>>(pa);
         GA_LAUNCH_CHECK();
         const float *z = reinterpret_cast<const float *>(t->zbits);
         // ---- decoder forward ----
         const float *V0 = t->params + t->L.v[0], *V1 = t->params + t->L.v[1], *V2 = t->params + t->L.v[2];
-        fc_fwd_kernel<128, true><<<B, 256, 0, st>>>(z, V0, t->params + t->L.c[0], t->d1, 256);
+        fc0_and_pool_count_kernel<<<B + t->tiles, 256, 0, st>>>(z, V0, t->params + t->L.c[0], t->d1, B, pa);
         fc_fwd_kernel<256, true><<<B, 256, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2, 256);
         fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
         GA_LAUNCH_CHECK();
