@@ -639,7 +639,7 @@ __global__ __launch_bounds__(F3_THREADS, 2) void encoder_fwd3_kernel(DeviceAE A,
 template <int ROWS>
 __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const float *adv, const int *rows,
                                                  int rows_per_cloud, const float *z, const int *zcnt, const float *dz,
-                                                 float *g_enc, const int b) {
+                                                 float *g_enc, const int b, const int r0) {
     using LD = EncLds<ROWS>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufP = lds;
@@ -652,7 +652,6 @@ __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const
     unsigned char *m3 = m2 + ROWS * 128;
     unsigned char *m4 = m3 + ROWS * 128;
 
-    const int r0 = blockIdx.x * ROWS;
     if (threadIdx.x < ROWS) {
         int rr = r0 + threadIdx.x;
         int p;
@@ -745,10 +744,9 @@ constexpr int BWM_ROWS = 32;
 constexpr size_t BWM_LDS_BYTES = sizeof(float) * (BWM_ROWS * 260 + BWM_ROWS * 132 + 3 * 2 * 16 * 64 + 128) +
                                  sizeof(int) * (BWM_ROWS + 128) + sizeof(unsigned) * BWM_ROWS * MASK_WORDS;
 
-__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_masked_kernel(DeviceAE A, int n, const unsigned *masks, const int *rows,
-                                                                        const float *z, const float *dz, const int *dense_flag,
-                                                                        float *g_enc) {
-    const int b = blockIdx.y;
+__device__ __forceinline__ void encoder_bwd_masked_body(const DeviceAE &A, int n, const unsigned *masks, const int *rows,
+                                                        const float *z, const float *dz, const int *dense_flag,
+                                                        float *g_enc, const int bx, const int b) {
     if (dense_flag[b] != 0) return;
     constexpr int ROWS = BWM_ROWS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -759,7 +757,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_masked_kernel(DeviceA
     int *rowid = reinterpret_cast<int *>(dzs + 128);    // [32]
     int *crit = rowid + ROWS;                           // [128]
     unsigned *mw = reinterpret_cast<unsigned *>(crit + 128);   // [32][MASK_WORDS]
-    const int r0 = blockIdx.x * ROWS;
+    const int r0 = bx * ROWS;
     if (threadIdx.x < 128) {
         const int c = threadIdx.x;
         crit[c] = rows[(size_t)b * 128 + c];
@@ -814,6 +812,12 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_masked_kernel(DeviceA
     }
 }
 
+__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_masked_kernel(DeviceAE A, int n, const unsigned *masks, const int *rows,
+                                                                        const float *z, const float *dz, const int *dense_flag,
+                                                                        float *g_enc) {
+    encoder_bwd_masked_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x, blockIdx.y);
+}
+
 // Sparse launch: grid (128 / ROWS, batch): block (tile, b) handles 32 of cloud b's 128 critical rows; flagged clouds
 // (exact tie in the max-pool) are skipped.  Dense launch: grid (n / ROWS, DENSE_SLOTS): the flagged clouds -- almost
 // never any -- are dealt round-robin to the DENSE_SLOTS block rows, which process every point of them; with no flagged
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(DeviceAE A, in
     if (!want_dense) {
         const int b = blockIdx.y;
         if (dense_flag[b] != 0) return;
-        encoder_bwd_tile<ROWS>(A, n, adv, rows, rows_per_cloud, z, zcnt, dz, g_enc, b);
+        encoder_bwd_tile<ROWS>(A, n, adv, rows, rows_per_cloud, z, zcnt, dz, g_enc, b, blockIdx.x * ROWS);
         return;
     }
     __shared__ int any_flag;                           // fast path: one parallel look at the flags, usually all zero
@@ -840,8 +844,38 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(DeviceAE A, in
     for (int b = 0; b < batch; ++b) {
         if (dense_flag[b] == 0) continue;
         if ((rank++ % (int)gridDim.y) != (int)blockIdx.y) continue;
-        encoder_bwd_tile<ROWS>(A, n, adv, nullptr, 0, z, zcnt, dz, g_enc, b);
+        encoder_bwd_tile<ROWS>(A, n, adv, nullptr, 0, z, zcnt, dz, g_enc, b, blockIdx.x * ROWS);
         __syncthreads();                               // LDS is reused for the next flagged cloud
+    }
+}
+
+// Both backward launches in one: blocks [0, 4 * batch) = masked sparse path, the rest = the dense path for clouds with a
+// tied maximum (its blocks read the flags and leave at once when there is none -- which is almost always).  A launch of
+// its own for that check costs ~4 us per iteration.
+constexpr int BWD_MERGED_DENSE_SLOTS = 2;
+__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_merged_kernel(DeviceAE A, int n, int batch, const unsigned *masks,
+                                                                        const int *rows, const float *z, const int *zcnt,
+                                                                        const float *dz, const int *dense_flag, const float *adv,
+                                                                        float *g_enc) {
+    const int nm = (128 / BWM_ROWS) * batch;
+    if ((int)blockIdx.x < nm) {
+        encoder_bwd_masked_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % (128 / BWM_ROWS), blockIdx.x / (128 / BWM_ROWS));
+        return;
+    }
+    const int d = blockIdx.x - nm, tiles = (n + 63) / 64, tile = d % tiles, slot = d / tiles;
+    __shared__ int any_flag;
+    if (threadIdx.x == 0) any_flag = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < batch; b += ENC_THREADS)
+        if (dense_flag[b] != 0) atomicOr(&any_flag, 1);
+    __syncthreads();
+    if (!any_flag) return;
+    int rank = 0;
+    for (int b = 0; b < batch; ++b) {
+        if (dense_flag[b] == 0) continue;
+        if ((rank++ % BWD_MERGED_DENSE_SLOTS) != slot) continue;
+        encoder_bwd_tile<64>(A, n, adv, nullptr, 0, z, zcnt, dz, g_enc, b, tile * 64);
+        __syncthreads();
     }
 }
 
@@ -866,6 +900,8 @@ static int set_lds_attr_once() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_masked_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWM_LDS_BYTES));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_merged_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::bwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_SPARSE_ROWS>::bwd_bytes));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_DENSE_ROWS, true>),
@@ -928,6 +964,15 @@ int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *cr
                        hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
+    static int merged = -1;
+    if (merged < 0) { const char *e = getenv("GEOADV_BWD_MERGED"); merged = e ? atoi(e) : 1; }
+    if (masks && fwd_variant() == 0 && merged) {
+        const size_t lds = BWM_LDS_BYTES > EncLds<64>::bwd_bytes ? BWM_LDS_BYTES : EncLds<64>::bwd_bytes;
+        const int grid = (128 / BWM_ROWS) * b + cdiv(A.n_points, 64) * BWD_MERGED_DENSE_SLOTS;
+        encoder_bwd_merged_kernel<<<grid, ENC_THREADS, lds, stream>>>(A, A.n_points, b, masks, crit_rows, z, zcnt, dz, dense_flag, adv, g_enc);
+        GA_LAUNCH_CHECK();
+        return GEOADV_OK;
+    }
     if (masks && fwd_variant() == 0)
         encoder_bwd_masked_kernel<<<dim3(128 / BWM_ROWS, b), ENC_THREADS, BWM_LDS_BYTES, stream>>>(A, A.n_points, masks, crit_rows, z, dz,
                                                                                                dense_flag, g_enc);
