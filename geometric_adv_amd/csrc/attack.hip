@@ -25,6 +25,13 @@ struct ChamferPair { const float *p, *q; float *dist1; int *idx1; float *dist2; 
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
 int launch_chamfer_light(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, hipStream_t stream);
+int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
+                              hipStream_t stream);
+int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need,
+                        hipStream_t stream);
+bool chamfer_grid_supports(int n, int m);
+int launch_decoder_fc2_and_grid(const DeviceAE &A, int b, const float *d2v, float *recon, const float *P, const float *Q, float *gd1,
+                                int *gi1, float *gd2, int *gi2, int n, int *need, hipStream_t stream);
 struct ForwardScratch {
     float *pmax; int *parg; int *pcnt; float *z; int *crit; int *zcnt; int *dense; float *d1, *d2; size_t bytes;
 };
@@ -369,6 +376,8 @@ struct geoadv_attack {
     float *emd_match, *emd_temp, *emd_cost, *emd_g1, *emd_g2;   // only when cfg.emd_weight > 0
     float *sym_ws;                   // column-minimum partials of the symmetric Chamfer kernel
     bool cgrad_done;                 // the cached forward's loss launch also produced the Chamfer gradients
+    bool chamfer_prune;              // nn_distance(adv, x) through the paired grid search (GEOADV_CHAMFER_PRUNE, default on)
+    int *need_adv;                   // [8 B] clouds the grid search handed back to the all-pairs kernel
     unsigned *masks;                 // [B][n][mask words] ReLU masks of the cached forward, or null (backward recomputes)
     bool chamfer_sym;
     // host state
@@ -446,6 +455,10 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         }
         GA_HIP(hipEventRecord(at->ev_scan, at->s2));
     }
+    // nn_distance(adv, x): adv = x + pert and most points barely move, so the exact grid search seeded with the pairing
+    // (chamfer_grid.hip) answers it for a fraction of the all-pairs cost; clouds whose pairing has become poor raise
+    // their `need` flag and are redone by the all-pairs launch below (same results either way)
+    const bool pruned = at->chamfer_prune && !split && at->chamfer_sym && chamfer_grid_supports(n, n);
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st);
         if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, at->adv_valid ? nullptr : at->adv, at->fs.pmax, at->fs.parg,
@@ -456,7 +469,10 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         ProfScope ps(at, GEOADV_PROF_DECODER_FWD, st);
         if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
                                           at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
-        if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
+        if (pruned) {   // the grid search rides in the FC2 launch (it needs nothing from the decoder)
+            if (int rc = launch_decoder_fc2_and_grid(A, B, at->fs.d2, at->recon, at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, n,
+                                                     at->need_adv, st)) return rc;
+        } else if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
     }
     {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
@@ -466,7 +482,9 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         } else if (at->chamfer_sym) {   // one distance evaluation per pair serves both directions
             const ChamferPair pairs[2] = {{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2},
                                           {at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2}};
-            if (int rc = launch_chamfer_sym(pairs, 2, B, n, n, at->sym_ws, st)) return rc;
+            if (pruned) {
+                if (int rc = launch_chamfer_sym_needed(pairs, 2, B, n, n, at->sym_ws, at->need_adv, st)) return rc;
+            } else if (int rc = launch_chamfer_sym(pairs, 2, B, n, n, at->sym_ws, st)) return rc;
         } else {
             const ChamferScan all[4] = {sc_recon[0], sc_recon[1], sc_adv[0], sc_adv[1]};
             if (int rc = launch_chamfer_scans(all, 4, B, st)) return rc;
@@ -630,6 +648,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     const char *mask_env = getenv("GEOADV_BWD_MASKS");             // "0": backward recomputes the forward (A/B tests)
     const size_t mask_words = (mask_env && mask_env[0] == '0') ? 0 : (size_t)encoder_mask_words() * bn;   // ReLU masks of the cached forward
     need(4 * mask_words);
+    need(4 * 8 * B);                                      // need_adv
     const bool emd = cfg->emd_weight > 0.f;
     const size_t emd_temp_f = emd ? geoadv_approx_match_temp_floats(at->B, at->n, at->n) : 0;
     if (emd) { need(4 * B * n * n); need(4 * emd_temp_f + 8); need(4 * B); need(4 * bn3); need(4 * bn3); }
@@ -656,6 +675,11 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
     at->sym_ws = F(4 * sym_floats);
     at->masks = mask_words ? reinterpret_cast<unsigned *>(take(4 * mask_words)) : nullptr;
+    at->need_adv = I(4 * 8 * B);
+    {
+        const char *e = getenv("GEOADV_CHAMFER_PRUNE");
+        at->chamfer_prune = !(e && e[0] == '0');
+    }
     {
         const char *e = getenv("GEOADV_CHAMFER_SYM");
         at->chamfer_sym = !(e && e[0] == '0');

@@ -1,0 +1,208 @@
+// Device side of the paired exact grid search (see chamfer_grid.hip for the method); a header so that its workgroups can
+// ride in another kernel's launch (decoder.hip: the FC2 forward leaves most of the chip idle).
+#pragma once
+#include "common.h"
+#include <limits.h>
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+namespace geoadv {
+
+constexpr int GR_THREADS = 512;
+constexpr int GR_G = 16;                        // cells per axis
+constexpr int GR_CELLS = GR_G * GR_G * GR_G;
+constexpr int GR_MAX_N = 4096;                  // points per cloud that fit the LDS layout below
+constexpr int GR_MAX_SPAN = 4;                  // cells per axis a lane walks on its own
+constexpr int GR_QSPLIT = 4;                    // workgroups per (cloud, direction): each sorts all targets, answers 1/4 of the queries
+constexpr float GR_LO = -0.5f, GR_INV_H = 16.0f;
+
+__device__ __forceinline__ float gr_sqdist(float tx, float ty, float tz, float qx, float qy, float qz) {
+    const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return (xx + yy) + zz;
+}
+
+__device__ __forceinline__ int gr_cell1(float v) {
+    const int c = (int)floorf((v - GR_LO) * GR_INV_H);
+    return c < 0 ? 0 : (c > GR_G - 1 ? GR_G - 1 : c);
+}
+
+struct GridArgs {
+    const float *P, *Q;           // [b][n][3]
+    float *d1; int *i1;           // P -> Q
+    float *d2; int *i2;           // Q -> P
+    int n;
+    int *need;                    // null, or int[8 * b]: (cloud, direction, query slice) -> 1 if that workgroup gave up
+                                  // (poor pairing: the caller runs the all-pairs kernel for the cloud), 0 if it wrote its outputs
+};
+
+// LDS: sorted targets float4 (x, y, z, index bits) [n], cell_start u16 [GR_CELLS + 1], scratch u32 [GR_CELLS] (counts,
+// later the queue of far queries)
+__device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud, const int dir, const int slice) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gr_lds[];
+    float4 *sorted = reinterpret_cast<float4 *>(gr_lds);
+    unsigned *counts = reinterpret_cast<unsigned *>(sorted + a.n);
+    unsigned short *cell_start = reinterpret_cast<unsigned short *>(counts + GR_CELLS);
+    __shared__ unsigned wave_tot[GR_THREADS / 64];
+    __shared__ int n_far;
+
+    const int n = a.n, t = threadIdx.x;
+    const int jbeg = (int)((long)n * slice / GR_QSPLIT), jend = (int)((long)n * (slice + 1) / GR_QSPLIT);   // this workgroup's queries
+    const float *A = (dir ? a.Q : a.P) + (size_t)cloud * n * 3;      // queries
+    const float *T = (dir ? a.P : a.Q) + (size_t)cloud * n * 3;      // targets
+    float *dist = (dir ? a.d2 : a.d1) + (size_t)cloud * n;
+    int *idx = (dir ? a.i2 : a.i1) + (size_t)cloud * n;
+
+    // ---- counting sort of the targets by cell ----
+    for (int c = t; c < GR_CELLS; c += GR_THREADS) counts[c] = 0;
+    if (t == 0) n_far = 0;
+    __syncthreads();
+    constexpr int PER = GR_MAX_N / GR_THREADS;                         // 8 points per thread at most
+    float tx[PER], ty[PER], tz[PER];
+    int tcell[PER], trank[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = t + k * GR_THREADS;
+        if (i < n) {
+            tx[k] = T[3 * i]; ty[k] = T[3 * i + 1]; tz[k] = T[3 * i + 2];
+            tcell[k] = (gr_cell1(tz[k]) * GR_G + gr_cell1(ty[k])) * GR_G + gr_cell1(tx[k]);
+            trank[k] = (int)atomicAdd(&counts[tcell[k]], 1u);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of counts[GR_CELLS] -> cell_start; thread t owns cells [8t, 8t + 8)
+        constexpr int CPT = GR_CELLS / GR_THREADS;
+        unsigned local[CPT], sum = 0;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { local[k] = counts[t * CPT + k]; sum += local[k]; }
+        unsigned incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned v = __shfl_up(incl, off);
+            if ((t & 63) >= off) incl += v;
+        }
+        if ((t & 63) == 63) wave_tot[t >> 6] = incl;
+        __syncthreads();
+        unsigned base = incl - sum;
+        for (int w = 0; w < (t >> 6); ++w) base += wave_tot[w];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { cell_start[t * CPT + k] = (unsigned short)base; base += local[k]; }
+        if (t == GR_THREADS - 1) cell_start[GR_CELLS] = (unsigned short)base;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = t + k * GR_THREADS;
+        if (i < n) sorted[cell_start[tcell[k]] + trank[k]] = make_float4(tx[k], ty[k], tz[k], __int_as_float(i));
+    }
+    __syncthreads();
+    unsigned *far_queue = counts;                                      // the counts are dead: queue of far queries
+
+    // ---- queries of this workgroup's slice: bound from the paired target, cells the ball touches ----
+    constexpr int QPT = (GR_MAX_N / GR_QSPLIT + GR_THREADS - 1) / GR_THREADS;          // queries per thread (<= 2)
+    float qx[QPT], qy[QPT], qz[QPT], qbest[QPT];
+    int qspan[QPT];                                    // x0 | x1 << 4 | y0 << 8 | y1 << 12 | z0 << 16 | z1 << 20, or -1 = far
+    int lf = 0, lc = 0;
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+        const int j = jbeg + t + k * GR_THREADS;
+        qspan[k] = 0;
+        if (j < jend) {
+            qx[k] = A[3 * j]; qy[k] = A[3 * j + 1]; qz[k] = A[3 * j + 2];
+            qbest[k] = gr_sqdist(T[3 * j], T[3 * j + 1], T[3 * j + 2], qx[k], qy[k], qz[k]);   // the paired target
+            const float r = sqrtf(qbest[k]) * 1.0001f + 1e-5f;
+            const int x0 = gr_cell1(qx[k] - r), x1 = gr_cell1(qx[k] + r), y0 = gr_cell1(qy[k] - r), y1 = gr_cell1(qy[k] + r);
+            const int z0 = gr_cell1(qz[k] - r), z1 = gr_cell1(qz[k] + r);
+            if (x1 - x0 >= GR_MAX_SPAN || y1 - y0 >= GR_MAX_SPAN || z1 - z0 >= GR_MAX_SPAN) { qspan[k] = -1; ++lf; }
+            else { qspan[k] = x0 | x1 << 4 | y0 << 8 | y1 << 12 | z0 << 16 | z1 << 20; lc += (x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1); }
+        }
+    }
+    if (a.need) {   // is the pairing good enough?  far queries cost a whole scan, near ones their cells: hand the cloud back
+        // to the all-pairs kernel if that would cost more (more than 1/16 far, or > 24 cells per query on average)
+        __shared__ int far_cnt, cell_cnt;
+        if (t == 0) { far_cnt = 0; cell_cnt = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lf += __shfl_xor(lf, off); lc += __shfl_xor(lc, off); }
+        if ((t & 63) == 0) { atomicAdd(&far_cnt, lf); atomicAdd(&cell_cnt, lc); }
+        __syncthreads();
+        const bool give_up = far_cnt * 16 > (jend - jbeg) || cell_cnt > 24 * (jend - jbeg);
+        if (t == 0) a.need[(2 * cloud + dir) * GR_QSPLIT + slice] = give_up ? 1 : 0;
+        if (give_up) return;
+    }
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+        const int j = jbeg + t + k * GR_THREADS;
+        if (j >= jend) continue;
+        if (qspan[k] < 0) {
+            far_queue[atomicAdd(&n_far, 1)] = (unsigned)j;               // (order of the queue does not matter)
+            continue;
+        }
+        const int x0 = qspan[k] & 15, x1 = (qspan[k] >> 4) & 15, y0 = (qspan[k] >> 8) & 15, y1 = (qspan[k] >> 12) & 15;
+        const int z0 = (qspan[k] >> 16) & 15, z1 = (qspan[k] >> 20) & 15;
+        float best = qbest[k];
+        int bestk = j;
+        for (int cz = z0; cz <= z1; ++cz)
+            for (int cy = y0; cy <= y1; ++cy) {
+                const int row = (cz * GR_G + cy) * GR_G;
+                const int s = cell_start[row + x0], e = cell_start[row + x1 + 1];   // cells x0..x1 are contiguous
+                for (int u = s; u < e; ++u) {
+                    const float4 p = sorted[u];
+                    const float d = gr_sqdist(p.x, p.y, p.z, qx[k], qy[k], qz[k]);
+                    const int kk = __float_as_int(p.w);
+                    if (d < best || (d == best && kk < bestk)) { best = d; bestk = kk; }
+                }
+            }
+        dist[j] = best;
+        idx[j] = bestk;
+    }
+    __syncthreads();
+    // ---- far queries: one wave per query, all targets ----
+    const int lane = t & 63, wave = t >> 6;
+    const int nf = n_far;
+    for (int f = wave; f < nf; f += GR_THREADS / 64) {
+        const int j = (int)far_queue[f];
+        const float qx = A[3 * j], qy = A[3 * j + 1], qz = A[3 * j + 2];
+        float best = INFINITY;
+        int bestk = INT_MAX;
+        // eight independent streams per lane keep eight LDS reads in flight (a single dependent chain pays the LDS
+        // latency 32 times per query); merged lexicographically afterwards
+        float bd[8];
+        int bk[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { bd[v] = INFINITY; bk[v] = INT_MAX; }
+        int u = lane;
+        for (; u + 7 * 64 < n; u += 8 * 64) {
+            float4 p[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) p[v] = sorted[u + 64 * v];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const float d = gr_sqdist(p[v].x, p[v].y, p[v].z, qx, qy, qz);
+                const int k = __float_as_int(p[v].w);
+                if (d < bd[v] || (d == bd[v] && k < bk[v])) { bd[v] = d; bk[v] = k; }
+            }
+        }
+        for (; u < n; u += 64) {
+            const float4 p = sorted[u];
+            const float d = gr_sqdist(p.x, p.y, p.z, qx, qy, qz);
+            const int k = __float_as_int(p.w);
+            if (d < bd[0] || (d == bd[0] && k < bk[0])) { bd[0] = d; bk[0] = k; }
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (bd[v] < best || (bd[v] == best && bk[v] < bestk)) { best = bd[v]; bestk = bk[v]; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float d2 = __shfl_xor(best, off);
+            const int k2 = __shfl_xor(bestk, off);
+            if (d2 < best || (d2 == best && k2 < bestk)) { best = d2; bestk = k2; }
+        }
+        if (lane == 0) { dist[j] = best; idx[j] = bestk; }
+    }
+}
+
+inline size_t chamfer_grid_lds_bytes(int n) { return sizeof(float4) * (size_t)n + sizeof(unsigned) * GR_CELLS + sizeof(unsigned short) * (GR_CELLS + 2); }
+
+}  // namespace geoadv

@@ -37,7 +37,15 @@ struct ChamferSymArgs {
     float *colpart;            // [pairs][clouds][tiles][m]
     float *rowpart_d;          // [pairs][clouds][csplit][n]   row minima per column slice
     int *rowpart_i;
+    const int *need[2];        // per pair: null = every cloud; else int[8 * clouds], cloud c is computed only if one of
+                               // its 8 flags is set (a workgroup of the paired grid search, chamfer_grid.hip, gave up)
 };
+
+__device__ __forceinline__ bool sym_needed(const int *need, int c) {
+    if (!need) return true;
+    const int4 lo = reinterpret_cast<const int4 *>(need)[2 * c], hi = reinterpret_cast<const int4 *>(need)[2 * c + 1];
+    return (lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0;
+}
 
 constexpr int CS_THREADS = 512;               // 8 waves share one row tile and split the columns 8 ways
 constexpr int CS_WAVES = 8;
@@ -63,6 +71,7 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     if (group >= a.clouds * a.pairs) return;
     const int tile = sub % a.tiles, cs = sub / a.tiles;    // row tile, column slice
     const int pi = group / a.clouds, c = group % a.clouds;
+    if (!sym_needed(a.need[pi], c)) return;
     const ChamferPair pr = a.pr[pi];
     const int n = a.n, m = a.m;
     const int q0 = tile * CS_ROWS;
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
     float *rx = lds, *ry = lds + tiles * CF_SEG, *rz = lds + 2 * tiles * CF_SEG;
     const int group = blockIdx.y;
     const int pi = group / a.clouds, c = group % a.clouds;
+    if (!sym_needed(a.need[pi], c)) return;
     const ChamferPair pr = a.pr[pi];
     const int n = a.n, m = a.m;
     const int cp = a.q_clouds > 0 ? (a.pair_base + c) / a.q_clouds : c;
@@ -279,15 +289,21 @@ size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
 
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
-                          int q_clouds, hipStream_t stream);
+                          int q_clouds, const int *need1, hipStream_t stream);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream) {
-    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, stream);
+    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, nullptr, stream);
+}
+// need1: per-cloud flags (int[8 * b], 16-byte aligned) restricting the SECOND pair to the clouds that still need the all-pairs kernel
+int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
+                              hipStream_t stream) {
+    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream);
 }
 
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
-                          int q_clouds, hipStream_t stream) {
+                          int q_clouds, const int *need1, hipStream_t stream) {
     if (b <= 0 || np <= 0) return GEOADV_OK;
     ChamferSymArgs a;
+    a.need[0] = nullptr; a.need[1] = need1;
     a.pair_base = pair_base; a.q_clouds = q_clouds;
     for (int i = 0; i < np; ++i) a.pr[i] = pairs[i];
     a.n = n; a.m = m; a.tiles = cdiv(n, CS_ROWS); a.clouds = b; a.pairs = np; a.colpart = workspace;
@@ -367,7 +383,7 @@ extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *
         float *ws = reinterpret_cast<float *>(i2 + (size_t)cnt * m);
         const ChamferPair pr{A, B, d1, i1, d2, i2};
         GA_REQUIRE(base <= 0x7fffffff, "chamfer_matrix: too many pairs");
-        if (int rc = launch_chamfer_sym_ex(&pr, 1, cnt, n, m, ws, (int)base, nb, st)) return rc;
+        if (int rc = launch_chamfer_sym_ex(&pr, 1, cnt, n, m, ws, (int)base, nb, nullptr, st)) return rc;
         chamfer_pair_mean_kernel<<<cnt, 256, 0, st>>>(n, m, d1, d2, out + base);
         GA_LAUNCH_CHECK();
     }

@@ -7,6 +7,7 @@
 // it runs on v_mfma_f32_32x32x2_f32 with the weights pre-packed in fragment order, each workgroup
 // streaming one 32-column block once (HBM/L2-bandwidth shaped, as SURVEY 8(a5) notes).
 #include "ae.h"
+#include "chamfer_grid.h"
 #include <limits.h>
 
 namespace geoadv {
@@ -106,9 +107,8 @@ __global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, i
 // FC2 forward: out[b][3N] = d2[b][256] @ V2 + c2.  grid = (column blocks of 32, row blocks of 32),
 // 256 threads = 4 waves splitting K = 256 four ways; partials are summed in a fixed order.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch, const float *d2, float *out) {
+__device__ __forceinline__ void decoder_fc2_block(const DeviceAE &A, int batch, const float *d2, float *out, const int cb, const int rb) {
     __shared__ float part[3][16][64];
-    const int cb = blockIdx.x, rb = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = lane >> 5, i = lane & 31;
     const PackedLayer &L = A.dec2_fwd;
@@ -152,6 +152,24 @@ __global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch,
             if (row < batch && col < ncols) out[(size_t)row * ncols + col] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch, const float *d2, float *out) {
+    decoder_fc2_block(A, batch, d2, out, blockIdx.x, blockIdx.y);
+}
+
+// The same launch with the workgroups of the attack's paired grid search nn_distance(adv, x) behind it
+// (chamfer_grid.h): that search needs nothing the decoder produces, and FC2 occupies 192 workgroups for 6 us.
+// 512 threads: FC2 blocks use the first four waves.
+__global__ __launch_bounds__(GR_THREADS) void decoder_fc2_and_grid_kernel(DeviceAE A, int batch, const float *d2, float *out, int cbs,
+                                                                        int rbs, GridArgs G) {
+    const int nfc = cbs * rbs;
+    if ((int)blockIdx.x < nfc) {
+        if (threadIdx.x < 256) decoder_fc2_block(A, batch, d2, out, blockIdx.x % cbs, blockIdx.x / cbs);
+        return;
+    }
+    const int g = blockIdx.x - nfc;                     // (cloud, direction, slice), slice fastest
+    grid_nn_block(G, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -253,6 +271,23 @@ int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int 
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
     latent_decode_kernel<<<b, LD_THREADS, 0, stream>>>(A, encoder_tiles(A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+// FC2 forward + the paired grid search of (P, Q) -> (d1, i1, d2, i2) with give-up flags `need` (chamfer_grid.hip)
+int launch_decoder_fc2_and_grid(const DeviceAE &A, int b, const float *d2v, float *recon, const float *P, const float *Q, float *gd1,
+                                int *gi1, float *gd2, int *gi2, int n, int *need, hipStream_t stream) {
+    if (b <= 0) return GEOADV_OK;
+    static bool attr = false;
+    if (!attr) {
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fc2_and_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)chamfer_grid_lds_bytes(GR_MAX_N)));
+        attr = true;
+    }
+    const int cbs = A.dec2_fwd.N / 32, rbs = cdiv(b, 32);
+    const GridArgs G{P, Q, gd1, gi1, gd2, gi2, n, need};
+    decoder_fc2_and_grid_kernel<<<cbs * rbs + b * 2 * GR_QSPLIT, GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(A, b, d2v, recon, cbs, rbs, G);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -53,6 +53,12 @@ int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2
 int geoadv_nn_distance_light(int b, int n, const float *xyz1, const float *xyz2,
                              float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
 
+/* Same results as geoadv_nn_distance for n == m <= 4096, from an exact grid search that uses xyz2[j] as the first guess
+ * for the neighbour of xyz1[j] (and vice versa): fast when the clouds are paired like the attack's (adv, x), never wrong
+ * otherwise (a query whose guess is poor is scanned against all points). */
+int geoadv_nn_distance_paired(int b, int n, const float *xyz1, const float *xyz2,
+                              float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
+
 /* NmDistanceGradKernelLauncher(b,n,xyz1,m,xyz2,grad_dist1,idx1,grad_dist2,idx2,grad_xyz1,grad_xyz2)
  * (tf_nndistance.cpp:208, kernel tf_nndistance_g.cu:132-157).  Outputs are fully overwritten
  * (the reference memsets them).  Unlike the reference GPU kernel (float atomicAdd) the

@@ -291,3 +291,31 @@ def test_masked_backward_equals_recomputing_backward(setup, monkeypatch, n):
         at.run(0, 6, 3)
         outs.append(at.peek()["pert"].clone())
     assert outs[0].abs().max() > 0 and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("lr,n", [(0.01, N), (0.3, N), (0.01, 200)])
+def test_pruned_source_distance_equals_all_pairs(setup, monkeypatch, lr, n):
+    """nn_distance(adv, x) through the paired grid search (default) vs the all-pairs kernel (GEOADV_CHAMFER_PRUNE=0): the
+    whole loop must agree bit for bit -- also when a huge learning rate scatters the points so that clouds hand themselves
+    back to the all-pairs kernel, and for a point count that is not a multiple of anything."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    w = W.randomized_weights(n)
+    ae = PointNetAE(w, n)
+    b = 3
+    x, gt = _clouds(81, b, n)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GEOADV_CHAMFER_PRUNE", flag)
+        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=12, num_iterations_thresh=3,
+                                              learning_rate=lr), ae=ae)
+        at.set_inputs(x, gt, None, 1.0)
+        at.init_pert(None, reset_optimizer=True)
+        at.run(0, 12, 3)
+        p = at.peek()
+        outs.append((p["pert"].clone(), p["idx_a1"].clone(), p["idx_a2"].clone()))
+    assert outs[0][0].abs().max() > 0
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)

@@ -143,3 +143,41 @@ def test_light_kernel_equals_default(b, n):
     got = ops.nn_distance_light(x, y)
     for a, c in zip(ref, got):
         assert torch.equal(a, c)
+
+
+def _paired_case(kind, b, n, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5))
+    if kind == "attack":              # most points barely move, a few fly far (what the attack's pert looks like)
+        pert = (1e-3 * rng.standard_normal((b, n, 3))).astype(np.float32)
+        far = rng.random((b, n)) < 0.02
+        pert[far] += (rng.standard_normal((int(far.sum()), 3)) * 0.8).astype(np.float32)
+        adv = x + pert
+    elif kind == "zero":              # adv == x exactly: every distance 0, ties between duplicated points
+        x[:, n // 2:] = x[:, :n - n // 2]
+        adv = x.copy()
+    elif kind == "unpaired":          # no relation at all: every query is a "far" query
+        adv = (rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5))
+    elif kind == "outside":           # clouds well outside the grid's box, duplicated targets
+        x = x * np.float32(3.0) + np.float32(0.7)
+        adv = x + (0.05 * rng.standard_normal((b, n, 3))).astype(np.float32)
+        if n > 1:
+            x[:, 1] = x[:, 0]
+    else:                             # medium moves: balls spanning several cells
+        adv = x + (0.05 * rng.standard_normal((b, n, 3))).astype(np.float32)
+    return adv.astype(np.float32), x
+
+
+@pytest.mark.parametrize("kind", ["attack", "zero", "unpaired", "outside", "medium"])
+@pytest.mark.parametrize("b,n", [(3, 2048), (2, 1000), (2, 64), (1, 1), (1, 4096)])
+def test_paired_grid_search_equals_default(kind, b, n):
+    """Exact grid search seeded with the pairing (the attack's nn_distance(adv, x)): dist and idx bit for bit, whatever
+    the data -- good pairing, none at all, exact ties, points outside the grid."""
+    import torch
+    from geometric_adv_amd import ops
+    adv, x = _paired_case(kind, b, n, 100 + n)
+    adv, x = torch.as_tensor(adv).cuda(), torch.as_tensor(x).cuda()
+    ref = ops.nn_distance(adv, x)
+    got = ops.nn_distance_paired(adv, x)
+    for a, c in zip(ref, got):
+        assert torch.equal(a, c)
