@@ -30,8 +30,9 @@ int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, in
 int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need,
                         hipStream_t stream);
 bool chamfer_grid_supports(int n, int m);
-int launch_decoder_fc2_and_grid(const DeviceAE &A, int b, const float *d2v, float *recon, const float *P, const float *Q, float *gd1,
-                                int *gi1, float *gd2, int *gi2, int n, int *need, hipStream_t stream);
+int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z, int *crit,
+                                  int *zcnt, int *dense, float *d1, float *d2, const float *P, const float *Q, float *gd1, int *gi1,
+                                  float *gd2, int *gi2, int n, int *need, hipStream_t stream);
 struct ForwardScratch {
     float *pmax; int *parg; int *pcnt; float *z; int *crit; int *zcnt; int *dense; float *d1, *d2; size_t bytes;
 };
@@ -467,12 +468,13 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     }
     {
         ProfScope ps(at, GEOADV_PROF_DECODER_FWD, st);
-        if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
-                                          at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
-        if (pruned) {   // the grid search rides in the FC2 launch (it needs nothing from the decoder)
-            if (int rc = launch_decoder_fc2_and_grid(A, B, at->fs.d2, at->recon, at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, n,
-                                                     at->need_adv, st)) return rc;
-        } else if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
+        if (pruned) {   // the grid search rides in the latent_decode launch (it needs nothing from the network)
+            if (int rc = launch_latent_decode_and_grid(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
+                                                       at->fs.dense, at->fs.d1, at->fs.d2, at->adv, at->x, at->a1, at->ia1, at->a2,
+                                                       at->ia2, n, at->need_adv, st)) return rc;
+        } else if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
+                                                 at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
+        if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
     }
     {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);

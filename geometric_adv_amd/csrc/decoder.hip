@@ -43,16 +43,16 @@ __device__ __forceinline__ float fc256_split4(const float *in_lds, const float *
     return ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];     // meaningful for t < 256
 }
 
-__global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
-                                                                   const int *pcnt, float *z, int *crit, int *zcnt,
-                                                                   int *dense, float *d1, float *d2) {
+__device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles, const float *pmax, const int *parg,
+                                                    const int *pcnt, float *z, int *crit, int *zcnt,
+                                                    int *dense, float *d1, float *d2, const int b) {
     __shared__ float gm[8][128];
     __shared__ int ga[8][128], gk[8][128];
     __shared__ float zs[128];
     __shared__ float hs[256];
     __shared__ float part[4][256];
     __shared__ int tie;
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     if (t == 0) tie = 0;
     {   // 8 contiguous tile groups x 128 channels; ascending tiles inside a group, groups merged in order
         const int c = t & 127, g = t >> 7;
@@ -101,6 +101,27 @@ __global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, i
         const float s = fc256_split4<256>(hs, A.v1, part);
         if (t < 256) d2[(size_t)b * 256 + t] = fmaxf(s + A.c1[t], 0.f);
     }
+}
+
+__global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
+                                                                   const int *pcnt, float *z, int *crit, int *zcnt,
+                                                                   int *dense, float *d1, float *d2) {
+    latent_decode_block(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
+}
+
+// The same launch with the workgroups of the attack's paired grid search nn_distance(adv, x) behind it (chamfer_grid.h):
+// that search needs nothing the network produces, and this launch keeps 32 workgroups busy for 9 us.  The grid blocks
+// use the first eight of the sixteen waves.
+__global__ __launch_bounds__(LD_THREADS) void latent_decode_and_grid_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
+                                                                            const int *pcnt, float *z, int *crit, int *zcnt, int *dense,
+                                                                            float *d1, float *d2, int batch, GridArgs G) {
+    if ((int)blockIdx.x < batch) {
+        latent_decode_block(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
+        return;
+    }
+    if (threadIdx.x >= GR_THREADS) return;
+    const int g = blockIdx.x - batch;                   // (cloud, direction, slice), slice fastest
+    grid_nn_block(G, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -156,20 +177,6 @@ __device__ __forceinline__ void decoder_fc2_block(const DeviceAE &A, int batch, 
 
 __global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch, const float *d2, float *out) {
     decoder_fc2_block(A, batch, d2, out, blockIdx.x, blockIdx.y);
-}
-
-// The same launch with the workgroups of the attack's paired grid search nn_distance(adv, x) behind it
-// (chamfer_grid.h): that search needs nothing the decoder produces, and FC2 occupies 192 workgroups for 6 us.
-// 512 threads: FC2 blocks use the first four waves.
-__global__ __launch_bounds__(GR_THREADS) void decoder_fc2_and_grid_kernel(DeviceAE A, int batch, const float *d2, float *out, int cbs,
-                                                                        int rbs, GridArgs G) {
-    const int nfc = cbs * rbs;
-    if ((int)blockIdx.x < nfc) {
-        if (threadIdx.x < 256) decoder_fc2_block(A, batch, d2, out, blockIdx.x % cbs, blockIdx.x / cbs);
-        return;
-    }
-    const int g = blockIdx.x - nfc;                     // (cloud, direction, slice), slice fastest
-    grid_nn_block(G, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -275,19 +282,20 @@ int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int 
     return GEOADV_OK;
 }
 
-// FC2 forward + the paired grid search of (P, Q) -> (d1, i1, d2, i2) with give-up flags `need` (chamfer_grid.hip)
-int launch_decoder_fc2_and_grid(const DeviceAE &A, int b, const float *d2v, float *recon, const float *P, const float *Q, float *gd1,
-                                int *gi1, float *gd2, int *gi2, int n, int *need, hipStream_t stream) {
+// latent_decode + the paired grid search of (P, Q) -> (gd1, gi1, gd2, gi2) with give-up flags `need` (chamfer_grid.hip)
+int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z, int *crit,
+                                  int *zcnt, int *dense, float *d1, float *d2, const float *P, const float *Q, float *gd1, int *gi1,
+                                  float *gd2, int *gi2, int n, int *need, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
     static bool attr = false;
     if (!attr) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_fc2_and_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(latent_decode_and_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)chamfer_grid_lds_bytes(GR_MAX_N)));
         attr = true;
     }
-    const int cbs = A.dec2_fwd.N / 32, rbs = cdiv(b, 32);
     const GridArgs G{P, Q, gd1, gi1, gd2, gi2, n, need};
-    decoder_fc2_and_grid_kernel<<<cbs * rbs + b * 2 * GR_QSPLIT, GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(A, b, d2v, recon, cbs, rbs, G);
+    latent_decode_and_grid_kernel<<<b + b * 2 * GR_QSPLIT, LD_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
+        A, encoder_tiles(A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
