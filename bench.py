@@ -42,18 +42,20 @@ def _encoder_entry(d):
 
 
 def chamfer_valu(avg_ms):
-    """VALU issue rate of the two Chamfer kernels of one step: wave-level VALU instructions from the committed PMC pass
-    (SQ_INSTS_VALU, profiles/r01_v5_pmc_sq.json) x 64 lanes / the measured time, beside two yardsticks measured on the box: geoadv_microbench
-    (profiles/r01_probe_valu_chamfer_v1.json: 52.1 T lane-instr/s for an alternating v_mul/v_add stream, 32 T for a single
-    instruction type) and the best rate a real kernel sustains (the two-scan Chamfer at B=256: 63 T)."""
+    """VALU issue rate of the all-pairs Chamfer kernels of one step: wave-level VALU instructions from the committed PMC
+    pass (SQ_INSTS_VALU, profiles/r01_v9_pmc_sq.json) x 64 lanes / the measured time, beside two yardsticks measured on the
+    box: geoadv_microbench (profiles/r01_probe_valu_chamfer_v1.json: 52.1 T lane-instr/s for an alternating v_mul/v_add
+    stream, 32 T for a single instruction type) and the best rate a real kernel sustains (the two-scan Chamfer at B=256: 63 T)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_sq.json")))
-        insts = d["chamfer_sym_kernel"]["SQ_INSTS_VALU"] + d["chamfer_sym_finish_kernel"]["SQ_INSTS_VALU"]
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_v9_pmc_sq.json")))
+        insts = d["geoadv::chamfer_sym_kernel"]["SQ_INSTS_VALU"]["mean"] + d["geoadv::chamfer_sym_finish_kernel"]["SQ_INSTS_VALU"]["mean"]
+        grid = d["geoadv::latent_decode_and_grid_kernel"]["SQ_INSTS_VALU"]["mean"] - d["geoadv::latent_decode_kernel"]["SQ_INSTS_VALU"]["mean"]
         ceil = json.load(open(os.path.join(ROOT, "profiles", "r01_probe_valu_chamfer_v1.json")))["valu_mul+add"]["Tinstr_lane_per_s"]
         rate = insts * 64.0 / (avg_ms * 1e-3) / 1e12
         return {"T_lane_instr_per_s": rate, "microbench_mul_add_T_lane_instr_per_s": ceil,
                 "best_sustained_by_a_kernel_T_lane_instr_per_s": 63.0,      # two-scan Chamfer at B=256 (7.0 T pair-evals/s x 9)
-                "frac_of_best_sustained": rate / 63.0, "wave_instr_per_step_pmc": insts}
+                "frac_of_best_sustained": rate / 63.0, "wave_instr_per_step_pmc": insts,
+                "paired_grid_search_wave_instr_per_step_pmc": grid}
     except Exception:               # pragma: no cover
         return None
 
@@ -256,8 +258,10 @@ def main():
     traffic, traffic_note = pmc_traffic_bytes()
     ch_n, ch_ms = prof["chamfer_fwd"]
     ch_avg_ms = ch_ms / max(ch_n, 1)
-    ch_pairs = 4.0 * B * N * N                                  # 2 problems x 2 directions of nn_distance per step
-    ch_bytes = 2 * 20.0 * B * (N + N)                           # 20*B*(N+M) per nn_distance call
+    pruned = os.environ.get("GEOADV_CHAMFER_PRUNE", "1") != "0"
+    # all-pairs kernels: nn_distance(recon, target) always; nn_distance(adv, x) too unless the paired grid search has it
+    ch_pairs = (2.0 if pruned else 4.0) * B * N * N             # problems x 2 directions per step
+    ch_bytes = (1 if pruned else 2) * 20.0 * B * (N + N)        # 20*B*(N+M) per nn_distance call
     out = {
         "metric": "attack-iterations/sec (B=32, N=2048) at 1/2/4/8 GPUs; Chamfer rel-err vs ref",
         "value": world * K / dt, "unit": "attack-iterations/sec", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -272,8 +276,11 @@ def main():
                      "unit": "TFLOP/s", "frac": enc_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                      "mfma_pipe_utilisation_pmc": pmc_mfma_util(),
                      "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop},
-        "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel (both directions of both "
-                                                         "problems from one distance evaluation per pair)", "avg_launch_ms": ch_avg_ms,
+        "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel: nn_distance(recon, target), both "
+                                                         "directions from one distance evaluation per pair" +
+                                                         ("; nn_distance(adv, x) is answered exactly by the paired grid search inside the "
+                                                          "latent_decode launch (decoder_fwd class)" if pruned else " (and nn_distance(adv, x))"),
+                             "avg_launch_ms": ch_avg_ms,
                              "launches_timed": ch_n, "achieved_Tpair_per_s": ch_pairs / (ch_avg_ms * 1e-3) / 1e12,
                              "valu": chamfer_valu(ch_avg_ms),
                              "algorithmic_bytes_per_launch": ch_bytes,
