@@ -21,6 +21,7 @@ def lib():
             raise GeoAdvError(
                 "libgeoadv.so not built: %s is missing. Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C geometric_adv_amd/csrc` (needs hipcc, --offload-arch=gfx950)." % LIB_PATH)
+        import torch  # noqa: F401  -- first: libgeoadv.so must bind to the HIP runtime torch ships, not to a second copy
         _lib = C.CDLL(LIB_PATH)
         _lib.geoadv_last_error.restype = C.c_char_p
         for name in ("geoadv_approx_match_temp_floats", "geoadv_ae_workspace_bytes", "geoadv_chamfer_matrix_workspace_floats"):

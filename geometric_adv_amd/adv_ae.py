@@ -141,8 +141,9 @@ class AdvAE:
                        _lib.stream_handle()), "attack_peek")
         return out
 
-    def profile(self, classes):
-        """classes: True/False for all/none, or an iterable of PROF_NAMES to time."""
+    def profile(self, classes, stride=1):
+        """classes: True/False for all/none, or an iterable of PROF_NAMES to time; stride: time every stride-th launch."""
+        _lib.check(_lib.lib().geoadv_attack_profile_stride(self._h, int(stride)), "attack_profile_stride")
         if classes is True:
             mask = -1
         elif not classes:

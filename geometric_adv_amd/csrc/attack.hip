@@ -392,6 +392,8 @@ struct geoadv_attack {
     hipEvent_t ev_fork, ev_scan, ev_loss, ev_gdist;
     // profiling
     unsigned prof_mask;
+    int prof_stride;                 // time every prof_stride-th launch of a selected class (1 = every launch)
+    unsigned prof_seen[GEOADV_PROF_COUNT];
     std::vector<hipEvent_t> ev;      // pool
     int ev_used;
     struct Mark { int which, e0, e1; };
@@ -423,6 +425,7 @@ int prof_flush(geoadv_attack *at) {
 struct ProfScope {
     geoadv_attack *at; int which; int e0; hipStream_t st; bool on;
     ProfScope(geoadv_attack *a, int w, hipStream_t s) : at(a), which(w), e0(-1), st(s), on((a->prof_mask >> w) & 1u) {
+        if (on && at->prof_stride > 1) on = (at->prof_seen[w]++ % (unsigned)at->prof_stride) == 0;
         if (!on) return;
         if (at->ev_used + 2 > (int)at->ev.size()) prof_flush(at);
         e0 = at->ev_used++;
@@ -694,7 +697,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->cgrad_done = false;
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
     at->fwd_valid = false; at->adv_valid = false;
-    at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr;
+    at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr; at->prof_stride = 1;
+    for (int i = 0; i < GEOADV_PROF_COUNT; ++i) at->prof_seen[i] = 0;
     {
         // GEOADV_OVERLAP (experiment switch): 0 (default) = single stream; 2 = the source-distance gradient runs on a
         // second stream beside the decoder/encoder backward; 3 = Chamfer(adv, x) runs beside the encoder forward; 1 = both.
@@ -842,6 +846,12 @@ extern "C" int geoadv_attack_profile(geoadv_attack *at, int enable) {
     if (at->prof_mask) { if (int rc = prof_flush(at)) return rc; }
     at->prof_mask = (unsigned)enable;
     if (enable) for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_profile_stride(geoadv_attack *at, int stride) {
+    GA_REQUIRE(at && stride >= 1, "attack_profile_stride: bad arguments");
+    at->prof_stride = stride;
     return GEOADV_OK;
 }
 

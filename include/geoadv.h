@@ -284,6 +284,9 @@ int geoadv_trainer_export(geoadv_trainer *t, const geoadv_ae_weights *dst, void 
 #define GEOADV_PROF_COUNT       7
 int geoadv_attack_profile(geoadv_attack *at, int enable);
 int geoadv_attack_profile_read(geoadv_attack *at, int which, int *launches, float *total_ms);
+/* Time only every stride-th launch of each selected class (a pair of events between two dependent kernels costs ~1 us of
+ * GPU time; sampling keeps a timed region honest).  Default 1. */
+int geoadv_attack_profile_stride(geoadv_attack *at, int stride);
 
 /* Diagnostic build of the encoder forward with s_memtime stamps at its phase boundaries (tools/encoder_phases.py);
  * stamps: device buffer of b * ceil(n/64) * 12 uint64.  Not part of the reference's surface. */

@@ -21,6 +21,7 @@ def test_header_declares_the_boundary():
 
 
 def test_library_exports_every_declared_symbol():
+    import torch  # noqa: F401  -- before the library, so that both bind to one HIP runtime if GPU tests share the process
     from geometric_adv_amd import _lib
     import __graft_entry__
     if not os.path.exists(_lib.LIB_PATH):
