@@ -715,6 +715,139 @@ __global__ __launch_bounds__(TR_THREADS, ROWS == 32 ? 4 : 2) void train_bwd_kern
     }
 }
 
+// The same backward layer as TWO kinds of workgroups in one launch, so that a CU holds one of each and their phases overlap
+// (in train_bwd_kernel a single 115 KB workgroup per CU runs tile loads, the dW GEMM, the dy GEMM and the epilogue strictly
+// one after the other):
+//   blocks [0, nw)      : weight gradient only -- persistent over 32-row tiles, dW accumulated in registers (64 VGPRs);
+//   blocks [nw, nw + T) : data gradient only -- one 64-row tile each: da @ W^T, ReLU mask, dy_{i-1} and its BN sums.
+// Both form da = f(dy, a) on load, i.e. dy_i and a_i are read twice (+ 2 * 4 * R * COUT bytes of HBM traffic per layer); that
+// buys two resident workgroups per CU (<= 128 VGPRs, <= 74 KB LDS each) and a shared MFMA pipe that rarely idles.
+template <int CIN, int COUT> struct SplitShape {
+    using W32 = BwdShape<CIN, COUT, 32>;
+    using D64 = BwdShape<CIN, COUT, 64>;
+    static constexpr int W_FLOATS = W32::DA_FLOATS + W32::H_FLOATS + W32::CC_FLOATS;
+    static constexpr int D_FLOATS = D64::DA_FLOATS + D64::SCRATCH_FLOATS + D64::CC_FLOATS + D64::RED_FLOATS;
+    static constexpr size_t lds_bytes = sizeof(float) * (W_FLOATS > D_FLOATS ? W_FLOATS : D_FLOATS);
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs A, int nw) {
+    extern __shared__ __align__(16) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hh = lane >> 5, li = lane & 31;
+    if ((int)blockIdx.x < nw) {
+        // ---------------- weight-gradient workgroup ----------------
+        using S = BwdShape<CIN, COUT, 32>;
+        constexpr int ROWS = 32;
+        float *da = lds, *ht = da + S::DA_FLOATS, *cc = ht + S::H_FLOATS;
+        for (int e = threadIdx.x; e < COUT; e += TR_THREADS) {
+            cc[e] = A.mean[e]; cc[COUT + e] = A.inv_std[e]; cc[2 * COUT + e] = A.gamma[e] * A.inv_std[e];
+            cc[3 * COUT + e] = A.m1[e]; cc[4 * COUT + e] = A.m2[e];
+        }
+        const int mb0 = (wave / S::WCOLS) * S::MBW, nb0 = (wave % S::WCOLS) * S::NBW;
+        f32x16 dw[S::MBW][S::NBW] = {};
+        float hs[S::MBW], hsh[S::MBW];
+#pragma unroll
+        for (int m = 0; m < S::MBW; ++m) { hs[m] = A.pscale[(mb0 + m) * 32 + li]; hsh[m] = A.pshift[(mb0 + m) * 32 + li]; }
+        float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        const int tiles32 = A.tiles * 2;
+        for (int tile = blockIdx.x; tile < tiles32; tile += nw) {
+            const size_t row0 = (size_t)tile * ROWS;
+            load_da_tile<COUT, ROWS>(A, row0, cc, da, dbacc);
+            load_raw_tile<CIN, ROWS>(A.aprev, row0, ht);
+            __syncthreads();
+#pragma unroll 8
+            for (int kk = 0; kk < ROWS / 2; ++kk) {
+                const int row = 2 * kk + hh;
+                float av[S::MBW], bv[S::NBW];
+#pragma unroll
+                for (int m = 0; m < S::MBW; ++m) av[m] = fmaxf(fmaf(ht[row * (CIN + 4) + (mb0 + m) * 32 + li], hs[m], hsh[m]), 0.f);
+#pragma unroll
+                for (int n = 0; n < S::NBW; ++n) bv[n] = da[row * (COUT + 4) + (nb0 + n) * 32 + li];
+#pragma unroll
+                for (int m = 0; m < S::MBW; ++m)
+#pragma unroll
+                    for (int n = 0; n < S::NBW; ++n)
+                        dw[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], dw[m][n], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        float *dst = A.dw_partial + (size_t)blockIdx.x * CIN * COUT;
+#pragma unroll
+        for (int m = 0; m < S::MBW; ++m)
+#pragma unroll
+            for (int n = 0; n < S::NBW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[(size_t)((mb0 + m) * 32 + acc_row(r, hh)) * COUT + (nb0 + n) * 32 + li] = dw[m][n][r];
+        constexpr int Q = COUT / 4, G = TR_THREADS / Q;
+        float *dbred = da;
+        *reinterpret_cast<float4 *>(dbred + (threadIdx.x / Q) * COUT + 4 * (threadIdx.x % Q)) = dbacc;
+        __syncthreads();
+        if (threadIdx.x < COUT) {
+            float s = dbred[threadIdx.x];
+#pragma unroll
+            for (int g = 1; g < G; ++g) s += dbred[g * COUT + threadIdx.x];
+            A.db_partial[(size_t)blockIdx.x * COUT + threadIdx.x] = s;
+        }
+        return;
+    }
+    // ---------------- data-gradient workgroup: one 64-row tile ----------------
+    using S = BwdShape<CIN, COUT, 64>;
+    constexpr int ROWS = 64;
+    float *da = lds, *scratch = da + S::DA_FLOATS, *cc = scratch + S::SCRATCH_FLOATS, *red = cc + S::CC_FLOATS;
+    for (int e = threadIdx.x; e < COUT; e += TR_THREADS) {
+        cc[e] = A.mean[e]; cc[COUT + e] = A.inv_std[e]; cc[2 * COUT + e] = A.gamma[e] * A.inv_std[e];
+        cc[3 * COUT + e] = A.m1[e]; cc[4 * COUT + e] = A.m2[e];
+    }
+    const int ocol = layer_gemm_lane_col<ROWS, CIN>();
+    const float ps = A.pscale[ocol], pt = A.pshift[ocol], pm = A.pmean[ocol], pis = A.pinv_std[ocol];
+    const int tile = blockIdx.x - nw;
+    const size_t row0 = (size_t)tile * ROWS;
+    float4 unused = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    load_da_tile<COUT, ROWS>(A, row0, cc, da, unused);
+    __syncthreads();
+    float q1 = 0.f, q2 = 0.f;
+    int rb_seen = 0;
+    bool ran = false;
+    constexpr int NV = (CIN / 32) * (ROWS / 32) > 8 ? 32 : 16;
+    float vals[NV], apv[NV];
+    int rows[NV];
+    int cnt = 0;
+    layer_gemm<ROWS, CIN, 0>(da, COUT + 4, A.WT, scratch, [&](int row, int c, float v) {
+        vals[cnt] = v; rows[cnt] = row; ++cnt;
+        rb_seen = row >> 5;
+        ran = true;
+    });
+    if (ran) {   // all a_{i-1} values of this lane first (L2: the weight-gradient workgroups stream the same rows), then the stores
+#pragma unroll
+        for (int j = 0; j < NV; ++j) apv[j] = A.aprev[(row0 + rows[j]) * CIN + ocol];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float dyv = fmaf(apv[j], ps, pt) > 0.f ? vals[j] : 0.f;
+            A.dy_out[(row0 + rows[j]) * CIN + ocol] = dyv;
+            q1 += dyv;
+            q2 = fmaf(dyv, (apv[j] - pm) * pis, q2);
+        }
+    }
+    q1 += __shfl_xor(q1, 32);
+    q2 += __shfl_xor(q2, 32);
+    constexpr bool WHOLE = (CIN / 32) * 2 > 8;
+    float2 *qred = reinterpret_cast<float2 *>(red);
+    if (WHOLE) {
+        if (ran && hh == 0) A.qsum_out[(size_t)tile * CIN + ocol] = make_float2(q1, q2);
+    } else {
+        if (ran && hh == 0) qred[rb_seen * CIN + ocol] = make_float2(q1, q2);
+        __syncthreads();
+        if (threadIdx.x < CIN) {
+            const float2 p = qred[threadIdx.x], q = qred[CIN + threadIdx.x];
+            A.qsum_out[(size_t)tile * CIN + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
+        }
+    }
+}
+
 // layer 0: dW0[k][c] = sum_r x[r][k] * da0[r][c], db0[c] = sum_r da0[r][c]; persistent, thread = (column, 8-row group)
 __global__ __launch_bounds__(TR_THREADS) void train_bwd0_kernel(BwdArgs A) {
     __shared__ float pts[TR_ROWS * 3];
@@ -1065,14 +1198,22 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
     static int skip = -1;
     if (skip < 0) { const char *e = getenv("GEOADV_TRAIN_SKIP"); skip = e ? atoi(e) : 0; }
     a.debug_skip = skip;
+    static int split = -1;
+    if (split < 0) { const char *e = getenv("GEOADV_TRAIN_SPLIT"); split = e ? atoi(e) : 1; }
     static bool attr = false;
     if (!attr) {
         GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_kernel<CIN, COUT, BWD_ROWS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_split_kernel<CIN, COUT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitShape<CIN, COUT>::lds_bytes));
         attr = true;
     }
     const int grid = a.tiles < t->grid_bwd ? a.tiles : t->grid_bwd;
-    train_bwd_kernel<CIN, COUT, BWD_ROWS><<<grid, TR_THREADS, S::lds_bytes, st>>>(a);
+    if (split && BWD_ROWS == 64) {
+        train_bwd_split_kernel<CIN, COUT><<<grid + a.tiles, TR_THREADS, SplitShape<CIN, COUT>::lds_bytes, st>>>(a, grid);
+    } else {
+        train_bwd_kernel<CIN, COUT, BWD_ROWS><<<grid, TR_THREADS, S::lds_bytes, st>>>(a);
+    }
     GA_LAUNCH_CHECK();
     return GEOADV_OK;                                   // its partials are reduced by post_layer (next launch)
 }
