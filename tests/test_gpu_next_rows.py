@@ -160,3 +160,47 @@ def test_run_attack_cli_end_to_end(tmp_path):
     m2, a2, r2 = AdvAE("adversary", conf).attack(src, tl, tgt, tr.reshape(-1), conf)
     assert np.array_equal(m2, np.load(out / "chair" / "adversarial_metrics.npy"))
     assert np.array_equal(a2, np.load(out / "chair" / "adversarial_pc_input.npy"))
+
+
+def test_train_checkpoint_attack_defend_pipeline(tmp_path):
+    """The widened rows end to end, the way the reference's scripts chain them: train the victim (f-4) on synthetic
+    shapes -> models.ckpt-N in TF V2 format (f-2) -> restore it by prefix in the attack class (a12) -> adversarial
+    clouds -> off-surface defense (a16/a17) -> reconstruct.  Training must make reconstructions better than at
+    initialisation, and the attack must pull the reconstruction of the source towards the target."""
+    import torch
+    from geometric_adv_amd import tf_checkpoint, defense
+    from geometric_adv_amd.trainer import PointNetAETrainer, initial_weights
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    n, b = 256, 8
+    rng = np.random.default_rng(0)
+
+    def shapes(count):                                   # points on randomly scaled ellipsoid shells and boxes
+        u = rng.standard_normal((count, n, 3)).astype(np.float32)
+        u /= np.linalg.norm(u, axis=2, keepdims=True)
+        scale = rng.uniform(0.15, 0.45, size=(count, 1, 3)).astype(np.float32)
+        box = rng.random((count, 1, 1)) < 0.5
+        cube = np.clip(u * 3.0, -1.0, 1.0)
+        return (np.where(box, cube, u) * scale).astype(np.float32)
+
+    data = shapes(64)
+    tr = PointNetAETrainer(initial_weights(n, seed=2), n, batch_size=b, learning_rate=0.002)
+    first = tr._single_epoch_train(data)[0]
+    for _ in range(14):
+        last = tr._single_epoch_train(data)[0]
+    assert last < 0.5 * first
+    prefix = str(tmp_path / "models.ckpt-15")
+    tf_checkpoint.write_checkpoint(prefix, tr.export_weights())
+
+    ae = PointNetAE(prefix, n)                           # restore_ae_model by checkpoint prefix, TF-free
+    src, tgt = shapes(b), shapes(b)
+    conf = Configuration(batch_size=b, n_points=n, weights=prefix, dist_weight_list=[1.0], num_iterations=60,
+                         num_iterations_thresh=40, learning_rate=0.01)
+    at = AdvAE("adversary", conf, ae=ae)
+    ref = ae.get_loss_per_pc(tgt)
+    metrics, adv, recon = at.attack(src, ae.transform(tgt), tgt, ref, conf)
+    before = ae.get_loss_per_pc(src, tgt)                # chamfer(recon(source), target) without the attack
+    assert np.isfinite(metrics).all() and (metrics[0, :, 4] < before).all()
+    out = defense.defend_surface(ae, adv[0], src)
+    assert out["defended_pc"].shape == (b, n, 3) and np.isfinite(out["defended_recon"]).all()
+    assert np.isfinite(out["recon_error_vs_source"]).all()
