@@ -27,12 +27,13 @@ int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, fl
 int launch_chamfer_light(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, hipStream_t stream);
 int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
                               hipStream_t stream);
-int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need,
+int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call,
                         hipStream_t stream);
 bool chamfer_grid_supports(int n, int m);
 int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z, int *crit,
                                   int *zcnt, int *dense, float *d1, float *d2, const float *P, const float *Q, float *gd1, int *gi1,
-                                  float *gd2, int *gi2, int n, int *need, hipStream_t stream);
+                                  float *gd2, int *gi2, int n, int *need, int call, const float *box, hipStream_t stream);
+int launch_chamfer_grid_box(const float *Q, int b, int n, float *box, hipStream_t stream);
 struct ForwardScratch {
     float *pmax; int *parg; int *pcnt; float *z; int *crit; int *zcnt; int *dense; float *d1, *d2; size_t bytes;
 };
@@ -379,6 +380,8 @@ struct geoadv_attack {
     bool cgrad_done;                 // the cached forward's loss launch also produced the Chamfer gradients
     bool chamfer_prune;              // nn_distance(adv, x) through the paired grid search (GEOADV_CHAMFER_PRUNE, default on)
     int *need_adv;                   // [8 B] clouds the grid search handed back to the all-pairs kernel
+    float *x_box;                    // [B][6] bounding boxes of the source clouds (the grid of the paired search)
+    int grid_calls;                  // running number of grid-search launches (paces the retries of clouds that gave up)
     unsigned *masks;                 // [B][n][mask words] ReLU masks of the cached forward, or null (backward recomputes)
     bool chamfer_sym;
     // host state
@@ -474,7 +477,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         if (pruned) {   // the grid search rides in the latent_decode launch (it needs nothing from the network)
             if (int rc = launch_latent_decode_and_grid(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
                                                        at->fs.dense, at->fs.d1, at->fs.d2, at->adv, at->x, at->a1, at->ia1, at->a2,
-                                                       at->ia2, n, at->need_adv, st)) return rc;
+                                                       at->ia2, n, at->need_adv, at->grid_calls++, at->x_box, st)) return rc;
         } else if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
                                                  at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
         if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
@@ -654,6 +657,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     const size_t mask_words = (mask_env && mask_env[0] == '0') ? 0 : (size_t)encoder_mask_words() * bn;   // ReLU masks of the cached forward
     need(4 * mask_words);
     need(4 * 8 * B);                                      // need_adv
+    need(4 * 6 * B);                                      // x_box
     const bool emd = cfg->emd_weight > 0.f;
     const size_t emd_temp_f = emd ? geoadv_approx_match_temp_floats(at->B, at->n, at->n) : 0;
     if (emd) { need(4 * B * n * n); need(4 * emd_temp_f + 8); need(4 * B); need(4 * bn3); need(4 * bn3); }
@@ -681,6 +685,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->sym_ws = F(4 * sym_floats);
     at->masks = mask_words ? reinterpret_cast<unsigned *>(take(4 * mask_words)) : nullptr;
     at->need_adv = I(4 * 8 * B);
+    at->grid_calls = 0;
+    at->x_box = F(4 * 6 * B);
     {
         const char *e = getenv("GEOADV_CHAMFER_PRUNE");
         at->chamfer_prune = !(e && e[0] == '0');
@@ -761,6 +767,8 @@ extern "C" int geoadv_attack_set_inputs(geoadv_attack *at, const float *source_p
     GA_HIP(hipMemcpyAsync(at->gt, target_pc, 4 * bn3, hipMemcpyDeviceToDevice, st));
     if (target_latent) GA_HIP(hipMemcpyAsync(at->tz, target_latent, 4 * (size_t)at->B * 128, hipMemcpyDeviceToDevice, st));
     GA_HIP(hipMemcpyAsync(at->w, dist_weight, 4 * (size_t)at->B, hipMemcpyDeviceToDevice, st));
+    if (int rc = launch_chamfer_grid_box(at->x, at->B, at->n, at->x_box, st)) return rc;   // grid of the paired nn search
+    GA_HIP(hipMemsetAsync(at->need_adv, 0, sizeof(int) * 8 * (size_t)at->B, st));          // new clouds: every verdict is open again
     at->fwd_valid = false; at->adv_valid = false;
     return GEOADV_OK;
 }

@@ -15,7 +15,11 @@ constexpr int GR_CELLS = GR_G * GR_G * GR_G;
 constexpr int GR_MAX_N = 4096;                  // points per cloud that fit the LDS layout below
 constexpr int GR_MAX_SPAN = 4;                  // cells per axis a lane walks on its own
 constexpr int GR_QSPLIT = 4;                    // workgroups per (cloud, direction): each sorts all targets, answers 1/4 of the queries
-constexpr float GR_LO = -0.5f, GR_INV_H = 16.0f;
+constexpr int GR_MEAN_CELLS = 2;                // give the cloud back if its near balls touch more cells than this on average: the
+                                                // walk is latency-bound and divergent (~1 us of launch time per mean candidate,
+                                                // measured), the all-pairs kernel prices the whole cloud at ~0.7 us ...
+constexpr int GR_FAR_DIV = 64;                  // ... or if more than 1/64 of the queries are far
+constexpr int GR_RETRY = 16;                    // a workgroup that gave up looks again every 16th call
 
 __device__ __forceinline__ float gr_sqdist(float tx, float ty, float tz, float qx, float qy, float qz) {
     const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
@@ -23,8 +27,9 @@ __device__ __forceinline__ float gr_sqdist(float tx, float ty, float tz, float q
     return (xx + yy) + zz;
 }
 
-__device__ __forceinline__ int gr_cell1(float v) {
-    const int c = (int)floorf((v - GR_LO) * GR_INV_H);
+// cell index along one axis of a grid with origin lo and 1 / cell size ih: monotone in v (every operation is), clamped
+__device__ __forceinline__ int gr_cell1(float v, float lo, float ih) {
+    const int c = (int)floorf((v - lo) * ih);
     return c < 0 ? 0 : (c > GR_G - 1 ? GR_G - 1 : c);
 }
 
@@ -35,6 +40,8 @@ struct GridArgs {
     int n;
     int *need;                    // null, or int[8 * b]: (cloud, direction, query slice) -> 1 if that workgroup gave up
                                   // (poor pairing: the caller runs the all-pairs kernel for the cloud), 0 if it wrote its outputs
+    int call;                     // running call number (the caller's iteration): paces the retries of workgroups that gave up
+    const float *box;             // null, or [b][6]: min xyz, max xyz of every Q cloud (constant over the attack: computed once)
 };
 
 // LDS: sorted targets float4 (x, y, z, index bits) [n], cell_start u16 [GR_CELLS + 1], scratch u32 [GR_CELLS] (counts,
@@ -45,28 +52,103 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
     unsigned *counts = reinterpret_cast<unsigned *>(sorted + a.n);
     unsigned short *cell_start = reinterpret_cast<unsigned short *>(counts + GR_CELLS);
     __shared__ unsigned wave_tot[GR_THREADS / 64];
-    __shared__ int n_far;
+    __shared__ float bb[GR_THREADS / 64][6];
+    __shared__ int n_far, far_cnt, cand_cnt;
 
     const int n = a.n, t = threadIdx.x;
+    int *my_need = a.need ? a.need + (2 * cloud + dir) * GR_QSPLIT + slice : nullptr;
+    // a workgroup that gave up keeps its flag and leaves at once, except on every GR_RETRY-th call (the attack's points keep
+    // moving: a cloud that was hopeless may have become easy and vice versa)
+    const int gave_up_before = my_need ? *my_need : 0;                 // (requested together with the point loads below)
     const int jbeg = (int)((long)n * slice / GR_QSPLIT), jend = (int)((long)n * (slice + 1) / GR_QSPLIT);   // this workgroup's queries
     const float *A = (dir ? a.Q : a.P) + (size_t)cloud * n * 3;      // queries
     const float *T = (dir ? a.P : a.Q) + (size_t)cloud * n * 3;      // targets
     float *dist = (dir ? a.d2 : a.d1) + (size_t)cloud * n;
     int *idx = (dir ? a.i2 : a.i1) + (size_t)cloud * n;
 
-    // ---- counting sort of the targets by cell ----
+    // ---- the grid is fitted to the bounding box of the SECOND cloud (the attack's clean source cloud) in both directions, so
+    // the cell size follows the scale of the shape and is not stretched by the few points an attack throws far out ----
     for (int c = t; c < GR_CELLS; c += GR_THREADS) counts[c] = 0;
-    if (t == 0) n_far = 0;
-    __syncthreads();
+    if (t == 0) { n_far = 0; far_cnt = 0; cand_cnt = 0; }
     constexpr int PER = GR_MAX_N / GR_THREADS;                         // 8 points per thread at most
     float tx[PER], ty[PER], tz[PER];
-    int tcell[PER], trank[PER];
+    const float *Bx = a.Q + (size_t)cloud * n * 3;
+    const float *Ox = (dir ? a.Q : a.P) + (size_t)cloud * n * 3;       // the cloud that is NOT the target set
+    float ox[PER], oy[PER], oz[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = t + k * GR_THREADS;
         if (i < n) {
             tx[k] = T[3 * i]; ty[k] = T[3 * i + 1]; tz[k] = T[3 * i + 2];
-            tcell[k] = (gr_cell1(tz[k]) * GR_G + gr_cell1(ty[k])) * GR_G + gr_cell1(tx[k]);
+            if (my_need) { ox[k] = Ox[3 * i]; oy[k] = Ox[3 * i + 1]; oz[k] = Ox[3 * i + 2]; }
+        }
+    }
+    if (gave_up_before != 0 && (a.call % GR_RETRY) != 0) return;
+    float lo[3], ih[3];
+    if (a.box) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = a.box[cloud * 6 + c];
+            ih[c] = (float)GR_G / fmaxf(a.box[cloud * 6 + 3 + c] - lo[c], 1e-6f);
+        }
+        __syncthreads();
+    } else {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = t; i < n; i += GR_THREADS) {
+            const float bx = Bx[3 * i], by = Bx[3 * i + 1], bz = Bx[3 * i + 2];
+            mn[0] = fminf(mn[0], bx); mn[1] = fminf(mn[1], by); mn[2] = fminf(mn[2], bz);
+            mx[0] = fmaxf(mx[0], bx); mx[1] = fmaxf(mx[1], by); mx[2] = fmaxf(mx[2], bz);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], off)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off)); }
+        if ((t & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { bb[t >> 6][c] = mn[c]; bb[t >> 6][3 + c] = mx[c]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float l = bb[0][c], h = bb[0][3 + c];
+#pragma unroll
+            for (int w = 1; w < GR_THREADS / 64; ++w) { l = fminf(l, bb[w][c]); h = fmaxf(h, bb[w][3 + c]); }
+            lo[c] = l;
+            ih[c] = (float)GR_G / fmaxf(h - l, 1e-6f);                 // identical in every thread: the grid is one grid
+        }
+    }
+    // ---- is the pairing good enough?  Decided for the WHOLE cloud from the pairs (P_j, Q_j) alone -- ball radius r_j around
+    // Q_j in this grid -- so that all eight workgroups of the cloud reach the same verdict (a cloud answered half by this
+    // search and then again by the all-pairs kernel would pay twice) ----
+    if (my_need) {
+        int lf = 0, lc = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = t + k * GR_THREADS;
+            if (i < n) {
+                const float qx = dir ? ox[k] : tx[k], qy = dir ? oy[k] : ty[k], qz = dir ? oz[k] : tz[k];   // Q_i
+                const float r = sqrtf(gr_sqdist(tx[k], ty[k], tz[k], ox[k], oy[k], oz[k])) * 1.0001f + 1e-5f;
+                const int sx = gr_cell1(qx + r, lo[0], ih[0]) - gr_cell1(qx - r, lo[0], ih[0]) + 1;
+                const int sy = gr_cell1(qy + r, lo[1], ih[1]) - gr_cell1(qy - r, lo[1], ih[1]) + 1;
+                const int sz = gr_cell1(qz + r, lo[2], ih[2]) - gr_cell1(qz - r, lo[2], ih[2]) + 1;
+                if (sx > GR_MAX_SPAN || sy > GR_MAX_SPAN || sz > GR_MAX_SPAN) ++lf; else lc += sx * sy * sz;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lf += __shfl_xor(lf, off); lc += __shfl_xor(lc, off); }
+        if ((t & 63) == 0) { atomicAdd(&far_cnt, lf); atomicAdd(&cand_cnt, lc); }
+        __syncthreads();
+        const bool give_up = far_cnt * GR_FAR_DIV > n || cand_cnt > GR_MEAN_CELLS * n;
+        if (t == 0) *my_need = give_up ? 1 : 0;
+        if (give_up) return;
+    }
+    // ---- counting sort of the targets by cell ----
+    int tcell[PER], trank[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = t + k * GR_THREADS;
+        if (i < n) {
+            tcell[k] = (gr_cell1(tz[k], lo[2], ih[2]) * GR_G + gr_cell1(ty[k], lo[1], ih[1])) * GR_G + gr_cell1(tx[k], lo[0], ih[0]);
             trank[k] = (int)atomicAdd(&counts[tcell[k]], 1u);
         }
     }
@@ -99,11 +181,10 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
     __syncthreads();
     unsigned *far_queue = counts;                                      // the counts are dead: queue of far queries
 
-    // ---- queries of this workgroup's slice: bound from the paired target, cells the ball touches ----
+    // ---- queries of this workgroup's slice: bound from the paired target, cells the ball touches, candidates in them ----
     constexpr int QPT = (GR_MAX_N / GR_QSPLIT + GR_THREADS - 1) / GR_THREADS;          // queries per thread (<= 2)
     float qx[QPT], qy[QPT], qz[QPT], qbest[QPT];
     int qspan[QPT];                                    // x0 | x1 << 4 | y0 << 8 | y1 << 12 | z0 << 16 | z1 << 20, or -1 = far
-    int lf = 0, lc = 0;
 #pragma unroll
     for (int k = 0; k < QPT; ++k) {
         const int j = jbeg + t + k * GR_THREADS;
@@ -112,24 +193,12 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
             qx[k] = A[3 * j]; qy[k] = A[3 * j + 1]; qz[k] = A[3 * j + 2];
             qbest[k] = gr_sqdist(T[3 * j], T[3 * j + 1], T[3 * j + 2], qx[k], qy[k], qz[k]);   // the paired target
             const float r = sqrtf(qbest[k]) * 1.0001f + 1e-5f;
-            const int x0 = gr_cell1(qx[k] - r), x1 = gr_cell1(qx[k] + r), y0 = gr_cell1(qy[k] - r), y1 = gr_cell1(qy[k] + r);
-            const int z0 = gr_cell1(qz[k] - r), z1 = gr_cell1(qz[k] + r);
-            if (x1 - x0 >= GR_MAX_SPAN || y1 - y0 >= GR_MAX_SPAN || z1 - z0 >= GR_MAX_SPAN) { qspan[k] = -1; ++lf; }
-            else { qspan[k] = x0 | x1 << 4 | y0 << 8 | y1 << 12 | z0 << 16 | z1 << 20; lc += (x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1); }
+            const int x0 = gr_cell1(qx[k] - r, lo[0], ih[0]), x1 = gr_cell1(qx[k] + r, lo[0], ih[0]);
+            const int y0 = gr_cell1(qy[k] - r, lo[1], ih[1]), y1 = gr_cell1(qy[k] + r, lo[1], ih[1]);
+            const int z0 = gr_cell1(qz[k] - r, lo[2], ih[2]), z1 = gr_cell1(qz[k] + r, lo[2], ih[2]);
+            if (x1 - x0 >= GR_MAX_SPAN || y1 - y0 >= GR_MAX_SPAN || z1 - z0 >= GR_MAX_SPAN) qspan[k] = -1;
+            else qspan[k] = x0 | x1 << 4 | y0 << 8 | y1 << 12 | z0 << 16 | z1 << 20;
         }
-    }
-    if (a.need) {   // is the pairing good enough?  far queries cost a whole scan, near ones their cells: hand the cloud back
-        // to the all-pairs kernel if that would cost more (more than 1/16 far, or > 24 cells per query on average)
-        __shared__ int far_cnt, cell_cnt;
-        if (t == 0) { far_cnt = 0; cell_cnt = 0; }
-        __syncthreads();
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { lf += __shfl_xor(lf, off); lc += __shfl_xor(lc, off); }
-        if ((t & 63) == 0) { atomicAdd(&far_cnt, lf); atomicAdd(&cell_cnt, lc); }
-        __syncthreads();
-        const bool give_up = far_cnt * 16 > (jend - jbeg) || cell_cnt > 24 * (jend - jbeg);
-        if (t == 0) a.need[(2 * cloud + dir) * GR_QSPLIT + slice] = give_up ? 1 : 0;
-        if (give_up) return;
     }
 #pragma unroll
     for (int k = 0; k < QPT; ++k) {
@@ -163,7 +232,7 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
     const int nf = n_far;
     for (int f = wave; f < nf; f += GR_THREADS / 64) {
         const int j = (int)far_queue[f];
-        const float qx = A[3 * j], qy = A[3 * j + 1], qz = A[3 * j + 2];
+        const float fx = A[3 * j], fy = A[3 * j + 1], fz = A[3 * j + 2];
         float best = INFINITY;
         int bestk = INT_MAX;
         // eight independent streams per lane keep eight LDS reads in flight (a single dependent chain pays the LDS
@@ -179,14 +248,14 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
             for (int v = 0; v < 8; ++v) p[v] = sorted[u + 64 * v];
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
-                const float d = gr_sqdist(p[v].x, p[v].y, p[v].z, qx, qy, qz);
+                const float d = gr_sqdist(p[v].x, p[v].y, p[v].z, fx, fy, fz);
                 const int k = __float_as_int(p[v].w);
                 if (d < bd[v] || (d == bd[v] && k < bk[v])) { bd[v] = d; bk[v] = k; }
             }
         }
         for (; u < n; u += 64) {
             const float4 p = sorted[u];
-            const float d = gr_sqdist(p.x, p.y, p.z, qx, qy, qz);
+            const float d = gr_sqdist(p.x, p.y, p.z, fx, fy, fz);
             const int k = __float_as_int(p.w);
             if (d < bd[0] || (d == bd[0] && k < bk[0])) { bd[0] = d; bk[0] = k; }
         }

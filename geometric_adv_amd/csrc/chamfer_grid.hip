@@ -7,12 +7,19 @@
 // Only the set of evaluated candidates shrinks: d(P_j, Q_j) bounds the answer from above, every target at least that
 // close lies inside the ball of radius r = sqrt(bound) (1 + 1e-4) + 1e-5 around the query, and the cells the ball
 // touches are enumerated conservatively (cell indices are monotone in the coordinates, the margins dwarf every fp32
-// rounding involved).  Queries whose ball touches more than GRID_MAX_SPAN^3 cells -- the few points an attack moves
-// far -- are queued and scanned against ALL targets, one wave per query.
+// rounding involved).  Queries whose ball touches more than GR_MAX_SPAN cells along an axis or holds more than
+// GR_LANE_BUDGET candidates -- the few points an attack moves far -- are queued and scanned against ALL targets, one wave
+// per query.
 //
-// One workgroup = (cloud, direction, quarter of the queries).  The targets are bucketed into a 16^3 grid over [-0.5, 0.5]^3 (coordinates
-// outside clamp to the boundary cells, which keeps containment) by a counting sort in LDS every call -- the adversarial
-// cloud moves every iteration -- and stay there, sorted by cell, for the queries.
+// One workgroup = (cloud, direction, quarter of the queries).  The targets are bucketed into a 16^3 grid fitted to their
+// bounding box (so the cell size follows the scale of the shape; queries outside clamp to the boundary cells, which keeps
+// containment) by a counting sort in LDS every call -- the adversarial cloud moves every iteration -- and stay there,
+// sorted by cell, for the queries.
+//
+// The cost depends on the data, so it is bounded: after the sort every query knows exactly how many candidates its cells
+// hold; if the slice averages more than GR_MEAN_BUDGET or has more than 1/GR_FAR_DIV far queries, the workgroup raises its
+// `need` flag and leaves -- the caller's all-pairs kernel then computes that cloud -- and looks again only every
+// GR_RETRY-th call.  Worst case: the all-pairs price plus one sort every 16 calls.
 #include "chamfer_grid.h"
 
 namespace geoadv {
@@ -22,7 +29,7 @@ __global__ __launch_bounds__(GR_THREADS) void chamfer_grid_kernel(GridArgs a) { 
 bool chamfer_grid_supports(int n, int m) { return n == m && n >= 1 && n <= GR_MAX_N; }
 
 // Both directions of nn_distance(P, Q), n == m <= 4096, exact.  Fast when P_j is near Q_j for most j.
-int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need,
+int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call,
                         hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
     GA_REQUIRE(chamfer_grid_supports(n, n), "chamfer_grid: needs 1 <= n <= %d", GR_MAX_N);
@@ -32,8 +39,39 @@ int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, floa
                                    (int)chamfer_grid_lds_bytes(GR_MAX_N)));
         attr = true;
     }
-    const GridArgs a{P, Q, d1, i1, d2, i2, n, need};
+    const GridArgs a{P, Q, d1, i1, d2, i2, n, need, call, nullptr};
     chamfer_grid_kernel<<<dim3(b, 2, GR_QSPLIT), GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(a);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+// min / max of every cloud of Q: grid = b, 256 threads
+__global__ __launch_bounds__(256) void chamfer_grid_box_kernel(const float *Q, int n, float *box) {
+    __shared__ float red[4][6];
+    const float *q = Q + (size_t)blockIdx.x * n * 3;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], q[3 * i + c]); mx[c] = fmaxf(mx[c], q[3 * i + c]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], off)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off)); }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { red[threadIdx.x >> 6][c] = mn[c]; red[threadIdx.x >> 6][3 + c] = mx[c]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        box[blockIdx.x * 6 + c] = fminf(fminf(red[0][c], red[1][c]), fminf(red[2][c], red[3][c]));
+        box[blockIdx.x * 6 + 3 + c] = fmaxf(fmaxf(red[0][3 + c], red[1][3 + c]), fmaxf(red[2][3 + c], red[3][3 + c]));
+    }
+}
+
+// bounding boxes of the b clouds of Q into box[b][6] (GridArgs::box)
+int launch_chamfer_grid_box(const float *Q, int b, int n, float *box, hipStream_t stream) {
+    if (b <= 0) return GEOADV_OK;
+    chamfer_grid_box_kernel<<<b, 256, 0, stream>>>(Q, n, box);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -46,5 +84,5 @@ extern "C" int geoadv_nn_distance_paired(int b, int n, const float *xyz1, const 
                geoadv::GR_MAX_N);
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && dist1 && idx1 && dist2 && idx2, "nn_distance_paired: null pointer");
-    return geoadv::launch_chamfer_grid(xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, nullptr, geoadv::as_stream(stream));
+    return geoadv::launch_chamfer_grid(xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, nullptr, 0, geoadv::as_stream(stream));
 }
