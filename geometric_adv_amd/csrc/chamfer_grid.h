@@ -20,6 +20,7 @@ constexpr int GR_MEAN_CELLS = 2;                // give the cloud back if its ne
                                                 // measured), the all-pairs kernel prices the whole cloud at ~0.7 us ...
 constexpr int GR_FAR_DIV = 64;                  // ... or if more than 1/64 of the queries are far
 constexpr int GR_RETRY = 16;                    // a workgroup that gave up looks again every 16th call
+constexpr int GR_RECHECK = 4;                   // one in good standing has its verdict re-examined every 4th call
 
 __device__ __forceinline__ float gr_sqdist(float tx, float ty, float tz, float qx, float qy, float qz) {
     const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
@@ -120,7 +121,9 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
     // ---- is the pairing good enough?  Decided for the WHOLE cloud from the pairs (P_j, Q_j) alone -- ball radius r_j around
     // Q_j in this grid -- so that all eight workgroups of the cloud reach the same verdict (a cloud answered half by this
     // search and then again by the all-pairs kernel would pay twice) ----
-    if (my_need) {
+    // (a cloud in good standing is re-examined every GR_RECHECK-th call only: the verdict changes slowly, the examination costs
+    // a fifth of the whole search)
+    if (my_need && (gave_up_before != 0 || (a.call % GR_RECHECK) == 0)) {
         int lf = 0, lc = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
