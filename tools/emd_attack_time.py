@@ -1,0 +1,23 @@
+"""Attack iteration time with the combined Chamfer + approx-EMD adversarial loss (BASELINE config 4's loss)."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from geometric_adv_amd import weights as W, ops
+from geometric_adv_amd.adv_ae import AdvAE, Configuration
+from geometric_adv_amd.autoencoder import PointNetAE
+N = 2048
+for B, iters in ((8, 40), (32, 20), (128, 8)):
+    rng = np.random.default_rng(B)
+    x = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5); gt = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)
+    w = W.synthetic_weights(N, seed=7); ae = PointNetAE(w, N)
+    at = AdvAE("a", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=iters + 5, num_iterations_thresh=10**6, emd_weight=1.0), ae=ae)
+    at.set_inputs(x, gt, ae.transform(gt), 1.0); at.init_pert(None, reset_optimizer=True)
+    at.run(0, 3, 10**6); torch.cuda.synchronize()
+    t0 = time.perf_counter(); at.run(3, iters, 10**6); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    xs, ys = torch.as_tensor(x).cuda(), torch.as_tensor(gt).cuda()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(3): m = ops.approx_match(xs, ys)
+    torch.cuda.synchronize(); tm = (time.perf_counter() - t1) / 3
+    print(json.dumps({"batch": B, "ms_per_iteration_chamfer_plus_emd": dt * 1e3, "approx_match_ms": tm * 1e3,
+                      "match_bytes_GB": B * N * N * 4 / 1e9}))
