@@ -139,28 +139,53 @@ __global__ __launch_bounds__(256) void emd_match_kernel(int n, int m, EmdLevels 
 }
 
 // cost[c] = sum_{k,l} sqrtf(|q_l - p_k|^2) * match[l][k]  (float product, double sum; :85-105).
-__global__ __launch_bounds__(1024) void emd_cost_kernel(int n, int m, const float *xyz1, const float *xyz2,
-                                                        const float *match, float *cost) {
-    __shared__ double red[1024];
-    const int c = blockIdx.x;
-    const float *p = xyz1 + (size_t)c * n * 3, *q = xyz2 + (size_t)c * m * 3, *mt = match + (size_t)c * n * m;
+// The match matrix is read once: workgroup = EMD_COST_ROWS rows l of one cloud, lanes across k (contiguous in match);
+// partial double sums go to a scratch vector and a second launch folds them in a fixed order.
+constexpr int EMD_COST_ROWS = 8;
+__global__ __launch_bounds__(256) void emd_cost_partial_kernel(int n, int m, const float *xyz1, const float *xyz2,
+                                                               const float *match, double *partial) {
+    __shared__ double red[4];
+    const int c = blockIdx.y, l0 = blockIdx.x * EMD_COST_ROWS;
+    const int rows = min(EMD_COST_ROWS, m - l0);
+    const float *p = xyz1 + (size_t)c * n * 3, *q = xyz2 + ((size_t)c * m + l0) * 3;
+    const float *mt = match + ((size_t)c * m + l0) * n;
     double acc = 0.0;
-    for (size_t e = threadIdx.x; e < (size_t)n * m; e += 1024) {
-        const int l = (int)(e / n), k = (int)(e % n);
-        const float dx = q[3 * l] - p[3 * k], dy = q[3 * l + 1] - p[3 * k + 1], dz = q[3 * l + 2] - p[3 * k + 2];
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz) * mt[e];
-        acc += (double)d;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float px = p[3 * k], py = p[3 * k + 1], pz = p[3 * k + 2];
+        float w[EMD_COST_ROWS];
+#pragma unroll
+        for (int r = 0; r < EMD_COST_ROWS; ++r) w[r] = r < rows ? mt[(size_t)r * n + k] : 0.f;
+#pragma unroll
+        for (int r = 0; r < EMD_COST_ROWS; ++r)
+            if (r < rows) {
+                const float dx = q[3 * r] - px, dy = q[3 * r + 1] - py, dz = q[3 * r + 2] - pz;
+                const float d = sqrtf(dx * dx + dy * dy + dz * dz) * w[r];
+                acc += (double)d;
+            }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)c * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void emd_cost_fold_kernel(int parts, const double *partial, float *cost) {
+    __shared__ double red[256];
+    const double *pp = partial + (size_t)blockIdx.x * parts;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < parts; i += 256) acc += pp[i];
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) cost[c] = (float)red[0];
+    if (threadIdx.x == 0) cost[blockIdx.x] = (float)red[0];
 }
 
 // grad1[k] = -sum_l match[l][k] * (q_l - p_k)/max(|q_l - p_k|, 1e-20), l ascending (the CPU's order, :110-133).
+constexpr int EMD_G1_AHEAD = 16;
 __global__ __launch_bounds__(256) void emd_grad1_kernel(int n, int m, const float *xyz1, const float *xyz2,
                                                         const float *match, float *grad1) {
     __shared__ float qx[EMD_TILE], qy[EMD_TILE], qz[EMD_TILE];
@@ -177,12 +202,19 @@ __global__ __launch_bounds__(256) void emd_grad1_kernel(int n, int m, const floa
         for (int e = threadIdx.x; e < cnt; e += 256) { qx[e] = q[3 * (t0 + e)]; qy[e] = q[3 * (t0 + e) + 1]; qz[e] = q[3 * (t0 + e) + 2]; }
         __syncthreads();
         if (live)
-            for (int e = 0; e < cnt; ++e) {
-                const float ox = qx[e] - px, oy = qy[e] - py, oz = qz[e] - pz;
-                float d = sqrtf(ox * ox + oy * oy + oz * oz);
-                d = d < 1e-20f ? 1e-20f : d;
-                const float w = mt[(size_t)(t0 + e) * n + k];
-                gx -= w * (ox / d); gy -= w * (oy / d); gz -= w * (oz / d);
+            for (int e0 = 0; e0 < cnt; e0 += EMD_G1_AHEAD) {     // the loads of a group are in flight together; the sum stays in l order
+                float w[EMD_G1_AHEAD];
+#pragma unroll
+                for (int u = 0; u < EMD_G1_AHEAD; ++u) w[u] = e0 + u < cnt ? mt[(size_t)(t0 + e0 + u) * n + k] : 0.f;
+#pragma unroll
+                for (int u = 0; u < EMD_G1_AHEAD; ++u)
+                    if (e0 + u < cnt) {
+                        const int e = e0 + u;
+                        const float ox = qx[e] - px, oy = qy[e] - py, oz = qz[e] - pz;
+                        float d = sqrtf(ox * ox + oy * oy + oz * oz);
+                        d = d < 1e-20f ? 1e-20f : d;
+                        gx -= w[u] * (ox / d); gy -= w[u] * (oy / d); gz -= w[u] * (oz / d);
+                    }
             }
     }
     if (live) { grad1[((size_t)c * n + k) * 3] = gx; grad1[((size_t)c * n + k) * 3 + 1] = gy; grad1[((size_t)c * n + k) * 3 + 2] = gz; }
@@ -256,8 +288,15 @@ extern "C" int geoadv_match_cost(int b, int n, int m, const float *xyz1, const f
     if (int rc = emd_check("match_cost", b, n, m)) return rc;
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && match && out, "match_cost: null pointer");
-    emd_cost_kernel<<<b, 1024, 0, as_stream(stream)>>>(n, m, xyz1, xyz2, match, out);
-    GA_LAUNCH_CHECK();
+    hipStream_t st = as_stream(stream);
+    const int parts = cdiv(m, EMD_COST_ROWS);
+    double *partial = nullptr;                        // stream-ordered scratch: concurrent callers never share it
+    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&partial), (size_t)b * parts * sizeof(double), st));
+    emd_cost_partial_kernel<<<dim3(parts, b), 256, 0, st>>>(n, m, xyz1, xyz2, match, partial);
+    emd_cost_fold_kernel<<<b, 256, 0, st>>>(parts, partial, out);
+    const hipError_t launched = hipGetLastError();
+    GA_HIP(hipFreeAsync(partial, st));
+    GA_HIP(launched);
     return GEOADV_OK;
 }
 

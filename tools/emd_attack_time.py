@@ -19,5 +19,11 @@ for B, iters in ((8, 40), (32, 20), (128, 8)):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     for _ in range(3): m = ops.approx_match(xs, ys)
     torch.cuda.synchronize(); tm = (time.perf_counter() - t1) / 3
+    def timed(f, reps=5):
+        f(); torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(reps): f()
+        torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+    tc = timed(lambda: ops.match_cost(xs, ys, m)); tg = timed(lambda: ops.match_cost_grad(xs, ys, m))
     print(json.dumps({"batch": B, "ms_per_iteration_chamfer_plus_emd": dt * 1e3, "approx_match_ms": tm * 1e3,
+                      "match_cost_ms": tc, "match_cost_grad_ms": tg,
                       "match_bytes_GB": B * N * N * 4 / 1e9}))
