@@ -27,7 +27,8 @@ int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, fl
 int launch_chamfer_light(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, hipStream_t stream);
 int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
                               hipStream_t stream);
-int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call,
+bool chamfer_grid_rides(int n);
+int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call, const float *box,
                         hipStream_t stream);
 bool chamfer_grid_supports(int n, int m);
 int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z, int *crit,
@@ -474,7 +475,12 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     }
     {
         ProfScope ps(at, GEOADV_PROF_DECODER_FWD, st);
-        if (pruned) {   // the grid search rides in the latent_decode launch (it needs nothing from the network)
+        if (pruned && !chamfer_grid_rides(n)) {   // large clouds: the search takes a CU's whole LDS, so it gets its own launch
+            if (int rc = launch_chamfer_grid(at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, B, n, at->need_adv, at->grid_calls++,
+                                             at->x_box, st)) return rc;
+            if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
+                                              at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
+        } else if (pruned) {   // the grid search rides in the latent_decode launch (it needs nothing from the network)
             if (int rc = launch_latent_decode_and_grid(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
                                                        at->fs.dense, at->fs.d1, at->fs.d2, at->adv, at->x, at->a1, at->ia1, at->a2,
                                                        at->ia2, n, at->need_adv, at->grid_calls++, at->x_box, st)) return rc;

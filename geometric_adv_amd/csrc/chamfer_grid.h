@@ -12,7 +12,8 @@ namespace geoadv {
 constexpr int GR_THREADS = 512;
 constexpr int GR_G = 16;                        // cells per axis
 constexpr int GR_CELLS = GR_G * GR_G * GR_G;
-constexpr int GR_MAX_N = 4096;                  // points per cloud that fit the LDS layout below
+constexpr int GR_MAX_N = 4096;                  // points per cloud of the default instantiation (two workgroups per CU up to n = 2048)
+constexpr int GR_MAX_N_BIG = 8192;              // the large one: 152 KB of the CU's 160 KB of LDS at n = 8192, one workgroup per CU
 constexpr int GR_MAX_SPAN = 4;                  // cells per axis a lane walks on its own
 constexpr int GR_QSPLIT = 4;                    // workgroups per (cloud, direction): each sorts all targets, answers 1/4 of the queries
 constexpr int GR_MEAN_CELLS = 2;                // give the cloud back if its near balls touch more cells than this on average: the
@@ -47,7 +48,9 @@ struct GridArgs {
 
 // LDS: sorted targets float4 (x, y, z, index bits) [n], cell_start u16 [GR_CELLS + 1], scratch u32 [GR_CELLS] (counts,
 // later the queue of far queries)
+template <int MAXN>
 __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud, const int dir, const int slice) {
+    static_assert(MAXN % GR_THREADS == 0 && MAXN <= 65535 && MAXN / GR_QSPLIT <= GR_CELLS, "u16 cell offsets; the far queue reuses the counts");
     extern __shared__ __attribute__((aligned(16))) unsigned char gr_lds[];
     float4 *sorted = reinterpret_cast<float4 *>(gr_lds);
     unsigned *counts = reinterpret_cast<unsigned *>(sorted + a.n);
@@ -71,7 +74,7 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
     // the cell size follows the scale of the shape and is not stretched by the few points an attack throws far out ----
     for (int c = t; c < GR_CELLS; c += GR_THREADS) counts[c] = 0;
     if (t == 0) { n_far = 0; far_cnt = 0; cand_cnt = 0; }
-    constexpr int PER = GR_MAX_N / GR_THREADS;                         // 8 points per thread at most
+    constexpr int PER = MAXN / GR_THREADS;                             // points per thread at most (8 or 16)
     float tx[PER], ty[PER], tz[PER];
     const float *Bx = a.Q + (size_t)cloud * n * 3;
     const float *Ox = (dir ? a.Q : a.P) + (size_t)cloud * n * 3;       // the cloud that is NOT the target set
@@ -185,7 +188,7 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
     unsigned *far_queue = counts;                                      // the counts are dead: queue of far queries
 
     // ---- queries of this workgroup's slice: bound from the paired target, cells the ball touches, candidates in them ----
-    constexpr int QPT = (GR_MAX_N / GR_QSPLIT + GR_THREADS - 1) / GR_THREADS;          // queries per thread (<= 2)
+    constexpr int QPT = (MAXN / GR_QSPLIT + GR_THREADS - 1) / GR_THREADS;              // queries per thread (2 or 4)
     float qx[QPT], qy[QPT], qz[QPT], qbest[QPT];
     int qspan[QPT];                                    // x0 | x1 << 4 | y0 << 8 | y1 << 12 | z0 << 16 | z1 << 20, or -1 = far
 #pragma unroll

@@ -11,7 +11,7 @@
 // GR_LANE_BUDGET candidates -- the few points an attack moves far -- are queued and scanned against ALL targets, one wave
 // per query.
 //
-// One workgroup = (cloud, direction, quarter of the queries).  The targets are bucketed into a 16^3 grid fitted to their
+// One workgroup = (cloud, direction, quarter of the queries); n <= 8192 (the sorted targets of a cloud live in LDS).  The targets are bucketed into a 16^3 grid fitted to their
 // bounding box (so the cell size follows the scale of the shape; queries outside clamp to the boundary cells, which keeps
 // containment) by a counting sort in LDS every call -- the adversarial cloud moves every iteration -- and stay there,
 // sorted by cell, for the queries.
@@ -24,25 +24,32 @@
 
 namespace geoadv {
 
-__global__ __launch_bounds__(GR_THREADS) void chamfer_grid_kernel(GridArgs a) { grid_nn_block(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+template <int MAXN>
+__global__ __launch_bounds__(GR_THREADS) void chamfer_grid_kernel(GridArgs a) { grid_nn_block<MAXN>(a, blockIdx.x, blockIdx.y, blockIdx.z); }
 
-bool chamfer_grid_supports(int n, int m) { return n == m && n >= 1 && n <= GR_MAX_N; }
+bool chamfer_grid_supports(int n, int m) { return n == m && n >= 1 && n <= GR_MAX_N_BIG; }
+bool chamfer_grid_rides(int n) { return n >= 1 && n <= GR_MAX_N; }      // small enough to share the latent_decode launch (decoder.hip)
 
-// Both directions of nn_distance(P, Q), n == m <= 4096, exact.  Fast when P_j is near Q_j for most j.
-int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call,
-                        hipStream_t stream) {
-    if (b <= 0) return GEOADV_OK;
-    GA_REQUIRE(chamfer_grid_supports(n, n), "chamfer_grid: needs 1 <= n <= %d", GR_MAX_N);
+template <int MAXN>
+static int launch_grid(const GridArgs &a, int b, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)chamfer_grid_lds_bytes(GR_MAX_N)));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grid_kernel<MAXN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)chamfer_grid_lds_bytes(MAXN)));
         attr = true;
     }
-    const GridArgs a{P, Q, d1, i1, d2, i2, n, need, call, nullptr};
-    chamfer_grid_kernel<<<dim3(b, 2, GR_QSPLIT), GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(a);
+    chamfer_grid_kernel<MAXN><<<dim3(b, 2, GR_QSPLIT), GR_THREADS, chamfer_grid_lds_bytes(a.n), stream>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
+}
+
+// Both directions of nn_distance(P, Q), n == m <= 8192, exact.  Fast when P_j is near Q_j for most j.
+int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call,
+                        const float *box, hipStream_t stream) {
+    if (b <= 0) return GEOADV_OK;
+    GA_REQUIRE(chamfer_grid_supports(n, n), "chamfer_grid: needs 1 <= n <= %d", GR_MAX_N_BIG);
+    const GridArgs a{P, Q, d1, i1, d2, i2, n, need, call, box};
+    return n <= GR_MAX_N ? launch_grid<GR_MAX_N>(a, b, stream) : launch_grid<GR_MAX_N_BIG>(a, b, stream);
 }
 
 // min / max of every cloud of Q: grid = b, 256 threads
@@ -81,8 +88,8 @@ int launch_chamfer_grid_box(const float *Q, int b, int n, float *box, hipStream_
 extern "C" int geoadv_nn_distance_paired(int b, int n, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
                                          float *dist2, int *idx2, void *stream) {
     GA_REQUIRE(b >= 0 && geoadv::chamfer_grid_supports(n, n), "nn_distance_paired: bad dimensions (b=%d n=%d, n <= %d)", b, n,
-               geoadv::GR_MAX_N);
+               geoadv::GR_MAX_N_BIG);
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && dist1 && idx1 && dist2 && idx2, "nn_distance_paired: null pointer");
-    return geoadv::launch_chamfer_grid(xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, nullptr, 0, geoadv::as_stream(stream));
+    return geoadv::launch_chamfer_grid(xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, nullptr, 0, nullptr, geoadv::as_stream(stream));
 }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(LD_THREADS) void latent_decode_and_grid_kernel(Devi
     }
     if (threadIdx.x >= GR_THREADS) return;
     const int g = blockIdx.x - batch;                   // (cloud, direction, slice), slice fastest
-    grid_nn_block(G, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
+    grid_nn_block<GR_MAX_N>(G, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -66,8 +66,8 @@ extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) 
         GA_HIP(hipEventSynchronize(e1));
     }
     GA_HIP(hipEventElapsedTime(ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(out);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
     return GEOADV_OK;
 }

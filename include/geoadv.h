@@ -53,7 +53,7 @@ int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2
 int geoadv_nn_distance_light(int b, int n, const float *xyz1, const float *xyz2,
                              float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
 
-/* Same results as geoadv_nn_distance for n == m <= 4096, from an exact grid search that uses xyz2[j] as the first guess
+/* Same results as geoadv_nn_distance for n == m <= 8192, from an exact grid search that uses xyz2[j] as the first guess
  * for the neighbour of xyz1[j] (and vice versa): fast when the clouds are paired like the attack's (adv, x), never wrong
  * otherwise (a query whose guess is poor is scanned against all points). */
 int geoadv_nn_distance_paired(int b, int n, const float *xyz1, const float *xyz2,

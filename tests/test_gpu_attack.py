@@ -293,11 +293,12 @@ def test_masked_backward_equals_recomputing_backward(setup, monkeypatch, n):
     assert outs[0].abs().max() > 0 and torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("lr,n", [(0.01, N), (0.3, N), (0.01, 200)])
+@pytest.mark.parametrize("lr,n", [(0.01, N), (0.3, N), (0.01, 200), (0.01, 8192), (0.3, 5000)])
 def test_pruned_source_distance_equals_all_pairs(setup, monkeypatch, lr, n):
     """nn_distance(adv, x) through the paired grid search (default) vs the all-pairs kernel (GEOADV_CHAMFER_PRUNE=0): the
     whole loop must agree bit for bit -- also when a huge learning rate scatters the points so that clouds hand themselves
-    back to the all-pairs kernel, and for a point count that is not a multiple of anything."""
+    back to the all-pairs kernel, for a point count that is not a multiple of anything, and for clouds of more than 4096
+    points (the search's large instantiation, launched on its own)."""
     import torch
     from geometric_adv_amd import weights as W
     from geometric_adv_amd.autoencoder import PointNetAE

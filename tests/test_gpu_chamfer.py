@@ -169,7 +169,7 @@ def _paired_case(kind, b, n, seed):
 
 
 @pytest.mark.parametrize("kind", ["attack", "zero", "unpaired", "outside", "medium"])
-@pytest.mark.parametrize("b,n", [(3, 2048), (2, 1000), (2, 64), (1, 1), (1, 4096)])
+@pytest.mark.parametrize("b,n", [(3, 2048), (2, 1000), (2, 64), (1, 1), (1, 4096), (2, 8192), (1, 5000)])
 def test_paired_grid_search_equals_default(kind, b, n):
     """Exact grid search seeded with the pairing (the attack's nn_distance(adv, x)): dist and idx bit for bit, whatever
     the data -- good pairing, none at all, exact ties, points outside the grid."""
