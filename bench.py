@@ -166,6 +166,43 @@ def training_leg(dev, steps=30, batch=50):
             "frac_of_fp32_mfma_peak_end_to_end": flop / dt / (PEAK_MFMA_F32_TFLOPS * 1e12)}
 
 
+def slots_leg(dev, weights, ae, slots=2, iters=300):
+    """Configuration.batch_slots: `slots` independent B = 32 batches attacked concurrently on this GPU (own handle, stream
+    and host thread each, AdvAE._attack_slots): aggregate attack iterations/s.  Reported beside the headline, which
+    stays one batch at a time."""
+    import threading
+    import torch
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    ats, streams = [], []
+    for s in range(slots):
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            at = AdvAE("adversary", Configuration(batch_size=B, n_points=N, weights=weights, num_iterations=iters + 20,
+                                                  num_iterations_thresh=10 ** 6), device=dev, ae=ae)
+            x, gt = clouds(500 + 2 * s, B, N), clouds(501 + 2 * s, B, N)
+            at.set_inputs(x, gt, None, 1.0)
+            at.init_pert(None, reset_optimizer=True)
+            at.run(0, 20, 10 ** 6)
+        ats.append(at)
+        streams.append(st)
+    torch.cuda.synchronize()
+
+    def work(at, st):
+        with torch.cuda.stream(st):
+            at.run(20, iters, 10 ** 6)
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(a, s)) for a, s in zip(ats, streams)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"slots": slots, "batch": B, "attack_iterations_per_sec_all_slots": slots * iters / dt,
+            "ms_per_iteration_per_slot": dt / iters * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,7 +326,7 @@ def main():
         "final_mean_target_recon_error": float(gathered[0, :, 4].mean().item()),
     }
     if world == 1:                  # the widened row f-4, measured beside the headline (not part of `value`)
-        out["secondary"] = {"ae_training_step": training_leg(dev)}
+        out["secondary"] = {"ae_training_step": training_leg(dev), "two_batch_slots": slots_leg(dev, weights, ae)}
     if world == 1 and not args.no_cpu_baseline:
         _, adv_best, recon_best = at.get_best(ref)
         out["cpu_baseline"] = cpu_baseline(weights, x, gt, args.cpu_iters,

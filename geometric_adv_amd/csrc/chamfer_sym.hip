@@ -211,8 +211,10 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
 // produces) and keeps the whole row cloud in LDS as SoA planes, one padded segment per row tile.  Thread =
 // one column: minimum over the row tiles + lowest tile attaining it, then that tile's rows are
 // re-evaluated in ascending order for the first one with d == minimum.
-constexpr int CF_THREADS = 256;
-constexpr int CF_COLS = CF_THREADS;                   // columns per workgroup (one per thread)
+constexpr int CF_Q = 4;                               // lanes per column: each re-evaluates a quarter of the winning tile
+constexpr int CF_COLS = 256;                          // columns per workgroup
+constexpr int CF_THREADS = CF_COLS * CF_Q;            // 16 waves: four per SIMD hide the LDS latency of the re-evaluation
+static_assert(CS_ROWS % (4 * CF_Q) == 0, "a lane's share of a tile is whole float4 groups");
 constexpr int CF_SEG = CS_ROWS + 4;                   // floats per tile segment: 16-B aligned, and the pad staggers the banks
 
 __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferSymArgs a) {
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
     }
     __syncthreads();
     if (a.csplit > 1) {   // row minima: lexicographic (distance, index) minimum over the column slices
-        for (int j = blockIdx.x * CF_COLS + threadIdx.x; j < n; j += gridDim.x * CF_COLS) {
+        for (int j = blockIdx.x * CF_THREADS + threadIdx.x; j < n; j += gridDim.x * CF_THREADS) {
             const size_t o = ((size_t)pi * a.clouds + c) * a.csplit * n + j;
             float d = a.rowpart_d[o];
             int i = a.rowpart_i[o];
@@ -249,37 +251,46 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
             pr.idx1[(size_t)c * n + j] = i;
         }
     }
-    const int k = blockIdx.x * CF_COLS + threadIdx.x;
-    if (k >= m) return;
-    float v = colpart[k];
+    const int quarter = threadIdx.x & (CF_Q - 1);
+    const int k = blockIdx.x * CF_COLS + (threadIdx.x >> 2);
+    const int kc = k < m ? k : m - 1;                     // (whole 4-lane groups stay in the shuffles below)
+    float v = colpart[kc];
     int bt = 0;
     for (int t = 1; t < tiles; ++t) {
-        const float w = colpart[(size_t)t * m + k];
+        const float w = colpart[(size_t)t * m + kc];
         if (w < v) { v = w; bt = t; }                     // strict: the lowest tile wins ties
     }
-    const float qx = Q[3 * (size_t)k], qy = Q[3 * (size_t)k + 1], qz = Q[3 * (size_t)k + 2];
+    const float qx = Q[3 * (size_t)kc], qy = Q[3 * (size_t)kc + 1], qz = Q[3 * (size_t)kc + 2];
     const int q0 = bt * CS_ROWS;
     const int nrows = min(CS_ROWS, n - q0);
-    const float *sx = rx + bt * CF_SEG, *sy = ry + bt * CF_SEG, *sz = rz + bt * CF_SEG;
+    constexpr int SHARE = CS_ROWS / CF_Q;                 // rows per lane: [quarter * SHARE, +SHARE) of the tile
+    const float *sx = rx + bt * CF_SEG + quarter * SHARE, *sy = ry + bt * CF_SEG + quarter * SHARE, *sz = rz + bt * CF_SEG + quarter * SHARE;
+    const int lim = nrows - quarter * SHARE;              // rows of this share that exist (may be <= 0)
     // descending, four rows per step (one ds_read_b128 per plane): the last hit kept is the lowest row.
-    // Rows beyond nrows inside the last 4-group are padding (never equal to v unless they duplicate a real
-    // row, and a lower real row then wins anyway) -- they are masked explicitly all the same.
-    int found = nrows;
-    for (int j4 = ((nrows + 3) >> 2) - 1; j4 >= 0; --j4) {
+    // Rows beyond the cloud are padding (never equal to v unless they duplicate a real row, and a lower real row then
+    // wins anyway) -- they are masked explicitly all the same.
+    int found = INT_MAX;
+#pragma unroll 4
+    for (int j4 = SHARE / 4 - 1; j4 >= 0; --j4) {
         const float4 xa = *reinterpret_cast<const float4 *>(sx + 4 * j4);
         const float4 ya = *reinterpret_cast<const float4 *>(sy + 4 * j4);
         const float4 za = *reinterpret_cast<const float4 *>(sz + 4 * j4);
         const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
         const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
         const int j = 4 * j4;
-        found = (d3 == v && j + 3 < nrows) ? j + 3 : found;
-        found = (d2 == v && j + 2 < nrows) ? j + 2 : found;
-        found = (d1 == v && j + 1 < nrows) ? j + 1 : found;
-        found = d0 == v ? j : found;
+        found = (d3 == v && j + 3 < lim) ? j + 3 : found;
+        found = (d2 == v && j + 2 < lim) ? j + 2 : found;
+        found = (d1 == v && j + 1 < lim) ? j + 1 : found;
+        found = (d0 == v && j < lim) ? j : found;
     }
-    if (found == nrows) found = 0;                        // only if v is NaN-tainted (out of contract)
-    pr.dist2[(size_t)c * m + k] = v;
-    pr.idx2[(size_t)c * m + k] = q0 + found;
+    if (found != INT_MAX) found += quarter * SHARE;
+    found = min(found, __shfl_xor(found, 1));
+    found = min(found, __shfl_xor(found, 2));
+    if (found == INT_MAX) found = 0;                      // only if v is NaN-tainted (out of contract)
+    if (quarter == 0 && k < m) {
+        pr.dist2[(size_t)c * m + k] = v;
+        pr.idx2[(size_t)c * m + k] = q0 + found;
+    }
 }
 
 constexpr int CS_MAX_SPLIT = 4;

@@ -39,13 +39,44 @@ __global__ __launch_bounds__(256) void mb_valu_kernel(float *out, int iters) {
     if (acc == 123.456f) out[0] = acc;   // keep everything live
 }
 
+// MFMA issue-rate probes (which = 5..9): every wave issues 16 * iters MFMAs with no memory traffic at all.
+//   5: v_mfma_f32_32x32x2_f32, ONE accumulator (every MFMA depends on the previous one -- the encoder's chain shape)
+//   6: the same with 2 independent accumulators, 7: with 4
+//   8: v_mfma_f32_16x16x4_f32, one accumulator;  9: with 4 independent accumulators
+// Launched with 4096 workgroups x 256 threads (waves per SIMD limited only by registers).
+typedef float mb16 __attribute__((ext_vector_type(16)));
+typedef float mb4 __attribute__((ext_vector_type(4)));
+template <int WHICH>
+__global__ __launch_bounds__(256) void mb_mfma_kernel(float *out, int iters) {
+    const float a = 1.0f + 1e-7f * threadIdx.x, b = 0.5f;
+    float r = 0.f;
+    if (WHICH <= 7) {
+        constexpr int NA = WHICH == 5 ? 1 : (WHICH == 6 ? 2 : 4);
+        mb16 acc[NA] = {};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u % NA] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u % NA], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) r += acc[q][0] + acc[q][15];
+    } else {
+        constexpr int NA = WHICH == 8 ? 1 : 4;
+        mb4 acc[NA] = {};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[u % NA], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) r += acc[q][0] + acc[q][3];
+    }
+    if (r == 123.456f) out[0] = r;
+}
+
 }  // namespace geoadv
 using namespace geoadv;
 
 // ms = time of one launch of 2048 workgroups x 256 threads, each thread issuing 16*iters VALU
 // instructions of the selected kind.
 extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) {
-    GA_REQUIRE(which >= 0 && which <= 4 && iters > 0 && ms, "microbench: bad arguments");
+    GA_REQUIRE(which >= 0 && which <= 9 && iters > 0 && ms, "microbench: bad arguments");
     hipStream_t st = as_stream(stream);
     float *out = nullptr;
     GA_HIP(hipMalloc(&out, 64));
@@ -59,7 +90,12 @@ extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) 
             case 1: mb_valu_kernel<1><<<2048, 256, 0, st>>>(out, iters); break;
             case 2: mb_valu_kernel<2><<<2048, 256, 0, st>>>(out, iters); break;
             case 3: mb_valu_kernel<3><<<2048, 256, 0, st>>>(out, iters); break;
-            default: mb_valu_kernel<4><<<2048, 256, 0, st>>>(out, iters); break;
+            case 4: mb_valu_kernel<4><<<2048, 256, 0, st>>>(out, iters); break;
+            case 5: mb_mfma_kernel<5><<<4096, 256, 0, st>>>(out, iters); break;
+            case 6: mb_mfma_kernel<6><<<4096, 256, 0, st>>>(out, iters); break;
+            case 7: mb_mfma_kernel<7><<<4096, 256, 0, st>>>(out, iters); break;
+            case 8: mb_mfma_kernel<8><<<4096, 256, 0, st>>>(out, iters); break;
+            default: mb_mfma_kernel<9><<<4096, 256, 0, st>>>(out, iters); break;
         }
         GA_LAUNCH_CHECK();
         GA_HIP(hipEventRecord(e1, st));

@@ -237,6 +237,29 @@ def test_attack_api_shapes_and_progress(setup):
         at.attack(x[:3], tz[:3], gt[:3], ref[:3], conf)                 # 3 % 2 != 0 (adv_ae.py:162)
 
 
+def test_batch_slots_equal_one_handle_per_run_of_batches(setup):
+    """Configuration.batch_slots = 2: two batches in flight on one GPU (own handle, stream and host thread each).  Slot k
+    takes the k-th contiguous run of batches, so the result must equal two separate handles walking those runs one
+    after the other -- bit for bit, Adam slots carried from batch to batch included -- and the log keeps batch order."""
+    import io
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    w, ae, model = setup
+    b, n_ex = 2, 10                                                     # 5 batches: runs of 3 and 2
+    x, gt = _clouds(71, n_ex)
+    ref = ae.get_loss_per_pc(gt)
+    tz = ae.transform(gt)
+    kw = dict(batch_size=b, n_points=N, weights=w, dist_weight_list=[0.5, 2.0], num_iterations=25, num_iterations_thresh=20)
+    log = io.StringIO()
+    got = AdvAE("adversary", Configuration(batch_slots=2, **kw), ae=ae).attack(x, tz, gt, ref, log_file=log)
+    want = []
+    for lo, hi in ((0, 6), (6, 10)):
+        want.append(AdvAE("adversary", Configuration(**kw), ae=ae).attack(x[lo:hi], tz[lo:hi], gt[lo:hi], ref[lo:hi]))
+    for k in range(3):
+        assert np.array_equal(got[k], np.concatenate([want[0][k], want[1][k]], axis=1))
+    marks = [ln for ln in log.getvalue().splitlines() if ln.startswith("Batch ")]
+    assert [int(ln.split()[1]) for ln in marks] == [1, 2, 3, 4, 5]
+
+
 def test_emd_combined_loss_step(setup):
     """configs[3]: Chamfer + EMD combined adversarial loss (build-defined: loss_adv = chamfer +
     emd_weight * match_cost(recon, gt) / N, match held constant in the backward like the reference's
