@@ -10,6 +10,7 @@
 // size n*m ever touches HBM in the fused form.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -75,37 +76,136 @@ __global__ __launch_bounds__(64) void selection_sort_kernel(int n, int k, size_t
 // (get_knn_dists_per_point.py:79-81: grouped - centre, sqrt(reduce_sum(deltas**2))).
 // ------------------------------------------------------------------------------------------
 template <int MODE>
+__device__ __forceinline__ void knn_row(float *val, int *idx, int n, int m, int k, int c, int q, const float *xyz1,
+                                        const float *xyz2, float *val_out, int *idx_out) {
+    const float *data = xyz1 + (size_t)c * n * 3;
+    const float *qry = xyz2 + (size_t)c * m * 3;
+    const float qx = qry[3 * q], qy = qry[3 * q + 1], qz = qry[3 * q + 2];
+    for (int t = threadIdx.x; t < n; t += 64) {
+        const float dx = data[3 * t] - qx, dy = data[3 * t + 1] - qy, dz = data[3 * t + 2] - qz;
+        val[t] = (dx * dx + dy * dy) + dz * dz;
+        idx[t] = t;
+    }
+    __syncthreads();
+    wave_selection_sort(val, idx, n, k);
+    if (MODE == 0) {
+        for (int s = threadIdx.x; s < k; s += 64) {
+            val_out[((size_t)c * m + q) * k + s] = val[s];
+            idx_out[((size_t)c * m + q) * k + s] = idx[s];
+        }
+    } else {
+        for (int s = threadIdx.x; s + 1 < k; s += 64) {
+            const int nb = idx[s + 1];
+            const float dx = data[3 * nb] - qx, dy = data[3 * nb + 1] - qy, dz = data[3 * nb + 2] - qz;
+            val_out[((size_t)c * m + q) * (k - 1) + s] = sqrtf((dx * dx + dy * dy) + dz * dz);
+        }
+    }
+    __syncthreads();
+}
+
+template <int MODE>
 __global__ __launch_bounds__(64) void knn_kernel(int n, int m, int k, int qper, const float *xyz1, const float *xyz2,
                                                  float *val_out, int *idx_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *val = lds;
     int *idx = reinterpret_cast<int *>(lds + n);
+    const int q_end = min(m, (int)(blockIdx.x + 1) * qper);
+    for (int q = blockIdx.x * qper; q < q_end; ++q) knn_row<MODE>(val, idx, n, m, k, blockIdx.y, q, xyz1, xyz2, val_out, idx_out);
+}
+
+// The queries the fast kernel below handed back (redo[0] = their number, then c * m + q each).
+template <int MODE>
+__global__ __launch_bounds__(64) void knn_redo_kernel(int n, int m, int k, const float *xyz1, const float *xyz2, float *val_out,
+                                                      int *idx_out, const int *redo) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *val = lds;
+    int *idx = reinterpret_cast<int *>(lds + n);
+    const int count = redo[0];
+    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+        const int cq = redo[1 + e];
+        knn_row<MODE>(val, idx, n, m, k, cq / m, cq % m, xyz1, xyz2, val_out, idx_out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast k-NN: one THREAD per query keeps its S smallest (distance, index) pairs sorted in registers while the dataset
+// streams through LDS (broadcast reads, four points per ds_read_b128).  The values and their order are the
+// reference's whatever it does with ties (the sorted k smallest distances are what they are); the INDICES are the
+// reference's whenever no two of the k + 1 smallest distances are equal -- then the selection is unique.  A query with
+// such a tie (duplicated points), or one that meets a NaN / infinite distance, is put on a list and redone by the
+// selection-sort kernel below, which reproduces the reference's swap order.  Visiting the dataset in ascending index
+// with strict '<' keeps equal distances in index order, so the tie test only has to look at neighbours in the list.
+//   MODE 0: val/idx of the k nearest (S >= k + 1: one extra slot for the tie test).
+//   MODE 1: sqrt of sorted distances 1..k-1 (the defender's graph; independent of the order among ties, S >= k).
+// The ~k ln(n/k) insertions per query are rare per lane but not per wave (64 lanes), so the insertion is a branch-free
+// shift of all S slots behind one wave-level branch.
+// ------------------------------------------------------------------------------------------
+constexpr int KF_THREADS = 256;
+constexpr int KF_TILE = 1024;
+
+template <int MODE, int S>
+__global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int k, const float *xyz1, const float *xyz2,
+                                                              float *val_out, int *idx_out, int *redo) {
+    __shared__ __attribute__((aligned(16))) float sx[KF_TILE], sy[KF_TILE], sz[KF_TILE];
     const int c = blockIdx.y;
     const float *data = xyz1 + (size_t)c * n * 3;
-    const float *qry = xyz2 + (size_t)c * m * 3;
-    const int q_end = min(m, (int)(blockIdx.x + 1) * qper);
-    for (int q = blockIdx.x * qper; q < q_end; ++q) {
-        const float qx = qry[3 * q], qy = qry[3 * q + 1], qz = qry[3 * q + 2];
-        for (int t = threadIdx.x; t < n; t += 64) {
-            const float dx = data[3 * t] - qx, dy = data[3 * t + 1] - qy, dz = data[3 * t + 2] - qz;
-            val[t] = (dx * dx + dy * dy) + dz * dz;
-            idx[t] = t;
+    const int q = blockIdx.x * KF_THREADS + threadIdx.x;
+    const bool live = q < m;
+    const float *qp = xyz2 + ((size_t)c * m + (live ? q : m - 1)) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    float v[S];
+    int ix[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
+    bool odd = false;                                      // met a NaN distance
+    for (int t0 = 0; t0 < n; t0 += KF_TILE) {
+        const int cnt = min(KF_TILE, n - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < KF_TILE; e += KF_THREADS) {
+            const bool in = e < cnt;                       // the pad never enters a list: NaN compares false
+            sx[e] = in ? data[3 * (size_t)(t0 + e)] : NAN; sy[e] = in ? data[3 * (size_t)(t0 + e) + 1] : NAN;
+            sz[e] = in ? data[3 * (size_t)(t0 + e) + 2] : NAN;
         }
         __syncthreads();
-        wave_selection_sort(val, idx, n, k);
-        if (MODE == 0) {
-            for (int s = threadIdx.x; s < k; s += 64) {
-                val_out[((size_t)c * m + q) * k + s] = val[s];
-                idx_out[((size_t)c * m + q) * k + s] = idx[s];
-            }
-        } else {
-            for (int s = threadIdx.x; s + 1 < k; s += 64) {
-                const int nb = idx[s + 1];
-                const float dx = data[3 * nb] - qx, dy = data[3 * nb + 1] - qy, dz = data[3 * nb + 2] - qz;
-                val_out[((size_t)c * m + q) * (k - 1) + s] = sqrtf((dx * dx + dy * dy) + dz * dz);
+        for (int e0 = 0; e0 < cnt; e0 += 4) {
+            const float4 xa = *reinterpret_cast<const float4 *>(&sx[e0]);
+            const float4 ya = *reinterpret_cast<const float4 *>(&sy[e0]);
+            const float4 za = *reinterpret_cast<const float4 *>(&sz[e0]);
+            const float tx[4] = {xa.x, xa.y, xa.z, xa.w}, ty[4] = {ya.x, ya.y, ya.z, ya.w}, tz[4] = {za.x, za.y, za.z, za.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dx = tx[u] - qx, dy = ty[u] - qy, dz = tz[u] - qz;
+                const float d = (dx * dx + dy * dy) + dz * dz;                      // tf_grouping.py:68, left to right
+                if (e0 + u < cnt) odd |= d != d;
+                if (d < v[S - 1]) {
+                    bool cl[S];
+#pragma unroll
+                    for (int i = 0; i < S; ++i) cl[i] = d < v[i];
+#pragma unroll
+                    for (int i = S - 1; i > 0; --i) {
+                        v[i] = cl[i - 1] ? v[i - 1] : (cl[i] ? d : v[i]);
+                        if (MODE == 0) ix[i] = cl[i - 1] ? ix[i - 1] : (cl[i] ? t0 + e0 + u : ix[i]);
+                    }
+                    if (cl[0]) { v[0] = d; if (MODE == 0) ix[0] = t0 + e0 + u; }
+                }
             }
         }
-        __syncthreads();
+    }
+    if (!live) return;
+    if (MODE == 0) {
+        bool again = odd || ix[k - 1] < 0;                 // fewer than k finite distances
+#pragma unroll
+        for (int i = 0; i + 1 < S; ++i)
+            if (i < k && v[i] == v[i + 1] && ix[i + 1] >= 0) again = true;         // a tie among the k + 1 smallest
+        if (again) { redo[1 + atomicAdd(redo, 1)] = c * m + q; return; }
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+            if (i < k) { val_out[((size_t)c * m + q) * k + i] = v[i]; idx_out[((size_t)c * m + q) * k + i] = ix[i]; }
+    } else {
+        if (odd || !(v[k - 1] < INFINITY)) { redo[1 + atomicAdd(redo, 1)] = c * m + q; return; }
+#pragma unroll
+        for (int i = 1; i < S; ++i)
+            if (i < k) val_out[((size_t)c * m + q) * (k - 1) + i - 1] = sqrtf(v[i]);
     }
 }
 
@@ -190,6 +290,8 @@ static int row_lds_attr() {
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(selection_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_redo_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_redo_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     done = true;
     return GEOADV_OK;
 }
@@ -208,9 +310,38 @@ extern "C" int geoadv_selection_sort(int b, int n, int m, int k, const float *di
     return GEOADV_OK;
 }
 
+template <int MODE, int S>
+static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx, hipStream_t st) {
+    int *redo = nullptr;                                  // stream-ordered scratch: counter + one entry per query at most
+    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&redo), sizeof(int) * ((size_t)b * m + 1), st));
+    GA_HIP(hipMemsetAsync(redo, 0, sizeof(int), st));
+    knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
+    knn_redo_kernel<MODE><<<1024, 64, (size_t)n * 8, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
+    const hipError_t launched = hipGetLastError();
+    GA_HIP(hipFreeAsync(redo, st));
+    GA_HIP(launched);
+    return GEOADV_OK;
+}
+
+// mode 0: knn_point (k values + indices); mode 1: the defender's distances (k includes the dropped self column)
 static int launch_knn(int mode, int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
                       hipStream_t st) {
     if (int rc = row_lds_attr()) return rc;
+    static int slow = -1;
+    if (slow < 0) { const char *e = getenv("GEOADV_KNN_SLOW"); slow = (e && e[0] == '1') ? 1 : 0; }
+    const int slots = mode == 0 ? k + 1 : k;              // register list of the fast kernel
+    if (!slow && slots <= 17 && (size_t)b * m < ((size_t)1 << 31)) {
+        if (mode == 0) {
+            if (slots <= 3) return launch_knn_fast<0, 3>(b, n, m, k, xyz1, xyz2, val, idx, st);
+            if (slots <= 5) return launch_knn_fast<0, 5>(b, n, m, k, xyz1, xyz2, val, idx, st);
+            if (slots <= 9) return launch_knn_fast<0, 9>(b, n, m, k, xyz1, xyz2, val, idx, st);
+            return launch_knn_fast<0, 17>(b, n, m, k, xyz1, xyz2, val, idx, st);
+        }
+        if (slots <= 3) return launch_knn_fast<1, 3>(b, n, m, k, xyz1, xyz2, val, idx, st);
+        if (slots <= 5) return launch_knn_fast<1, 5>(b, n, m, k, xyz1, xyz2, val, idx, st);
+        if (slots <= 9) return launch_knn_fast<1, 9>(b, n, m, k, xyz1, xyz2, val, idx, st);
+        return launch_knn_fast<1, 17>(b, n, m, k, xyz1, xyz2, val, idx, st);
+    }
     // enough workgroups to fill the chip, a few queries each to amortise the launch
     int qper = 1;
     while ((long)cdiv(m, qper) * b > 16384 && qper < 16) qper *= 2;

@@ -44,7 +44,8 @@ def test_query_ball_vs_oracle_sparse_hits(oracle):
         assert np.array_equal(idx.cpu().numpy()[hit], want_idx[hit])
 
 
-@pytest.mark.parametrize("b,n,m,k", [(2, 200, 77, 9), (1, 2048, 64, 9), (3, 64, 64, 64), (2, 500, 10, 1)])
+@pytest.mark.parametrize("b,n,m,k", [(2, 200, 77, 9), (1, 2048, 64, 9), (3, 64, 64, 64), (2, 500, 10, 1), (2, 3000, 300, 16),
+                                     (2, 1500, 257, 4), (1, 5, 5, 5), (2, 2048, 100, 2), (1, 1100, 40, 17)])
 def test_knn_point_vs_oracle(oracle, b, n, m, k):
     from geometric_adv_amd import ops
     from conftest import cloud
@@ -64,6 +65,25 @@ def test_knn_point_exact_ties_follow_the_swap_rule(oracle):
     val, idx = ops.knn_point(9, _t(x), _t(x))
     assert np.array_equal(idx.cpu().numpy(), want_idx)
     assert np.array_equal(val.cpu().numpy(), want_val)
+
+
+def test_knn_mixed_ties_and_infinities(oracle):
+    """One launch, both paths: most queries have a unique answer (register top-k), the ones with duplicated neighbours or
+    non-finite distances are handed to the selection-sort kernel -- the results are the reference's throughout."""
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    n = 700
+    x = cloud(33, 3, n)
+    x[:, 100:160] = x[:, 300:360]                 # 60 duplicated points: ties for them and their neighbours
+    x[1, 5, 0] = np.inf                           # one point at infinity: NaN / inf distances
+    q = np.concatenate([x[:, :200], cloud(34, 3, 50)], axis=1)
+    for k in (3, 8):
+        want_val, want_idx = oracle.knn_point(k, x, q)
+        val, idx = ops.knn_point(k, _t(x), _t(q))
+        assert np.array_equal(idx.cpu().numpy(), want_idx)
+        assert np.array_equal(val.cpu().numpy(), want_val, equal_nan=True)
+    x[1, 5, 0] = 0.25
+    assert np.array_equal(ops.knn_dists(_t(x), 8).cpu().numpy(), oracle.knn_dists(x, 8))
 
 
 def test_knn_dists_vs_oracle_and_defense(oracle):

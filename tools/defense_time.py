@@ -1,0 +1,30 @@
+"""Timing of the kNN grouping operators and the two defenses at BASELINE config 3's shape (B = 256, N = 2048).
+    python tools/defense_time.py"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from geometric_adv_amd import ops, defense, weights as W
+from geometric_adv_amd.autoencoder import PointNetAE
+B, N = 256, 2048
+rng = np.random.default_rng(3)
+x = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)
+xs = torch.as_tensor(x).cuda()
+
+
+def timed(f, reps=5):
+    f(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+
+
+out = {"batch": B, "n_points": N}
+out["knn_dists_k8_ms"] = timed(lambda: ops.knn_dists(xs, 8))
+out["knn_point_k8_ms"] = timed(lambda: ops.knn_point(8, xs, xs))
+out["query_ball_point_r0.1_ns32_ms"] = timed(lambda: ops.query_ball_point(0.1, 32, xs, xs))
+idx = ops.knn_point(8, xs, xs)[1]
+out["group_point_k8_ms"] = timed(lambda: ops.group_point(xs, idx))
+w = W.synthetic_weights(N, seed=7); ae = PointNetAE(w, N)
+out["defend_surface_ms"] = timed(lambda: defense.defend_surface(ae, x, x), reps=2)
+out["defend_critical_ms"] = timed(lambda: defense.defend_critical(ae, x, x), reps=2)
+out["pairs_G"] = B * N * N / 1e9
+print(json.dumps(out))
