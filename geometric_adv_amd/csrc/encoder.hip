@@ -177,11 +177,24 @@ constexpr int MASK_WORDS = 18;
 constexpr int MASK_OFF2 = 2, MASK_OFF3 = 6, MASK_OFF4 = 10;
 constexpr size_t FWD2_LDS_BYTES_MASKS = FWD2_LDS_BYTES + sizeof(unsigned) * 64 * MASK_WORDS;
 
-// lane r (< 16) collects the two mask words of accumulator register r: rows acc_row(r, 0) and acc_row(r, 1)
+// lane r (< 16) collects the two mask words of accumulator register r: rows acc_row(r, 0) and acc_row(r, 1).
+// v_writelane_b32 moves each half of the ballot (an SGPR pair) into that lane with ONE VALU instruction; the portable
+// form `if (lane == r) { wl = lo; wh = hi; }` costs a v_mov + v_cndmask per word (a select cannot read two SGPR operands).
+#define GA_WRITELANE_CASE(L) case L: asm("v_writelane_b32 %0, %1, " #L : "+v"(dst) : "s"(src)); break;
+__device__ __forceinline__ void writelane16(unsigned &dst, unsigned src, int lane_sel) {   // lane_sel: constant after unrolling
+    switch (lane_sel) {
+        GA_WRITELANE_CASE(0) GA_WRITELANE_CASE(1) GA_WRITELANE_CASE(2) GA_WRITELANE_CASE(3)
+        GA_WRITELANE_CASE(4) GA_WRITELANE_CASE(5) GA_WRITELANE_CASE(6) GA_WRITELANE_CASE(7)
+        GA_WRITELANE_CASE(8) GA_WRITELANE_CASE(9) GA_WRITELANE_CASE(10) GA_WRITELANE_CASE(11)
+        GA_WRITELANE_CASE(12) GA_WRITELANE_CASE(13) GA_WRITELANE_CASE(14) GA_WRITELANE_CASE(15)
+    }
+}
+#undef GA_WRITELANE_CASE
 #define MASK_COLLECT(r, positive, wl, wh)                                   \
     do {                                                                    \
         const unsigned long long bal_ = __ballot(positive);                 \
-        if (lane == (r)) { wl = (unsigned)bal_; wh = (unsigned)(bal_ >> 32); } \
+        writelane16(wl, (unsigned)bal_, r);                                 \
+        writelane16(wh, (unsigned)(bal_ >> 32), r);                         \
     } while (0)
 
 // B-fragment ring carried ACROSS chains: while the last four k-groups of a chain run, the freed
@@ -194,15 +207,22 @@ __device__ __forceinline__ void ring_fill(BRing &r, const float4 *bp) { r.b[0] =
 // nt k-groups (multiple of 4) starting at fragment pointer bp (lane offset included); A rows from `ar`
 // (lane's row, +4*h applied), first A k-group index at0.  ring holds fragments 0..3 of this chain on entry
 // and fragments 0..3 of the chain at bp_next on exit (if bp_next).
-__device__ __forceinline__ void chain_ring(const float *ar, int at0, const float4 *bp, int nt, BRing &ring,
+// NT (chain length in k-groups) is a compile-time constant -- the encoder widths are fixed (ae_create checks them) -- so
+// the chain is fully unrolled: the first MFMA takes the inline constant 0 as its accumulator (no 16 x v_mov per chain),
+// every A / B address is base + immediate, and no select survives.  That matters more than it looks: plain VALU
+// instructions do NOT overlap with the matrix pipe on this part (tools/mfma_probe.py: 4 MFMA + 16 v_add_f32 per group
+// runs 14 % slower than the MFMAs alone), so every VALU instruction of this kernel is paid in MFMA time.
+template <int NT>
+__device__ __forceinline__ void chain_ring(const float *ar, int at0, const float4 *bp, BRing &ring,
                                            const float4 *bp_next, f32x16 (&acc)[1]) {
+    static_assert(NT % 4 == 0, "chain lengths are multiples of four k-groups");
     float4 a0[1], a1[1];
     a0[0] = *reinterpret_cast<const float4 *>(ar + 8 * at0);
-    for (int t = 0; t < nt; t += 4) {
-        // every refill is UNCONDITIONAL (a clamped, always valid address): with a branch around a load the
-        // compiler can no longer count outstanding loads and degrades the s_waitcnt vmcnt(3) below to
-        // vmcnt(2)/(1)/(0), i.e. it drains the ring every four k-groups
-        const bool more = t + 4 < nt;
+#pragma unroll
+    for (int t = 0; t < NT; t += 4) {
+        // every refill is UNCONDITIONAL (an always valid address): with a branch around a load the compiler can no
+        // longer count outstanding loads and degrades the s_waitcnt vmcnt(3) below to vmcnt(2)/(1)/(0)
+        const bool more = t + 4 < NT;
         const float4 *src = more ? bp + (size_t)(t + 4) * 64 : (bp_next ? bp_next : bp);
         a1[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + t + 1));
         __builtin_amdgcn_sched_barrier(0);       // the next A fragment is requested BEFORE this group's MFMAs issue
@@ -213,17 +233,17 @@ __device__ __forceinline__ void chain_ring(const float *ar, int at0, const float
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<1>(a1, ring.b[1], acc);
         ring.b[1] = ld_pinned(src + 64);
-        __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
+        __builtin_amdgcn_sched_barrier(0);
         a1[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + t + 3));
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<1>(a0, ring.b[2], acc);
         ring.b[2] = ld_pinned(src + 128);
-        __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
+        __builtin_amdgcn_sched_barrier(0);
         a0[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + (more ? t + 4 : t)));
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<1>(a1, ring.b[3], acc);
         ring.b[3] = ld_pinned(src + 192);
-        __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     const int h = lane >> 5, i = lane & 31;
     const int cb = wave & 3, rb = wave >> 2;          // this wave's (column block, row block) unit in every 128-wide product
     // fragment bases of this wave's eight chains
-    const int kg1 = A.enc_fwd[1].K >> 3, kg2 = A.enc_fwd[2].K >> 3, kg3 = A.enc_fwd[3].K >> 3, kg4 = A.enc_fwd[4].K >> 3;
+    constexpr int kg1 = 64 >> 3, kg2 = 128 >> 3, kg3 = 128 >> 3, kg4 = 256 >> 3;   // k-groups of layers 1-4 (widths fixed, ae.hip)
     const float4 *w1 = reinterpret_cast<const float4 *>(A.enc_fwd[1].w) + (size_t)cb * kg1 * 64 + lane;
     const float4 *w2 = reinterpret_cast<const float4 *>(A.enc_fwd[2].w) + (size_t)cb * kg2 * 64 + lane;
     const float4 *w3a = reinterpret_cast<const float4 *>(A.enc_fwd[3].w) + (size_t)cb * kg3 * 64 + lane;
@@ -313,17 +333,19 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     const int mrow = orow_of(rb) + (lane & 3) + 8 * ((lane & 15) >> 2);    // lanes 0-15: row acc_row(lane, 0) of this wave's block
 
     const int orow = orow_of(rb);                     // accumulator rows of this wave: orow + acc_row(r, h)
+    // epilogue stores: one lane-dependent base per buffer, the register's row as an immediate offset
+    float *bufA_w = bufA + (orow + 4 * h) * 132 + ccol, *bufB_w = bufB + (orow + 4 * h) * 132 + ccol;
     // ---- layer 1: 64 -> 128, canonical K halves (4 + 4 k-groups) ----
     {
         const float *ar = bufA + (orow + i) * 68 + 4 * h;
         f32x16 acc[1] = {}, part[1] = {};
-        chain_ring(ar, 0, w1, kg1 / 2, ring, w1 + (size_t)(kg1 / 2) * 64, acc);
-        chain_ring(ar, kg1 / 2, w1 + (size_t)(kg1 / 2) * 64, kg1 / 2, ring, w2, part);
+        chain_ring<kg1 / 2>(ar, 0, w1, ring, w1 + (size_t)(kg1 / 2) * 64, acc);
+        chain_ring<kg1 / 2>(ar, kg1 / 2, w1 + (size_t)(kg1 / 2) * 64, ring, w2, part);
         unsigned wl = 0, wh = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = fmaxf(fmaf(acc[0][r] + part[0][r], sc1, sh1), 0.f);
-            bufB[(orow + acc_row(r, h)) * 132 + ccol] = v;
+            bufB_w[acc_row(r, 0) * 132] = v;
             if (MASKS) MASK_COLLECT(r, v > 0.f, wl, wh);
         }
         if (MASKS && lane < 16) { mtile[mrow * MASK_WORDS + MASK_OFF2 + cb] = wl; mtile[(mrow + 4) * MASK_WORDS + MASK_OFF2 + cb] = wh; }
@@ -334,13 +356,13 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     {
         const float *ar = bufB + (orow + i) * 132 + 4 * h;
         f32x16 acc[1] = {}, part[1] = {};
-        chain_ring(ar, 0, w2, kg2 / 2, ring, w2 + (size_t)(kg2 / 2) * 64, acc);
-        chain_ring(ar, kg2 / 2, w2 + (size_t)(kg2 / 2) * 64, kg2 / 2, ring, w3a, part);
+        chain_ring<kg2 / 2>(ar, 0, w2, ring, w2 + (size_t)(kg2 / 2) * 64, acc);
+        chain_ring<kg2 / 2>(ar, kg2 / 2, w2 + (size_t)(kg2 / 2) * 64, ring, w3a, part);
         unsigned wl = 0, wh = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = fmaxf(fmaf(acc[0][r] + part[0][r], sc2, sh2), 0.f);
-            bufA[(orow + acc_row(r, h)) * 132 + ccol] = v;
+            bufA_w[acc_row(r, 0) * 132] = v;
             if (MASKS) MASK_COLLECT(r, v > 0.f, wl, wh);
         }
         if (MASKS && lane < 16) { mtile[mrow * MASK_WORDS + MASK_OFF3 + cb] = wl; mtile[(mrow + 4) * MASK_WORDS + MASK_OFF3 + cb] = wh; }
@@ -354,13 +376,13 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         {
             const float *ar = bufA + (orow + i) * 132 + 4 * h;
             f32x16 acc[1] = {};
-            chain_ring(ar, 0, half ? w3b : w3a, kg3, ring, w4 + (size_t)(kg4 / 2) * half * 64, acc);   // one full-K chain
+            chain_ring<kg3>(ar, 0, half ? w3b : w3a, ring, w4 + (size_t)(kg4 / 2) * half * 64, acc);   // one full-K chain
             const float sc = half ? sc3b : sc3a, sh = half ? sh3b : sh3a;
             unsigned wl = 0, wh = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = fmaxf(fmaf(acc[0][r], sc, sh), 0.f);
-                bufB[(orow + acc_row(r, h)) * 132 + ccol] = v;
+                bufB_w[acc_row(r, 0) * 132] = v;
                 if (MASKS) MASK_COLLECT(r, v > 0.f, wl, wh);
             }
             if (MASKS && lane < 16) {
@@ -371,23 +393,30 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         stamp(4 + 2 * half);
         {
             const float *ar = bufB + (orow + i) * 132 + 4 * h;
-            chain_ring(ar, 0, w4 + (size_t)(kg4 / 2) * half * 64, kg4 / 2, ring, half ? nullptr : w3b, acc4);
+            chain_ring<kg4 / 2>(ar, 0, w4 + (size_t)(kg4 / 2) * half * 64, ring, half ? nullptr : w3b, acc4);
         }
         if (half == 0) __syncthreads();               // bufB is rewritten by the second half of layer 3
         stamp(5 + 2 * half);
     }
-    // canonical combination: part0 + part1, then BN + ReLU and the max-pool from the registers
+    // BN + ReLU and the max-pool from the registers: maximum, FIRST row attaining it, number of rows attaining it.
+    // Two branch-free passes (max, then compare) -- a third of the VALU instructions of the if / else-if form.
     const int col = ccol;
     float mx = -1.f;
     int arg = INT_MAX, cnt = 0;
+    {
+        float v[16];
+        const bool whole = n0 + ROWS <= n;                // only the last tile of a cloud can hold rows beyond n
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = orow + acc_row(r, h);
-        const float a = acc4[0][r];
-        const float v = fmaxf(fmaf(a, sc4, sh4), 0.f);
-        if (n0 + row < n) {
-            if (v > mx) { mx = v; arg = n0 + row; cnt = 1; }
-            else if (v == mx) cnt++;
+        for (int r = 0; r < 16; ++r) {
+            v[r] = fmaxf(fmaf(acc4[0][r], sc4, sh4), 0.f);
+            if (!whole && n0 + orow + acc_row(r, h) >= n) v[r] = -2.f;      // never the maximum, never equal to it
+            mx = fmaxf(mx, v[r]);
+        }
+#pragma unroll
+        for (int r = 15; r >= 0; --r) {                   // rows ascend with r: the last hit kept is the lowest row
+            const bool hit = v[r] == mx;
+            arg = hit ? n0 + orow + acc_row(r, h) : arg;
+            cnt += hit ? 1 : 0;
         }
     }
     {

@@ -70,16 +70,92 @@ __global__ __launch_bounds__(256) void mb_mfma_kernel(float *out, int iters) {
     if (r == 123.456f) out[0] = r;
 }
 
+// Issue-slot probe (which = 15..17): 16 dependent 32x32x2 MFMAs per iteration plus NV independent v_add_f32 per group of four
+// (NV = 4, 8, 16).  If plain VALU instructions of the same or of other waves overlapped with the matrix pipe, the time
+// would not move.
+template <int NV>
+__global__ __launch_bounds__(256) void mb_mix_kernel(float *out, int iters) {
+    const float a = 1.0f + 1e-7f * threadIdx.x, b = 0.5f;
+    mb16 acc = {};
+    float s[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = a + i;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) asm volatile("v_add_f32 %0, %0, %1" : "+v"(s[v]) : "v"(b));
+        }
+    float r = acc[0] + acc[15];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += s[i];
+    if (r == 123.456f) out[0] = r;
+}
+
+// Operand-delivery probes (which = 10..12): the encoder's inner loop shape -- per k-group one ds_read_b128 (A fragment, LDS)
+// and one 1 KiB global_load_dwordx4 per wave (B fragment, L2-resident weights, 4-deep register ring), then 4 dependent
+// v_mfma_f32_32x32x2_f32 -- with the epilogues, barriers and prologue taken away.  512 threads, 72 KB of LDS per
+// workgroup (two per CU, 4 waves per SIMD, like encoder_fwd2_kernel).
+//   10: MFMAs + LDS reads, 11: MFMAs + global ring, 12: both
+template <int WHICH>
+__global__ __launch_bounds__(512, 4) void mb_feed_kernel(float *out, const float4 *wts, int wts_groups, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float mb_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < 64 * 132; e += 512) mb_lds[e] = 1.0f + 1e-6f * e;
+    __syncthreads();
+    const float *ar = mb_lds + ((wave >> 2) * 32 + (lane & 31)) * 132 + 4 * (lane >> 5);
+    const float4 *bp = wts + lane + (size_t)(wave & 3) * 16 * 64;
+    mb16 acc = {};
+    float4 ring[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ring[u] = bp[(size_t)u * 64];
+    float4 a = *reinterpret_cast<const float4 *>(ar);
+    int g = 4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 an = a;
+            if (WHICH != 11) an = *reinterpret_cast<const float4 *>(ar + 8 * ((it * 4 + u + 1) & 15));
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 b = ring[u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            if (WHICH != 10) {
+                typedef float v4 __attribute__((ext_vector_type(4)));
+                const v4 t = *reinterpret_cast<const v4 *>(bp + (size_t)g * 64);
+                ring[u] = make_float4(t.x, t.y, t.z, t.w);
+                g = g + 1 < wts_groups ? g + 1 : 0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a = an;
+        }
+    }
+    if (acc[0] + acc[15] == 123.456f) out[0] = acc[0];
+}
+
 }  // namespace geoadv
 using namespace geoadv;
 
 // ms = time of one launch of 2048 workgroups x 256 threads, each thread issuing 16*iters VALU
 // instructions of the selected kind.
 extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) {
-    GA_REQUIRE(which >= 0 && which <= 9 && iters > 0 && ms, "microbench: bad arguments");
+    GA_REQUIRE(which >= 0 && which <= 17 && iters > 0 && ms, "microbench: bad arguments");
     hipStream_t st = as_stream(stream);
     float *out = nullptr;
     GA_HIP(hipMalloc(&out, 64));
+    const int groups = 352;                                  // 352 KiB of "weights": the encoder's 361 KB, L2-resident (13 / 14: 16 KB / 4 MB)
+    float4 *wts = nullptr;
+    if (which >= 10) {
+        GA_HIP(hipMalloc(&wts, sizeof(float4) * 64 * (size_t)(4096 + 64)));
+        GA_HIP(hipMemset(wts, 0, sizeof(float4) * 64 * (size_t)(4096 + 64)));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mb_feed_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mb_feed_kernel<11>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mb_feed_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    }
     hipEvent_t e0, e1;
     GA_HIP(hipEventCreate(&e0));
     GA_HIP(hipEventCreate(&e1));
@@ -95,7 +171,15 @@ extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) 
             case 6: mb_mfma_kernel<6><<<4096, 256, 0, st>>>(out, iters); break;
             case 7: mb_mfma_kernel<7><<<4096, 256, 0, st>>>(out, iters); break;
             case 8: mb_mfma_kernel<8><<<4096, 256, 0, st>>>(out, iters); break;
-            default: mb_mfma_kernel<9><<<4096, 256, 0, st>>>(out, iters); break;
+            case 9: mb_mfma_kernel<9><<<4096, 256, 0, st>>>(out, iters); break;
+            case 10: mb_feed_kernel<10><<<1024, 512, 72 * 1024, st>>>(out, wts, groups, iters); break;
+            case 11: mb_feed_kernel<11><<<1024, 512, 72 * 1024, st>>>(out, wts, groups, iters); break;
+            case 12: mb_feed_kernel<12><<<1024, 512, 72 * 1024, st>>>(out, wts, groups, iters); break;
+            case 13: mb_feed_kernel<11><<<1024, 512, 72 * 1024, st>>>(out, wts, 4, iters); break;        // 16 KB of weights: L1 hits
+            case 14: mb_feed_kernel<11><<<1024, 512, 72 * 1024, st>>>(out, wts, 4096, iters); break;     // 4 MB: streams through L2
+            case 15: mb_mix_kernel<4><<<4096, 256, 0, st>>>(out, iters); break;
+            case 16: mb_mix_kernel<8><<<4096, 256, 0, st>>>(out, iters); break;
+            default: mb_mix_kernel<16><<<4096, 256, 0, st>>>(out, iters); break;
         }
         GA_LAUNCH_CHECK();
         GA_HIP(hipEventRecord(e1, st));
@@ -105,5 +189,6 @@ extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) 
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(out);
+    if (wts) (void)hipFree(wts);
     return GEOADV_OK;
 }
