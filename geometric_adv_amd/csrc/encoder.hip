@@ -202,47 +202,64 @@ __device__ __forceinline__ void writelane16(unsigned &dst, unsigned src, int lan
 // activations, so the request may cross the epilogue and the barrier).  Without it every chain start
 // exposes one L2 round trip (~900 cycles, 8 chains per tile = 13 % of the tile).
 struct BRing { float4 b[4]; };
-__device__ __forceinline__ void ring_fill(BRing &r, const float4 *bp) { r.b[0] = bp[0]; r.b[1] = bp[64]; r.b[2] = bp[128]; r.b[3] = bp[192]; }
-
-// nt k-groups (multiple of 4) starting at fragment pointer bp (lane offset included); A rows from `ar`
-// (lane's row, +4*h applied), first A k-group index at0.  ring holds fragments 0..3 of this chain on entry
-// and fragments 0..3 of the chain at bp_next on exit (if bp_next).
+// B fragments come through BUFFER loads: descriptor (the layer's packed weights) and byte offset of the fragment in SGPRs,
+// the lane's 16 bytes in one VGPR, 0 / 1 / 2 / 3 KiB as the instruction's immediate -- so stepping to the next fragments is
+// scalar arithmetic.  (A global_load from `uniform pointer + lane` ends up with a 64-bit VGPR address and a
+// v_lshl_add_u64 per step: the compiler hoists the sum.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct FragSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int off;                                               // wave-uniform byte offset of the chain's first fragment
+};
+__device__ __forceinline__ FragSrc frag_src(const float *w, int first_kgroup) {
+    return FragSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, 0x7fffffff, 0x00020000), first_kgroup * 1024};
+}
+__device__ __forceinline__ FragSrc frag_at(const FragSrc &f, int kgroups) { return FragSrc{f.rsrc, f.off + kgroups * 1024}; }
+__device__ __forceinline__ float4 ld_frag(const FragSrc &f, int kgroup, unsigned lane_bytes) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(f.rsrc, lane_bytes, f.off + kgroup * 1024, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+}
+__device__ __forceinline__ void ring_fill(BRing &r, const FragSrc &f, unsigned lb) {
+    r.b[0] = ld_frag(f, 0, lb); r.b[1] = ld_frag(f, 1, lb); r.b[2] = ld_frag(f, 2, lb); r.b[3] = ld_frag(f, 3, lb);
+}
 // NT (chain length in k-groups) is a compile-time constant -- the encoder widths are fixed (ae_create checks them) -- so
 // the chain is fully unrolled: the first MFMA takes the inline constant 0 as its accumulator (no 16 x v_mov per chain),
 // every A / B address is base + immediate, and no select survives.  That matters more than it looks: plain VALU
 // instructions do NOT overlap with the matrix pipe on this part (tools/mfma_probe.py: 4 MFMA + 16 v_add_f32 per group
 // runs 14 % slower than the MFMAs alone), so every VALU instruction of this kernel is paid in MFMA time.
-template <int NT>
-__device__ __forceinline__ void chain_ring(const float *ar, int at0, const float4 *bp, BRing &ring,
-                                           const float4 *bp_next, f32x16 (&acc)[1]) {
+template <int NT, bool HAS_NEXT>
+__device__ __forceinline__ void chain_ring(const float *ar, int at0, const FragSrc &cur, unsigned lb, BRing &ring,
+                                           const FragSrc &next, f32x16 (&acc)[1]) {
     static_assert(NT % 4 == 0, "chain lengths are multiples of four k-groups");
     float4 a0[1], a1[1];
     a0[0] = *reinterpret_cast<const float4 *>(ar + 8 * at0);
 #pragma unroll
     for (int t = 0; t < NT; t += 4) {
-        // every refill is UNCONDITIONAL (an always valid address): with a branch around a load the compiler can no
-        // longer count outstanding loads and degrades the s_waitcnt vmcnt(3) below to vmcnt(2)/(1)/(0)
+        // every refill is UNCONDITIONAL (an always valid address: the chain's own first fragments if nothing follows):
+        // with a branch around a load the compiler can no longer count outstanding loads and degrades the
+        // s_waitcnt vmcnt(3) below to vmcnt(2)/(1)/(0)
         const bool more = t + 4 < NT;
-        const float4 *src = more ? bp + (size_t)(t + 4) * 64 : (bp_next ? bp_next : bp);
+        const FragSrc &src = more ? cur : (HAS_NEXT ? next : cur);
+        const int g = more ? t + 4 : 0;
         a1[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + t + 1));
         __builtin_amdgcn_sched_barrier(0);       // the next A fragment is requested BEFORE this group's MFMAs issue
         mfma_group<1>(a0, ring.b[0], acc);
-        ring.b[0] = ld_pinned(src + 0);
+        ring.b[0] = ld_frag(src, g + 0, lb);
         __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
         a0[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + t + 2));
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<1>(a1, ring.b[1], acc);
-        ring.b[1] = ld_pinned(src + 64);
+        ring.b[1] = ld_frag(src, g + 1, lb);
         __builtin_amdgcn_sched_barrier(0);
         a1[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + t + 3));
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<1>(a0, ring.b[2], acc);
-        ring.b[2] = ld_pinned(src + 128);
+        ring.b[2] = ld_frag(src, g + 2, lb);
         __builtin_amdgcn_sched_barrier(0);
         a0[0] = *reinterpret_cast<const float4 *>(ar + 8 * (at0 + (more ? t + 4 : t)));
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<1>(a1, ring.b[3], acc);
-        ring.b[3] = ld_pinned(src + 192);
+        ring.b[3] = ld_frag(src, g + 3, lb);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -270,18 +287,20 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     int *redc = reda + 256;
     unsigned *mtile = reinterpret_cast<unsigned *>(redc + 256);   // [64][MASK_WORDS] (MASKS only)
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: everything derived from it (weight bases, row block offsets) then lives in SGPRs, the
+    // B-fragment loads use the SGPR-base + lane-offset form and their address updates are SALU work -- VALU instructions
+    // cost matrix-pipe time here, SALU instructions do not
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, i = lane & 31;
     const int cb = wave & 3, rb = wave >> 2;          // this wave's (column block, row block) unit in every 128-wide product
     // fragment bases of this wave's eight chains
     constexpr int kg1 = 64 >> 3, kg2 = 128 >> 3, kg3 = 128 >> 3, kg4 = 256 >> 3;   // k-groups of layers 1-4 (widths fixed, ae.hip)
-    const float4 *w1 = reinterpret_cast<const float4 *>(A.enc_fwd[1].w) + (size_t)cb * kg1 * 64 + lane;
-    const float4 *w2 = reinterpret_cast<const float4 *>(A.enc_fwd[2].w) + (size_t)cb * kg2 * 64 + lane;
-    const float4 *w3a = reinterpret_cast<const float4 *>(A.enc_fwd[3].w) + (size_t)cb * kg3 * 64 + lane;
-    const float4 *w3b = reinterpret_cast<const float4 *>(A.enc_fwd[3].w) + (size_t)(4 + cb) * kg3 * 64 + lane;
-    const float4 *w4 = reinterpret_cast<const float4 *>(A.enc_fwd[4].w) + (size_t)cb * kg4 * 64 + lane;
+    const FragSrc w1 = frag_src(A.enc_fwd[1].w, cb * kg1), w2 = frag_src(A.enc_fwd[2].w, cb * kg2);     // wave-uniform
+    const FragSrc w3a = frag_src(A.enc_fwd[3].w, cb * kg3), w3b = frag_src(A.enc_fwd[3].w, (4 + cb) * kg3);
+    const FragSrc w4 = frag_src(A.enc_fwd[4].w, cb * kg4);
+    const unsigned lb = (unsigned)lane * 16u;         // this lane's 16 bytes of every 1 KiB fragment
     BRing ring;
-    ring_fill(ring, w1);                              // in flight during the point load and layer 0
+    ring_fill(ring, w1, lb);                          // in flight during the point load and layer 0
     // every per-lane constant is requested up front too (a load at its point of use costs an exposed
     // L2 round trip per epilogue): BN scale/shift of this lane's column in layers 1-4 ...
     const int ccol = cb * 32 + i;
@@ -339,8 +358,8 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     {
         const float *ar = bufA + (orow + i) * 68 + 4 * h;
         f32x16 acc[1] = {}, part[1] = {};
-        chain_ring<kg1 / 2>(ar, 0, w1, ring, w1 + (size_t)(kg1 / 2) * 64, acc);
-        chain_ring<kg1 / 2>(ar, kg1 / 2, w1 + (size_t)(kg1 / 2) * 64, ring, w2, part);
+        chain_ring<kg1 / 2, true>(ar, 0, w1, lb, ring, frag_at(w1, kg1 / 2), acc);
+        chain_ring<kg1 / 2, true>(ar, kg1 / 2, frag_at(w1, kg1 / 2), lb, ring, w2, part);
         unsigned wl = 0, wh = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -356,8 +375,8 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     {
         const float *ar = bufB + (orow + i) * 132 + 4 * h;
         f32x16 acc[1] = {}, part[1] = {};
-        chain_ring<kg2 / 2>(ar, 0, w2, ring, w2 + (size_t)(kg2 / 2) * 64, acc);
-        chain_ring<kg2 / 2>(ar, kg2 / 2, w2 + (size_t)(kg2 / 2) * 64, ring, w3a, part);
+        chain_ring<kg2 / 2, true>(ar, 0, w2, lb, ring, frag_at(w2, kg2 / 2), acc);
+        chain_ring<kg2 / 2, true>(ar, kg2 / 2, frag_at(w2, kg2 / 2), lb, ring, w3a, part);
         unsigned wl = 0, wh = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         {
             const float *ar = bufA + (orow + i) * 132 + 4 * h;
             f32x16 acc[1] = {};
-            chain_ring<kg3>(ar, 0, half ? w3b : w3a, ring, w4 + (size_t)(kg4 / 2) * half * 64, acc);   // one full-K chain
+            chain_ring<kg3, true>(ar, 0, half ? w3b : w3a, lb, ring, frag_at(w4, (kg4 / 2) * half), acc);   // one full-K chain
             const float sc = half ? sc3b : sc3a, sh = half ? sh3b : sh3a;
             unsigned wl = 0, wh = 0;
 #pragma unroll
@@ -393,7 +412,8 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         stamp(4 + 2 * half);
         {
             const float *ar = bufB + (orow + i) * 132 + 4 * h;
-            chain_ring<kg4 / 2>(ar, 0, w4 + (size_t)(kg4 / 2) * half * 64, ring, half ? nullptr : w3b, acc4);
+            if (half == 0) chain_ring<kg4 / 2, true>(ar, 0, w4, lb, ring, w3b, acc4);
+            else chain_ring<kg4 / 2, false>(ar, 0, frag_at(w4, kg4 / 2), lb, ring, w4, acc4);
         }
         if (half == 0) __syncthreads();               // bufB is rewritten by the second half of layer 3
         stamp(5 + 2 * half);

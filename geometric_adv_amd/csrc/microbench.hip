@@ -70,6 +70,42 @@ __global__ __launch_bounds__(256) void mb_mfma_kernel(float *out, int iters) {
     if (r == 123.456f) out[0] = r;
 }
 
+// Plain VALU issue rates by opcode (which = 18..27): 16 * iters instructions per lane, eight independent chains.
+//   18 v_add_f32  19 v_mul_f32  20 v_sub_f32  21 v_min_u32  22 v_min3_f32  23 v_min3_u32  24 v_max_f32  25 v_cndmask_b32
+//   26 v_cmp_lt_f32 (to SGPR pair)  27 v_mov_b32  28 v_cndmask_b32_e64 (SGPR-pair mask)  29 v_writelane_b32  30 v_fma_f32
+//   31 v_lshl_add_u32 + v_add_u32
+template <int WHICH>
+__global__ __launch_bounds__(256) void mb_op_kernel(float *out, int iters) {
+    float s = 1.0f + 1e-7f * threadIdx.x;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.5f + i;
+    const unsigned long long msk = __ballot((threadIdx.x & 3) == 1) + (unsigned long long)iters;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (WHICH == 18) asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 19) asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 20) asm volatile("v_sub_f32 %0, %0, %1\n\tv_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 21) asm volatile("v_min_u32 %0, %0, %1\n\tv_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 22) asm volatile("v_min3_f32 %0, %0, %1, %1\n\tv_min3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 23) asm volatile("v_min3_u32 %0, %0, %1, %1\n\tv_min3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 24) asm volatile("v_max_f32 %0, %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 25) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(s) : "vcc");
+            else if (WHICH == 26) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1\n\tv_cmp_lt_f32 s[22:23], %1, %0" : "+v"(a[i]) : "v"(s) : "s20", "s21", "s22", "s23");
+            else if (WHICH == 27) asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %0, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 28) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "s"(msk));
+            else if (WHICH == 29) asm volatile("v_writelane_b32 %0, %1, 3\n\tv_writelane_b32 %0, %1, 5" : "+v"(a[i]) : "s"((unsigned)msk));
+            else if (WHICH == 30) asm volatile("v_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(s));
+            else asm volatile("v_lshl_add_u32 %0, %0, 1, %1\n\tv_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        }
+    }
+    float acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += a[i];
+    if (acc == 123.456f) out[0] = acc;
+}
+
 // Issue-slot probe (which = 15..17): 16 dependent 32x32x2 MFMAs per iteration plus NV independent v_add_f32 per group of four
 // (NV = 4, 8, 16).  If plain VALU instructions of the same or of other waves overlapped with the matrix pipe, the time
 // would not move.
@@ -143,7 +179,7 @@ using namespace geoadv;
 // ms = time of one launch of 2048 workgroups x 256 threads, each thread issuing 16*iters VALU
 // instructions of the selected kind.
 extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) {
-    GA_REQUIRE(which >= 0 && which <= 17 && iters > 0 && ms, "microbench: bad arguments");
+    GA_REQUIRE(which >= 0 && which <= 31 && iters > 0 && ms, "microbench: bad arguments");
     hipStream_t st = as_stream(stream);
     float *out = nullptr;
     GA_HIP(hipMalloc(&out, 64));
@@ -179,7 +215,21 @@ extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) 
             case 14: mb_feed_kernel<11><<<1024, 512, 72 * 1024, st>>>(out, wts, 4096, iters); break;     // 4 MB: streams through L2
             case 15: mb_mix_kernel<4><<<4096, 256, 0, st>>>(out, iters); break;
             case 16: mb_mix_kernel<8><<<4096, 256, 0, st>>>(out, iters); break;
-            default: mb_mix_kernel<16><<<4096, 256, 0, st>>>(out, iters); break;
+            case 17: mb_mix_kernel<16><<<4096, 256, 0, st>>>(out, iters); break;
+            case 18: mb_op_kernel<18><<<2048, 256, 0, st>>>(out, iters); break;
+            case 19: mb_op_kernel<19><<<2048, 256, 0, st>>>(out, iters); break;
+            case 20: mb_op_kernel<20><<<2048, 256, 0, st>>>(out, iters); break;
+            case 21: mb_op_kernel<21><<<2048, 256, 0, st>>>(out, iters); break;
+            case 22: mb_op_kernel<22><<<2048, 256, 0, st>>>(out, iters); break;
+            case 23: mb_op_kernel<23><<<2048, 256, 0, st>>>(out, iters); break;
+            case 24: mb_op_kernel<24><<<2048, 256, 0, st>>>(out, iters); break;
+            case 25: mb_op_kernel<25><<<2048, 256, 0, st>>>(out, iters); break;
+            case 26: mb_op_kernel<26><<<2048, 256, 0, st>>>(out, iters); break;
+            case 27: mb_op_kernel<27><<<2048, 256, 0, st>>>(out, iters); break;
+            case 28: mb_op_kernel<28><<<2048, 256, 0, st>>>(out, iters); break;
+            case 29: mb_op_kernel<29><<<2048, 256, 0, st>>>(out, iters); break;
+            case 30: mb_op_kernel<30><<<2048, 256, 0, st>>>(out, iters); break;
+            default: mb_op_kernel<31><<<2048, 256, 0, st>>>(out, iters); break;
         }
         GA_LAUNCH_CHECK();
         GA_HIP(hipEventRecord(e1, st));

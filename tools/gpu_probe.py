@@ -21,6 +21,14 @@ for w, nm in enumerate(names):
     out["valu_" + nm] = {"ms": ms, "Tinstr_lane_per_s": inst / ms / 1e9}
     print(nm, ms, "ms", inst / ms / 1e9, "T lane-instr/s")
 
+for w, nm in zip(range(18, 32), ["add", "mul", "sub", "min_u32", "min3_f32", "min3_u32", "max_f32", "cndmask_vcc", "cmp_lt_f32", "mov",
+                            "cndmask_sgpr_mask", "writelane", "fma", "lshl_add_u32+add_u32"]):
+    ms = min(ops.microbench(w, iters) for _ in range(2))
+    inst = 2048 * 256 * 16 * iters
+    cyc = ms * 1e-3 * 2.4e9 * 1024 / (2048 * 4 * 16 * iters)      # SIMD cycles per wave instruction at 2.4 GHz
+    out["valu_" + nm] = {"ms": ms, "Tinstr_lane_per_s": inst / ms / 1e9, "cycles_per_wave_instr": cyc}
+    print(nm, round(ms, 3), "ms", round(inst / ms / 1e9, 1), "T lane-instr/s", round(cyc, 2), "cycles/instr")
+
 for (b, n) in [(32, 2048), (4, 2048), (32, 8192), (256, 2048)]:
     x = torch.rand((b, n, 3), device=dev) - 0.5
     y = torch.rand((b, n, 3), device=dev) - 0.5
