@@ -202,23 +202,6 @@ __device__ __forceinline__ void writelane16(unsigned &dst, unsigned src, int lan
 // activations, so the request may cross the epilogue and the barrier).  Without it every chain start
 // exposes one L2 round trip (~900 cycles, 8 chains per tile = 13 % of the tile).
 struct BRing { float4 b[4]; };
-// B fragments come through BUFFER loads: descriptor (the layer's packed weights) and byte offset of the fragment in SGPRs,
-// the lane's 16 bytes in one VGPR, 0 / 1 / 2 / 3 KiB as the instruction's immediate -- so stepping to the next fragments is
-// scalar arithmetic.  (A global_load from `uniform pointer + lane` ends up with a 64-bit VGPR address and a
-// v_lshl_add_u64 per step: the compiler hoists the sum.)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct FragSrc {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int off;                                               // wave-uniform byte offset of the chain's first fragment
-};
-__device__ __forceinline__ FragSrc frag_src(const float *w, int first_kgroup) {
-    return FragSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, 0x7fffffff, 0x00020000), first_kgroup * 1024};
-}
-__device__ __forceinline__ FragSrc frag_at(const FragSrc &f, int kgroups) { return FragSrc{f.rsrc, f.off + kgroups * 1024}; }
-__device__ __forceinline__ float4 ld_frag(const FragSrc &f, int kgroup, unsigned lane_bytes) {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(f.rsrc, lane_bytes, f.off + kgroup * 1024, 0);
-    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
-}
 __device__ __forceinline__ void ring_fill(BRing &r, const FragSrc &f, unsigned lb) {
     r.b[0] = ld_frag(f, 0, lb); r.b[1] = ld_frag(f, 1, lb); r.b[2] = ld_frag(f, 2, lb); r.b[3] = ld_frag(f, 3, lb);
 }

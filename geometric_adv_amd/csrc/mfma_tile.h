@@ -24,6 +24,23 @@ __device__ __forceinline__ float4 ld_pinned(const float4 *p) {
     return make_float4(t.x, t.y, t.z, t.w);
 }
 
+// B fragments come through BUFFER loads: descriptor (the layer's packed weights) and byte offset of the fragment in SGPRs,
+// the lane's 16 bytes in one VGPR, 0 / 1 / 2 / 3 KiB as the instruction's immediate -- so stepping to the next fragments is
+// scalar arithmetic.  (A global_load from `uniform pointer + lane` ends up with a 64-bit VGPR address and a
+// v_lshl_add_u64 per step: the compiler hoists the sum.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct FragSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int off;                                               // wave-uniform byte offset of the chain's first fragment
+};
+__device__ __forceinline__ FragSrc frag_src(const float *w, int first_kgroup) {
+    return FragSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, 0x7fffffff, 0x00020000), first_kgroup * 1024};
+}
+__device__ __forceinline__ FragSrc frag_at(const FragSrc &f, int kgroups) { return FragSrc{f.rsrc, f.off + kgroups * 1024}; }
+__device__ __forceinline__ float4 ld_frag(const FragSrc &f, int kgroup, unsigned lane_bytes) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(f.rsrc, lane_bytes, f.off + kgroup * 1024, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+}
 template <int RM>
 __device__ __forceinline__ void mfma_group(const float4 (&a)[RM], const float4 &b, f32x16 (&acc)[RM]) {
 #pragma unroll
@@ -40,17 +57,20 @@ __device__ __forceinline__ void mfma_group(const float4 (&a)[RM], const float4 &
 // SIMD's MFMA pipe) while an L2 hit takes ~800 cycles under load, so B fragments run through a
 // 4-slot register ring (4 loads in flight); A fragments (LDS, ~130 cycles) are fetched one
 // k-group ahead.
+// cb (the column block) must be wave-uniform and held in an SGPR (layer_gemm reads the wave index with readfirstlane):
+// the fragment offsets are then scalar and the refills cost no VALU instruction.
 template <int RM>
 __device__ __forceinline__ void gemm_chain(const float *in, int s_in, int row0, const PackedLayer &L, int cb, int t0,
                                            int t1, f32x16 (&acc)[RM]) {
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5, i = lane & 31;
     const int kg = L.K >> 3;
-    const float4 *bp = reinterpret_cast<const float4 *>(L.w) + (size_t)cb * kg * 64 + lane;
+    const FragSrc bp = frag_src(L.w, cb * kg);
+    const unsigned lb = (unsigned)lane * 16u;
     const float *ar[RM];
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) ar[rm] = in + (row0 + rm * 32 + i) * s_in + 4 * h;
-    float4 b0 = bp[(size_t)t0 * 64], b1 = bp[(size_t)(t0 + 1) * 64], b2 = bp[(size_t)(t0 + 2) * 64], b3 = bp[(size_t)(t0 + 3) * 64];
+    float4 b0 = ld_frag(bp, t0, lb), b1 = ld_frag(bp, t0 + 1, lb), b2 = ld_frag(bp, t0 + 2, lb), b3 = ld_frag(bp, t0 + 3, lb);
     float4 a0[RM], a1[RM];
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * t0);
@@ -62,25 +82,25 @@ __device__ __forceinline__ void gemm_chain(const float *in, int s_in, int row0, 
         for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 1));
         __builtin_amdgcn_sched_barrier(0);           // A prefetch stays ahead of the MFMA group
         mfma_group<RM>(a0, b0, acc);
-        b0 = ld_pinned(bp + (size_t)tn * 64);
+        b0 = ld_frag(bp, tn, lb);
         __builtin_amdgcn_sched_barrier(0);           // pin the refill between the MFMA groups
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 2));
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<RM>(a1, b1, acc);
-        b1 = ld_pinned(bp + (size_t)(tn + 1) * 64);
+        b1 = ld_frag(bp, tn + 1, lb);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (t + 3));
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<RM>(a0, b2, acc);
-        b2 = ld_pinned(bp + (size_t)(tn + 2) * 64);
+        b2 = ld_frag(bp, tn + 2, lb);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * tn);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<RM>(a1, b3, acc);
-        b3 = ld_pinned(bp + (size_t)(tn + 3) * 64);
+        b3 = ld_frag(bp, tn + 3, lb);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -97,7 +117,7 @@ __device__ __forceinline__ void layer_gemm(const float *in, int s_in, const Pack
     constexpr int KC = KC_REQ > 0 ? KC_REQ : SPARE;
     constexpr int KS = (SPARE >= KC) ? KC : 1;               // K parts computed by different waves, or all by one
     static_assert(KS == KC || KS == 1, "bad K split");
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // scalar: see gemm_chain
     const int h = lane >> 5, i = lane & 31;
     const int unit = wave % UNITS, ks = wave / UNITS;
     const int cb = unit % CB, rb = RM2 ? 0 : unit / CB;
@@ -143,7 +163,7 @@ template <int ROWS, int NOUT>
 __device__ __forceinline__ int layer_gemm_lane_col() {
     constexpr int CB = NOUT / 32, RB = ROWS / 32;
     constexpr int UNITS = (CB * RB > 8) ? CB : CB * RB;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     return ((wave % UNITS) % CB) * 32 + (threadIdx.x & 31);
 }
 
