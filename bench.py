@@ -29,8 +29,8 @@ B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_HBM_FILE = os.path.join(ROOT, "profiles", "r01_v7_pmc_hbm.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-PMC_SQ_FILE = os.path.join(ROOT, "profiles", "r01_v7_pmc_sq.json")       # rocprofv3 --pmc SQ_* pass
+PMC_HBM_FILE = os.path.join(ROOT, "profiles", "r01_v13_pmc_hbm.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SQ_FILE = os.path.join(ROOT, "profiles", "r01_v13_pmc_sq.json")       # rocprofv3 --pmc SQ_* pass
 
 
 def _encoder_entry(d):
@@ -67,7 +67,7 @@ def pmc_traffic_bytes():
     try:
         k = _encoder_entry(json.load(open(PMC_HBM_FILE)))
         fetch, write = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
-        return (2.0 * fetch + write) * 1024.0, "profiles/r01_v7_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
+        return (2.0 * fetch + write) * 1024.0, "profiles/r01_v13_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
     except Exception as e:          # pragma: no cover
         return None, "no PMC profile: %s" % e
 
@@ -210,6 +210,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--slots", type=int, default=0,
+                    help="also measure S concurrent batch slots (secondary.batch_slots; off by default: its overlapping "
+                         "launches would distort the per-kernel averages of a rocprofv3 run of this command)")
     args = ap.parse_args()
 
     import torch
@@ -326,7 +329,9 @@ def main():
         "final_mean_target_recon_error": float(gathered[0, :, 4].mean().item()),
     }
     if world == 1:                  # the widened row f-4, measured beside the headline (not part of `value`)
-        out["secondary"] = {"ae_training_step": training_leg(dev), "two_batch_slots": slots_leg(dev, weights, ae)}
+        out["secondary"] = {"ae_training_step": training_leg(dev)}
+        if args.slots > 1:
+            out["secondary"]["batch_slots"] = slots_leg(dev, weights, ae, args.slots)
     if world == 1 and not args.no_cpu_baseline:
         _, adv_best, recon_best = at.get_best(ref)
         out["cpu_baseline"] = cpu_baseline(weights, x, gt, args.cpu_iters,
