@@ -164,24 +164,32 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
             __builtin_amdgcn_wave_barrier();              // the buffer is rewritten by the next round
         }
     }
-    // row minima: first index attaining the minimum inside the winning chunk, then merge the 4 waves
-    __syncthreads();
+    // row minima: first index attaining the minimum inside the winning chunk, then merge the waves.  With a single LDS
+    // stage (m <= 2048 per slice: the attack's shape) the chunk is still in the stage buffer; otherwise it is re-read from
+    // global memory.  The stage buffer becomes the merge arrays afterwards, hence the barrier between the two loops.
+    const bool staged = mend - mbeg <= CS_STAGE;            // uniform
+    int found[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int found = INT_MAX;
+        found[r] = INT_MAX;
         if (bestk[r] >= 0) {
-            found = bestk[r];
+            found[r] = bestk[r];
             bool hit = false;
             for (int u = 0; u < CS_CHUNK; ++u) {
                 const int k = bestk[r] + u;
                 if (k < mend) {
-                    const float d = sqdist_s(Q[3 * (size_t)k], Q[3 * (size_t)k + 1], Q[3 * (size_t)k + 2], px[r], py[r], pz[r]);
-                    if (!hit && d == best[r]) { hit = true; found = k; }
+                    const float d = staged ? sqdist_s(sx[k - mbeg], sy[k - mbeg], sz[k - mbeg], px[r], py[r], pz[r])
+                                           : sqdist_s(Q[3 * (size_t)k], Q[3 * (size_t)k + 1], Q[3 * (size_t)k + 2], px[r], py[r], pz[r]);
+                    if (!hit && d == best[r]) { hit = true; found[r] = k; }
                 }
             }
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
         mdist[wave][r * kWave + lane] = best[r];
-        midx[wave][r * kWave + lane] = found;
+        midx[wave][r * kWave + lane] = found[r];
     }
     __syncthreads();
     for (int qq = threadIdx.x; qq < CS_ROWS; qq += CS_THREADS) {
