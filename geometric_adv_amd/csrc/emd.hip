@@ -35,8 +35,7 @@ static inline double emd_level(int li) {        // li = 0..10  <->  j = 8..-2
 // temp layout per cloud (doubles): remL[n] remR[m] then per level: fL[n] fR[m]
 __host__ __device__ inline size_t emd_temp_doubles_per_cloud(int n, int m) { return (size_t)(n + m) * (1 + EMD_LEVELS); }
 
-__device__ __forceinline__ double pair_w(double level, double ox, double oy, double oz, float px, float py, float pz) {
-    const double x2 = px, y2 = py, z2 = pz;
+__device__ __forceinline__ double pair_w(double level, double ox, double oy, double oz, double x2, double y2, double z2) {
     const double d2 = (ox - x2) * (ox - x2) + (oy - y2) * (oy - y2) + (oz - z2) * (oz - z2);
     return (double)expf((float)(level * d2));
 }
@@ -55,7 +54,9 @@ __global__ void emd_init_kernel(int n, int m, double *temp) {
 template <int PASS>
 __global__ __launch_bounds__(256) void emd_sweep_kernel(int n, int m, int li, double level, const float *xyz1,
                                                         const float *xyz2, double *temp) {
-    __shared__ float ox[EMD_TILE], oy[EMD_TILE], oz[EMD_TILE];
+    // the other cloud's coordinates are widened to double ONCE per tile here (the CPU widens them per pair, :38-41: same
+    // values), not once per pair in the loop: conversions issue at the same rate as the fp64 arithmetic they feed
+    __shared__ double ox[EMD_TILE], oy[EMD_TILE], oz[EMD_TILE];
     __shared__ double of[EMD_TILE];
     const int c = blockIdx.y;
     double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);

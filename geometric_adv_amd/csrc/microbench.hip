@@ -106,6 +106,35 @@ __global__ __launch_bounds__(256) void mb_op_kernel(float *out, int iters) {
     if (acc == 123.456f) out[0] = acc;
 }
 
+// fp64 / conversion / transcendental issue rates (which = 32..39), same harness:
+//   32 v_add_f64  33 v_mul_f64  34 v_fma_f64  35 v_cvt_f64_f32  36 v_cvt_f32_f64  37 v_exp_f32  38 v_ldexp_f32  39 v_rndne_f32
+template <int WHICH>
+__global__ __launch_bounds__(256) void mb_op64_kernel(float *out, int iters) {
+    const double s = 1.0 + 1e-7 * threadIdx.x;
+    const float sf = (float)s;
+    double a[8];
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = 0.5 + i; f[i] = 0.25f + i; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (WHICH == 32) asm volatile("v_add_f64 %0, %0, %1\n\tv_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 33) asm volatile("v_mul_f64 %0, %0, %1\n\tv_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 34) asm volatile("v_fma_f64 %0, %0, %1, %1\n\tv_fma_f64 %0, %0, %1, %1" : "+v"(a[i]) : "v"(s));
+            else if (WHICH == 35) asm volatile("v_cvt_f64_f32 %0, %1\n\tv_cvt_f64_f32 %0, %1" : "+v"(a[i]) : "v"(f[i]));
+            else if (WHICH == 36) asm volatile("v_cvt_f32_f64 %0, %1\n\tv_cvt_f32_f64 %0, %1" : "+v"(f[i]) : "v"(a[i]));
+            else if (WHICH == 37) asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %0, %0" : "+v"(f[i]));
+            else if (WHICH == 38) asm volatile("v_ldexp_f32 %0, %0, %1\n\tv_ldexp_f32 %0, %0, %1" : "+v"(f[i]) : "v"(1));
+            else asm volatile("v_rndne_f32 %0, %0\n\tv_rndne_f32 %0, %0" : "+v"(f[i]));
+        }
+    }
+    double acc = sf;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += a[i] + f[i];
+    if (acc == 123.456) out[0] = (float)acc;
+}
+
 // Issue-slot probe (which = 15..17): 16 dependent 32x32x2 MFMAs per iteration plus NV independent v_add_f32 per group of four
 // (NV = 4, 8, 16).  If plain VALU instructions of the same or of other waves overlapped with the matrix pipe, the time
 // would not move.
@@ -179,7 +208,7 @@ using namespace geoadv;
 // ms = time of one launch of 2048 workgroups x 256 threads, each thread issuing 16*iters VALU
 // instructions of the selected kind.
 extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) {
-    GA_REQUIRE(which >= 0 && which <= 31 && iters > 0 && ms, "microbench: bad arguments");
+    GA_REQUIRE(which >= 0 && which <= 39 && iters > 0 && ms, "microbench: bad arguments");
     hipStream_t st = as_stream(stream);
     float *out = nullptr;
     GA_HIP(hipMalloc(&out, 64));
@@ -229,7 +258,15 @@ extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) 
             case 28: mb_op_kernel<28><<<2048, 256, 0, st>>>(out, iters); break;
             case 29: mb_op_kernel<29><<<2048, 256, 0, st>>>(out, iters); break;
             case 30: mb_op_kernel<30><<<2048, 256, 0, st>>>(out, iters); break;
-            default: mb_op_kernel<31><<<2048, 256, 0, st>>>(out, iters); break;
+            case 31: mb_op_kernel<31><<<2048, 256, 0, st>>>(out, iters); break;
+            case 32: mb_op64_kernel<32><<<2048, 256, 0, st>>>(out, iters); break;
+            case 33: mb_op64_kernel<33><<<2048, 256, 0, st>>>(out, iters); break;
+            case 34: mb_op64_kernel<34><<<2048, 256, 0, st>>>(out, iters); break;
+            case 35: mb_op64_kernel<35><<<2048, 256, 0, st>>>(out, iters); break;
+            case 36: mb_op64_kernel<36><<<2048, 256, 0, st>>>(out, iters); break;
+            case 37: mb_op64_kernel<37><<<2048, 256, 0, st>>>(out, iters); break;
+            case 38: mb_op64_kernel<38><<<2048, 256, 0, st>>>(out, iters); break;
+            default: mb_op64_kernel<39><<<2048, 256, 0, st>>>(out, iters); break;
         }
         GA_LAUNCH_CHECK();
         GA_HIP(hipEventRecord(e1, st));
