@@ -12,7 +12,8 @@
 //     fL_j[k] = remL[k] / (1e-9 + sum_l w_j remR[l]),                       (pass A, thread per k)
 //     T_l = sum_k w_j fL_j[k];  r = min(remR[l] / (1e-9 + remR[l] T_l), 1);
 //     fR_j[l] = remR[l] r;  remR[l] <- max(remR[l] - fR_j[l] T_l, 0)        (pass B, thread per l)
-//     remL[k] <- max(remL[k] - fL_j[k] sum_l w_j fR_j[l], 0)                (pass C, thread per k)
+//     remL[k] <- max(remL[k] - fL_j[k] sum_l w_j fR_j[l], 0)                (pass C, thread per k; fused with pass A of
+//                                                                            level j+1: one distance, two weights)
 // which is the CPU loop (:36-78) with the row/column normalisations pulled out of the pair sums.
 // Only 12 (n+m) doubles per cloud live in HBM during the levels; match is written ONCE at the end
 // (sum over the 11 levels, accumulated level by level in float like the CPU's `match[k] += weight[k]`).
@@ -98,6 +99,44 @@ __global__ __launch_bounds__(256) void emd_sweep_kernel(int n, int m, int li, do
         const double left = remL[i] - fL[i] * acc;
         remL[i] = left > 0.0 ? left : 0.0;
     }
+}
+
+// Pass C of level li and pass A of level li + 1 in one walk over the other cloud: both are "thread per k, sum over l", pass A
+// does not read what pass C writes for other k, and the pair distance -- a third of the per-pair work -- is computed once
+// for the two weights.  The two sums run in the same order as in the separate passes: same bits.
+__global__ __launch_bounds__(256) void emd_sweep_ca_kernel(int n, int m, int li, double level_c, double level_a, const float *xyz1,
+                                                           const float *xyz2, double *temp) {
+    __shared__ double ox[EMD_TILE], oy[EMD_TILE], oz[EMD_TILE];
+    __shared__ double ofc[EMD_TILE], ofa[EMD_TILE];
+    const int c = blockIdx.y;
+    double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
+    double *remL = t, *remR = t + n, *fL = t + (size_t)(n + m) * (1 + li), *fR = fL + n, *fL_next = fL + (n + m);
+    const float *own = xyz1 + (size_t)c * n * 3, *oth = xyz2 + (size_t)c * m * 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    double px = 0, py = 0, pz = 0;
+    if (live) { px = own[3 * i]; py = own[3 * i + 1]; pz = own[3 * i + 2]; }
+    double acc_c = 0.0, acc_a = 1e-9;               // pass A: the CPU starts its row sum at 1e-9 (:49)
+    for (int t0 = 0; t0 < m; t0 += EMD_TILE) {
+        const int cnt = min(EMD_TILE, m - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += 256) {
+            ox[e] = oth[3 * (size_t)(t0 + e)]; oy[e] = oth[3 * (size_t)(t0 + e) + 1]; oz[e] = oth[3 * (size_t)(t0 + e) + 2];
+            ofc[e] = fR[t0 + e]; ofa[e] = remR[t0 + e];
+        }
+        __syncthreads();
+        if (live)
+            for (int e = 0; e < cnt; ++e) {
+                const double d2 = (px - ox[e]) * (px - ox[e]) + (py - oy[e]) * (py - oy[e]) + (pz - oz[e]) * (pz - oz[e]);
+                acc_c += (double)expf((float)(level_c * d2)) * ofc[e];
+                acc_a += (double)expf((float)(level_a * d2)) * ofa[e];
+            }
+    }
+    if (!live) return;
+    const double left = remL[i] - fL[i] * acc_c;
+    const double rl = left > 0.0 ? left : 0.0;
+    remL[i] = rl;
+    fL_next[i] = rl / acc_a;
 }
 
 // match[c][l][k] = sum over levels of w_j(k,l) fL_j[k] fR_j[l], accumulated in float level by level.
@@ -272,11 +311,14 @@ extern "C" int geoadv_approx_match(int b, int n, int m, const float *xyz1, const
     emd_init_kernel<<<dim3(cdiv(n + m, 256), b), 256, 0, st>>>(n, m, t);
     GA_LAUNCH_CHECK();
     EmdLevels lv;
+    for (int li = 0; li < EMD_LEVELS; ++li) lv.v[li] = emd_level(li);
+    emd_sweep_kernel<0><<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, 0, lv.v[0], xyz1, xyz2, t);
     for (int li = 0; li < EMD_LEVELS; ++li) {
-        lv.v[li] = emd_level(li);
-        emd_sweep_kernel<0><<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, li, lv.v[li], xyz1, xyz2, t);
         emd_sweep_kernel<1><<<dim3(cdiv(m, 256), b), 256, 0, st>>>(n, m, li, lv.v[li], xyz1, xyz2, t);
-        emd_sweep_kernel<2><<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, li, lv.v[li], xyz1, xyz2, t);
+        if (li + 1 < EMD_LEVELS)                       // pass C of this level with pass A of the next
+            emd_sweep_ca_kernel<<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, li, lv.v[li], lv.v[li + 1], xyz1, xyz2, t);
+        else
+            emd_sweep_kernel<2><<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, li, lv.v[li], xyz1, xyz2, t);
         GA_LAUNCH_CHECK();
     }
     emd_match_kernel<<<dim3(cdiv(n, 256), cdiv(m, EMD_LT), b), 256, 0, st>>>(n, m, lv, xyz1, xyz2, t, match);
