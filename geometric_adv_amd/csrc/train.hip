@@ -755,14 +755,16 @@ __global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs 
         for (int tile = blockIdx.x; tile < tiles32; tile += nw) {
             const size_t row0 = (size_t)tile * ROWS;
             load_da_tile<COUT, ROWS>(A, row0, cc, da, dbacc);
-            load_raw_tile<CIN, ROWS>(A.aprev, row0, ht);
+            // h = relu(a_{i-1} * s + t) once per element on the way into LDS, not once per use in the MFMA loop (every
+            // element feeds COUT / 64 waves, and VALU instructions in that loop cost matrix-pipe time): same arithmetic
+            load_activated_tile<CIN, ROWS>(A.aprev, row0, A.pscale, A.pshift, ht);
             __syncthreads();
 #pragma unroll 8
             for (int kk = 0; kk < ROWS / 2; ++kk) {
                 const int row = 2 * kk + hh;
                 float av[S::MBW], bv[S::NBW];
 #pragma unroll
-                for (int m = 0; m < S::MBW; ++m) av[m] = fmaxf(fmaf(ht[row * (CIN + 4) + (mb0 + m) * 32 + li], hs[m], hsh[m]), 0.f);
+                for (int m = 0; m < S::MBW; ++m) av[m] = ht[row * (CIN + 4) + (mb0 + m) * 32 + li];
 #pragma unroll
                 for (int n = 0; n < S::NBW; ++n) bv[n] = da[row * (COUT + 4) + (nb0 + n) * 32 + li];
 #pragma unroll
