@@ -38,6 +38,8 @@ def build_parser():
     p.add_argument('--output_folder_name', type=str, default='attack_res')
     p.add_argument('--top_dir', type=str, default='.', help='root that --ae_folder / --attack_pc_idx are relative to')
     p.add_argument('--class_names', nargs='+', default=None, help='classes to attack / target [default: all]')
+    p.add_argument('--batch_slots', type=int, default=1,
+                   help='batches attacked concurrently on each GPU (AdvAE.attack; not a reference flag) [default: 1]')
     return p
 
 
@@ -83,7 +85,7 @@ def main(argv=None):
                          dist_weight_list=[float(w) for w in flags.dist_weight_list],
                          max_point_pert_weight=flags.max_point_pert_weight, max_point_dist_weight=flags.max_point_dist_weight,
                          num_iterations=flags.num_iterations, num_iterations_thresh=flags.num_iterations_thresh,
-                         learning_rate=flags.learning_rate)
+                         learning_rate=flags.learning_rate, batch_slots=flags.batch_slots)
     import torch
     dev = torch.device("cuda", local)
     ae = None
