@@ -185,7 +185,11 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
         if (i < n) sorted[cell_start[tcell[k]] + trank[k]] = make_float4(tx[k], ty[k], tz[k], __int_as_float(i));
     }
     __syncthreads();
-    unsigned *far_queue = counts;                                      // the counts are dead: queue of far queries
+    // the counts are dead: queue of far queries -- index and coordinates (16 B each, so that the scan below does not start
+    // with a global round trip) where the slice's queries fit the 16 KB, the index alone for the large instantiation
+    constexpr bool QXYZ = (MAXN / GR_QSPLIT) * 4 <= GR_CELLS;
+    unsigned *far_queue = counts;
+    float4 *far_queue4 = reinterpret_cast<float4 *>(counts);
 
     // ---- queries of this workgroup's slice: bound from the paired target, cells the ball touches, candidates in them ----
     constexpr int QPT = (MAXN / GR_QSPLIT + GR_THREADS - 1) / GR_THREADS;              // queries per thread (2 or 4)
@@ -211,7 +215,9 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
         const int j = jbeg + t + k * GR_THREADS;
         if (j >= jend) continue;
         if (qspan[k] < 0) {
-            far_queue[atomicAdd(&n_far, 1)] = (unsigned)j;               // (order of the queue does not matter)
+            const int pos = atomicAdd(&n_far, 1);                        // (order of the queue does not matter)
+            if (QXYZ) far_queue4[pos] = make_float4(qx[k], qy[k], qz[k], __int_as_float(j));
+            else far_queue[pos] = (unsigned)j;
             continue;
         }
         const int x0 = qspan[k] & 15, x1 = (qspan[k] >> 4) & 15, y0 = (qspan[k] >> 8) & 15, y1 = (qspan[k] >> 12) & 15;
@@ -237,8 +243,10 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
     const int lane = t & 63, wave = t >> 6;
     const int nf = n_far;
     for (int f = wave; f < nf; f += GR_THREADS / 64) {
-        const int j = (int)far_queue[f];
-        const float fx = A[3 * j], fy = A[3 * j + 1], fz = A[3 * j + 2];
+        int j;
+        float fx, fy, fz;
+        if (QXYZ) { const float4 q = far_queue4[f]; fx = q.x; fy = q.y; fz = q.z; j = __float_as_int(q.w); }
+        else { j = (int)far_queue[f]; fx = A[3 * j]; fy = A[3 * j + 1]; fz = A[3 * j + 2]; }
         float best = INFINITY;
         int bestk = INT_MAX;
         // eight independent streams per lane keep eight LDS reads in flight (a single dependent chain pays the LDS
@@ -268,12 +276,7 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
 #pragma unroll
         for (int v = 0; v < 8; ++v)
             if (bd[v] < best || (bd[v] == best && bk[v] < bestk)) { best = bd[v]; bestk = bk[v]; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float d2 = __shfl_xor(best, off);
-            const int k2 = __shfl_xor(bestk, off);
-            if (d2 < best || (d2 == best && k2 < bestk)) { best = d2; bestk = k2; }
-        }
+        wave_lexmin(best, bestk);
         if (lane == 0) { dist[j] = best; idx[j] = bestk; }
     }
 }

@@ -33,4 +33,33 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;   // gfx950 wavefront
 
+#ifdef __HIPCC__
+// Lexicographic (value, index) minimum over the 64 lanes of a wave; every lane ends up with the result.  Four DPP steps
+// reduce each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- register-to-register, a few cycles
+// each, where a __shfl_xor is a ds_bpermute round trip of ~150), v_readlane collects the four rows.
+__device__ __forceinline__ void wave_lexmin(float &d, int &k) {
+#define GA_LEXMIN_DPP(CTRL)                                                                              \
+    do {                                                                                                 \
+        const float d2_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), CTRL, 0xf, 0xf, false)); \
+        const int k2_ = __builtin_amdgcn_update_dpp(0, k, CTRL, 0xf, 0xf, false);                        \
+        if (d2_ < d || (d2_ == d && k2_ < k)) { d = d2_; k = k2_; }                                      \
+    } while (0)
+    GA_LEXMIN_DPP(0xB1);      // quad_perm [1,0,3,2]
+    GA_LEXMIN_DPP(0x4E);      // quad_perm [2,3,0,1]
+    GA_LEXMIN_DPP(0x141);     // row_half_mirror
+    GA_LEXMIN_DPP(0x140);     // row_mirror
+#undef GA_LEXMIN_DPP
+    float bd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 0));
+    int bk = __builtin_amdgcn_readlane(k, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+        const float d2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 16 * row));
+        const int k2 = __builtin_amdgcn_readlane(k, 16 * row);
+        if (d2 < bd || (d2 == bd && k2 < bk)) { bd = d2; bk = k2; }
+    }
+    d = bd;
+    k = bk;
+}
+#endif
+
 }  // namespace geoadv
