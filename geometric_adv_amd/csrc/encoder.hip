@@ -408,13 +408,15 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     int arg = INT_MAX, cnt = 0;
     {
         float v[16];
-        const bool whole = n0 + ROWS <= n;                // only the last tile of a cloud can hold rows beyond n
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = fmaxf(fmaf(acc4[0][r], sc4, sh4), 0.f);
-            if (!whole && n0 + orow + acc_row(r, h) >= n) v[r] = -2.f;      // never the maximum, never equal to it
-            mx = fmaxf(mx, v[r]);
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(fmaf(acc4[0][r], sc4, sh4), 0.f);
+        if (n0 + ROWS > n) {                              // only the last tile of a cloud can hold rows beyond n (uniform branch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (n0 + orow + acc_row(r, h) >= n) v[r] = -2.f;            // never the maximum, never equal to it
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, v[r]);
 #pragma unroll
         for (int r = 15; r >= 0; --r) {                   // rows ascend with r: the last hit kept is the lowest row
             const bool hit = v[r] == mx;
