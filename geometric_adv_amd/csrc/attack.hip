@@ -238,7 +238,9 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradA
 // than the CPU op's sequential fp32 sum, from which it differs by normal fp32 rounding only).
 // The bit-exact-vs-CPU sorted form stays behind the public NnDistanceGrad op (chamfer.hip).
 constexpr double CG_FX = 17592186044416.0;          // 2^44
-constexpr int CG_FX_MAX_N = 5000;                   // 3 * 8 B * n <= 120 KB
+constexpr int CG_FX_MAX_N = 5000;                   // 3 * 8 B * n <= 120 KB: the three coordinates in one pass
+constexpr int CG_FX_MAX_N_PLANE = 15000;            // larger clouds: one coordinate per pass, 8 B * n of LDS
+inline size_t cgrad_fx_lds_bytes(int n) { return sizeof(unsigned long long) * (n <= CG_FX_MAX_N ? 3 : 1) * (size_t)n; }
 
 __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
@@ -251,25 +253,46 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
     const float *p = pr.p + (size_t)b * n * 3, *q = pr.q + (size_t)b * n * 3;
     const int *i1 = pr.idx1 + (size_t)b * n, *i2 = pr.idx2 + (size_t)b * n;
     const int js = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
-    for (int e = threadIdx.x; e < 3 * n; e += CGA_THREADS) acc[e] = 0ull;
-    __syncthreads();
-    for (int k = threadIdx.x; k < n; k += CGA_THREADS) {
-        const int j = i2[k];                          // other point k matched our point j
+    if (n <= CG_FX_MAX_N) {
+        for (int e = threadIdx.x; e < 3 * n; e += CGA_THREADS) acc[e] = 0ull;
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += CGA_THREADS) {
+            const int j = i2[k];                          // other point k matched our point j
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float t = g2 * (q[3 * k + c] - p[3 * j + c]);
-            const long long f = __double2ll_rn((double)t * CG_FX);
-            atomicAdd(&acc[3 * j + c], (unsigned long long)f);
+            for (int c = 0; c < 3; ++c) {
+                const float t = g2 * (q[3 * k + c] - p[3 * j + c]);
+                const long long f = __double2ll_rn((double)t * CG_FX);
+                atomicAdd(&acc[3 * j + c], (unsigned long long)f);
+            }
         }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < n; j += CGA_THREADS) {
-        const int mj = i1[j];
-        const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += CGA_THREADS) {
+            const int mj = i1[j];
+            const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float own = gown * (p[3 * j + c] - q[3 * mj + c]);
-            const float sc = (float)((double)(long long)acc[3 * j + c] * (1.0 / CG_FX));
+            for (int c = 0; c < 3; ++c) {
+                const float own = gown * (p[3 * j + c] - q[3 * mj + c]);
+                const float sc = (float)((double)(long long)acc[3 * j + c] * (1.0 / CG_FX));
+                pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
+            }
+        }
+        return;
+    }
+    // large clouds (config 5: n = 8192): the same sums one coordinate at a time, so that the accumulators still fit in LDS
+    for (int c = 0; c < 3; ++c) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += CGA_THREADS) acc[e] = 0ull;
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += CGA_THREADS) {
+            const int j = i2[k];
+            const float t = g2 * (q[3 * k + c] - p[3 * j + c]);
+            atomicAdd(&acc[j], (unsigned long long)__double2ll_rn((double)t * CG_FX));
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += CGA_THREADS) {
+            const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
+            const float own = gown * (p[3 * j + c] - q[3 * i1[j] + c]);
+            const float sc = (float)((double)(long long)acc[j] * (1.0 / CG_FX));
             pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
         }
     }
@@ -530,9 +553,9 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         if (adv_chamfer) ca.pr[np++] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
         if (dist_chamfer) ca.pr[np++] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, 0.f};
         at->cgrad_done = false;
-        if (np && !max_term && !at->overlap && n <= CG_FX_MAX_N) {
+        if (np && !max_term && !at->overlap && n <= CG_FX_MAX_N_PLANE) {
             ca.n = n; ca.P = 0;
-            loss_cgrad_kernel<<<dim3(B, 1 + np), CGA_THREADS, sizeof(unsigned long long) * 3 * (size_t)n, st>>>(la, ca);
+            loss_cgrad_kernel<<<dim3(B, 1 + np), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(la, ca);
             at->cgrad_done = true;
         } else {
             loss_metrics_kernel<<<B, 256, 0, st>>>(la);
@@ -550,8 +573,8 @@ int launch_cgrad(const CGradProblem *pr, int np, int B, int n, hipStream_t st) {
     CGradArgs ca;
     for (int i = 0; i < np; ++i) ca.pr[i] = pr[i];
     ca.n = n; ca.P = pow2_ge(n);
-    if (n <= CG_FX_MAX_N) {
-        chamfer_grad_attack_fx_kernel<<<dim3(B, np), CGA_THREADS, sizeof(unsigned long long) * 3 * (size_t)n, st>>>(ca);
+    if (n <= CG_FX_MAX_N_PLANE) {
+        chamfer_grad_attack_fx_kernel<<<dim3(B, np), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(ca);
         GA_LAUNCH_CHECK();
         return GEOADV_OK;
     }

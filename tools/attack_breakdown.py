@@ -6,7 +6,7 @@ import numpy as np, torch
 from geometric_adv_amd import weights as W
 from geometric_adv_amd.adv_ae import AdvAE, Configuration
 from geometric_adv_amd.autoencoder import PointNetAE
-N = 2048
+N = int(os.environ.get("GEOADV_TOOL_N", "2048"))
 for B in [int(a) for a in sys.argv[1:]] or [1, 32]:
     rng = np.random.default_rng(B)
     x = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5); gt = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)
