@@ -282,42 +282,53 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     const FragSrc w3a = frag_src(A.enc_fwd[3].w, cb * kg3), w3b = frag_src(A.enc_fwd[3].w, (4 + cb) * kg3);
     const FragSrc w4 = frag_src(A.enc_fwd[4].w, cb * kg4);
     const unsigned lb = (unsigned)lane * 16u;         // this lane's 16 bytes of every 1 KiB fragment
+    // First of all, the loads the first barrier waits for (loads return in order: issued behind the fourteen per-lane
+    // constants below they would wait for those too): the tile's points, and layer 0's 320 constants (W0 [3][64], scale,
+    // shift), which go through LDS -- one global load per thread instead of the forty that "every thread fetches the 8
+    // channels it computes" costs.  They are only REQUESTED here; the LDS stores follow the other requests.
+    float *l0c = redm;                                 // (the pool's reduction buffers are free until the end)
+    const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
+    const int n0 = tile * ROWS;
+    float pv = 0.f, pp = 0.f, l0v = 0.f;
+    size_t pg = 0;
+    bool pvalid = false;
+    if (threadIdx.x < ROWS * 3) {
+        const int r = threadIdx.x / 3, a = threadIdx.x % 3;
+        int p = n0 + r;
+        pvalid = p < n;
+        p = pvalid ? p : n - 1;
+        pg = ((size_t)b * n + p) * 3 + a;
+        pv = x[pg];
+        if (pert) pp = pert[pg];
+    } else {
+        const int e = threadIdx.x - 192;
+        l0v = e < 192 ? A.w0[e] : (e < 256 ? A.scale[0][e - 192] : A.shift[0][e - 256]);
+    }
     BRing ring;
-    ring_fill(ring, w1, lb);                          // in flight during the point load and layer 0
+    ring_fill(ring, w1, lb);                          // in flight during layer 0
     // every per-lane constant is requested up front too (a load at its point of use costs an exposed
     // L2 round trip per epilogue): BN scale/shift of this lane's column in layers 1-4 ...
     const int ccol = cb * 32 + i;
     const float sc1 = A.scale[1][ccol], sh1 = A.shift[1][ccol], sc2 = A.scale[2][ccol], sh2 = A.shift[2][ccol];
     const float sc3a = A.scale[3][ccol], sh3a = A.shift[3][ccol], sc3b = A.scale[3][128 + ccol], sh3b = A.shift[3][128 + ccol];
     const float sc4 = A.scale[4][ccol], sh4 = A.shift[4][ccol];
-    // ... and the 8 channels of layer 0 this thread computes (row = tid/8, channels 8*(tid%8) ..)
-    float l0w[3][8], l0s[8], l0t[8];
-    {
-        const int c0 = (threadIdx.x & 7) * 8;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            l0w[0][c] = A.w0[c0 + c]; l0w[1][c] = A.w0[64 + c0 + c]; l0w[2][c] = A.w0[128 + c0 + c];
-            l0s[c] = A.scale[0][c0 + c]; l0t[c] = A.shift[0][c0 + c];
-        }
-    }
-
-    const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
-    const int n0 = tile * ROWS;
     if (threadIdx.x < ROWS * 3) {
-        const int r = threadIdx.x / 3, a = threadIdx.x % 3;
-        int p = n0 + r;
-        const bool valid = p < n;
-        p = valid ? p : n - 1;
-        const size_t g = ((size_t)b * n + p) * 3 + a;
-        float v = x[g];
-        if (pert) v += pert[g];
+        const float v = pert ? pv + pp : pv;
         pts[threadIdx.x] = v;
-        if (adv_out && valid) adv_out[g] = v;
+        if (adv_out && pvalid) adv_out[pg] = v;
+    } else {
+        l0c[threadIdx.x - 192] = l0v;
     }
     __syncthreads();
     {   // layer 0 (fan-in 3) on the VALU, same arithmetic as fwd_layer0
         const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 8;
         const float px = pts[row * 3], py = pts[row * 3 + 1], pz = pts[row * 3 + 2];
+        float l0w[3][8], l0s[8], l0t[8];               // the 8 channels this thread computes (row = tid/8, channels 8*(tid%8) ..)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            l0w[0][c] = l0c[c0 + c]; l0w[1][c] = l0c[64 + c0 + c]; l0w[2][c] = l0c[128 + c0 + c];
+            l0s[c] = l0c[192 + c0 + c]; l0t[c] = l0c[256 + c0 + c];
+        }
         unsigned bits = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
