@@ -29,8 +29,8 @@ B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_HBM_FILE = os.path.join(ROOT, "profiles", "r01_v14_pmc_hbm.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-PMC_SQ_FILE = os.path.join(ROOT, "profiles", "r01_v14_pmc_sq.json")       # rocprofv3 --pmc SQ_* pass
+PMC_HBM_FILE = os.path.join(ROOT, "profiles", "r01_v15_pmc_hbm.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SQ_FILE = os.path.join(ROOT, "profiles", "r01_v15_pmc_sq.json")       # rocprofv3 --pmc SQ_* pass
 
 
 def _encoder_entry(d):
@@ -67,7 +67,7 @@ def pmc_traffic_bytes():
     try:
         k = _encoder_entry(json.load(open(PMC_HBM_FILE)))
         fetch, write = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
-        return (2.0 * fetch + write) * 1024.0, "profiles/r01_v14_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
+        return (2.0 * fetch + write) * 1024.0, "profiles/r01_v15_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
     except Exception as e:          # pragma: no cover
         return None, "no PMC profile: %s" % e
 
