@@ -239,6 +239,16 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
     const float *P = pr.p + (size_t)cp * n * 3;
     const float *Q = pr.q + (size_t)cq * m * 3;
     const float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * tiles) * m;
+    // this thread's column: its tile minima and coordinates are REQUESTED before the row cloud is staged, so that the two
+    // global round trips overlap (the kernel is latency-bound: 256 workgroups, a few microseconds each)
+    const int quarter = threadIdx.x & (CF_Q - 1);
+    const int k = blockIdx.x * CF_COLS + (threadIdx.x >> 2);
+    const int kc = k < m ? k : m - 1;                     // (whole 4-lane groups stay in the shuffles below)
+    constexpr int CP = 8;                                 // tile minima fetched up front (n <= 2048); further tiles in a loop
+    float cpv[CP];
+#pragma unroll
+    for (int t = 0; t < CP; ++t) cpv[t] = colpart[(size_t)(t < tiles ? t : 0) * m + kc];
+    const float qx = Q[3 * (size_t)kc], qy = Q[3 * (size_t)kc + 1], qz = Q[3 * (size_t)kc + 2];
     for (int e = threadIdx.x; e < tiles * CS_ROWS; e += CF_THREADS) {
         const int o = (e / CS_ROWS) * CF_SEG + (e % CS_ROWS);
         const int src = e < n ? e : n - 1;
@@ -259,16 +269,15 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
             pr.idx1[(size_t)c * n + j] = i;
         }
     }
-    const int quarter = threadIdx.x & (CF_Q - 1);
-    const int k = blockIdx.x * CF_COLS + (threadIdx.x >> 2);
-    const int kc = k < m ? k : m - 1;                     // (whole 4-lane groups stay in the shuffles below)
-    float v = colpart[kc];
+    float v = cpv[0];
     int bt = 0;
-    for (int t = 1; t < tiles; ++t) {
+#pragma unroll
+    for (int t = 1; t < CP; ++t)
+        if (t < tiles && cpv[t] < v) { v = cpv[t]; bt = t; }   // strict: the lowest tile wins ties
+    for (int t = CP; t < tiles; ++t) {
         const float w = colpart[(size_t)t * m + kc];
-        if (w < v) { v = w; bt = t; }                     // strict: the lowest tile wins ties
+        if (w < v) { v = w; bt = t; }
     }
-    const float qx = Q[3 * (size_t)kc], qy = Q[3 * (size_t)kc + 1], qz = Q[3 * (size_t)kc + 2];
     const int q0 = bt * CS_ROWS;
     const int nrows = min(CS_ROWS, n - q0);
     constexpr int SHARE = CS_ROWS / CF_Q;                 // rows per lane: [quarter * SHARE, +SHARE) of the tile
