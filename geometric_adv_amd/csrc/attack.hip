@@ -256,24 +256,54 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
     if (n <= CG_FX_MAX_N) {
         for (int e = threadIdx.x; e < 3 * n; e += CGA_THREADS) acc[e] = 0ull;
         __syncthreads();
-        for (int k = threadIdx.x; k < n; k += CGA_THREADS) {
-            const int j = i2[k];                          // other point k matched our point j
+        // Four points per thread and pass, index loads first, then all the dependent gathers: the launch is latency-bound
+        // (one workgroup per cloud and problem), and a loop of "load index, gather, add" pays two global round trips per point.
+        constexpr int U = 4;
+        for (int k0 = threadIdx.x; k0 < n; k0 += U * CGA_THREADS) {
+            int jj[U];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float t = g2 * (q[3 * k + c] - p[3 * j + c]);
-                const long long f = __double2ll_rn((double)t * CG_FX);
-                atomicAdd(&acc[3 * j + c], (unsigned long long)f);
+            for (int u = 0; u < U; ++u) jj[u] = k0 + u * CGA_THREADS < n ? i2[k0 + u * CGA_THREADS] : 0;   // other point k matched our point j
+            float qv[U][3], pv[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * CGA_THREADS < n ? k0 + u * CGA_THREADS : 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { qv[u][c] = q[3 * k + c]; pv[u][c] = p[3 * jj[u] + c]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u * CGA_THREADS >= n) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float t = g2 * (qv[u][c] - pv[u][c]);
+                    const long long f = __double2ll_rn((double)t * CG_FX);
+                    atomicAdd(&acc[3 * jj[u] + c], (unsigned long long)f);
+                }
             }
         }
         __syncthreads();
-        for (int j = threadIdx.x; j < n; j += CGA_THREADS) {
-            const int mj = i1[j];
-            const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
+        for (int j0 = threadIdx.x; j0 < n; j0 += U * CGA_THREADS) {
+            int mj[U];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float own = gown * (p[3 * j + c] - q[3 * mj + c]);
-                const float sc = (float)((double)(long long)acc[3 * j + c] * (1.0 / CG_FX));
-                pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
+            for (int u = 0; u < U; ++u) mj[u] = j0 + u * CGA_THREADS < n ? i1[j0 + u * CGA_THREADS] : 0;
+            float qv[U][3], pv[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * CGA_THREADS < n ? j0 + u * CGA_THREADS : 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { pv[u][c] = p[3 * j + c]; qv[u][c] = q[3 * mj[u] + c]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * CGA_THREADS;
+                if (j >= n) continue;
+                const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float own = gown * (pv[u][c] - qv[u][c]);
+                    const float sc = (float)((double)(long long)acc[3 * j + c] * (1.0 / CG_FX));
+                    pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
+                }
             }
         }
         return;
