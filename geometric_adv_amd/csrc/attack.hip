@@ -133,15 +133,27 @@ __device__ __forceinline__ void loss_metrics_body(const LossArgs &a, const int b
     r.s1 = r.s2 = r.s3 = r.s4 = r.sp = 0.f;
     r.ma = r.mp = -1.f;
     r.ja = r.jp = INT_MAX;
-    for (int j = t; j < n; j += 256) {
-        r.s1 += a.r1[o + j]; r.s2 += a.r2[o + j];
-        const float d = a.a1[o + j];
-        r.s3 += d; r.s4 += a.a2[o + j];
-        if (d > r.ma) { r.ma = d; r.ja = j; }
-        const float px = a.pert[(o + j) * 3], py = a.pert[(o + j) * 3 + 1], pz = a.pert[(o + j) * 3 + 2];
-        const float p2 = (px * px + py * py) + pz * pz;
-        r.sp += p2;
-        if (p2 > r.mp) { r.mp = p2; r.jp = j; }
+    constexpr int U = 4;                                  // points per thread and pass: all 7 * U loads requested first
+    for (int j0 = t; j0 < n; j0 += U * 256) {             // (same order of accumulation as one point per pass)
+        float v1[U], v2[U], v3[U], v4[U], vx[U], vy[U], vz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * 256 < n ? j0 + u * 256 : t;
+            v1[u] = a.r1[o + j]; v2[u] = a.r2[o + j]; v3[u] = a.a1[o + j]; v4[u] = a.a2[o + j];
+            vx[u] = a.pert[(o + j) * 3]; vy[u] = a.pert[(o + j) * 3 + 1]; vz[u] = a.pert[(o + j) * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * 256;
+            if (j >= n) continue;
+            r.s1 += v1[u]; r.s2 += v2[u];
+            const float d = v3[u];
+            r.s3 += d; r.s4 += v4[u];
+            if (d > r.ma) { r.ma = d; r.ja = j; }
+            const float p2 = (vx[u] * vx[u] + vy[u] * vy[u]) + vz[u] * vz[u];
+            r.sp += p2;
+            if (p2 > r.mp) { r.mp = p2; r.jp = j; }
+        }
     }
     r = block_reduce(r, shf, shi);
     float ma = r.ma, mp = r.mp;
