@@ -10,6 +10,7 @@
 // size n*m ever touches HBM in the fused form.
 #include "common.h"
 #include <math.h>
+#include <float.h>
 #include <stdlib.h>
 
 #pragma clang fp contract(off)
@@ -245,6 +246,54 @@ __global__ __launch_bounds__(64) void query_ball_kernel(int n, int m, float radi
     if (pts_cnt && lane == 0) pts_cnt[(size_t)c * m + q] = cnt;
 }
 
+// The same, one THREAD per query (256 queries per workgroup, the dataset streams through LDS): the wave-per-query form above
+// spends a ballot and a prefix count per 64 candidates; here a candidate costs the nine distance instructions and one
+// compare.  `max(sqrtf(d2), 1e-20f) < radius` is decided WITHOUT the square root: sqrtf is correctly rounded and monotone, so
+// the host finds the largest float t2max with sqrtf(t2max) < radius once, and the test is d2 <= t2max (NaN fails both).
+constexpr int QB_THREADS = 256;
+constexpr int QB_TILE = 1024;
+__global__ __launch_bounds__(QB_THREADS) void query_ball_fast_kernel(int n, int m, float t2max, int nsample, const float *xyz1,
+                                                                     const float *xyz2, int *idx, int *pts_cnt) {
+    __shared__ __attribute__((aligned(16))) float sx[QB_TILE], sy[QB_TILE], sz[QB_TILE];
+    const int c = blockIdx.y;
+    const float *data = xyz1 + (size_t)c * n * 3;
+    const int q = blockIdx.x * QB_THREADS + threadIdx.x;
+    const bool live = q < m;
+    const float *qp = xyz2 + ((size_t)c * m + (live ? q : m - 1)) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    int *row = idx + ((size_t)c * m + (live ? q : m - 1)) * nsample;
+    int cnt = live ? 0 : nsample, first = -1;               // (a dead lane counts as finished)
+    for (int t0 = 0; t0 < n; t0 += QB_TILE) {
+        if (__syncthreads_and(cnt >= nsample)) break;        // every query of the workgroup has its nsample hits
+        const int tn = min(QB_TILE, n - t0);
+        for (int e = threadIdx.x; e < QB_TILE; e += QB_THREADS) {
+            const bool in = e < tn;                          // the pad never hits: NaN compares false
+            sx[e] = in ? data[3 * (size_t)(t0 + e)] : NAN; sy[e] = in ? data[3 * (size_t)(t0 + e) + 1] : NAN;
+            sz[e] = in ? data[3 * (size_t)(t0 + e) + 2] : NAN;
+        }
+        __syncthreads();
+        for (int e0 = 0; e0 < tn; e0 += 4) {
+            const float4 xa = *reinterpret_cast<const float4 *>(&sx[e0]);
+            const float4 ya = *reinterpret_cast<const float4 *>(&sy[e0]);
+            const float4 za = *reinterpret_cast<const float4 *>(&sz[e0]);
+            const float tx[4] = {xa.x, xa.y, xa.z, xa.w}, ty[4] = {ya.x, ya.y, ya.z, ya.w}, tz[4] = {za.x, za.y, za.z, za.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dx = qx - tx[u], dy = qy - ty[u], dz = qz - tz[u];
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 <= t2max && cnt < nsample) {
+                    if (first < 0) first = t0 + e0 + u;
+                    row[cnt++] = t0 + e0 + u;
+                }
+            }
+        }
+    }
+    if (!live) return;
+    if (first >= 0)
+        for (int l = cnt; l < nsample; ++l) row[l] = first;  // pad with the first hit
+    if (pts_cnt) pts_cnt[(size_t)c * m + q] = cnt;
+}
+
 // GroupPoint gather (tf_grouping_g.cu:40-57): out[b,j,k,:] = points[b, idx[b,j,k], :]
 __global__ void group_point_kernel(int n, int cch, size_t per_cloud, size_t total, const float *points, const int *idx,
                                    float *out) {
@@ -381,7 +430,24 @@ extern "C" int geoadv_query_ball_point(int b, int n, int m, float radius, int ns
     GA_REQUIRE(b <= 65535, "query_ball_point: batch %d exceeds 65535", b);
     if (b == 0 || m == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && idx, "query_ball_point: null pointer");
-    query_ball_kernel<<<dim3(m, b), 64, 0, as_stream(stream)>>>(n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt);
+    static int slow = -1;
+    if (slow < 0) { const char *e = getenv("GEOADV_QUERY_BALL_SLOW"); slow = (e && e[0] == '1') ? 1 : 0; }
+    if (slow) {
+        query_ball_kernel<<<dim3(m, b), 64, 0, as_stream(stream)>>>(n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt);
+        GA_LAUNCH_CHECK();
+        return GEOADV_OK;
+    }
+    // largest squared distance that still passes `max(sqrtf(d2), 1e-20f) < radius` (none if radius <= 1e-20f; every finite one
+    // if radius is infinite)
+    float t2max = -1.f;
+    if (radius > 1e-20f) {
+        t2max = radius * radius;
+        if (!(t2max < INFINITY)) t2max = FLT_MAX;
+        while (t2max > 0.f && !(sqrtf(t2max) < radius)) t2max = nextafterf(t2max, 0.f);
+        while (t2max < FLT_MAX && sqrtf(nextafterf(t2max, INFINITY)) < radius) t2max = nextafterf(t2max, INFINITY);
+        if (!(sqrtf(t2max) < radius)) t2max = -1.f;         // (radius so small that not even d2 = 0 ... cannot happen above 1e-20)
+    }
+    query_ball_fast_kernel<<<dim3(cdiv(m, QB_THREADS), b), QB_THREADS, 0, as_stream(stream)>>>(n, m, t2max, nsample, xyz1, xyz2, idx, pts_cnt);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -44,6 +44,30 @@ def test_query_ball_vs_oracle_sparse_hits(oracle):
         assert np.array_equal(idx.cpu().numpy()[hit], want_idx[hit])
 
 
+def test_query_ball_radius_boundary_and_large(oracle):
+    """The kernel decides `max(sqrtf(d2), 1e-20) < radius` from d2 alone (largest float whose square root is below the
+    radius): exact at the boundary -- lattice distances that EQUAL the radius are not hits, one ulp more radius makes them
+    hits -- and for a dataset that spans several LDS tiles with early exits at nsample."""
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    rng = np.random.default_rng(5)
+    lat = (rng.integers(-3, 4, size=(2, 400, 3)) * 0.25).astype(np.float32)
+    for radius in (0.25, float(np.nextafter(np.float32(0.25), np.float32(1))), float(np.nextafter(np.float32(0.25), np.float32(0))),
+                   0.4330127, 1e-21, 1e30):
+        want_idx, want_cnt = oracle.query_ball_point(radius, 8, lat, lat[:, :60])
+        idx, cnt = ops.query_ball_point(radius, 8, _t(lat), _t(np.ascontiguousarray(lat[:, :60])))
+        assert np.array_equal(cnt.cpu().numpy(), want_cnt), radius
+        hit = want_cnt > 0
+        assert np.array_equal(idx.cpu().numpy()[hit], want_idx[hit]), radius
+    x1, x2 = cloud(7, 2, 2500) + 0.5, cloud(8, 2, 300) + 0.5
+    for radius, ns in [(0.1, 32), (0.3, 5)]:
+        want_idx, want_cnt = oracle.query_ball_point(radius, ns, x1, x2)
+        idx, cnt = ops.query_ball_point(radius, ns, _t(x1), _t(x2))
+        assert np.array_equal(cnt.cpu().numpy(), want_cnt)
+        hit = want_cnt > 0
+        assert np.array_equal(idx.cpu().numpy()[hit], want_idx[hit])
+
+
 @pytest.mark.parametrize("b,n,m,k", [(2, 200, 77, 9), (1, 2048, 64, 9), (3, 64, 64, 64), (2, 500, 10, 1), (2, 3000, 300, 16),
                                      (2, 1500, 257, 4), (1, 5, 5, 5), (2, 2048, 100, 2), (1, 1100, 40, 17)])
 def test_knn_point_vs_oracle(oracle, b, n, m, k):
