@@ -260,6 +260,26 @@ def test_batch_slots_equal_one_handle_per_run_of_batches(setup):
     assert [int(ln.split()[1]) for ln in marks] == [1, 2, 3, 4, 5]
 
 
+def test_odd_sizes_all_code_paths_agree():
+    """Ragged and extreme cloud sizes (1 point, sizes around the 64-row encoder tile, the 256-row Chamfer tile, the 2048 /
+    4096-point limits of the grid search's instantiations) through every alternative code path the library keeps behind an
+    environment switch: the whole trajectory -- perturbation, nearest-neighbour indices, keep-best metrics -- must be
+    bit-identical to the default path.  Each path runs in its own process (the switches are read once)."""
+    import json, os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_paths_child.py")
+    sizes = ["1", "2", "31", "64", "65", "255", "257", "1023", "2049", "4097"]
+    got = {}
+    for name, env in [("default", {}), ("all-pairs source distance", {"GEOADV_CHAMFER_PRUNE": "0"}),
+                      ("recomputing backward", {"GEOADV_BWD_MASKS": "0"}), ("two-scan Chamfer", {"GEOADV_CHAMFER_SYM": "0"}),
+                      ("row-stationary forward", {"GEOADV_FWD_ROWS": "256"})]:
+        o = subprocess.run([sys.executable, child] + sizes, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in o.stdout.splitlines() if ln.startswith("HASHES ")]
+        assert o.returncode == 0 and lines, (name, o.stderr[-400:])
+        got[name] = json.loads(lines[-1][7:])
+    for name, h in got.items():
+        assert h == got["default"], name
+
+
 def test_emd_combined_loss_step(setup):
     """configs[3]: Chamfer + EMD combined adversarial loss (build-defined: loss_adv = chamfer +
     emd_weight * match_cost(recon, gt) / N, match held constant in the backward like the reference's
