@@ -159,7 +159,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnArgs A) {
     double s1 = 0.0, s2 = 0.0;
     if (A.mode != 2) {
         int t = g;
-        for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight, summed in ascending tile order
+        for (; t + 15 * 32 < A.tiles; t += 16 * 32) {              // sixteen loads in flight (the kernel is a handful of workgroups:
+            float2 p[16];                                          // pure latency), summed in ascending tile order
+#pragma unroll
+            for (int u = 0; u < 16; ++u) p[u] = A.psum[(size_t)(t + 32 * u) * A.C + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { s1 += p[u].x; s2 += p[u].y; }
+        }
+        for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight
             const float2 p0 = A.psum[(size_t)t * A.C + c], p1 = A.psum[(size_t)(t + 32) * A.C + c];
             const float2 p2 = A.psum[(size_t)(t + 64) * A.C + c], p3 = A.psum[(size_t)(t + 96) * A.C + c];
             s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
@@ -513,7 +520,14 @@ __device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdArgs &A, const 
     double s1 = 0.0, s2 = 0.0;
     if (A.mode != 2) {
         int t = g;
-        for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight, summed in ascending tile order
+        for (; t + 15 * 32 < A.tiles; t += 16 * 32) {              // sixteen loads in flight, summed in ascending tile order
+            float2 p[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) p[u] = A.qsum[(size_t)(t + 32 * u) * A.C + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { s1 += p[u].x; s2 += p[u].y; }
+        }
+        for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight
             const float2 p0 = A.qsum[(size_t)t * A.C + c], p1 = A.qsum[(size_t)(t + 32) * A.C + c];
             const float2 p2 = A.qsum[(size_t)(t + 64) * A.C + c], p3 = A.qsum[(size_t)(t + 96) * A.C + c];
             s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
