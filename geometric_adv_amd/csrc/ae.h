@@ -22,7 +22,6 @@ struct DeviceAE {
     int dec_dims[GEOADV_DEC_LAYERS + 1];
     // encoder: layer 0 (fan-in 3) stays un-packed, [3][C1] row-major, plus its transpose use
     const float *w0;               // [3][C1]
-    const float *enc_stream;       // all encoder B fragments (layers 1-4) in the order the row-stationary forward consumes them
     PackedLayer enc_fwd[ENC_L];    // [1..4] used: in[r][C_i] -> [C_{i+1}]
     PackedLayer enc_bwd[ENC_L];    // [1..4] used: W_i^T : [C_{i+1}] -> [C_i]
     const float *scale[ENC_L];     // BN folded: h = max(a*scale + shift, 0), a = x@W (no bias)

@@ -8,13 +8,11 @@
 namespace geoadv {
 
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream);
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
 int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
 int encoder_tiles(int n);
-int launch_encoder_fwd_stamped(const DeviceAE &A, int b, const float *x, float *pmax, int *parg, int *pcnt,
-                               unsigned long long *stamps, hipStream_t stream);
 
 static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -94,8 +92,6 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     std::vector<float> host;
     auto reserve = [&](size_t count) { size_t off = rup(host.size(), 64); host.resize(off + count, 0.f); return off; };
     size_t o_w0 = reserve(3 * C[1]);
-    const size_t stream_frags = 352 + 8;                 // + 8 padding fragments for the prefetch ring's run-out
-    size_t o_stream = reserve(stream_frags * 256);
     size_t o_fwd[ENC_L] = {0}, o_bwd[ENC_L] = {0}, o_scale[ENC_L], o_shift[ENC_L];
     for (int i = 1; i < ENC_L; ++i) {
         o_fwd[i] = reserve((size_t)C[i] * C[i + 1]);
@@ -113,30 +109,6 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
         pack_fragments(host, o_fwd[i], K, N, K, N, [&](int k, int nn) { return W[(size_t)k * N + nn]; });
         // transposed product: B[k][nn] = W[nn][k], K' = N, N' = K
         pack_fragments(host, o_bwd[i], N, K, N, (int)rup(K, 32), [&](int k, int nn) { return W[(size_t)nn * N + k]; });
-    }
-    {   // Row-stationary forward (encoder_fwd3_kernel): one fragment = 64 lanes x float4 = the B operands of one k-group
-        // (8 k) for one 32-column block.  Consumption order of every wave:
-        //   layer 1: K-half 0 (t = 0..3), K-half 1 (t = 4..7), each: for t: for cb = 0..3
-        //   layer 2: K-half 0 (t = 0..7), K-half 1 (t = 8..15), each: for t: for cb = 0..3
-        //   for chunk c = 0..7: layer 3 column block c (t = 0..15); layer 4 k-groups 4c..4c+3: for t: for cb = 0..3
-        size_t f = 0;
-        auto put = [&](int layer, int cb, int t) {
-            const float *W = hw->enc_w[layer];
-            const int N = C[layer + 1];
-            for (int lane = 0; lane < 64; ++lane)
-                for (int u = 0; u < 4; ++u) {
-                    const int k = 8 * t + 4 * (lane >> 5) + u, nn = 32 * cb + (lane & 31);
-                    host[o_stream + (f * 64 + lane) * 4 + u] = W[(size_t)k * N + nn];
-                }
-            ++f;
-        };
-        for (int half = 0; half < 2; ++half) for (int t = 4 * half; t < 4 * half + 4; ++t) for (int cb = 0; cb < 4; ++cb) put(1, cb, t);
-        for (int half = 0; half < 2; ++half) for (int t = 8 * half; t < 8 * half + 8; ++t) for (int cb = 0; cb < 4; ++cb) put(2, cb, t);
-        for (int c = 0; c < 8; ++c) {
-            for (int t = 0; t < 16; ++t) put(3, c, t);
-            for (int t = 4 * c; t < 4 * c + 4; ++t) for (int cb = 0; cb < 4; ++cb) put(4, cb, t);
-        }
-        // f == 352; the 8 padding fragments stay zero
     }
     for (int i = 0; i < ENC_L; ++i)
         for (int c = 0; c < C[i + 1]; ++c) {
@@ -182,7 +154,6 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     memcpy(d.enc_dims, hw->enc_dims, sizeof(d.enc_dims));
     memcpy(d.dec_dims, hw->dec_dims, sizeof(d.dec_dims));
     d.w0 = base + o_w0;
-    d.enc_stream = base + o_stream;
     for (int i = 0; i < ENC_L; ++i) {
         d.enc_fwd[i] = PackedLayer{i ? base + o_fwd[i] : nullptr, C[i], C[i + 1]};
         d.enc_bwd[i] = PackedLayer{i ? base + o_bwd[i] : nullptr, C[i + 1], (int)rup(C[i], 32)};
@@ -236,13 +207,4 @@ extern "C" int geoadv_ae_critical(const geoadv_ae *ae, int b, const float *pc, f
     if (latent) GA_HIP(hipMemcpyAsync(latent, s.z, sizeof(float) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
     if (arg_idx) GA_HIP(hipMemcpyAsync(arg_idx, s.crit, sizeof(int) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
     return GEOADV_OK;
-}
-
-// Diagnostic only (tools/encoder_phases.py): phase stamps of the forward kernel, stamps[b][n/64][12] (device, u64).
-extern "C" int geoadv_debug_encoder_stamps(const geoadv_ae *ae, int b, const float *pc, void *workspace,
-                                           unsigned long long *stamps, void *stream) {
-    GA_REQUIRE(ae && b > 0 && pc && workspace && stamps, "debug_encoder_stamps: bad arguments");
-    void *aligned = reinterpret_cast<void *>(rup(reinterpret_cast<size_t>(workspace), 256));
-    ForwardScratch s = carve_forward_scratch(aligned, b, ae->d.n_points);
-    return launch_encoder_fwd_stamped(ae->d, b, pc, s.pmax, s.parg, s.pcnt, stamps, as_stream(stream));
 }

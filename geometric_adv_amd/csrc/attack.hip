@@ -24,7 +24,6 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
 struct ChamferPair { const float *p, *q; float *dist1; int *idx1; float *dist2; int *idx2; };
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
-int launch_chamfer_light(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, hipStream_t stream);
 int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
                               hipStream_t stream);
 bool chamfer_grid_rides(int n);
@@ -40,7 +39,7 @@ struct ForwardScratch {
 };
 ForwardScratch carve_forward_scratch(void *base, int b, int n_points);
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream);
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 int encoder_mask_words();
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
@@ -454,11 +453,6 @@ struct geoadv_attack {
     float beta1_pow, beta2_pow;
     bool fwd_valid;
     bool adv_valid;                  // adv == x + pert already (written by the Adam kernel)
-    bool overlap;                    // second stream in use
-    bool overlap_fwd;                // run Chamfer(adv, x) (LDS-free scalar-fed kernel) beside the encoder forward
-    bool overlap_bwd;                // run the source-distance gradient beside the decoder / encoder backward
-    hipStream_t s2;
-    hipEvent_t ev_fork, ev_scan, ev_loss, ev_gdist;
     // profiling
     unsigned prof_mask;
     int prof_stride;                 // time every prof_stride-th launch of a selected class (1 = every launch)
@@ -479,7 +473,6 @@ inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 int prof_flush(geoadv_attack *at) {
     if (at->marks.empty()) return GEOADV_OK;
     GA_HIP(hipStreamSynchronize(at->prof_stream));
-    if (at->s2) GA_HIP(hipStreamSynchronize(at->s2));
     for (const auto &mk : at->marks) {
         float ms = 0;
         GA_HIP(hipEventElapsedTime(&ms, at->ev[mk.e0], at->ev[mk.e1]));
@@ -491,51 +484,48 @@ int prof_flush(geoadv_attack *at) {
     return GEOADV_OK;
 }
 
+// Two ways to time a class.  Bracketing (default): hipEventRecord before and after the scope's launches -- the interval
+// includes the dispatch gaps around them (~2 us each between dependent kernels).  Kernel-timed (`kernel` = true, one launch
+// per scope): the scope only reserves the two events and the launcher hands them to hipExtLaunchKernel, which stamps the
+// kernel's own begin / end -- the quantity rocprofv3 --kernel-trace reports, so the two agree.
 struct ProfScope {
-    geoadv_attack *at; int which; int e0; hipStream_t st; bool on;
-    ProfScope(geoadv_attack *a, int w, hipStream_t s) : at(a), which(w), e0(-1), st(s), on((a->prof_mask >> w) & 1u) {
+    geoadv_attack *at; int which; int e0, e1; hipStream_t st; bool on, kernel;
+    ProfScope(geoadv_attack *a, int w, hipStream_t s, bool kernel_timed = false)
+        : at(a), which(w), e0(-1), e1(-1), st(s), on((a->prof_mask >> w) & 1u), kernel(kernel_timed) {
         if (on && at->prof_stride > 1) on = (at->prof_seen[w]++ % (unsigned)at->prof_stride) == 0;
         if (!on) return;
         if (at->ev_used + 2 > (int)at->ev.size()) prof_flush(at);
         e0 = at->ev_used++;
-        (void)hipEventRecord(at->ev[e0], st);
+        if (kernel) e1 = at->ev_used++;
+        else (void)hipEventRecord(at->ev[e0], st);
     }
+    hipEvent_t start() const { return on && kernel ? at->ev[e0] : nullptr; }
+    hipEvent_t stop() const { return on && kernel ? at->ev[e1] : nullptr; }
     ~ProfScope() {
         if (!on) return;
-        const int e1 = at->ev_used++;
-        (void)hipEventRecord(at->ev[e1], st);
+        if (!kernel) {
+            e1 = at->ev_used++;
+            (void)hipEventRecord(at->ev[e1], st);
+        }
         at->marks.push_back({which, e0, e1});
     }
 };
 
 
 // forward(pert): encoder -> latent/decoder -> both Chamfer problems -> per-cloud losses (+ metrics / keep-best).
-// With `overlap`, Chamfer(adv, x) -- VALU bound, and independent of the network -- runs on the second
-// stream while the MFMA-bound encoder/decoder run on the main one; both kinds of workgroup fit on one
-// CU (104 KB + 2 x 24 KB of LDS) and use different pipes.
 int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     const DeviceAE &A = at->ae->d;
     const int B = at->B, n = at->n;
-    const bool split = at->overlap && at->overlap_fwd && at->adv_valid;
     const ChamferScan sc_recon[2] = {{at->recon, at->gt, at->r1, at->ir1, n, n}, {at->gt, at->recon, at->r2, at->ir2, n, n}};
     const ChamferScan sc_adv[2] = {{at->adv, at->x, at->a1, at->ia1, n, n}, {at->x, at->adv, at->a2, at->ia2, n, n}};
-    if (split) {
-        GA_HIP(hipEventRecord(at->ev_fork, st));
-        GA_HIP(hipStreamWaitEvent(at->s2, at->ev_fork, 0));
-        {
-            ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, at->s2);
-            if (int rc = launch_chamfer_light(at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, B, n, at->s2)) return rc;
-        }
-        GA_HIP(hipEventRecord(at->ev_scan, at->s2));
-    }
     // nn_distance(adv, x): adv = x + pert and most points barely move, so the exact grid search seeded with the pairing
     // (chamfer_grid.hip) answers it for a fraction of the all-pairs cost; clouds whose pairing has become poor raise
     // their `need` flag and are redone by the all-pairs launch below (same results either way)
-    const bool pruned = at->chamfer_prune && !split && at->chamfer_sym && chamfer_grid_supports(n, n);
+    const bool pruned = at->chamfer_prune && at->chamfer_sym && chamfer_grid_supports(n, n);
     {
-        ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st);
+        ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st, true);
         if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, at->adv_valid ? nullptr : at->adv, at->fs.pmax, at->fs.parg,
-                                        at->fs.pcnt, at->masks, st)) return rc;
+                                        at->fs.pcnt, at->masks, st, ps.start(), ps.stop())) return rc;
         at->adv_valid = true;
     }
     {
@@ -555,10 +545,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     }
     {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
-        if (split) {
-            const ChamferPair pair{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2};
-            if (int rc = launch_chamfer_sym(&pair, 1, B, n, n, at->sym_ws, st)) return rc;
-        } else if (at->chamfer_sym) {   // one distance evaluation per pair serves both directions
+        if (at->chamfer_sym) {   // one distance evaluation per pair serves both directions
             const ChamferPair pairs[2] = {{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2},
                                           {at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2}};
             if (pruned) {
@@ -574,7 +561,6 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         if (int rc = geoadv_approx_match(B, n, n, at->recon, at->gt, at->emd_match, at->emd_temp, st)) return rc;
         if (int rc = geoadv_match_cost(B, n, n, at->recon, at->gt, at->emd_match, at->emd_cost, st)) return rc;
     }
-    if (split) GA_HIP(hipStreamWaitEvent(st, at->ev_scan, 0));
     {
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
         LossArgs la;
@@ -595,7 +581,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         if (adv_chamfer) ca.pr[np++] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
         if (dist_chamfer) ca.pr[np++] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, 0.f};
         at->cgrad_done = false;
-        if (np && !max_term && !at->overlap && n <= CG_FX_MAX_N_PLANE) {
+        if (np && !max_term && n <= CG_FX_MAX_N_PLANE) {
             ca.n = n; ca.P = 0;
             loss_cgrad_kernel<<<dim3(B, 1 + np), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(la, ca);
             at->cgrad_done = true;
@@ -604,7 +590,6 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         }
         GA_LAUNCH_CHECK();
     }
-    if (at->overlap) GA_HIP(hipEventRecord(at->ev_loss, st));
     at->fwd_valid = true;
     return GEOADV_OK;
 }
@@ -633,21 +618,12 @@ int do_step(geoadv_attack *at, hipStream_t st) {
     const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
     const CGradProblem p_recon{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
     const CGradProblem p_dist{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, at->cfg.max_point_dist_weight};
-    const bool split = at->overlap && at->overlap_bwd && dist_chamfer;
-    if (split) {   // the source-distance gradient does not depend on the network: second stream
-        GA_HIP(hipStreamWaitEvent(at->s2, at->ev_loss, 0));
-        {
-            ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, at->s2);
-            if (int rc = launch_cgrad(&p_dist, 1, B, n, at->s2)) return rc;
-        }
-        GA_HIP(hipEventRecord(at->ev_gdist, at->s2));
-    }
     if (!at->cgrad_done) {   // (normally already produced by the forward's loss launch)
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
         CGradProblem pr[2];
         int np = 0;
         if (adv_chamfer) pr[np++] = p_recon;
-        if (dist_chamfer && !split) pr[np++] = p_dist;
+        if (dist_chamfer) pr[np++] = p_dist;
         if (np)
             if (int rc = launch_cgrad(pr, np, B, n, st)) return rc;
     }
@@ -668,7 +644,6 @@ int do_step(geoadv_attack *at, hipStream_t st) {
         if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, at->masks, st))
             return rc;
     }
-    if (split) GA_HIP(hipStreamWaitEvent(st, at->ev_gdist, 0));
     {
         ProfScope ps(at, GEOADV_PROF_ADAM, st);
         AdamArgs aa;
@@ -759,8 +734,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->grid_calls = 0;
     at->x_box = F(4 * 6 * B);
     {
-        const char *e = getenv("GEOADV_CHAMFER_PRUNE");
-        at->chamfer_prune = !(e && e[0] == '0');
+        const char *e = getenv("GEOADV_CHAMFER_PRUNE");        // A/B override for the parity tests
+        at->chamfer_prune = e ? e[0] != '0' : cfg->all_pairs_source_dist == 0;
     }
     {
         const char *e = getenv("GEOADV_CHAMFER_SYM");
@@ -776,40 +751,17 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->fwd_valid = false; at->adv_valid = false;
     at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr; at->prof_stride = 1;
     for (int i = 0; i < GEOADV_PROF_COUNT; ++i) at->prof_seen[i] = 0;
-    {
-        // GEOADV_OVERLAP (experiment switch): 0 (default) = single stream; 2 = the source-distance gradient runs on a
-        // second stream beside the decoder/encoder backward; 3 = Chamfer(adv, x) runs beside the encoder forward; 1 = both.
-        // Measured on MI355X (B=32, N=2048), all SLOWER than one stream: beside the encoder, LDS-staged Chamfer
-        // workgroups fragment the LDS the encoder needs (2451 vs 2794 it/s at the time); the LDS-free, scalar-fed
-        // chamfer_light_kernel (18-61 VGPRs, no LDS: it does co-reside) still stretches the encoder from 104 to 125-139 us
-        // (3355-3375 vs 3815 it/s) -- MFMA and VALU streams on one SIMD are not free of each other; mode 2: 2630 vs
-        // 2790 it/s (event hand-offs cost more than the small kernels they hide).
-        const char *e = getenv("GEOADV_OVERLAP");
-        const int mode = e ? atoi(e) : 0;
-        at->overlap = mode != 0;
-        at->overlap_fwd = mode == 1 || mode == 3;
-        at->overlap_bwd = mode == 1 || mode == 2;
-    }
-    at->s2 = nullptr;
-    if (at->overlap) {
-        bool ok = hipStreamCreateWithFlags(&at->s2, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&at->ev_fork, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&at->ev_scan, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&at->ev_loss, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&at->ev_gdist, hipEventDisableTiming) == hipSuccess;
-        if (!ok) { at->overlap = false; at->s2 = nullptr; }
-    }
     for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_fx_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(loss_cgrad_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N);
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_attack_fx_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(loss_cgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N));
+            return GEOADV_OK;
+        })) { geoadv_attack_destroy(at); return rc; }
     *out = at;
     return GEOADV_OK;
 }
@@ -817,12 +769,6 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
 extern "C" void geoadv_attack_destroy(geoadv_attack *at) {
     if (!at) return;
     for (auto e : at->ev) (void)hipEventDestroy(e);
-    if (at->s2) {
-        (void)hipStreamSynchronize(at->s2);
-        (void)hipEventDestroy(at->ev_fork); (void)hipEventDestroy(at->ev_scan);
-        (void)hipEventDestroy(at->ev_loss); (void)hipEventDestroy(at->ev_gdist);
-        (void)hipStreamDestroy(at->s2);
-    }
     (void)hipFree(at->arena);
     delete at;
 }

@@ -205,12 +205,10 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
         args.tiles = cdiv(maxq, kWave * R);
         return dim3((unsigned)(args.tiles * 8 * cdiv(b * live, 8)));
     };
-    static int force_r = -1;
-    if (force_r < 0) { const char *e = getenv("GEOADV_CHAMFER_R"); force_r = e ? atoi(e) : 0; }
-    if (force_r == 4 || (!force_r && groups(4) >= 768)) {
+    if (groups(4) >= 768) {
         const dim3 g = grid(4);
         chamfer_scan_kernel<4><<<g, block, 0, stream>>>(args);
-    } else if (force_r == 2 || (!force_r && groups(2) >= 768)) {
+    } else if (groups(2) >= 768) {
         const dim3 g = grid(2);
         chamfer_scan_kernel<2><<<g, block, 0, stream>>>(args);
     } else {
@@ -221,98 +219,7 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
     return GEOADV_OK;
 }
 
-// ------------------------------------------------------------------------------------------
-// "Light" scan for running BESIDE an MFMA-bound kernel on the same CUs: no LDS at all and few registers.  Every wave
-// owns 64 * R queries and walks the whole target cloud on its own; the targets are wave-uniform, so they arrive through
-// the scalar cache into SGPRs (s_load) and enter the VALU as scalar operands.  One problem pair (P, Q), both
-// directions; same arithmetic, chunk-of-8 arg-min and tie rule as chamfer_scan_kernel.
-// ------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(256, 8) void chamfer_light_kernel(const float *__restrict__ P, const float *__restrict__ Q,
-                                                              float *__restrict__ d1, int *__restrict__ i1,
-                                                              float *__restrict__ d2, int *__restrict__ i2, int n, int clouds) {
-    const int lane = threadIdx.x & 63;
-    const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave-uniform
-    const int upc = (n + 64 * R - 1) / (64 * R);                 // units per (scan, cloud)
-    if (unit >= 2 * clouds * upc) return;
-    const int scan = unit / (clouds * upc), c = (unit / upc) % clouds, q0 = (unit % upc) * 64 * R;
-    const float *__restrict__ Qr = (scan ? Q : P) + (size_t)c * n * 3;      // queries
-    const float *__restrict__ T = (scan ? P : Q) + (size_t)c * n * 3;       // targets
-    // the same cloud seen through the constant address space: wave-uniform loads from it are scalar (s_load into SGPRs);
-    // nothing writes the clouds while this kernel runs
-    typedef const float __attribute__((address_space(4))) *scalar_ptr;
-    const scalar_ptr Ts = (scalar_ptr)(unsigned long long)T;
-    float qx[R], qy[R], qz[R], best[R];
-    int bestk[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int qi = q0 + r * 64 + lane;
-        qi = qi < n ? qi : n - 1;
-        qx[r] = Qr[3 * qi]; qy[r] = Qr[3 * qi + 1]; qz[r] = Qr[3 * qi + 2];
-        best[r] = INFINITY; bestk[r] = 0;
-    }
-    auto chunk = [&](const float (&t)[3 * CH_CHUNK], int k0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float cm = sqdist(t[0], t[1], t[2], qx[r], qy[r], qz[r]);
-#pragma unroll
-            for (int u = 1; u < CH_CHUNK; ++u) cm = fminf(cm, sqdist(t[3 * u], t[3 * u + 1], t[3 * u + 2], qx[r], qy[r], qz[r]));
-            if (cm < best[r]) { best[r] = cm; bestk[r] = k0; }
-        }
-    };
-    const int nfull = n & ~(CH_CHUNK - 1);
-    for (int k0 = 0; k0 < nfull; k0 += CH_CHUNK) {                // 24 consecutive dwords: s_load_dwordx16 + s_load_dwordx8
-        float t[3 * CH_CHUNK];                                    // (their latency is covered by the other resident waves)
-#pragma unroll
-        for (int u = 0; u < 3 * CH_CHUNK; ++u) t[u] = Ts[3 * (size_t)k0 + u];
-        chunk(t, k0);
-    }
-    if (nfull < n) {                                              // ragged tail: repeat the last target (cannot win a tie: higher u)
-        float t[3 * CH_CHUNK];
-#pragma unroll
-        for (int u = 0; u < CH_CHUNK; ++u) {
-            const int k = nfull + u < n ? nfull + u : n - 1;
-            t[3 * u] = Ts[3 * (size_t)k]; t[3 * u + 1] = Ts[3 * (size_t)k + 1]; t[3 * u + 2] = Ts[3 * (size_t)k + 2];
-        }
-        chunk(t, nfull);
-    }
-    float *dist = (scan ? d2 : d1) + (size_t)c * n;
-    int *idx = (scan ? i2 : i1) + (size_t)c * n;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int found = bestk[r];
-        bool hit = false;
-        for (int u = 0; u < CH_CHUNK; ++u) {
-            const int k = bestk[r] + u;
-            if (k < n) {
-                const float d = sqdist(T[3 * (size_t)k], T[3 * (size_t)k + 1], T[3 * (size_t)k + 2], qx[r], qy[r], qz[r]);
-                if (!hit && d == best[r]) { hit = true; found = k; }
-            }
-        }
-        const int qi = q0 + r * 64 + lane;
-        if (qi < n) { dist[qi] = best[r]; idx[qi] = found; }
-    }
-}
-
-// Both directions of nn_distance(P, Q) for equal point counts, LDS-free (see chamfer_light_kernel).
-int launch_chamfer_light(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, hipStream_t stream) {
-    if (b <= 0 || n <= 0) return GEOADV_OK;
-    constexpr int R = 1;      // two of these waves per SIMD at B = 32, N = 2048: they cover each other's scalar-load latency
-    const int units = 2 * b * cdiv(n, 64 * R);
-    chamfer_light_kernel<R><<<cdiv(units, 4), 256, 0, stream>>>(P, Q, d1, i1, d2, i2, n, b);
-    GA_LAUNCH_CHECK();
-    return GEOADV_OK;
-}
-
 }  // namespace geoadv
-
-extern "C" int geoadv_nn_distance_light(int b, int n, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
-                                        float *dist2, int *idx2, void *stream) {
-    GA_REQUIRE(b >= 0 && n >= 1, "nn_distance_light: bad dimensions (b=%d n=%d)", b, n);
-    if (b == 0) return GEOADV_OK;
-    GA_REQUIRE(xyz1 && xyz2 && dist1 && idx1 && dist2 && idx2, "nn_distance_light: null pointer");
-    return geoadv::launch_chamfer_light(xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, geoadv::as_stream(stream));
-}
 
 namespace geoadv {
 
@@ -366,12 +273,12 @@ int launch_chamfer_grad(int b, int n, const float *xyz1, int m, const float *xyz
     const int P1 = pow2_at_least(n), P2 = pow2_at_least(m);
     const size_t l1 = grad_lds_bytes(P1), l2 = grad_lds_bytes(P2);
     const size_t lds = l1 > l2 ? l1 : l2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        attr_set = true;
-    }
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            return GEOADV_OK;
+        })) return rc;
     chamfer_grad_kernel<<<dim3(b, g2 ? 2 : 1), CG_THREADS, lds, stream>>>(n, xyz1, m, xyz2, gd1, idx1, gd2, idx2,
                                                                          g1, g2, P1, P2);
     GA_LAUNCH_CHECK();

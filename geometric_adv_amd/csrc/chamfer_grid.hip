@@ -32,12 +32,12 @@ bool chamfer_grid_rides(int n) { return n >= 1 && n <= GR_MAX_N; }      // small
 
 template <int MAXN>
 static int launch_grid(const GridArgs &a, int b, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grid_kernel<MAXN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)chamfer_grid_lds_bytes(MAXN)));
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_grid_kernel<MAXN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)chamfer_grid_lds_bytes(MAXN)));
+            return GEOADV_OK;
+        })) return rc;
     chamfer_grid_kernel<MAXN><<<dim3(b, 2, GR_QSPLIT), GR_THREADS, chamfer_grid_lds_bytes(a.n), stream>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;

@@ -336,19 +336,16 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     for (int i = 0; i < np; ++i) a.pr[i] = pairs[i];
     a.n = n; a.m = m; a.tiles = cdiv(n, CS_ROWS); a.clouds = b; a.pairs = np; a.colpart = workspace;
     // column slices so that the grid fills the chip (4 workgroups per CU resident): 1, 2 or 4
-    static int force_split = -1;
-    if (force_split < 0) { const char *e = getenv("GEOADV_SYM_SPLIT"); force_split = e ? atoi(e) : 0; }
     a.csplit = 1;
     while (a.csplit < CS_MAX_SPLIT && (long)a.tiles * a.csplit * b * np < 256 && m / (a.csplit * 2) >= 256) a.csplit *= 2;   // measured: slicing only pays when the grid would not even cover the CUs
-    if (force_split == 1 || force_split == 2 || force_split == 4) a.csplit = force_split;
     a.rowpart_d = workspace + (size_t)np * b * a.tiles * m;
     a.rowpart_i = reinterpret_cast<int *>(a.rowpart_d + (size_t)np * b * CS_MAX_SPLIT * n);
-    static bool attr = false;
-    if (!attr) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_finish_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_finish_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            return GEOADV_OK;
+        })) return rc;
     const unsigned grid = (unsigned)(a.tiles * a.csplit * 8 * cdiv(b * np, 8));
     chamfer_sym_kernel<<<grid, CS_THREADS, 0, stream>>>(a);
     GA_LAUNCH_CHECK();

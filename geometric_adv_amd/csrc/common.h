@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 #include "../../include/geoadv.h"
 
 namespace geoadv {
@@ -32,6 +33,22 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;   // gfx950 wavefront
+
+// One-time kernel attribute setup (hipFuncSetAttribute applies to the CURRENT device only): run(f) calls f once per device
+// ordinal, under a lock, so handles created on cuda:1 after cuda:0, or from several host threads, all get their >64 KB LDS opt-in.
+struct DeviceOnce {
+    std::mutex mu;
+    unsigned long long done = 0;
+    template <class F> int run(F f) {
+        int dev = 0;
+        GA_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> g(mu);
+        if ((done >> (dev & 63)) & 1ull) return GEOADV_OK;
+        if (int rc = f()) return rc;
+        done |= 1ull << (dev & 63);
+        return GEOADV_OK;
+    }
+};
 
 #ifdef __HIPCC__
 // Lexicographic (value, index) minimum over the 64 lanes of a wave; every lane ends up with the result.  Four DPP steps

@@ -287,12 +287,12 @@ int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, c
                                   int *zcnt, int *dense, float *d1, float *d2, const float *P, const float *Q, float *gd1, int *gi1,
                                   float *gd2, int *gi2, int n, int *need, int call, const float *box, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
-    static bool attr = false;
-    if (!attr) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(latent_decode_and_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)chamfer_grid_lds_bytes(GR_MAX_N)));
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(latent_decode_and_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)chamfer_grid_lds_bytes(GR_MAX_N)));
+            return GEOADV_OK;
+        })) return rc;
     const GridArgs G{P, Q, gd1, gi1, gd2, gi2, n, need, call, box};
     latent_decode_and_grid_kernel<<<b + b * 2 * GR_QSPLIT, LD_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
         A, encoder_tiles(A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);

@@ -22,6 +22,7 @@
 // (half0 + half1), layers 3 and 4 run one chain in ascending k.
 #include "ae.h"
 #include "mfma_tile.h"
+#include <hip/hip_ext.h>
 #include <limits.h>
 #include <stdlib.h>
 
@@ -35,8 +36,6 @@ template <int ROWS> struct EncLds {
     static constexpr int Q_FLOATS = ROWS * (128 + 4);
     static constexpr int SCRATCH_FLOATS = ROWS == 32 ? 3 * 2 * 16 * 64 : 16 * 64 * 4;   // K-part hand-off
     static constexpr int MASK_BYTES = ROWS * (64 + 128 + 128 + 256);
-    static constexpr int FWD_SCRATCH_FLOATS = ROWS == 32 ? 4 * 16 * 64 : 0;                 // 128-wide layers: 4 units x 1 hand-off
-    static constexpr size_t fwd_bytes = sizeof(float) * (P_FLOATS + Q_FLOATS + FWD_SCRATCH_FLOATS + ROWS * 3 + 256) + sizeof(int) * 512;
     static constexpr size_t bwd_bytes = sizeof(float) * (P_FLOATS + Q_FLOATS + SCRATCH_FLOATS + ROWS * 3) + sizeof(int) * ROWS + MASK_BYTES;
 };
 
@@ -77,92 +76,9 @@ __device__ __forceinline__ void fwd_layer0(const float *pts /*LDS [ROWS][3]*/, f
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward kernel.  grid = (tiles per cloud, clouds).  Outputs per tile and channel: the maximum
-// of h5 over the tile's valid rows, the first row attaining it, and how many rows attain it.
-// ------------------------------------------------------------------------------------------
-template <int ROWS>
-__global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(DeviceAE A, int n, const float *x,
-                                                                  const float *pert, float *adv_out, float *pmax,
-                                                                  int *parg, int *pcnt) {
-    using LD = EncLds<ROWS>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *bufP = lds;
-    float *bufQ = bufP + LD::P_FLOATS;
-    float *scratch = bufQ + LD::Q_FLOATS;
-    float *pts = scratch + LD::FWD_SCRATCH_FLOATS;    // [ROWS][3]
-    float *redm = pts + ROWS * 3;                     // [2][128]
-    int *reda = reinterpret_cast<int *>(redm + 256);  // [2][128]
-    int *redc = reda + 256;                           // [2][128]
-
-    const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
-    const int n0 = tile * ROWS;
-    if (threadIdx.x < ROWS * 3) {
-        const int r = threadIdx.x / 3, a = threadIdx.x % 3;
-        int p = n0 + r;
-        const bool valid = p < n;
-        p = valid ? p : n - 1;                        // padding rows repeat the last point (masked below)
-        const size_t g = ((size_t)b * n + p) * 3 + a;
-        float v = x[g];
-        if (pert) v += pert[g];
-        pts[threadIdx.x] = v;
-        if (adv_out && valid) adv_out[g] = v;
-    }
-    __syncthreads();
-    fwd_layer0<ROWS, false>(pts, bufQ, 68, A, nullptr);
-    __syncthreads();
-    fwd_layer<ROWS, 128, false>(bufQ, 68, bufP, 132, A.enc_fwd[1], A.scale[1], A.shift[1], nullptr, scratch);
-    __syncthreads();
-    fwd_layer<ROWS, 128, false>(bufP, 132, bufQ, 132, A.enc_fwd[2], A.scale[2], A.shift[2], nullptr, scratch);
-    __syncthreads();
-    fwd_layer<ROWS, 256, false>(bufQ, 132, bufP, 260, A.enc_fwd[3], A.scale[3], A.shift[3], nullptr, scratch);
-    __syncthreads();
-
-    // layer 4 + symmetric max-pool straight from the accumulators: every lane owns one column and
-    // 16 rows per row block (ascending), so the running (max, first row, count) stays in registers.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = lane >> 5;
-    float mx = -1.f;
-    int arg = INT_MAX, cnt = 0, mycol = 0, myrb = 0;
-    {
-        constexpr int UNITS = 4 * (ROWS / 32);
-        const int unit = wave % UNITS;
-        mycol = (unit % 4) * 32 + (lane & 31);
-        myrb = unit / 4;
-    }
-    const float sc = A.scale[4][mycol], sh = A.shift[4][mycol];
-    layer_gemm<ROWS, 128, KC_L4>(bufP, 260, A.enc_fwd[4], scratch, [&](int row, int col, float a) {
-        const float v = fmaxf(fmaf(a, sc, sh), 0.f);
-        if (n0 + row < n) {
-            if (v > mx) { mx = v; arg = n0 + row; cnt = 1; }
-            else if (v == mx) cnt++;
-        }
-    });
-    {   // the two lane halves hold interleaved rows of the same column
-        const float m2 = __shfl_xor(mx, 32);
-        const int a2 = __shfl_xor(arg, 32), c2 = __shfl_xor(cnt, 32);
-        if (m2 > mx) { mx = m2; arg = a2; cnt = c2; }
-        else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += c2; }
-    }
-    constexpr int OWNERS = 4 * (ROWS / 32);           // waves that own an output unit of layer 4
-    if (wave < OWNERS && h == 0) { redm[myrb * 128 + mycol] = mx; reda[myrb * 128 + mycol] = arg; redc[myrb * 128 + mycol] = cnt; }
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const int c = threadIdx.x;
-        float m = redm[c];
-        int a = reda[c], k = redc[c];
-        if (ROWS == 64) {
-            const float m2 = redm[128 + c];
-            if (m2 > m) { m = m2; a = reda[128 + c]; k = redc[128 + c]; }
-            else if (m2 == m) { k += redc[128 + c]; }   // rows of block 1 are higher: arg stays
-        }
-        const size_t o = ((size_t)b * tiles + tile) * 128 + c;
-        pmax[o] = m; parg[o] = a; pcnt[o] = k;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Forward kernel, two-buffer form (default).  Same arithmetic and the same canonical accumulation
-// order as encoder_fwd_kernel<64>, but the 256-wide h4 is never held whole: layer 3 is computed in
+// Forward kernel.  grid = (tiles of 64 points per cloud, clouds).  Outputs per tile and channel: the maximum of h5 over
+// the tile's valid rows, the first row attaining it, and how many rows attain it.  Same arithmetic and canonical
+// accumulation order as the recomputing backward below; the 256-wide h4 is never held whole: layer 3 is computed in
 // two column halves and each half is consumed at once by the matching K-half of layer 4 (whose
 // canonical order IS "K-half 0 + K-half 1").  Two 64 x 132 buffers (67.6 KB) instead of 100 KB, so
 // TWO workgroups share a CU and one's epilogues / barriers / first-operand latencies hide under
@@ -249,17 +165,10 @@ __device__ __forceinline__ void chain_ring(const float *ar, int at0, const FragS
 
 __device__ __forceinline__ int orow_of(int rb) { return rb * 32; }
 
-template <bool STAMP, bool MASKS>
+template <bool MASKS>
 __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A, int n, const float *x, const float *pert,
                                                                      float *adv_out, float *pmax, int *parg, int *pcnt,
-                                                                     unsigned long long *stamps, unsigned *masks) {
-    // STAMP: diagnostic build only (geoadv_debug_encoder_stamps): wave 0 of every workgroup records s_memtime at the
-    // phase boundaries into its own buffer; no output depends on them.
-    auto stamp = [&](int k) {
-        if (STAMP && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + k] = __builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
-    if (STAMP && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + 9] = __builtin_amdgcn_s_memrealtime();
+                                                                     unsigned *masks) {
     constexpr int ROWS = 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds;
@@ -342,7 +251,6 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         if (MASKS) reinterpret_cast<unsigned char *>(mtile)[row * (4 * MASK_WORDS) + (threadIdx.x & 7)] = (unsigned char)bits;
     }
     __syncthreads();
-    stamp(1);
     const int mrow = orow_of(rb) + (lane & 3) + 8 * ((lane & 15) >> 2);    // lanes 0-15: row acc_row(lane, 0) of this wave's block
 
     const int orow = orow_of(rb);                     // accumulator rows of this wave: orow + acc_row(r, h)
@@ -364,7 +272,6 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         if (MASKS && lane < 16) { mtile[mrow * MASK_WORDS + MASK_OFF2 + cb] = wl; mtile[(mrow + 4) * MASK_WORDS + MASK_OFF2 + cb] = wh; }
     }
     __syncthreads();
-    stamp(2);
     // ---- layer 2: 128 -> 128, canonical K halves (8 + 8) ----
     {
         const float *ar = bufB + (orow + i) * 132 + 4 * h;
@@ -381,7 +288,6 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         if (MASKS && lane < 16) { mtile[mrow * MASK_WORDS + MASK_OFF3 + cb] = wl; mtile[(mrow + 4) * MASK_WORDS + MASK_OFF3 + cb] = wh; }
     }
     __syncthreads();
-    stamp(3);
     // ---- layers 3 + 4 interleaved by halves: h4[:, 128*half ..] feeds K-half `half` of layer 4 ----
     f32x16 acc4[1] = {};                              // layer 4: ONE chain over K = 256 (canonical), fed half by half
 #pragma unroll
@@ -403,14 +309,12 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
             }
         }
         __syncthreads();
-        stamp(4 + 2 * half);
         {
             const float *ar = bufB + (orow + i) * 132 + 4 * h;
             if (half == 0) chain_ring<kg4 / 2, true>(ar, 0, w4, lb, ring, w3b, acc4);
             else chain_ring<kg4 / 2, false>(ar, 0, frag_at(w4, kg4 / 2), lb, ring, w4, acc4);
         }
         if (half == 0) __syncthreads();               // bufB is rewritten by the second half of layer 3
-        stamp(5 + 2 * half);
     }
     // BN + ReLU and the max-pool from the registers: maximum, FIRST row attaining it, number of rows attaining it.
     // Two branch-free passes (max, then compare) -- a third of the VALU instructions of the if / else-if form.
@@ -457,221 +361,6 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         const int live = n - n0 < ROWS ? n - n0 : ROWS;   // they count in vmcnt and stall the fragment ring)
         unsigned *dst = masks + ((size_t)b * n + n0) * MASK_WORDS;
         for (int e = threadIdx.x; e < live * MASK_WORDS; e += ENC_THREADS) dst[e] = mtile[e];
-    }
-    stamp(8);
-    if (STAMP && threadIdx.x == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + 10] = __builtin_amdgcn_s_memrealtime();
-}
-
-// ------------------------------------------------------------------------------------------
-// Forward kernel, ROW-STATIONARY form.  The per-point MLP has no coupling between points, so a wave that owns
-// 32 points can take them through all five layers on its own: no workgroup barrier anywhere before the pool, the
-// A fragment of a k-group is reused for four column blocks (one ds_read_b128 per 16 MFMAs), and the 256-row
-// workgroups (8 waves) fill the chip in ONE round at B = 32 (256 workgroups = 256 CUs) instead of two lockstep
-// rounds of 64-row tiles.  All waves consume the same weight fragments in the same order, so the weights are
-// pre-packed into one linear stream (DeviceAE::enc_stream) that each wave walks through an 8-deep register ring.
-// LDS per wave: its activations [32][<=128] fp32, updated in place layer after layer (16 KB, XOR-swizzled instead
-// of padded so that 8 waves fit), plus a [32][32] scratch (4 KB) through which the 256-wide h4 passes 32 columns
-// at a time straight into layer 4 -- h4 is never materialised.  8 x 20 KB = all 160 KB of the CU.
-// Accumulation orders are the canonical ones (layers 1/2: K-half 0 + K-half 1; layers 3/4: one chain), so the sparse
-// backward's recompute stays bit-identical.
-// ------------------------------------------------------------------------------------------
-constexpr int F3_THREADS = 512;
-constexpr int F3_ROWS = 256;                                   // per workgroup (32 per wave)
-constexpr int F3_WAVE_FLOATS = 32 * 128 + 32 * 32;             // activations + h4 scratch
-constexpr size_t F3_LDS_BYTES = sizeof(float) * 8 * F3_WAVE_FLOATS;
-
-__device__ __forceinline__ int swz128(int row, int col) { return row * 128 + ((((col >> 2) ^ (row & 31)) << 2) | (col & 3)); }
-__device__ __forceinline__ int swz64(int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); }
-__device__ __forceinline__ int swz32(int row, int col) { return row * 32 + ((((col >> 2) ^ ((row >> 1) & 7)) << 2) | (col & 3)); }
-
-__global__ __launch_bounds__(F3_THREADS, 2) void encoder_fwd3_kernel(DeviceAE A, int n, const float *x, const float *pert,
-                                                                    float *adv_out, float *pmax, int *parg, int *pcnt) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = lane >> 5, i = lane & 31;
-    float *hbuf = lds + wave * F3_WAVE_FLOATS;                 // [32][64 or 128], swizzled
-    float *cbuf = hbuf + 32 * 128;                             // [32][32], swizzled
-    const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
-    const int n0 = tile * F3_ROWS + wave * 32;                 // first point of this wave
-
-    // the weight stream: fragment j is 64 x float4 at stream + 64 j; ring q[] always holds fragments pos .. pos+3
-    const float4 *stream = reinterpret_cast<const float4 *>(A.enc_stream) + lane;
-    float4 q[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) q[j] = stream[(size_t)j * 64];
-    int pos = 0;
-#define F3_CONSUME(slot, avec, accv)                                                        \
-    do {                                                                                    \
-        accv = __builtin_amdgcn_mfma_f32_32x32x2f32((avec).x, q[slot].x, accv, 0, 0, 0);    \
-        accv = __builtin_amdgcn_mfma_f32_32x32x2f32((avec).y, q[slot].y, accv, 0, 0, 0);    \
-        accv = __builtin_amdgcn_mfma_f32_32x32x2f32((avec).z, q[slot].z, accv, 0, 0, 0);    \
-        accv = __builtin_amdgcn_mfma_f32_32x32x2f32((avec).w, q[slot].w, accv, 0, 0, 0);    \
-        q[slot] = stream[(size_t)(pos + 4 + (slot)) * 64];                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-    } while (0)
-
-    // ---- points of this wave (lanes 0..31: one row each) and layer 0 (lane = channel, loop over the 32 rows) ----
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (h == 0) {
-        int p = n0 + i;
-        const bool valid = p < n;
-        p = valid ? p : n - 1;
-        const size_t g = ((size_t)b * n + p) * 3;
-        px = x[g]; py = x[g + 1]; pz = x[g + 2];
-        if (pert) { px += pert[g]; py += pert[g + 1]; pz += pert[g + 2]; }
-        if (adv_out && valid) { adv_out[g] = px; adv_out[g + 1] = py; adv_out[g + 2] = pz; }
-    }
-    {
-        const float wx = A.w0[lane], wy = A.w0[64 + lane], wz = A.w0[128 + lane];
-        const float s0 = A.scale[0][lane], t0 = A.shift[0][lane];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const float rx = __shfl(px, r), ry = __shfl(py, r), rz = __shfl(pz, r);
-            float a = rx * wx;
-            a = fmaf(ry, wy, a);
-            a = fmaf(rz, wz, a);
-            hbuf[swz64(r, lane)] = fmaxf(fmaf(a, s0, t0), 0.f);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // A fragment of k-group t for this lane's row: logical columns 8t + 4h .. +3
-#define F3_A64(t) (*reinterpret_cast<const float4 *>(hbuf + i * 64 + ((((2 * (t) + h) ^ (i & 15))) << 2)))
-#define F3_A128(t) (*reinterpret_cast<const float4 *>(hbuf + i * 128 + ((((2 * (t) + h) ^ (i & 31))) << 2)))
-#define F3_AC(t) (*reinterpret_cast<const float4 *>(cbuf + i * 32 + ((((2 * (t) + h) ^ ((i >> 1) & 7))) << 2)))
-
-    // ---- layer 1: 64 -> 128 ----
-    {
-        f32x16 acc[2][4] = {};
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {               // 2 k-groups (8 fragments) per ring turn
-                const float4 a0 = F3_A64(4 * half + 2 * t2), a1 = F3_A64(4 * half + 2 * t2 + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                F3_CONSUME(0, a0, acc[half][0]); F3_CONSUME(1, a0, acc[half][1]); F3_CONSUME(2, a0, acc[half][2]); F3_CONSUME(3, a0, acc[half][3]);
-                pos += 4;
-                F3_CONSUME(0, a1, acc[half][0]); F3_CONSUME(1, a1, acc[half][1]); F3_CONSUME(2, a1, acc[half][2]); F3_CONSUME(3, a1, acc[half][3]);
-                pos += 4;
-            }
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const int col = cb * 32 + i;
-            const float sc = A.scale[1][col], sh = A.shift[1][col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                hbuf[swz128(acc_row(r, h), col)] = fmaxf(fmaf(acc[0][cb][r] + acc[1][cb][r], sc, sh), 0.f);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- layer 2: 128 -> 128 (in place) ----
-    {
-        f32x16 acc[2][4] = {};
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-            for (int t2 = 0; t2 < 4; ++t2) {
-                const float4 a0 = F3_A128(8 * half + 2 * t2), a1 = F3_A128(8 * half + 2 * t2 + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                F3_CONSUME(0, a0, acc[half][0]); F3_CONSUME(1, a0, acc[half][1]); F3_CONSUME(2, a0, acc[half][2]); F3_CONSUME(3, a0, acc[half][3]);
-                pos += 4;
-                F3_CONSUME(0, a1, acc[half][0]); F3_CONSUME(1, a1, acc[half][1]); F3_CONSUME(2, a1, acc[half][2]); F3_CONSUME(3, a1, acc[half][3]);
-                pos += 4;
-            }
-        __builtin_amdgcn_wave_barrier();                  // every A fragment of h2 has been read: overwrite in place
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const int col = cb * 32 + i;
-            const float sc = A.scale[2][col], sh = A.shift[2][col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                hbuf[swz128(acc_row(r, h), col)] = fmaxf(fmaf(acc[0][cb][r] + acc[1][cb][r], sc, sh), 0.f);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- layers 3 + 4: h4 passes through cbuf 32 columns at a time ----
-    f32x16 acc4[4] = {};                              // layer 4: one chain per column block over all of K (canonical)
-    for (int c = 0; c < 8; ++c) {
-        f32x16 acc3 = {};
-        for (int t4 = 0; t4 < 4; ++t4) {                  // 4 k-groups (4 fragments) per ring turn
-            const float4 a0 = F3_A128(4 * t4), a1 = F3_A128(4 * t4 + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            F3_CONSUME(0, a0, acc3);
-            const float4 a2 = F3_A128(4 * t4 + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            F3_CONSUME(1, a1, acc3);
-            const float4 a3 = F3_A128(4 * t4 + 3);
-            __builtin_amdgcn_sched_barrier(0);
-            F3_CONSUME(2, a2, acc3);
-            F3_CONSUME(3, a3, acc3);
-            pos += 4;
-        }
-        {
-            const int col = c * 32 + i;
-            const float sc = A.scale[3][col], sh = A.shift[3][col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cbuf[swz32(acc_row(r, h), i)] = fmaxf(fmaf(acc3[r], sc, sh), 0.f);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const float4 a0 = F3_AC(2 * t2), a1 = F3_AC(2 * t2 + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            F3_CONSUME(0, a0, acc4[0]); F3_CONSUME(1, a0, acc4[1]); F3_CONSUME(2, a0, acc4[2]); F3_CONSUME(3, a0, acc4[3]);
-            pos += 4;
-            F3_CONSUME(0, a1, acc4[0]); F3_CONSUME(1, a1, acc4[1]); F3_CONSUME(2, a1, acc4[2]); F3_CONSUME(3, a1, acc4[3]);
-            pos += 4;
-        }
-        __builtin_amdgcn_wave_barrier();                  // cbuf is rewritten by the next chunk
-    }
-#undef F3_CONSUME
-#undef F3_A64
-#undef F3_A128
-#undef F3_AC
-    // ---- pool: this wave's 32 rows per column, then the 8 waves of the workgroup in row order ----
-    float wm[4]; int wa[4], wc[4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int col = cb * 32 + i;
-        const float sc = A.scale[4][col], sh = A.shift[4][col];
-        float mx = -1.f;
-        int arg = INT_MAX, cnt = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, h);
-            const float v = fmaxf(fmaf(acc4[cb][r], sc, sh), 0.f);
-            if (n0 + row < n) {
-                if (v > mx) { mx = v; arg = n0 + row; cnt = 1; }
-                else if (v == mx) cnt++;
-            }
-        }
-        const float m2 = __shfl_xor(mx, 32);
-        const int a2 = __shfl_xor(arg, 32), c2 = __shfl_xor(cnt, 32);
-        if (m2 > mx) { mx = m2; arg = a2; cnt = c2; }
-        else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += c2; }
-        wm[cb] = mx; wa[cb] = arg; wc[cb] = cnt;
-    }
-    __syncthreads();                                       // all waves are done with their LDS regions
-    float *redm = lds;                                     // [8][128]
-    int *reda = reinterpret_cast<int *>(lds + 1024), *redc = reda + 1024;
-    if (h == 0) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            redm[wave * 128 + cb * 32 + i] = wm[cb]; reda[wave * 128 + cb * 32 + i] = wa[cb]; redc[wave * 128 + cb * 32 + i] = wc[cb];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const int cidx = threadIdx.x;
-        float m = redm[cidx];
-        int a = reda[cidx], k = redc[cidx];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) {
-            const float m2 = redm[w * 128 + cidx];
-            if (m2 > m) { m = m2; a = reda[w * 128 + cidx]; k = redc[w * 128 + cidx]; }
-            else if (m2 == m) k += redc[w * 128 + cidx];    // later waves hold higher rows: arg stays
-        }
-        const size_t o = ((size_t)b * tiles + tile) * 128 + cidx;
-        pmax[o] = m; parg[o] = a; pcnt[o] = k;
     }
 }
 
@@ -857,12 +546,6 @@ __device__ __forceinline__ void encoder_bwd_masked_body(const DeviceAE &A, int n
     }
 }
 
-__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_masked_kernel(DeviceAE A, int n, const unsigned *masks, const int *rows,
-                                                                        const float *z, const float *dz, const int *dense_flag,
-                                                                        float *g_enc) {
-    encoder_bwd_masked_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x, blockIdx.y);
-}
-
 // Sparse launch: grid (128 / ROWS, batch): block (tile, b) handles 32 of cloud b's 128 critical rows; flagged clouds
 // (exact tie in the max-pool) are skipped.  Dense launch: grid (n / ROWS, DENSE_SLOTS): the flagged clouds -- almost
 // never any -- are dealt round-robin to the DENSE_SLOTS block rows, which process every point of them; with no flagged
@@ -929,115 +612,71 @@ constexpr int BWD_SPARSE_ROWS = 32;
 constexpr int BWD_DENSE_ROWS = 64;
 
 static int set_lds_attr_once() {
-    static bool done = false;
-    if (done) return GEOADV_OK;
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<64>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::fwd_bytes));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd_kernel<32>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<32>::fwd_bytes));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)F3_LDS_BYTES));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES_MASKS));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<true, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_masked_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWM_LDS_BYTES));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_merged_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::bwd_bytes));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_SPARSE_ROWS>::bwd_bytes));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_DENSE_ROWS, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_DENSE_ROWS>::bwd_bytes));
-    done = true;
-    return GEOADV_OK;
+    static DeviceOnce once;
+    return once.run([]() -> int {
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES_MASKS));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_merged_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::bwd_bytes));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_SPARSE_ROWS>::bwd_bytes));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_DENSE_ROWS, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<BWD_DENSE_ROWS>::bwd_bytes));
+        return GEOADV_OK;
+    });
 }
 
-// Forward kernel selection (GEOADV_FWD_ROWS): "256" = row-stationary form (encoder_fwd3_kernel; measured equal to the
-// default at B=32: 102.6 vs 101.5 us -- interleaving its MFMAs over the four independent accumulators made it SLOWER,
-// 111 us); unset/"2buf" = two-buffer 64-row form (2 workgroups per CU,
-// default); "64" = single-pass 64-row form (1 per CU); "32" = 32-row form (2 per CU, K split over waves).
-static int fwd_variant() {          // 3: row-stationary (256 rows), 0: two-buffer (64), 64, 32
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GEOADV_FWD_ROWS");
-        v = !e ? 0 : (atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : (atoi(e) == 256 ? 3 : 0)));
-    }
-    return v;
-}
-int encoder_fwd_rows() { return fwd_variant() == 3 ? F3_ROWS : (fwd_variant() == 32 ? 32 : 64); }
-int encoder_tiles(int n) { return cdiv(n, encoder_fwd_rows()); }
+int encoder_fwd_rows() { return 64; }
+int encoder_tiles(int n) { return cdiv(n, 64); }
 
-// pmax/parg/pcnt: [b][tiles][128]
-// Words of ReLU mask per point the default forward can leave for the sparse backward (0: this build's forward variant
-// does not write masks and the backward recomputes).
-int encoder_mask_words() { return fwd_variant() == 0 ? MASK_WORDS : 0; }
+// Words of ReLU mask per point the forward leaves for the sparse backward.
+int encoder_mask_words() { return MASK_WORDS; }
 
+// pmax/parg/pcnt: [b][tiles][128]; masks: [b][n][MASK_WORDS] or null (plain forward: geoadv_ae_forward, recomputing backward)
+// start / stop (optional): events that receive the kernel's own begin / end time stamps (geoadv_attack_profile).
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream) {
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
-    if (masks && fwd_variant() == 0) {
-        encoder_fwd2_kernel<false, true><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES_MASKS, stream>>>(
-            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr, masks);
-        GA_LAUNCH_CHECK();
-        return GEOADV_OK;
-    }
-    if (fwd_variant() == 3)
-        encoder_fwd3_kernel<<<dim3(encoder_tiles(A.n_points), b), F3_THREADS, F3_LDS_BYTES, stream>>>(
-            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
-    else if (fwd_variant() == 0)
-        encoder_fwd2_kernel<false, false><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
-            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr, nullptr);
-    else if (fwd_variant() == 64)
-        encoder_fwd_kernel<64><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<64>::fwd_bytes, stream>>>(
-            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
+    const dim3 grid(encoder_tiles(A.n_points), b);
+    if (start && stop) {
+        if (masks)
+            hipExtLaunchKernelGGL(encoder_fwd2_kernel<true>, grid, dim3(ENC_THREADS), (unsigned)FWD2_LDS_BYTES_MASKS, stream, start, stop, 0,
+                                  A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks);
+        else
+            hipExtLaunchKernelGGL(encoder_fwd2_kernel<false>, grid, dim3(ENC_THREADS), (unsigned)FWD2_LDS_BYTES, stream, start, stop, 0,
+                                  A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, (unsigned *)nullptr);
+    } else if (masks)
+        encoder_fwd2_kernel<true><<<grid, ENC_THREADS, FWD2_LDS_BYTES_MASKS, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks);
     else
-        encoder_fwd_kernel<32><<<dim3(encoder_tiles(A.n_points), b), ENC_THREADS, EncLds<32>::fwd_bytes, stream>>>(
-            A, A.n_points, x, pert, adv_out, pmax, parg, pcnt);
+        encoder_fwd2_kernel<false><<<grid, ENC_THREADS, FWD2_LDS_BYTES, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
 
-// Sparse pass over the 128 critical rows of every un-flagged cloud, then a dense pass that only
-// does work for flagged clouds (its workgroups exit at once otherwise).  g_enc must be zeroed by
-// the caller (rows that are not critical keep gradient 0).
+// masks != null: one launch = masked sparse blocks (128 critical rows of every un-flagged cloud) + dense recomputing blocks
+// that only do work for clouds with a tied pool maximum.  masks == null (GEOADV_BWD_MASKS=0, the A/B of
+// tests/test_gpu_attack.py): the recomputing kernel for both, sparse then dense.  g_enc must be zeroed by the caller
+// (rows that are not critical keep gradient 0).
 int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *crit_rows, const float *z,
                        const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, const unsigned *masks,
                        hipStream_t stream) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
-    static int merged = -1;
-    if (merged < 0) { const char *e = getenv("GEOADV_BWD_MERGED"); merged = e ? atoi(e) : 1; }
-    if (masks && fwd_variant() == 0 && merged) {
+    if (masks) {
         const size_t lds = BWM_LDS_BYTES > EncLds<64>::bwd_bytes ? BWM_LDS_BYTES : EncLds<64>::bwd_bytes;
         const int grid = (128 / BWM_ROWS) * b + cdiv(A.n_points, 64) * BWD_MERGED_DENSE_SLOTS;
         encoder_bwd_merged_kernel<<<grid, ENC_THREADS, lds, stream>>>(A, A.n_points, b, masks, crit_rows, z, zcnt, dz, dense_flag, adv, g_enc);
         GA_LAUNCH_CHECK();
         return GEOADV_OK;
     }
-    if (masks && fwd_variant() == 0)
-        encoder_bwd_masked_kernel<<<dim3(128 / BWM_ROWS, b), ENC_THREADS, BWM_LDS_BYTES, stream>>>(A, A.n_points, masks, crit_rows, z, dz,
-                                                                                               dense_flag, g_enc);
-    else
     encoder_bwd_kernel<BWD_SPARSE_ROWS, false><<<dim3(128 / BWD_SPARSE_ROWS, b), ENC_THREADS, EncLds<BWD_SPARSE_ROWS>::bwd_bytes, stream>>>(
         A, A.n_points, b, adv, crit_rows, 128, z, zcnt, dz, dense_flag, g_enc);
     GA_LAUNCH_CHECK();
     encoder_bwd_kernel<BWD_DENSE_ROWS, true><<<dim3(cdiv(A.n_points, BWD_DENSE_ROWS), BWD_DENSE_SLOTS), ENC_THREADS, EncLds<BWD_DENSE_ROWS>::bwd_bytes, stream>>>(
         A, A.n_points, b, adv, nullptr, 0, z, zcnt, dz, dense_flag, g_enc);
-    GA_LAUNCH_CHECK();
-    return GEOADV_OK;
-}
-
-
-// Diagnostic (not part of the product path): the two-buffer forward with phase stamps.  stamps: [b][tiles][12] u64.
-int launch_encoder_fwd_stamped(const DeviceAE &A, int b, const float *x, float *pmax, int *parg, int *pcnt,
-                               unsigned long long *stamps, hipStream_t stream) {
-    if (int st = set_lds_attr_once()) return st;
-    encoder_fwd2_kernel<true, false><<<dim3(cdiv(A.n_points, 64), b), ENC_THREADS, FWD2_LDS_BYTES, stream>>>(
-        A, A.n_points, x, nullptr, nullptr, pmax, parg, pcnt, stamps, nullptr);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -213,42 +213,10 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
 // ------------------------------------------------------------------------------------------
 // QueryBallPoint (tf_grouping_g.cu:3-36): the FIRST nsample dataset points with
 // max(sqrt(d2), 1e-20) < radius, padded with the first hit; pts_cnt = number found.
-// One wave per query: 64 candidates at a time, ballot + prefix count keep the ascending order.
+// One THREAD per query (256 queries per workgroup, the dataset streams through LDS): a candidate costs the nine distance
+// instructions and one compare.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void query_ball_kernel(int n, int m, float radius, int nsample, const float *xyz1,
-                                                        const float *xyz2, int *idx, int *pts_cnt) {
-    const int c = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
-    const float *data = xyz1 + (size_t)c * n * 3;
-    const float *qp = xyz2 + ((size_t)c * m + q) * 3;
-    int *row = idx + ((size_t)c * m + q) * nsample;
-    const float qx = qp[0], qy = qp[1], qz = qp[2];
-    int cnt = 0, first = -1;
-    for (int t0 = 0; t0 < n && cnt < nsample; t0 += 64) {
-        const int t = t0 + lane;
-        bool hit = false;
-        if (t < n) {
-            const float dx = qx - data[3 * t], dy = qy - data[3 * t + 1], dz = qz - data[3 * t + 2];
-            float d = sqrtf((dx * dx + dy * dy) + dz * dz);
-            d = d < 1e-20f ? 1e-20f : d;
-            hit = d < radius;
-        }
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
-            const int before = __popcll(mask & ((1ull << lane) - 1ull));
-            if (first < 0) first = t0 + __ffsll((long long)mask) - 1;
-            if (hit && cnt + before < nsample) row[cnt + before] = t;
-            cnt += __popcll(mask);
-        }
-    }
-    cnt = cnt < nsample ? cnt : nsample;
-    if (first >= 0)
-        for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;   // pad with the first hit
-    if (pts_cnt && lane == 0) pts_cnt[(size_t)c * m + q] = cnt;
-}
-
-// The same, one THREAD per query (256 queries per workgroup, the dataset streams through LDS): the wave-per-query form above
-// spends a ballot and a prefix count per 64 candidates; here a candidate costs the nine distance instructions and one
-// compare.  `max(sqrtf(d2), 1e-20f) < radius` is decided WITHOUT the square root: sqrtf is correctly rounded and monotone, so
+// `max(sqrtf(d2), 1e-20f) < radius` is decided WITHOUT the square root: sqrtf is correctly rounded and monotone, so
 // the host finds the largest float t2max with sqrtf(t2max) < radius once, and the test is d2 <= t2max (NaN fails both).
 constexpr int QB_THREADS = 256;
 constexpr int QB_TILE = 1024;
@@ -333,16 +301,16 @@ __global__ __launch_bounds__(256) void group_point_grad_kernel(int n, int cch, i
 using namespace geoadv;
 
 static int row_lds_attr() {
-    static bool done = false;
-    if (done) return GEOADV_OK;
-    const int cap = ROW_MAX_N * 8;
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(selection_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_redo_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_redo_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    done = true;
-    return GEOADV_OK;
+    static DeviceOnce once;
+    return once.run([]() -> int {
+        const int cap = ROW_MAX_N * 8;
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(selection_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_redo_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_redo_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        return GEOADV_OK;
+    });
 }
 
 extern "C" int geoadv_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream) {
@@ -376,10 +344,8 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
 static int launch_knn(int mode, int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
                       hipStream_t st) {
     if (int rc = row_lds_attr()) return rc;
-    static int slow = -1;
-    if (slow < 0) { const char *e = getenv("GEOADV_KNN_SLOW"); slow = (e && e[0] == '1') ? 1 : 0; }
     const int slots = mode == 0 ? k + 1 : k;              // register list of the fast kernel
-    if (!slow && slots <= 17 && (size_t)b * m < ((size_t)1 << 31)) {
+    if (slots <= 17 && (size_t)b * m < ((size_t)1 << 31)) {
         if (mode == 0) {
             if (slots <= 3) return launch_knn_fast<0, 3>(b, n, m, k, xyz1, xyz2, val, idx, st);
             if (slots <= 5) return launch_knn_fast<0, 5>(b, n, m, k, xyz1, xyz2, val, idx, st);
@@ -430,13 +396,6 @@ extern "C" int geoadv_query_ball_point(int b, int n, int m, float radius, int ns
     GA_REQUIRE(b <= 65535, "query_ball_point: batch %d exceeds 65535", b);
     if (b == 0 || m == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && idx, "query_ball_point: null pointer");
-    static int slow = -1;
-    if (slow < 0) { const char *e = getenv("GEOADV_QUERY_BALL_SLOW"); slow = (e && e[0] == '1') ? 1 : 0; }
-    if (slow) {
-        query_ball_kernel<<<dim3(m, b), 64, 0, as_stream(stream)>>>(n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt);
-        GA_LAUNCH_CHECK();
-        return GEOADV_OK;
-    }
     // largest squared distance that still passes `max(sqrtf(d2), 1e-20f) < radius` (none if radius <= 1e-20f; every finite one
     // if radius is infinite)
     float t2max = -1.f;

@@ -568,7 +568,6 @@ struct BwdArgs {
     float2 *qsum_out;                // [tiles][CIN]
     float *dw_partial;               // [grid][CIN][COUT]
     float *db_partial;               // [grid][COUT]
-    int debug_skip;                  // timing experiments only (GEOADV_TRAIN_SKIP): 1 = no dW GEMM, 2 = no dy GEMM, 4 = no tile loads
 };
 
 // da tile = gamma * inv_std * (dy - m1 - xhat * m2), xhat = (a - mean) * inv_std -> LDS [64][C + 4]; returns this
@@ -612,126 +611,9 @@ template <int CIN, int COUT, int ROWS> struct BwdShape {
     static constexpr size_t lds_bytes = sizeof(float) * (DA_FLOATS + H_FLOATS + SCRATCH_FLOATS + CC_FLOATS + RED_FLOATS);
 };
 
-template <int CIN, int COUT, int ROWS>
-__global__ __launch_bounds__(TR_THREADS, ROWS == 32 ? 4 : 2) void train_bwd_kernel(BwdArgs A) {
-    using S = BwdShape<CIN, COUT, ROWS>;
-    extern __shared__ __align__(16) float lds[];
-    float *da = lds;
-    float *ht = da + S::DA_FLOATS;
-    float *scratch = ht + S::H_FLOATS;
-    float *cc = scratch + S::SCRATCH_FLOATS;
-    float *red = cc + S::CC_FLOATS;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int hh = lane >> 5, li = lane & 31;
-    for (int e = threadIdx.x; e < COUT; e += TR_THREADS) {
-        cc[e] = A.mean[e]; cc[COUT + e] = A.inv_std[e]; cc[2 * COUT + e] = A.gamma[e] * A.inv_std[e];
-        cc[3 * COUT + e] = A.m1[e]; cc[4 * COUT + e] = A.m2[e];
-    }
-    // previous layer's BN constants of this lane's dy_out column
-    const int ocol = layer_gemm_lane_col<ROWS, CIN>();
-    const float ps = A.pscale[ocol], pt = A.pshift[ocol], pm = A.pmean[ocol], pis = A.pinv_std[ocol];
-    const int mb0 = (wave / S::WCOLS) * S::MBW, nb0 = (wave % S::WCOLS) * S::NBW;
-    f32x16 dw[S::MBW][S::NBW] = {};
-    float hs[S::MBW], hsh[S::MBW];                       // previous layer's folded BN of this lane's h columns
-#pragma unroll
-    for (int m = 0; m < S::MBW; ++m) { hs[m] = A.pscale[(mb0 + m) * 32 + li]; hsh[m] = A.pshift[(mb0 + m) * 32 + li]; }
-    float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    for (int tile = blockIdx.x; tile < A.tiles; tile += gridDim.x) {
-        const size_t row0 = (size_t)tile * ROWS;
-        if (!(A.debug_skip & 4)) {
-            load_da_tile<COUT, ROWS>(A, row0, cc, da, dbacc);
-            load_raw_tile<CIN, ROWS>(A.aprev, row0, ht);          // raw a_{i-1}: activated on the way into the MFMA
-        }
-        __syncthreads();
-        // dW += h^T @ da : A operand = h^T (lane: m = channel li of block mb, k = row 2kk + hh), B operand = da
-        if (!(A.debug_skip & 1))
-#pragma unroll 8
-        for (int kk = 0; kk < ROWS / 2; ++kk) {
-            const int row = 2 * kk + hh;
-            float av[S::MBW], bv[S::NBW];
-#pragma unroll
-            for (int m = 0; m < S::MBW; ++m) av[m] = fmaxf(fmaf(ht[row * (CIN + 4) + (mb0 + m) * 32 + li], hs[m], hsh[m]), 0.f);
-#pragma unroll
-            for (int n = 0; n < S::NBW; ++n) bv[n] = da[row * (COUT + 4) + (nb0 + n) * 32 + li];
-#pragma unroll
-            for (int m = 0; m < S::MBW; ++m)
-#pragma unroll
-                for (int n = 0; n < S::NBW; ++n)
-                    dw[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], dw[m][n], 0, 0, 0);
-        }
-        // dy_{i-1} = (da @ W^T) * [h > 0], with the sums the BN backward of the previous layer needs
-        float q1 = 0.f, q2 = 0.f;
-        int rb_seen = 0;
-        bool ran = false;
-        // The accumulators are parked first; the a_{i-1} values of this lane come back from the LDS tile (reading them
-        // from global memory between the dy stores costs an L2 round trip per element).
-        constexpr int NV = (CIN / 32) * (ROWS / 32) > 8 ? 32 : 16;
-        float vals[NV], apv[NV];
-        int rows[NV];
-        int cnt = 0;
-        if (!(A.debug_skip & 2))
-        layer_gemm<ROWS, CIN, 0>(da, COUT + 4, A.WT, scratch, [&](int row, int c, float v) {
-            vals[cnt] = v; rows[cnt] = row; ++cnt;
-            rb_seen = row >> 5;
-            ran = true;
-        });
-        if (ran && (A.debug_skip & 8)) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) q1 += vals[j];
-        } else if (ran) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) apv[j] = ht[rows[j] * (CIN + 4) + ocol];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const float dyv = fmaf(apv[j], ps, pt) > 0.f ? vals[j] : 0.f;
-                A.dy_out[(row0 + rows[j]) * CIN + ocol] = dyv;
-                q1 += dyv;
-                q2 = fmaf(dyv, (apv[j] - pm) * pis, q2);
-            }
-        }
-        q1 += __shfl_xor(q1, 32);
-        q2 += __shfl_xor(q2, 32);
-        constexpr bool WHOLE = (ROWS == 32) || (CIN / 32) * 2 > 8;       // one wave holds the whole column of the tile
-        float2 *qred = reinterpret_cast<float2 *>(red);              // [2][CIN]
-        if (WHOLE) {
-            if (ran && hh == 0) A.qsum_out[(size_t)tile * CIN + ocol] = make_float2(q1, q2);
-            __syncthreads();
-        } else {
-            if (ran && hh == 0) qred[rb_seen * CIN + ocol] = make_float2(q1, q2);
-            __syncthreads();
-            if (threadIdx.x < CIN) {
-                const float2 p = qred[threadIdx.x], q = qred[CIN + threadIdx.x];
-                A.qsum_out[(size_t)tile * CIN + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
-            }
-        }
-    }
-    // weight-gradient partial of this workgroup, canonical [CIN][COUT] layout
-    float *dst = A.dw_partial + (size_t)blockIdx.x * CIN * COUT;
-#pragma unroll
-    for (int m = 0; m < S::MBW; ++m)
-#pragma unroll
-        for (int n = 0; n < S::NBW; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dst[(size_t)((mb0 + m) * 32 + acc_row(r, hh)) * COUT + (nb0 + n) * 32 + li] = dw[m][n][r];
-    // bias-gradient partial: threads sharing a float4 column group are summed in a fixed order
-    constexpr int Q = COUT / 4, G = TR_THREADS / Q;
-    float *dbred = da;                                              // [G][COUT], the tile is no longer needed
-    __syncthreads();
-    *reinterpret_cast<float4 *>(dbred + (threadIdx.x / Q) * COUT + 4 * (threadIdx.x % Q)) = dbacc;
-    __syncthreads();
-    if (threadIdx.x < COUT) {
-        float s = dbred[threadIdx.x];
-#pragma unroll
-        for (int g = 1; g < G; ++g) s += dbred[g * COUT + threadIdx.x];
-        A.db_partial[(size_t)blockIdx.x * COUT + threadIdx.x] = s;
-    }
-}
-
-// The same backward layer as TWO kinds of workgroups in one launch, so that a CU holds one of each and their phases overlap
-// (in train_bwd_kernel a single 115 KB workgroup per CU runs tile loads, the dW GEMM, the dy GEMM and the epilogue strictly
-// one after the other):
+// One backward layer as TWO kinds of workgroups in one launch, so that a CU holds one of each and their phases overlap
+// (a single fused 115 KB workgroup per CU would run tile loads, the dW GEMM, the dy GEMM and the epilogue strictly one after
+// the other):
 //   blocks [0, nw)      : weight gradient only -- persistent over 32-row tiles, dW accumulated in registers (64 VGPRs);
 //   blocks [nw, nw + T) : data gradient only -- one 64-row tile each: da @ W^T, ReLU mask, dy_{i-1} and its BN sums.
 // Both form da = f(dy, a) on load, i.e. dy_i and a_i are read twice (+ 2 * 4 * R * COUT bytes of HBM traffic per layer); that
@@ -1176,12 +1058,12 @@ static int launch_fwd(geoadv_trainer *t, int i, hipStream_t st) {
     a.W = PackedLayer{t->packed_fwd[i], CIN, COUT};
     a.bias = t->params + t->L.b[i]; a.out = t->act[i]; a.psum = t->psum;
     const size_t lds = sizeof(float) * (TR_ROWS * (CIN + 4) + 4 * COUT);
-    static bool attr = false;
-    if (!attr) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_fwd_kernel<CIN, COUT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_fwd_kernel<CIN, COUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return GEOADV_OK;
+        })) return rc;
     train_fwd_kernel<CIN, COUT><<<t->tiles, TR_THREADS, lds, st>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
@@ -1203,7 +1085,6 @@ static int launch_bn(geoadv_trainer *t, int i, int mode, int slot, hipStream_t s
 
 template <int CIN, int COUT>
 static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, hipStream_t st) {
-    using S = BwdShape<CIN, COUT, BWD_ROWS>;
     BwdArgs a;
     a.tiles = t->R / BWD_ROWS; a.dy = dy; a.a = t->act[i];
     a.mean = t->bn_mean[i]; a.inv_std = t->bn_istd[i]; a.gamma = t->params + t->L.gamma[i]; a.m1 = t->bn_m1[i]; a.m2 = t->bn_m2[i];
@@ -1211,25 +1092,15 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
     a.pscale = t->bn_scale[i - 1]; a.pshift = t->bn_shift[i - 1]; a.pmean = t->bn_mean[i - 1]; a.pinv_std = t->bn_istd[i - 1];
     a.WT = PackedLayer{t->packed_bwd[i], COUT, CIN};
     a.dy_out = dy_out; a.qsum_out = t->qsum; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
-    static int skip = -1;
-    if (skip < 0) { const char *e = getenv("GEOADV_TRAIN_SKIP"); skip = e ? atoi(e) : 0; }
-    a.debug_skip = skip;
-    static int split = -1;
-    if (split < 0) { const char *e = getenv("GEOADV_TRAIN_SPLIT"); split = e ? atoi(e) : 1; }
-    static bool attr = false;
-    if (!attr) {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_kernel<CIN, COUT, BWD_ROWS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes));
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_split_kernel<CIN, COUT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitShape<CIN, COUT>::lds_bytes));
-        attr = true;
-    }
+    static_assert(BWD_ROWS == 64, "the split backward is built on 64-row data-gradient tiles");
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_split_kernel<CIN, COUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitShape<CIN, COUT>::lds_bytes));
+            return GEOADV_OK;
+        })) return rc;
     const int grid = a.tiles < t->grid_bwd ? a.tiles : t->grid_bwd;
-    if (split && BWD_ROWS == 64) {
-        train_bwd_split_kernel<CIN, COUT><<<grid + a.tiles, TR_THREADS, SplitShape<CIN, COUT>::lds_bytes, st>>>(a, grid);
-    } else {
-        train_bwd_kernel<CIN, COUT, BWD_ROWS><<<grid, TR_THREADS, S::lds_bytes, st>>>(a);
-    }
+    train_bwd_split_kernel<CIN, COUT><<<grid + a.tiles, TR_THREADS, SplitShape<CIN, COUT>::lds_bytes, st>>>(a, grid);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;                                   // its partials are reduced by post_layer (next launch)
 }

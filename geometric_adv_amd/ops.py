@@ -63,23 +63,6 @@ def nn_distance(xyz1, xyz2):
     return dist1, idx1, dist2, idx2
 
 
-def nn_distance_light(xyz1, xyz2):
-    """nn_distance for clouds of equal size through the LDS-free, scalar-fed kernel (the one the attack loop runs
-    beside the encoder); identical results."""
-    xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "NnDistance")
-    b, n, _ = xyz1.shape
-    if xyz2.shape[1] != n:
-        raise ValueError("nn_distance_light needs clouds of equal size")
-    dist1 = torch.empty((b, n), dtype=torch.float32, device=xyz1.device)
-    idx1 = torch.empty((b, n), dtype=torch.int32, device=xyz1.device)
-    dist2, idx2 = torch.empty_like(dist1), torch.empty_like(idx1)
-    with torch.cuda.device(xyz1.device):
-        st = _lib.lib().geoadv_nn_distance_light(b, n, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(idx1),
-                                                 _lib.ptr(dist2), _lib.ptr(idx2), _lib.stream_handle())
-    _lib.check(st, "nn_distance_light")
-    return dist1, idx1, dist2, idx2
-
-
 def nn_distance_paired(xyz1, xyz2):
     """nn_distance for paired clouds of equal size (xyz1[j] close to xyz2[j] for most j, like adv = x + pert): exact
     grid search seeded with the pairing; identical results, fast when the pairing is good."""

@@ -48,11 +48,6 @@ const char *geoadv_last_error(void);
 int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
                        float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
 
-/* Same results as geoadv_nn_distance for n == m, from an LDS-free kernel whose targets travel through the scalar
- * cache (s_load) -- built to run beside the MFMA-bound encoder on the same CUs (the attack loop's second stream). */
-int geoadv_nn_distance_light(int b, int n, const float *xyz1, const float *xyz2,
-                             float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
-
 /* Same results as geoadv_nn_distance for n == m <= 8192, from an exact grid search that uses xyz2[j] as the first guess
  * for the neighbour of xyz1[j] (and vice versa): fast when the clouds are paired like the attack's (adv, x), never wrong
  * otherwise (a query whose guess is poor is scanned against all points). */
@@ -185,6 +180,8 @@ typedef struct geoadv_attack_config {
     float max_point_dist_weight;    /* conf.max_point_dist_weight (adv_ae.py:99-100)          */
     float learning_rate;            /* conf.learning_rate (adv_ae.py:146,152)                 */
     float emd_weight;               /* build-defined: loss_adv += emd_weight*match_cost/N; 0 = off */
+    int   all_pairs_source_dist;    /* 0 (default): nn_distance(adv, x) by the exact paired grid search, falling back per
+                                     * cloud to the all-pairs kernel; 1: always the all-pairs kernel.  Same results.     */
 } geoadv_attack_config;
 
 int  geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, const geoadv_attack_config *cfg);
@@ -287,11 +284,6 @@ int geoadv_attack_profile_read(geoadv_attack *at, int which, int *launches, floa
 /* Time only every stride-th launch of each selected class (a pair of events between two dependent kernels costs ~1 us of
  * GPU time; sampling keeps a timed region honest).  Default 1. */
 int geoadv_attack_profile_stride(geoadv_attack *at, int stride);
-
-/* Diagnostic build of the encoder forward with s_memtime stamps at its phase boundaries (tools/encoder_phases.py);
- * stamps: device buffer of b * ceil(n/64) * 12 uint64.  Not part of the reference's surface. */
-int geoadv_debug_encoder_stamps(const geoadv_ae *ae, int b, const float *pc, void *workspace,
-                                unsigned long long *stamps, void *stream);
 
 /* Micro-benchmarks used by bench.py / DESIGN.md to calibrate the rooflines on the box
  * (not part of the reference's surface).  Returns elapsed ms of `iters` repetitions. */

@@ -1,5 +1,6 @@
 """One small invocation of the whole hot path on the GPU, checked against the oracle
-(imported only from __graft_entry__.smoke(); the oracle is the checker, never the path)."""
+(imported only from __graft_entry__.smoke(); the oracle is the checker, never the path).  Lives under tests/: nothing
+inside the product package geometric_adv_amd/ may reference the oracle."""
 import numpy as np
 
 

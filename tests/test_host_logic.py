@@ -64,13 +64,12 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 def test_product_never_imports_the_oracle():
-    """The oracle is test infrastructure: nothing under geometric_adv_amd/ may reference it,
-    except smoke_attack.py which exists only for __graft_entry__.smoke()."""
+    """The oracle is test infrastructure: nothing under geometric_adv_amd/ may reference it."""
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geometric_adv_amd")
     for dirpath, _, files in os.walk(root):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")) and f != "smoke_attack.py":
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("oracle of record", ""), os.path.join(dirpath, f)
 

@@ -13,4 +13,4 @@ for B in (32, 64, 256, 1024):
     for _ in range(50): ae.forward(x, want_recon=False)
     e1.record(); torch.cuda.synchronize()
     ms=e0.elapsed_time(e1)/50
-    print(os.environ.get("GEOADV_FWD_ROWS","2buf"), "B=%d encode %.3f ms -> %.1f TFLOP/s" % (B, ms, 2*90304*B*N/ms/1e9))
+    print("B=%d encode %.3f ms -> %.1f TFLOP/s" % (B, ms, 2*90304*B*N/ms/1e9))
