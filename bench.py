@@ -2,25 +2,32 @@
 """bench.py -- attack-iterations/sec of the geometric adversarial attack loop on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): B = 32 clouds of N = 2048 points per batch, output-space
-attack (loss_adv_type = chamfer, loss_dist_type = chamfer, dist_weight 1.0, lr 0.01), synthetic
-uniform clouds and seeded random-init weights of the reference architecture.  A "step" is one attack
-iteration on one batch: Adam step on pert + the metrics of the updated pert (+ keep-best for the last
-20 % of the run, like thresh 400 of 500).  Multi-GPU: every rank attacks its OWN batch of 32 (the
-reference walks examples in independent batches, adv_ae.py:166-177) -- weak scaling, no data-path
-collective; the final per-cloud loss scalars are all-gathered once (RCCL).
+N > 1 from a bare shell: this process starts N ranks itself (a child `python -m torch.distributed.run`, spawned before
+anything here touches the GPU), relays rank 0's JSON line and exits with the children's status.  Under an external
+torchrun (WORLD_SIZE set) it is one of the ranks.
+
+Workload (BASELINE.json configs[1]): B = 32 clouds of N = 2048 points per batch, output-space attack (loss_adv_type =
+chamfer, loss_dist_type = chamfer, dist_weight 1.0, lr 0.01), synthetic uniform clouds and seeded random-init weights
+of the reference architecture.  A "step" is one attack iteration on one batch: Adam step on pert + the metrics of the
+updated pert (+ keep-best for the last 20 % of a window, like thresh 400 of 500).
+
+Timing: a WINDOW is exactly K steps between barrier + synchronize pairs (max over ranks); WINDOWS windows run back to
+back and the MEDIAN window is reported (a single 20-step window is 4 ms -- shorter than the clock ramp of an idle chip).
+
+Multi-GPU: `value` = weak scaling, every rank attacks its OWN batch of 32 (the reference walks examples in independent
+batches, adv_ae.py:166-177; no data-path collective, the final per-cloud loss scalars are all-gathered once per window,
+RCCL).  `strong_scaling` = ONE global batch of 32 split 32/N per rank (SURVEY 8e's definition), measured the same way.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,101 +36,157 @@ B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_HBM_FILE = os.path.join(ROOT, "profiles", "r01_v15_pmc_hbm.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-PMC_SQ_FILE = os.path.join(ROOT, "profiles", "r01_v15_pmc_sq.json")       # rocprofv3 --pmc SQ_* pass
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
+CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
+# measured batch sweep of round 1 (profiles/r01_attack_sweep.json): ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU --
+# the honest expectation for the strong-scaling leg (per-launch latency floors do not shrink with the batch)
+R01_SWEEP_MS = {32: 0.2120, 16: 0.1597, 8: 0.1226, 4: 0.1161}
 
 
-def _encoder_entry(d):
-    """The attack loop's forward kernel in a tools/pmc_summary.py file: the mask-writing instantiation
-    encoder_fwd2_kernel<false, true> (the <false, false> one is the plain geoadv_ae_forward)."""
-    names = [n for n in d if "encoder_fwd" in n]
-    names.sort(key=lambda n: ("true>" not in n, n))
-    return d[names[0]]
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each; the median is reported")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--slots", type=int, default=0,
+                    help="also measure S concurrent batch slots (secondary.batch_slots; off by default: its overlapping "
+                         "launches would distort the per-kernel averages of a rocprofv3 run of this command)")
+    return ap.parse_args()
 
 
-def chamfer_valu(avg_ms):
-    """VALU issue rate of the all-pairs Chamfer kernels of one step: wave-level VALU instructions from the committed PMC
-    pass (SQ_INSTS_VALU, profiles/r01_v9_pmc_sq.json) x 64 lanes / the measured time, beside two yardsticks measured on the
-    box: geoadv_microbench (profiles/r01_probe_valu_chamfer_v1.json: 52.1 T lane-instr/s for an alternating v_mul/v_add
-    stream, 32 T for a single instruction type) and the best rate a real kernel sustains (the two-scan Chamfer at B=256: 63 T)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_v9_pmc_sq.json")))
-        insts = d["geoadv::chamfer_sym_kernel"]["SQ_INSTS_VALU"]["mean"] + d["geoadv::chamfer_sym_finish_kernel"]["SQ_INSTS_VALU"]["mean"]
-        grid = d["geoadv::latent_decode_and_grid_kernel"]["SQ_INSTS_VALU"]["mean"] - d["geoadv::latent_decode_kernel"]["SQ_INSTS_VALU"]["mean"]
-        ceil = json.load(open(os.path.join(ROOT, "profiles", "r01_probe_valu_chamfer_v1.json")))["valu_mul+add"]["Tinstr_lane_per_s"]
-        rate = insts * 64.0 / (avg_ms * 1e-3) / 1e12
-        return {"T_lane_instr_per_s": rate, "microbench_mul_add_T_lane_instr_per_s": ceil,
-                "best_sustained_by_a_kernel_T_lane_instr_per_s": 63.0,      # two-scan Chamfer at B=256 (7.0 T pair-evals/s x 9)
-                "frac_of_best_sustained": rate / 63.0, "wave_instr_per_step_pmc": insts,
-                "paired_grid_search_wave_instr_per_step_pmc": grid}
-    except Exception:               # pragma: no cover
-        return None
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch (parent side; must not touch the GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def ensure_built():
+    """Build libgeoadv.so BEFORE any rank starts (make only: nothing here loads the library or initialises HIP), so no
+    rank can dlopen a half-linked file."""
+    lib = os.path.join(ROOT, "geometric_adv_amd", "lib", "libgeoadv.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 4))], check=True, stdout=sys.stderr)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=sys.stderr)
 
 
-def pmc_traffic_bytes():
-    """HBM-side bytes per encoder launch from the committed PMC passes (separate --pmc runs, guide recipe):
-    FETCH_SIZE is in KiB and under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM),
-    WRITE_SIZE is exact.  Returns (bytes, note) or (None, reason)."""
-    try:
-        k = _encoder_entry(json.load(open(PMC_HBM_FILE)))
-        fetch, write = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
-        return (2.0 * fetch + write) * 1024.0, "profiles/r01_v15_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"
-    except Exception as e:          # pragma: no cover
-        return None, "no PMC profile: %s" % e
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def pmc_mfma_util():
-    try:
-        k = _encoder_entry(json.load(open(PMC_SQ_FILE)))
-        return k["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / (k["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
-    except Exception:               # pragma: no cover
-        return None
+def launch_ranks(args):
+    ensure_built()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["GEOADV_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            sys.stderr.write(ln + "\n")
+    if p.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit %d)\n" % (args.gpus, p.returncode))
+        sys.exit(p.returncode or 1)
+    print(lines[-1])
+    sys.exit(0)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# helpers (rank side)
+# ------------------------------------------------------------------------------------------------------------------
 def clouds(seed, b, n):
+    import numpy as np
     rng = np.random.default_rng(seed)
     return (rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
 
 
-def cpu_baseline(weights, x, gt, iters=5, gpu_clouds=None):
-    """The oracle's attack iteration (numpy fp32 GEMMs on all cores + the single-threaded C Chamfer
-    restatement, i.e. the reference's threading: NnDistanceOp::Compute is single-threaded,
-    tf_nndistance.cpp:79-80) in the REFERENCE schedule: step (fwd+bwd+Adam) + a second metrics
-    forward (adv_ae.py:217-221).  Bounded sample: `iters` iterations after one warm-up."""
-    from geometric_adv_amd import weights as W
-    from oracle.attack_model import AEModel, AttackModel
-    from geometric_adv_amd.adversary import init_pert_value
-    model = AEModel(W.canonical(weights, N), N, np.float32)
-    am = AttackModel(model, x, gt, None, np.ones(B, np.float32))
-    am.init_pert(init_pert_value(B, N))
-    am.step(); am.forward()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        am.step()
-        am.forward()
-    dt = time.perf_counter() - t0
-    # second leg (SURVEY 8d ii, shown for honesty): the same iterations with the Chamfer restatement
-    # parallelised over the clouds of the batch with OpenMP -- something the reference op does not do
-    import oracle.attack_model as am_mod
-    from oracle.cpu_oracle import Oracle
-    all_cores = None
+def source_hashes(files):
+    out = {}
+    for f in files:
+        try:
+            out[f] = hashlib.sha1(open(os.path.join(CSRC, f), "rb").read()).hexdigest()[:12]
+        except OSError:
+            out[f] = None
+    return out
+
+
+def pmc_encoder():
+    """HBM-side bytes per encoder launch and MFMA pipe utilisation from the committed PMC passes (separate --pmc runs;
+    FETCH_SIZE is in KiB and under-reports wide coalesced reads by 2x on gfx950, WRITE_SIZE is exact: MI355X_MICROARCH.md).
+    The file records the sha1 of the kernel sources it was taken at; if they differ from the tree, the counters are stale
+    and nothing derived from them is reported."""
     try:
-        saved, am_mod._oracle = am_mod._oracle, Oracle(omp=True)
+        d = json.load(open(PMC_FILE))
+    except Exception as e:
+        return None, None, "no PMC profile (%s)" % e
+    want = d.get("_source_sha1", {})
+    if not want or source_hashes(sorted(want)) != want:
+        return None, None, "%s was taken at different kernel sources: dropped" % os.path.basename(PMC_FILE)
+    names = [n for n in d if "encoder_fwd" in n]
+    names.sort(key=lambda n: ("true>" not in n, n))
+    k = d[names[0]]
+    traffic = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
+    util = None
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
+        util = k["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / (k["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
+    return traffic, util, "profiles/%s: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes" % os.path.basename(PMC_FILE)
+
+
+class TimedOracle:
+    """Oracle proxy that accumulates the seconds spent in the C Chamfer restatement (cpu_baseline's per-part breakdown)."""
+
+    def __init__(self, inner):
+        self.inner, self.seconds = inner, 0.0
+
+    def nn_distance(self, a, b):
+        t = time.perf_counter()
+        out = self.inner.nn_distance(a, b)
+        self.seconds += time.perf_counter() - t
+        return out
+
+
+def cpu_baseline(weights, x, gt, iters, gpu_clouds=None):
+    """The attack iteration on the host cores, REFERENCE schedule (step = forward + backward + Adam, then a second metrics
+    forward: adv_ae.py:217-221), BLAS-backed as SURVEY 8d prescribes: the network in torch-CPU fp32 (oracle/torch_model.py:
+    conv1d / batch_norm / linear on the MKL / oneDNN GEMMs, all cores) + the single-threaded C Chamfer restatement (the
+    reference op is single-threaded: NnDistanceOp::Compute, tf_nndistance.cpp:79-80).  Bounded sample: `iters` iterations
+    after one warm-up.  A second leg runs the Chamfer restatement under OpenMP too (not what the reference does)."""
+    import numpy as np
+    import torch
+    from geometric_adv_amd.adversary import init_pert_value
+    from oracle.cpu_oracle import Oracle
+    from oracle.torch_model import TorchAE, TorchAttack
+    threads = torch.get_num_threads()
+    ae = TorchAE(weights, N, torch.float32)
+
+    def leg(oracle):
+        to = TimedOracle(oracle)
+        am = TorchAttack(ae, x, gt, None, np.ones(B, np.float32), oracle=to)
+        am.init_pert(init_pert_value(B, N))
         am.step(); am.forward()
-        t1 = time.perf_counter()
+        to.seconds = 0.0
+        t0 = time.perf_counter()
         for _ in range(iters):
             am.step()
             am.forward()
-        dt2 = time.perf_counter() - t1
-        am_mod._oracle = saved
-        all_cores = {"value": iters / dt2, "sec_per_iteration": dt2 / iters,
+        dt = time.perf_counter() - t0
+        return dt, to.seconds
+
+    dt, ch = leg(Oracle())
+    all_cores = None
+    try:
+        dt2, ch2 = leg(Oracle(omp=True))
+        all_cores = {"value": iters / dt2, "sec_per_iteration": dt2 / iters, "chamfer_sec_per_iteration": ch2 / iters,
                      "note": "Chamfer restatement with OpenMP over the clouds of the batch (not what the reference does)"}
     except OSError:                 # OpenMP build of the oracle missing
         pass
     parity = None
     if gpu_clouds is not None:      # the oracle as the checker of the metric's second half: Chamfer rel-err and exact indices
         from geometric_adv_amd import ops
-        import torch
         p, q = gpu_clouds           # GPU tensors (recon, target) of the attacked batch, first clouds only
         d1, i1, d2, i2 = [t.cpu().numpy() for t in ops.nn_distance(p, q)]
         o1, oi1, o2, oi2 = Oracle().nn_distance(p.cpu().numpy(), q.cpu().numpy())
@@ -140,11 +203,18 @@ def cpu_baseline(weights, x, gt, iters=5, gpu_clouds=None):
                 break
     except OSError:
         pass
-    return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": os.cpu_count(), "kind": "port", "parity": parity,
-            "cpu_model": cpu_model, "oracle_flags": "gcc -O2 -ffp-contract=off (oracle/Makefile); numpy %s BLAS" % np.__version__,
-            "sample": "%d iterations of config 2 (B=32, N=2048) after 1 warm-up, reference schedule (2 forwards/iter); "
-                      "numpy fp32 GEMMs on all cores, Chamfer single-threaded C (gcc -O2 -ffp-contract=off)" % iters,
-            "sec_per_iteration": dt / iters, "all_cores": all_cores}
+    gemm_s = (dt - ch) / iters
+    flop = 3 * ENC_FLOP_PER_POINT * B * N + 3 * 2.0 * B * (98304 + 768 * N)      # 2 forwards + 1 backward-to-input
+    return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "parity": parity, "cpu_model": cpu_model,
+            "sample": "%d iterations of config 2 (B=32, N=2048) after 1 warm-up, reference schedule (2 forwards + 1 backward per "
+                      "iteration); network = torch-CPU %s fp32 (conv1d / batch_norm / linear + autograd, %d threads), Chamfer = "
+                      "single-threaded C restatement (gcc -O2 -ffp-contract=off), 4 nn_distance calls per iteration"
+                      % (iters, torch.__version__, threads),
+            "sec_per_iteration": dt / iters,
+            "breakdown_sec_per_iteration": {"network_gemm": gemm_s, "chamfer": ch / iters,
+                                            "network_gflops": flop / gemm_s / 1e9},
+            "all_cores": all_cores}
 
 
 def training_leg(dev, steps=30, batch=50):
@@ -203,39 +273,79 @@ def slots_leg(dev, weights, ae, slots=2, iters=300):
             "ms_per_iteration_per_slot": dt / iters * 1e3}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=5)
-    ap.add_argument("--slots", type=int, default=0,
-                    help="also measure S concurrent batch slots (secondary.batch_slots; off by default: its overlapping "
-                         "launches would distort the per-kernel averages of a rocprofv3 run of this command)")
-    args = ap.parse_args()
+class Leg:
+    """One attack handle on this rank + the timed-window protocol."""
 
+    def __init__(self, dev, weights, ae, x, gt, warmup, steps, prune=True):
+        import torch
+        from geometric_adv_amd.adv_ae import AdvAE, Configuration
+        self.K, self.W = steps, warmup
+        self.thresh = warmup + int(0.8 * steps) + 1
+        b = x.shape[0]
+        conf = Configuration(batch_size=b, n_points=N, weights=weights, loss_adv_type="chamfer", loss_dist_type="chamfer",
+                             dist_weight_list=[1.0], num_iterations=warmup + steps, num_iterations_thresh=self.thresh,
+                             learning_rate=0.01, chamfer_prune=prune)
+        self.ref = torch.as_tensor(ae.get_loss_per_pc(gt)).to(dev)      # target_ae_loss_ref
+        self.at = AdvAE("adversary", conf, device=dev, ae=ae)
+        self.at.set_inputs(x, gt, ae.transform(gt), 1.0)
+        self.at.init_pert(None, reset_optimizer=True)
+        self.at.run(0, warmup, self.thresh)                             # W untimed warm-up steps
+        self.gathered = None
+
+    def window(self, gdist, backend, dev):
+        """Exactly K timed steps bracketed by barrier + synchronize on both sides; returns the max over ranks (seconds)."""
+        import torch
+        torch.cuda.synchronize()
+        gdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.at.run(self.W, self.K, self.thresh)                        # no host sync inside
+        metrics, _, _ = self.at.get_best(self.ref)
+        self.gathered = gdist.all_gather_examples(metrics[None] if backend == "nccl" else metrics[None].cpu(), axis=1)   # final loss scalars only
+        torch.cuda.synchronize()
+        gdist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return gdist.max_over_ranks(dt, device=dev if backend == "nccl" else "cpu")
+
+    def windows(self, count, gdist, backend, dev):
+        return [self.window(gdist, backend, dev) for _ in range(count)]
+
+
+def median(v):
+    s = sorted(v)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)                                    # never returns
+    if "WORLD_SIZE" not in os.environ:
+        ensure_built()
+
+    import numpy as np
     import torch
     from geometric_adv_amd import _lib, dist as gdist
     rank, world, local = gdist.env_rank()
-    if not os.path.exists(_lib.LIB_PATH):                     # clean checkout: build in-tree first (no fallback path exists)
-        if rank == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        else:                                                 # the other ranks wait for rank 0's build
-            for _ in range(600):
-                if os.path.exists(_lib.LIB_PATH):
-                    break
-                time.sleep(0.5)
+    if not os.path.exists(_lib.LIB_PATH):
+        raise SystemExit("bench.py: %s is missing; under an external torchrun build first "
+                         "(python -c 'import __graft_entry__ as g; g.build()')" % _lib.LIB_PATH)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # GEOADV_BENCH_SHARE_GPU=1: every rank on cuda:0 with a gloo group -- the 2-ranks-on-one-GPU simulation of the N > 1
+    # path (tests/test_gpu_configs.py); RCCL refuses two ranks on one device
+    share = os.environ.get("GEOADV_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    local = 0 if share else local
+    if local >= ndev:
+        raise SystemExit("bench.py: rank %d wants cuda:%d but the node has %d GPUs" % (rank, local, ndev))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    backend = "nccl"
+    backend = "gloo" if share else "nccl"
     try:
-        gdist.init("nccl")                       # RCCL over xGMI
+        gdist.init(backend)                      # RCCL over xGMI
         if world > 1:
             gdist.barrier()
     except Exception as e:                       # keep the scaling run alive if RCCL cannot come up
@@ -247,45 +357,55 @@ def main():
         gdist.init("gloo")
 
     from geometric_adv_amd import weights as W
-    from geometric_adv_amd.adv_ae import AdvAE, Configuration
     from geometric_adv_amd.autoencoder import PointNetAE
 
-    K, Wm = args.steps, args.warmup
+    K, Wm, R = args.steps, args.warmup, max(1, args.windows)
     weights = W.synthetic_weights(N, seed=7)
+    ae = PointNetAE(weights, N, device=dev)
     x = clouds(1000 + 2 + 17 * rank, B, N)            # source batch of this rank
     gt = clouds(2000 + 2 + 17 * rank, B, N)           # target batch of this rank
-    total = Wm + K
-    thresh = Wm + int(0.8 * K) + 1
-    conf = Configuration(batch_size=B, n_points=N, weights=weights, loss_adv_type="chamfer", loss_dist_type="chamfer",
-                         dist_weight_list=[1.0], num_iterations=total, num_iterations_thresh=thresh, learning_rate=0.01)
-    ae = PointNetAE(weights, N, device=dev)
-    ref = torch.as_tensor(ae.get_loss_per_pc(gt)).to(dev)      # target_ae_loss_ref
-    tz = ae.transform(gt)
-    at = AdvAE("adversary", conf, device=dev, ae=ae)
-    at.set_inputs(x, gt, tz, 1.0)
-    at.init_pert(None, reset_optimizer=True)
 
-    at.run(0, Wm, thresh)                                      # W untimed warm-up steps
-    at.profile(["encoder_fwd"], stride=4)                      # HIP events on the launch stream around every 4th launch of the
-                                                               # dominant kernel in the timed region (each pair costs ~1 % if on all)
-    torch.cuda.synchronize()
-    gdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    at.run(Wm, K, thresh)                                      # exactly K timed steps, no host sync inside
-    metrics, _, _ = at.get_best(ref)
-    gathered = gdist.all_gather_examples(metrics[None] if backend == "nccl" else metrics[None].cpu(), axis=1)   # final loss scalars only
-    torch.cuda.synchronize()
-    gdist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = gdist.max_over_ranks(dt, device=dev if backend == "nccl" else "cpu")
-    prof = at.profile_read()
-    at.profile(False)
+    # ---- headline leg: one batch of 32 per rank (weak scaling), paired grid search on ----
+    leg = Leg(dev, weights, ae, x, gt, Wm, K)
+    stride = max(1, (R * K + 1499) // 1500)                    # <= 1500 kernel-timed encoder launches (event pool: 2048 pairs)
+    leg.at.profile(["encoder_fwd"], stride=stride)             # the kernel's own begin / end stamps (hipExtLaunchKernel): no extra
+    dts = leg.windows(R, gdist, backend, dev)                  # packets between dependent kernels, agrees with rocprofv3
+    prof = leg.at.profile_read()
+    leg.at.profile(False)
+    dt = median(dts)
+
+    # ---- the same with nn_distance(adv, x) by the all-pairs kernel (no data-dependent shortcut) ----
+    leg_ap = Leg(dev, weights, ae, x, gt, Wm, K, prune=False)
+    dts_ap = leg_ap.windows(min(R, 3), gdist, backend, dev)
+    dt_ap = median(dts_ap)
+    del leg_ap
+
+    # ---- strong scaling: ONE global batch of 32 (rank 0's seeds), 32 / world clouds per rank ----
+    strong = None
+    if B % world == 0:
+        bs = B // world
+        if world == 1:
+            strong = {"value": K / dt, "ms_per_step": dt / K * 1e3, "note": "one GPU: identical to `value`"}
+        else:
+            xs, gs = clouds(1002, B, N)[rank * bs:(rank + 1) * bs], clouds(2002, B, N)[rank * bs:(rank + 1) * bs]
+            leg_s = Leg(dev, weights, ae, xs, gs, Wm, K)
+            dts_s = leg_s.windows(R, gdist, backend, dev)
+            dt_s = median(dts_s)
+            strong = {"value": K / dt_s, "ms_per_step": dt_s / K * 1e3, "windows_ms": [round(t * 1e3, 3) for t in dts_s]}
+            del leg_s
+        exp = R01_SWEEP_MS.get(bs)
+        strong.update({"definition": "attack iterations/s on ONE global batch of 32 clouds split contiguously over the ranks "
+                                     "(SURVEY 8e); every rank runs the whole loop on its 32/N clouds, final scalars all-gathered",
+                       "global_batch": B, "batch_per_gpu": bs,
+                       "expected_speedup_vs_1gpu_from_r01_sweep": (R01_SWEEP_MS[32] / exp) if exp else None,
+                       "expectation_note": "an iteration is ten dependent launches whose latency floor (0.11 ms at B = 1) does not "
+                                           "shrink with the batch: the >= 6x target of the north star is a weak-scaling figure here"})
 
     if rank != 0:
         return
-    # per-kernel breakdown in a separate, untimed pass
+    at = leg.at
+    total = Wm + K
+    # per-kernel-class breakdown in a separate, untimed pass (bracketing events: each class interval includes its dispatch gaps)
     at.profile(True)
     at.run(total, 50, total + 1000)
     torch.cuda.synchronize()
@@ -296,44 +416,49 @@ def main():
     enc_avg_ms = enc_ms / max(enc_n, 1)
     enc_flop = ENC_FLOP_PER_POINT * B * N                       # algorithmic flop per launch
     enc_tflops = enc_flop / (enc_avg_ms * 1e-3) / 1e12
-    traffic, traffic_note = pmc_traffic_bytes()
-    ch_n, ch_avg_ms = 50, breakdown["chamfer_fwd"]              # (from the untimed per-class pass: every pair of events costs ~1 %)
-    pruned = os.environ.get("GEOADV_CHAMFER_PRUNE", "1") != "0"
-    # all-pairs kernels: nn_distance(recon, target) always; nn_distance(adv, x) too unless the paired grid search has it
-    ch_pairs = (2.0 if pruned else 4.0) * B * N * N             # problems x 2 directions per step
-    ch_bytes = (1 if pruned else 2) * 20.0 * B * (N + N)        # 20*B*(N+M) per nn_distance call
+    traffic, mfma_util, traffic_note = pmc_encoder()
+    ch_avg_ms = breakdown["chamfer_fwd"]
+    ch_pairs = 2.0 * B * N * N                                  # nn_distance(recon, target), 2 directions per step (adv/x: grid search)
+    ch_bytes = 20.0 * B * (N + N)                               # 20*B*(N+M) per nn_distance call
     out = {
         "metric": "attack-iterations/sec (B=32, N=2048) at 1/2/4/8 GPUs; Chamfer rel-err vs ref",
         "value": world * K / dt, "unit": "attack-iterations/sec", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "timing": "median of %d windows of exactly %d steps, each bracketed by barrier + synchronize, max over ranks" % (R, K),
+        "windows_ms": [round(t * 1e3, 3) for t in dts],
+        "value_all_pairs": world * K / dt_ap,
+        "value_all_pairs_note": "nn_distance(adv, x) by the all-pairs kernel for every cloud (Configuration.chamfer_prune=False): what a "
+                                "victim whose adversarial points leave their grid cells gets; same results bit for bit",
         "config": {"workload": "BASELINE configs[1]: B=32 random clouds x N=2048, output-space attack (chamfer/chamfer, "
                                "dist_weight 1.0, lr 0.01), one batch per GPU", "batch_per_gpu": B, "n_points": N,
                    "global_batch": B * world, "parallelism": "batches sharded, dp%d, no data-path collective" % world,
-                   "collective_backend": backend if world > 1 else "none",
+                   "ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
                    "thresh_fraction": 0.8},
-        "roofline": {"bound": "mfma", "kernel": "encoder_fwd2_kernel", "achieved": enc_tflops, "peak": PEAK_MFMA_F32_TFLOPS,
+        "strong_scaling": strong,
+        "roofline": {"bound": "mfma", "kernel": "encoder_fwd2_kernel<true>", "achieved": enc_tflops, "peak": PEAK_MFMA_F32_TFLOPS,
                      "unit": "TFLOP/s", "frac": enc_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
-                     "mfma_pipe_utilisation_pmc": pmc_mfma_util(),
-                     "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop},
+                     "mfma_pipe_utilisation_pmc": mfma_util,
+                     "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop,
+                     "timing": "kernel begin/end stamps (hipExtLaunchKernel start/stop events) of every %s launch inside the "
+                               "timed windows" % ("" if stride == 1 else "%d-th" % stride)},
         "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel: nn_distance(recon, target), both "
-                                                         "directions from one distance evaluation per pair" +
-                                                         ("; nn_distance(adv, x) is answered exactly by the paired grid search inside the "
-                                                          "latent_decode launch (decoder_fwd class)" if pruned else " (and nn_distance(adv, x))"),
-                             "avg_launch_ms": ch_avg_ms,
-                             "launches_timed": ch_n, "achieved_Tpair_per_s": ch_pairs / (ch_avg_ms * 1e-3) / 1e12,
-                             "valu": chamfer_valu(ch_avg_ms),
+                                                         "directions from one distance evaluation per pair; nn_distance(adv, x) is answered "
+                                                         "exactly by the paired grid search inside the latent_decode launch (decoder_fwd class)",
+                             "avg_class_ms": ch_avg_ms, "launches_timed": 50,
+                             "achieved_Tpair_per_s": ch_pairs / (ch_avg_ms * 1e-3) / 1e12,
                              "algorithmic_bytes_per_launch": ch_bytes,
                              "achieved_hbm_GBps": ch_bytes / (ch_avg_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS},
         "kernel_ms_per_iteration": breakdown,
-        "final_mean_target_recon_error": float(gathered[0, :, 4].mean().item()),
+        "kernel_ms_note": "bracketing events per class (dispatch gaps included), untimed 50-iteration pass; encoder_fwd here is kernel-timed",
+        "final_mean_target_recon_error": float(leg.gathered[0, :, 4].mean().item()),
     }
     if world == 1:                  # the widened row f-4, measured beside the headline (not part of `value`)
         out["secondary"] = {"ae_training_step": training_leg(dev)}
         if args.slots > 1:
             out["secondary"]["batch_slots"] = slots_leg(dev, weights, ae, args.slots)
     if world == 1 and not args.no_cpu_baseline:
-        _, adv_best, recon_best = at.get_best(ref)
+        _, adv_best, recon_best = at.get_best(leg.ref)
         out["cpu_baseline"] = cpu_baseline(weights, x, gt, args.cpu_iters,
                                            gpu_clouds=(recon_best[:4].contiguous(), torch.as_tensor(gt[:4]).to(dev)))
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -207,6 +207,25 @@ __device__ __forceinline__ void loss_metrics_body(const LossArgs &a, const int b
 
 __global__ __launch_bounds__(256) void loss_metrics_kernel(LossArgs a) { loss_metrics_body(a, blockIdx.x, gridDim.x); }
 
+// chamfer_dist = reduce_mean(dist1, axis=1) + reduce_mean(dist2, axis=1) (get_dists_per_point.py:75, prepare_indices_for_attack.py:114)
+// as an operator, in EXACTLY the summation order of loss_metrics_body (thread t adds elements t, t+256, ... in ascending
+// order; xor-shuffle tree; waves 0..3 left to right; sum * (1/n) per direction): the Chamfer distance recomputed from a saved
+// adversarial cloud equals the loop's own source_chamfer_dist metric bit for bit -- the reference's sanity check
+// (get_dists_per_point.py:114-115) compares them with np.array_equal.
+__global__ __launch_bounds__(256) void chamfer_per_pc_kernel(int n, int m, const float *d1, const float *d2, float *out) {
+    __shared__ float shf[4][8];
+    __shared__ int shi[4][2];
+    const int b = blockIdx.x, t = threadIdx.x;
+    CloudRed r;
+    r.s1 = r.s2 = r.s3 = r.s4 = r.sp = 0.f;
+    r.ma = r.mp = -1.f;
+    r.ja = r.jp = INT_MAX;
+    for (int j = t; j < n; j += 256) r.s3 += d1[(size_t)b * n + j];
+    for (int j = t; j < m; j += 256) r.s4 += d2[(size_t)b * m + j];
+    r = block_reduce(r, shf, shi);
+    if (t == 0) out[b] = r.s3 * (1.0f / (float)n) + r.s4 * (1.0f / (float)m);
+}
+
 // ------------------------------------------------------------------------------------------
 // Chamfer gradient w.r.t. the FIRST cloud only, with per-cloud constant upstream gradients
 // (mean over points => 1/n, times dist_weight for the source-distance term) -- the two uses the
@@ -669,6 +688,15 @@ int do_step(geoadv_attack *at, hipStream_t st) {
 
 namespace geoadv {   // the same gradient for the training step (train.hip)
 int launch_chamfer_grad(const CGradProblem *pr, int np, int B, int n, hipStream_t st) { return launch_cgrad(pr, np, B, n, st); }
+}
+
+extern "C" int geoadv_chamfer_per_pc(int b, int n, int m, const float *dist1, const float *dist2, float *out, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 1 && m >= 1, "chamfer_per_pc: bad dimensions (b=%d n=%d m=%d)", b, n, m);
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(dist1 && dist2 && out, "chamfer_per_pc: null pointer");
+    chamfer_per_pc_kernel<<<b, 256, 0, as_stream(stream)>>>(n, m, dist1, dist2, out);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
 }
 
 extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, const geoadv_attack_config *cfg) {

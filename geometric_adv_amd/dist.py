@@ -89,12 +89,20 @@ def all_gather_examples(local, counts=None, axis=1):
     return out.movedim(0, axis).contiguous()
 
 
-def attack_sharded(adv_ae, source_pc, target_latent, target_pc, target_ae_loss_ref, gather_clouds=False, device=None):
+def attack_sharded(adv_ae, source_pc, target_latent, target_pc, target_ae_loss_ref, gather_clouds=False, device=None,
+                   log_file=None):
     """AdvAE.attack over all examples with the batches sharded across ranks.
 
     Every rank passes the FULL arrays (n_examples must divide by batch_size, adv_ae.py:162).
-    Returns (metrics [W, n_examples, 5] on every rank, adv, recon): adv/recon cover all examples
-    when gather_clouds else only this rank's (with `local_slice` giving their position)."""
+    Returns a 4-tuple (metrics [W, n_examples, 5] on every rank, adv, recon, local_slice): adv / recon cover all examples
+    when gather_clouds, else only this rank's, whose position in the example order is `local_slice`.
+    log_file: this rank's log (the per-iteration and per-batch lines of adv_ae.py:223-232,181-184 for ITS batches).
+
+    Adam state and sharding: the reference initialises Adam's slots and beta powers once per graph and never resets them
+    (adv_ae.py:74, 152-153), so in a one-process run batch k starts from the slots batch k-1 left behind.  A rank here is one
+    such graph for ITS run of batches: an N-rank result equals, bit for bit, N single-process attacks on the N shards (and
+    `Configuration.batch_slots = N` on one GPU) -- not a one-process attack over all batches, whose later batches inherit
+    other slots.  Every batch's optimum is the same problem either way; only the trajectory differs."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     c = adv_ae.configuration
     n_examples = len(source_pc)
@@ -104,8 +112,9 @@ def attack_sharded(adv_ae, source_pc, target_latent, target_pc, target_ae_loss_r
     lo, hi = mine.start * c.batch_size, mine.stop * c.batch_size
     W = len(c.dist_weight_list)
     if hi > lo:
-        m_, a_, r_ = adv_ae.attack(source_pc[lo:hi], None if target_latent is None else target_latent[lo:hi],
-                                   target_pc[lo:hi], target_ae_loss_ref[lo:hi], c)
+        args = (source_pc[lo:hi], None if target_latent is None else target_latent[lo:hi], target_pc[lo:hi],
+                target_ae_loss_ref[lo:hi], c)
+        m_, a_, r_ = adv_ae.attack(*args, log_file=log_file) if log_file is not None else adv_ae.attack(*args)
     else:
         n = c.n_input[0]
         m_, a_, r_ = np.zeros((W, 0, 5), np.float32), np.zeros((W, 0, n, 3), np.float32), np.zeros((W, 0, n, 3), np.float32)

@@ -63,6 +63,22 @@ def nn_distance(xyz1, xyz2):
     return dist1, idx1, dist2, idx2
 
 
+def chamfer_per_pc(dist1, dist2):
+    """tf.reduce_mean(dist1, axis=1) + tf.reduce_mean(dist2, axis=1) of nn_distance's outputs (adv_ae.py:121,132;
+    get_dists_per_point.py:75): (b,n), (b,m) -> (b,).  Summation order = the attack loop's own metrics, so a Chamfer
+    distance recomputed from saved clouds is bit-identical to adversarial_metrics[:, :, 2]."""
+    dist1, dist2 = _f32(dist1, "dist1", 2), _f32(dist2, "dist2", 2)
+    if dist1.shape[0] != dist2.shape[0]:
+        raise ValueError("chamfer_per_pc expects dist1 and dist2 have same batch size")
+    b, n = dist1.shape
+    m = dist2.shape[1]
+    out = torch.empty((b,), dtype=torch.float32, device=dist1.device)
+    with torch.cuda.device(dist1.device):
+        st = _lib.lib().geoadv_chamfer_per_pc(b, n, m, _lib.ptr(dist1), _lib.ptr(dist2), _lib.ptr(out), _lib.stream_handle())
+    _lib.check(st, "chamfer_per_pc")
+    return out
+
+
 def nn_distance_paired(xyz1, xyz2):
     """nn_distance for paired clouds of equal size (xyz1[j] close to xyz2[j] for most j, like adv = x + pert): exact
     grid search seeded with the pairing; identical results, fast when the pairing is good."""

@@ -6,7 +6,9 @@ Differences forced by the environment: the victim's weights are read from <ae_fo
 by a TF-free reader of the V2 checkpoint format (tf_checkpoint.py; <ae_folder>/weights.npz with the same variable
 names is the fallback), and the class list of the pickled Configuration (conf.class_names,
 which needs tflearn to unpickle) is passed with --class_names (default: all of pc_classes).  Multi-GPU: launch with
-torchrun; every rank attacks a contiguous run of batches and the metrics are all-gathered (dist.attack_sharded).
+torchrun; every rank attacks a contiguous run of batches and the metrics are all-gathered (dist.attack_sharded).  Adam's slots
+are never reset between batches (the reference's behaviour, adv_ae.py:74) and live per rank, so an N-rank run equals N
+one-process runs on the N shards (or --batch_slots N), not a one-process run over all batches, bit for bit.
 
     python -m geometric_adv_amd.run_attack --ae_folder log/autoencoder_victim --batch_size 10 ...
 """
@@ -86,6 +88,16 @@ def main(argv=None):
                          max_point_pert_weight=flags.max_point_pert_weight, max_point_dist_weight=flags.max_point_dist_weight,
                          num_iterations=flags.num_iterations, num_iterations_thresh=flags.num_iterations_thresh,
                          learning_rate=flags.learning_rate, batch_slots=flags.batch_slots)
+    if rank == 0:      # the reference pickles its Configuration here (run_attack.py:109; unpickling needs tflearn): same fields as JSON
+        import json
+        with open(osp.join(output_path, 'attack_configuration.json'), 'w') as f:
+            json.dump({'class_names': classes, 'target_pc_idx_type': flags.target_pc_idx_type,
+                       'num_pc_for_attack': flags.num_pc_for_attack, 'num_pc_for_target': flags.num_pc_for_target,
+                       'correct_pred_only': flags.correct_pred_only, 'dist_weight_list': conf.dist_weight_list,
+                       'batch_size': flags.batch_size, 'learning_rate': flags.learning_rate, 'loss_adv_type': flags.loss_adv_type,
+                       'loss_dist_type': flags.loss_dist_type, 'num_iterations': flags.num_iterations,
+                       'num_iterations_thresh': flags.num_iterations_thresh, 'restore_epoch': flags.restore_epoch,
+                       'max_point_pert_weight': flags.max_point_pert_weight, 'max_point_dist_weight': flags.max_point_dist_weight}, f)
     import torch
     dev = torch.device("cuda", local)
     ae = None
@@ -102,12 +114,12 @@ def main(argv=None):
         _, target_latent = prep(latent_vectors)
         _, target_ae_loss_ref = prep(ae_loss)
         target_ae_loss_ref = target_ae_loss_ref.reshape(-1)
-        fout = open(osp.join(save_dir, 'attack_stats.txt'), 'a', 1) if rank == 0 else None
-        if fout:
-            fout.write('Train flags: %s\n' % flags)
+        # rank 0 writes attack_stats.txt like the reference; the other ranks log THEIR batches to attack_stats.rank<r>.txt
+        fout = open(osp.join(save_dir, 'attack_stats.txt' if rank == 0 else 'attack_stats.rank%d.txt' % rank), 'a', 1)
+        fout.write('Train flags: %s\n' % flags)
         if world > 1:
             metrics, pc_in, pc_rec, _ = gdist.attack_sharded(adv, source_pc, target_latent, target_pc, target_ae_loss_ref,
-                                                             gather_clouds=True)
+                                                             gather_clouds=True, log_file=fout)
         else:
             metrics, pc_in, pc_rec = adv.attack(source_pc, target_latent, target_pc, target_ae_loss_ref, conf, log_file=fout)
         if fout:

@@ -26,9 +26,23 @@ def get_chamfer_dist_mat_slice(point_clouds, pc_start_idx, pc_batch_size, device
 
 
 def sort_dist_mat_rows(dist_mat):
-    """Ascending neighbour order per row (the argsort at the heart of sort_dist_mat, :167-190, without the per-class
-    bookkeeping that needs the data set's labels)."""
+    """Ascending neighbour order per row (the argsort at the heart of sort_dist_mat)."""
     return np.argsort(dist_mat, axis=1).astype(np.int16 if dist_mat.shape[1] < 32768 else np.int32)
+
+
+def sort_dist_mat(dist_mat, slice_idx):
+    """prepare_indices_for_attack.py:167-183: for every (source class i, target class j) block of the distance matrix,
+    the ascending order of the targets of class j for each source of class i, as int16 indices LOCAL to class j (they
+    start from 0 in every block; for i == j the first entry is the instance itself at distance 0, which
+    prepare_data_for_attack skips).  slice_idx: class boundaries, len = classes + 1."""
+    nn_idx = -1 * np.ones(dist_mat.shape, dtype=np.int16)
+    k = len(slice_idx) - 1
+    for i in range(k):
+        for j in range(k):
+            block = dist_mat[slice_idx[i]:slice_idx[i + 1], slice_idx[j]:slice_idx[j + 1]]
+            nn_idx[slice_idx[i]:slice_idx[i + 1], slice_idx[j]:slice_idx[j + 1]] = np.argsort(block, axis=1).astype(np.int16)
+    assert nn_idx.min() >= 0, 'the nn_idx matrix was not filled correctly'
+    return nn_idx
 
 
 def get_chamfer_dist_mat_sharded(point_clouds, device=None, col_chunk=100):

@@ -1,7 +1,13 @@
-"""autoencoder/train_ae.py on MI355X: trains the victim auto-encoder and writes what the reference's
-run leaves in --train_folder: `models.ckpt-<epoch>` (TF V2 checkpoint format, written without TensorFlow by
-tf_checkpoint.py; saver_step 50 plus the first and last epoch, autoencoder.py:213-215) and `train_stats.txt`
-(epoch, loss, minutes: autoencoder.py:206-209).
+"""autoencoder/train_ae.py on MI355X: trains the victim auto-encoder and writes `models.ckpt-<epoch>`
+(TF V2 checkpoint format, written without TensorFlow by tf_checkpoint.py; saver_step 50 plus the first and last epoch,
+autoencoder.py:213-215) and `train_stats.txt` (epoch, loss, minutes: autoencoder.py:206-209) into --train_folder.
+
+Limitation of the checkpoint: the bundle holds the 36 `autoencoder/*` model variables (weights, biases, BN parameters and
+moving averages) -- exactly what the attack path restores (restore_ae_model filters the var_list by the 'autoencoder' prefix,
+adversary_autoencoder.py:42-51).  It does NOT hold `autoencoder/epoch`, the Adam slots or the beta powers, so the
+reference's own AutoEncoder.restore_model (neural_net.py:33-36, a Saver over ALL globals) would fail with NotFound on it:
+it is a victim for the attack, not a resumable training state.  The reader / writer pair is pinned to the published format
+and to its own round trip only; no TF-written bundle exists in this environment to test against.
 
 Differences forced by the environment: the ShapeNet folder reader (src/in_out.load_dataset, PLY files) is out of
 scope, so the training clouds come from one `.npy` of shape (n, 2048, 3) (--train_data; axes already sorted if

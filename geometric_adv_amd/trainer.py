@@ -43,9 +43,11 @@ def _fill_weights_struct(hw, canon, n_points):
 
 
 def initial_weights(n_points, seed=0, ae_name=W.AE_NAME):
-    """Fresh variables with tflearn 0.3.2's initialisers (third-party, restated): conv_1d W 'uniform_scaling'
-    (U(+-sqrt(3/fan_in)) with fan_in = Cin for a width-1 filter), fully_connected W truncated_normal(stddev 0.02),
-    biases 0, BN gamma ~ N(1, 0.002), beta 0, moving_mean 0, moving_variance 1."""
+    """Fresh variables with the initialisers the reference's layers are built with (tflearn 0.3.2, third-party, restated):
+    conv_1d W: tflearn's default 'uniform_scaling' = U(+-sqrt(3/fan_in)), fan_in = Cin for a width-1 filter
+    (encoders_decoders.py:43-44 passes no weights_init); fully_connected W: weights_init='xavier'
+    (encoders_decoders.py:107,132) = tf.contrib.layers.xavier_initializer(uniform=True) = U(+-sqrt(6/(fan_in+fan_out)));
+    biases 0; BN gamma ~ N(1, 0.002), beta 0, moving_mean 0, moving_variance 1."""
     rng = np.random.default_rng(seed)
     w = {}
     ed, dd = W.enc_dims(), W.dec_dims(n_points)
@@ -62,12 +64,8 @@ def initial_weights(n_points, seed=0, ae_name=W.AE_NAME):
     for k in range(3):
         cin, cout = dd[k], dd[k + 1]
         p = "%s/decoder_fc_%d" % (ae_name, k)
-        t = rng.standard_normal((cin, cout))
-        bad = np.abs(t) > 2.0
-        while bad.any():                                   # truncated normal: redraw beyond two sigma
-            t[bad] = rng.standard_normal(int(bad.sum()))
-            bad = np.abs(t) > 2.0
-        w[p + "/W"] = (0.02 * t).astype(np.float32)
+        lim = np.sqrt(6.0 / (cin + cout))                  # Glorot / Xavier uniform
+        w[p + "/W"] = rng.uniform(-lim, lim, size=(cin, cout)).astype(np.float32)
         w[p + "/b"] = np.zeros(cout, np.float32)
     return w
 

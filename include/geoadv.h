@@ -48,6 +48,12 @@ const char *geoadv_last_error(void);
 int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
                        float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
 
+/* chamfer_dist[b] = reduce_mean(dist1[b,:]) + reduce_mean(dist2[b,:]) -- the scalar every caller of nn_distance forms next
+ * (adv_ae.py:121,132; get_dists_per_point.py:75; prepare_indices_for_attack.py:114) -- in the summation order of the
+ * attack loop's own metrics, so that a Chamfer distance recomputed from saved clouds equals adversarial_metrics[:,:,2]
+ * bit for bit (the np.array_equal sanity check of get_dists_per_point.py:114-115). */
+int geoadv_chamfer_per_pc(int b, int n, int m, const float *dist1, const float *dist2, float *out, void *stream);
+
 /* Same results as geoadv_nn_distance for n == m <= 8192, from an exact grid search that uses xyz2[j] as the first guess
  * for the neighbour of xyz1[j] (and vice versa): fast when the clouds are paired like the attack's (adv, x), never wrong
  * otherwise (a query whose guess is poor is scanned against all points). */

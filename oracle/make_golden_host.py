@@ -10,6 +10,7 @@ Only inputs and the reference's outputs are stored (tests/golden/host_logic.npz)
   src/adversary_utils.py:149-178  get_outlier_pc_inlier_pc
   src/general_utils.py:64-91      get_complementary_points / get_complementary_idx
   src/ae_utils.py:12-80           get_critical_points / get_critical_pc_non_critical_pc
+  attacker/prepare_indices_for_attack.py:167-180  sort_dist_mat
 """
 import os
 import sys
@@ -82,6 +83,15 @@ def main():
     pre[1, 7, :4] = 9.0                            # one point critical for several channels
     cp, ci, cn, crit_pc, noncrit_pc = ns["get_critical_pc_non_critical_pc"](pc, pre)
     g.update(crit_in_pc=pc, crit_pre=pre, crit_points=cp, crit_idx=ci, crit_num=cn, crit_pc=crit_pc, crit_noncrit_pc=noncrit_pc)
+
+    # ---- sort_dist_mat (attacker/prepare_indices_for_attack.py:167-183; reads the module globals range_num_classes, slice_idx) ----
+    sizes = [4, 3, 5]
+    sl = np.concatenate([[0], np.cumsum(sizes)])
+    pts = rng.random((sl[-1], 6))
+    dm = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1)).astype(np.float32)      # symmetric, zero diagonal, no ties off it
+    ns2 = {"np": np, "range_num_classes": range(len(sizes)), "slice_idx": sl}
+    exec(lines("attacker/prepare_indices_for_attack.py", 167, 180), ns2)
+    g.update(sdm_dist=dm, sdm_slice_idx=sl, sdm_nn_idx=ns2["sort_dist_mat"](dm))
 
     np.savez_compressed(os.path.join(OUT, "host_logic.npz"), **g)
     print("host_logic.npz", os.path.getsize(os.path.join(OUT, "host_logic.npz")) // 1024, "KiB")

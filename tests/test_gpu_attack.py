@@ -363,3 +363,97 @@ def test_pruned_source_distance_equals_all_pairs(setup, monkeypatch, lr, n):
     assert outs[0][0].abs().max() > 0
     for a, c in zip(outs[0], outs[1]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("case", ["output", "latent", "tied"])
+def test_forward_and_gradient_match_torch_golden(case):
+    """The second opinion (oracle/torch_model.py: torch library layers + autograd, fp64; vectors in
+    tests/golden/torch_second_opinion.npz written by oracle/make_golden_torch.py): latent / reconstruction 2e-6, per-cloud
+    losses 1e-5 relative, NN indices exact (when the GPU's reconstruction picks the same matches), gradient 1e-4 of its
+    maximum -- incl. the tied max-pool case (every point duplicated), where the gradient splits equally (TF _MinOrMaxGrad)."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    g = np.load(os.path.join(GOLDEN, "torch_second_opinion.npz"))
+    n, x, gt, pert = int(g[f"{case}_n"]), g[f"{case}_x"], g[f"{case}_gt"], g[f"{case}_pert"]
+    b = len(x)
+    w = W.randomized_weights(n, seed=int(g[f"{case}_wseed"]))
+    ae = PointNetAE(w, n)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, loss_adv_type=str(g[f"{case}_adv_type"]),
+                                          loss_dist_type=str(g[f"{case}_dist_type"]), num_iterations=2, num_iterations_thresh=1), ae=ae)
+    at.set_inputs(x, gt, g[f"{case}_tz"], float(g[f"{case}_dw"]))
+    at.init_pert(pert, reset_optimizer=True)
+    s = {k: v.cpu().numpy() for k, v in at.peek().items()}
+    np.testing.assert_allclose(s["latent"], g[f"{case}_z"], atol=2e-6)
+    np.testing.assert_allclose(s["recon"], g[f"{case}_recon"], atol=2e-6)
+    same = all(np.array_equal(s[k], g[f"{case}_idx{i}"]) for i, k in enumerate(("idx_r1", "idx_r2", "idx_a1", "idx_a2")))
+    hist = torch.empty((1, 6, b), device=ae.device)
+    at.run(0, 1, 1, hist)                                          # backward of that forward + Adam
+    got = at.peek()["grad"].cpu().numpy()
+    want = g[f"{case}_grad"]
+    if same:                                                       # (a flipped near-tie in fp32 would legitimately move the gradient)
+        sc = np.abs(want).reshape(b, -1).max(1)[:, None, None]
+        np.testing.assert_allclose(got / sc, want / sc, atol=1e-4)
+    else:
+        assert case != "tied"
+    if case == "tied":
+        assert np.array_equal(got[:, :n // 2], got[:, n // 2:])    # duplicates receive identical gradient
+
+
+_SHARD_WORKER = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from geometric_adv_amd import dist as gdist, weights as W
+from geometric_adv_amd.adv_ae import AdvAE, Configuration
+rank, world, local = gdist.init("gloo")                      # both ranks share the one GPU of the test box (RCCL refuses that)
+d = np.load(sys.argv[1])
+n = d["x"].shape[1]
+conf = Configuration(batch_size=2, n_points=n, weights=W.randomized_weights(n), dist_weight_list=[0.5, 2.0],
+                     num_iterations=8, num_iterations_thresh=5)
+at = AdvAE("adversary", conf, device="cuda:0")
+log = open(sys.argv[2] + ".rank%d.txt" % rank, "w")
+m, a, r, sl = gdist.attack_sharded(at, d["x"], d["tz"], d["gt"], d["ref"], gather_clouds=True, log_file=log)
+log.close()
+torch.cuda.synchronize()
+np.savez(sys.argv[2] + ".rank%d.npz" % rank, m=m, a=a, r=r, lo=sl.start, hi=sl.stop)
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_real_attack_sharded_over_two_ranks_on_one_gpu(setup, tmp_path):
+    """The north-star path through dist.attack_sharded with the REAL AdvAE and world size 2 (gloo group, both ranks on cuda:0):
+    metrics / clouds gathered in example order on every rank, equal bit for bit to (a) two single-process attacks on the two
+    shards and (b) one process with Configuration.batch_slots = 2; every rank logs its own batches."""
+    import os, socket, subprocess, sys
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    w, ae, model = setup
+    n_ex = 6                                                  # 3 batches of 2: rank 0 takes two of them, rank 1 one
+    x, gt = _clouds(91, n_ex)
+    tz = ae.transform(gt)
+    ref = ae.get_loss_per_pc(gt)
+    np.savez(tmp_path / "in.npz", x=x, gt=gt, tz=tz, ref=ref)
+    (tmp_path / "worker.py").write_text(_SHARD_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, str(tmp_path / "worker.py"), str(tmp_path / "in.npz"), str(tmp_path / "out")]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=os.getcwd())
+    got = [np.load(str(tmp_path / "out") + ".rank%d.npz" % r) for r in range(2)]
+    assert (int(got[0]["lo"]), int(got[0]["hi"]), int(got[1]["lo"]), int(got[1]["hi"])) == (0, 4, 4, 6)
+    for k in ("m", "a", "r"):
+        assert np.array_equal(got[0][k], got[1][k])           # every rank holds the gathered result
+    kw = dict(batch_size=2, n_points=N, weights=w, dist_weight_list=[0.5, 2.0], num_iterations=8, num_iterations_thresh=5)
+    shards = [AdvAE("adversary", Configuration(**kw), ae=ae).attack(x[lo:hi], tz[lo:hi], gt[lo:hi], ref[lo:hi])
+              for lo, hi in ((0, 4), (4, 6))]
+    slots = AdvAE("adversary", Configuration(batch_slots=2, **kw), ae=ae).attack(x, tz, gt, ref)
+    for i, k in enumerate(("m", "a", "r")):
+        assert np.array_equal(got[0][k], np.concatenate([shards[0][i], shards[1][i]], axis=1)), k
+        assert np.array_equal(got[0][k], slots[i]), k
+    assert got[0]["m"].shape == (2, n_ex, 5) and got[0]["a"].shape == (2, n_ex, N, 3)
+    logs = [open(str(tmp_path / "out") + ".rank%d.txt" % r).read() for r in range(2)]
+    assert logs[0].count("Batch ") == 2 and logs[1].count("Batch ") == 1 and "Dist weight" in logs[1]

@@ -101,3 +101,143 @@ def test_config2_latent_attack_then_knn_defense_b256():
         assert out["outlier_num"][j] == (~keep).sum()
         assert np.array_equal(out["defended_pc"][j, :keep.sum()], adv[0, j][keep])
     assert out["recon_error_vs_source"].shape == (b,) and np.isfinite(out["recon_error_vs_source"]).all()
+
+
+@pytest.mark.parametrize("prune", [True, False])
+def test_config1_full_shape_b32_n2048(oracle, prune):
+    """configs[1] at its OWN shape (B = 32, N = 2048, chamfer/chamfer -- bench.py's workload: 1024 encoder tiles in two rounds,
+    8 row tiles in the symmetric Chamfer kernel, the 2048-point grid-search instantiation riding in the latent_decode launch):
+    three iterations, each checked from the GPU's own state -- reconstruction vs the fp64 model 2e-6, all four nearest-neighbour
+    index arrays np.array_equal to the pinned oracle on the GPU's own clouds, the six metric rows 1e-5 relative -- once with the
+    paired grid search and once with the all-pairs kernel for nn_distance(adv, x)."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from oracle.attack_model import AEModel, AttackModel
+    from conftest import cloud
+    b, n = 32, 2048
+    w = W.synthetic_weights(n, seed=7)                    # bench.py's weights and seeds
+    ae = PointNetAE(w, n)
+    model = AEModel(W.canonical(w, n), n, np.float64)
+    x, gt = cloud(1002, b, n), cloud(2002, b, n)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=4, num_iterations_thresh=2,
+                                          chamfer_prune=prune), ae=ae)
+    at.set_inputs(x, gt, None, 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    am = AttackModel(model, x, gt, None, np.ones(b))
+    hist = torch.empty((1, 6, b), device=ae.device)
+    for it in range(3):
+        at.run(it, 1, 2, hist)
+        s = {k: v.cpu().numpy() for k, v in at.peek().items()}
+        am.pert = s["pert"].astype(np.float64)
+        f = am.forward()
+        np.testing.assert_allclose(s["adv"], f["adv"], atol=1e-7)
+        np.testing.assert_allclose(s["recon"], f["recon"], atol=2e-6)
+        _, i1, _, i2 = oracle.nn_distance(s["recon"], gt)
+        assert np.array_equal(s["idx_r1"], i1) and np.array_equal(s["idx_r2"], i2), it
+        _, i1, _, i2 = oracle.nn_distance(s["adv"], x)
+        assert np.array_equal(s["idx_a1"], i1) and np.array_equal(s["idx_a2"], i2), it
+        h = hist.cpu().numpy()[0]
+        want = [f["loss_adv"], f["loss_dist"], f["loss_pert"], f["max_dist"], f["input_dist"], f["loss_ae"]]
+        for k, wv in enumerate(want):
+            np.testing.assert_allclose(h[k], wv, rtol=1e-5, atol=1e-12, err_msg="iteration %d metric %d" % (it, k))
+    m, adv, recon = at.get_best(ae.get_loss_per_pc(gt))      # keep-best took iterations 2 and 3 (thresh 2)
+    assert np.isfinite(m.cpu().numpy()).all() and (m[:, 4] > 0).all()
+
+
+def test_config3_per_gpu_shape_b128_chamfer_plus_emd(oracle):
+    """configs[3] at its per-GPU shape (B = 1024 over 8 GPUs => B = 128, N = 2048, loss_adv = Chamfer + EMD/N): one step.
+    Gradient vs the fp64 model (pinned C approx_match / match_cost_grad inside) on 4 sampled clouds -- the batch is a sum of
+    independent clouds, so a cloud's gradient does not depend on the others --; transport-plan properties of the GPU's own
+    match on ALL 128 clouds: non-negative, every target column receives at most its capacity 1, every source row ships at
+    most 1, total mass within 2 % of N (tf_approxmatch.cpp:23-84: remainders decay geometrically over the 10 levels)."""
+    import torch
+    from geometric_adv_amd import ops, weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from oracle.attack_model import AEModel, AttackModel
+    from conftest import cloud
+    b, n = 128, 2048
+    w = W.synthetic_weights(n, seed=7)
+    ae = PointNetAE(w, n)
+    x, gt = cloud(1003, b, n), cloud(2003, b, n)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=2, num_iterations_thresh=1,
+                                          emd_weight=1.0), ae=ae)
+    at.set_inputs(x, gt, None, 1.0)
+    p0 = (1e-3 * np.random.default_rng(3).standard_normal((b, n, 3))).astype(np.float32)
+    at.init_pert(p0, reset_optimizer=True)
+    s = {k: v.cpu().numpy() for k, v in at.peek().items()}
+    hist = torch.empty((1, 6, b), device=ae.device)
+    at.run(0, 1, 1, hist)
+    got = at.peek()["grad"].cpu().numpy()
+    sel = [0, 37, 90, 127]
+    model = AEModel(W.canonical(w, n), n, np.float64)
+    am = AttackModel(model, x[sel], gt[sel], None, np.ones(len(sel)), emd_weight=1.0)
+    am.init_pert(p0[sel])
+    f = am.forward(idx_override=tuple(s[k][sel] for k in ("idx_r1", "idx_r2", "idx_a1", "idx_a2")))
+    np.testing.assert_allclose(s["recon"][sel], f["recon"], atol=2e-6)
+    g = am.gradient(f)
+    sc = np.abs(g).reshape(len(sel), -1).max(1)[:, None, None]
+    np.testing.assert_allclose(got[sel] / sc, g / sc, atol=2e-4)
+    # the plan the loop used = approx_match of the forward's reconstruction (recomputed every forward: NoGradient op)
+    recon = torch.as_tensor(s["recon"]).to(ae.device)
+    gtd = torch.as_tensor(gt).to(ae.device)
+    for lo in range(0, b, 32):                               # 32 x 2048 x 2048 floats = 537 MB per slice
+        match = ops.approx_match(recon[lo:lo + 32], gtd[lo:lo + 32])       # (b, m, n) GPU layout
+        assert (match >= 0).all()
+        per_target, per_source = match.sum(2), match.sum(1)
+        assert per_target.max() <= 1.0 + 1e-4 and per_source.max() <= 1.0 + 1e-4
+        total = match.sum((1, 2))
+        assert (total > 0.98 * n).all() and (total <= n * (1 + 1e-5)).all()
+        cost = ops.match_cost(recon[lo:lo + 32], gtd[lo:lo + 32], match)
+        assert torch.isfinite(cost).all() and (cost > 0).all()
+
+
+def test_config4_full_batch_b32_n8192_indices(oracle):
+    """configs[4] at its per-GPU shape (B = 256 over 8 GPUs => B = 32, N = 8192): two iterations of the loop, then all four
+    nearest-neighbour index arrays of 4 sampled clouds against the pinned oracle on the GPU's own clouds, and the six metric
+    rows of those clouds against fp64 means of the oracle's distances (1e-5 relative)."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from conftest import cloud
+    b, n = 32, 8192
+    w = W.synthetic_weights(n, seed=7)
+    x, gt = cloud(1004, b, n), cloud(2004, b, n)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=3, num_iterations_thresh=1))
+    at.set_inputs(x, gt, None, 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    hist = torch.empty((2, 6, b), device=at.device)
+    at.run(0, 2, 1, hist)
+    s = {k: v.cpu().numpy() for k, v in at.peek().items()}
+    h = hist.cpu().numpy()[-1]
+    sel = [0, 11, 20, 31]
+    r1, i1, r2, i2 = oracle.nn_distance(s["recon"][sel], gt[sel])
+    assert np.array_equal(s["idx_r1"][sel], i1) and np.array_equal(s["idx_r2"][sel], i2)
+    a1, j1, a2, j2 = oracle.nn_distance(s["adv"][sel], x[sel])
+    assert np.array_equal(s["idx_a1"][sel], j1) and np.array_equal(s["idx_a2"][sel], j2)
+    np.testing.assert_allclose(h[5][sel], r1.mean(1, dtype=np.float64) + r2.mean(1, dtype=np.float64), rtol=1e-5)
+    np.testing.assert_allclose(h[4][sel], a1.mean(1, dtype=np.float64) + a2.mean(1, dtype=np.float64), rtol=1e-5)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` from a bare shell (no torchrun, WORLD_SIZE unset): the parent spawns the two ranks before
+    touching the GPU and relays rank 0's line.  The box has one GPU, so GEOADV_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 with
+    a gloo group (RCCL refuses two ranks on one device): the N > 1 code path -- weak leg, all-pairs leg, strong-scaling leg,
+    the gather of the final scalars -- runs for real."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["GEOADV_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--windows", "3"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["global_batch"] == 64
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["value_all_pairs"] > 0
+    s = out["strong_scaling"]
+    assert s["global_batch"] == 32 and s["batch_per_gpu"] == 16 and s["value"] > 0
+    assert out["roofline"]["launches_timed"] >= 50 and 0 < out["roofline"]["frac"] < 1

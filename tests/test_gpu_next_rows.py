@@ -143,7 +143,7 @@ def test_run_attack_cli_end_to_end(tmp_path):
             "--dist_weight_list", "0.5", "2.0", "--class_names", "chair", "car"]
     run_attack.main(args)
     out = ev / "attack_res"
-    assert sorted(os.listdir(out)) == ["car", "chair"]
+    assert sorted(os.listdir(out)) == ["attack_configuration.json", "car", "chair"]
     for cls in ("chair", "car"):
         m = np.load(out / cls / "adversarial_metrics.npy")
         a = np.load(out / cls / "adversarial_pc_input.npy")
@@ -160,6 +160,57 @@ def test_run_attack_cli_end_to_end(tmp_path):
     m2, a2, r2 = AdvAE("adversary", conf).attack(src, tl, tgt, tr.reshape(-1), conf)
     assert np.array_equal(m2, np.load(out / "chair" / "adversarial_metrics.npy"))
     assert np.array_equal(a2, np.load(out / "chair" / "adversarial_pc_input.npy"))
+    # f-1, second half: get_dists_per_point chained on those outputs WITH the reference's sanity check
+    # (get_dists_per_point.py:114-115): the Chamfer distance the op recomputes from the saved adversarial clouds must be
+    # np.array_equal to the source_chamfer_dist the loop recorded
+    from geometric_adv_amd import get_dists_per_point, ops
+    import torch
+    get_dists_per_point.main(["--top_dir", str(top), "--ae_folder", "log/ae", "--attack_pc_idx", "log/ae/eval/sel_idx.npy",
+                              "--do_sanity_checks", "1"])
+    for cls in ("chair", "car"):
+        d = np.load(out / cls / "adversarial_pc_input_dists.npy")
+        a = np.load(out / cls / "adversarial_pc_input.npy")
+        assert d.shape == a.shape[:3] and d.dtype == np.float32 and (d >= 0).all()
+    s_pc, _ = prepare_data_for_attack(classes, ["chair"], ["chair", "car"], pcs, slice_idx, attack_idx, 1, nn_idx, None)
+    first = oracle_first_dists(np.load(out / "chair" / "adversarial_pc_input.npy")[1], s_pc)
+    assert np.array_equal(np.load(out / "chair" / "adversarial_pc_input_dists.npy")[1], np.sqrt(first))
+
+
+def oracle_first_dists(adv, src):
+    from oracle.cpu_oracle import Oracle
+    return Oracle().nn_distance(adv, src)[0]
+
+
+def test_chamfer_per_pc_equals_loop_metric_at_full_shape():
+    """The reduction-order contract behind that sanity check at configs[1]'s shape (B = 32, N = 2048), where a private
+    summation order would show: input_dist / loss_ae of the loop's history == ops.chamfer_per_pc(ops.nn_distance(...)) on the
+    loop's own clouds, bit for bit; and within 1e-6 relative of the fp64 mean (north star: 1e-5)."""
+    import torch
+    from geometric_adv_amd import ops, weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from conftest import cloud
+    b, n = 32, 2048
+    w = W.synthetic_weights(n)
+    ae = PointNetAE(w, n)
+    x, gt = cloud(1002, b, n), cloud(2002, b, n)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=4, num_iterations_thresh=1), ae=ae)
+    at.set_inputs(x, gt, None, 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    hist = torch.empty((3, 6, b), device=ae.device)
+    at.run(0, 3, 1, hist)
+    s = at.peek()
+    h = hist.cpu().numpy()[-1]
+    xd, gd = torch.as_tensor(x).to(ae.device), torch.as_tensor(gt).to(ae.device)
+    a1, _, a2, _ = ops.nn_distance(s["adv"], xd)
+    r1, _, r2, _ = ops.nn_distance(s["recon"], gd)
+    assert np.array_equal(ops.chamfer_per_pc(a1, a2).cpu().numpy(), h[4])           # input_dist = source_chamfer_dist
+    assert np.array_equal(ops.chamfer_per_pc(r1, r2).cpu().numpy(), h[5])           # loss_ae = target_recon_error
+    want = a1.double().mean(1) + a2.double().mean(1)
+    np.testing.assert_allclose(h[4], want.cpu().numpy(), rtol=1e-6)
+    # ragged sizes and n != m through the operator alone
+    d1, d2 = torch.rand((3, 777), device=ae.device), torch.rand((3, 1300), device=ae.device)
+    np.testing.assert_allclose(ops.chamfer_per_pc(d1, d2).cpu().numpy(), (d1.double().mean(1) + d2.double().mean(1)).cpu().numpy(), rtol=1e-6)
 
 
 def test_train_checkpoint_attack_defend_pipeline(tmp_path):

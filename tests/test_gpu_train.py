@@ -10,6 +10,13 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
 torch = pytest.importorskip("torch")
 
 
@@ -205,9 +212,10 @@ def test_data_parallel_step_equals_summed_shard_gradients(tmp_path):
     x = _clouds(21, b, n)
     np.save(tmp_path / "x.npy", x)
     (tmp_path / "worker.py").write_text(_DP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    _PORT1 = _free_port()                              # (a fixed port collides with a concurrent run of this suite)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_PORT1, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", str(tmp_path / "worker.py"), str(tmp_path / "x.npy"), str(tmp_path / "out.npz")]
+           "--master-port", _PORT1, str(tmp_path / "worker.py"), str(tmp_path / "x.npy"), str(tmp_path / "out.npz")]
     subprocess.run(cmd, check=True, env=env, timeout=300, cwd=os.getcwd())
     got = np.load(tmp_path / "out.npz")
     # the same thing in one process: two replicas, gradients added by hand
@@ -266,9 +274,10 @@ def test_synchronised_bn_equals_one_replica_on_the_global_batch(tmp_path):
     x = _batch(TrainModel(W.canonical(w0, n), n), b, n, 31)
     np.save(tmp_path / "x.npy", x)
     (tmp_path / "worker.py").write_text(_SYNC_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    _PORT2 = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_PORT2, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", str(tmp_path / "worker.py"), str(tmp_path / "x.npy"), str(tmp_path / "out.npz")]
+           "--master-port", _PORT2, str(tmp_path / "worker.py"), str(tmp_path / "x.npy"), str(tmp_path / "out.npz")]
     subprocess.run(cmd, check=True, env=env, timeout=300, cwd=os.getcwd())
     got = np.load(tmp_path / "out.npz")
     one = PointNetAETrainer(w0, n, batch_size=b)

@@ -57,3 +57,30 @@ def test_load_data_by_basename(tmp_path):
     assert load_data(str(tmp_path), files, ["ae_loss"]).shape == (2,)
     with pytest.raises(IndexError):
         load_data(str(tmp_path), files, ["missing"])
+
+
+@pytest.mark.parametrize("case", ["output", "latent", "tied"])
+def test_attack_model_matches_torch_golden(case):
+    """oracle/attack_model.py (numpy, hand-written backward) against the committed vectors of the torch second opinion."""
+    from geometric_adv_amd import weights as W
+    from oracle.attack_model import AEModel, AttackModel
+    g = np.load(os.path.join(GOLDEN, "torch_second_opinion.npz"))
+    n, x, gt = int(g[f"{case}_n"]), g[f"{case}_x"], g[f"{case}_gt"]
+    w = W.randomized_weights(n, seed=int(g[f"{case}_wseed"]))
+    m = AEModel(W.canonical(w, n), n, np.float64)
+    am = AttackModel(m, x, gt, g[f"{case}_tz"], np.full(len(x), float(g[f"{case}_dw"])), str(g[f"{case}_adv_type"]), str(g[f"{case}_dist_type"]))
+    am.init_pert(g[f"{case}_pert"])
+    f = am.forward(idx_override=tuple(g[f"{case}_idx{k}"] for k in range(4)))
+    np.testing.assert_allclose(f["z"], g[f"{case}_z"], atol=1e-12)
+    np.testing.assert_allclose(f["recon"], g[f"{case}_recon"], atol=1e-12)
+    np.testing.assert_allclose(f["loss_ae"], g[f"{case}_loss_ae"], rtol=1e-12)
+    np.testing.assert_allclose(f["loss_adv"], g[f"{case}_loss_adv"], rtol=1e-10)
+    want = g[f"{case}_grad"]
+    np.testing.assert_allclose(am.gradient(f), want, atol=1e-10 * np.abs(want).max())
+
+
+def test_sort_dist_mat(g):
+    """scorer.sort_dist_mat against the reference's own function body (prepare_indices_for_attack.py:167-183)."""
+    from geometric_adv_amd.scorer import sort_dist_mat
+    got = sort_dist_mat(g["sdm_dist"], g["sdm_slice_idx"])
+    assert got.dtype == np.int16 and np.array_equal(got, g["sdm_nn_idx"])

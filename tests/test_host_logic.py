@@ -191,3 +191,23 @@ def test_train_model_gradients_match_finite_differences():
     for _ in range(6):
         l1 = tm.step(x)[0]
     assert l1 < 0.5 * l0
+
+
+def test_trainer_initial_weights_follow_the_reference_initialisers():
+    """conv_1d: tflearn 'uniform_scaling' U(+-sqrt(3/fan_in)); fully_connected: weights_init='xavier'
+    (encoders_decoders.py:107,132) = U(+-sqrt(6/(fan_in+fan_out))) -- per-layer std and bounds."""
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.trainer import initial_weights
+    n = 256
+    w = initial_weights(n, seed=3)
+    ed, dd = W.enc_dims(), W.dec_dims(n)
+    for i in range(5):
+        a = w["autoencoder/encoder_conv_layer_%d/W" % i]
+        lim = np.sqrt(3.0 / ed[i])
+        assert np.abs(a).max() <= lim and abs(a.std() / (lim / np.sqrt(3)) - 1) < 0.1
+    for k in range(3):
+        a = w["autoencoder/decoder_fc_%d/W" % k]
+        lim = np.sqrt(6.0 / (dd[k] + dd[k + 1]))
+        assert a.shape == (dd[k], dd[k + 1]) and np.abs(a).max() <= lim
+        assert abs(a.std() / (lim / np.sqrt(3)) - 1) < 0.03
+    assert abs(w["autoencoder/decoder_fc_0/W"].std() - 0.072) < 0.003          # 128 -> 256: not the 0.02 of a truncated normal
