@@ -24,7 +24,8 @@ def lib():
         import torch  # noqa: F401  -- first: libgeoadv.so must bind to the HIP runtime torch ships, not to a second copy
         _lib = C.CDLL(LIB_PATH)
         _lib.geoadv_last_error.restype = C.c_char_p
-        for name in ("geoadv_approx_match_temp_floats", "geoadv_ae_workspace_bytes", "geoadv_chamfer_matrix_workspace_floats"):
+        for name in ("geoadv_approx_match_temp_floats", "geoadv_ae_workspace_bytes", "geoadv_chamfer_matrix_workspace_floats",
+                     "geoadv_emd_cost_grad1_temp_floats"):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

@@ -459,7 +459,7 @@ struct geoadv_attack {
     float *dz, *dec_partial;
     float *losses; int *jstar;
     float *best_err, *best_metrics, *best_adv, *best_recon;
-    float *emd_match, *emd_temp, *emd_cost, *emd_g1, *emd_g2;   // only when cfg.emd_weight > 0
+    float *emd_temp, *emd_cost, *emd_g1;   // only when cfg.emd_weight > 0
     float *sym_ws;                   // column-minimum partials of the symmetric Chamfer kernel
     bool cgrad_done;                 // the cached forward's loss launch also produced the Chamfer gradients
     bool chamfer_prune;              // nn_distance(adv, x) through the paired grid search (GEOADV_CHAMFER_PRUNE, default on)
@@ -575,10 +575,9 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
             if (int rc = launch_chamfer_scans(all, 4, B, st)) return rc;
         }
     }
-    if (at->emd_match) {   // approx_match is NoGradient (tf_approxmatch.py:19): the plan is recomputed every forward
-        ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
-        if (int rc = geoadv_approx_match(B, n, n, at->recon, at->gt, at->emd_match, at->emd_temp, st)) return rc;
-        if (int rc = geoadv_match_cost(B, n, n, at->recon, at->gt, at->emd_match, at->emd_cost, st)) return rc;
+    if (at->emd_temp) {   // approx_match is NoGradient (tf_approxmatch.py:19): the plan is recomputed every forward; the loop
+        ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);   // needs only its cost and d cost / d recon, so the plan itself is never stored
+        if (int rc = geoadv_emd_cost_grad1(B, n, n, at->recon, at->gt, at->emd_cost, at->emd_g1, at->emd_temp, st)) return rc;
     }
     {
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
@@ -587,7 +586,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         la.mp_pert_w = at->cfg.max_point_pert_weight; la.mp_dist_w = at->cfg.max_point_dist_weight;
         la.r1 = at->r1; la.r2 = at->r2; la.a1 = at->a1; la.a2 = at->a2; la.pert = at->pert;
         la.z = at->fs.z; la.tz = at->tz; la.w = at->w; la.losses = at->losses; la.jstar = at->jstar;
-        la.emd_cost = at->emd_match ? at->emd_cost : nullptr; la.emd_weight = at->cfg.emd_weight;
+        la.emd_cost = at->emd_temp ? at->emd_cost : nullptr; la.emd_weight = at->cfg.emd_weight;
         la.dz_latent = at->dz; la.hist = hist_slot; la.keep = keep; la.best_err = at->best_err;
         la.best_metrics = at->best_metrics; la.adv = at->adv; la.recon = at->recon;
         la.best_adv = at->best_adv; la.best_recon = at->best_recon;
@@ -647,9 +646,8 @@ int do_step(geoadv_attack *at, hipStream_t st) {
             if (int rc = launch_cgrad(pr, np, B, n, st)) return rc;
     }
     at->cgrad_done = false;
-    if (adv_chamfer && at->emd_match) {   // d(emd_weight * cost / n)/d recon, match held constant
+    if (adv_chamfer && at->emd_temp) {   // d(emd_weight * cost / n)/d recon, match held constant: emd_g1 came with the cached forward
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
-        if (int rc = geoadv_match_cost_grad(B, n, n, at->recon, at->gt, at->emd_match, at->emd_g1, at->emd_g2, st)) return rc;
         const size_t total = (size_t)B * n * 3;
         axpy_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(at->g_recon, at->emd_g1, at->cfg.emd_weight / (float)n, total);
         GA_LAUNCH_CHECK();
@@ -733,8 +731,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * 8 * B);                                      // need_adv
     need(4 * 6 * B);                                      // x_box
     const bool emd = cfg->emd_weight > 0.f;
-    const size_t emd_temp_f = emd ? geoadv_approx_match_temp_floats(at->B, at->n, at->n) : 0;
-    if (emd) { need(4 * B * n * n); need(4 * emd_temp_f + 8); need(4 * B); need(4 * bn3); need(4 * bn3); }
+    const size_t emd_temp_f = emd ? geoadv_emd_cost_grad1_temp_floats(at->B, at->n, at->n) : 0;
+    if (emd) { need(4 * emd_temp_f + 8); need(4 * B); need(4 * bn3); }
     at->arena_bytes = total;
     if (hipMalloc(&at->arena, total) != hipSuccess) {
         delete at;
@@ -769,11 +767,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
         const char *e = getenv("GEOADV_CHAMFER_SYM");
         at->chamfer_sym = !(e && e[0] == '0');
     }
-    at->emd_match = at->emd_temp = at->emd_cost = at->emd_g1 = at->emd_g2 = nullptr;
-    if (emd) {
-        at->emd_match = F(4 * B * n * n); at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B);
-        at->emd_g1 = F(4 * bn3); at->emd_g2 = F(4 * bn3);
-    }
+    at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;
+    if (emd) { at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B); at->emd_g1 = F(4 * bn3); }
     at->cgrad_done = false;
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
     at->fwd_valid = false; at->adv_valid = false;

@@ -3,21 +3,35 @@
 // Replaces approxmatchLauncher / matchcostLauncher / matchcostgradLauncher
 // (external/structural_losses/tf_approxmatch.cpp:141-143; kernels tf_approxmatch_g.cu).
 // Parity target: the reference CPU op (tf_approxmatch.cpp:23-140): 11 levels j = 8..-2 with
-// level = -4^j (0 at j = -2), double bookkeeping, expf of the float-narrowed exponent.
+// level = -4^j (0 at j = -2), double bookkeeping of the remaining capacities.
 //
 // The reference GPU kernel read-modify-writes the (b,m,n) match matrix once per level -- 10 x 2 x 4
 // bytes per pair, the dominant HBM traffic.  Here the per-level weights are kept in
-// FACTORISED form: with w_j(k,l) = expf(level_j * |p_k - q_l|^2),
+// FACTORISED form: with w_j(k,l) = exp(level_j * |p_k - q_l|^2),
 //     weight_j(k,l) = w_j(k,l) * fL_j[k] * fR_j[l],
-//     fL_j[k] = remL[k] / (1e-9 + sum_l w_j remR[l]),                       (pass A, thread per k)
+//     fL_j[k] = remL[k] / (1e-9 + sum_l w_j remR[l]),                       (pass A, one sum per k)
 //     T_l = sum_k w_j fL_j[k];  r = min(remR[l] / (1e-9 + remR[l] T_l), 1);
-//     fR_j[l] = remR[l] r;  remR[l] <- max(remR[l] - fR_j[l] T_l, 0)        (pass B, thread per l)
-//     remL[k] <- max(remL[k] - fL_j[k] sum_l w_j fR_j[l], 0)                (pass C, thread per k; fused with pass A of
+//     fR_j[l] = remR[l] r;  remR[l] <- max(remR[l] - fR_j[l] T_l, 0)        (pass B, one sum per l)
+//     remL[k] <- max(remL[k] - fL_j[k] sum_l w_j fR_j[l], 0)                (pass C, one sum per k; fused with pass A of
 //                                                                            level j+1: one distance, two weights)
 // which is the CPU loop (:36-78) with the row/column normalisations pulled out of the pair sums.
 // Only 12 (n+m) doubles per cloud live in HBM during the levels; match is written ONCE at the end
-// (sum over the 11 levels, accumulated level by level in float like the CPU's `match[k] += weight[k]`).
-// All sweeps are exp/VALU bound; every per-point sum runs sequentially in the CPU's order.
+// (sum over the 11 levels, accumulated level by level in float like the CPU's `match[k] += weight[k]`) -- and not at
+// all inside the attack loop, which only needs the plan's cost and gradient (geoadv_emd_cost_grad1).
+//
+// Arithmetic (round 2; round 1 walked every pair in fp64 with the accurate expf at one wave per SIMD: 4.6 ms per
+// approx_match at B = 32, N = 2048): the pair WEIGHT is fp32 -- d2 with FMAs, one v_exp_f32 of d2 * (level * log2 e) --
+// and everything it is multiplied into stays fp64: factors, running sums (v_fma_f64), capacities, the 1e-9 guards.
+// Why exactly this split.  The algorithm is not forgiving about its sums: a source next to an exhausted target has
+// s = 1e-9 + w * (residual capacity ~1e-9..1e-7), so residual capacities compete with the 1e-9 guard, and they are
+// themselves differences like rem - f * T with f * T = rem * (1 - 3e-7): a 6e-8 rounding of a factor, or an fp32 partial
+// sum, turns into a 10 % error of such a residual and then into a 1e-3 error of a plan entry two levels later (measured on
+// golden cloud a[1]; reproduced in numpy).  What it IS forgiving about is the weight itself, as long as passes A, B, C and
+// the plan use the SAME value: w appears in numerator and denominator of every normalisation, so a relative error of w
+// (here <= ~1e-6: fp32 distance, v_exp argument) perturbs the plan by the same order only.  Hence: one pair_d2() for every
+// kernel (bit-identical w everywhere), fp64 for the rest.  Tests hold match to rtol 2e-5 / atol 2e-6 of the reference CPU
+// goldens (tests/test_gpu_emd.py); measured worst case 7e-7 absolute.
+// Level j = -2 has level 0, i.e. w = 1 for every pair: its three sweeps are O(n + m) reductions, not O(n m) walks.
 #include "common.h"
 #include <math.h>
 
@@ -26,20 +40,16 @@
 namespace geoadv {
 
 constexpr int EMD_LEVELS = 11;                  // j = 8 .. -2 (tf_approxmatch.cpp:31)
-constexpr int EMD_TILE = 1024;                  // "other" points staged per LDS tile
+constexpr int EMD_TILE = 1024;                  // "other" points staged per LDS tile (cost / gradient kernels)
 
 static inline double emd_level(int li) {        // li = 0..10  <->  j = 8..-2
     const int j = 8 - li;
     return j == -2 ? 0.0 : -(double)powf(4.0f, (float)j);     // level = -powf(4.0, j) (:33-35)
 }
+static inline float emd_level_log2e(int li) { return (float)(emd_level(li) * 1.4426950408889634); }
 
 // temp layout per cloud (doubles): remL[n] remR[m] then per level: fL[n] fR[m]
 __host__ __device__ inline size_t emd_temp_doubles_per_cloud(int n, int m) { return (size_t)(n + m) * (1 + EMD_LEVELS); }
-
-__device__ __forceinline__ double pair_w(double level, double ox, double oy, double oz, double x2, double y2, double z2) {
-    const double d2 = (ox - x2) * (ox - x2) + (oy - y2) * (oy - y2) + (oz - z2) * (oz - z2);
-    return (double)expf((float)(level * d2));
-}
 
 __global__ void emd_init_kernel(int n, int m, double *temp) {
     const int c = blockIdx.y;
@@ -50,104 +60,159 @@ __global__ void emd_init_kernel(int n, int m, double *temp) {
     else if (i < n + m) t[i] = (double)(big / m);            // factorr (:26)
 }
 
-// PASS 0 = A, 1 = B, 2 = C.  Thread per "own" point; the "other" cloud and its per-point factor are
-// staged through LDS and walked in ascending order.
+// |p - o|^2 in fp32, the ONE form every kernel uses for a pair weight (sign-symmetric: the same bits whichever cloud is "own")
+__device__ __forceinline__ float pair_d2(float px, float py, float pz, float ox, float oy, float oz) {
+    const float dx = px - ox, dy = py - oy, dz = pz - oz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+// ------------------------------------------------------------------------------------------
+// One level sweep.  A workgroup = 8 waves owns 128 "own" points (two per lane, the same in every wave); the "other" cloud
+// is staged through LDS 1024 points at a time (coordinates fp32, factors fp64) and each wave walks one eighth of every tile, so a
+// B = 32 x N = 2048 sweep is 512 workgroups = 4 waves per SIMD (round 1: thread per own point over the WHOLE other cloud,
+// 1 wave per SIMD).  The eight partial sums of a point are folded in wave order -- a fixed order, so results are
+// reproducible run to run.  PASS 0 = A, 1 = B, 2 = C, 3 = C of level li and A of level li + 1 in one walk (one distance,
+// two weights: pass A of the next level reads nothing pass C writes for other points).
+// ------------------------------------------------------------------------------------------
+constexpr int SW_WAVES = 8, SW_THREADS = 64 * SW_WAVES, SW_OWN = 128, SW_TILE = 1024;
+
 template <int PASS>
-__global__ __launch_bounds__(256) void emd_sweep_kernel(int n, int m, int li, double level, const float *xyz1,
-                                                        const float *xyz2, double *temp) {
-    // the other cloud's coordinates are widened to double ONCE per tile here (the CPU widens them per pair, :38-41: same
-    // values), not once per pair in the loop: conversions issue at the same rate as the fp64 arithmetic they feed
-    __shared__ double ox[EMD_TILE], oy[EMD_TILE], oz[EMD_TILE];
-    __shared__ double of[EMD_TILE];
+__global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, int li, float c0, float c1, const float *xyz1,
+                                                                 const float *xyz2, double *temp) {
+    constexpr int NF = PASS == 3 ? 2 : 1;
+    __shared__ float4 st[SW_TILE];                          // x, y, z of the other cloud's points
+    __shared__ double sf[NF][SW_TILE];                      // their factors, fp64 (see the note on consistency above)
+    __shared__ double part[NF][SW_WAVES][SW_OWN];
     const int c = blockIdx.y;
     double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
-    double *remL = t, *remR = t + n, *fL = t + (size_t)(n + m) * (1 + li), *fR = fL + n;
+    double *remL = t, *remR = t + n, *fL = t + (size_t)(n + m) * (1 + li), *fR = fL + n, *fL_next = fL + (n + m);
     const bool own_is_1 = PASS != 1;
     const int n_own = own_is_1 ? n : m, n_oth = own_is_1 ? m : n;
     const float *own = (own_is_1 ? xyz1 : xyz2) + (size_t)c * n_own * 3;
     const float *oth = (own_is_1 ? xyz2 : xyz1) + (size_t)c * n_oth * 3;
-    const double *ofac = PASS == 0 ? remR : (PASS == 1 ? fL : fR);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < n_own;
-    double px = 0, py = 0, pz = 0;
-    if (live) { px = own[3 * i]; py = own[3 * i + 1]; pz = own[3 * i + 2]; }
-    double acc = PASS == 0 ? 1e-9 : 0.0;            // pass A: the CPU starts its row sum at 1e-9 (:49)
-    for (int t0 = 0; t0 < n_oth; t0 += EMD_TILE) {
-        const int cnt = min(EMD_TILE, n_oth - t0);
+    const double *fac0 = PASS == 0 ? remR : (PASS == 1 ? fL : fR);      // PASS 3: C's factor fR_li ...
+    const double *fac1 = remR;                                           // ... and A's factor remR
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float px[2], py[2], pz[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int i = blockIdx.x * SW_OWN + r * 64 + lane;
+        i = i < n_own ? i : n_own - 1;                       // (clamped lanes compute a valid point and are not stored)
+        px[r] = own[3 * i]; py[r] = own[3 * i + 1]; pz[r] = own[3 * i + 2];
+    }
+    double acc[NF][2] = {};
+    for (int t0 = 0; t0 < n_oth; t0 += SW_TILE) {
+        const int cnt = min(SW_TILE, n_oth - t0);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += 256) {
-            ox[e] = oth[3 * (size_t)(t0 + e)]; oy[e] = oth[3 * (size_t)(t0 + e) + 1]; oz[e] = oth[3 * (size_t)(t0 + e) + 2];
-            of[e] = ofac[t0 + e];
+        for (int e = threadIdx.x; e < cnt; e += SW_THREADS) {
+            const float *q = oth + 3 * (size_t)(t0 + e);
+            st[e] = make_float4(q[0], q[1], q[2], 0.f);
+            sf[0][e] = fac0[t0 + e];
+            if (NF == 2) sf[1][e] = fac1[t0 + e];
         }
         __syncthreads();
-        if (live)
-            for (int e = 0; e < cnt; ++e) acc += pair_w(level, px, py, pz, ox[e], oy[e], oz[e]) * of[e];
+        const int per = (cnt + SW_WAVES - 1) / SW_WAVES;
+        const int lo = wave * per, hi = min(cnt, lo + per);
+#pragma unroll 4
+        for (int e = lo; e < hi; ++e) {
+            const float4 o = st[e];
+            const double f0 = sf[0][e];
+            const double f1 = NF == 2 ? sf[1][e] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float d2 = pair_d2(px[r], py[r], pz[r], o.x, o.y, o.z);
+                acc[0][r] = fma((double)__builtin_amdgcn_exp2f(d2 * c0), f0, acc[0][r]);
+                if (NF == 2) acc[1][r] = fma((double)__builtin_amdgcn_exp2f(d2 * c1), f1, acc[1][r]);
+            }
+        }
     }
-    if (!live) return;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { part[f][wave][lane] = acc[f][0]; part[f][wave][64 + lane] = acc[f][1]; }
+    __syncthreads();
+    if (threadIdx.x >= SW_OWN) return;
+    const int i = blockIdx.x * SW_OWN + threadIdx.x;
+    if (i >= n_own) return;
+    double tot[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        double v = part[f][0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < SW_WAVES; ++w) v += part[f][w][threadIdx.x];
+        tot[f] = v;
+    }
     if (PASS == 0) {
-        fL[i] = remL[i] / acc;
+        fL[i] = remL[i] / (1e-9 + tot[0]);                   // the CPU starts its row sum at 1e-9 (:49)
     } else if (PASS == 1) {
         const double rr = remR[i];
-        const double ss = 1e-9 + rr * acc;
+        const double ss = 1e-9 + rr * tot[0];
         double r = rr / ss;
         r = r < 1.0 ? r : 1.0;
         const double f = rr * r;
         fR[i] = f;
-        const double left = rr - f * acc;
+        const double left = rr - f * tot[0];
         remR[i] = left > 0.0 ? left : 0.0;
     } else {
-        const double left = remL[i] - fL[i] * acc;
-        remL[i] = left > 0.0 ? left : 0.0;
+        const double left = remL[i] - fL[i] * tot[0];
+        const double rl = left > 0.0 ? left : 0.0;
+        remL[i] = rl;
+        if (PASS == 3) fL_next[i] = rl / (1e-9 + tot[NF - 1]);
     }
 }
 
-// Pass C of level li and pass A of level li + 1 in one walk over the other cloud: both are "thread per k, sum over l", pass A
-// does not read what pass C writes for other k, and the pair distance -- a third of the per-pair work -- is computed once
-// for the two weights.  The two sums run in the same order as in the separate passes: same bits.
-__global__ __launch_bounds__(256) void emd_sweep_ca_kernel(int n, int m, int li, double level_c, double level_a, const float *xyz1,
-                                                           const float *xyz2, double *temp) {
-    __shared__ double ox[EMD_TILE], oy[EMD_TILE], oz[EMD_TILE];
-    __shared__ double ofc[EMD_TILE], ofa[EMD_TILE];
-    const int c = blockIdx.y;
+// Level j = -2: level = 0, every pair weight is expf(0) = 1, so the row sums are the same for every point:
+//   A: fL[k] = remL[k] / (1e-9 + sum_l remR[l]);  B: T = sum_k fL[k], fR[l] = remR[l] * min(remR[l] / (1e-9 + remR[l] T), 1).
+// (The capacities left after this last level are never read.)  One workgroup per cloud.
+__device__ __forceinline__ double block_sum_1024(double v, double *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void emd_level0_kernel(int n, int m, int li, double *temp) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
     double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
-    double *remL = t, *remR = t + n, *fL = t + (size_t)(n + m) * (1 + li), *fR = fL + n, *fL_next = fL + (n + m);
-    const float *own = xyz1 + (size_t)c * n * 3, *oth = xyz2 + (size_t)c * m * 3;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < n;
-    double px = 0, py = 0, pz = 0;
-    if (live) { px = own[3 * i]; py = own[3 * i + 1]; pz = own[3 * i + 2]; }
-    double acc_c = 0.0, acc_a = 1e-9;               // pass A: the CPU starts its row sum at 1e-9 (:49)
-    for (int t0 = 0; t0 < m; t0 += EMD_TILE) {
-        const int cnt = min(EMD_TILE, m - t0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += 256) {
-            ox[e] = oth[3 * (size_t)(t0 + e)]; oy[e] = oth[3 * (size_t)(t0 + e) + 1]; oz[e] = oth[3 * (size_t)(t0 + e) + 2];
-            ofc[e] = fR[t0 + e]; ofa[e] = remR[t0 + e];
-        }
-        __syncthreads();
-        if (live)
-            for (int e = 0; e < cnt; ++e) {
-                const double d2 = (px - ox[e]) * (px - ox[e]) + (py - oy[e]) * (py - oy[e]) + (pz - oz[e]) * (pz - oz[e]);
-                acc_c += (double)expf((float)(level_c * d2)) * ofc[e];
-                acc_a += (double)expf((float)(level_a * d2)) * ofa[e];
-            }
+    double *remL = t, *remR = t + n, *fL = t + (size_t)(n + m) * (1 + li), *fR = fL + n;
+    double a = 0.0;
+    for (int l = threadIdx.x; l < m; l += blockDim.x) a += remR[l];
+    const double s = 1e-9 + block_sum_1024(a, red);
+    double b = 0.0;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const double f = remL[k] / s;
+        fL[k] = f;
+        b += f;
     }
-    if (!live) return;
-    const double left = remL[i] - fL[i] * acc_c;
-    const double rl = left > 0.0 ? left : 0.0;
-    remL[i] = rl;
-    fL_next[i] = rl / acc_a;
+    const double T = block_sum_1024(b, red);
+    for (int l = threadIdx.x; l < m; l += blockDim.x) {
+        const double rr = remR[l];
+        double r = rr / (1e-9 + rr * T);
+        r = r < 1.0 ? r : 1.0;
+        fR[l] = rr * r;
+    }
 }
 
-// match[c][l][k] = sum over levels of w_j(k,l) fL_j[k] fR_j[l], accumulated in float level by level.
-// grid = (n/256, m/32, b): thread = one k, 32 l's.
-constexpr int EMD_LT = 32;
-struct EmdLevels { double v[EMD_LEVELS]; };
+struct EmdLevels { float c[EMD_LEVELS]; };      // level * log2(e); c[10] = 0
 
+// match value of one pair from its squared distance: sum over the levels of exp2(c_j d2) * fR_j[l] * fL_j[k], accumulated
+// level by level in float like the CPU's `match[k] += weight[k]` (:75-76).  fr: LDS row of the 11 column factors.
+__device__ __forceinline__ float plan_value(const EmdLevels &lv, float d2, const float (&fl)[EMD_LEVELS], const float *fr, int stride) {
+    float mf = 0.f;
+#pragma unroll
+    for (int j = 0; j < EMD_LEVELS - 1; ++j) mf = fmaf(__builtin_amdgcn_exp2f(d2 * lv.c[j]) * fr[j * stride], fl[j], mf);
+    return fmaf(fr[(EMD_LEVELS - 1) * stride], fl[EMD_LEVELS - 1], mf);      // level 0: w = 1
+}
+
+// match[c][l][k] for the public op.  grid = (n/256, m/32, b): thread = one k, 32 l's.
+constexpr int EMD_LT = 32;
 __global__ __launch_bounds__(256) void emd_match_kernel(int n, int m, EmdLevels lv, const float *xyz1, const float *xyz2,
                                                         const double *temp, float *match) {
     __shared__ float qx[EMD_LT], qy[EMD_LT], qz[EMD_LT];
-    __shared__ double fr[EMD_LEVELS][EMD_LT];
+    __shared__ float fr[EMD_LEVELS][EMD_LT];
     const int c = blockIdx.z;
     const double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
     const int l0 = blockIdx.y * EMD_LT;
@@ -155,26 +220,91 @@ __global__ __launch_bounds__(256) void emd_match_kernel(int n, int m, EmdLevels 
     for (int e = threadIdx.x; e < lcnt * (3 + EMD_LEVELS); e += 256) {
         const int l = e % lcnt, what = e / lcnt;
         if (what < 3) (what == 0 ? qx : what == 1 ? qy : qz)[l] = xyz2[((size_t)c * m + l0 + l) * 3 + what];
-        else fr[what - 3][l] = t[(size_t)(n + m) * (1 + (what - 3)) + n + l0 + l];
+        else fr[what - 3][l] = (float)t[(size_t)(n + m) * (1 + (what - 3)) + n + l0 + l];
     }
     __syncthreads();
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const float *p = xyz1 + ((size_t)c * n + k) * 3;
-    const double px = p[0], py = p[1], pz = p[2];
-    double fl[EMD_LEVELS];
+    const float px = p[0], py = p[1], pz = p[2];
+    float fl[EMD_LEVELS];
 #pragma unroll
-    for (int j = 0; j < EMD_LEVELS; ++j) fl[j] = t[(size_t)(n + m) * (1 + j) + k];
+    for (int j = 0; j < EMD_LEVELS; ++j) fl[j] = (float)t[(size_t)(n + m) * (1 + j) + k];
     for (int l = 0; l < lcnt; ++l) {
-        const double x2 = qx[l], y2 = qy[l], z2 = qz[l];
-        const double d2 = (px - x2) * (px - x2) + (py - y2) * (py - y2) + (pz - z2) * (pz - z2);
-        float mf = 0.f;
+        match[((size_t)c * m + l0 + l) * n + k] = plan_value(lv, pair_d2(px, py, pz, qx[l], qy[l], qz[l]), fl, &fr[0][l], EMD_LT);
+    }
+}
+
+// The attack loop's use of the plan (adv_ae.py:120-124 with the build-defined EMD term): match_cost and
+// match_cost_grad w.r.t. xyz1 only, with the plan treated as a constant (ApproxMatch is NoGradient, tf_approxmatch.py:19).
+// Both are sums over pairs of match[l][k] times a function of the pair, so the plan is formed pair by pair in registers
+// and never written: 4 n m bytes per cloud (537 MB at B = 32) neither stored nor re-read twice.  Same pair arithmetic as
+// matchcost_cpu / matchcostgrad_cpu (:85-133): float distance, sqrtf, max(d, 1e-20).  Workgroup = 8 waves x 64 points k;
+// each wave walks one eighth of the other cloud; partials folded in wave order.
+constexpr int PL_TILE = 1024;
+__global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int n, int m, EmdLevels lv, const float *xyz1, const float *xyz2,
+                                                                           const double *temp, double *cost_partial, float *grad1) {
+    __shared__ float qx[PL_TILE], qy[PL_TILE], qz[PL_TILE];
+    __shared__ float fr[EMD_LEVELS][PL_TILE];
+    __shared__ float gpart[SW_WAVES][3][64];
+    __shared__ double cpart[SW_WAVES];
+    const int c = blockIdx.y;
+    const double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int k = blockIdx.x * 64 + lane;
+    const bool live = k < n;
+    k = live ? k : n - 1;
+    const float *p = xyz1 + ((size_t)c * n + k) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    float fl[EMD_LEVELS];
 #pragma unroll
-        for (int j = 0; j < EMD_LEVELS; ++j) {
-            const double w = (double)expf((float)(lv.v[j] * d2)) * fr[j][l] * fl[j];
-            mf = (float)((double)mf + w);
+    for (int j = 0; j < EMD_LEVELS; ++j) fl[j] = (float)t[(size_t)(n + m) * (1 + j) + k];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    double cost = 0.0;
+    for (int t0 = 0; t0 < m; t0 += PL_TILE) {
+        const int cnt = min(PL_TILE, m - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += SW_THREADS) {
+            const float *q = xyz2 + ((size_t)c * m + t0 + e) * 3;
+            qx[e] = q[0]; qy[e] = q[1]; qz[e] = q[2];
         }
-        match[((size_t)c * m + l0 + l) * n + k] = mf;
+        for (int e = threadIdx.x; e < cnt * EMD_LEVELS; e += SW_THREADS) {
+            const int j = e / cnt, l = e % cnt;
+            fr[j][l] = (float)t[(size_t)(n + m) * (1 + j) + n + t0 + l];
+        }
+        __syncthreads();
+        const int per = (cnt + SW_WAVES - 1) / SW_WAVES;
+        const int lo = wave * per, hi = min(cnt, lo + per);
+        float cs = 0.f;
+        for (int l = lo; l < hi; ++l) {
+            const float ox = qx[l] - px, oy = qy[l] - py, oz = qz[l] - pz;          // q - p, like the CPU loops
+            const float w = plan_value(lv, pair_d2(px, py, pz, qx[l], qy[l], qz[l]), fl, &fr[0][l], PL_TILE);
+            const float d = sqrtf(ox * ox + oy * oy + oz * oz);                     // matchcost_cpu's own float distance (:93-96)
+            cs += d * w;                                                            // (:97-99) float product, summed below in double
+            const float inv = 1.0f / fmaxf(d, 1e-20f);
+            gx = fmaf(-w, ox * inv, gx); gy = fmaf(-w, oy * inv, gy); gz = fmaf(-w, oz * inv, gz);
+        }
+        cost += (double)cs;
+    }
+    if (!live) cost = 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cost += __shfl_xor(cost, off);
+    gpart[wave][0][lane] = gx; gpart[wave][1][lane] = gy; gpart[wave][2][lane] = gz;
+    if (lane == 0) cpart[wave] = cost;
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int a = threadIdx.x / 64, ln = threadIdx.x % 64;
+        float g = gpart[0][a][ln];
+#pragma unroll
+        for (int w = 1; w < SW_WAVES; ++w) g += gpart[w][a][ln];
+        const int kk = blockIdx.x * 64 + ln;
+        if (kk < n) grad1[((size_t)c * n + kk) * 3 + a] = g;
+    }
+    if (threadIdx.x == 0) {
+        double s = cpart[0];
+#pragma unroll
+        for (int w = 1; w < SW_WAVES; ++w) s += cpart[w];
+        cost_partial[(size_t)c * gridDim.x + blockIdx.x] = s;
     }
 }
 
@@ -301,6 +431,26 @@ static int emd_check(const char *op, int b, int n, int m) {
     return GEOADV_OK;
 }
 
+// the eleven levels: capacities and factors into temp (fp64), no plan yet
+static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, double *t, EmdLevels &lv, hipStream_t st) {
+    emd_init_kernel<<<dim3(cdiv(n + m, 256), b), 256, 0, st>>>(n, m, t);
+    GA_LAUNCH_CHECK();
+    for (int li = 0; li < EMD_LEVELS; ++li) lv.c[li] = emd_level_log2e(li);
+    const dim3 g1(cdiv(n, SW_OWN), b), g2(cdiv(m, SW_OWN), b);
+    emd_sweep_kernel<0><<<g1, SW_THREADS, 0, st>>>(n, m, 0, lv.c[0], 0.f, xyz1, xyz2, t);
+    for (int li = 0; li < EMD_LEVELS - 1; ++li) {
+        emd_sweep_kernel<1><<<g2, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0.f, xyz1, xyz2, t);
+        if (li + 2 < EMD_LEVELS)                       // pass C of this level with pass A of the next
+            emd_sweep_kernel<3><<<g1, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], lv.c[li + 1], xyz1, xyz2, t);
+        else                                           // the next level is the weightless one: it forms its own fL
+            emd_sweep_kernel<2><<<g1, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0.f, xyz1, xyz2, t);
+        GA_LAUNCH_CHECK();
+    }
+    emd_level0_kernel<<<b, 1024, 0, st>>>(n, m, EMD_LEVELS - 1, t);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
 extern "C" int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
                                    void *stream) {
     if (int rc = emd_check("approx_match", b, n, m)) return rc;
@@ -308,20 +458,32 @@ extern "C" int geoadv_approx_match(int b, int n, int m, const float *xyz1, const
     GA_REQUIRE(xyz1 && xyz2 && match && temp, "approx_match: null pointer");
     hipStream_t st = as_stream(stream);
     double *t = reinterpret_cast<double *>((reinterpret_cast<size_t>(temp) + 7) & ~(size_t)7);
-    emd_init_kernel<<<dim3(cdiv(n + m, 256), b), 256, 0, st>>>(n, m, t);
-    GA_LAUNCH_CHECK();
     EmdLevels lv;
-    for (int li = 0; li < EMD_LEVELS; ++li) lv.v[li] = emd_level(li);
-    emd_sweep_kernel<0><<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, 0, lv.v[0], xyz1, xyz2, t);
-    for (int li = 0; li < EMD_LEVELS; ++li) {
-        emd_sweep_kernel<1><<<dim3(cdiv(m, 256), b), 256, 0, st>>>(n, m, li, lv.v[li], xyz1, xyz2, t);
-        if (li + 1 < EMD_LEVELS)                       // pass C of this level with pass A of the next
-            emd_sweep_ca_kernel<<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, li, lv.v[li], lv.v[li + 1], xyz1, xyz2, t);
-        else
-            emd_sweep_kernel<2><<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, li, lv.v[li], xyz1, xyz2, t);
-        GA_LAUNCH_CHECK();
-    }
+    if (int rc = emd_run_levels(b, n, m, xyz1, xyz2, t, lv, st)) return rc;
     emd_match_kernel<<<dim3(cdiv(n, 256), cdiv(m, EMD_LT), b), 256, 0, st>>>(n, m, lv, xyz1, xyz2, t, match);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" size_t geoadv_emd_cost_grad1_temp_floats(int b, int n, int m) {
+    if (b <= 0 || n + m <= 0) return 16;
+    return geoadv_approx_match_temp_floats(b, n, m) + 2 * (size_t)b * cdiv(n, 64) + 16;
+}
+
+extern "C" int geoadv_emd_cost_grad1(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
+                                     float *temp, void *stream) {
+    if (int rc = emd_check("emd_cost_grad1", b, n, m)) return rc;
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(xyz1 && xyz2 && cost && grad1 && temp, "emd_cost_grad1: null pointer");
+    hipStream_t st = as_stream(stream);
+    double *t = reinterpret_cast<double *>((reinterpret_cast<size_t>(temp) + 7) & ~(size_t)7);
+    double *partial = t + (size_t)b * emd_temp_doubles_per_cloud(n, m);
+    EmdLevels lv;
+    if (int rc = emd_run_levels(b, n, m, xyz1, xyz2, t, lv, st)) return rc;
+    const int parts = cdiv(n, 64);
+    emd_plan_cost_grad1_kernel<<<dim3(parts, b), SW_THREADS, 0, st>>>(n, m, lv, xyz1, xyz2, t, partial, grad1);
+    GA_LAUNCH_CHECK();
+    emd_cost_fold_kernel<<<b, 256, 0, st>>>(parts, partial, cost);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -347,11 +509,13 @@ extern "C" int geoadv_match_cost_grad(int b, int n, int m, const float *xyz1, co
                                       float *grad1, float *grad2, void *stream) {
     if (int rc = emd_check("match_cost_grad", b, n, m)) return rc;
     if (b == 0) return GEOADV_OK;
-    GA_REQUIRE(xyz1 && xyz2 && match && grad1 && grad2, "match_cost_grad: null pointer");
+    GA_REQUIRE(xyz1 && xyz2 && match && grad1, "match_cost_grad: null pointer");
     hipStream_t st = as_stream(stream);
     emd_grad1_kernel<<<dim3(cdiv(n, 256), b), 256, 0, st>>>(n, m, xyz1, xyz2, match, grad1);
     GA_LAUNCH_CHECK();
-    emd_grad2_kernel<<<dim3(m, b), 64, 0, st>>>(n, m, xyz1, xyz2, match, grad2);
-    GA_LAUNCH_CHECK();
+    if (grad2) {                                       // (a caller that differentiates w.r.t. xyz1 only passes NULL)
+        emd_grad2_kernel<<<dim3(m, b), 64, 0, st>>>(n, m, xyz1, xyz2, match, grad2);
+        GA_LAUNCH_CHECK();
+    }
     return GEOADV_OK;
 }

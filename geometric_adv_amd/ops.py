@@ -288,6 +288,21 @@ def match_cost_grad(xyz1, xyz2, match):
     return g1, g2
 
 
+def emd_cost_grad1(xyz1, xyz2):
+    """match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) and its gradient w.r.t. xyz1 with the plan held constant, without
+    materialising the (b,m,n) plan -- the fused form the attack loop uses.  -> (cost (b,), grad1 (b,n,3))."""
+    xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "ApproxMatch")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    cost = torch.empty((b,), dtype=torch.float32, device=xyz1.device)
+    g1 = torch.empty_like(xyz1)
+    with torch.cuda.device(xyz1.device):
+        nf = _lib.lib().geoadv_emd_cost_grad1_temp_floats(b, n, m)
+        temp = torch.empty(int(nf), dtype=torch.float32, device=xyz1.device)
+        _call("geoadv_emd_cost_grad1", b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(temp))
+    return cost, g1
+
+
 class _MatchCostFn(torch.autograd.Function):
     """@tf.RegisterGradient('MatchCost') (tf_approxmatch.py:38-50): grads scaled by grad_cost[b],
     no gradient w.r.t. match (ApproxMatch is registered NoGradient, :19)."""

@@ -90,7 +90,14 @@ int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz
 /* matchcostLauncher (tf_approxmatch.cpp:142; tf_approxmatch_g.cu:183-227): out[b]. */
 int geoadv_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *out, void *stream);
-/* matchcostgradLauncher (tf_approxmatch.cpp:143; tf_approxmatch_g.cu:229-295). */
+/* match_cost and match_cost_grad w.r.t. xyz1 of the plan approx_match(xyz1, xyz2) WITHOUT materialising the plan: what a
+ * caller that treats the plan as a constant (ApproxMatch is NoGradient, tf_approxmatch.py:19) and differentiates w.r.t.
+ * xyz1 only needs -- the attack loop's Chamfer+EMD loss.  cost[b], grad1[b,n,3]; temp: scratch of
+ * geoadv_emd_cost_grad1_temp_floats(b,n,m) floats.  Equal to the three separate ops up to the order of the fp32 sums. */
+size_t geoadv_emd_cost_grad1_temp_floats(int b, int n, int m);
+int geoadv_emd_cost_grad1(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
+                          float *temp, void *stream);
+/* matchcostgradLauncher (tf_approxmatch.cpp:143; tf_approxmatch_g.cu:229-295).  grad2 may be NULL (only grad1 wanted). */
 int geoadv_match_cost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
                            const float *match, float *grad1, float *grad2, void *stream);
 

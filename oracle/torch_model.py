@@ -35,16 +35,21 @@ _AE = "autoencoder"
 class TorchAE:
     """weights: dict keyed by the reference's TF variable names (geometric_adv_amd/weights.py docstring)."""
 
-    def __init__(self, weights, n_points, dtype=torch.float64, ae_name=_AE):
+    def __init__(self, weights, n_points, dtype=torch.float64, ae_name=_AE, impl="conv"):
+        """impl: "conv" = F.conv1d on [B, C, N] (the form closest to tflearn's conv_1d; the second-opinion tests use it);
+        "mm" = the same layer as one [B*N, Cin] x [Cin, Cout] addmm, which is what runs at BLAS speed on a many-core host
+        (bench.py's cpu_baseline: conv1d through oneDNN reached 14 GFLOP/s on 128 threads, addmm an order of magnitude more)."""
         self.n = n_points
         self.dt = dtype
+        self.impl = impl
         t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(dtype)
         self.conv = []
         for i in range(5):
             p = "%s/encoder_conv_layer_%d" % (ae_name, i)
             w = t(weights[p + "/W"])
             w = w.reshape(w.shape[-2], w.shape[-1])                  # [Cin, Cout] of the [1,1,Cin,Cout] conv2d filter
-            self.conv.append(dict(w=w.t().contiguous()[:, :, None],  # conv1d weight [Cout, Cin, 1]
+            self.conv.append(dict(w2=w.contiguous(),                 # [Cin, Cout] for addmm
+                                  w=w.t().contiguous()[:, :, None],  # conv1d weight [Cout, Cin, 1]
                                   b=t(weights[p + "/b"]), gamma=t(weights[p + "_bnorm/gamma"]), beta=t(weights[p + "_bnorm/beta"]),
                                   mean=t(weights[p + "_bnorm/moving_mean"]), var=t(weights[p + "_bnorm/moving_variance"])))
         self.fc = []
@@ -53,6 +58,13 @@ class TorchAE:
             self.fc.append((t(weights[p + "/W"]).t().contiguous(), t(weights[p + "/b"])))   # F.linear wants [out, in]
 
     def encode(self, pc):
+        if self.impl == "mm":
+            b, n = pc.shape[:2]
+            h = pc.to(self.dt).reshape(b * n, 3)
+            for L in self.conv:
+                h = torch.addmm(L["b"], h, L["w2"])
+                h = F.relu(F.batch_norm(h, L["mean"], L["var"], L["gamma"], L["beta"], training=False, eps=1e-5))
+            return torch.amax(h.reshape(b, n, -1), dim=1)
         h = pc.to(self.dt).transpose(1, 2)                           # [B, 3, N] channels-first for conv1d
         for L in self.conv:
             h = F.conv1d(h, L["w"], L["b"])

@@ -1,8 +1,14 @@
 """GPU parity of approx-EMD against the golden vectors (reference CPU functions,
-tf_approxmatch.cpp:23-140).  Tolerances: the GPU path uses the CPU op's level schedule and double
-bookkeeping; the only arithmetic differences are the device expf (<= 1-2 ulp vs glibc) and the
-factorised normalisation, so match agrees to ~1e-6 (the reference's own CPU-vs-GPU check allows
-1e-2, approxmatch.cpp:222)."""
+tf_approxmatch.cpp:23-140).
+
+Tolerances.  The GPU path uses the CPU op's level schedule with fp64 capacities, factors and sums; the pair WEIGHT
+exp(level * d2) is fp32 (d2 by FMAs, v_exp_f32) where the CPU op forms d2 in double and calls expf: <= ~3e-6 relative on a
+weight.  The plan is a smooth function of the weights except where a nearly exhausted capacity competes with the op's 1e-9
+guard; there the weight error is amplified by up to ~10 (csrc/emd.hip header; measured).  So:
+  * the reference's golden vectors: rtol 2e-5 / atol 2e-6 on EVERY entry (measured worst case 7e-7 absolute);
+  * larger random clouds vs the pinned oracle: the same bound on >= 99.99 % of the entries, and rtol 1e-4 / atol 2e-5 on all
+    (measured: 1 entry of 393 216 at 3.0e-5 relative).
+For scale: the reference's own CPU-vs-GPU check of this op allows 1e-2 ABSOLUTE per entry (approxmatch.cpp:222)."""
 import numpy as np
 import pytest
 
@@ -40,7 +46,11 @@ def test_approx_match_vs_oracle_medium(oracle):
     x1, x2 = cloud(1, 2, 512), cloud(2, 2, 384)
     want = oracle.approx_match(x1, x2)
     got = ops.approx_match(_t(x1), _t(x2)).cpu().numpy().transpose(0, 2, 1)
-    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    strict = np.abs(got - want) <= 2e-6 + 2e-5 * np.abs(want)
+    assert strict.mean() >= 0.9999, strict.mean()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got.sum(2), want.sum(2), rtol=1e-4, atol=2e-5)          # mass shipped per source / received per target
+    np.testing.assert_allclose(got.sum(1), want.sum(1), rtol=1e-4, atol=2e-5)
 
 
 def test_approx_match_is_a_transport_plan_full_size():
@@ -83,3 +93,34 @@ def test_emd_argument_errors():
         ops.match_cost(x, x, torch.rand((2, 10, 9), device="cuda:0"))
     with pytest.raises(ValueError):
         ops.approx_match(x, torch.rand((3, 10, 3), device="cuda:0"))
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 2048, 2048), (3, 300, 517), (2, 64, 1100), (1, 1, 5)])
+def test_fused_cost_grad1_equals_the_three_ops(b, n, m):
+    """The attack loop's fused kernel (plan formed pair by pair in registers, never stored) against approx_match ->
+    match_cost / match_cost_grad on the same clouds: same pair arithmetic, different order of the fp32 sums."""
+    import torch
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x1, x2 = _t(cloud(11, b, n)), _t(0.7 * cloud(12, b, m))
+    match = ops.approx_match(x1, x2)
+    want_cost = ops.match_cost(x1, x2, match)
+    want_g1, _ = ops.match_cost_grad(x1, x2, match)
+    cost, g1 = ops.emd_cost_grad1(x1, x2)
+    torch.testing.assert_close(cost, want_cost, rtol=2e-6, atol=0)
+    sc = want_g1.abs().amax((1, 2), keepdim=True)
+    torch.testing.assert_close(g1 / sc, want_g1 / sc, rtol=0, atol=1e-5)          # 2048-term fp32 sums in a different order
+
+
+def test_approx_match_deterministic_and_order_free():
+    """Two runs give the same bits (fixed-order folds, no atomics); permuting the clouds permutes the plan (sums run in a
+    different order: 1e-5)."""
+    import torch
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x1, x2 = _t(cloud(21, 2, 700)), _t(cloud(22, 2, 900))
+    a, b2 = ops.approx_match(x1, x2), ops.approx_match(x1, x2)
+    assert torch.equal(a, b2)
+    p1, p2 = torch.randperm(700, device="cuda:0"), torch.randperm(900, device="cuda:0")
+    c = ops.approx_match(x1[:, p1], x2[:, p2])
+    torch.testing.assert_close(c, a[:, p2][:, :, p1], rtol=1e-4, atol=2e-6)

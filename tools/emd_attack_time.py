@@ -24,6 +24,10 @@ for B, iters in ((8, 40), (32, 20), (128, 8)):
         for _ in range(reps): f()
         torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
     tc = timed(lambda: ops.match_cost(xs, ys, m)); tg = timed(lambda: ops.match_cost_grad(xs, ys, m))
+    tf = timed(lambda: ops.emd_cost_grad1(xs, ys))
+    tm = timed(lambda: ops.approx_match(xs, ys), 3) * 1e-3
+    pw = 21.4 * B * N * N                    # pair-weights per approx_match: 10 levels x (B + C + A) sweeps, minus the missing first C / last A
     print(json.dumps({"batch": B, "ms_per_iteration_chamfer_plus_emd": dt * 1e3, "approx_match_ms": tm * 1e3,
-                      "match_cost_ms": tc, "match_cost_grad_ms": tg,
+                      "match_cost_ms": tc, "match_cost_grad_ms": tg, "fused_levels_cost_grad1_ms": tf,
+                      "sweep_Tpair_weights_per_s_incl_plan_write": pw / tm / 1e12,
                       "match_bytes_GB": B * N * N * 4 / 1e9}))
