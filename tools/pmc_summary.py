@@ -3,8 +3,11 @@
 Each OUT_DIR is one `rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d OUT_DIR -- ...` pass (counters
 are collected in separate passes, see /opt/skills/guides/MI355X_MICROARCH.md); the `*_counter_collection.csv` files are
 merged by kernel name (template arguments kept, parameter list dropped)."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geometric_adv_amd", "csrc")
+HASHED = ("encoder.hip", "mfma_tile.h")      # bench.py drops counters taken at other sources of the dominant kernel
 
 
 def main(dirs):
@@ -26,6 +29,7 @@ def main(dirs):
         out[name] = {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()}
         if dur[name]:
             out[name]["avg_us_profiled"] = sum(dur[name]) / len(dur[name])
+    out["_source_sha1"] = {f: hashlib.sha1(open(os.path.join(CSRC, f), "rb").read()).hexdigest()[:12] for f in HASHED}
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 
