@@ -169,18 +169,41 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     // global memory.  The stage buffer becomes the merge arrays afterwards, hence the barrier between the two loops.
     const bool staged = mend - mbeg <= CS_STAGE;            // uniform
     int found[R];
+    if (staged) {
+        // branch-free: the chunk's eight columns come back as two ds_read_b128 per plane (chunks start at multiples of 8
+        // inside the stage; columns beyond the slice are staged as +inf and can never equal a finite minimum), and the
+        // hits are taken in DESCENDING order so that the last one kept is the lowest index -- a sixth of the
+        // instructions of the generic loop below, which every wave used to run for its four rows
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        found[r] = INT_MAX;
-        if (bestk[r] >= 0) {
-            found[r] = bestk[r];
-            bool hit = false;
-            for (int u = 0; u < CS_CHUNK; ++u) {
-                const int k = bestk[r] + u;
-                if (k < mend) {
-                    const float d = staged ? sqdist_s(sx[k - mbeg], sy[k - mbeg], sz[k - mbeg], px[r], py[r], pz[r])
-                                           : sqdist_s(Q[3 * (size_t)k], Q[3 * (size_t)k + 1], Q[3 * (size_t)k + 2], px[r], py[r], pz[r]);
-                    if (!hit && d == best[r]) { hit = true; found[r] = k; }
+        for (int r = 0; r < R; ++r) {
+            found[r] = INT_MAX;
+            if (bestk[r] < 0) continue;                   // (uniform: a wave either scanned columns or did not)
+            const int kb = bestk[r] - mbeg;
+            const float4 xa = *reinterpret_cast<const float4 *>(&sx[kb]), xb = *reinterpret_cast<const float4 *>(&sx[kb + 4]);
+            const float4 ya = *reinterpret_cast<const float4 *>(&sy[kb]), yb = *reinterpret_cast<const float4 *>(&sy[kb + 4]);
+            const float4 za = *reinterpret_cast<const float4 *>(&sz[kb]), zb = *reinterpret_cast<const float4 *>(&sz[kb + 4]);
+            const float tx[CS_CHUNK] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            const float ty[CS_CHUNK] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+            const float tz[CS_CHUNK] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+            int f = bestk[r];
+#pragma unroll
+            for (int u = CS_CHUNK - 1; u >= 0; --u)
+                f = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]) == best[r] ? bestk[r] + u : f;
+            found[r] = f;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            found[r] = INT_MAX;
+            if (bestk[r] >= 0) {
+                found[r] = bestk[r];
+                bool hit = false;
+                for (int u = 0; u < CS_CHUNK; ++u) {
+                    const int k = bestk[r] + u;
+                    if (k < mend) {
+                        const float d = sqdist_s(Q[3 * (size_t)k], Q[3 * (size_t)k + 1], Q[3 * (size_t)k + 2], px[r], py[r], pz[r]);
+                        if (!hit && d == best[r]) { hit = true; found[r] = k; }
+                    }
                 }
             }
         }
