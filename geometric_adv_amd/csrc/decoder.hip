@@ -28,21 +28,27 @@ constexpr int LD_THREADS = 1024;
 
 // out[o] (o < 256) = sum_k in[k] * Wt[k][256 + ...]: K split over 4 thread groups, partials in LDS,
 // summed in a fixed order by the first 256 threads.
-template <int K>
+// THREADS = 1024: one K quarter per thread; 512: two (quarters ks and ks + 2, one after the other) -- the four partial sums
+// and their order are the same either way, so both give the same bits.
+template <int K, int THREADS = LD_THREADS>
 __device__ __forceinline__ float fc256_split4(const float *in_lds, const float *W /*[K][256]*/, float (*part)[256]) {
-    const int t = threadIdx.x, o = t & 255, ks = t >> 8;
+    const int t = threadIdx.x, o = t & 255;
     constexpr int PER = K / 4;
-    float w[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) w[k] = W[(size_t)(ks * PER + k) * 256 + o];
-    float s = 0.f;
+    for (int ks = t >> 8; ks < 4; ks += THREADS / 256) {
+        float w[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) s = fmaf(in_lds[ks * PER + k], w[k], s);
-    part[ks][o] = s;
+        for (int k = 0; k < PER; ++k) w[k] = W[(size_t)(ks * PER + k) * 256 + o];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) s = fmaf(in_lds[ks * PER + k], w[k], s);
+        part[ks][o] = s;
+    }
     __syncthreads();
     return ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];     // meaningful for t < 256
 }
 
+template <int THREADS>
 __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles, const float *pmax, const int *parg,
                                                     const int *pcnt, float *z, int *crit, int *zcnt,
                                                     int *dense, float *d1, float *d2, const int b) {
@@ -54,8 +60,9 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
     __shared__ int tie;
     const int t = threadIdx.x;
     if (t == 0) tie = 0;
-    {   // 8 contiguous tile groups x 128 channels; ascending tiles inside a group, groups merged in order
-        const int c = t & 127, g = t >> 7;
+    // 8 contiguous tile groups x 128 channels; ascending tiles inside a group, groups merged in order
+    for (int g = t >> 7; g < 8; g += THREADS / 128) {
+        const int c = t & 127;
         const int tb = tiles * g / 8, te = tiles * (g + 1) / 8;
         float m = -1.f;
         int a = INT_MAX, k = 0;
@@ -89,7 +96,7 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
     if (t == 0) dense[b] = tie;
     if (!d1) return;
     {   // FC0 + ReLU: 128 -> 256
-        const float s = fc256_split4<128>(zs, A.v0, part);
+        const float s = fc256_split4<128, THREADS>(zs, A.v0, part);
         if (t < 256) {
             const float v = fmaxf(s + A.c0[t], 0.f);
             hs[t] = v;
@@ -98,7 +105,7 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
     }
     __syncthreads();
     {   // FC1 + ReLU: 256 -> 256
-        const float s = fc256_split4<256>(hs, A.v1, part);
+        const float s = fc256_split4<256, THREADS>(hs, A.v1, part);
         if (t < 256) d2[(size_t)b * 256 + t] = fmaxf(s + A.c1[t], 0.f);
     }
 }
@@ -106,20 +113,21 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
 __global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
                                                                    const int *pcnt, float *z, int *crit, int *zcnt,
                                                                    int *dense, float *d1, float *d2) {
-    latent_decode_block(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
+    latent_decode_block<LD_THREADS>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
 }
 
 // The same launch with the workgroups of the attack's paired grid search nn_distance(adv, x) behind it (chamfer_grid.h):
-// that search needs nothing the network produces, and this launch keeps 32 workgroups busy for 9 us.  The grid blocks
-// use the first eight of the sixteen waves.
-__global__ __launch_bounds__(LD_THREADS) void latent_decode_and_grid_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
+// that search needs nothing the network produces, and this launch keeps 32 workgroups busy for 9 us.  EVERY workgroup of
+// this launch has GR_THREADS = 512 threads: with 1024 (the grid blocks idling their upper half) a workgroup's 16 waves
+// x 112 VGPRs allowed only one per CU, so the 9 B workgroups of a B = 32 batch took two rounds on the 256 CUs (21 us);
+// 8-wave workgroups sit two to a CU and the launch is one round.  The latent blocks do their two K quarters in sequence.
+__global__ __launch_bounds__(GR_THREADS) void latent_decode_and_grid_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
                                                                             const int *pcnt, float *z, int *crit, int *zcnt, int *dense,
                                                                             float *d1, float *d2, int batch, GridArgs G) {
     if ((int)blockIdx.x < batch) {
-        latent_decode_block(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
+        latent_decode_block<GR_THREADS>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
         return;
     }
-    if (threadIdx.x >= GR_THREADS) return;
     const int g = blockIdx.x - batch;                   // (cloud, direction, slice), slice fastest
     grid_nn_block<GR_MAX_N>(G, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
 }
@@ -294,7 +302,7 @@ int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, c
             return GEOADV_OK;
         })) return rc;
     const GridArgs G{P, Q, gd1, gi1, gd2, gi2, n, need, call, box};
-    latent_decode_and_grid_kernel<<<b + b * 2 * GR_QSPLIT, LD_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
+    latent_decode_and_grid_kernel<<<b + b * 2 * GR_QSPLIT, GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
         A, encoder_tiles(A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
