@@ -12,7 +12,7 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
 int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
-int encoder_tiles(int n);
+int encoder_tiles_max(int n);
 
 static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -39,7 +39,7 @@ struct ForwardScratch {
 
 ForwardScratch carve_forward_scratch(void *base, int b, int n_points) {
     ForwardScratch s;
-    const size_t tiles = encoder_tiles(n_points);
+    const size_t tiles = encoder_tiles_max(n_points);     // (the forward picks its tile height per launch: encoder.hip)
     char *p = static_cast<char *>(base);
     auto take = [&](size_t bytes) { char *q = p; p += rup(bytes, 256); return q; };
     s.pmax = reinterpret_cast<float *>(take(sizeof(float) * b * tiles * 128));

@@ -12,7 +12,7 @@
 
 namespace geoadv {
 
-int encoder_tiles(int n);
+int encoder_tiles(int b, int n);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int acc_row16(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -117,17 +117,21 @@ __global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, i
 }
 
 // The same launch with the workgroups of the attack's paired grid search nn_distance(adv, x) behind it (chamfer_grid.h):
-// that search needs nothing the network produces, and this launch keeps 32 workgroups busy for 9 us.  EVERY workgroup of
-// this launch has GR_THREADS = 512 threads: with 1024 (the grid blocks idling their upper half) a workgroup's 16 waves
-// x 112 VGPRs allowed only one per CU, so the 9 B workgroups of a B = 32 batch took two rounds on the 256 CUs (21 us);
-// 8-wave workgroups sit two to a CU and the launch is one round.  The latent blocks do their two K quarters in sequence.
-__global__ __launch_bounds__(GR_THREADS) void latent_decode_and_grid_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
-                                                                            const int *pcnt, float *z, int *crit, int *zcnt, int *dense,
-                                                                            float *d1, float *d2, int batch, GridArgs G) {
+// that search needs nothing the network produces, and this launch keeps 32 workgroups busy for 9 us.  Two shapes.
+// THREADS = 1024 (the latent blocks' own shape; the grid blocks use the first eight of the sixteen waves): 16 waves x 112
+// VGPRs admit ONE workgroup per CU, fine while the 9 B workgroups of the launch fit the 256 CUs (B <= 28).  THREADS = 512:
+// two workgroups per CU, so a B = 32 batch (288 workgroups) still runs in one round -- with 1024 it took two (21 us instead
+// of 15) --, and the latent blocks do their two K quarters in sequence (13 instead of 10 us, which is why small batches keep
+// the first shape).  Same arithmetic in the same order either way.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void latent_decode_and_grid_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
+                                                                         const int *pcnt, float *z, int *crit, int *zcnt, int *dense,
+                                                                         float *d1, float *d2, int batch, GridArgs G) {
     if ((int)blockIdx.x < batch) {
-        latent_decode_block<GR_THREADS>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
+        latent_decode_block<THREADS>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
         return;
     }
+    if (THREADS > GR_THREADS && threadIdx.x >= GR_THREADS) return;
     const int g = blockIdx.x - batch;                   // (cloud, direction, slice), slice fastest
     grid_nn_block<GR_MAX_N>(G, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
 }
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
-    latent_decode_kernel<<<b, LD_THREADS, 0, stream>>>(A, encoder_tiles(A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
+    latent_decode_kernel<<<b, LD_THREADS, 0, stream>>>(A, encoder_tiles(b, A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -297,13 +301,20 @@ int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, c
     if (b <= 0) return GEOADV_OK;
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(latent_decode_and_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)chamfer_grid_lds_bytes(GR_MAX_N)));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(latent_decode_and_grid_kernel<LD_THREADS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)chamfer_grid_lds_bytes(GR_MAX_N)));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(latent_decode_and_grid_kernel<GR_THREADS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)chamfer_grid_lds_bytes(GR_MAX_N)));
             return GEOADV_OK;
         })) return rc;
     const GridArgs G{P, Q, gd1, gi1, gd2, gi2, n, need, call, box};
-    latent_decode_and_grid_kernel<<<b + b * 2 * GR_QSPLIT, GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
-        A, encoder_tiles(A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
+    const int blocks = b + b * 2 * GR_QSPLIT;
+    if (blocks <= kCUs)     // one workgroup per CU is enough: keep the latent blocks at their 16 waves
+        latent_decode_and_grid_kernel<LD_THREADS><<<blocks, LD_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
+            A, encoder_tiles(b, A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
+    else
+        latent_decode_and_grid_kernel<GR_THREADS><<<blocks, GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
+            A, encoder_tiles(b, A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

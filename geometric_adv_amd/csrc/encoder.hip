@@ -84,14 +84,21 @@ __device__ __forceinline__ void fwd_layer0(const float *pts /*LDS [ROWS][3]*/, f
 // TWO workgroups share a CU and one's epilogues / barriers / first-operand latencies hide under
 // the other's MFMAs.
 // ------------------------------------------------------------------------------------------
-constexpr int FWD2_BUF_FLOATS = 64 * 132;
-constexpr size_t FWD2_LDS_BYTES = sizeof(float) * (2 * FWD2_BUF_FLOATS + 64 * 3 + 256) + sizeof(int) * 512;
 // ReLU masks of h1..h4 for the sparse backward (which then needs no forward recompute): MASK_WORDS 32-bit words per
 // point, bit c&31 of word OFF_L + (c>>5) = [h_L[c] > 0]; h1: words 0-1, h2: 2-5, h3: 6-9, h4: 10-17.  The h5 mask is
 // implied (the arg-max of a channel with z > 0 is positive).  Staged per tile in LDS, written out coalesced.
 constexpr int MASK_WORDS = 18;
 constexpr int MASK_OFF2 = 2, MASK_OFF3 = 6, MASK_OFF4 = 10;
-constexpr size_t FWD2_LDS_BYTES_MASKS = FWD2_LDS_BYTES + sizeof(unsigned) * 64 * MASK_WORDS;
+// ROWS = 64: 8 waves, two workgroups per CU (the B = 32 shape).  ROWS = 32: 4 waves owning one row block -- the same chains,
+// the same bits -- for launches that would otherwise leave CUs without a tile (batch * n / 64 < 256, i.e. B <= 7 at
+// N = 2048: what each GPU sees when ONE batch of 32 is split over 8): a tile's five dependent layers are ~19 us of MFMA
+// time on one CU at 64 rows however few tiles there are, ~9 us at 32.
+template <int ROWS> struct Fwd2 {
+    static constexpr int THREADS = ROWS * 8;
+    static constexpr int BUF_FLOATS = ROWS * 132;
+    static constexpr size_t LDS_BYTES = sizeof(float) * (2 * BUF_FLOATS + ROWS * 3 + 256) + sizeof(int) * 512;
+    static constexpr size_t LDS_BYTES_MASKS = LDS_BYTES + sizeof(unsigned) * ROWS * MASK_WORDS;
+};
 
 // lane r (< 16) collects the two mask words of accumulator register r: rows acc_row(r, 0) and acc_row(r, 1).
 // v_writelane_b32 moves each half of the ballot (an SGPR pair) into that lane with ONE VALU instruction; the portable
@@ -165,15 +172,15 @@ __device__ __forceinline__ void chain_ring(const float *ar, int at0, const FragS
 
 __device__ __forceinline__ int orow_of(int rb) { return rb * 32; }
 
-template <bool MASKS>
-__global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A, int n, const float *x, const float *pert,
-                                                                     float *adv_out, float *pmax, int *parg, int *pcnt,
-                                                                     unsigned *masks) {
-    constexpr int ROWS = 64;
+template <bool MASKS, int ROWS>
+__global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, int n, const float *x, const float *pert,
+                                                                  float *adv_out, float *pmax, int *parg, int *pcnt,
+                                                                  unsigned *masks) {
+    constexpr int THREADS = Fwd2<ROWS>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds;
-    float *bufB = bufA + FWD2_BUF_FLOATS;
-    float *pts = bufB + FWD2_BUF_FLOATS;              // [64][3]
+    float *bufB = bufA + Fwd2<ROWS>::BUF_FLOATS;
+    float *pts = bufB + Fwd2<ROWS>::BUF_FLOATS;       // [ROWS][3]
     float *redm = pts + ROWS * 3;                     // [2][128]
     int *reda = reinterpret_cast<int *>(redm + 256);
     int *redc = reda + 256;
@@ -198,9 +205,12 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
     float *l0c = redm;                                 // (the pool's reduction buffers are free until the end)
     const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
     const int n0 = tile * ROWS;
-    float pv = 0.f, pp = 0.f, l0v = 0.f;
+    float pv = 0.f, pp = 0.f;
     size_t pg = 0;
     bool pvalid = false;
+    constexpr int L0_LOADERS = THREADS - ROWS * 3;    // 320 (64-row form) or 160 threads: one or two constants each
+    constexpr int L0_PER = (320 + L0_LOADERS - 1) / L0_LOADERS;
+    float l0v[L0_PER] = {};
     if (threadIdx.x < ROWS * 3) {
         const int r = threadIdx.x / 3, a = threadIdx.x % 3;
         int p = n0 + r;
@@ -210,8 +220,11 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         pv = x[pg];
         if (pert) pp = pert[pg];
     } else {
-        const int e = threadIdx.x - 192;
-        l0v = e < 192 ? A.w0[e] : (e < 256 ? A.scale[0][e - 192] : A.shift[0][e - 256]);
+#pragma unroll
+        for (int q = 0; q < L0_PER; ++q) {
+            const int e = threadIdx.x - ROWS * 3 + q * L0_LOADERS;
+            if (e < 320) l0v[q] = e < 192 ? A.w0[e] : (e < 256 ? A.scale[0][e - 192] : A.shift[0][e - 256]);
+        }
     }
     BRing ring;
     ring_fill(ring, w1, lb);                          // in flight during layer 0
@@ -226,7 +239,11 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         pts[threadIdx.x] = v;
         if (adv_out && pvalid) adv_out[pg] = v;
     } else {
-        l0c[threadIdx.x - 192] = l0v;
+#pragma unroll
+        for (int q = 0; q < L0_PER; ++q) {
+            const int e = threadIdx.x - ROWS * 3 + q * L0_LOADERS;
+            if (e < 320) l0c[e] = l0v[q];
+        }
     }
     __syncthreads();
     {   // layer 0 (fan-in 3) on the VALU, same arithmetic as fwd_layer0
@@ -351,16 +368,18 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encoder_fwd2_kernel(DeviceAE A
         const int c = threadIdx.x;
         float m = redm[c];
         int a = reda[c], k = redc[c];
-        const float m2 = redm[128 + c];
-        if (m2 > m) { m = m2; a = reda[128 + c]; k = redc[128 + c]; }
-        else if (m2 == m) { k += redc[128 + c]; }
+        if (ROWS == 64) {
+            const float m2 = redm[128 + c];
+            if (m2 > m) { m = m2; a = reda[128 + c]; k = redc[128 + c]; }
+            else if (m2 == m) { k += redc[128 + c]; }
+        }
         const size_t o = ((size_t)b * tiles + tile) * 128 + c;
         pmax[o] = m; parg[o] = a; pcnt[o] = k;
     }
     if (MASKS) {   // the tile's mask rows are contiguous in HBM (issuing these stores before the last chain is slower:
         const int live = n - n0 < ROWS ? n - n0 : ROWS;   // they count in vmcnt and stall the fragment ring)
         unsigned *dst = masks + ((size_t)b * n + n0) * MASK_WORDS;
-        for (int e = threadIdx.x; e < live * MASK_WORDS; e += ENC_THREADS) dst[e] = mtile[e];
+        for (int e = threadIdx.x; e < live * MASK_WORDS; e += THREADS) dst[e] = mtile[e];
     }
 }
 
@@ -614,10 +633,10 @@ constexpr int BWD_DENSE_ROWS = 64;
 static int set_lds_attr_once() {
     static DeviceOnce once;
     return once.run([]() -> int {
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES));
-        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD2_LDS_BYTES_MASKS));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<false, 64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Fwd2<64>::LDS_BYTES));
+        GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd2_kernel<true, 64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Fwd2<64>::LDS_BYTES_MASKS));
         GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_merged_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)EncLds<64>::bwd_bytes));
         GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_bwd_kernel<BWD_SPARSE_ROWS, false>),
@@ -628,30 +647,40 @@ static int set_lds_attr_once() {
     });
 }
 
-int encoder_fwd_rows() { return 64; }
-int encoder_tiles(int n) { return cdiv(n, 64); }
+// Tile height of the forward for a batch of b clouds: 32 rows when 64-row tiles would not even give every CU one tile.
+int encoder_fwd_rows(int b, int n) { return (long)b * cdiv(n, 64) < kCUs ? 32 : 64; }
+int encoder_tiles(int b, int n) { return cdiv(n, encoder_fwd_rows(b, n)); }
+int encoder_tiles_max(int n) { return cdiv(n, 32); }              // what the pool-partial buffers are sized for
 
 // Words of ReLU mask per point the forward leaves for the sparse backward.
 int encoder_mask_words() { return MASK_WORDS; }
 
-// pmax/parg/pcnt: [b][tiles][128]; masks: [b][n][MASK_WORDS] or null (plain forward: geoadv_ae_forward, recomputing backward)
+template <bool MASKS, int ROWS>
+static void launch_fwd2(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg, int *pcnt,
+                        unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+    const dim3 grid(cdiv(A.n_points, ROWS), b), block(Fwd2<ROWS>::THREADS);
+    const unsigned lds = (unsigned)(MASKS ? Fwd2<ROWS>::LDS_BYTES_MASKS : Fwd2<ROWS>::LDS_BYTES);
+    if (start && stop)
+        hipExtLaunchKernelGGL((encoder_fwd2_kernel<MASKS, ROWS>), grid, block, lds, stream, start, stop, 0,
+                              A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks);
+    else
+        encoder_fwd2_kernel<MASKS, ROWS><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks);
+}
+
+// pmax/parg/pcnt: [b][encoder_tiles(b, n)][128]; masks: [b][n][MASK_WORDS] or null (plain forward: geoadv_ae_forward, recomputing backward)
 // start / stop (optional): events that receive the kernel's own begin / end time stamps (geoadv_attack_profile).
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
                        int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
-    const dim3 grid(encoder_tiles(A.n_points), b);
-    if (start && stop) {
-        if (masks)
-            hipExtLaunchKernelGGL(encoder_fwd2_kernel<true>, grid, dim3(ENC_THREADS), (unsigned)FWD2_LDS_BYTES_MASKS, stream, start, stop, 0,
-                                  A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks);
-        else
-            hipExtLaunchKernelGGL(encoder_fwd2_kernel<false>, grid, dim3(ENC_THREADS), (unsigned)FWD2_LDS_BYTES, stream, start, stop, 0,
-                                  A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, (unsigned *)nullptr);
-    } else if (masks)
-        encoder_fwd2_kernel<true><<<grid, ENC_THREADS, FWD2_LDS_BYTES_MASKS, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks);
-    else
-        encoder_fwd2_kernel<false><<<grid, ENC_THREADS, FWD2_LDS_BYTES, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, nullptr);
+    const bool small = encoder_fwd_rows(b, A.n_points) == 32;
+    if (masks) {
+        if (small) launch_fwd2<true, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop);
+        else launch_fwd2<true, 64>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop);
+    } else {
+        if (small) launch_fwd2<false, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, nullptr, stream, start, stop);
+        else launch_fwd2<false, 64>(A, b, x, pert, adv_out, pmax, parg, pcnt, nullptr, stream, start, stop);
+    }
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
