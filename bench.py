@@ -250,6 +250,42 @@ def training_leg(dev, steps=30, batch=50):
             "frac_of_fp32_mfma_peak_end_to_end": flop / dt / (PEAK_MFMA_F32_TFLOPS * 1e12)}
 
 
+def emd_leg(dev):
+    """Row a15 (config 3's loss): approx_match and the loop's fused levels + cost + gradient at B = 32 and at config 3's per-GPU
+    batch B = 128 (N = 2048) against the kernels' bound, which is VALU issue.  Work per pair of points: 21.4 sweep
+    pair-weights (10 levels x (B + C + A) sweeps of exp(level * d2) * factor, the first C and the last A missing) at
+    3 v_sub + 2 v_mul (2.65 cycles per wave instruction each) + 2 v_fmac_f32 (4.4) + v_exp_f32 (8.3) + v_cvt_f64_f32 +
+    v_fma_f64 (4.7 each) = 39.75 cycles per 64 lanes, plus the plan: one distance (19.4 cycles) and 10 x (v_mul, v_exp, v_mul,
+    v_fmac) = 10 x 18.0 -- per-opcode issue costs measured on the box (profiles/r01_probe_valu_v2.json), 1024 SIMDs, 2.4 GHz."""
+    import torch
+    from geometric_adv_amd import ops
+    out = {}
+    cyc_pw = 3 * 2.65 + 2 * 2.65 + 2 * 4.4 + 8.3 + 4.7 + 4.7
+    cyc_pair = 21.4 * cyc_pw + (3 * 2.65 + 2.65 + 2 * 4.4) + 10 * (2.65 + 8.3 + 2.65 + 4.4)
+    for b in (32, 128):
+        xs, ys = torch.as_tensor(clouds(31, b, N)).to(dev), torch.as_tensor(clouds(32, b, N)).to(dev)
+
+        def timed(f, reps):
+            f(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                r = f()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps, r
+        reps = 6 if b == 32 else 3
+        t_match, m = timed(lambda: ops.approx_match(xs, ys), reps)
+        del m
+        t_fused, _ = timed(lambda: ops.emd_cost_grad1(xs, ys), reps)
+        bound_ms = b * N * N / 64.0 * cyc_pair / (1024 * 2.4e9) * 1e3
+        out["B%d" % b] = {"approx_match_ms": t_match, "levels_cost_grad1_fused_ms": t_fused, "issue_bound_ms": bound_ms,
+                          "frac": bound_ms / t_match, "achieved_Tpair_weights_per_s_sweeps_only": 21.4 * b * N * N / (t_match * 1e-3) / 1e12}
+    out.update({"bound": "valu issue", "cycles_per_64_pairs": cyc_pair, "cycles_per_64_sweep_pair_weights": cyc_pw,
+                "hbm_note": "approx_match writes the 4 B N M plan once (537 MB at B = 32: ~0.1 ms at 5 TB/s); the fused form writes nothing",
+                "round1_approx_match_ms_B32": 4.61})
+    return out
+
+
 def slots_leg(dev, weights, ae, slots=2, iters=300):
     """Configuration.batch_slots: `slots` independent B = 32 batches attacked concurrently on this GPU (own handle, stream
     and host thread each, AdvAE._attack_slots): aggregate attack iterations/s.  Reported beside the headline, which
@@ -475,7 +511,7 @@ def main():
         "final_mean_target_recon_error": float(leg.gathered[0, :, 4].mean().item()),
     }
     if world == 1:                  # the widened row f-4, measured beside the headline (not part of `value`)
-        out["secondary"] = {"ae_training_step": training_leg(dev)}
+        out["secondary"] = {"ae_training_step": training_leg(dev), "roofline_emd": emd_leg(dev)}
         if args.slots > 1:
             out["secondary"]["batch_slots"] = slots_leg(dev, weights, ae, args.slots)
     if world == 1 and not args.no_cpu_baseline:

@@ -156,6 +156,10 @@ class AdvAE:
             mask = sum(1 << PROF_NAMES.index(c) for c in classes)
         _lib.check(_lib.lib().geoadv_attack_profile(self._h, int(mask)), "attack_profile")
 
+    def markers(self, enable=True):
+        """roctx ranges 'geoadv:<class>' around the launches of every kernel class (rocprofv3 --marker-trace)."""
+        _lib.check(_lib.lib().geoadv_attack_markers(self._h, int(bool(enable))), "attack_markers")
+
     def profile_read(self):
         """{kernel class: (launches, total_ms)} measured with HIP events on the launch stream."""
         out = {}

@@ -9,6 +9,7 @@
 // index-aligned with the reference (metrics of iteration k describe the state after k+1 updates).
 #include "ae.h"
 #include "chamfer_grad.h"
+#include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -483,6 +484,7 @@ struct geoadv_attack {
     double prof_ms[GEOADV_PROF_COUNT];
     int prof_n[GEOADV_PROF_COUNT];
     hipStream_t prof_stream;
+    bool markers;                    // roctx ranges around every kernel class (geoadv_attack_markers)
 };
 
 namespace {
@@ -503,14 +505,34 @@ int prof_flush(geoadv_attack *at) {
     return GEOADV_OK;
 }
 
+// roctx ranges (tracing): libroctx64 is looked up at run time -- the library has no link-time dependency on the
+// tracer -- and the ranges show up in `rocprofv3 --marker-trace` / rocprof-compute timelines as "geoadv:<class>".
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void *h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+const Roctx &roctx() { static const Roctx r; return r; }
+const char *const kClassNames[GEOADV_PROF_COUNT] = {"geoadv:encoder_fwd", "geoadv:decoder_fwd", "geoadv:chamfer_fwd", "geoadv:loss_grad",
+                                                    "geoadv:decoder_bwd", "geoadv:encoder_bwd", "geoadv:adam"};
+
 // Two ways to time a class.  Bracketing (default): hipEventRecord before and after the scope's launches -- the interval
 // includes the dispatch gaps around them (~2 us each between dependent kernels).  Kernel-timed (`kernel` = true, one launch
 // per scope): the scope only reserves the two events and the launcher hands them to hipExtLaunchKernel, which stamps the
 // kernel's own begin / end -- the quantity rocprofv3 --kernel-trace reports, so the two agree.
 struct ProfScope {
-    geoadv_attack *at; int which; int e0, e1; hipStream_t st; bool on, kernel;
+    geoadv_attack *at; int which; int e0, e1; hipStream_t st; bool on, kernel, marked;
     ProfScope(geoadv_attack *a, int w, hipStream_t s, bool kernel_timed = false)
-        : at(a), which(w), e0(-1), e1(-1), st(s), on((a->prof_mask >> w) & 1u), kernel(kernel_timed) {
+        : at(a), which(w), e0(-1), e1(-1), st(s), on((a->prof_mask >> w) & 1u), kernel(kernel_timed),
+          marked(a->markers && roctx().push != nullptr) {
+        if (marked) roctx().push(kClassNames[w]);
         if (on && at->prof_stride > 1) on = (at->prof_seen[w]++ % (unsigned)at->prof_stride) == 0;
         if (!on) return;
         if (at->ev_used + 2 > (int)at->ev.size()) prof_flush(at);
@@ -521,6 +543,7 @@ struct ProfScope {
     hipEvent_t start() const { return on && kernel ? at->ev[e0] : nullptr; }
     hipEvent_t stop() const { return on && kernel ? at->ev[e1] : nullptr; }
     ~ProfScope() {
+        if (marked) roctx().pop();
         if (!on) return;
         if (!kernel) {
             e1 = at->ev_used++;
@@ -772,7 +795,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->cgrad_done = false;
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
     at->fwd_valid = false; at->adv_valid = false;
-    at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr; at->prof_stride = 1;
+    at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr; at->prof_stride = 1; at->markers = false;
     for (int i = 0; i < GEOADV_PROF_COUNT; ++i) at->prof_seen[i] = 0;
     for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
     static DeviceOnce attr;
@@ -894,6 +917,13 @@ extern "C" int geoadv_attack_profile(geoadv_attack *at, int enable) {
     if (at->prof_mask) { if (int rc = prof_flush(at)) return rc; }
     at->prof_mask = (unsigned)enable;
     if (enable) for (int i = 0; i < GEOADV_PROF_COUNT; ++i) { at->prof_ms[i] = 0; at->prof_n[i] = 0; }
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_markers(geoadv_attack *at, int enable) {
+    GA_REQUIRE(at, "attack_markers: null handle");
+    GA_REQUIRE(!enable || roctx().push, "attack_markers: libroctx64.so not found");
+    at->markers = enable != 0;
     return GEOADV_OK;
 }
 

@@ -294,6 +294,9 @@ int geoadv_trainer_export(geoadv_trainer *t, const geoadv_ae_weights *dst, void 
 #define GEOADV_PROF_COUNT       7
 int geoadv_attack_profile(geoadv_attack *at, int enable);
 int geoadv_attack_profile_read(geoadv_attack *at, int which, int *launches, float *total_ms);
+/* roctx ranges "geoadv:<class>" around the launches of every kernel class (for rocprofv3 --marker-trace timelines);
+ * libroctx64 is looked up at run time.  Returns GEOADV_EINVAL if it cannot be found. */
+int geoadv_attack_markers(geoadv_attack *at, int enable);
 /* Time only every stride-th launch of each selected class (a pair of events between two dependent kernels costs ~1 us of
  * GPU time; sampling keeps a timed region honest).  Default 1. */
 int geoadv_attack_profile_stride(geoadv_attack *at, int stride);

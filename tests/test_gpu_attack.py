@@ -457,3 +457,27 @@ def test_real_attack_sharded_over_two_ranks_on_one_gpu(setup, tmp_path):
     assert got[0]["m"].shape == (2, n_ex, 5) and got[0]["a"].shape == (2, n_ex, N, 3)
     logs = [open(str(tmp_path / "out") + ".rank%d.txt" % r).read() for r in range(2)]
     assert logs[0].count("Batch ") == 2 and logs[1].count("Batch ") == 1 and "Dist weight" in logs[1]
+
+
+def test_roctx_markers_and_kernel_timing_leave_results_alone(setup):
+    """Tracing hooks: roctx ranges (libroctx64 looked up at run time) and per-class timing -- kernel begin/end stamps for the
+    encoder forward, bracketing events for the rest -- must not change a bit of the trajectory."""
+    import torch
+    w, ae, model = setup
+    b = 3
+    x, gt = _clouds(61, b)
+    outs = []
+    for traced in (False, True):
+        at = _mk_attack(w, ae, b)
+        at.set_inputs(x, gt, None, 1.0)
+        at.init_pert(None, reset_optimizer=True)
+        if traced:
+            at.markers(True)
+            at.profile(True)
+        at.run(0, 6, 3)
+        if traced:
+            prof = at.profile_read()
+            assert prof["encoder_fwd"][0] == 7 and all(0 < ms < 50 for _, ms in prof.values())     # 6 iterations + the first forward
+            at.profile(False); at.markers(False)
+        outs.append(at.peek()["pert"].clone())
+    assert torch.equal(outs[0], outs[1])
