@@ -190,7 +190,9 @@ def cpu_baseline(weights, x, gt, iters, gpu_clouds=None):
         dt = time.perf_counter() - t0
         return dt, to.seconds
 
-    dt, ch = leg(Oracle())
+    from oracle.cpu_oracle import Reference
+    ref_chamfer = Reference.available()          # oracle/_ref: the reference's OWN nnsearch (tf_nndistance.cpp:21-43) compiled by
+    dt, ch = leg(Reference() if ref_chamfer else Oracle())   # oracle/build_ref.sh; it travels to the GPU box as a built .so
     all_cores = None
     try:
         dt2, ch2 = leg(Oracle(omp=True))
@@ -220,6 +222,7 @@ def cpu_baseline(weights, x, gt, iters, gpu_clouds=None):
     gemm_s = (dt - ch) / iters
     flop = 3 * ENC_FLOP_PER_POINT * B * N + 3 * 2.0 * B * (98304 + 768 * N)      # 2 forwards + 1 backward-to-input
     return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "chamfer_kind": "reference (oracle/_ref: the reference's nnsearch compiled from its own source)" if ref_chamfer else "port",
             "parity": parity, "cpu_model": cpu_model,
             "sample": "%d iterations of config 2 (B=32, N=2048) after 1 warm-up, reference schedule (2 forwards + 1 backward per "
                       "iteration); network = torch-CPU %s fp32 (addmm / batch_norm / linear + autograd, best of 8..all threads = %d), Chamfer = "

@@ -1,4 +1,6 @@
 """CPU: host-side logic of the package (no GPU, no compute calls through the C ABI)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -211,3 +213,19 @@ def test_trainer_initial_weights_follow_the_reference_initialisers():
         assert a.shape == (dd[k], dd[k + 1]) and np.abs(a).max() <= lim
         assert abs(a.std() / (lim / np.sqrt(3)) - 1) < 0.03
     assert abs(w["autoencoder/decoder_fc_0/W"].std() - 0.072) < 0.003          # 128 -> 256: not the 0.02 of a truncated normal
+
+
+def test_bench_parent_launcher_fails_cleanly_without_gpus():
+    """bench.py --gpus 2 from a bare shell spawns its ranks itself (before touching any GPU); on a box without GPUs the ranks
+    die on their assertion and the parent must relay a non-zero status and no JSON line -- no hang, no half-printed result."""
+    import subprocess, sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the GPU-less build container")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "2-rank run failed" in p.stderr
