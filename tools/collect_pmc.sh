@@ -12,7 +12,7 @@ for set in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_VALU_MF
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/bench_$i" -- $BENCH > "$OUT/bench_$i.log" 2>&1
 done
 python3 tools/pmc_summary.py "$OUT"/bench_* > "$OUT/r02_pmc_encoder.json"
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/emd_1" -- python3 tools/emd_attack_time.py > "$OUT/emd_1.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/emd_1" -- python3 tools/emd_attack_time.py 32 > "$OUT/emd_1.log" 2>&1
 python3 tools/pmc_summary.py "$OUT"/emd_1 > "$OUT/r02_pmc_emd.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- $BENCH > "$OUT/bench_stats.log" 2>&1
 cp "$OUT"/bench_stats/*/*_kernel_stats.csv "$OUT/r02_bench_kernel_stats.csv" 2>/dev/null

@@ -6,7 +6,8 @@ from geometric_adv_amd import weights as W, ops
 from geometric_adv_amd.adv_ae import AdvAE, Configuration
 from geometric_adv_amd.autoencoder import PointNetAE
 N = 2048
-for B, iters in ((8, 40), (32, 20), (128, 8)):
+CASES = {8: 40, 32: 20, 128: 8}
+for B, iters in ([(int(a), CASES.get(int(a), 10)) for a in sys.argv[1:]] or list(CASES.items())):
     rng = np.random.default_rng(B)
     x = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5); gt = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)
     w = W.synthetic_weights(N, seed=7); ae = PointNetAE(w, N)
