@@ -297,9 +297,13 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
 #pragma unroll
     for (int t = 1; t < CP; ++t)
         if (t < tiles && cpv[t] < v) { v = cpv[t]; bt = t; }   // strict: the lowest tile wins ties
-    for (int t = CP; t < tiles; ++t) {
-        const float w = colpart[(size_t)t * m + kc];
-        if (w < v) { v = w; bt = t; }
+    for (int t0 = CP; t0 < tiles; t0 += CP) {             // larger clouds: eight tile minima in flight per step (one load at a
+        float w[CP];                                      // time is a dependent chain of L2 round trips: 24 of them at n = 8192)
+#pragma unroll
+        for (int t = 0; t < CP; ++t) w[t] = colpart[(size_t)(t0 + t < tiles ? t0 + t : 0) * m + kc];
+#pragma unroll
+        for (int t = 0; t < CP; ++t)
+            if (t0 + t < tiles && w[t] < v) { v = w[t]; bt = t0 + t; }
     }
     const int q0 = bt * CS_ROWS;
     const int nrows = min(CS_ROWS, n - q0);
