@@ -787,8 +787,13 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
         at->chamfer_prune = e ? e[0] != '0' : cfg->all_pairs_source_dist == 0;
     }
     {
+        // Small batches (<= 16 K points in all: B <= 8 at N = 2048 -- what a GPU holds when ONE batch of 32 is split over 4 or
+        // 8): both Chamfer problems as the public op's four plain scans in ONE launch (20 us at B = 4) beat the symmetric
+        // scan + its finish launch + the grid search riding in the latent launch (16 + 11 + 2): every one of those is fixed
+        // latency there, not arithmetic.  From B = 16 on the symmetric form's halved arithmetic wins.  Same bits either way.
+        // GEOADV_CHAMFER_SYM = 0 / 1 forces one form (the A/B of tests/test_gpu_attack.py).
         const char *e = getenv("GEOADV_CHAMFER_SYM");
-        at->chamfer_sym = !(e && e[0] == '0');
+        at->chamfer_sym = e ? e[0] != '0' : (long)at->B * at->n > 16384;
     }
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;
     if (emd) { at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B); at->emd_g1 = F(4 * bn3); }

@@ -271,6 +271,8 @@ def test_odd_sizes_all_code_paths_agree():
     got = {}
     for name, env in [("default", {}), ("all-pairs source distance", {"GEOADV_CHAMFER_PRUNE": "0"}),
                       ("recomputing backward", {"GEOADV_BWD_MASKS": "0"}), ("two-scan Chamfer", {"GEOADV_CHAMFER_SYM": "0"}),
+                      ("symmetric Chamfer + grid search", {"GEOADV_CHAMFER_SYM": "1"}),
+                      ("symmetric Chamfer, all-pairs source distance", {"GEOADV_CHAMFER_SYM": "1", "GEOADV_CHAMFER_PRUNE": "0"}),
                       ("row-stationary forward", {"GEOADV_FWD_ROWS": "256"})]:
         o = subprocess.run([sys.executable, child] + sizes, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         lines = [ln for ln in o.stdout.splitlines() if ln.startswith("HASHES ")]
@@ -351,6 +353,7 @@ def test_pruned_source_distance_equals_all_pairs(setup, monkeypatch, lr, n):
     b = 3
     x, gt = _clouds(81, b, n)
     outs = []
+    monkeypatch.setenv("GEOADV_CHAMFER_SYM", "1")      # (batches this small default to the two-scan form, which has no grid search)
     for flag in ("1", "0"):
         monkeypatch.setenv("GEOADV_CHAMFER_PRUNE", flag)
         at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=12, num_iterations_thresh=3,
