@@ -40,7 +40,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_encoder.json")     # tools/pm
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep (profiles/r02_attack_sweep.json): ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- the honest
 # expectation for the strong-scaling leg (the latency floor of ten dependent launches does not shrink with the batch)
-R01_SWEEP_MS = {32: 0.1991, 16: 0.1505, 8: 0.1077, 4: 0.0894}
+SWEEP_MS = {32: 0.1991, 16: 0.1505, 8: 0.1077, 4: 0.0894}
 
 
 def parse_args():
@@ -452,11 +452,11 @@ def main():
             dt_s = median(dts_s)
             strong = {"value": K / dt_s, "ms_per_step": dt_s / K * 1e3, "windows_ms": [round(t * 1e3, 3) for t in dts_s]}
             del leg_s
-        exp = R01_SWEEP_MS.get(bs)
+        exp = SWEEP_MS.get(bs)
         strong.update({"definition": "attack iterations/s on ONE global batch of 32 clouds split contiguously over the ranks "
                                      "(SURVEY 8e); every rank runs the whole loop on its 32/N clouds, final scalars all-gathered",
                        "global_batch": B, "batch_per_gpu": bs,
-                       "expected_speedup_vs_1gpu_from_r01_sweep": (R01_SWEEP_MS[32] / exp) if exp else None,
+                       "expected_speedup_vs_1gpu_from_r01_sweep": (SWEEP_MS[32] / exp) if exp else None,
                        "expectation_note": "an iteration is ten dependent launches whose latency floor (0.085 ms at B = 1) does not "
                                            "shrink with the batch: the >= 6x target of the north star is a weak-scaling figure here"})
 
