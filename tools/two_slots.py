@@ -7,7 +7,7 @@ import numpy as np, torch
 from geometric_adv_amd import weights as W
 from geometric_adv_amd.adv_ae import AdvAE, Configuration
 from geometric_adv_amd.autoencoder import PointNetAE
-B, N, ITERS = 32, 2048, 400
+B, N, ITERS = int(os.environ.get("GEOADV_TOOL_B", "32")), 2048, 400
 w = W.synthetic_weights(N, seed=7)
 for slots in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
     ats, streams = [], []
@@ -31,5 +31,5 @@ for slots in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
     for t in th: t.join()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"slots": slots, "batch": B, "iterations_per_s_all_slots": slots * ITERS / dt, "ms_per_iteration_per_slot": dt / ITERS * 1e3}))
+    print(json.dumps({"slots": slots, "batch": B, "iterations_per_s_all_slots": slots * ITERS / dt, "cloud_iterations_per_s": slots * B * ITERS / dt, "ms_per_iteration_per_slot": dt / ITERS * 1e3}))
     del ats
