@@ -74,7 +74,8 @@ __device__ __forceinline__ float pair_d2(float px, float py, float pz, float ox,
 // reproducible run to run.  PASS 0 = A, 1 = B, 2 = C, 3 = C of level li and A of level li + 1 in one walk (one distance,
 // two weights: pass A of the next level reads nothing pass C writes for other points).
 // ------------------------------------------------------------------------------------------
-constexpr int SW_WAVES = 8, SW_THREADS = 64 * SW_WAVES, SW_OWN = 128, SW_TILE = 1024;
+constexpr int SW_WAVES = 8, SW_THREADS = 64 * SW_WAVES, SW_TILE = 1024;
+constexpr int SW_R = 2, SW_OWN = 64 * SW_R;   // own points per lane: 1 is 8 % slower (LDS reads per pair double), 4 the same (measured)
 
 template <int PASS>
 __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, int li, float c0, float c1, const float *xyz1,
@@ -93,14 +94,14 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
     const double *fac0 = PASS == 0 ? remR : (PASS == 1 ? fL : fR);      // PASS 3: C's factor fR_li ...
     const double *fac1 = remR;                                           // ... and A's factor remR
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float px[2], py[2], pz[2];
+    float px[SW_R], py[SW_R], pz[SW_R];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < SW_R; ++r) {
         int i = blockIdx.x * SW_OWN + r * 64 + lane;
         i = i < n_own ? i : n_own - 1;                       // (clamped lanes compute a valid point and are not stored)
         px[r] = own[3 * i]; py[r] = own[3 * i + 1]; pz[r] = own[3 * i + 2];
     }
-    double acc[NF][2] = {};
+    double acc[NF][SW_R] = {};
     for (int t0 = 0; t0 < n_oth; t0 += SW_TILE) {
         const int cnt = min(SW_TILE, n_oth - t0);
         __syncthreads();
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
             const double f0 = sf[0][e];
             const double f1 = NF == 2 ? sf[1][e] : 0.0;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < SW_R; ++r) {
                 const float d2 = pair_d2(px[r], py[r], pz[r], o.x, o.y, o.z);
                 acc[0][r] = fma((double)__builtin_amdgcn_exp2f(d2 * c0), f0, acc[0][r]);
                 if (NF == 2) acc[1][r] = fma((double)__builtin_amdgcn_exp2f(d2 * c1), f1, acc[1][r]);
@@ -127,7 +128,9 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
         }
     }
 #pragma unroll
-    for (int f = 0; f < NF; ++f) { part[f][wave][lane] = acc[f][0]; part[f][wave][64 + lane] = acc[f][1]; }
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < SW_R; ++r) part[f][wave][r * 64 + lane] = acc[f][r];
     __syncthreads();
     if (threadIdx.x >= SW_OWN) return;
     const int i = blockIdx.x * SW_OWN + threadIdx.x;
