@@ -37,7 +37,11 @@ def get_chamfer_nn(flags):
     point_clouds, slice_idx = load_data(data_path, files, ['point_clouds_test_set', 'slice_idx_test_set'])
     parts = [f for f in files if 'slice_idx_test_set' in f][0].split('_')[-3:]              # e.g. test_set_13l.npy (:58-59)
     n_all = len(point_clouds)
-    cur = get_chamfer_dist_mat_slice(point_clouds, flags.pc_start_idx, flags.pc_batch_size, flags.device)
+    if flags.pc_start_idx == 0 and flags.pc_batch_size >= n_all:        # the whole matrix at once: half the work (symmetry)
+        from .scorer import get_chamfer_dist_mat_full
+        cur = get_chamfer_dist_mat_full(point_clouds, flags.device)
+    else:
+        cur = get_chamfer_dist_mat_slice(point_clouds, flags.pc_start_idx, flags.pc_batch_size, flags.device)
     assert cur.min() >= 0, 'the chamfer_dist_mat_curr matrix was not filled correctly'
     mat_path = osp.join(data_path, '_'.join(['chamfer_dist_mat_complete'] + parts))
     mat = np.load(mat_path) if osp.exists(mat_path) else -1 * np.ones([n_all, n_all], dtype=np.float32)

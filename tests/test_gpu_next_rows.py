@@ -255,3 +255,16 @@ def test_train_checkpoint_attack_defend_pipeline(tmp_path):
     out = defense.defend_surface(ae, adv[0], src)
     assert out["defended_pc"].shape == (b, n, 3) and np.isfinite(out["defended_recon"]).all()
     assert np.isfinite(out["recon_error_vs_source"]).all()
+
+
+def test_full_chamfer_matrix_by_symmetry_equals_slices():
+    """scorer.get_chamfer_dist_mat_full (upper-triangular block pairs, mirrored) == the reference-shaped column slices, bit for
+    bit, for a set size that is not a multiple of the block; two 'ranks' sum to the same matrix."""
+    from geometric_adv_amd.scorer import get_chamfer_dist_mat_full, get_chamfer_dist_mat_slice
+    from conftest import cloud
+    pcs = cloud(23, 21, 192)
+    full = get_chamfer_dist_mat_full(pcs, block=8)
+    want = np.concatenate([get_chamfer_dist_mat_slice(pcs, s, 7) for s in range(0, 21, 7)], axis=1)
+    assert np.array_equal(full, want) and np.array_equal(full, full.T) and not np.diagonal(full).any()
+    parts = [get_chamfer_dist_mat_full(pcs, block=8, rank=r, world=2) for r in range(2)]
+    assert np.array_equal(parts[0] + parts[1], full)
