@@ -460,6 +460,11 @@ def main():
                        "expectation_note": "an iteration is ten dependent launches whose latency floor (0.085 ms at B = 1) does not "
                                            "shrink with the batch: the >= 6x target of the north star is a weak-scaling figure here"})
 
+    if world > 1:                                # every collective of the run is behind us: leave the group cleanly on all ranks
+        import torch.distributed as tdist
+        gdist.barrier()
+        if tdist.is_initialized():
+            tdist.destroy_process_group()
     if rank != 0:
         return
     at = leg.at
