@@ -269,11 +269,15 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradA
 // than the CPU op's sequential fp32 sum, from which it differs by normal fp32 rounding only).
 // The bit-exact-vs-CPU sorted form stays behind the public NnDistanceGrad op (chamfer.hip).
 constexpr double CG_FX = 17592186044416.0;          // 2^44
-constexpr int CG_FX_MAX_N = 5000;                   // 3 * 8 B * n <= 120 KB: the three coordinates in one pass
-constexpr int CG_FX_MAX_N_PLANE = 15000;            // larger clouds: one coordinate per pass, 8 B * n of LDS
-inline size_t cgrad_fx_lds_bytes(int n) { return sizeof(unsigned long long) * (n <= CG_FX_MAX_N ? 3 : 1) * (size_t)n; }
+constexpr int CG_FX_MAX_N = 5000;                   // 3 * 8 B * n <= 120 KB: one workgroup holds the accumulators of a whole cloud
+constexpr int CG_FX_MAX_N_PLANE = 15000;            // larger clouds: H = 2 or 3 workgroups per (cloud, problem), each owning a
+                                                    // contiguous range of the receiving points (config 4: n = 8192, H = 2)
+inline int cgrad_fx_parts(int n) { return (n + CG_FX_MAX_N - 1) / CG_FX_MAX_N; }
+inline int cgrad_fx_range(int n) { return (n + cgrad_fx_parts(n) - 1) / cgrad_fx_parts(n); }
+inline size_t cgrad_fx_lds_bytes(int n) { return sizeof(unsigned long long) * 3 * (size_t)cgrad_fx_range(n); }
 
-__device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, const int b) {
+// part h of H: this workgroup owns the receiving points [j_lo, j_hi); it scans ALL scatter sources and keeps those that land there
+__device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, const int b, const int h, const int H) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(lds);     // [n][3]
     const CGradProblem pr = a.pr[pi];
@@ -284,91 +288,76 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
     const float *p = pr.p + (size_t)b * n * 3, *q = pr.q + (size_t)b * n * 3;
     const int *i1 = pr.idx1 + (size_t)b * n, *i2 = pr.idx2 + (size_t)b * n;
     const int js = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
-    if (n <= CG_FX_MAX_N) {
-        for (int e = threadIdx.x; e < 3 * n; e += CGA_THREADS) acc[e] = 0ull;
-        __syncthreads();
-        // Four points per thread and pass, index loads first, then all the dependent gathers: the launch is latency-bound
-        // (one workgroup per cloud and problem), and a loop of "load index, gather, add" pays two global round trips per point.
-        constexpr int U = 4;
-        for (int k0 = threadIdx.x; k0 < n; k0 += U * CGA_THREADS) {
-            int jj[U];
+    const int range = (n + H - 1) / H;
+    const int j_lo = h * range, j_hi = min(n, j_lo + range);
+    for (int e = threadIdx.x; e < 3 * (j_hi - j_lo); e += CGA_THREADS) acc[e] = 0ull;
+    __syncthreads();
+    // Four points per thread and pass, index loads first, then all the dependent gathers: the launch is latency-bound
+    // (one workgroup per cloud, problem and part), and a loop of "load index, gather, add" pays two global round trips per point.
+    constexpr int U = 4;
+    for (int k0 = threadIdx.x; k0 < n; k0 += U * CGA_THREADS) {
+        int jj[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) jj[u] = k0 + u * CGA_THREADS < n ? i2[k0 + u * CGA_THREADS] : 0;   // other point k matched our point j
-            float qv[U][3], pv[U][3];
+        for (int u = 0; u < U; ++u) jj[u] = k0 + u * CGA_THREADS < n ? i2[k0 + u * CGA_THREADS] : -1;   // other point k matched our point j
+        float qv[U][3], pv[U][3];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + u * CGA_THREADS < n ? k0 + u * CGA_THREADS : 0;
+        for (int u = 0; u < U; ++u) {
+            const bool mine = jj[u] >= j_lo && jj[u] < j_hi;
+            const int k = mine ? k0 + u * CGA_THREADS : 0, j = mine ? jj[u] : 0;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { qv[u][c] = q[3 * k + c]; pv[u][c] = p[3 * jj[u] + c]; }
-            }
+            for (int c = 0; c < 3; ++c) { qv[u][c] = q[3 * k + c]; pv[u][c] = p[3 * j + c]; }
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k0 + u * CGA_THREADS >= n) continue;
+        for (int u = 0; u < U; ++u) {
+            if (jj[u] < j_lo || jj[u] >= j_hi) continue;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float t = g2 * (qv[u][c] - pv[u][c]);
-                    const long long f = __double2ll_rn((double)t * CG_FX);
-                    atomicAdd(&acc[3 * jj[u] + c], (unsigned long long)f);
-                }
+            for (int c = 0; c < 3; ++c) {
+                const float t = g2 * (qv[u][c] - pv[u][c]);
+                const long long f = __double2ll_rn((double)t * CG_FX);
+                atomicAdd(&acc[3 * (jj[u] - j_lo) + c], (unsigned long long)f);
             }
         }
-        __syncthreads();
-        for (int j0 = threadIdx.x; j0 < n; j0 += U * CGA_THREADS) {
-            int mj[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) mj[u] = j0 + u * CGA_THREADS < n ? i1[j0 + u * CGA_THREADS] : 0;
-            float qv[U][3], pv[U][3];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = j0 + u * CGA_THREADS < n ? j0 + u * CGA_THREADS : 0;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { pv[u][c] = p[3 * j + c]; qv[u][c] = q[3 * mj[u] + c]; }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = j0 + u * CGA_THREADS;
-                if (j >= n) continue;
-                const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float own = gown * (pv[u][c] - qv[u][c]);
-                    const float sc = (float)((double)(long long)acc[3 * j + c] * (1.0 / CG_FX));
-                    pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
-                }
-            }
-        }
-        return;
     }
-    // large clouds (config 5: n = 8192): the same sums one coordinate at a time, so that the accumulators still fit in LDS
-    for (int c = 0; c < 3; ++c) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < n; e += CGA_THREADS) acc[e] = 0ull;
-        __syncthreads();
-        for (int k = threadIdx.x; k < n; k += CGA_THREADS) {
-            const int j = i2[k];
-            const float t = g2 * (q[3 * k + c] - p[3 * j + c]);
-            atomicAdd(&acc[j], (unsigned long long)__double2ll_rn((double)t * CG_FX));
+    __syncthreads();
+    for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += U * CGA_THREADS) {
+        int mj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) mj[u] = j0 + u * CGA_THREADS < j_hi ? i1[j0 + u * CGA_THREADS] : 0;
+        float qv[U][3], pv[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * CGA_THREADS < j_hi ? j0 + u * CGA_THREADS : j_lo;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { pv[u][c] = p[3 * j + c]; qv[u][c] = q[3 * mj[u] + c]; }
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < n; j += CGA_THREADS) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * CGA_THREADS;
+            if (j >= j_hi) continue;
             const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
-            const float own = gown * (p[3 * j + c] - q[3 * i1[j] + c]);
-            const float sc = (float)((double)(long long)acc[j] * (1.0 / CG_FX));
-            pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float own = gown * (pv[u][c] - qv[u][c]);
+                const float sc = (float)((double)(long long)acc[3 * (j - j_lo) + c] * (1.0 / CG_FX));
+                pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGradArgs a) { cgrad_fx_body(a, blockIdx.y, blockIdx.x); }
+// grid = (clouds, problems * H)
+__global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGradArgs a, int H) {
+    cgrad_fx_body(a, blockIdx.y / H, blockIdx.x, blockIdx.y % H, H);
+}
 
 // The per-cloud losses and the Chamfer gradients read the same NN results and do not depend on each other (unless the
 // max-distance term is on: it needs the arg-max the loss pass finds), so one launch does both: grid = (clouds,
-// 1 + problems); row 0 = losses / metrics / keep-best (its four upper waves leave at once), rows 1.. = gradients.
-__global__ __launch_bounds__(CGA_THREADS) void loss_cgrad_kernel(LossArgs la, CGradArgs ca) {
+// 1 + problems * H); row 0 = losses / metrics / keep-best (its four upper waves leave at once), rows 1.. = gradients.
+__global__ __launch_bounds__(CGA_THREADS) void loss_cgrad_kernel(LossArgs la, CGradArgs ca, int H) {
     if (blockIdx.y == 0) {
         if (threadIdx.x < 256) loss_metrics_body(la, blockIdx.x, gridDim.x);
     } else {
-        cgrad_fx_body(ca, blockIdx.y - 1, blockIdx.x);
+        cgrad_fx_body(ca, (blockIdx.y - 1) / H, blockIdx.x, (blockIdx.y - 1) % H, H);
     }
 }
 
@@ -624,7 +613,8 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         at->cgrad_done = false;
         if (np && !max_term && n <= CG_FX_MAX_N_PLANE) {
             ca.n = n; ca.P = 0;
-            loss_cgrad_kernel<<<dim3(B, 1 + np), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(la, ca);
+            const int H = cgrad_fx_parts(n);
+            loss_cgrad_kernel<<<dim3(B, 1 + np * H), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(la, ca, H);
             at->cgrad_done = true;
         } else {
             loss_metrics_kernel<<<B, 256, 0, st>>>(la);
@@ -642,7 +632,8 @@ int launch_cgrad(const CGradProblem *pr, int np, int B, int n, hipStream_t st) {
     for (int i = 0; i < np; ++i) ca.pr[i] = pr[i];
     ca.n = n; ca.P = pow2_ge(n);
     if (n <= CG_FX_MAX_N_PLANE) {
-        chamfer_grad_attack_fx_kernel<<<dim3(B, np), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(ca);
+        const int H = cgrad_fx_parts(n);
+        chamfer_grad_attack_fx_kernel<<<dim3(B, np * H), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(ca, H);
         GA_LAUNCH_CHECK();
         return GEOADV_OK;
     }

@@ -33,6 +33,7 @@ struct ChamferPair {
 struct ChamferSymArgs {
     ChamferPair pr[2];
     int n, m, tiles, clouds, pairs, csplit;
+    int fin_reps;              // finish kernel: column sub-slices of CF_COLS a workgroup walks after staging the row cloud once
     int pair_base, q_clouds;   // q_clouds > 0: cloud c is the pair (P cloud (pair_base+c)/q_clouds, Q cloud (pair_base+c)%q_clouds)
     float *colpart;            // [pairs][clouds][tiles][m]
     float *rowpart_d;          // [pairs][clouds][csplit][n]   row minima per column slice
@@ -263,15 +264,17 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
     const float *Q = pr.q + (size_t)cq * m * 3;
     const float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * tiles) * m;
     // this thread's column: its tile minima and coordinates are REQUESTED before the row cloud is staged, so that the two
-    // global round trips overlap (the kernel is latency-bound: 256 workgroups, a few microseconds each)
+    // global round trips overlap (the kernel is latency-bound: 256 workgroups, a few microseconds each).  Large clouds
+    // (fin_reps > 1: staging the rows is ~100 KB per workgroup, one workgroup per CU) walk several column sub-slices per
+    // staging instead of paying it once per 256 columns.
     const int quarter = threadIdx.x & (CF_Q - 1);
-    const int k = blockIdx.x * CF_COLS + (threadIdx.x >> 2);
-    const int kc = k < m ? k : m - 1;                     // (whole 4-lane groups stay in the shuffles below)
     constexpr int CP = 8;                                 // tile minima fetched up front (n <= 2048); further tiles in a loop
+    int k = (blockIdx.x * a.fin_reps) * CF_COLS + (threadIdx.x >> 2);
+    int kc = k < m ? k : m - 1;                           // (whole 4-lane groups stay in the shuffles below)
     float cpv[CP];
 #pragma unroll
     for (int t = 0; t < CP; ++t) cpv[t] = colpart[(size_t)(t < tiles ? t : 0) * m + kc];
-    const float qx = Q[3 * (size_t)kc], qy = Q[3 * (size_t)kc + 1], qz = Q[3 * (size_t)kc + 2];
+    float qx = Q[3 * (size_t)kc], qy = Q[3 * (size_t)kc + 1], qz = Q[3 * (size_t)kc + 2];
     for (int e = threadIdx.x; e < tiles * CS_ROWS; e += CF_THREADS) {
         const int o = (e / CS_ROWS) * CF_SEG + (e % CS_ROWS);
         const int src = e < n ? e : n - 1;
@@ -292,48 +295,57 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
             pr.idx1[(size_t)c * n + j] = i;
         }
     }
-    float v = cpv[0];
-    int bt = 0;
+    for (int rep = 0; rep < a.fin_reps; ++rep) {
+        float v = cpv[0];
+        int bt = 0;
+    #pragma unroll
+        for (int t = 1; t < CP; ++t)
+            if (t < tiles && cpv[t] < v) { v = cpv[t]; bt = t; }   // strict: the lowest tile wins ties
+        for (int t0 = CP; t0 < tiles; t0 += CP) {             // larger clouds: eight tile minima in flight per step (one load at a
+            float w[CP];                                      // time is a dependent chain of L2 round trips: 24 of them at n = 8192)
+    #pragma unroll
+            for (int t = 0; t < CP; ++t) w[t] = colpart[(size_t)(t0 + t < tiles ? t0 + t : 0) * m + kc];
+    #pragma unroll
+            for (int t = 0; t < CP; ++t)
+                if (t0 + t < tiles && w[t] < v) { v = w[t]; bt = t0 + t; }
+        }
+        const int q0 = bt * CS_ROWS;
+        const int nrows = min(CS_ROWS, n - q0);
+        constexpr int SHARE = CS_ROWS / CF_Q;                 // rows per lane: [quarter * SHARE, +SHARE) of the tile
+        const float *sx = rx + bt * CF_SEG + quarter * SHARE, *sy = ry + bt * CF_SEG + quarter * SHARE, *sz = rz + bt * CF_SEG + quarter * SHARE;
+        const int lim = nrows - quarter * SHARE;              // rows of this share that exist (may be <= 0)
+        // descending, four rows per step (one ds_read_b128 per plane): the last hit kept is the lowest row.
+        // Rows beyond the cloud are padding (never equal to v unless they duplicate a real row, and a lower real row then
+        // wins anyway) -- they are masked explicitly all the same.
+        int found = INT_MAX;
+    #pragma unroll 4
+        for (int j4 = SHARE / 4 - 1; j4 >= 0; --j4) {
+            const float4 xa = *reinterpret_cast<const float4 *>(sx + 4 * j4);
+            const float4 ya = *reinterpret_cast<const float4 *>(sy + 4 * j4);
+            const float4 za = *reinterpret_cast<const float4 *>(sz + 4 * j4);
+            const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
+            const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
+            const int j = 4 * j4;
+            found = (d3 == v && j + 3 < lim) ? j + 3 : found;
+            found = (d2 == v && j + 2 < lim) ? j + 2 : found;
+            found = (d1 == v && j + 1 < lim) ? j + 1 : found;
+            found = (d0 == v && j < lim) ? j : found;
+        }
+        if (found != INT_MAX) found += quarter * SHARE;
+        found = min(found, __shfl_xor(found, 1));
+        found = min(found, __shfl_xor(found, 2));
+        if (found == INT_MAX) found = 0;                      // only if v is NaN-tainted (out of contract)
+        if (quarter == 0 && k < m) {
+            pr.dist2[(size_t)c * m + k] = v;
+            pr.idx2[(size_t)c * m + k] = q0 + found;
+        }
+        if (rep + 1 < a.fin_reps) {                       // next sub-slice: its tile minima and coordinates
+            k += CF_COLS;
+            kc = k < m ? k : m - 1;
 #pragma unroll
-    for (int t = 1; t < CP; ++t)
-        if (t < tiles && cpv[t] < v) { v = cpv[t]; bt = t; }   // strict: the lowest tile wins ties
-    for (int t0 = CP; t0 < tiles; t0 += CP) {             // larger clouds: eight tile minima in flight per step (one load at a
-        float w[CP];                                      // time is a dependent chain of L2 round trips: 24 of them at n = 8192)
-#pragma unroll
-        for (int t = 0; t < CP; ++t) w[t] = colpart[(size_t)(t0 + t < tiles ? t0 + t : 0) * m + kc];
-#pragma unroll
-        for (int t = 0; t < CP; ++t)
-            if (t0 + t < tiles && w[t] < v) { v = w[t]; bt = t0 + t; }
-    }
-    const int q0 = bt * CS_ROWS;
-    const int nrows = min(CS_ROWS, n - q0);
-    constexpr int SHARE = CS_ROWS / CF_Q;                 // rows per lane: [quarter * SHARE, +SHARE) of the tile
-    const float *sx = rx + bt * CF_SEG + quarter * SHARE, *sy = ry + bt * CF_SEG + quarter * SHARE, *sz = rz + bt * CF_SEG + quarter * SHARE;
-    const int lim = nrows - quarter * SHARE;              // rows of this share that exist (may be <= 0)
-    // descending, four rows per step (one ds_read_b128 per plane): the last hit kept is the lowest row.
-    // Rows beyond the cloud are padding (never equal to v unless they duplicate a real row, and a lower real row then
-    // wins anyway) -- they are masked explicitly all the same.
-    int found = INT_MAX;
-#pragma unroll 4
-    for (int j4 = SHARE / 4 - 1; j4 >= 0; --j4) {
-        const float4 xa = *reinterpret_cast<const float4 *>(sx + 4 * j4);
-        const float4 ya = *reinterpret_cast<const float4 *>(sy + 4 * j4);
-        const float4 za = *reinterpret_cast<const float4 *>(sz + 4 * j4);
-        const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
-        const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
-        const int j = 4 * j4;
-        found = (d3 == v && j + 3 < lim) ? j + 3 : found;
-        found = (d2 == v && j + 2 < lim) ? j + 2 : found;
-        found = (d1 == v && j + 1 < lim) ? j + 1 : found;
-        found = (d0 == v && j < lim) ? j : found;
-    }
-    if (found != INT_MAX) found += quarter * SHARE;
-    found = min(found, __shfl_xor(found, 1));
-    found = min(found, __shfl_xor(found, 2));
-    if (found == INT_MAX) found = 0;                      // only if v is NaN-tainted (out of contract)
-    if (quarter == 0 && k < m) {
-        pr.dist2[(size_t)c * m + k] = v;
-        pr.idx2[(size_t)c * m + k] = q0 + found;
+            for (int t = 0; t < CP; ++t) cpv[t] = colpart[(size_t)(t < tiles ? t : 0) * m + kc];
+            qx = Q[3 * (size_t)kc]; qy = Q[3 * (size_t)kc + 1]; qz = Q[3 * (size_t)kc + 2];
+        }
     }
 }
 
@@ -378,7 +390,8 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     GA_LAUNCH_CHECK();
     const size_t lds = sizeof(float) * 3 * (size_t)a.tiles * CF_SEG;
     GA_REQUIRE(lds <= 150 * 1024, "chamfer_sym: too many rows (%d)", n);
-    chamfer_sym_finish_kernel<<<dim3(cdiv(m, CF_COLS), b * np), CF_THREADS, lds, stream>>>(a);
+    a.fin_reps = a.tiles > 8 ? (a.tiles >= 32 ? 4 : 2) : 1;
+    chamfer_sym_finish_kernel<<<dim3(cdiv(m, CF_COLS * a.fin_reps), b * np), CF_THREADS, lds, stream>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
