@@ -589,7 +589,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     }
     if (at->emd_temp) {   // approx_match is NoGradient (tf_approxmatch.py:19): the plan is recomputed every forward; the loop
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);   // needs only its cost and d cost / d recon, so the plan itself is never stored
-        if (int rc = geoadv_emd_cost_grad1(B, n, n, at->recon, at->gt, at->emd_cost, at->emd_g1, at->emd_temp, st)) return rc;
+        if (int rc = geoadv_emd_cost_grad1_mode(at->cfg.emd_weight_mode, B, n, n, at->recon, at->gt, at->emd_cost, at->emd_g1, at->emd_temp, st)) return rc;
     }
     {
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
@@ -719,6 +719,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     GA_REQUIRE(cfg->loss_dist_type == GEOADV_LOSS_DIST_CHAMFER || cfg->loss_dist_type == GEOADV_LOSS_DIST_PERT,
                "attack_create: unknown loss_dist_type %d", cfg->loss_dist_type);
     GA_REQUIRE(cfg->emd_weight >= 0.f, "attack_create: emd_weight must be >= 0");
+    GA_REQUIRE(cfg->emd_weight_mode == GEOADV_EMD_FAST || cfg->emd_weight_mode == GEOADV_EMD_REFERENCE,
+               "attack_create: unknown emd_weight_mode %d", cfg->emd_weight_mode);
     GA_REQUIRE(cfg->emd_weight == 0.f || cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER,
                "attack_create: emd_weight needs the output-space attack (loss_adv_type chamfer)");
     geoadv_attack *at = new geoadv_attack();

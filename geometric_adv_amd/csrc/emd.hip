@@ -28,9 +28,18 @@
 // sum, turns into a 10 % error of such a residual and then into a 1e-3 error of a plan entry two levels later (measured on
 // golden cloud a[1]; reproduced in numpy).  What it IS forgiving about is the weight itself, as long as passes A, B, C and
 // the plan use the SAME value: w appears in numerator and denominator of every normalisation, so a relative error of w
-// (here <= ~1e-6: fp32 distance, v_exp argument) perturbs the plan by the same order only.  Hence: one pair_d2() for every
+// (here <= ~1e-6: fp32 distance, v_exp argument) perturbs the plan by the same order only.  Hence: one PairWeight::d2() for every
 // kernel (bit-identical w everywhere), fp64 for the rest.  Tests hold match to rtol 2e-5 / atol 2e-6 of the reference CPU
 // goldens (tests/test_gpu_emd.py); measured worst case 7e-7 absolute.
+// On big clouds the fp32 weight shows: a handful of plan entries per million sit up to ~1e-4 relative from the CPU op (the
+// statistical bound in tests/test_gpu_emd.py).  GEOADV_EMD_REFERENCE (the *_mode entry points) removes that: the weight's
+// ARGUMENT is then the CPU op's own bits -- double coordinates, double distance without FMA, level * d2 in double, rounded
+// to float where the CPU calls expf (:41-46) -- and the exponential is glibc's expf algorithm evaluated in fp64 (a 1.5-ulp
+// exponential was measured NOT to be enough: one entry of 8.4 M at n = 4096 still moved by 1.1e-4 relative), so the weights
+// are the CPU op's bit for bit, and the plan's level terms are formed and added in double like the CPU's `match += weight`.
+// What remains is the order of the fp64 sums: plans within ~2 float ulps of the CPU op on EVERY entry at every size tested
+// (2.0e-7 relative worst over 13 M entries; 40-80 % bit-equal).  3.7x the time of the fast mode (4.6 ms per approx_match
+// at B = 32 x 2048^2, round 1's speed).  The attack loop defaults to the fast mode.
 // Level j = -2 has level 0, i.e. w = 1 for every pair: its three sweeps are O(n + m) reductions, not O(n m) walks.
 #include "common.h"
 #include <math.h>
@@ -46,7 +55,63 @@ static inline double emd_level(int li) {        // li = 0..10  <->  j = 8..-2
     const int j = 8 - li;
     return j == -2 ? 0.0 : -(double)powf(4.0f, (float)j);     // level = -powf(4.0, j) (:33-35)
 }
-static inline float emd_level_log2e(int li) { return (float)(emd_level(li) * 1.4426950408889634); }
+
+// The pair weight exp(level * |p - o|^2) in its two modes.  C: coordinate / distance type; L: what a level is passed as.
+template <bool REF> struct PairWeight;
+template <> struct PairWeight<false> {                     // fast: fp32 distance with FMAs, one v_exp_f32 of d2 * (level * log2 e)
+    using C = float;
+    using L = float;
+    using F = float;                                       // the plan's factors: fp32 products, `match += weight` by fmaf
+    static L level(int li) { return (float)(emd_level(li) * 1.4426950408889634); }
+    // the ONE form every kernel uses (sign-symmetric: the same bits whichever cloud is "own")
+    static __device__ __forceinline__ float d2(float px, float py, float pz, float ox, float oy, float oz) {
+        const float dx = px - ox, dy = py - oy, dz = pz - oz;
+        return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    }
+    static __device__ __forceinline__ float w(float d2, float c, const unsigned long long *) { return __builtin_amdgcn_exp2f(d2 * c); }
+};
+// expf as glibc >= 2.27 evaluates it (sysdeps/ieee754/flt-32/e_expf.c: the ARM optimized-routines algorithm): in double,
+// x * 32 / ln 2 = k + r, 2^(k/32) from a 32-entry table, a cubic in r, one rounding to float.  Restated from the published
+// algorithm with its constants; tests/test_expf_table.py checks the table against 2^(i/32) and, without a GPU, this very
+// sequence of double operations bit for bit against the host libm (220 000 arguments incl. the denormal range).
+// EXPF_TAB[i] = bits(2^(i/32)) - (i << 47), so that adding k << 47 yields bits(2^(k/32)).
+__device__ const unsigned long long EXPF_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+template <> struct PairWeight<true> {                      // reference: the CPU op's argument bits and glibc's expf
+    using C = double;
+    using L = double;
+    using F = double;                                      // the plan's level terms in double, added into the float like the CPU's (:75-76)
+    static L level(int li) { return emd_level(li); }
+    static __device__ __forceinline__ double d2(double px, double py, double pz, double ox, double oy, double oz) {
+        const double dx = px - ox, dy = py - oy, dz = pz - oz;
+        return (dx * dx + dy * dy) + dz * dz;              // (:46), no contraction in this file
+    }
+    static __device__ __forceinline__ float w(double d2, double level, const unsigned long long *tab) {
+        const float a = (float)(level * d2);               // expf's argument, rounded like the CPU's call; a <= 0
+        constexpr double INV_LN2_N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p52;
+        constexpr double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+        const double z = INV_LN2_N * (double)a;
+        double kd = z + SHIFT;
+        const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+        kd -= SHIFT;
+        const double r = z - kd;
+        const double s = __longlong_as_double((long long)(tab[ki & 31] + (ki << 47)));
+        const double p = C0 * r + C1;
+        const double r2 = r * r;
+        double y = C2 * r + 1.0;
+        y = p * r2 + y;
+        y = y * s;
+        return a < -0x1.9fe368p6f ? 0.f : (float)y;        // glibc's underflow cut; below it the table arithmetic is meaningless
+    }
+};
 
 // temp layout per cloud (doubles): remL[n] remR[m] then per level: fL[n] fR[m]
 __host__ __device__ inline size_t emd_temp_doubles_per_cloud(int n, int m) { return (size_t)(n + m) * (1 + EMD_LEVELS); }
@@ -60,12 +125,6 @@ __global__ void emd_init_kernel(int n, int m, double *temp) {
     else if (i < n + m) t[i] = (double)(big / m);            // factorr (:26)
 }
 
-// |p - o|^2 in fp32, the ONE form every kernel uses for a pair weight (sign-symmetric: the same bits whichever cloud is "own")
-__device__ __forceinline__ float pair_d2(float px, float py, float pz, float ox, float oy, float oz) {
-    const float dx = px - ox, dy = py - oy, dz = pz - oz;
-    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-}
-
 // ------------------------------------------------------------------------------------------
 // One level sweep.  A workgroup = 8 waves owns 128 "own" points (two per lane, the same in every wave); the "other" cloud
 // is staged through LDS 1024 points at a time (coordinates fp32, factors fp64) and each wave walks one eighth of every tile, so a
@@ -77,13 +136,19 @@ __device__ __forceinline__ float pair_d2(float px, float py, float pz, float ox,
 constexpr int SW_WAVES = 8, SW_THREADS = 64 * SW_WAVES, SW_TILE = 1024;
 constexpr int SW_R = 2, SW_OWN = 64 * SW_R;   // own points per lane: 1 is 8 % slower (LDS reads per pair double), 4 the same (measured)
 
-template <int PASS>
-__global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, int li, float c0, float c1, const float *xyz1,
+template <int PASS, bool REF>
+__global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, int li, typename PairWeight<REF>::L c0,
+                                                                 typename PairWeight<REF>::L c1, const float *xyz1,
                                                                  const float *xyz2, double *temp) {
+    using PW = PairWeight<REF>;
+    using C = typename PW::C;
+    struct alignas(16) Pt { C x, y, z, pad; };
     constexpr int NF = PASS == 3 ? 2 : 1;
-    __shared__ float4 st[SW_TILE];                          // x, y, z of the other cloud's points
+    __shared__ Pt st[SW_TILE];                              // x, y, z of the other cloud's points
     __shared__ double sf[NF][SW_TILE];                      // their factors, fp64 (see the note on consistency above)
     __shared__ double part[NF][SW_WAVES][SW_OWN];
+    __shared__ unsigned long long etab[REF ? 32 : 1];
+    if (REF && threadIdx.x < 32) etab[threadIdx.x] = EXPF_TAB[threadIdx.x];       // (the tile loop's barrier orders it)
     const int c = blockIdx.y;
     double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
     double *remL = t, *remR = t + n, *fL = t + (size_t)(n + m) * (1 + li), *fR = fL + n, *fL_next = fL + (n + m);
@@ -94,7 +159,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
     const double *fac0 = PASS == 0 ? remR : (PASS == 1 ? fL : fR);      // PASS 3: C's factor fR_li ...
     const double *fac1 = remR;                                           // ... and A's factor remR
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float px[SW_R], py[SW_R], pz[SW_R];
+    C px[SW_R], py[SW_R], pz[SW_R];
 #pragma unroll
     for (int r = 0; r < SW_R; ++r) {
         int i = blockIdx.x * SW_OWN + r * 64 + lane;
@@ -107,7 +172,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
         __syncthreads();
         for (int e = threadIdx.x; e < cnt; e += SW_THREADS) {
             const float *q = oth + 3 * (size_t)(t0 + e);
-            st[e] = make_float4(q[0], q[1], q[2], 0.f);
+            st[e] = Pt{(C)q[0], (C)q[1], (C)q[2], (C)0};
             sf[0][e] = fac0[t0 + e];
             if (NF == 2) sf[1][e] = fac1[t0 + e];
         }
@@ -116,14 +181,14 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
         const int lo = wave * per, hi = min(cnt, lo + per);
 #pragma unroll 4
         for (int e = lo; e < hi; ++e) {
-            const float4 o = st[e];
+            const Pt o = st[e];
             const double f0 = sf[0][e];
             const double f1 = NF == 2 ? sf[1][e] : 0.0;
 #pragma unroll
             for (int r = 0; r < SW_R; ++r) {
-                const float d2 = pair_d2(px[r], py[r], pz[r], o.x, o.y, o.z);
-                acc[0][r] = fma((double)__builtin_amdgcn_exp2f(d2 * c0), f0, acc[0][r]);
-                if (NF == 2) acc[1][r] = fma((double)__builtin_amdgcn_exp2f(d2 * c1), f1, acc[1][r]);
+                const C d2 = PW::d2(px[r], py[r], pz[r], o.x, o.y, o.z);
+                acc[0][r] = fma((double)PW::w(d2, c0, etab), f0, acc[0][r]);
+                if (NF == 2) acc[1][r] = fma((double)PW::w(d2, c1, etab), f1, acc[1][r]);
             }
         }
     }
@@ -199,23 +264,38 @@ __global__ __launch_bounds__(1024) void emd_level0_kernel(int n, int m, int li, 
     }
 }
 
-struct EmdLevels { float c[EMD_LEVELS]; };      // level * log2(e); c[10] = 0
+template <bool REF> struct EmdLevels { typename PairWeight<REF>::L c[EMD_LEVELS]; };      // fast: level * log2(e); c[10] = 0
 
 // match value of one pair from its squared distance: sum over the levels of exp2(c_j d2) * fR_j[l] * fL_j[k], accumulated
 // level by level in float like the CPU's `match[k] += weight[k]` (:75-76).  fr: LDS row of the 11 column factors.
-__device__ __forceinline__ float plan_value(const EmdLevels &lv, float d2, const float (&fl)[EMD_LEVELS], const float *fr, int stride) {
+template <bool REF>
+__device__ __forceinline__ float plan_value(const EmdLevels<REF> &lv, typename PairWeight<REF>::C d2,
+                                            const typename PairWeight<REF>::F (&fl)[EMD_LEVELS], const typename PairWeight<REF>::F *fr,
+                                            int stride, const unsigned long long *etab) {
     float mf = 0.f;
+    if (REF) {
 #pragma unroll
-    for (int j = 0; j < EMD_LEVELS - 1; ++j) mf = fmaf(__builtin_amdgcn_exp2f(d2 * lv.c[j]) * fr[j * stride], fl[j], mf);
+        for (int j = 0; j < EMD_LEVELS - 1; ++j)
+            mf = (float)((double)mf + ((double)PairWeight<REF>::w(d2, lv.c[j], etab) * fl[j]) * fr[j * stride]);
+        return (float)((double)mf + (double)fl[EMD_LEVELS - 1] * fr[(EMD_LEVELS - 1) * stride]);
+    }
+#pragma unroll
+    for (int j = 0; j < EMD_LEVELS - 1; ++j) mf = fmaf(PairWeight<REF>::w(d2, lv.c[j], etab) * fr[j * stride], fl[j], mf);
     return fmaf(fr[(EMD_LEVELS - 1) * stride], fl[EMD_LEVELS - 1], mf);      // level 0: w = 1
 }
 
 // match[c][l][k] for the public op.  grid = (n/256, m/32, b): thread = one k, 32 l's.
 constexpr int EMD_LT = 32;
-__global__ __launch_bounds__(256) void emd_match_kernel(int n, int m, EmdLevels lv, const float *xyz1, const float *xyz2,
+template <bool REF>
+__global__ __launch_bounds__(256) void emd_match_kernel(int n, int m, EmdLevels<REF> lv, const float *xyz1, const float *xyz2,
                                                         const double *temp, float *match) {
-    __shared__ float qx[EMD_LT], qy[EMD_LT], qz[EMD_LT];
-    __shared__ float fr[EMD_LEVELS][EMD_LT];
+    using PW = PairWeight<REF>;
+    using C = typename PW::C;
+    using F = typename PW::F;
+    __shared__ C qx[EMD_LT], qy[EMD_LT], qz[EMD_LT];
+    __shared__ F fr[EMD_LEVELS][EMD_LT];
+    __shared__ unsigned long long etab[REF ? 32 : 1];
+    if (REF && threadIdx.x < 32) etab[threadIdx.x] = EXPF_TAB[threadIdx.x];
     const int c = blockIdx.z;
     const double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
     const int l0 = blockIdx.y * EMD_LT;
@@ -223,18 +303,18 @@ __global__ __launch_bounds__(256) void emd_match_kernel(int n, int m, EmdLevels 
     for (int e = threadIdx.x; e < lcnt * (3 + EMD_LEVELS); e += 256) {
         const int l = e % lcnt, what = e / lcnt;
         if (what < 3) (what == 0 ? qx : what == 1 ? qy : qz)[l] = xyz2[((size_t)c * m + l0 + l) * 3 + what];
-        else fr[what - 3][l] = (float)t[(size_t)(n + m) * (1 + (what - 3)) + n + l0 + l];
+        else fr[what - 3][l] = (F)t[(size_t)(n + m) * (1 + (what - 3)) + n + l0 + l];
     }
     __syncthreads();
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const float *p = xyz1 + ((size_t)c * n + k) * 3;
-    const float px = p[0], py = p[1], pz = p[2];
-    float fl[EMD_LEVELS];
+    const C px = p[0], py = p[1], pz = p[2];
+    F fl[EMD_LEVELS];
 #pragma unroll
-    for (int j = 0; j < EMD_LEVELS; ++j) fl[j] = (float)t[(size_t)(n + m) * (1 + j) + k];
+    for (int j = 0; j < EMD_LEVELS; ++j) fl[j] = (F)t[(size_t)(n + m) * (1 + j) + k];
     for (int l = 0; l < lcnt; ++l) {
-        match[((size_t)c * m + l0 + l) * n + k] = plan_value(lv, pair_d2(px, py, pz, qx[l], qy[l], qz[l]), fl, &fr[0][l], EMD_LT);
+        match[((size_t)c * m + l0 + l) * n + k] = plan_value<REF>(lv, PW::d2(px, py, pz, qx[l], qy[l], qz[l]), fl, &fr[0][l], EMD_LT, etab);
     }
 }
 
@@ -244,13 +324,19 @@ __global__ __launch_bounds__(256) void emd_match_kernel(int n, int m, EmdLevels 
 // and never written: 4 n m bytes per cloud (537 MB at B = 32) neither stored nor re-read twice.  Same pair arithmetic as
 // matchcost_cpu / matchcostgrad_cpu (:85-133): float distance, sqrtf, max(d, 1e-20).  Workgroup = 8 waves x 64 points k;
 // each wave walks one eighth of the other cloud; partials folded in wave order.
-constexpr int PL_TILE = 1024;
-__global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int n, int m, EmdLevels lv, const float *xyz1, const float *xyz2,
+template <bool REF> constexpr int PL_TILE = REF ? 512 : 1024;      // (double factors: the same LDS either way)
+template <bool REF>
+__global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int n, int m, EmdLevels<REF> lv, const float *xyz1, const float *xyz2,
                                                                            const double *temp, double *cost_partial, float *grad1) {
-    __shared__ float qx[PL_TILE], qy[PL_TILE], qz[PL_TILE];
-    __shared__ float fr[EMD_LEVELS][PL_TILE];
+    using PW = PairWeight<REF>;
+    using F = typename PW::F;
+    constexpr int TILE = PL_TILE<REF>;
+    __shared__ float qx[TILE], qy[TILE], qz[TILE];
+    __shared__ F fr[EMD_LEVELS][TILE];
     __shared__ float gpart[SW_WAVES][3][64];
     __shared__ double cpart[SW_WAVES];
+    __shared__ unsigned long long etab[REF ? 32 : 1];
+    if (REF && threadIdx.x < 32) etab[threadIdx.x] = EXPF_TAB[threadIdx.x];
     const int c = blockIdx.y;
     const double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -259,13 +345,13 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int 
     k = live ? k : n - 1;
     const float *p = xyz1 + ((size_t)c * n + k) * 3;
     const float px = p[0], py = p[1], pz = p[2];
-    float fl[EMD_LEVELS];
+    F fl[EMD_LEVELS];
 #pragma unroll
-    for (int j = 0; j < EMD_LEVELS; ++j) fl[j] = (float)t[(size_t)(n + m) * (1 + j) + k];
+    for (int j = 0; j < EMD_LEVELS; ++j) fl[j] = (F)t[(size_t)(n + m) * (1 + j) + k];
     float gx = 0.f, gy = 0.f, gz = 0.f;
     double cost = 0.0;
-    for (int t0 = 0; t0 < m; t0 += PL_TILE) {
-        const int cnt = min(PL_TILE, m - t0);
+    for (int t0 = 0; t0 < m; t0 += TILE) {
+        const int cnt = min(TILE, m - t0);
         __syncthreads();
         for (int e = threadIdx.x; e < cnt; e += SW_THREADS) {
             const float *q = xyz2 + ((size_t)c * m + t0 + e) * 3;
@@ -273,7 +359,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int 
         }
         for (int e = threadIdx.x; e < cnt * EMD_LEVELS; e += SW_THREADS) {
             const int j = e / cnt, l = e % cnt;
-            fr[j][l] = (float)t[(size_t)(n + m) * (1 + j) + n + t0 + l];
+            fr[j][l] = (F)t[(size_t)(n + m) * (1 + j) + n + t0 + l];
         }
         __syncthreads();
         const int per = (cnt + SW_WAVES - 1) / SW_WAVES;
@@ -281,7 +367,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int 
         float cs = 0.f;
         for (int l = lo; l < hi; ++l) {
             const float ox = qx[l] - px, oy = qy[l] - py, oz = qz[l] - pz;          // q - p, like the CPU loops
-            const float w = plan_value(lv, pair_d2(px, py, pz, qx[l], qy[l], qz[l]), fl, &fr[0][l], PL_TILE);
+            const float w = plan_value<REF>(lv, PW::d2(px, py, pz, qx[l], qy[l], qz[l]), fl, &fr[0][l], TILE, etab);
             const float d = sqrtf(ox * ox + oy * oy + oz * oz);                     // matchcost_cpu's own float distance (:93-96)
             cs += d * w;                                                            // (:97-99) float product, summed below in double
             const float inv = 1.0f / fmaxf(d, 1e-20f);
@@ -435,18 +521,19 @@ static int emd_check(const char *op, int b, int n, int m) {
 }
 
 // the eleven levels: capacities and factors into temp (fp64), no plan yet
-static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, double *t, EmdLevels &lv, hipStream_t st) {
+template <bool REF>
+static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, double *t, EmdLevels<REF> &lv, hipStream_t st) {
     emd_init_kernel<<<dim3(cdiv(n + m, 256), b), 256, 0, st>>>(n, m, t);
     GA_LAUNCH_CHECK();
-    for (int li = 0; li < EMD_LEVELS; ++li) lv.c[li] = emd_level_log2e(li);
+    for (int li = 0; li < EMD_LEVELS; ++li) lv.c[li] = PairWeight<REF>::level(li);
     const dim3 g1(cdiv(n, SW_OWN), b), g2(cdiv(m, SW_OWN), b);
-    emd_sweep_kernel<0><<<g1, SW_THREADS, 0, st>>>(n, m, 0, lv.c[0], 0.f, xyz1, xyz2, t);
+    emd_sweep_kernel<0, REF><<<g1, SW_THREADS, 0, st>>>(n, m, 0, lv.c[0], 0, xyz1, xyz2, t);
     for (int li = 0; li < EMD_LEVELS - 1; ++li) {
-        emd_sweep_kernel<1><<<g2, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0.f, xyz1, xyz2, t);
+        emd_sweep_kernel<1, REF><<<g2, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0, xyz1, xyz2, t);
         if (li + 2 < EMD_LEVELS)                       // pass C of this level with pass A of the next
-            emd_sweep_kernel<3><<<g1, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], lv.c[li + 1], xyz1, xyz2, t);
+            emd_sweep_kernel<3, REF><<<g1, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], lv.c[li + 1], xyz1, xyz2, t);
         else                                           // the next level is the weightless one: it forms its own fL
-            emd_sweep_kernel<2><<<g1, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0.f, xyz1, xyz2, t);
+            emd_sweep_kernel<2, REF><<<g1, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0, xyz1, xyz2, t);
         GA_LAUNCH_CHECK();
     }
     emd_level0_kernel<<<b, 1024, 0, st>>>(n, m, EMD_LEVELS - 1, t);
@@ -454,18 +541,35 @@ static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *x
     return GEOADV_OK;
 }
 
-extern "C" int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
-                                   void *stream) {
+static int emd_mode_check(const char *op, int mode) {
+    GA_REQUIRE(mode == GEOADV_EMD_FAST || mode == GEOADV_EMD_REFERENCE, "%s: unknown weight mode %d", op, mode);
+    return GEOADV_OK;
+}
+
+template <bool REF>
+static int approx_match_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, double *t, hipStream_t st) {
+    EmdLevels<REF> lv;
+    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, lv, st)) return rc;
+    emd_match_kernel<REF><<<dim3(cdiv(n, 256), cdiv(m, EMD_LT), b), 256, 0, st>>>(n, m, lv, xyz1, xyz2, t, match);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_approx_match_mode(int mode, int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                                        float *temp, void *stream) {
+    if (int rc = emd_mode_check("approx_match", mode)) return rc;
     if (int rc = emd_check("approx_match", b, n, m)) return rc;
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && match && temp, "approx_match: null pointer");
     hipStream_t st = as_stream(stream);
     double *t = reinterpret_cast<double *>((reinterpret_cast<size_t>(temp) + 7) & ~(size_t)7);
-    EmdLevels lv;
-    if (int rc = emd_run_levels(b, n, m, xyz1, xyz2, t, lv, st)) return rc;
-    emd_match_kernel<<<dim3(cdiv(n, 256), cdiv(m, EMD_LT), b), 256, 0, st>>>(n, m, lv, xyz1, xyz2, t, match);
-    GA_LAUNCH_CHECK();
-    return GEOADV_OK;
+    return mode == GEOADV_EMD_REFERENCE ? approx_match_impl<true>(b, n, m, xyz1, xyz2, match, t, st)
+                                        : approx_match_impl<false>(b, n, m, xyz1, xyz2, match, t, st);
+}
+
+extern "C" int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                                   void *stream) {
+    return geoadv_approx_match_mode(GEOADV_EMD_FAST, b, n, m, xyz1, xyz2, match, temp, stream);
 }
 
 extern "C" size_t geoadv_emd_cost_grad1_temp_floats(int b, int n, int m) {
@@ -473,22 +577,35 @@ extern "C" size_t geoadv_emd_cost_grad1_temp_floats(int b, int n, int m) {
     return geoadv_approx_match_temp_floats(b, n, m) + 2 * (size_t)b * cdiv(n, 64) + 16;
 }
 
-extern "C" int geoadv_emd_cost_grad1(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
-                                     float *temp, void *stream) {
+template <bool REF>
+static int emd_cost_grad1_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, double *t,
+                               hipStream_t st) {
+    double *partial = t + (size_t)b * emd_temp_doubles_per_cloud(n, m);
+    EmdLevels<REF> lv;
+    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, lv, st)) return rc;
+    const int parts = cdiv(n, 64);
+    emd_plan_cost_grad1_kernel<REF><<<dim3(parts, b), SW_THREADS, 0, st>>>(n, m, lv, xyz1, xyz2, t, partial, grad1);
+    GA_LAUNCH_CHECK();
+    emd_cost_fold_kernel<<<b, 256, 0, st>>>(parts, partial, cost);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_emd_cost_grad1_mode(int mode, int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
+                                          float *grad1, float *temp, void *stream) {
+    if (int rc = emd_mode_check("emd_cost_grad1", mode)) return rc;
     if (int rc = emd_check("emd_cost_grad1", b, n, m)) return rc;
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && cost && grad1 && temp, "emd_cost_grad1: null pointer");
     hipStream_t st = as_stream(stream);
     double *t = reinterpret_cast<double *>((reinterpret_cast<size_t>(temp) + 7) & ~(size_t)7);
-    double *partial = t + (size_t)b * emd_temp_doubles_per_cloud(n, m);
-    EmdLevels lv;
-    if (int rc = emd_run_levels(b, n, m, xyz1, xyz2, t, lv, st)) return rc;
-    const int parts = cdiv(n, 64);
-    emd_plan_cost_grad1_kernel<<<dim3(parts, b), SW_THREADS, 0, st>>>(n, m, lv, xyz1, xyz2, t, partial, grad1);
-    GA_LAUNCH_CHECK();
-    emd_cost_fold_kernel<<<b, 256, 0, st>>>(parts, partial, cost);
-    GA_LAUNCH_CHECK();
-    return GEOADV_OK;
+    return mode == GEOADV_EMD_REFERENCE ? emd_cost_grad1_impl<true>(b, n, m, xyz1, xyz2, cost, grad1, t, st)
+                                        : emd_cost_grad1_impl<false>(b, n, m, xyz1, xyz2, cost, grad1, t, st);
+}
+
+extern "C" int geoadv_emd_cost_grad1(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
+                                     float *temp, void *stream) {
+    return geoadv_emd_cost_grad1_mode(GEOADV_EMD_FAST, b, n, m, xyz1, xyz2, cost, grad1, temp, stream);
 }
 
 extern "C" int geoadv_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *out,

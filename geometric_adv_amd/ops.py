@@ -243,10 +243,15 @@ def knn_dists(pc, num_knn):
 # ---------------------------------------------------------------------------------------------
 # external/structural_losses/tf_approxmatch.py
 # ---------------------------------------------------------------------------------------------
-def approx_match(xyz1, xyz2):
+EMD_FAST, EMD_REFERENCE = 0, 1          # include/geoadv.h: how the pair weight expf(level * d2) is evaluated
+
+
+def approx_match(xyz1, xyz2, reference_weights=False):
     """tf_approxmatch.py:10-18.  xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n): match[b,l,k] is the
     soft assignment between xyz2 point l and xyz1 point k (the reference GPU op's layout; the CPU
-    op writes the transpose into the same declared shape).  Level schedule of the CPU op."""
+    op writes the transpose into the same declared shape).  Level schedule of the CPU op.
+    reference_weights: every pair weight bit for bit the CPU op's (GEOADV_EMD_REFERENCE: every plan entry within ~2 float
+    ulps of the CPU op, ~3.7x the time) instead of the fp32 fast form (typically 1e-6, rare entries 1e-4 relative)."""
     xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "ApproxMatch")
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
@@ -254,7 +259,8 @@ def approx_match(xyz1, xyz2):
     with torch.cuda.device(xyz1.device):
         nf = _lib.lib().geoadv_approx_match_temp_floats(b, n, m)
         temp = torch.empty(int(nf), dtype=torch.float32, device=xyz1.device)
-        _call("geoadv_approx_match", b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(temp))
+        _call("geoadv_approx_match_mode", EMD_REFERENCE if reference_weights else EMD_FAST, b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2),
+              _lib.ptr(match), _lib.ptr(temp))
     return match
 
 
@@ -288,7 +294,7 @@ def match_cost_grad(xyz1, xyz2, match):
     return g1, g2
 
 
-def emd_cost_grad1(xyz1, xyz2):
+def emd_cost_grad1(xyz1, xyz2, reference_weights=False):
     """match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) and its gradient w.r.t. xyz1 with the plan held constant, without
     materialising the (b,m,n) plan -- the fused form the attack loop uses.  -> (cost (b,), grad1 (b,n,3))."""
     xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "ApproxMatch")
@@ -299,7 +305,8 @@ def emd_cost_grad1(xyz1, xyz2):
     with torch.cuda.device(xyz1.device):
         nf = _lib.lib().geoadv_emd_cost_grad1_temp_floats(b, n, m)
         temp = torch.empty(int(nf), dtype=torch.float32, device=xyz1.device)
-        _call("geoadv_emd_cost_grad1", b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(temp))
+        _call("geoadv_emd_cost_grad1_mode", EMD_REFERENCE if reference_weights else EMD_FAST, b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2),
+              _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(temp))
     return cost, g1
 
 

@@ -87,6 +87,17 @@ int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *A, const fl
 size_t geoadv_approx_match_temp_floats(int b, int n, int m);
 int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2,
                         float *match, float *temp, void *stream);
+/* How the pair weight expf(level * |p - q|^2) (tf_approxmatch.cpp:46) is evaluated; the rest of the algorithm (fp64
+ * capacities, factors and sums) is the same in both modes (csrc/emd.hip header):
+ *   FAST       fp32 distance, v_exp_f32.  Plan entries typically within 1e-6 relative of the CPU op; on clouds of
+ *              thousands of points a few entries per million reach ~1e-4 (the algorithm amplifies the weight rounding).
+ *   REFERENCE  the CPU op's own weights bit for bit (double distance, float expf argument, glibc's expf algorithm in fp64)
+ *              and double level terms: every entry within ~2 float ulps of the CPU op; ~3.7x the time.
+ * geoadv_approx_match / geoadv_emd_cost_grad1 are the FAST mode. */
+#define GEOADV_EMD_FAST 0
+#define GEOADV_EMD_REFERENCE 1
+int geoadv_approx_match_mode(int mode, int b, int n, int m, const float *xyz1, const float *xyz2,
+                             float *match, float *temp, void *stream);
 /* matchcostLauncher (tf_approxmatch.cpp:142; tf_approxmatch_g.cu:183-227): out[b]. */
 int geoadv_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *out, void *stream);
@@ -97,6 +108,8 @@ int geoadv_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2,
 size_t geoadv_emd_cost_grad1_temp_floats(int b, int n, int m);
 int geoadv_emd_cost_grad1(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
                           float *temp, void *stream);
+int geoadv_emd_cost_grad1_mode(int mode, int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
+                               float *grad1, float *temp, void *stream);
 /* matchcostgradLauncher (tf_approxmatch.cpp:143; tf_approxmatch_g.cu:229-295).  grad2 may be NULL (only grad1 wanted). */
 int geoadv_match_cost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
                            const float *match, float *grad1, float *grad2, void *stream);
@@ -195,6 +208,7 @@ typedef struct geoadv_attack_config {
     float emd_weight;               /* build-defined: loss_adv += emd_weight*match_cost/N; 0 = off */
     int   all_pairs_source_dist;    /* 0 (default): nn_distance(adv, x) by the exact paired grid search, falling back per
                                      * cloud to the all-pairs kernel; 1: always the all-pairs kernel.  Same results.     */
+    int   emd_weight_mode;          /* GEOADV_EMD_FAST (0, default) or GEOADV_EMD_REFERENCE for the EMD term's plan       */
 } geoadv_attack_config;
 
 int  geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, const geoadv_attack_config *cfg);

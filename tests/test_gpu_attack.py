@@ -281,16 +281,18 @@ def test_odd_sizes_all_code_paths_agree():
         assert h == got["default"], name
 
 
-def test_emd_combined_loss_step(setup):
+@pytest.mark.parametrize("reference_weights", [False, True])
+def test_emd_combined_loss_step(setup, reference_weights):
     """configs[3]: Chamfer + EMD combined adversarial loss (build-defined: loss_adv = chamfer +
     emd_weight * match_cost(recon, gt) / N, match held constant in the backward like the reference's
-    NoGradient registration): loss value and gradient of one iteration against the model."""
+    NoGradient registration): loss value and gradient of one iteration against the model, with the plan's pair weights in
+    either mode (Configuration.emd_reference_weights)."""
     import torch
     from oracle.attack_model import AttackModel
     w, ae, model = setup
     b = 2
     x, gt = _clouds(71, b)
-    at = _mk_attack(w, ae, b, "chamfer", "chamfer", emd_weight=0.5)
+    at = _mk_attack(w, ae, b, "chamfer", "chamfer", emd_weight=0.5, emd_reference_weights=reference_weights)
     at.set_inputs(x, gt, None, 1.0)
     p0 = (1e-3 * np.random.default_rng(2).standard_normal((b, N, 3))).astype(np.float32)
     at.init_pert(p0, reset_optimizer=True)

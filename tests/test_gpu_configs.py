@@ -151,7 +151,9 @@ def test_config3_per_gpu_shape_b128_chamfer_plus_emd(oracle):
     Gradient vs the fp64 model (pinned C approx_match / match_cost_grad inside) on 4 sampled clouds -- the batch is a sum of
     independent clouds, so a cloud's gradient does not depend on the others --; transport-plan properties of the GPU's own
     match on ALL 128 clouds: non-negative, every target column receives at most its capacity 1, every source row ships at
-    most 1, total mass within 2 % of N (tf_approxmatch.cpp:23-84: remainders decay geometrically over the 10 levels)."""
+    most 1, total mass within 2 % of N (tf_approxmatch.cpp:23-84: remainders decay geometrically over the 10 levels);
+    and all 537 M plan entries of the fast weight mode against the reference mode (the CPU op's weights bit for bit, itself
+    held to 2 ulps of the oracle in test_gpu_emd.py): the statistical bound of the fast mode at the full shape."""
     import torch
     from geometric_adv_amd import ops, weights as W
     from geometric_adv_amd.adv_ae import AdvAE, Configuration
@@ -192,6 +194,11 @@ def test_config3_per_gpu_shape_b128_chamfer_plus_emd(oracle):
         assert (total > 0.98 * n).all() and (total <= n * (1 + 1e-5)).all()
         cost = ops.match_cost(recon[lo:lo + 32], gtd[lo:lo + 32], match)
         assert torch.isfinite(cost).all() and (cost > 0).all()
+        ref = ops.approx_match(recon[lo:lo + 32], gtd[lo:lo + 32], reference_weights=True)
+        err = (match - ref).abs()
+        outside = (err > 2e-6 + 2e-5 * ref.abs()).sum().item()
+        assert outside <= 1e-5 * ref.numel() and err.max().item() < 1e-3, (lo, outside, err.max().item())
+        del ref, err
 
 
 def test_config4_full_batch_b32_n8192_indices(oracle):

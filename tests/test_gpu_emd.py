@@ -8,6 +8,11 @@ guard; there the weight error is amplified by up to ~10 (csrc/emd.hip header; me
   * the reference's golden vectors: rtol 2e-5 / atol 2e-6 on EVERY entry (measured worst case 7e-7 absolute);
   * larger random clouds vs the pinned oracle: the same bound on >= 99.99 % of the entries, and rtol 1e-4 / atol 2e-5 on all
     (measured: 1 entry of 393 216 at 3.0e-5 relative).
+With reference_weights=True (GEOADV_EMD_REFERENCE) every pair weight is the CPU op's bit for bit (its double distance, its
+float expf argument, glibc's expf algorithm: tests/test_expf_table.py) and the plan's level terms are added in double like
+the CPU's: what is left is the order of the fp64 sums, amplified by the same conditioning to at most ~2 float ulps
+(measured 2.0e-7 relative over 13 M entries, 40-80 % of them bit-equal).  Held to rtol 2e-6 / atol 2e-8 on EVERY entry at
+every size, here and in test_gpu_reference_checks.py.
 For scale: the reference's own CPU-vs-GPU check of this op allows 1e-2 ABSOLUTE per entry (approxmatch.cpp:222)."""
 import numpy as np
 import pytest
@@ -15,20 +20,24 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+REF_TOL = dict(rtol=2e-6, atol=2e-8)            # reference_weights=True, every entry
+
+
 def _t(a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
-def test_approx_match_and_cost_golden(golden_emd):
+@pytest.mark.parametrize("reference_weights", [False, True])
+def test_approx_match_and_cost_golden(golden_emd, reference_weights):
     from geometric_adv_amd import ops
     g = golden_emd
     for name in g["cases"]:
         x1, x2 = g[f"{name}_xyz1"], g[f"{name}_xyz2"]
         want = g[f"{name}_match_nm"]                                    # CPU layout (b, n, m)
-        match = ops.approx_match(_t(x1), _t(x2))                        # (b, m, n)
+        match = ops.approx_match(_t(x1), _t(x2), reference_weights)     # (b, m, n)
         got = match.cpu().numpy().transpose(0, 2, 1)
-        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(got, want, err_msg=name, **(REF_TOL if reference_weights else dict(rtol=2e-5, atol=2e-6)))
         cost = ops.match_cost(_t(x1), _t(x2), match).cpu().numpy()
         np.testing.assert_allclose(cost, g[f"{name}_cost"], rtol=1e-5, err_msg=name)
         # cost / grad kernels in isolation: feed them the REFERENCE's match
@@ -51,6 +60,18 @@ def test_approx_match_vs_oracle_medium(oracle):
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(got.sum(2), want.sum(2), rtol=1e-4, atol=2e-5)          # mass shipped per source / received per target
     np.testing.assert_allclose(got.sum(1), want.sum(1), rtol=1e-4, atol=2e-5)
+
+
+def test_approx_match_reference_weights_vs_oracle_every_entry(oracle):
+    """The same clouds with the CPU op's own weights: a few float ulps on every entry, plus ragged sizes (tiles of 1024
+    staged points, 128 own points per workgroup: 1100 and 300 leave partial ones) and factorl / factorr > 1."""
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    for b, n, m, s1, s2 in [(2, 512, 384, 1, 2), (1, 300, 1100, 5, 6), (1, 1100, 300, 7, 8), (1, 1, 5, 9, 10)]:
+        x1, x2 = cloud(s1, b, n), cloud(s2, b, m)
+        want = oracle.approx_match(x1, x2)
+        got = ops.approx_match(_t(x1), _t(x2), reference_weights=True).cpu().numpy().transpose(0, 2, 1)
+        np.testing.assert_allclose(got, want, err_msg=str((n, m)), **REF_TOL)
 
 
 def test_approx_match_is_a_transport_plan_full_size():
@@ -93,20 +114,25 @@ def test_emd_argument_errors():
         ops.match_cost(x, x, torch.rand((2, 10, 9), device="cuda:0"))
     with pytest.raises(ValueError):
         ops.approx_match(x, torch.rand((3, 10, 3), device="cuda:0"))
+    from geometric_adv_amd import _lib
+    out, temp = torch.empty((2, 10, 10), device="cuda:0"), torch.empty(4096, device="cuda:0")
+    rc = _lib.lib().geoadv_approx_match_mode(7, 2, 10, 10, _lib.ptr(x), _lib.ptr(x), _lib.ptr(out), _lib.ptr(temp), None)
+    assert rc != 0 and b"unknown weight mode" in _lib.lib().geoadv_last_error()
 
 
+@pytest.mark.parametrize("reference_weights", [False, True])
 @pytest.mark.parametrize("b,n,m", [(2, 2048, 2048), (3, 300, 517), (2, 64, 1100), (1, 1, 5)])
-def test_fused_cost_grad1_equals_the_three_ops(b, n, m):
+def test_fused_cost_grad1_equals_the_three_ops(b, n, m, reference_weights):
     """The attack loop's fused kernel (plan formed pair by pair in registers, never stored) against approx_match ->
     match_cost / match_cost_grad on the same clouds: same pair arithmetic, different order of the fp32 sums."""
     import torch
     from geometric_adv_amd import ops
     from conftest import cloud
     x1, x2 = _t(cloud(11, b, n)), _t(0.7 * cloud(12, b, m))
-    match = ops.approx_match(x1, x2)
+    match = ops.approx_match(x1, x2, reference_weights)
     want_cost = ops.match_cost(x1, x2, match)
     want_g1, _ = ops.match_cost_grad(x1, x2, match)
-    cost, g1 = ops.emd_cost_grad1(x1, x2)
+    cost, g1 = ops.emd_cost_grad1(x1, x2, reference_weights)
     torch.testing.assert_close(cost, want_cost, rtol=2e-6, atol=0)
     sc = want_g1.abs().amax((1, 2), keepdim=True)
     torch.testing.assert_close(g1 / sc, want_g1 / sc, rtol=0, atol=1e-5)          # 2048-term fp32 sums in a different order

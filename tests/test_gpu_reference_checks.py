@@ -60,6 +60,7 @@ def test_approx_match_harness_shape_n4096_m1024(oracle):
     reference's abort threshold |d match| > 1e-2 -- and this build's own bounds at this size (8.4 M entries per cloud pair):
     rtol 2e-5 / atol 2e-6 on >= 99.999 % of the entries, 1e-3 absolute on all (measured: ONE entry of 8 388 608 off by 6.8e-5,
     the fp32 pair weight amplified where an almost exhausted capacity meets the op's 1e-9 guard, csrc/emd.hip header);
+    with reference_weights=True (the CPU op's own weights, bit for bit) rtol 2e-6 / atol 2e-8 on EVERY entry;
     the commented-out row / column sum checks of the harness (:151-172) as assertions; cost and gradient like its printed
     mean errors.  Two clouds (the harness runs its CPU side on 2 of its 32)."""
     from geometric_adv_amd import ops
@@ -72,6 +73,8 @@ def test_approx_match_harness_shape_n4096_m1024(oracle):
     err = np.abs(got - want)
     assert err.max() < 1e-2                                              # approxmatch.cpp:222
     assert err.max() < 1e-3 and (err <= 2e-6 + 2e-5 * np.abs(want)).mean() >= 0.99999
+    ref = ops.approx_match(_t(x1), _t(x2), reference_weights=True).cpu().numpy().transpose(0, 2, 1)
+    np.testing.assert_allclose(ref, want, rtol=2e-6, atol=2e-8)
     assert ((got >= 0) & (got <= 1 + 1e-6)).all()
     np.testing.assert_allclose(got.sum(2), 1.0, atol=1e-3)               # every source ships its unit mass (:159-161)
     np.testing.assert_allclose(got.sum(1), 4.0, atol=1e-3)               # every target receives factorr = 4 (:168-170)
