@@ -273,27 +273,134 @@ __global__ void group_point_kernel(int n, int cch, size_t per_cloud, size_t tota
     out[e] = points[(cloud * n + idx[entry]) * cch + ch];
 }
 
-// GroupPointGrad (tf_grouping_g.cu:61-78) without float atomics: thread (point, channel) walks the
-// cloud's entries in ascending order -- the CPU twin's accumulation order
-// (test/query_ball_point.cpp:70-84) -- with the index list staged through LDS.
-__global__ __launch_bounds__(256) void group_point_grad_kernel(int n, int cch, int entries, const float *grad_out,
-                                                               const int *idx, float *grad_points) {
-    __shared__ int sidx[1024];
+// GroupPointGrad (tf_grouping_g.cu:61-78) without float atomics and in the CPU twin's accumulation order
+// (test/query_ball_point.cpp:70-84: entries ascending), in time linear in the number of entries: a stable LSD radix sort
+// of the entries by destination point, six bits per pass, then one in-order sum per (point, channel).
+// One pass = count, scan, place.  A WAVE owns one segment of the (current order of the) entries and all 64 digit values,
+// lane = digit: it walks its segment 64 entries at a time; six ballots of the digit's bits give every lane, without LDS,
+// both the entries whose digit is the lane's own (count / cursor advance) and, as an entry, its peers with the same digit
+// in the group -- its slot is cursor[digit] + (peers in lower lanes).  Counts are laid out digit-major, segment-minor, so
+// one exclusive scan yields every (digit, segment) cursor and the order inside a digit stays the entry order: stable.
+// No atomics anywhere: the result does not depend on scheduling.  Invalid destinations sort behind the last point and
+// are never summed.  Round 1 let every (point, channel) thread walk every entry: O(n c m nsample) per cloud.
+constexpr int GPG_WAVES = 4, GPG_AHEAD = 4;
+
+template <bool PLACE>
+__global__ __launch_bounds__(64 * GPG_WAVES) void gpg_pass_kernel(int n, int entries, int shift, int segs, int seg_len,
+                                                                  const int *keys_in, const int *perm_in, int *table,
+                                                                  int *keys_out, int *perm_out) {
+    const int c = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * GPG_WAVES + (threadIdx.x >> 6);
+    if (seg >= segs) return;                                 // (no workgroup barrier below: waves are independent)
+    const int *kin = keys_in + (size_t)c * entries;
+    const int *pin = perm_in ? perm_in + (size_t)c * entries : nullptr;       // first pass: the identity
+    int *slot = table + (size_t)c * (64 * segs + 1) + lane * segs + seg;
+    const int lo = seg * seg_len, hi = min(entries, lo + seg_len);
+    int cursor = PLACE ? *slot : 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int i0 = lo; i0 < hi; i0 += 64 * GPG_AHEAD) {
+        int key[GPG_AHEAD], src[GPG_AHEAD];
+#pragma unroll
+        for (int u = 0; u < GPG_AHEAD; ++u) {                // the loads of several groups in flight together
+            const int i = i0 + u * 64 + lane;
+            key[u] = 0; src[u] = i;
+            if (i < hi) {
+                key[u] = kin[i];
+                if (PLACE && pin) src[u] = pin[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GPG_AHEAD; ++u) {
+            const int i = i0 + u * 64 + lane;
+            const bool in = i < hi;
+            int k = key[u];
+            if (!pin) k = (k < 0 || k >= n) ? n : k;         // first pass: raw indices; invalid ones behind the last point
+            const int digit = (k >> shift) & 63;
+            const unsigned long long any = __ballot(in);
+            if (any == 0) break;
+            unsigned long long to_me = any, peers = any;
+#pragma unroll
+            for (int bit = 0; bit < 6; ++bit) {
+                const unsigned long long set = __ballot(in && ((digit >> bit) & 1));
+                to_me &= ((lane >> bit) & 1) ? set : ~set;
+                if (PLACE) peers &= ((digit >> bit) & 1) ? set : ~set;
+            }
+            if (PLACE) {
+                const int base = __shfl(cursor, digit);      // (every lane takes part in the permute)
+                if (in) {
+                    const size_t o = (size_t)c * entries + base + __popcll(peers & below);
+                    keys_out[o] = k;
+                    perm_out[o] = src[u];
+                }
+            }
+            cursor += __popcll(to_me);
+        }
+    }
+    if (!PLACE) *slot = cursor;
+}
+
+// in place: cnt[c][0..n) -> start[c][0..n], start[c][n] = total
+__global__ __launch_bounds__(1024) void gpg_scan_kernel(int n, int *cnt) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    int *row = cnt + (size_t)blockIdx.x * (n + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < n; p0 += 1024) {
+        const int p = p0 + threadIdx.x;
+        const int v = p < n ? row[p] : 0;
+        int inc = v;                                        // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (p < n) row[p] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row[n] = carry;
+}
+
+// start[c][p] = first position of point p in the sorted destinations (p = 0 .. n; start[n] = number of valid entries)
+__global__ __launch_bounds__(256) void gpg_bounds_kernel(int n, int entries, const int *sorted_keys, int *start) {
+    const int c = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p > n) return;
+    const int *k = sorted_keys + (size_t)c * entries;
+    int lo = 0, hi = entries;                               // lower bound of p
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (k[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    start[(size_t)c * (n + 1) + p] = lo;
+}
+
+__global__ __launch_bounds__(256) void gpg_sum_kernel(int n, int cch, int entries, const float *grad_out, const int *start,
+                                                      const int *perm, float *grad_points) {
     const int c = blockIdx.y;
     const int pc = blockIdx.x * 256 + threadIdx.x;     // (point, channel) pair of this cloud
+    if (pc >= n * cch) return;
     const int p = pc / cch, ch = pc % cch;
-    const bool live = pc < n * cch;
+    const int lo = start[(size_t)c * (n + 1) + p], hi = start[(size_t)c * (n + 1) + p + 1];
+    const int *pm = perm + (size_t)c * entries;
+    const float *go = grad_out + (size_t)c * entries * cch;
     float acc = 0.f;
-    for (int e0 = 0; e0 < entries; e0 += 1024) {
-        const int cnt = min(1024, entries - e0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += 256) sidx[e] = idx[(size_t)c * entries + e0 + e];
-        __syncthreads();
-        if (live)
-            for (int e = 0; e < cnt; ++e)
-                if (sidx[e] == p) acc += grad_out[((size_t)c * entries + e0 + e) * cch + ch];
+    int i = lo;
+    for (; i + 4 <= hi; i += 4) {                      // four rows in flight; the sum stays in entry order
+        const int e0 = pm[i], e1 = pm[i + 1], e2 = pm[i + 2], e3 = pm[i + 3];
+        const float v0 = go[(size_t)e0 * cch + ch], v1 = go[(size_t)e1 * cch + ch], v2 = go[(size_t)e2 * cch + ch], v3 = go[(size_t)e3 * cch + ch];
+        acc += v0; acc += v1; acc += v2; acc += v3;
     }
-    if (live) grad_points[((size_t)c * n + p) * cch + ch] = acc;
+    for (; i < hi; ++i) acc += go[(size_t)pm[i] * cch + ch];
+    grad_points[((size_t)c * n + p) * cch + ch] = acc;
 }
 
 }  // namespace geoadv
@@ -428,7 +535,37 @@ extern "C" int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, 
     GA_REQUIRE(b <= 65535, "group_point_grad: batch %d exceeds 65535", b);
     if ((size_t)b * n * c == 0) return GEOADV_OK;
     GA_REQUIRE(grad_points && (m * nsample == 0 || (grad_out && idx)), "group_point_grad: null pointer");
-    group_point_grad_kernel<<<dim3(cdiv(n * c, 256), b), 256, 0, as_stream(stream)>>>(n, c, m * nsample, grad_out, idx, grad_points);
-    GA_LAUNCH_CHECK();
+    GA_REQUIRE((size_t)m * nsample < ((size_t)1 << 30), "group_point_grad: m * nsample too large");
+    hipStream_t st = as_stream(stream);
+    const int entries = m * nsample;
+    if (entries == 0) {
+        GA_HIP(hipMemsetAsync(grad_points, 0, (size_t)b * n * c * sizeof(float), st));        // tf_grouping.cpp:204
+        return GEOADV_OK;
+    }
+    // segments of >= 16 groups of 64 entries, at most 64 of them per cloud
+    const int segs = std::max(1, std::min(64, entries / (64 * 16)));
+    const int seg_len = cdiv(cdiv(entries, segs), 64) * 64;
+    int passes = 1;
+    while ((n >> (6 * passes)) != 0) ++passes;              // destinations 0 .. n (n = invalid)
+    // stream-ordered scratch: two (keys, perm) buffers, the (digit, segment) table, start[b][n + 1]
+    const size_t per = (size_t)b * entries, table_ints = (size_t)b * (64 * segs + 1), start_ints = (size_t)b * (n + 1);
+    int *scratch = nullptr;
+    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), (4 * per + table_ints + start_ints) * sizeof(int), st));
+    int *keys[2] = {scratch, scratch + per}, *perm[2] = {scratch + 2 * per, scratch + 3 * per};
+    int *table = scratch + 4 * per, *start = table + table_ints;
+    const dim3 grid(cdiv(segs, GPG_WAVES), b);
+    const int *kin = idx, *pin = nullptr;
+    for (int pass = 0; pass < passes; ++pass) {
+        int *kout = keys[pass & 1], *pout = perm[pass & 1];
+        gpg_pass_kernel<false><<<grid, 64 * GPG_WAVES, 0, st>>>(n, entries, 6 * pass, segs, seg_len, kin, pin, table, nullptr, nullptr);
+        gpg_scan_kernel<<<b, 1024, 0, st>>>(64 * segs, table);
+        gpg_pass_kernel<true><<<grid, 64 * GPG_WAVES, 0, st>>>(n, entries, 6 * pass, segs, seg_len, kin, pin, table, kout, pout);
+        kin = kout; pin = pout;
+    }
+    gpg_bounds_kernel<<<dim3(cdiv(n + 1, 256), b), 256, 0, st>>>(n, entries, kin, start);
+    gpg_sum_kernel<<<dim3(cdiv(n * c, 256), b), 256, 0, st>>>(n, c, entries, grad_out, start, pin, grad_points);
+    const hipError_t err = hipGetLastError();
+    GA_HIP(hipFreeAsync(scratch, st));
+    GA_HIP(err);
     return GEOADV_OK;
 }

@@ -31,6 +31,31 @@ def test_query_ball_and_group_point_golden(golden_grouping):
     assert np.array_equal(gp.cpu().numpy(), g["gp_grad_points"])            # same accumulation order => same bits
 
 
+@pytest.mark.parametrize("b,n,c,m,ns,skew", [(3, 300, 5, 77, 9, "uniform"), (2, 2048, 64, 2048, 32, "uniform"), (2, 1000, 3, 900, 16, "few"),
+                                             (1, 130, 2, 4096, 16, "one"), (2, 63, 4, 50, 3, "uniform"), (1, 5000, 1, 333, 7, "runs")])
+def test_group_point_grad_vs_oracle_bit_exact(oracle, b, n, c, m, ns, skew):
+    """The counting-sort scatter against the CPU twin (test/query_ball_point.cpp:70-84), bit for bit: float sums in entry
+    order.  Destinations uniform, concentrated on a few points (long per-point lists), all on ONE point (every entry of a
+    64-entry group is a peer of every other), or in runs (query_ball_point's padding repeats the first hit); point counts
+    that are not multiples of the 64-point wave ranges; more points than one scan pass of 1024."""
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(n + m)
+    if skew == "uniform":
+        idx = rng.integers(0, n, size=(b, m, ns))
+    elif skew == "few":
+        idx = rng.choice(np.array([0, 1, 63, 64, 65, n - 1]), size=(b, m, ns))
+    elif skew == "one":
+        idx = np.full((b, m, ns), n - 1)
+    else:
+        idx = np.repeat(rng.integers(0, n, size=(b, m, 1)), ns, axis=2)
+    idx = idx.astype(np.int32)
+    points = rng.standard_normal((b, n, c)).astype(np.float32)
+    grad_out = rng.standard_normal((b, m, ns, c)).astype(np.float32)
+    want = oracle.group_point_grad(points, idx, grad_out)
+    got = ops.group_point_grad(_t(points), _t(idx), _t(grad_out)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
 def test_query_ball_vs_oracle_sparse_hits(oracle):
     from geometric_adv_amd import ops
     from conftest import cloud
