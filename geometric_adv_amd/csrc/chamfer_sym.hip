@@ -153,12 +153,15 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
             __builtin_amdgcn_wave_barrier();
             {
                 const int col = lane >> 2, quarter = lane & 3;
-                const float4 *src = reinterpret_cast<const float4 *>(tb + col * CS_TSTRIDE + quarter * 16);
-                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                float mn = fminf(fminf(fminf(v0.x, v0.y), fminf(v0.z, v0.w)), fminf(fminf(v1.x, v1.y), fminf(v1.z, v1.w)));
-                mn = fminf(mn, fminf(fminf(fminf(v2.x, v2.y), fminf(v2.z, v2.w)), fminf(fminf(v3.x, v3.y), fminf(v3.z, v3.w))));
-                mn = fminf(mn, __shfl_xor(mn, 1));
-                mn = fminf(mn, __shfl_xor(mn, 2));
+                // squared distances are >= +0 (or +inf): their order as floats is their order as unsigned integers, and an
+                // integer minimum needs no canonicalising v_max in front of every value that comes back from LDS
+                const uint4 *src = reinterpret_cast<const uint4 *>(tb + col * CS_TSTRIDE + quarter * 16);
+                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                unsigned mb = min(min(min(v0.x, v0.y), min(v0.z, v0.w)), min(min(v1.x, v1.y), min(v1.z, v1.w)));
+                mb = min(mb, min(min(min(v2.x, v2.y), min(v2.z, v2.w)), min(min(v3.x, v3.y), min(v3.z, v3.w))));
+                mb = min(mb, (unsigned)__shfl_xor((int)mb, 1));
+                mb = min(mb, (unsigned)__shfl_xor((int)mb, 2));
+                const float mn = __uint_as_float(mb);
                 const int k = t0 + k0 + col;
                 if (quarter == 0 && k < mend) colpart[k] = mn;
             }
@@ -310,15 +313,13 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
                 if (t0 + t < tiles && w[t] < v) { v = w[t]; bt = t0 + t; }
         }
         const int q0 = bt * CS_ROWS;
-        const int nrows = min(CS_ROWS, n - q0);
         constexpr int SHARE = CS_ROWS / CF_Q;                 // rows per lane: [quarter * SHARE, +SHARE) of the tile
         const float *sx = rx + bt * CF_SEG + quarter * SHARE, *sy = ry + bt * CF_SEG + quarter * SHARE, *sz = rz + bt * CF_SEG + quarter * SHARE;
-        const int lim = nrows - quarter * SHARE;              // rows of this share that exist (may be <= 0)
-        // descending, four rows per step (one ds_read_b128 per plane): the last hit kept is the lowest row.
-        // Rows beyond the cloud are padding (never equal to v unless they duplicate a real row, and a lower real row then
-        // wins anyway) -- they are masked explicitly all the same.
+        // descending, four rows per step (one ds_read_b128 per plane): the last hit kept is the lowest row.  Fully unrolled:
+        // the row numbers are inline constants of the selects.  Rows beyond the cloud are staged as copies of its last row
+        // (above), so a padding row can only match where row n - 1 matches too -- and that one, being lower, is kept.
         int found = INT_MAX;
-    #pragma unroll 4
+    #pragma unroll
         for (int j4 = SHARE / 4 - 1; j4 >= 0; --j4) {
             const float4 xa = *reinterpret_cast<const float4 *>(sx + 4 * j4);
             const float4 ya = *reinterpret_cast<const float4 *>(sy + 4 * j4);
@@ -326,10 +327,10 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
             const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
             const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
             const int j = 4 * j4;
-            found = (d3 == v && j + 3 < lim) ? j + 3 : found;
-            found = (d2 == v && j + 2 < lim) ? j + 2 : found;
-            found = (d1 == v && j + 1 < lim) ? j + 1 : found;
-            found = (d0 == v && j < lim) ? j : found;
+            found = d3 == v ? j + 3 : found;
+            found = d2 == v ? j + 2 : found;
+            found = d1 == v ? j + 1 : found;
+            found = d0 == v ? j : found;
         }
         if (found != INT_MAX) found += quarter * SHARE;
         found = min(found, __shfl_xor(found, 1));
