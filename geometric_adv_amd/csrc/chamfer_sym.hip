@@ -9,13 +9,14 @@
 // R per lane, in registers); wave w scans the w-th quarter of the columns (Q points, LDS-staged SoA planes,
 // broadcast reads).  Row minima: running min per chunk of 8 columns + re-scan of the winning chunk, as
 // before.  Column minima: every lane reduces its R rows in registers (v_min3), then the 64 lanes of the
-// wave are reduced through a 4 KB LDS transpose per 16 columns (16 ds_write_b32 + 4 ds_read_b128 + 2
-// shuffles per lane: ~8 % on top of the distance arithmetic; a DPP butterfly per column would cost 19 %).
+// wave are reduced through a 4 KB LDS transpose per 16 columns (16 ds_write_b32 + 4 ds_read_b128 per lane:
+// ~8 % on top of the distance arithmetic; a DPP butterfly per column would cost 19 %).
 // Each column is visited by exactly one wave of the workgroup, so the reduced value IS the column's
-// minimum over this row tile; it goes to colpart[tile][k].
-// Kernel 2 (chamfer_sym_finish_kernel): per column, minimum over the row tiles and the LOWEST tile
-// attaining it; then only that tile's 64*R rows are re-evaluated to find the lowest row index with
-// d == minimum (exactly the reference's tie rule): 1/8 of a scan at n = 2048.
+// minimum over this row tile; the four partial minima it is folded from (one per 16 lanes = 64 rows) go to
+// colpart[tile][k][0..3].
+// Kernel 2 (chamfer_sym_finish_kernel): per column, minimum over the (tile, quarter) partials and the LOWEST tile
+// attaining it; then only the 64 rows of that tile's winning quarter are re-evaluated to find the lowest row index
+// with d == minimum (exactly the reference's tie rule): 1/32 of a scan at n = 2048.
 #include "common.h"
 #include <limits.h>
 #include <math.h>
@@ -35,7 +36,7 @@ struct ChamferSymArgs {
     int n, m, tiles, clouds, pairs, csplit;
     int fin_reps;              // finish kernel: column sub-slices of CF_COLS a workgroup walks after staging the row cloud once
     int pair_base, q_clouds;   // q_clouds > 0: cloud c is the pair (P cloud (pair_base+c)/q_clouds, Q cloud (pair_base+c)%q_clouds)
-    float *colpart;            // [pairs][clouds][tiles][m]
+    float *colpart;            // [pairs][clouds][tiles][m][4]: minima over the four 64-row quarters of a tile (rows 64 r + 16 q + i)
     float *rowpart_d;          // [pairs][clouds][csplit][n]   row minima per column slice
     int *rowpart_i;
     const int *need[2];        // per pair: null = every cloud; else int[8 * clouds], cloud c is computed only if one of
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     const int cq = a.q_clouds > 0 ? (a.pair_base + c) % a.q_clouds : c;
     const float *P = pr.p + (size_t)cp * n * 3;
     const float *Q = pr.q + (size_t)cq * m * 3;
-    float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * a.tiles + tile) * m;
+    float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * a.tiles + tile) * m * 4;      // [m][4 quarters]
 
     __shared__ __attribute__((aligned(16))) float stage[3 * CS_STAGE];
     __shared__ __attribute__((aligned(16))) float tbuf[CS_WAVES][CS_ROUND * CS_TSTRIDE];
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
                 const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
                 unsigned mb = min(min(min(v0.x, v0.y), min(v0.z, v0.w)), min(min(v1.x, v1.y), min(v1.z, v1.w)));
                 mb = min(mb, min(min(min(v2.x, v2.y), min(v2.z, v2.w)), min(min(v3.x, v3.y), min(v3.z, v3.w))));
-                mb = min(mb, (unsigned)__shfl_xor((int)mb, 1));
-                mb = min(mb, (unsigned)__shfl_xor((int)mb, 2));
-                const float mn = __uint_as_float(mb);
+                // lane (col, quarter) now holds the minimum over lanes 16 quarter .. 16 quarter + 15, i.e. over the rows
+                // {64 r + 16 quarter + i} of this tile: all four quarter minima are kept (one coalesced 256-byte store per
+                // round) -- the finish kernel then re-evaluates 64 rows per column instead of 256
                 const int k = t0 + k0 + col;
-                if (quarter == 0 && k < mend) colpart[k] = mn;
+                if (k < mend) colpart[(size_t)k * 4 + quarter] = __uint_as_float(mb);
             }
             __builtin_amdgcn_wave_barrier();              // the buffer is rewritten by the next round
         }
@@ -244,13 +245,35 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
 // grid = (column slices, clouds * pairs).  Every workgroup takes an equal slice of COLUMNS (so the work is
 // balanced even when all column minima fall into one row tile, which is what a collapsed reconstruction
 // produces) and keeps the whole row cloud in LDS as SoA planes, one padded segment per row tile.  Thread =
-// one column: minimum over the row tiles + lowest tile attaining it, then that tile's rows are
-// re-evaluated in ascending order for the first one with d == minimum.
-constexpr int CF_Q = 4;                               // lanes per column: each re-evaluates a quarter of the winning tile
-constexpr int CF_COLS = 256;                          // columns per workgroup
-constexpr int CF_THREADS = CF_COLS * CF_Q;            // 16 waves: four per SIMD hide the LDS latency of the re-evaluation
-static_assert(CS_ROWS % (4 * CF_Q) == 0, "a lane's share of a tile is whole float4 groups");
+// one column: minimum over the (tile, quarter) partials + the lowest tile attaining it, then the 64 rows of that
+// tile's winning quarter are re-evaluated for the lowest one with d == minimum (exactly the reference's tie rule).
+// Several quarters of the tile attaining the minimum (exact ties between rows 16 apart or more) are rare: those
+// columns walk their further quarters in a loop the other lanes sit out.
+constexpr int CF_COLS = 512;                          // columns = threads per workgroup (measured: 128: 10.0, 256: 8.0, 512: 6.9, 1024: 8.9 us at B = 32, N = 2048 -- staging the rows per workgroup against workgroups per chip)
+constexpr int CF_THREADS = CF_COLS;
 constexpr int CF_SEG = CS_ROWS + 4;                   // floats per tile segment: 16-B aligned, and the pad staggers the banks
+
+// lowest row of quarter q (rows 64 r + 16 q + i) of the tile staged at (sx, sy, sz) whose distance to the column equals v
+__device__ __forceinline__ int finish_quarter(const float *sx, const float *sy, const float *sz, int q, float qx, float qy, float qz, float v) {
+    int found = INT_MAX;
+#pragma unroll
+    for (int r = CS_R - 1; r >= 0; --r)                   // descending: the last hit kept is the lowest row
+#pragma unroll
+        for (int j4 = 3; j4 >= 0; --j4) {
+            const int o = 64 * r + 16 * q + 4 * j4;
+            const float4 xa = *reinterpret_cast<const float4 *>(sx + o);
+            const float4 ya = *reinterpret_cast<const float4 *>(sy + o);
+            const float4 za = *reinterpret_cast<const float4 *>(sz + o);
+            const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
+            const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
+            const int j = 64 * r + 4 * j4;                // (+ 16 q, added by the caller: the selects keep inline constants)
+            found = d3 == v ? j + 3 : found;
+            found = d2 == v ? j + 2 : found;
+            found = d1 == v ? j + 1 : found;
+            found = d0 == v ? j : found;
+        }
+    return found == INT_MAX ? INT_MAX : found + 16 * q;
+}
 
 __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferSymArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -265,23 +288,21 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
     const int cq = a.q_clouds > 0 ? (a.pair_base + c) % a.q_clouds : c;
     const float *P = pr.p + (size_t)cp * n * 3;
     const float *Q = pr.q + (size_t)cq * m * 3;
-    const float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * tiles) * m;
-    // this thread's column: its tile minima and coordinates are REQUESTED before the row cloud is staged, so that the two
-    // global round trips overlap (the kernel is latency-bound: 256 workgroups, a few microseconds each).  Large clouds
-    // (fin_reps > 1: staging the rows is ~100 KB per workgroup, one workgroup per CU) walk several column sub-slices per
-    // staging instead of paying it once per 256 columns.
-    const int quarter = threadIdx.x & (CF_Q - 1);
-    constexpr int CP = 8;                                 // tile minima fetched up front (n <= 2048); further tiles in a loop
-    int k = (blockIdx.x * a.fin_reps) * CF_COLS + (threadIdx.x >> 2);
-    int kc = k < m ? k : m - 1;                           // (whole 4-lane groups stay in the shuffles below)
-    float cpv[CP];
+    const float4 *colpart = reinterpret_cast<const float4 *>(a.colpart) + (((size_t)pi * a.clouds + c) * tiles) * m;
+    // this thread's column: its partial minima and coordinates are REQUESTED before the row cloud is staged, so that the
+    // two global round trips overlap (the kernel is latency-bound).  Large clouds (fin_reps > 1: staging the rows is
+    // ~100 KB per workgroup, one workgroup per CU) walk several column sub-slices per staging.
+    constexpr int CP = 8;                                 // tiles fetched up front (n <= 2048); further tiles in a loop
+    int k = (blockIdx.x * a.fin_reps) * CF_COLS + threadIdx.x;
+    int kc = k < m ? k : m - 1;
+    float4 cpv[CP];
 #pragma unroll
     for (int t = 0; t < CP; ++t) cpv[t] = colpart[(size_t)(t < tiles ? t : 0) * m + kc];
     float qx = Q[3 * (size_t)kc], qy = Q[3 * (size_t)kc + 1], qz = Q[3 * (size_t)kc + 2];
     for (int e = threadIdx.x; e < tiles * CS_ROWS; e += CF_THREADS) {
         const int o = (e / CS_ROWS) * CF_SEG + (e % CS_ROWS);
-        const int src = e < n ? e : n - 1;
-        rx[o] = P[3 * (size_t)src]; ry[o] = P[3 * (size_t)src + 1]; rz[o] = P[3 * (size_t)src + 2];
+        const int src = e < n ? e : n - 1;                // rows beyond the cloud: copies of its last row (a copy can only
+        rx[o] = P[3 * (size_t)src]; ry[o] = P[3 * (size_t)src + 1]; rz[o] = P[3 * (size_t)src + 2];   // tie with it, and it is lower)
     }
     __syncthreads();
     if (a.csplit > 1) {   // row minima: lexicographic (distance, index) minimum over the column slices
@@ -299,48 +320,39 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
         }
     }
     for (int rep = 0; rep < a.fin_reps; ++rep) {
-        float v = cpv[0];
+        // minimum over the tiles and the LOWEST tile attaining it (strict compare), with that tile's four quarter minima
+        float4 win = cpv[0];
+        float v = fminf(fminf(win.x, win.y), fminf(win.z, win.w));
         int bt = 0;
-    #pragma unroll
-        for (int t = 1; t < CP; ++t)
-            if (t < tiles && cpv[t] < v) { v = cpv[t]; bt = t; }   // strict: the lowest tile wins ties
-        for (int t0 = CP; t0 < tiles; t0 += CP) {             // larger clouds: eight tile minima in flight per step (one load at a
-            float w[CP];                                      // time is a dependent chain of L2 round trips: 24 of them at n = 8192)
-    #pragma unroll
+#pragma unroll
+        for (int t = 1; t < CP; ++t) {
+            const float tv = fminf(fminf(cpv[t].x, cpv[t].y), fminf(cpv[t].z, cpv[t].w));
+            if (t < tiles && tv < v) { v = tv; bt = t; win = cpv[t]; }
+        }
+        for (int t0 = CP; t0 < tiles; t0 += CP) {             // larger clouds: eight tiles in flight per step
+            float4 w[CP];
+#pragma unroll
             for (int t = 0; t < CP; ++t) w[t] = colpart[(size_t)(t0 + t < tiles ? t0 + t : 0) * m + kc];
-    #pragma unroll
-            for (int t = 0; t < CP; ++t)
-                if (t0 + t < tiles && w[t] < v) { v = w[t]; bt = t0 + t; }
+#pragma unroll
+            for (int t = 0; t < CP; ++t) {
+                const float tv = fminf(fminf(w[t].x, w[t].y), fminf(w[t].z, w[t].w));
+                if (t0 + t < tiles && tv < v) { v = tv; bt = t0 + t; win = w[t]; }
+            }
         }
-        const int q0 = bt * CS_ROWS;
-        constexpr int SHARE = CS_ROWS / CF_Q;                 // rows per lane: [quarter * SHARE, +SHARE) of the tile
-        const float *sx = rx + bt * CF_SEG + quarter * SHARE, *sy = ry + bt * CF_SEG + quarter * SHARE, *sz = rz + bt * CF_SEG + quarter * SHARE;
-        // descending, four rows per step (one ds_read_b128 per plane): the last hit kept is the lowest row.  Fully unrolled:
-        // the row numbers are inline constants of the selects.  Rows beyond the cloud are staged as copies of its last row
-        // (above), so a padding row can only match where row n - 1 matches too -- and that one, being lower, is kept.
-        int found = INT_MAX;
-    #pragma unroll
-        for (int j4 = SHARE / 4 - 1; j4 >= 0; --j4) {
-            const float4 xa = *reinterpret_cast<const float4 *>(sx + 4 * j4);
-            const float4 ya = *reinterpret_cast<const float4 *>(sy + 4 * j4);
-            const float4 za = *reinterpret_cast<const float4 *>(sz + 4 * j4);
-            const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
-            const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
-            const int j = 4 * j4;
-            found = d3 == v ? j + 3 : found;
-            found = d2 == v ? j + 2 : found;
-            found = d1 == v ? j + 1 : found;
-            found = d0 == v ? j : found;
-        }
-        if (found != INT_MAX) found += quarter * SHARE;
-        found = min(found, __shfl_xor(found, 1));
-        found = min(found, __shfl_xor(found, 2));
+        const float *sx = rx + bt * CF_SEG, *sy = ry + bt * CF_SEG, *sz = rz + bt * CF_SEG;
+        const float qv[4] = {win.x, win.y, win.z, win.w};
+        int q1 = 3;                                           // lowest quarter attaining the minimum
+#pragma unroll
+        for (int q = 2; q >= 0; --q) q1 = qv[q] == v ? q : q1;
+        int found = finish_quarter(sx, sy, sz, q1, qx, qy, qz, v);
+        for (int q = q1 + 1; q < 4; ++q)                      // exact ties across quarters: rare
+            if (qv[q] == v) found = min(found, finish_quarter(sx, sy, sz, q, qx, qy, qz, v));
         if (found == INT_MAX) found = 0;                      // only if v is NaN-tainted (out of contract)
-        if (quarter == 0 && k < m) {
+        if (k < m) {
             pr.dist2[(size_t)c * m + k] = v;
-            pr.idx2[(size_t)c * m + k] = q0 + found;
+            pr.idx2[(size_t)c * m + k] = bt * CS_ROWS + found;
         }
-        if (rep + 1 < a.fin_reps) {                       // next sub-slice: its tile minima and coordinates
+        if (rep + 1 < a.fin_reps) {                       // next sub-slice: its partial minima and coordinates
             k += CF_COLS;
             kc = k < m ? k : m - 1;
 #pragma unroll
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
 
 constexpr int CS_MAX_SPLIT = 4;
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
-    return (size_t)pairs * b * cdiv(n, CS_ROWS) * m + 2 * (size_t)pairs * b * CS_MAX_SPLIT * n + 64;
+    return 4 * (size_t)pairs * b * cdiv(n, CS_ROWS) * m + 2 * (size_t)pairs * b * CS_MAX_SPLIT * n + 64;
 }
 
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
@@ -378,7 +390,7 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     // column slices so that the grid fills the chip (4 workgroups per CU resident): 1, 2 or 4
     a.csplit = 1;
     while (a.csplit < CS_MAX_SPLIT && (long)a.tiles * a.csplit * b * np < 256 && m / (a.csplit * 2) >= 256) a.csplit *= 2;   // measured: slicing only pays when the grid would not even cover the CUs
-    a.rowpart_d = workspace + (size_t)np * b * a.tiles * m;
+    a.rowpart_d = workspace + 4 * (size_t)np * b * a.tiles * m;
     a.rowpart_i = reinterpret_cast<int *>(a.rowpart_d + (size_t)np * b * CS_MAX_SPLIT * n);
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
@@ -391,7 +403,8 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     GA_LAUNCH_CHECK();
     const size_t lds = sizeof(float) * 3 * (size_t)a.tiles * CF_SEG;
     GA_REQUIRE(lds <= 150 * 1024, "chamfer_sym: too many rows (%d)", n);
-    a.fin_reps = a.tiles > 8 ? (a.tiles >= 32 ? 4 : 2) : 1;
+    // large clouds stage ~100 KB of rows per workgroup: several column sub-slices per staging, as long as every CU still gets a workgroup
+    a.fin_reps = a.tiles > 8 ? std::max(1, std::min(4, (int)((long)cdiv(m, CF_COLS) * b * np / kCUs))) : 1;
     chamfer_sym_finish_kernel<<<dim3(cdiv(m, CF_COLS * a.fin_reps), b * np), CF_THREADS, lds, stream>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
