@@ -40,7 +40,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_encoder.json")     # tools/pm
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep (profiles/r02_attack_sweep.json): ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- the honest
 # expectation for the strong-scaling leg (the latency floor of ten dependent launches does not shrink with the batch)
-SWEEP_MS = {32: 0.1991, 16: 0.1505, 8: 0.1077, 4: 0.0894}
+SWEEP_MS = {32: 0.1975, 16: 0.1482, 8: 0.1090, 4: 0.0906}
 
 
 def parse_args():
