@@ -20,7 +20,7 @@
 namespace geoadv {
 
 // ---- from the other translation units ------------------------------------------------------
-struct ChamferScan { const float *query; const float *target; float *dist; int *idx; int nq, nt; };
+struct ChamferScan { const float *query; const float *target; float *dist; int *idx; int nq, nt; const int *need; };
 int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t stream);
 struct ChamferPair { const float *p, *q; float *dist1; int *idx1; float *dist2; int *idx2; };
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
@@ -552,7 +552,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     // nn_distance(adv, x): adv = x + pert and most points barely move, so the exact grid search seeded with the pairing
     // (chamfer_grid.hip) answers it for a fraction of the all-pairs cost; clouds whose pairing has become poor raise
     // their `need` flag and are redone by the all-pairs launch below (same results either way)
-    const bool pruned = at->chamfer_prune && at->chamfer_sym && chamfer_grid_supports(n, n);
+    const bool pruned = at->chamfer_prune && chamfer_grid_supports(n, n);
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st, true);
         if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, at->adv_valid ? nullptr : at->adv, at->fs.pmax, at->fs.parg,
@@ -583,7 +583,8 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
                 if (int rc = launch_chamfer_sym_needed(pairs, 2, B, n, n, at->sym_ws, at->need_adv, st)) return rc;
             } else if (int rc = launch_chamfer_sym(pairs, 2, B, n, n, at->sym_ws, st)) return rc;
         } else {
-            const ChamferScan all[4] = {sc_recon[0], sc_recon[1], sc_adv[0], sc_adv[1]};
+            ChamferScan all[4] = {sc_recon[0], sc_recon[1], sc_adv[0], sc_adv[1]};
+            if (pruned) all[2].need = all[3].need = at->need_adv;      // only the clouds the grid search handed back
             if (int rc = launch_chamfer_scans(all, 4, B, st)) return rc;
         }
     }
@@ -780,13 +781,14 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
         at->chamfer_prune = e ? e[0] != '0' : cfg->all_pairs_source_dist == 0;
     }
     {
-        // Small batches (<= 16 K points in all: B <= 8 at N = 2048 -- what a GPU holds when ONE batch of 32 is split over 4 or
-        // 8): both Chamfer problems as the public op's four plain scans in ONE launch (20 us at B = 4) beat the symmetric
-        // scan + its finish launch + the grid search riding in the latent launch (16 + 11 + 2): every one of those is fixed
-        // latency there, not arithmetic.  From B = 16 on the symmetric form's halved arithmetic wins.  Same bits either way.
+        // Small batches (<= 40 K points in all: B <= 20 at N = 2048 -- what a GPU holds when ONE batch of 32 is split over 2, 4
+        // or 8): the public op's plain scans in ONE launch -- both directions of (recon, target), and of (adv, source) only
+        // for the clouds the grid search riding in the latent launch handed back -- beat the symmetric scan + its finish
+        // launch: launches are fixed latency there, not arithmetic (measured ms per iteration, plain / symmetric: B = 8:
+        // 0.102 / 0.113, 16: 0.135 / 0.148, 24: 0.178 / 0.174, 32: 0.200 / 0.197).  Same bits either way.
         // GEOADV_CHAMFER_SYM = 0 / 1 forces one form (the A/B of tests/test_gpu_attack.py).
         const char *e = getenv("GEOADV_CHAMFER_SYM");
-        at->chamfer_sym = e ? e[0] != '0' : (long)at->B * at->n > 16384;
+        at->chamfer_sym = e ? e[0] != '0' : (long)at->B * at->n > 40960;
     }
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;
     if (emd) { at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B); at->emd_g1 = F(4 * bn3); }

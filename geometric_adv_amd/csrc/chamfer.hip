@@ -31,14 +31,14 @@ struct ChamferScan {
     float *dist;          // [b, nq]
     int *idx;             // [b, nq]
     int nq, nt;
+    const int *need;      // null = every cloud; else int[8 * b] (16-byte aligned): cloud c is scanned only if one of its 8
+                          // flags is set (a workgroup of the paired grid search, chamfer_grid.hip, gave up on it)
 };
 struct ChamferArgs {
     ChamferScan s[4];
     int tiles, clouds, scans;   // 1-D grid decomposition (XCD aware, see the kernel)
 };
 
-constexpr int CH_THREADS = 256;
-constexpr int CH_WAVES = CH_THREADS / kWave;
 constexpr int CH_CHUNK = 8;        // targets per argmin chunk
 constexpr int CH_STAGE = 2048;     // targets per LDS stage: 3 planes x 8 KB (24 KB per workgroup, so that two
                                    // workgroups fit next to an encoder workgroup on one CU)
@@ -51,8 +51,13 @@ __device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, 
 
 // __launch_bounds__(256, 4): at most 128 VGPRs, so 4 workgroups (16 waves) fit per CU and the 1024
 // workgroups of the B = 32, N = 2048 attack step are all resident at once (no partial second round).
-template <int R>
-__global__ __launch_bounds__(CH_THREADS, 4) void chamfer_scan_kernel(ChamferArgs args) {
+// WAVES = 4 (256 threads) is the throughput shape.  WAVES = 16 (R = 1 only): the same 64 queries against the same staged
+// targets with each wave walking a sixteenth of them -- for launches too small to fill the chip (the attack loop at
+// B <= 8), where a workgroup's run time is one wave's serial walk (17 us for 512 targets) and nothing else is waiting
+// for the CU.
+template <int R, int WAVES>
+__global__ __launch_bounds__(kWave * WAVES, 16 / WAVES) void chamfer_scan_kernel(ChamferArgs args) {
+    constexpr int CH_THREADS = kWave * WAVES, CH_WAVES = WAVES;
     // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own
     // L2), so all query tiles of one (scan, cloud) group -- which stream the same target cloud -- are
     // given the same `blockIdx % 8`: the cloud is then fetched into ONE L2 instead of eight.
@@ -65,6 +70,10 @@ __global__ __launch_bounds__(CH_THREADS, 4) void chamfer_scan_kernel(ChamferArgs
     const int q0 = tile * (kWave * R);
     if (q0 >= nq) return;
     const int c = group % args.clouds;
+    if (sc.need) {
+        const int4 lo = reinterpret_cast<const int4 *>(sc.need)[2 * c], hi = reinterpret_cast<const int4 *>(sc.need)[2 * c + 1];
+        if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) return;
+    }
     const float *Q = sc.query + (size_t)c * nq * 3;
     const float *T = sc.target + (size_t)c * nt * 3;
 
@@ -138,24 +147,51 @@ __global__ __launch_bounds__(CH_THREADS, 4) void chamfer_scan_kernel(ChamferArgs
         }
     }
 
-    // Re-scan the winning chunk of every query for the first index attaining the minimum.
-    __syncthreads();   // every wave is done with the stage planes: they become the merge arrays
+    // Re-scan the winning chunk of every query for the first index attaining the minimum.  With a single LDS stage
+    // (nt <= 2048: the attack's shape) the chunk is still in the stage planes: two ds_read_b128 per plane, hits taken in
+    // DESCENDING order so that the last one kept is the lowest index (padding is +inf and never equals a finite minimum).
+    int found[R];
+    const bool staged = nt <= CH_STAGE;                    // uniform
+    if (staged) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int found = INT_MAX;
-        if (bestk[r] >= 0) {
-            found = bestk[r];
-            bool hit = false;
-            for (int u = 0; u < CH_CHUNK; ++u) {
-                const int k = bestk[r] + u;
-                if (k < nt) {
-                    const float d = sqdist(T[3 * (size_t)k], T[3 * (size_t)k + 1], T[3 * (size_t)k + 2], qx[r], qy[r], qz[r]);
-                    if (!hit && d == best[r]) { hit = true; found = k; }
+        for (int r = 0; r < R; ++r) {
+            found[r] = INT_MAX;
+            if (bestk[r] < 0) continue;                    // (uniform: a wave either scanned targets or did not)
+            const int kb = bestk[r];
+            const float4 xa = *reinterpret_cast<const float4 *>(&sx[kb]), xb = *reinterpret_cast<const float4 *>(&sx[kb + 4]);
+            const float4 ya = *reinterpret_cast<const float4 *>(&sy[kb]), yb = *reinterpret_cast<const float4 *>(&sy[kb + 4]);
+            const float4 za = *reinterpret_cast<const float4 *>(&sz[kb]), zb = *reinterpret_cast<const float4 *>(&sz[kb + 4]);
+            const float tx[CH_CHUNK] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            const float ty[CH_CHUNK] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+            const float tz[CH_CHUNK] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+            int f = kb;
+#pragma unroll
+            for (int u = CH_CHUNK - 1; u >= 0; --u)
+                f = sqdist(tx[u], ty[u], tz[u], qx[r], qy[r], qz[r]) == best[r] ? kb + u : f;
+            found[r] = f;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            found[r] = INT_MAX;
+            if (bestk[r] >= 0) {
+                found[r] = bestk[r];
+                bool hit = false;
+                for (int u = 0; u < CH_CHUNK; ++u) {
+                    const int k = bestk[r] + u;
+                    if (k < nt) {
+                        const float d = sqdist(T[3 * (size_t)k], T[3 * (size_t)k + 1], T[3 * (size_t)k + 2], qx[r], qy[r], qz[r]);
+                        if (!hit && d == best[r]) { hit = true; found[r] = k; }
+                    }
                 }
             }
         }
+    }
+    __syncthreads();   // every wave is done with the stage planes: they become the merge arrays
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
         mdist[wave][r * kWave + lane] = best[r];
-        midx[wave][r * kWave + lane] = found;
+        midx[wave][r * kWave + lane] = found[r];
     }
     __syncthreads();
     for (int qq = threadIdx.x; qq < kWave * R; qq += CH_THREADS) {
@@ -199,7 +235,6 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
     if (!live) return GEOADV_OK;
     // Pick the register blocking so that the grid still fills 256 CUs x 4 workgroups.
     auto groups = [&](int R) { return (long)cdiv(maxq, kWave * R) * b * live; };
-    dim3 block(CH_THREADS);
     args.clouds = b; args.scans = live;
     auto grid = [&](int R) {
         args.tiles = cdiv(maxq, kWave * R);
@@ -207,13 +242,16 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
     };
     if (groups(4) >= 768) {
         const dim3 g = grid(4);
-        chamfer_scan_kernel<4><<<g, block, 0, stream>>>(args);
+        chamfer_scan_kernel<4, 4><<<g, 256, 0, stream>>>(args);
     } else if (groups(2) >= 768) {
         const dim3 g = grid(2);
-        chamfer_scan_kernel<2><<<g, block, 0, stream>>>(args);
-    } else {
+        chamfer_scan_kernel<2, 4><<<g, 256, 0, stream>>>(args);
+    } else if (groups(1) > 1024) {
         const dim3 g = grid(1);
-        chamfer_scan_kernel<1><<<g, block, 0, stream>>>(args);
+        chamfer_scan_kernel<1, 4><<<g, 256, 0, stream>>>(args);
+    } else {                                               // fewer workgroups than the chip holds: shorten each one
+        const dim3 g = grid(1);
+        chamfer_scan_kernel<1, 16><<<g, 1024, 0, stream>>>(args);
     }
     GA_LAUNCH_CHECK();
     return GEOADV_OK;

@@ -1,0 +1,12 @@
+# kernel trace of the plain attack loop at batch $1 (default 32): bash tools/debug/prof_loop.sh [B]
+cd /tmp && export TMPDIR=/tmp
+B=${1:-32}
+rm -rf /tmp/pl
+rocprofv3 --kernel-trace --stats -d /tmp/pl -o pl --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/attack_breakdown.py $B > /tmp/pl.log 2>&1
+f=$(find /tmp/pl -name "*kernel_stats*" | head -1)
+python3 - "$f" <<PY
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:14]:
+    print("%-62s calls %5s avg %8.2f us %6s%%" % (r["Name"][:62], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+PY
+grep -o '{"batch.*' /tmp/pl.log | cut -c1-400

@@ -1,0 +1,11 @@
+"""ms per iteration with the symmetric scan forced on / off around the small-batch threshold (attack.hip: chamfer_sym).
+    python tools/debug/sym_threshold.py [B ...]"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+code = "import sys; sys.path.insert(0, %r + '/tools'); import attack_sweep as s, json; print(json.dumps(s.run(int(sys.argv[1]), 2048, 300)))" % ROOT
+for B in [int(a) for a in sys.argv[1:]] or [8, 12, 16, 24]:
+    row = {"batch": B}
+    for sym in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", code, str(B)], env=dict(os.environ, GEOADV_CHAMFER_SYM=sym), capture_output=True, text=True).stdout
+        row["sym" + sym] = round(json.loads(out.strip().splitlines()[-1])["ms_per_iteration"], 4)
+    print(json.dumps(row), flush=True)
