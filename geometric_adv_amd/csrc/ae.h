@@ -15,6 +15,9 @@ struct PackedLayer {
     const float *w;   // packed fragments (device)
     int K, N;         // fan-in, (padded) fan-out
 };
+// The same for v_mfma_f32_16x16x4_f32 (16-row tiles: the masked encoder backward): K a multiple of 16, N of 16,
+//   packed16[((cb * K/16 + t) * 64 + lane) * 4 + u] = W[16t + 4*(lane>>4) + u][16cb + (lane&15)]
+// -- again one coalesced 1 KiB load per wave for the B operands of four consecutive MFMA k-steps of column block cb.
 
 struct DeviceAE {
     int n_points, bneck;
@@ -24,6 +27,7 @@ struct DeviceAE {
     const float *w0;               // [3][C1]
     PackedLayer enc_fwd[ENC_L];    // [1..4] used: in[r][C_i] -> [C_{i+1}]
     PackedLayer enc_bwd[ENC_L];    // [1..4] used: W_i^T : [C_{i+1}] -> [C_i]
+    PackedLayer enc_bwd16[ENC_L];  // the same products packed for the 16x16x4 shape
     const float *scale[ENC_L];     // BN folded: h = max(a*scale + shift, 0), a = x@W (no bias)
     const float *shift[ENC_L];     // shift = b*scale + (beta - mean*scale)
     // decoder

@@ -29,6 +29,19 @@ static void pack_fragments(std::vector<float> &dst, size_t off, int K, int N, in
                 }
 }
 
+// the 16x16x4 packing (ae.h)
+template <class F>
+static void pack_fragments16(std::vector<float> &dst, size_t off, int K, int N, int Kp, int Np, F at) {
+    const int kg = Kp / 16;
+    for (int cb = 0; cb < Np / 16; ++cb)
+        for (int t = 0; t < kg; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 16 * t + 4 * (lane >> 4) + u, n = 16 * cb + (lane & 15);
+                    dst[off + (((size_t)cb * kg + t) * 64 + lane) * 4 + u] = (k < K && n < N) ? at(k, n) : 0.f;
+                }
+}
+
 struct ForwardScratch {
     float *pmax; int *parg; int *pcnt;   // [b][tiles][128]
     float *z; int *crit; int *zcnt;      // [b][128]
@@ -92,10 +105,11 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     std::vector<float> host;
     auto reserve = [&](size_t count) { size_t off = rup(host.size(), 64); host.resize(off + count, 0.f); return off; };
     size_t o_w0 = reserve(3 * C[1]);
-    size_t o_fwd[ENC_L] = {0}, o_bwd[ENC_L] = {0}, o_scale[ENC_L], o_shift[ENC_L];
+    size_t o_fwd[ENC_L] = {0}, o_bwd[ENC_L] = {0}, o_bwd16[ENC_L] = {0}, o_scale[ENC_L], o_shift[ENC_L];
     for (int i = 1; i < ENC_L; ++i) {
         o_fwd[i] = reserve((size_t)C[i] * C[i + 1]);
         o_bwd[i] = reserve((size_t)C[i] * C[i + 1]);
+        o_bwd16[i] = reserve((size_t)C[i] * C[i + 1]);
     }
     for (int i = 0; i < ENC_L; ++i) { o_scale[i] = reserve(C[i + 1]); o_shift[i] = reserve(C[i + 1]); }
     size_t o_v0 = reserve(128 * 256), o_c0 = reserve(256), o_v1 = reserve(256 * 256), o_c1 = reserve(256);
@@ -109,6 +123,7 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
         pack_fragments(host, o_fwd[i], K, N, K, N, [&](int k, int nn) { return W[(size_t)k * N + nn]; });
         // transposed product: B[k][nn] = W[nn][k], K' = N, N' = K
         pack_fragments(host, o_bwd[i], N, K, N, (int)rup(K, 32), [&](int k, int nn) { return W[(size_t)nn * N + k]; });
+        pack_fragments16(host, o_bwd16[i], N, K, N, K, [&](int k, int nn) { return W[(size_t)nn * N + k]; });   // (widths are multiples of 64)
     }
     for (int i = 0; i < ENC_L; ++i)
         for (int c = 0; c < C[i + 1]; ++c) {
@@ -157,6 +172,7 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     for (int i = 0; i < ENC_L; ++i) {
         d.enc_fwd[i] = PackedLayer{i ? base + o_fwd[i] : nullptr, C[i], C[i + 1]};
         d.enc_bwd[i] = PackedLayer{i ? base + o_bwd[i] : nullptr, C[i + 1], (int)rup(C[i], 32)};
+        d.enc_bwd16[i] = PackedLayer{i ? base + o_bwd16[i] : nullptr, C[i + 1], C[i]};
         d.scale[i] = base + o_scale[i];
         d.shift[i] = base + o_shift[i];
     }

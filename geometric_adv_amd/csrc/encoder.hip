@@ -489,12 +489,16 @@ __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const
 }
 
 
-// Sparse backward from the forward's ReLU masks: no recompute.  grid = (128 / 32, batch); a workgroup handles 32 of the
-// cloud's 128 critical rows (slot c = the arg-max row of channel c; a row listed several times is computed several times
-// with the same result).  da4[slot][c] = dz[c] * scale4[c] where that slot's row IS the arg-max of channel c and z > 0
-// (clouds with a tied maximum are flagged and go through the dense, recomputing launch instead).
-constexpr int BWM_ROWS = 32;
-constexpr size_t BWM_LDS_BYTES = sizeof(float) * (BWM_ROWS * 260 + BWM_ROWS * 132 + 3 * 2 * 16 * 64 + 128) +
+// Sparse backward from the forward's ReLU masks: no recompute.  A workgroup handles 16 of the cloud's 128 critical rows
+// (slot c = the arg-max row of channel c; a row listed several times is computed several times with the same result) on
+// the 16x16x4 MFMA shape (mfma_tile.h: layer_gemm16): 8 workgroups per cloud -- every CU at B = 32, where 32-row tiles
+// left half of them idle -- and half the matrix time per workgroup.  da4[slot][c] = dz[c] * scale4[c] where that slot's
+// row IS the arg-max of channel c and z > 0 (clouds with a tied maximum are flagged and go through the dense, recomputing
+// path instead).  The products are the recomputing path's, summed in the 16x16x4 pipe's order instead of the 32x32x2
+// one's: the two paths agree to rounding, not bit for bit.
+constexpr int BWM_ROWS = 16;
+constexpr int BWM_SCALES = 64 + 128 + 128 + 256;       // scale0 .. scale3, staged once
+constexpr size_t BWM_LDS_BYTES = sizeof(float) * (BWM_ROWS * 260 + BWM_ROWS * 132 + BWM_SCALES + 128) +
                                  sizeof(int) * (BWM_ROWS + 128) + sizeof(unsigned) * BWM_ROWS * MASK_WORDS;
 
 __device__ __forceinline__ void encoder_bwd_masked_body(const DeviceAE &A, int n, const unsigned *masks, const int *rows,
@@ -502,6 +506,80 @@ __device__ __forceinline__ void encoder_bwd_masked_body(const DeviceAE &A, int n
                                                         float *g_enc, const int bx, const int b) {
     if (dense_flag[b] != 0) return;
     constexpr int ROWS = BWM_ROWS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *bufP = lds;                                  // [16][260]
+    float *bufQ = bufP + ROWS * 260;                    // [16][132]
+    float *sc0 = bufQ + ROWS * 132;                     // BN scales of layers 0..3
+    float *sc1 = sc0 + 64, *sc2 = sc1 + 128, *sc3 = sc2 + 128;
+    float *dzs = sc0 + BWM_SCALES;                      // [128] dz * scale4 where z > 0
+    int *rowid = reinterpret_cast<int *>(dzs + 128);    // [16]
+    int *crit = rowid + ROWS;                           // [128]
+    unsigned *mw = reinterpret_cast<unsigned *>(crit + 128);   // [16][MASK_WORDS]
+    const int r0 = bx * ROWS;
+    // weights are requested one layer ahead of their use (mfma_tile.h: Frag16): the first two before anything else
+    Frag16<128, 256> f4;
+    Frag16<256, 128> f3;
+    Frag16<128, 128> f2;
+    Frag16<128, 64> f1;
+    frag16_load(f4, A.enc_bwd16[4]);
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        crit[c] = rows[(size_t)b * 128 + c];
+        dzs[c] = z[(size_t)b * 128 + c] > 0.f ? dz[(size_t)b * 128 + c] * A.scale[4][c] : 0.f;
+        sc1[c] = A.scale[1][c]; sc2[c] = A.scale[2][c];
+        if (c < 64) sc0[c] = A.scale[0][c];
+    } else if (threadIdx.x < 384) {
+        sc3[threadIdx.x - 128] = A.scale[3][threadIdx.x - 128];
+    }
+    __syncthreads();
+    if (threadIdx.x < ROWS) rowid[threadIdx.x] = crit[r0 + threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < ROWS * MASK_WORDS; e += ENC_THREADS)
+        mw[e] = masks[((size_t)b * n + rowid[e / MASK_WORDS]) * MASK_WORDS + e % MASK_WORDS];
+    for (int e = threadIdx.x; e < ROWS * 128; e += ENC_THREADS) {
+        const int s = e >> 7, c = e & 127;
+        bufQ[s * 132 + c] = crit[c] == rowid[s] ? dzs[c] : 0.f;
+    }
+    __syncthreads();
+    auto bit = [&](int row, int off, int c) { return (mw[row * MASK_WORDS + off + (c >> 5)] >> (c & 31)) & 1u; };
+    // dh4 = da4 @ W4^T (128 -> 256); da3 = dh4 * mask4 * scale3   into bufP
+    frag16_load(f3, A.enc_bwd16[3]);
+    layer_gemm16(bufQ, 132, f4, [&](int row, int c, float a) { bufP[row * 260 + c] = bit(row, MASK_OFF4, c) ? a * sc3[c] : 0.f; });
+    __syncthreads();
+    // dh3 = da3 @ W3^T (256 -> 128); da2 = dh3 * mask3 * scale2   into bufQ
+    frag16_load(f2, A.enc_bwd16[2]);
+    layer_gemm16(bufP, 260, f3, [&](int row, int c, float a) { bufQ[row * 132 + c] = bit(row, MASK_OFF3, c) ? a * sc2[c] : 0.f; });
+    __syncthreads();
+    // dh2 = da2 @ W2^T (128 -> 128); da1 = dh2 * mask2 * scale1   into bufP (stride 132)
+    frag16_load(f1, A.enc_bwd16[1]);
+    layer_gemm16(bufQ, 132, f2, [&](int row, int c, float a) { bufP[row * 132 + c] = bit(row, MASK_OFF2, c) ? a * sc1[c] : 0.f; });
+    __syncthreads();
+    // dh1 = da1 @ W1^T (128 -> 64); da0 = dh1 * mask1 * scale0   into bufQ (stride 68)
+    layer_gemm16(bufP, 132, f1, [&](int row, int c, float a) { bufQ[row * 68 + c] = bit(row, 0, c) ? a * sc0[c] : 0.f; });
+    __syncthreads();
+    if (threadIdx.x < ROWS * 3) {   // dh0 = da0 @ W0^T (64 -> 3) on the VALU
+        const int r = threadIdx.x / 3, a = threadIdx.x % 3;
+        float s = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) s = fmaf(bufQ[r * 68 + c], A.w0[a * 64 + c], s);
+        g_enc[((size_t)b * n + rowid[r]) * 3 + a] = s;
+    }
+}
+
+// The same on 32-row tiles and the 32x32x2 shape (layer_gemm): the throughput form, for batches whose 16-row workgroups
+// would need more than one round of the chip (B > 32).  A workgroup handles 32 of the
+// cloud's 128 critical rows (slot c = the arg-max row of channel c; a row listed several times is computed several times
+// with the same result).  da4[slot][c] = dz[c] * scale4[c] where that slot's row IS the arg-max of channel c and z > 0
+// (clouds with a tied maximum are flagged and go through the dense, recomputing launch instead).
+constexpr int BWM32_ROWS = 32;
+constexpr size_t BWM32_LDS_BYTES = sizeof(float) * (BWM32_ROWS * 260 + BWM32_ROWS * 132 + 3 * 2 * 16 * 64 + 128) +
+                                 sizeof(int) * (BWM32_ROWS + 128) + sizeof(unsigned) * BWM32_ROWS * MASK_WORDS;
+
+__device__ __forceinline__ void encoder_bwd_masked32_body(const DeviceAE &A, int n, const unsigned *masks, const int *rows,
+                                                        const float *z, const float *dz, const int *dense_flag,
+                                                        float *g_enc, const int bx, const int b) {
+    if (dense_flag[b] != 0) return;
+    constexpr int ROWS = BWM32_ROWS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufP = lds;                                  // [32][260]
     float *bufQ = bufP + ROWS * 260;                    // [32][132]
@@ -596,17 +674,19 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(DeviceAE A, in
     }
 }
 
-// Both backward launches in one: blocks [0, 4 * batch) = masked sparse path, the rest = the dense path for clouds with a
+// Both backward launches in one: blocks [0, 8 * batch) (or 4 * batch: 32-row form) = masked sparse path, the rest = the dense path for clouds with a
 // tied maximum (its blocks read the flags and leave at once when there is none -- which is almost always).  A launch of
 // its own for that check costs ~4 us per iteration.
 constexpr int BWD_MERGED_DENSE_SLOTS = 2;
 __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_merged_kernel(DeviceAE A, int n, int batch, const unsigned *masks,
                                                                         const int *rows, const float *z, const int *zcnt,
                                                                         const float *dz, const int *dense_flag, const float *adv,
-                                                                        float *g_enc) {
-    const int nm = (128 / BWM_ROWS) * batch;
+                                                                        float *g_enc, int rows16) {
+    const int per = rows16 ? 128 / BWM_ROWS : 128 / BWM32_ROWS;
+    const int nm = per * batch;
     if ((int)blockIdx.x < nm) {
-        encoder_bwd_masked_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % (128 / BWM_ROWS), blockIdx.x / (128 / BWM_ROWS));
+        if (rows16) encoder_bwd_masked_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % per, blockIdx.x / per);
+        else encoder_bwd_masked32_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % per, blockIdx.x / per);
         return;
     }
     const int d = blockIdx.x - nm, tiles = (n + 63) / 64, tile = d % tiles, slot = d / tiles;
@@ -695,9 +775,12 @@ int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *cr
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
     if (masks) {
-        const size_t lds = BWM_LDS_BYTES > EncLds<64>::bwd_bytes ? BWM_LDS_BYTES : EncLds<64>::bwd_bytes;
-        const int grid = (128 / BWM_ROWS) * b + cdiv(A.n_points, 64) * BWD_MERGED_DENSE_SLOTS;
-        encoder_bwd_merged_kernel<<<grid, ENC_THREADS, lds, stream>>>(A, A.n_points, b, masks, crit_rows, z, zcnt, dz, dense_flag, adv, g_enc);
+        // 16-row workgroups (8 per cloud) while they fit the chip in one round, else the 32-row throughput form
+        // (ms per iteration, 16 / 32 rows: B = 4: 0.079 / 0.086, 32: 0.192 / 0.197, 64: 0.327 / 0.322, 256: 1.129 / 1.109)
+        const int rows16 = (128 / BWM_ROWS) * b <= kCUs;
+        const size_t lds = std::max(std::max(BWM_LDS_BYTES, BWM32_LDS_BYTES), EncLds<64>::bwd_bytes);
+        const int grid = (rows16 ? 128 / BWM_ROWS : 128 / BWM32_ROWS) * b + cdiv(A.n_points, 64) * BWD_MERGED_DENSE_SLOTS;
+        encoder_bwd_merged_kernel<<<grid, ENC_THREADS, lds, stream>>>(A, A.n_points, b, masks, crit_rows, z, zcnt, dz, dense_flag, adv, g_enc, rows16);
         GA_LAUNCH_CHECK();
         return GEOADV_OK;
     }

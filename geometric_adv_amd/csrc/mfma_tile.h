@@ -158,6 +158,63 @@ __device__ __forceinline__ void layer_gemm(const float *in, int s_in, const Pack
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 16-row tiles on v_mfma_f32_16x16x4_f32 (PackedLayer packed16, ae.h): out tile [16][NOUT] = in tile [16][K] @ W.
+// For work that has only a few rows per cloud -- the masked encoder backward: 128 critical rows -- 16-row tiles give twice
+// the workgroups of 32-row ones, i.e. every CU instead of half of them at B = 32, and half the MFMA time per workgroup.
+// A operand of k-step u of k-group t: in[lane & 15][16 t + 4 (lane >> 4) + u] (one ds_read_b128 per k-group); B: the
+// lane's 16 bytes of the packed fragment; C: rows 4 (lane >> 4) + r, column lane & 15.  NOUT / 16 column tiles are dealt
+// to the 8 waves, CN = NOUT / 128 per wave (sharing the A fragments) -- or one each to the first NOUT / 16 waves.  K and
+// NOUT are compile-time: the chain is fully unrolled and all of a wave's fragment loads of a layer are in flight at once
+// (at most 16 fragments = 64 VGPRs).  Must be called by every wave of the workgroup; no barrier inside.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A wave's B fragments of one layer.  Loading them is a step of its own (frag16_load) so that the caller can request the
+// NEXT layer's weights before it multiplies the current one: weights do not depend on activations, and a layer of this
+// size is one L2 round trip of latency against ~1 us of MFMA time.
+template <int K, int NOUT> struct Frag16 {
+    static constexpr int TILES = NOUT / 16, CN = TILES >= 8 ? TILES / 8 : 1, KG = K / 16;
+    float4 b[CN][KG];
+};
+template <int K, int NOUT>
+__device__ __forceinline__ void frag16_load(Frag16<K, NOUT> &f, const PackedLayer &L) {
+    using F = Frag16<K, NOUT>;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave * F::CN >= F::TILES) return;
+    const unsigned lb = (unsigned)(threadIdx.x & 63) * 16u;
+#pragma unroll
+    for (int cn = 0; cn < F::CN; ++cn) {
+        const FragSrc bp = frag_src(L.w, (wave * F::CN + cn) * F::KG);
+#pragma unroll
+        for (int t = 0; t < F::KG; ++t) f.b[cn][t] = ld_frag(bp, t, lb);
+    }
+}
+template <int K, int NOUT, class Epi>
+__device__ __forceinline__ void layer_gemm16(const float *in, int s_in, const Frag16<K, NOUT> &f, Epi epi) {
+    using F = Frag16<K, NOUT>;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave * F::CN >= F::TILES) return;
+    const int q = lane >> 4, m = lane & 15;
+    const float *ar = in + m * s_in + 4 * q;
+    f32x4 acc[F::CN] = {};
+#pragma unroll
+    for (int t = 0; t < F::KG; ++t) {
+        const float4 a = *reinterpret_cast<const float4 *>(ar + 16 * t);
+#pragma unroll
+        for (int cn = 0; cn < F::CN; ++cn) {
+            acc[cn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, f.b[cn][t].x, acc[cn], 0, 0, 0);
+            acc[cn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, f.b[cn][t].y, acc[cn], 0, 0, 0);
+            acc[cn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, f.b[cn][t].z, acc[cn], 0, 0, 0);
+            acc[cn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, f.b[cn][t].w, acc[cn], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int cn = 0; cn < F::CN; ++cn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epi(4 * q + r, (wave * F::CN + cn) * 16 + m, acc[cn][r]);
+}
+
 // The output column layer_gemm<ROWS, NOUT, *> hands to the calling lane's epilogue (constant per lane).
 template <int ROWS, int NOUT>
 __device__ __forceinline__ int layer_gemm_lane_col() {
