@@ -146,6 +146,11 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
                         colp[hf * CS_CHUNK + u] = r == 0 ? d : fminf(colp[hf * CS_CHUNK + u], d);
                     }
                     if (cm < best[r]) { best[r] = cm; bestk[r] = t0 + k0 + hf * CS_CHUNK; }
+                    // one row's eight distances die here: left alone the scheduler evaluates all 64 of the round first and
+                    // folds the minima afterwards -- 54 VGPRs of live distances at the 128-register cap, spills around the
+                    // loop (measured 32.5 -> 31.2 us).  (Fetching the next half's columns ahead on top of this spills 36
+                    // registers: 56 us.)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // 64-lane reduction of the 16 column partials through LDS: [column][lane] -> 4 lanes per column
