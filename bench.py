@@ -40,7 +40,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_encoder.json")     # tools/pm
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep (profiles/r02_attack_sweep.json): ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- the honest
 # expectation for the strong-scaling leg (the latency floor of ten dependent launches does not shrink with the batch)
-SWEEP_MS = {32: 0.1914, 16: 0.1286, 8: 0.0953, 4: 0.0786}
+SWEEP_MS = {32: 0.1899, 16: 0.1289, 8: 0.0946, 4: 0.0789}
 
 
 def parse_args():
