@@ -69,6 +69,31 @@ def test_nn_distance_vs_oracle(dev, oracle, b, n, m):
     assert np.array_equal(_bits(g2.cpu().numpy()), _bits(wg2))
 
 
+def test_nn_distance_random_shapes_vs_oracle(dev, oracle):
+    """Forty random (b, n, m) from one point to a few thousand, with exact duplicates and lattice coordinates (ties) mixed in:
+    every register blocking / workgroup shape the launcher picks -- 4 or 16 waves, 1, 2 or 4 queries per lane, ragged last
+    tiles and chunks, several LDS stages -- against the pinned oracle, bit for bit."""
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        b = int(rng.integers(1, 40)) if trial % 4 else int(rng.integers(1, 4))
+        n = int(rng.integers(1, 300)) if trial % 3 == 0 else int(rng.integers(1, 3000))
+        m = int(rng.integers(1, 300)) if trial % 5 == 0 else int(rng.integers(1, 5000))
+        if b * max(n, m) > 60000:
+            b = max(1, 60000 // max(n, m))
+        x1 = rng.random((b, n, 3), dtype=np.float32)
+        x2 = rng.random((b, m, 3), dtype=np.float32)
+        if trial % 2:                                                    # a coarse lattice: many exactly equal distances
+            x1, x2 = np.round(x1 * 4) / 4, np.round(x2 * 4) / 4
+        if trial % 7 == 0 and m > 1:                                     # duplicated targets: the lowest index must win
+            x2[:, m // 2:] = x2[:, : m - m // 2]
+        x1, x2 = x1.astype(np.float32), x2.astype(np.float32)
+        want = oracle.nn_distance(x1, x2)
+        got = ops.nn_distance(_t(x1, dev), _t(x2, dev))
+        for w, gt, what in zip(want, got, ["dist1", "idx1", "dist2", "idx2"]):
+            assert np.array_equal(_bits(gt.cpu().numpy()), _bits(w)), (trial, b, n, m, what)
+
+
 def test_nn_distance_full_size_properties(dev):
     """Config-2 size (B=32, N=2048): size-independent properties instead of a CPU re-run:
     a cloud against itself gives idx = identity / dist = 0; against a permuted copy gives the
