@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <algorithm>
 #include <mutex>
 #include "../../include/geoadv.h"
 
