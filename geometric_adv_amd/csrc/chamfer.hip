@@ -51,7 +51,8 @@ __device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, 
 
 // __launch_bounds__(256, 4): at most 128 VGPRs, so 4 workgroups (16 waves) fit per CU and the 1024
 // workgroups of the B = 32, N = 2048 attack step are all resident at once (no partial second round).
-// WAVES = 4 (256 threads) is the throughput shape.  WAVES = 16 (R = 1 only): the same 64 queries against the same staged
+// WAVES = 4 (256 threads) is the throughput shape; WAVES = 8 keeps R = 4 when there are only 384..767 query tiles (B = 32,
+// N = 2048 through the public op: 52.6 -> 49.6 us against R = 2 on 4 waves).  WAVES = 16 (R = 1 only): the same 64 queries against the same staged
 // targets with each wave walking a sixteenth of them -- for launches too small to fill the chip (the attack loop at
 // B <= 8), where a workgroup's run time is one wave's serial walk (17 us for 512 targets) and nothing else is waiting
 // for the CU.
@@ -243,6 +244,9 @@ int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t
     if (groups(4) >= 768) {
         const dim3 g = grid(4);
         chamfer_scan_kernel<4, 4><<<g, 256, 0, stream>>>(args);
+    } else if (groups(4) >= 384) {                         // half as many workgroups of twice the waves: still 4 queries per lane
+        const dim3 g = grid(4);
+        chamfer_scan_kernel<4, 8><<<g, 512, 0, stream>>>(args);
     } else if (groups(2) >= 768) {
         const dim3 g = grid(2);
         chamfer_scan_kernel<2, 4><<<g, 256, 0, stream>>>(args);
