@@ -781,14 +781,14 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
         at->chamfer_prune = e ? e[0] != '0' : cfg->all_pairs_source_dist == 0;
     }
     {
-        // Small batches (<= 36 K points in all: B <= 18 at N = 2048 -- what a GPU holds when ONE batch of 32 is split over 2, 4
+        // Small batches (<= 34 K points in all: B <= 17 at N = 2048 -- what a GPU holds when ONE batch of 32 is split over 2, 4
         // or 8): the public op's plain scans in ONE launch -- both directions of (recon, target), and of (adv, source) only
         // for the clouds the grid search riding in the latent launch handed back -- beat the symmetric scan + its finish
         // launch: launches are fixed latency there, not arithmetic (measured ms per iteration, plain / symmetric: B = 8:
-        // 0.102 / 0.113, 12: 0.129 / 0.129, 16: 0.130 / 0.140, 20: 0.167 / 0.164, 24: 0.170 / 0.164).  Same bits either way.
+        // 0.096 / 0.105, 12: 0.127 / 0.130, 16: 0.129 / 0.141, 18: 0.168 / 0.163, 20: 0.167 / 0.164, 24: 0.170 / 0.164).  Same bits either way.
         // GEOADV_CHAMFER_SYM = 0 / 1 forces one form (the A/B of tests/test_gpu_attack.py).
         const char *e = getenv("GEOADV_CHAMFER_SYM");
-        at->chamfer_sym = e ? e[0] != '0' : (long)at->B * at->n > 36864;
+        at->chamfer_sym = e ? e[0] != '0' : (long)at->B * at->n > 34816;
     }
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;
     if (emd) { at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B); at->emd_g1 = F(4 * bn3); }
