@@ -39,8 +39,8 @@ PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep (profiles/r02_attack_sweep.json): ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- the honest
-# expectation for the strong-scaling leg (the latency floor of ten dependent launches does not shrink with the batch)
-SWEEP_MS = {32: 0.1899, 16: 0.1289, 8: 0.0946, 4: 0.0789}
+# expectation for the strong-scaling leg (the latency floor of nine dependent launches does not shrink with the batch)
+SWEEP_MS = {32: 0.1871, 16: 0.1256, 8: 0.0927, 4: 0.0762}
 
 
 def parse_args():
@@ -457,7 +457,7 @@ def main():
                                      "(SURVEY 8e); every rank runs the whole loop on its 32/N clouds, final scalars all-gathered",
                        "global_batch": B, "batch_per_gpu": bs,
                        "expected_speedup_vs_1gpu_from_r01_sweep": (SWEEP_MS[32] / exp) if exp else None,
-                       "expectation_note": "an iteration is ten dependent launches whose latency floor (0.075 ms at B = 1) does not "
+                       "expectation_note": "an iteration is nine dependent launches whose latency floor (0.073 ms at B = 1) does not "
                                            "shrink with the batch: the >= 6x target of the north star is a weak-scaling figure here"})
 
     if world > 1:                                # every collective of the run is behind us: leave the group cleanly on all ranks

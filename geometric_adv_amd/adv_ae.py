@@ -200,7 +200,7 @@ class AdvAE:
         return np.concatenate(metrics, axis=1), np.concatenate(pcs_in, axis=1), np.concatenate(pcs_rec, axis=1)
 
     def _attack_slots(self, source_pc, target_latent, target_pc, target_ae_loss_ref, n_batches, log_file):
-        """The batch loop with `batch_slots` batches in flight on this GPU.  A B = 32 iteration is ten dependent launches and
+        """The batch loop with `batch_slots` batches in flight on this GPU.  A B = 32 iteration is nine dependent launches and
         leaves the chip part idle between them; independent batches fill those gaps (two slots: +31 % iterations/s on
         MI355X, tools/two_slots.py).  Every slot is one attack handle with its own stream and host thread and takes a
         contiguous run of batches, exactly like one rank of dist.shard_batches -- including that rank's Adam slots, which

@@ -39,6 +39,15 @@ struct DeviceAE {
     const float *c2;               // [3*n_points]
 };
 
+// The attack's Adam step on `pert` folded into the NEXT encoder forward (attack.hip): the forward's point loaders update
+// their own coordinate first.  m == nullptr: off.  Same arithmetic as adam_kernel, element by element.
+struct FusedAdam {
+    float *pert, *m, *v, *g_enc;     // g_enc is read and zeroed (the next backward scatters into it)
+    const float *g_dist;
+    float *grad_out;                 // optional copy of the total gradient (tests)
+    float alpha, one_minus_b1, one_minus_b2, eps;
+};
+
 }  // namespace geoadv
 
 struct geoadv_ae {

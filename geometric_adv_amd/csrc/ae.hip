@@ -8,7 +8,8 @@
 namespace geoadv {
 
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
+                       const FusedAdam *fused = nullptr);
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
 int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);

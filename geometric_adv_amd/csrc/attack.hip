@@ -40,7 +40,8 @@ struct ForwardScratch {
 };
 ForwardScratch carve_forward_scratch(void *base, int b, int n_points);
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
+                       const FusedAdam *fused = nullptr);
 int encoder_mask_words();
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
@@ -462,6 +463,9 @@ struct geoadv_attack {
     float beta1_pow, beta2_pow;
     bool fwd_valid;
     bool adv_valid;                  // adv == x + pert already (written by the Adam kernel)
+    bool fuse_adam;                  // the Adam step rides in the next forward's point loads (GEOADV_FUSED_ADAM=0: own launch)
+    bool adam_pending;               // ... and one is waiting there
+    FusedAdam pending;
     // profiling
     unsigned prof_mask;
     int prof_stride;                 // time every prof_stride-th launch of a selected class (1 = every launch)
@@ -555,8 +559,10 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     const bool pruned = at->chamfer_prune && chamfer_grid_supports(n, n);
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st, true);
-        if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, at->adv_valid ? nullptr : at->adv, at->fs.pmax, at->fs.parg,
-                                        at->fs.pcnt, at->masks, st, ps.start(), ps.stop())) return rc;
+        if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, (at->adv_valid && !at->adam_pending) ? nullptr : at->adv, at->fs.pmax,
+                                        at->fs.parg, at->fs.pcnt, at->masks, st, ps.start(), ps.stop(),
+                                        at->adam_pending ? &at->pending : nullptr)) return rc;
+        at->adam_pending = false;
         at->adv_valid = true;
     }
     {
@@ -677,23 +683,31 @@ int do_step(geoadv_attack *at, hipStream_t st) {
             return rc;
     }
     {
-        ProfScope ps(at, GEOADV_PROF_ADAM, st);
-        AdamArgs aa;
-        aa.n = n; aa.B = B; aa.pert = at->pert; aa.m = at->m; aa.v = at->v; aa.g_enc = at->g_enc;
-        aa.g_dist = dist_chamfer ? at->g_dist : nullptr; aa.w = at->w; aa.losses = at->losses; aa.jstar = at->jstar;
-        aa.loss_dist_type = at->cfg.loss_dist_type; aa.mp_pert_w = at->cfg.max_point_pert_weight;
         const float beta1 = 0.9f, beta2 = 0.999f;
-        aa.alpha = at->cfg.learning_rate * sqrtf(1.0f - at->beta2_pow) / (1.0f - at->beta1_pow);
-        aa.one_minus_b1 = 1.0f - beta1; aa.one_minus_b2 = 1.0f - beta2; aa.eps = 1e-8f;
-        aa.grad_out = at->grad_last; aa.x = at->x; aa.adv_out = at->adv;
-        const size_t total = (size_t)B * n * 3;
-        adam_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(aa);
-        GA_LAUNCH_CHECK();
+        const float alpha = at->cfg.learning_rate * sqrtf(1.0f - at->beta2_pow) / (1.0f - at->beta1_pow);
+        if (at->fuse_adam && dist_chamfer) {
+            // every element's update only needs that element: the next forward's point loaders do it on their way in (one
+            // launch less per iteration; attack_run always follows a step with a forward)
+            at->pending = FusedAdam{at->pert, at->m, at->v, at->g_enc, at->g_dist, at->grad_last, alpha, 1.0f - beta1, 1.0f - beta2, 1e-8f};
+            at->adam_pending = true;
+        } else {
+            ProfScope ps(at, GEOADV_PROF_ADAM, st);
+            AdamArgs aa;
+            aa.n = n; aa.B = B; aa.pert = at->pert; aa.m = at->m; aa.v = at->v; aa.g_enc = at->g_enc;
+            aa.g_dist = dist_chamfer ? at->g_dist : nullptr; aa.w = at->w; aa.losses = at->losses; aa.jstar = at->jstar;
+            aa.loss_dist_type = at->cfg.loss_dist_type; aa.mp_pert_w = at->cfg.max_point_pert_weight;
+            aa.alpha = alpha;
+            aa.one_minus_b1 = 1.0f - beta1; aa.one_minus_b2 = 1.0f - beta2; aa.eps = 1e-8f;
+            aa.grad_out = at->grad_last; aa.x = at->x; aa.adv_out = at->adv;
+            const size_t total = (size_t)B * n * 3;
+            adam_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(aa);
+            GA_LAUNCH_CHECK();
+        }
         at->beta1_pow *= beta1;
         at->beta2_pow *= beta2;
     }
     at->fwd_valid = false;
-    at->adv_valid = true;
+    at->adv_valid = !at->adam_pending;
     return GEOADV_OK;
 }
 
@@ -793,6 +807,11 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;
     if (emd) { at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B); at->emd_g1 = F(4 * bn3); }
     at->cgrad_done = false;
+    {
+        const char *e = getenv("GEOADV_FUSED_ADAM");           // "0": Adam as its own launch (A/B of tests/test_gpu_attack.py)
+        at->fuse_adam = !(e && e[0] == '0');
+        at->adam_pending = false;
+    }
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
     at->fwd_valid = false; at->adv_valid = false;
     at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr; at->prof_stride = 1; at->markers = false;
@@ -840,6 +859,7 @@ extern "C" int geoadv_attack_init_pert(geoadv_attack *at, const float *init_pert
     GA_REQUIRE(at && init_pert, "attack_init_pert: null argument");
     hipStream_t st = as_stream(stream);
     const size_t bn3 = (size_t)at->B * at->n * 3;
+    at->adam_pending = false;                          // (a step that never reached its forward is dropped with the old pert)
     GA_HIP(hipMemcpyAsync(at->pert, init_pert, 4 * bn3, hipMemcpyDeviceToDevice, st));
     if (reset_optimizer) {
         GA_HIP(hipMemsetAsync(at->m, 0, 4 * bn3, st));

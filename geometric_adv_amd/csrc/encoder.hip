@@ -175,7 +175,7 @@ __device__ __forceinline__ int orow_of(int rb) { return rb * 32; }
 template <bool MASKS, int ROWS>
 __global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, int n, const float *x, const float *pert,
                                                                   float *adv_out, float *pmax, int *parg, int *pcnt,
-                                                                  unsigned *masks) {
+                                                                  unsigned *masks, FusedAdam fa) {
     constexpr int THREADS = Fwd2<ROWS>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, i
     float *l0c = redm;                                 // (the pool's reduction buffers are free until the end)
     const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
     const int n0 = tile * ROWS;
-    float pv = 0.f, pp = 0.f;
+    float pv = 0.f, pp = 0.f, ag = 0.f, agd = 0.f, am = 0.f, av = 0.f;
     size_t pg = 0;
     bool pvalid = false;
     constexpr int L0_LOADERS = THREADS - ROWS * 3;    // 320 (64-row form) or 160 threads: one or two constants each
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, i
         pg = ((size_t)b * n + p) * 3 + a;
         pv = x[pg];
         if (pert) pp = pert[pg];
+        if (fa.m) { ag = fa.g_enc[pg]; agd = fa.g_dist[pg]; am = fa.m[pg]; av = fa.v[pg]; }      // (uniform branch)
     } else {
 #pragma unroll
         for (int q = 0; q < L0_PER; ++q) {
@@ -235,7 +236,21 @@ __global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, i
     const float sc3a = A.scale[3][ccol], sh3a = A.shift[3][ccol], sc3b = A.scale[3][128 + ccol], sh3b = A.shift[3][128 + ccol];
     const float sc4 = A.scale[4][ccol], sh4 = A.shift[4][ccol];
     if (threadIdx.x < ROWS * 3) {
-        const float v = pert ? pv + pp : pv;
+        float v = pert ? pv + pp : pv;
+        if (fa.m) {   // the pending Adam step of this coordinate (attack.hip adam_kernel, the same operations in the same order)
+            float g = ag;
+            g += agd;
+            float m = am, vv = av;
+            m += (g - m) * fa.one_minus_b1;
+            vv += (g * g - vv) * fa.one_minus_b2;
+            const float pnew = pp - (m * fa.alpha) / (sqrtf(vv) + fa.eps);
+            v = pv + pnew;
+            if (pvalid) {   // (padding rows repeat the cloud's last point and are never pooled: they only must not store)
+                fa.g_enc[pg] = 0.f;
+                if (fa.grad_out) fa.grad_out[pg] = g;
+                fa.m[pg] = m; fa.v[pg] = vv; fa.pert[pg] = pnew;
+            }
+        }
         pts[threadIdx.x] = v;
         if (adv_out && pvalid) adv_out[pg] = v;
     } else {
@@ -737,29 +752,37 @@ int encoder_mask_words() { return MASK_WORDS; }
 
 template <bool MASKS, int ROWS>
 static void launch_fwd2(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg, int *pcnt,
-                        unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+                        unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const FusedAdam &fa) {
     const dim3 grid(cdiv(A.n_points, ROWS), b), block(Fwd2<ROWS>::THREADS);
     const unsigned lds = (unsigned)(MASKS ? Fwd2<ROWS>::LDS_BYTES_MASKS : Fwd2<ROWS>::LDS_BYTES);
     if (start && stop)
         hipExtLaunchKernelGGL((encoder_fwd2_kernel<MASKS, ROWS>), grid, block, lds, stream, start, stop, 0,
-                              A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks);
+                              A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
     else
-        encoder_fwd2_kernel<MASKS, ROWS><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks);
+        encoder_fwd2_kernel<MASKS, ROWS><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
 }
 
 // pmax/parg/pcnt: [b][encoder_tiles(b, n)][128]; masks: [b][n][MASK_WORDS] or null (plain forward: geoadv_ae_forward, recomputing backward)
 // start / stop (optional): events that receive the kernel's own begin / end time stamps (geoadv_attack_profile).
+// fused (optional): a pending Adam step on pert, applied by the point loaders before they form adv = x + pert (needs pert
+// and adv_out)
 int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax,
-                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+                       int *parg, int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop,
+                       const FusedAdam *fused) {
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
+    FusedAdam fa{};
+    if (fused) {
+        GA_REQUIRE(pert && adv_out && fused->m && fused->pert == pert, "encoder_fwd: the fused Adam step needs pert and adv_out");
+        fa = *fused;
+    }
     const bool small = encoder_fwd_rows(b, A.n_points) == 32;
     if (masks) {
-        if (small) launch_fwd2<true, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop);
-        else launch_fwd2<true, 64>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop);
+        if (small) launch_fwd2<true, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);
+        else launch_fwd2<true, 64>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);
     } else {
-        if (small) launch_fwd2<false, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, nullptr, stream, start, stop);
-        else launch_fwd2<false, 64>(A, b, x, pert, adv_out, pmax, parg, pcnt, nullptr, stream, start, stop);
+        if (small) launch_fwd2<false, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, nullptr, stream, start, stop, fa);
+        else launch_fwd2<false, 64>(A, b, x, pert, adv_out, pmax, parg, pcnt, nullptr, stream, start, stop, fa);
     }
     GA_LAUNCH_CHECK();
     return GEOADV_OK;

@@ -272,6 +272,7 @@ def test_odd_sizes_all_code_paths_agree():
     sizes = ["1", "2", "31", "64", "65", "255", "257", "1023", "2049", "4097"]
     got = {}
     for name, env in [("default", {}), ("all-pairs source distance", {"GEOADV_CHAMFER_PRUNE": "0"}),
+                      ("Adam in its own launch", {"GEOADV_FUSED_ADAM": "0"}),
                       ("two-scan Chamfer", {"GEOADV_CHAMFER_SYM": "0"}),
                       ("two-scan Chamfer, all-pairs source distance", {"GEOADV_CHAMFER_SYM": "0", "GEOADV_CHAMFER_PRUNE": "0"}),
                       ("symmetric Chamfer + grid search", {"GEOADV_CHAMFER_SYM": "1"}),
@@ -493,7 +494,9 @@ def test_roctx_markers_and_kernel_timing_leave_results_alone(setup):
         at.run(0, 6, 3)
         if traced:
             prof = at.profile_read()
-            assert prof["encoder_fwd"][0] == 7 and all(0 < ms < 50 for _, ms in prof.values())     # 6 iterations + the first forward
+            assert prof["encoder_fwd"][0] == 7                                                     # 6 iterations + the first forward
+            assert prof["adam"][0] == 0                       # (the step rides in the next forward's point loads: no launch of its own)
+            assert all(0 < ms < 50 for name, (_, ms) in prof.items() if name != "adam")
             at.profile(False); at.markers(False)
         outs.append(at.peek()["pert"].clone())
     assert torch.equal(outs[0], outs[1])
