@@ -38,8 +38,8 @@ PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x3
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
-# measured batch sweep (profiles/r02_attack_sweep.json): ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- the honest
-# expectation for the strong-scaling leg (the latency floor of nine dependent launches does not shrink with the batch)
+# measured batch sweep: ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- what each rank of the strong-scaling leg runs
+SWEEP_SRC = "profiles/r02_attack_sweep.json"
 SWEEP_MS = {32: 0.1871, 16: 0.1256, 8: 0.0927, 4: 0.0762}
 
 
@@ -51,6 +51,15 @@ def parse_args():
     ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--window-timeout", type=float, default=120.0,
+                    help="wall-clock limit in seconds for the process-group start-up and for every timed window; a rank that "
+                         "exceeds it prints what it was waiting for and exits 3 (no hang: a dead peer or a stuck collective "
+                         "ends the run)")
+    ap.add_argument("--run-timeout", type=float, default=1500.0,
+                    help="self-launched N > 1 runs: wall-clock limit in seconds for all ranks together")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="(internal) child mode: bring up a ONE-rank RCCL group on cuda:0, run the collectives of the N > 1 path "
+                         "on device tensors, print one JSON line")
     ap.add_argument("--slots", type=int, default=0,
                     help="also measure S concurrent batch slots (secondary.batch_slots; off by default: its overlapping "
                          "launches would distort the per-kernel averages of a rocprofv3 run of this command)")
@@ -81,11 +90,26 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["GEOADV_BENCH_CHILD"] = "1"
+    if env.get("GEOADV_BENCH_SHARE_GPU") != "1":
+        import torch                                   # device_count() does not initialise the GPU on this image
+        ndev = torch.cuda.device_count()
+        if args.gpus > ndev:
+            sys.stderr.write("bench.py: --gpus %d but this node has %d GPU(s); one rank per GPU (RCCL refuses two ranks on one "
+                             "device).  GEOADV_BENCH_SHARE_GPU=1 runs the ranks on cuda:0 with a gloo group instead.\n" % (args.gpus, ndev))
+            sys.exit(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
-    for ln in p.stdout.splitlines():
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)   # own process group: killable as one
+    try:
+        stdout, _ = p.communicate(timeout=args.run_timeout)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(p.pid, signal.SIGKILL)               # exactly the group started above
+        p.wait()
+        sys.stderr.write("bench.py: the %d-rank run exceeded --run-timeout %.0f s and was killed\n" % (args.gpus, args.run_timeout))
+        sys.exit(124)
+    lines = [ln for ln in stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in stdout.splitlines():
         if not ln.startswith('{"metric"'):
             sys.stderr.write(ln + "\n")
     if p.returncode != 0 or not lines:
@@ -93,6 +117,38 @@ def launch_ranks(args):
         sys.exit(p.returncode or 1)
     print(lines[-1])
     sys.exit(0)
+
+
+class Watchdog:
+    """Wall-clock limit for the phases of a rank that wait on OTHER ranks (process-group start-up, every timed window): when a
+    phase overruns, the rank says what it was doing and exits 3 -- torchrun then ends the other ranks -- instead of sitting in a
+    collective for ever.  A timer thread and os._exit: nothing is exec'ed, no new process is started from a GPU process."""
+
+    def __init__(self, rank, limit_s):
+        import threading
+        self.rank, self.limit, self.deadline, self.label = rank, float(limit_s), None, ""
+        self.lock = threading.Lock()
+        t = threading.Thread(target=self._watch, daemon=True)
+        t.start()
+
+    def arm(self, label, scale=1.0):
+        with self.lock:
+            self.label, self.deadline = label, time.monotonic() + self.limit * scale
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def _watch(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                label = self.label
+            if late:
+                sys.stderr.write("bench.py: rank %d exceeded --window-timeout (%.0f s) in: %s -- exiting 3\n" % (self.rank, self.limit, label))
+                sys.stderr.flush()
+                os._exit(3)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -329,8 +385,9 @@ def slots_leg(dev, weights, ae, slots=2, iters=300):
 class Leg:
     """One attack handle on this rank + the timed-window protocol."""
 
-    def __init__(self, dev, weights, ae, x, gt, warmup, steps, prune=True):
+    def __init__(self, dev, weights, ae, x, gt, warmup, steps, prune=True, dog=None):
         import torch
+        self.dog = dog
         from geometric_adv_amd.adv_ae import AdvAE, Configuration
         self.K, self.W = steps, warmup
         self.thresh = warmup + int(0.8 * steps) + 1
@@ -348,6 +405,8 @@ class Leg:
     def window(self, gdist, backend, dev):
         """Exactly K timed steps bracketed by barrier + synchronize on both sides; returns the max over ranks (seconds)."""
         import torch
+        if self.dog:
+            self.dog.arm("a timed window of %d steps (barrier, loop, gather of the final scalars, barrier)" % self.K)
         torch.cuda.synchronize()
         gdist.barrier()
         torch.cuda.synchronize()
@@ -359,7 +418,10 @@ class Leg:
         gdist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        return gdist.max_over_ranks(dt, device=dev if backend == "nccl" else "cpu")
+        dt = gdist.max_over_ranks(dt, device=dev if backend == "nccl" else "cpu")
+        if self.dog:
+            self.dog.disarm()
+        return dt
 
     def windows(self, count, gdist, backend, dev, prime_ms=100.0):
         """`count` timed windows after untimed priming windows worth ~prime_ms of GPU work (an idle chip ramps its clock over
@@ -370,6 +432,51 @@ class Leg:
         return [self.window(gdist, backend, dev) for _ in range(count)]
 
 
+def rccl_selftest_child():
+    """One-rank 'nccl' (= RCCL) group on cuda:0: barrier, the metrics all-gather, a sum all-reduce and the max-over-ranks of the
+    timing protocol on device tensors.  RCCL refuses two ranks on one device; one rank it accepts, so a 1-GPU box can show that
+    librccl loads, the communicator comes up and the collectives of the N > 1 path complete."""
+    import torch
+    from geometric_adv_amd import dist as gdist
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    t0 = time.perf_counter()
+    gdist.init("nccl", single_rank_group=True, timeout_s=60)
+    dev = torch.device("cuda", 0)
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t_up = time.perf_counter() - t0
+    m = torch.arange(32 * 5, dtype=torch.float32, device=dev).reshape(1, 32, 5)
+    ok = bool(torch.equal(gdist.all_gather_examples(m), m))
+    t = torch.ones(1 << 20, device=dev)
+    gdist.all_reduce_sum_(t)
+    ok = ok and bool((t == 1).all().item()) and gdist.max_over_ranks(1.5, device=dev) == 1.5
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        gdist.all_gather_examples(m)
+    torch.cuda.synchronize()
+    info = gdist.backend_info()
+    info.update({"ok": ok, "communicator_up_s": round(t_up, 3), "metrics_gather_us": round((time.perf_counter() - t1) / 20 * 1e6, 1)})
+    import torch.distributed as tdist
+    tdist.destroy_process_group()
+    print("RCCL_SELFTEST " + json.dumps(info))
+
+
+def rccl_selftest():
+    """Runs rccl_selftest_child in a CHILD process (bounded by a timeout; this process keeps the GPU state of the finished
+    measurement) and returns its report, or the reason it failed."""
+    try:
+        o = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-selftest"], capture_output=True, text=True, timeout=180,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    except subprocess.TimeoutExpired:
+        return {"ok": False, "error": "timed out after 180 s"}
+    for ln in o.stdout.splitlines():
+        if ln.startswith("RCCL_SELFTEST "):
+            return json.loads(ln[len("RCCL_SELFTEST "):])
+    return {"ok": False, "error": (o.stderr or o.stdout)[-400:]}
+
+
 def median(v):
     s = sorted(v)
     return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
@@ -377,6 +484,8 @@ def median(v):
 
 def main():
     args = parse_args()
+    if args.rccl_selftest:
+        return rccl_selftest_child()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args)                                    # never returns
     if "WORLD_SIZE" not in os.environ:
@@ -401,18 +510,19 @@ def main():
         raise SystemExit("bench.py: rank %d wants cuda:%d but the node has %d GPUs" % (rank, local, ndev))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # ONE backend for every rank, fixed before the first collective: RCCL (one rank per GPU), or gloo for the shared-GPU
+    # simulation.  There is no per-rank fallback -- ranks on different backends would wait for each other for ever; a group
+    # that cannot come up ends the run with a message (watchdog), non-zero.
     backend = "gloo" if share else "nccl"
-    try:
-        gdist.init(backend)                      # RCCL over xGMI
-        if world > 1:
-            gdist.barrier()
-    except Exception as e:                       # keep the scaling run alive if RCCL cannot come up
-        sys.stderr.write("bench.py: RCCL init failed (%s); falling back to gloo for the KB-sized gather\n" % e)
-        backend = "gloo"
-        import torch.distributed as tdist
-        if tdist.is_initialized():
-            tdist.destroy_process_group()
-        gdist.init("gloo")
+    dog = Watchdog(rank, args.window_timeout)
+    if world > 1:
+        dog.arm("process-group start-up (%s) + first barrier" % ("RCCL" if backend == "nccl" else backend))
+        gdist.init(backend, timeout_s=args.window_timeout)
+        gdist.barrier()
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        dog.disarm()
+    group_info = gdist.backend_info()
 
     from geometric_adv_amd import weights as W
     from geometric_adv_amd.autoencoder import PointNetAE
@@ -424,7 +534,7 @@ def main():
     gt = clouds(2000 + 2 + 17 * rank, B, N)           # target batch of this rank
 
     # ---- headline leg: one batch of 32 per rank (weak scaling), paired grid search on ----
-    leg = Leg(dev, weights, ae, x, gt, Wm, K)
+    leg = Leg(dev, weights, ae, x, gt, Wm, K, dog=dog)
     # kernel-timed encoder launches: ~64 of them over the timed windows (>= 50 even at the driver's --steps 20).  A stamped
     # launch costs the loop ~5 us (measured: --steps 20 with every launch stamped 5100 it/s, every 4th 5207), so they are
     # kept sparse; the event pool holds 2048 pairs
@@ -437,7 +547,7 @@ def main():
     dt = median(dts)
 
     # ---- the same with nn_distance(adv, x) by the all-pairs kernel (no data-dependent shortcut) ----
-    leg_ap = Leg(dev, weights, ae, x, gt, Wm, K, prune=False)
+    leg_ap = Leg(dev, weights, ae, x, gt, Wm, K, prune=False, dog=dog)
     dts_ap = leg_ap.windows(min(R, 3), gdist, backend, dev)
     dt_ap = median(dts_ap)
     del leg_ap
@@ -450,7 +560,7 @@ def main():
             strong = {"value": K / dt, "ms_per_step": dt / K * 1e3, "note": "one GPU: identical to `value`"}
         else:
             xs, gs = clouds(1002, B, N)[rank * bs:(rank + 1) * bs], clouds(2002, B, N)[rank * bs:(rank + 1) * bs]
-            leg_s = Leg(dev, weights, ae, xs, gs, Wm, K)
+            leg_s = Leg(dev, weights, ae, xs, gs, Wm, K, dog=dog)
             dts_s = leg_s.windows(R, gdist, backend, dev)
             dt_s = median(dts_s)
             strong = {"value": K / dt_s, "ms_per_step": dt_s / K * 1e3, "windows_ms": [round(t * 1e3, 3) for t in dts_s]}
@@ -459,9 +569,10 @@ def main():
         strong.update({"definition": "attack iterations/s on ONE global batch of 32 clouds split contiguously over the ranks "
                                      "(SURVEY 8e); every rank runs the whole loop on its 32/N clouds, final scalars all-gathered",
                        "global_batch": B, "batch_per_gpu": bs,
-                       "expected_speedup_vs_1gpu_from_r01_sweep": (SWEEP_MS[32] / exp) if exp else None,
-                       "expectation_note": "an iteration is nine dependent launches whose latency floor (0.073 ms at B = 1) does not "
-                                           "shrink with the batch: the >= 6x target of the north star is a weak-scaling figure here"})
+                       "expected_speedup_vs_1gpu_from_sweep": (SWEEP_MS[32] / exp) if exp else None,
+                       "expectation_note": "ms per iteration of ONE GPU at B = 32 / 16 / 8 / 4 (%s): %s -- what a rank of the "
+                                           "strong-scaled run executes; both scalings are printed (`value` weak, this object strong)"
+                                           % (SWEEP_SRC, ", ".join("%.4f" % SWEEP_MS[k] for k in (32, 16, 8, 4)))})
 
     if world > 1:                                # every collective of the run is behind us: leave the group cleanly on all ranks
         import torch.distributed as tdist
@@ -501,7 +612,8 @@ def main():
         "config": {"workload": "BASELINE configs[1]: B=32 random clouds x N=2048, output-space attack (chamfer/chamfer, "
                                "dist_weight 1.0, lr 0.01), one batch per GPU", "batch_per_gpu": B, "n_points": N,
                    "global_batch": B * world, "parallelism": "batches sharded, dp%d, no data-path collective" % world,
-                   "ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
+                   "ranks": world, "collective_backend": group_info["backend"], "collective_world": group_info["world"],
+                   "rccl_version": group_info["rccl_version"],
                    "thresh_fraction": 0.8},
         "strong_scaling": strong,
         "roofline": {"bound": "mfma", "kernel": "encoder_fwd2_kernel<true, 64>", "achieved": enc_tflops, "peak": PEAK_MFMA_F32_TFLOPS,
@@ -521,6 +633,8 @@ def main():
         "kernel_ms_note": "bracketing events per class (dispatch gaps included), untimed 50-iteration pass; encoder_fwd here is kernel-timed",
         "final_mean_target_recon_error": float(leg.gathered[0, :, 4].mean().item()),
     }
+    if world == 1:                  # no collective ran at N = 1: show in a child process that RCCL comes up on this box
+        out["config"]["rccl_selftest"] = rccl_selftest()
     if world == 1:                  # the widened row f-4, measured beside the headline (not part of `value`)
         out["secondary"] = {"ae_training_step": training_leg(dev), "roofline_emd": emd_leg(dev)}
         if args.slots > 1:

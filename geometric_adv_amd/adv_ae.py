@@ -24,7 +24,8 @@ class Configuration:
                  loss_dist_type="chamfer", dist_weight_list=(1.0,), max_point_pert_weight=0.0,
                  max_point_dist_weight=0.0, num_iterations=500, num_iterations_thresh=400,
                  learning_rate=0.01, ae_name="autoencoder", emd_weight=0.0, verbose=False, batch_slots=1,
-                 chamfer_prune=True, emd_reference_weights=False):
+                 chamfer_prune=True, emd_reference_weights=False, recompute_backward=False, separate_adam=False,
+                 chamfer_kernel="auto"):
         self.batch_size = int(batch_size)
         self.n_input = [int(n_points), 3]
         self.n_output = [int(n_points), 3]
@@ -44,13 +45,23 @@ class Configuration:
         self.batch_slots = int(batch_slots)      # batches attacked concurrently on this GPU (AdvAE.attack); 1 = the reference's order
         self.chamfer_prune = bool(chamfer_prune) # False: nn_distance(adv, x) always by the all-pairs kernel (same results)
         self.emd_reference_weights = bool(emd_reference_weights)   # True: the EMD term's plan from the CPU op's expf arguments (ops.approx_match)
+        # alternative code paths with the same results (geoadv_attack_config; the parity tests run each against the default)
+        self.recompute_backward = bool(recompute_backward)   # encoder backward re-runs the forward instead of reading ReLU masks
+        self.separate_adam = bool(separate_adam)             # Adam step as its own launch
+        if chamfer_kernel not in CHAMFER_KERNELS:
+            raise ValueError("chamfer_kernel must be one of %s" % sorted(CHAMFER_KERNELS))
+        self.chamfer_kernel = chamfer_kernel                 # "auto" (by batch size), "two_scan" or "symmetric"
+
+
+CHAMFER_KERNELS = {"auto": 0, "two_scan": 1, "symmetric": 2}
 
 
 class _AttackConfig(C.Structure):
     _fields_ = [("batch", C.c_int), ("loss_adv_type", C.c_int), ("loss_dist_type", C.c_int),
                 ("max_point_pert_weight", C.c_float), ("max_point_dist_weight", C.c_float),
                 ("learning_rate", C.c_float), ("emd_weight", C.c_float), ("all_pairs_source_dist", C.c_int),
-                ("emd_weight_mode", C.c_int)]
+                ("emd_weight_mode", C.c_int), ("recompute_backward", C.c_int), ("separate_adam", C.c_int),
+                ("chamfer_kernel", C.c_int)]
 
 
 PROF_NAMES = ["encoder_fwd", "decoder_fwd", "chamfer_fwd", "loss_grad", "decoder_bwd", "encoder_bwd", "adam"]
@@ -73,7 +84,9 @@ class AdvAE:
         self.B = c.batch_size
         cfg = _AttackConfig(self.B, 1 if c.loss_adv_type == "latent" else 0, 1 if c.loss_dist_type == "pert" else 0,
                             c.max_point_pert_weight, c.max_point_dist_weight, c.learning_rate, c.emd_weight,
-                            0 if getattr(c, "chamfer_prune", True) else 1, 1 if getattr(c, "emd_reference_weights", False) else 0)
+                            0 if getattr(c, "chamfer_prune", True) else 1, 1 if getattr(c, "emd_reference_weights", False) else 0,
+                            1 if getattr(c, "recompute_backward", False) else 0, 1 if getattr(c, "separate_adam", False) else 0,
+                            CHAMFER_KERNELS[getattr(c, "chamfer_kernel", "auto")])
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_attack_create(C.byref(self._h), self.ae.handle, C.byref(cfg)), "attack_create")

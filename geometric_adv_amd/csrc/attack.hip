@@ -453,7 +453,7 @@ struct geoadv_attack {
     float *emd_temp, *emd_cost, *emd_g1;   // only when cfg.emd_weight > 0
     float *sym_ws;                   // column-minimum partials of the symmetric Chamfer kernel
     bool cgrad_done;                 // the cached forward's loss launch also produced the Chamfer gradients
-    bool chamfer_prune;              // nn_distance(adv, x) through the paired grid search (GEOADV_CHAMFER_PRUNE, default on)
+    bool chamfer_prune;              // nn_distance(adv, x) through the paired grid search (cfg.all_pairs_source_dist = 0, the default)
     int *need_adv;                   // [8 B] clouds the grid search handed back to the all-pairs kernel
     float *x_box;                    // [B][6] bounding boxes of the source clouds (the grid of the paired search)
     int grid_calls;                  // running number of grid-search launches (paces the retries of clouds that gave up)
@@ -463,7 +463,7 @@ struct geoadv_attack {
     float beta1_pow, beta2_pow;
     bool fwd_valid;
     bool adv_valid;                  // adv == x + pert already (written by the Adam kernel)
-    bool fuse_adam;                  // the Adam step rides in the next forward's point loads (GEOADV_FUSED_ADAM=0: own launch)
+    bool fuse_adam;                  // the Adam step rides in the next forward's point loads (cfg.separate_adam: own launch)
     bool adam_pending;               // ... and one is waiting there
     FusedAdam pending;
     // profiling
@@ -736,6 +736,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     GA_REQUIRE(cfg->emd_weight >= 0.f, "attack_create: emd_weight must be >= 0");
     GA_REQUIRE(cfg->emd_weight_mode == GEOADV_EMD_FAST || cfg->emd_weight_mode == GEOADV_EMD_REFERENCE,
                "attack_create: unknown emd_weight_mode %d", cfg->emd_weight_mode);
+    GA_REQUIRE(cfg->chamfer_kernel >= GEOADV_CHAMFER_AUTO && cfg->chamfer_kernel <= GEOADV_CHAMFER_SYMMETRIC,
+               "attack_create: unknown chamfer_kernel %d", cfg->chamfer_kernel);
     GA_REQUIRE(cfg->emd_weight == 0.f || cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER,
                "attack_create: emd_weight needs the output-space attack (loss_adv_type chamfer)");
     geoadv_attack *at = new geoadv_attack();
@@ -756,8 +758,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * B); need(4 * B * 4); need(4 * bn3); need(4 * bn3);
     const size_t sym_floats = chamfer_sym_workspace_floats(2, at->B, at->n, at->n);
     need(4 * sym_floats);
-    const char *mask_env = getenv("GEOADV_BWD_MASKS");             // "0": backward recomputes the forward (A/B tests)
-    const size_t mask_words = (mask_env && mask_env[0] == '0') ? 0 : (size_t)encoder_mask_words() * bn;   // ReLU masks of the cached forward
+    const size_t mask_words = cfg->recompute_backward ? 0 : (size_t)encoder_mask_words() * bn;   // ReLU masks of the cached forward
     need(4 * mask_words);
     need(4 * 8 * B);                                      // need_adv
     need(4 * 6 * B);                                      // x_box
@@ -790,28 +791,22 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->need_adv = I(4 * 8 * B);
     at->grid_calls = 0;
     at->x_box = F(4 * 6 * B);
-    {
-        const char *e = getenv("GEOADV_CHAMFER_PRUNE");        // A/B override for the parity tests
-        at->chamfer_prune = e ? e[0] != '0' : cfg->all_pairs_source_dist == 0;
-    }
+    at->chamfer_prune = cfg->all_pairs_source_dist == 0;
     {
         // Small batches (<= 34 K points in all: B <= 17 at N = 2048 -- what a GPU holds when ONE batch of 32 is split over 2, 4
         // or 8): the public op's plain scans in ONE launch -- both directions of (recon, target), and of (adv, source) only
         // for the clouds the grid search riding in the latent launch handed back -- beat the symmetric scan + its finish
         // launch: launches are fixed latency there, not arithmetic (measured ms per iteration, plain / symmetric: B = 8:
         // 0.096 / 0.105, 12: 0.127 / 0.130, 16: 0.129 / 0.141, 18: 0.168 / 0.163, 20: 0.167 / 0.164, 24: 0.170 / 0.164).  Same bits either way.
-        // GEOADV_CHAMFER_SYM = 0 / 1 forces one form (the A/B of tests/test_gpu_attack.py).
-        const char *e = getenv("GEOADV_CHAMFER_SYM");
-        at->chamfer_sym = e ? e[0] != '0' : (long)at->B * at->n > 34816;
+        // cfg->chamfer_kernel forces one form (the A/B of tests/test_gpu_attack.py).
+        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n > 34816
+                                                                     : cfg->chamfer_kernel == GEOADV_CHAMFER_SYMMETRIC;
     }
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;
     if (emd) { at->emd_temp = F(4 * emd_temp_f + 8); at->emd_cost = F(4 * B); at->emd_g1 = F(4 * bn3); }
     at->cgrad_done = false;
-    {
-        const char *e = getenv("GEOADV_FUSED_ADAM");           // "0": Adam as its own launch (A/B of tests/test_gpu_attack.py)
-        at->fuse_adam = !(e && e[0] == '0');
-        at->adam_pending = false;
-    }
+    at->fuse_adam = cfg->separate_adam == 0;
+    at->adam_pending = false;
     at->beta1_pow = 0.9f; at->beta2_pow = 0.999f;      // TF: beta*_power variables start at beta*
     at->fwd_valid = false; at->adv_valid = false;
     at->prof_mask = 0; at->ev_used = 0; at->prof_stream = nullptr; at->prof_stride = 1; at->markers = false;
@@ -845,6 +840,8 @@ extern "C" int geoadv_attack_set_inputs(geoadv_attack *at, const float *source_p
                "attack_set_inputs: target_latent is required for loss_adv_type 'latent'");
     hipStream_t st = as_stream(stream);
     const size_t bn3 = (size_t)at->B * at->n * 3;
+    if (at->adam_pending)    // a step that has not reached its forward yet: apply it to pert (with the old clouds) before they change
+        if (int rc = do_forward(at, nullptr, 0, st)) return rc;
     GA_HIP(hipMemcpyAsync(at->x, source_pc, 4 * bn3, hipMemcpyDeviceToDevice, st));
     GA_HIP(hipMemcpyAsync(at->gt, target_pc, 4 * bn3, hipMemcpyDeviceToDevice, st));
     if (target_latent) GA_HIP(hipMemcpyAsync(at->tz, target_latent, 4 * (size_t)at->B * 128, hipMemcpyDeviceToDevice, st));
@@ -914,7 +911,9 @@ extern "C" int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, fl
     GA_REQUIRE(at, "attack_peek: null handle");
     hipStream_t st = as_stream(stream);
     const size_t bn3 = 4 * (size_t)at->B * at->n * 3, bn = 4 * (size_t)at->B * at->n;
-    if (!at->fwd_valid && (adv || recon || latent || idx_r1 || idx_r2 || idx_a1 || idx_a2))
+    // a step whose Adam update is still waiting for the next forward's point loaders (fused Adam) has not touched pert /
+    // grad_last yet: run that forward first, whatever is asked for
+    if (at->adam_pending || (!at->fwd_valid && (adv || recon || latent || idx_r1 || idx_r2 || idx_a1 || idx_a2)))
         if (int rc = do_forward(at, nullptr, 0, st)) return rc;
     if (pert) GA_HIP(hipMemcpyAsync(pert, at->pert, bn3, hipMemcpyDeviceToDevice, st));
     if (adv) GA_HIP(hipMemcpyAsync(adv, at->adv, bn3, hipMemcpyDeviceToDevice, st));

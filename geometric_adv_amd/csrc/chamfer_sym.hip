@@ -465,6 +465,8 @@ extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *
         float *d1 = workspace, *d2 = d1 + (size_t)cnt * n;
         int *i1 = reinterpret_cast<int *>(d2 + (size_t)cnt * m), *i2 = i1 + (size_t)cnt * n;
         float *ws = reinterpret_cast<float *>(i2 + (size_t)cnt * m);
+        ws += (4 - ((size_t)cnt * 2 * (n + m)) % 4) % 4;       // the column partials are accessed as float4: keep them 16-byte aligned
+                                                               // (odd cnt * (n + m); the + 64 floats of slack per pair cover it)
         const ChamferPair pr{A, B, d1, i1, d2, i2};
         GA_REQUIRE(base <= 0x7fffffff, "chamfer_matrix: too many pairs");
         if (int rc = launch_chamfer_sym_ex(&pr, 1, cnt, n, m, ws, (int)base, nb, nullptr, st)) return rc;

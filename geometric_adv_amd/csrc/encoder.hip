@@ -789,7 +789,7 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
 }
 
 // masks != null: one launch = masked sparse blocks (128 critical rows of every un-flagged cloud) + dense recomputing blocks
-// that only do work for clouds with a tied pool maximum.  masks == null (GEOADV_BWD_MASKS=0, the A/B of
+// that only do work for clouds with a tied pool maximum.  masks == null (cfg.recompute_backward, the A/B of
 // tests/test_gpu_attack.py): the recomputing kernel for both, sparse then dense.  g_enc must be zeroed by the caller
 // (rows that are not critical keep gradient 0).
 int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *crit_rows, const float *z,

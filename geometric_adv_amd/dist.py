@@ -21,18 +21,47 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the environment if WORLD_SIZE > 1.  Returns (rank, world, local_rank)."""
+def init(backend=None, single_rank_group=False, timeout_s=None):
+    """Initialise torch.distributed from the environment if WORLD_SIZE > 1.  Returns (rank, world, local_rank).
+
+    single_rank_group: also create a group when WORLD_SIZE is 1 (rendezvous on a private TCP port of 127.0.0.1) -- the
+    collectives below then really run through the backend (RCCL accepts ONE rank per device, so this is how a 1-GPU box
+    exercises librccl: tests/test_gpu_dist_rccl.py, bench.py at --gpus 1).  timeout_s: collective / rendezvous timeout."""
     rank, world, local = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            kw["init_method"] = "tcp://127.0.0.1:%d" % port
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def backend_info():
+    """What the collectives of this process run on: {"backend", "world", "rccl_version"} (rccl_version only for 'nccl' = RCCL
+    on ROCm; the world size is the one the process group reports, i.e. after the communicator came up)."""
+    if not dist.is_initialized():
+        return {"backend": "none", "world": 1, "rccl_version": None}
+    b = dist.get_backend()
+    ver = None
+    if b == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = "unknown"
+    return {"backend": "rccl" if b == "nccl" else b, "world": dist.get_world_size(), "rccl_version": ver}
 
 
 def shard_batches(n_batches, rank, world):
@@ -57,7 +86,7 @@ def max_over_ranks(value, device="cpu"):
 def all_reduce_sum_(t):
     """In-place sum over the ranks of a (GPU) tensor: RCCL directly; a gloo group (CPU tests, or several ranks sharing
     one GPU) stages through host memory."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return t
     if dist.get_backend() == "gloo" and t.is_cuda:
         h = t.detach().cpu()
@@ -71,7 +100,7 @@ def all_reduce_sum_(t):
 def all_gather_examples(local, counts=None, axis=1):
     """all-gather a tensor whose `axis` is the example axis, concatenated in rank order.
     Ranks may hold different numbers of examples (pads to the maximum, trims after)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     world = dist.get_world_size()
     n_local = torch.tensor([local.shape[axis]], dtype=torch.int64, device=local.device)

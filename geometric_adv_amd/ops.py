@@ -141,14 +141,6 @@ def nn_distance_autograd(xyz1, xyz2):
     return _NnDistanceFn.apply(xyz1, xyz2)
 
 
-def microbench(which, iters=2000):
-    """Calibration: ms for 2048x256 threads x 16*iters VALU instructions of kind `which`."""
-    ms = C.c_float(0)
-    st = _lib.lib().geoadv_microbench(int(which), int(iters), C.byref(ms), _lib.stream_handle())
-    _lib.check(st, "microbench")
-    return ms.value
-
-
 # ---------------------------------------------------------------------------------------------
 # external/grouping/tf_grouping.py
 # ---------------------------------------------------------------------------------------------

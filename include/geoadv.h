@@ -209,7 +209,18 @@ typedef struct geoadv_attack_config {
     int   all_pairs_source_dist;    /* 0 (default): nn_distance(adv, x) by the exact paired grid search, falling back per
                                      * cloud to the all-pairs kernel; 1: always the all-pairs kernel.  Same results.     */
     int   emd_weight_mode;          /* GEOADV_EMD_FAST (0, default) or GEOADV_EMD_REFERENCE for the EMD term's plan       */
+    /* Alternative code paths with the same results, selected explicitly (never by the environment); all 0 = defaults.
+     * The parity tests run every one of them against the default path.                                                */
+    int   recompute_backward;       /* 1: the sparse encoder backward re-runs the forward for the critical rows instead
+                                     * of reading the ReLU masks the forward kept (the path tied clouds always take)    */
+    int   separate_adam;            /* 1: the Adam step is its own launch (the path loss_dist_type 'pert' always takes)
+                                     * instead of riding in the next forward's point loaders                           */
+    int   chamfer_kernel;           /* GEOADV_CHAMFER_AUTO (0: by batch size), _TWO_SCAN (the public op's kernel),
+                                     * _SYMMETRIC (one evaluation per pair serves both directions)                      */
 } geoadv_attack_config;
+#define GEOADV_CHAMFER_AUTO      0
+#define GEOADV_CHAMFER_TWO_SCAN  1
+#define GEOADV_CHAMFER_SYMMETRIC 2
 
 int  geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, const geoadv_attack_config *cfg);
 void geoadv_attack_destroy(geoadv_attack *at);
@@ -314,10 +325,6 @@ int geoadv_attack_markers(geoadv_attack *at, int enable);
 /* Time only every stride-th launch of each selected class (a pair of events between two dependent kernels costs ~1 us of
  * GPU time; sampling keeps a timed region honest).  Default 1. */
 int geoadv_attack_profile_stride(geoadv_attack *at, int stride);
-
-/* Micro-benchmarks used by bench.py / DESIGN.md to calibrate the rooflines on the box
- * (not part of the reference's surface).  Returns elapsed ms of `iters` repetitions. */
-int geoadv_microbench(int which, int iters, float *ms, void *stream);
 
 #ifdef __cplusplus
 }

@@ -262,22 +262,22 @@ def test_batch_slots_equal_one_handle_per_run_of_batches(setup):
 
 def test_odd_sizes_all_code_paths_agree():
     """Ragged and extreme cloud sizes (1 point, sizes around the 64-row encoder tile, the 256-row Chamfer tile, the 2048 /
-    4096-point limits of the grid search's instantiations) through every alternative code path the library keeps behind an
-    environment switch: the whole trajectory -- perturbation, nearest-neighbour indices, keep-best metrics -- must be
-    bit-identical to the default path.  Each path runs in its own process (the switches are read once).  (The recomputing
+    4096-point limits of the grid search's instantiations) through every alternative code path the library keeps behind a
+    geoadv_attack_config switch: the whole trajectory -- perturbation, nearest-neighbour indices, keep-best metrics -- must be
+    bit-identical to the default path.  Each path runs in its own process.  (The recomputing
     encoder backward is not in the list: it sums the same products in another MFMA shape's order and is held to a
     tolerance in test_masked_backward_equals_recomputing_backward, odd sizes included.)"""
     import json, os, subprocess, sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_paths_child.py")
     sizes = ["1", "2", "31", "64", "65", "255", "257", "1023", "2049", "4097"]
     got = {}
-    for name, env in [("default", {}), ("all-pairs source distance", {"GEOADV_CHAMFER_PRUNE": "0"}),
-                      ("Adam in its own launch", {"GEOADV_FUSED_ADAM": "0"}),
-                      ("two-scan Chamfer", {"GEOADV_CHAMFER_SYM": "0"}),
-                      ("two-scan Chamfer, all-pairs source distance", {"GEOADV_CHAMFER_SYM": "0", "GEOADV_CHAMFER_PRUNE": "0"}),
-                      ("symmetric Chamfer + grid search", {"GEOADV_CHAMFER_SYM": "1"}),
-                      ("symmetric Chamfer, all-pairs source distance", {"GEOADV_CHAMFER_SYM": "1", "GEOADV_CHAMFER_PRUNE": "0"})]:
-        o = subprocess.run([sys.executable, child] + sizes, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    for name, cfg in [("default", {}), ("all-pairs source distance", {"chamfer_prune": False}),
+                      ("Adam in its own launch", {"separate_adam": True}),
+                      ("two-scan Chamfer", {"chamfer_kernel": "two_scan"}),
+                      ("two-scan Chamfer, all-pairs source distance", {"chamfer_kernel": "two_scan", "chamfer_prune": False}),
+                      ("symmetric Chamfer + grid search", {"chamfer_kernel": "symmetric"}),
+                      ("symmetric Chamfer, all-pairs source distance", {"chamfer_kernel": "symmetric", "chamfer_prune": False})]:
+        o = subprocess.run([sys.executable, child, json.dumps(cfg)] + sizes, capture_output=True, text=True, timeout=600)
         lines = [ln for ln in o.stdout.splitlines() if ln.startswith("HASHES ")]
         assert o.returncode == 0 and lines, (name, o.stderr[-400:])
         got[name] = json.loads(lines[-1][7:])
@@ -320,9 +320,9 @@ def test_emd_combined_loss_step(setup, reference_weights):
 
 
 @pytest.mark.parametrize("n", [N, 200, 1, 65, 257])
-def test_masked_backward_equals_recomputing_backward(setup, monkeypatch, n):
+def test_masked_backward_equals_recomputing_backward(setup, n):
     """The sparse encoder backward reads the ReLU masks the forward left behind (16-row tiles on the 16x16x4 MFMA shape); with
-    GEOADV_BWD_MASKS=0 it re-runs the forward for the critical rows instead (32-row tiles, 32x32x2).  The same products in
+    Configuration(recompute_backward=True) it re-runs the forward for the critical rows instead (32-row tiles, 32x32x2).  The same products in
     two summation orders: the first iteration's gradient agrees to 2e-6 of its largest component, and the perturbation
     after 6 Adam steps to 1e-4 of its size (also for a ragged point count, whose last tile is partly empty)."""
     import torch
@@ -334,9 +334,9 @@ def test_masked_backward_equals_recomputing_backward(setup, monkeypatch, n):
     b = 3
     x, gt = _clouds(71, b, n)
     grads, outs = [], []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("GEOADV_BWD_MASKS", flag)
-        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=6, num_iterations_thresh=3), ae=ae)
+    for recompute in (False, True):
+        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=6, num_iterations_thresh=3,
+                                              recompute_backward=recompute), ae=ae)
         at.set_inputs(x, gt, None, 1.0)
         at.init_pert(None, reset_optimizer=True)
         at.run(0, 1, 3)
@@ -350,10 +350,10 @@ def test_masked_backward_equals_recomputing_backward(setup, monkeypatch, n):
     torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-4 * outs[1].abs().max().item())
 
 
-@pytest.mark.parametrize("sym", ["1", "0"])
+@pytest.mark.parametrize("sym", ["symmetric", "two_scan"])
 @pytest.mark.parametrize("lr,n", [(0.01, N), (0.3, N), (0.01, 200), (0.01, 8192), (0.3, 5000)])
-def test_pruned_source_distance_equals_all_pairs(setup, monkeypatch, lr, n, sym):
-    """nn_distance(adv, x) through the paired grid search (default) vs the all-pairs kernel (GEOADV_CHAMFER_PRUNE=0): the
+def test_pruned_source_distance_equals_all_pairs(setup, lr, n, sym):
+    """nn_distance(adv, x) through the paired grid search (default) vs the all-pairs kernel (Configuration(chamfer_prune=False)): the
     whole loop must agree bit for bit -- also when a huge learning rate scatters the points so that clouds hand themselves
     back to the all-pairs kernel, for a point count that is not a multiple of anything, and for clouds of more than 4096
     points (the search's large instantiation, launched on its own).  In both forms of the all-pairs side: the symmetric
@@ -367,11 +367,9 @@ def test_pruned_source_distance_equals_all_pairs(setup, monkeypatch, lr, n, sym)
     b = 3
     x, gt = _clouds(81, b, n)
     outs = []
-    monkeypatch.setenv("GEOADV_CHAMFER_SYM", sym)
-    for flag in ("1", "0"):
-        monkeypatch.setenv("GEOADV_CHAMFER_PRUNE", flag)
+    for prune in (True, False):
         at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=12, num_iterations_thresh=3,
-                                              learning_rate=lr), ae=ae)
+                                              learning_rate=lr, chamfer_kernel=sym, chamfer_prune=prune), ae=ae)
         at.set_inputs(x, gt, None, 1.0)
         at.init_pert(None, reset_optimizer=True)
         at.run(0, 12, 3)

@@ -10,7 +10,8 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
-@pytest.mark.parametrize("na,nb,n,m", [(3, 5, 300, 300), (2, 2, 1024, 1024), (4, 3, 130, 517), (1, 7, 2048, 2048)])
+@pytest.mark.parametrize("na,nb,n,m", [(3, 5, 300, 300), (2, 2, 1024, 1024), (4, 3, 130, 517), (1, 7, 2048, 2048),
+                                     (3, 1, 130, 517)])   # odd pair count x odd n + m: the workspace of the float4 column partials is re-aligned
 def test_chamfer_matrix_vs_oracle(oracle, na, nb, n, m):
     """Every entry equals mean(dist1) + mean(dist2) of the pinned oracle's nn_distance on that pair (sums in
     float64 on the oracle side; the kernel sums fp32 in a fixed order => 1e-6 relative)."""

@@ -10,13 +10,13 @@ from geometric_adv_amd.adv_ae import AdvAE, Configuration
 from geometric_adv_amd.autoencoder import PointNetAE
 
 
-def run(B, N, iters):
+def run(B, N, iters, **cfg):
     rng = np.random.default_rng(B * 7 + N)
     x = (rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5))
     gt = (rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5))
     w = W.synthetic_weights(N, seed=7)
     ae = PointNetAE(w, N)
-    conf = Configuration(batch_size=B, n_points=N, weights=w, num_iterations=iters + 20, num_iterations_thresh=iters)
+    conf = Configuration(batch_size=B, n_points=N, weights=w, num_iterations=iters + 20, num_iterations_thresh=iters, **cfg)
     at = AdvAE("adversary", conf, ae=ae)
     at.set_inputs(x, gt, ae.transform(gt), 1.0)
     at.init_pert(None, reset_optimizer=True)

@@ -1,8 +1,10 @@
 # A/B of library variants on ONE box: for every geometric_adv_amd/lib/variants/libgeoadv_*.so, swap it in, run the command
 # given as arguments (default: kernel trace of the B = 32 loop), print the chamfer lines, restore.
 #   bash tools/debug/ab_variants.sh [reps]
-cd $GRAFT_REPO_ROOT
+set -eu
+cd "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 cp geometric_adv_amd/lib/libgeoadv.so /tmp/libgeoadv_keep.so
+trap 'cp /tmp/libgeoadv_keep.so "$GRAFT_REPO_ROOT/geometric_adv_amd/lib/libgeoadv.so"' EXIT   # also on failure / interrupt
 export TMPDIR=/tmp
 for rep in $(seq 1 ${1:-2}); do
 for v in geometric_adv_amd/lib/variants/libgeoadv_*.so; do
@@ -14,4 +16,3 @@ for v in geometric_adv_amd/lib/variants/libgeoadv_*.so; do
     grep -o '"ms_per_iteration": [0-9.]*' /tmp/ab.log | head -1
 done
 done
-cp /tmp/libgeoadv_keep.so geometric_adv_amd/lib/libgeoadv.so

@@ -8,7 +8,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from geometric_adv_amd import ops
+from geometric_adv_amd import ops  # noqa: F401
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe"))
+import probe
 
 out = {}
 dev = torch.device("cuda:0")
@@ -16,7 +18,7 @@ print(torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).multi_p
 names = ["mul+add", "pk_mul+pk_add", "min", "fma", "pk_fma"]
 iters = 4000
 for w, nm in enumerate(names):
-    ms = ops.microbench(w, iters)
+    ms = probe.microbench(w, iters)
     inst = 2048 * 256 * 16 * iters
     out["valu_" + nm] = {"ms": ms, "Tinstr_lane_per_s": inst / ms / 1e9}
     print(nm, ms, "ms", inst / ms / 1e9, "T lane-instr/s")
@@ -24,7 +26,7 @@ for w, nm in enumerate(names):
 for w, nm in zip(range(18, 40), ["add", "mul", "sub", "min_u32", "min3_f32", "min3_u32", "max_f32", "cndmask_vcc", "cmp_lt_f32", "mov",
                             "cndmask_sgpr_mask", "writelane", "fma", "lshl_add_u32+add_u32", "add_f64", "mul_f64", "fma_f64",
                             "cvt_f64_f32", "cvt_f32_f64", "exp_f32", "ldexp_f32", "rndne_f32"]):
-    ms = min(ops.microbench(w, iters) for _ in range(2))
+    ms = min(probe.microbench(w, iters) for _ in range(2))
     inst = 2048 * 256 * 16 * iters
     cyc = ms * 1e-3 * 2.4e9 * 1024 / (2048 * 4 * 16 * iters)      # SIMD cycles per wave instruction at 2.4 GHz
     out["valu_" + nm] = {"ms": ms, "Tinstr_lane_per_s": inst / ms / 1e9, "cycles_per_wave_instr": cyc}

@@ -1,7 +1,8 @@
 // Roofline calibration micro-benchmarks (not part of the reference's surface): how many fp32
 // VALU lane-operations per second the box sustains with plain vs packed instructions.  The
 // Chamfer / kNN scans are VALU-issue bound, so DESIGN.md prices them against these numbers.
-#include "common.h"
+#include "../../geometric_adv_amd/csrc/common.h"
+#include <string.h>
 
 namespace geoadv {
 
@@ -202,12 +203,21 @@ __global__ __launch_bounds__(512, 4) void mb_feed_kernel(float *out, const float
     if (acc[0] + acc[15] == 123.456f) out[0] = acc[0];
 }
 
+static thread_local char g_probe_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_probe_err, sizeof(g_probe_err), fmt, ap);
+    va_end(ap);
+}
 }  // namespace geoadv
 using namespace geoadv;
+extern "C" const char *geoadv_probe_last_error(void) { return geoadv::g_probe_err; }
+
 
 // ms = time of one launch of 2048 workgroups x 256 threads, each thread issuing 16*iters VALU
 // instructions of the selected kind.
-extern "C" int geoadv_microbench(int which, int iters, float *ms, void *stream) {
+extern "C" int geoadv_probe_microbench(int which, int iters, float *ms, void *stream) {
     GA_REQUIRE(which >= 0 && which <= 39 && iters > 0 && ms, "microbench: bad arguments");
     hipStream_t st = as_stream(stream);
     float *out = nullptr;

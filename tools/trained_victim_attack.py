@@ -23,12 +23,13 @@ def main():
     from geometric_adv_amd import ops
     N, B = 2048, 32
     rng = np.random.default_rng(0)
-    if len(sys.argv) > 1:                                     # child: time the loop under the inherited environment
+    if len(sys.argv) > 1:                                     # child: time the loop with the grid search on (argv[2] = 1) or off
         w = dict(np.load(sys.argv[1]))
         w = {k.replace("__", "/"): v for k, v in w.items()}
         ae = PointNetAE(w, N)
         src, tgt = shapes(rng, B, N), shapes(rng, B, N)
-        at = AdvAE("a", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=520, num_iterations_thresh=10**6), ae=ae)
+        at = AdvAE("a", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=520, num_iterations_thresh=10**6,
+                                      chamfer_prune=sys.argv[2] == "1"), ae=ae)
         at.set_inputs(src, tgt, ae.transform(tgt), 1.0); at.init_pert(None, reset_optimizer=True)
         at.run(0, 20, 10**6); torch.cuda.synchronize()
         t0 = time.perf_counter(); at.run(20, 500, 10**6); torch.cuda.synchronize()
@@ -36,7 +37,7 @@ def main():
         p = at.peek()
         pn = p["pert"].norm(dim=2).flatten()
         d1, _, d2, _ = ops.nn_distance(p["recon"], torch.as_tensor(tgt).cuda())
-        print(json.dumps({"prune": os.environ.get("GEOADV_CHAMFER_PRUNE", "1"), "it_per_s": 1 / dt, "ms": dt * 1e3,
+        print(json.dumps({"prune": sys.argv[2], "it_per_s": 1 / dt, "ms": dt * 1e3,
                           "pert_median": pn.median().item(), "pert_p99": torch.quantile(pn[:1000000], 0.99).item(), "pert_max": pn.max().item(),
                           "recon_to_target_nn_dist_median": d1.sqrt().median().item(), "target_to_recon_nn_dist_median": d2.sqrt().median().item()}))
         return
@@ -49,7 +50,7 @@ def main():
     path = "/tmp/trained_victim.npz"
     W.save_npz(path, tr.export_weights())
     for flag in ("1", "0"):
-        subprocess.run([sys.executable, os.path.abspath(__file__), path], env=dict(os.environ, GEOADV_CHAMFER_PRUNE=flag), check=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), path, flag], check=True)
 
 
 if __name__ == "__main__":
