@@ -9,6 +9,7 @@
 // index-aligned with the reference (metrics of iteration k describe the state after k+1 updates).
 #include "ae.h"
 #include "chamfer_grad.h"
+#include "chamfer_grid.h"
 #include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
@@ -27,6 +28,8 @@ size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
 int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
                               hipStream_t stream);
+int launch_chamfer_sym_rider(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
+                             const GridArgs *rider, hipStream_t stream);
 bool chamfer_grid_rides(int n);
 int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call, const float *box,
                         hipStream_t stream);
@@ -355,11 +358,13 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGr
 // max-distance term is on: it needs the arg-max the loss pass finds), so one launch does both: grid = (clouds,
 // 1 + problems * H); row 0 = losses / metrics / keep-best (its four upper waves leave at once), rows 1.. = gradients.
 __global__ __launch_bounds__(CGA_THREADS) void loss_cgrad_kernel(LossArgs la, CGradArgs ca, int H) {
+    GA_STAMP(0, 0);
     if (blockIdx.y == 0) {
         if (threadIdx.x < 256) loss_metrics_body(la, blockIdx.x, gridDim.x);
     } else {
         cgrad_fx_body(ca, (blockIdx.y - 1) / H, blockIdx.x, (blockIdx.y - 1) % H, H);
     }
+    GA_STAMP(0, 7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -454,7 +459,9 @@ struct geoadv_attack {
     float *sym_ws;                   // column-minimum partials of the symmetric Chamfer kernel
     bool cgrad_done;                 // the cached forward's loss launch also produced the Chamfer gradients
     bool chamfer_prune;              // nn_distance(adv, x) through the paired grid search (cfg.all_pairs_source_dist = 0, the default)
-    int *need_adv;                   // [8 B] clouds the grid search handed back to the all-pairs kernel
+    int *need_adv[2];                // [8 B] each: clouds the grid search handed back to the all-pairs kernel.  When the search
+                                     // shares the all-pairs launch, call k reads [k & 1] (the verdicts of call k - 1) and
+                                     // writes [(k + 1) & 1]; a search in its own launch (n > 4096) uses [0] in place
     float *x_box;                    // [B][6] bounding boxes of the source clouds (the grid of the paired search)
     int grid_calls;                  // running number of grid-search launches (paces the retries of clouds that gave up)
     unsigned *masks;                 // [B][n][mask words] ReLU masks of the cached forward, or null (backward recomputes)
@@ -565,17 +572,28 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         at->adam_pending = false;
         at->adv_valid = true;
     }
+    // The paired search needs nothing the network produces and ~11-16 us per workgroup (latency-bound: counting sort, cell
+    // walks).  With the symmetric scan (large batches) it shares the launch of the all-pairs scan of (recon, target), which is
+    // longer and which it cannot slow down by much -- in the latent_decode launch, where it rode until round 2, it was the
+    // longer half (in-kernel stamps: 16.1 against 11.5 us at B = 32).  The scans of (adv, source) in that same launch therefore
+    // follow the verdicts of the PREVIOUS call (GridArgs::need_prev).  Small batches (two-scan kernel: 16-wave workgroups that
+    // fill a CU's registers, so the search's workgroups would only start when the scans are done) keep it beside
+    // latent_decode; clouds of more than GR_MAX_N points keep the search in a launch of its own, ahead of the scans.
+    const bool rides_scan = pruned && chamfer_grid_rides(n) && at->chamfer_sym;
+    const bool rides_latent = pruned && chamfer_grid_rides(n) && !at->chamfer_sym;
+    const int call = at->grid_calls;
+    int *need_new = at->need_adv[rides_scan ? (call + 1) & 1 : 0];
+    const int *need_scan = at->need_adv[rides_scan ? call & 1 : 0];      // what the all-pairs kernels act on in this call
+    if (pruned) at->grid_calls++;
     {
         ProfScope ps(at, GEOADV_PROF_DECODER_FWD, st);
-        if (pruned && !chamfer_grid_rides(n)) {   // large clouds: the search takes a CU's whole LDS, so it gets its own launch
-            if (int rc = launch_chamfer_grid(at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, B, n, at->need_adv, at->grid_calls++,
-                                             at->x_box, st)) return rc;
-            if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
-                                              at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
-        } else if (pruned) {   // the grid search rides in the latent_decode launch (it needs nothing from the network)
+        if (pruned && !rides_scan && !rides_latent) {   // large clouds: the search takes a CU's whole LDS, so it gets its own launch
+            if (int rc = launch_chamfer_grid(at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, B, n, need_new, call, at->x_box, st)) return rc;
+        }
+        if (rides_latent) {
             if (int rc = launch_latent_decode_and_grid(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
                                                        at->fs.dense, at->fs.d1, at->fs.d2, at->adv, at->x, at->a1, at->ia1, at->a2,
-                                                       at->ia2, n, at->need_adv, at->grid_calls++, at->x_box, st)) return rc;
+                                                       at->ia2, n, need_new, call, at->x_box, st)) return rc;
         } else if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
                                                  at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
         if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
@@ -585,12 +603,15 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         if (at->chamfer_sym) {   // one distance evaluation per pair serves both directions
             const ChamferPair pairs[2] = {{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2},
                                           {at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2}};
-            if (pruned) {
-                if (int rc = launch_chamfer_sym_needed(pairs, 2, B, n, n, at->sym_ws, at->need_adv, st)) return rc;
+            if (rides_scan) {
+                const GridArgs rider{at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, n, need_new, need_scan, call, at->x_box};
+                if (int rc = launch_chamfer_sym_rider(pairs, 2, B, n, n, at->sym_ws, need_scan, &rider, st)) return rc;
+            } else if (pruned) {
+                if (int rc = launch_chamfer_sym_needed(pairs, 2, B, n, n, at->sym_ws, need_scan, st)) return rc;
             } else if (int rc = launch_chamfer_sym(pairs, 2, B, n, n, at->sym_ws, st)) return rc;
         } else {
             ChamferScan all[4] = {sc_recon[0], sc_recon[1], sc_adv[0], sc_adv[1]};
-            if (pruned) all[2].need = all[3].need = at->need_adv;      // only the clouds the grid search handed back
+            if (pruned) all[2].need = all[3].need = need_scan;         // only the clouds the grid search handed back
             if (int rc = launch_chamfer_scans(all, 4, B, st)) return rc;
         }
     }
@@ -760,7 +781,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * sym_floats);
     const size_t mask_words = cfg->recompute_backward ? 0 : (size_t)encoder_mask_words() * bn;   // ReLU masks of the cached forward
     need(4 * mask_words);
-    need(4 * 8 * B);                                      // need_adv
+    need(4 * 8 * B); need(4 * 8 * B);                     // need_adv[2]
     need(4 * 6 * B);                                      // x_box
     const bool emd = cfg->emd_weight > 0.f;
     const size_t emd_temp_f = emd ? geoadv_emd_cost_grad1_temp_floats(at->B, at->n, at->n) : 0;
@@ -788,7 +809,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
     at->sym_ws = F(4 * sym_floats);
     at->masks = mask_words ? reinterpret_cast<unsigned *>(take(4 * mask_words)) : nullptr;
-    at->need_adv = I(4 * 8 * B);
+    at->need_adv[0] = I(4 * 8 * B); at->need_adv[1] = I(4 * 8 * B);
     at->grid_calls = 0;
     at->x_box = F(4 * 6 * B);
     at->chamfer_prune = cfg->all_pairs_source_dist == 0;
@@ -847,7 +868,8 @@ extern "C" int geoadv_attack_set_inputs(geoadv_attack *at, const float *source_p
     if (target_latent) GA_HIP(hipMemcpyAsync(at->tz, target_latent, 4 * (size_t)at->B * 128, hipMemcpyDeviceToDevice, st));
     GA_HIP(hipMemcpyAsync(at->w, dist_weight, 4 * (size_t)at->B, hipMemcpyDeviceToDevice, st));
     if (int rc = launch_chamfer_grid_box(at->x, at->B, at->n, at->x_box, st)) return rc;   // grid of the paired nn search
-    GA_HIP(hipMemsetAsync(at->need_adv, 0, sizeof(int) * 8 * (size_t)at->B, st));          // new clouds: every verdict is open again
+    for (int i = 0; i < 2; ++i)                                                            // new clouds: every verdict is open again
+        GA_HIP(hipMemsetAsync(at->need_adv[i], 0, sizeof(int) * 8 * (size_t)at->B, st));
     at->fwd_valid = false; at->adv_valid = false;
     return GEOADV_OK;
 }
@@ -959,3 +981,4 @@ extern "C" int geoadv_attack_profile_read(geoadv_attack *at, int which, int *lau
     *total_ms = (float)at->prof_ms[which];
     return GEOADV_OK;
 }
+GA_STAMPS_GETTER(geoadv_debug_stamps_attack)

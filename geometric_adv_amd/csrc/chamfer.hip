@@ -59,6 +59,7 @@ __device__ __forceinline__ float sqdist(float tx, float ty, float tz, float qx, 
 template <int R, int WAVES>
 __global__ __launch_bounds__(kWave * WAVES, 16 / WAVES) void chamfer_scan_kernel(ChamferArgs args) {
     constexpr int CH_THREADS = kWave * WAVES, CH_WAVES = WAVES;
+    GA_STAMP(0, 0);
     // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own
     // L2), so all query tiles of one (scan, cloud) group -- which stream the same target cloud -- are
     // given the same `blockIdx % 8`: the cloud is then fetched into ONE L2 instead of eight.
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(kWave * WAVES, 16 / WAVES) void chamfer_scan_kernel
             sx[e] = x; sy[e] = y; sz[e] = z;
         }
         __syncthreads();
+        GA_STAMP(0, 1);
         const int nchunks = cntp / CH_CHUNK;
         const int cbeg = nchunks * wave / CH_WAVES, cend = nchunks * (wave + 1) / CH_WAVES;
         if (cbeg < cend) {
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(kWave * WAVES, 16 / WAVES) void chamfer_scan_kernel
         }
     }
 
+    GA_STAMP(0, 2);
     // Re-scan the winning chunk of every query for the first index attaining the minimum.  With a single LDS stage
     // (nt <= 2048: the attack's shape) the chunk is still in the stage planes: two ds_read_b128 per plane, hits taken in
     // DESCENDING order so that the last one kept is the lowest index (padding is +inf and never equals a finite minimum).
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(kWave * WAVES, 16 / WAVES) void chamfer_scan_kernel
             sc.idx[(size_t)c * nq + q0 + qq] = k;
         }
     }
+    GA_STAMP(0, 7);
 }
 
 // m == 0: the reference CPU loop leaves best = 0, besti = 0 (tf_nndistance.cpp:27-28,39-40).
@@ -349,3 +353,4 @@ extern "C" int geoadv_nn_distance_grad(int b, int n, const float *xyz1, int m, c
     return launch_chamfer_grad(b, n, xyz1, m, xyz2, grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2,
                                as_stream(stream));
 }
+GA_STAMPS_GETTER(geoadv_debug_stamps_chamfer)

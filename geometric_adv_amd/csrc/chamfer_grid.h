@@ -42,6 +42,12 @@ struct GridArgs {
     int n;
     int *need;                    // null, or int[8 * b]: (cloud, direction, query slice) -> 1 if that workgroup gave up
                                   // (poor pairing: the caller runs the all-pairs kernel for the cloud), 0 if it wrote its outputs
+    const int *need_prev;         // null: the verdict takes effect in THIS call (the caller's all-pairs launch comes after this
+                                  // one and reads `need`).  Else int[8 * b], the verdicts of the PREVIOUS call: this search
+                                  // shares its launch with the all-pairs kernel, which therefore acts on need_prev -- a
+                                  // workgroup answers its queries iff need_prev says 0 (whatever it thinks of the pairing now:
+                                  // the search is exact either way, only slower on a poor pairing) and writes its new verdict
+                                  // to `need` for the next call.
     int call;                     // running call number (the caller's iteration): paces the retries of workgroups that gave up
     const float *box;             // null, or [b][6]: min xyz, max xyz of every Q cloud (constant over the attack: computed once)
 };
@@ -55,15 +61,19 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
     float4 *sorted = reinterpret_cast<float4 *>(gr_lds);
     unsigned *counts = reinterpret_cast<unsigned *>(sorted + a.n);
     unsigned short *cell_start = reinterpret_cast<unsigned short *>(counts + GR_CELLS);
+    // (static LDS of a multiple of 16 bytes -- 32 + 192 + 16 -- so that the dynamic region behind it, which the kernels
+    // hosting this block read with ds_read_b128, stays 16-byte aligned: cdna_hip_programming.md, Guideline 17)
     __shared__ unsigned wave_tot[GR_THREADS / 64];
     __shared__ float bb[GR_THREADS / 64][6];
-    __shared__ int n_far, far_cnt, cand_cnt;
+    __shared__ int gr_cnt[4];
+    int &n_far = gr_cnt[0], &far_cnt = gr_cnt[1], &cand_cnt = gr_cnt[2];
 
     const int n = a.n, t = threadIdx.x;
-    int *my_need = a.need ? a.need + (2 * cloud + dir) * GR_QSPLIT + slice : nullptr;
+    const int need_off = (2 * cloud + dir) * GR_QSPLIT + slice;
+    int *my_need = a.need ? a.need + need_off : nullptr;
     // a workgroup that gave up keeps its flag and leaves at once, except on every GR_RETRY-th call (the attack's points keep
     // moving: a cloud that was hopeless may have become easy and vice versa)
-    const int gave_up_before = my_need ? *my_need : 0;                 // (requested together with the point loads below)
+    const int gave_up_before = my_need ? (a.need_prev ? a.need_prev[need_off] : *my_need) : 0;   // (requested together with the point loads below)
     const int jbeg = (int)((long)n * slice / GR_QSPLIT), jend = (int)((long)n * (slice + 1) / GR_QSPLIT);   // this workgroup's queries
     const float *A = (dir ? a.Q : a.P) + (size_t)cloud * n * 3;      // queries
     const float *T = (dir ? a.P : a.Q) + (size_t)cloud * n * 3;      // targets
@@ -87,7 +97,10 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
             if (my_need) { ox[k] = Ox[3 * i]; oy[k] = Ox[3 * i + 1]; oz[k] = Ox[3 * i + 2]; }
         }
     }
-    if (gave_up_before != 0 && (a.call % GR_RETRY) != 0) return;
+    if (gave_up_before != 0 && (a.call % GR_RETRY) != 0) {
+        if (a.need_prev && t == 0) *my_need = gave_up_before;         // (two flag arrays: carry the verdict over)
+        return;
+    }
     float lo[3], ih[3];
     if (a.box) {
 #pragma unroll
@@ -121,6 +134,7 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
             ih[c] = (float)GR_G / fmaxf(h - l, 1e-6f);                 // identical in every thread: the grid is one grid
         }
     }
+    GA_STAMP(1, 1);
     // ---- is the pairing good enough?  Decided for the WHOLE cloud from the pairs (P_j, Q_j) alone -- ball radius r_j around
     // Q_j in this grid -- so that all eight workgroups of the cloud reach the same verdict (a cloud answered half by this
     // search and then again by the all-pairs kernel would pay twice) ----
@@ -146,8 +160,11 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
         __syncthreads();
         const bool give_up = far_cnt * GR_FAR_DIV > n || cand_cnt > GR_MEAN_CELLS * n;
         if (t == 0) *my_need = give_up ? 1 : 0;
-        if (give_up) return;
+        if (a.need_prev ? gave_up_before != 0 : give_up) return;       // shared launch: the all-pairs kernel follows the OLD verdict
+    } else if (a.need_prev && my_need && t == 0) {
+        *my_need = 0;                                                  // in good standing, not re-examined this call
     }
+    GA_STAMP(1, 2);
     // ---- counting sort of the targets by cell ----
     int tcell[PER], trank[PER];
 #pragma unroll
@@ -185,6 +202,7 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
         if (i < n) sorted[cell_start[tcell[k]] + trank[k]] = make_float4(tx[k], ty[k], tz[k], __int_as_float(i));
     }
     __syncthreads();
+    GA_STAMP(1, 3);
     // the counts are dead: queue of far queries -- index and coordinates (16 B each, so that the scan below does not start
     // with a global round trip) where the slice's queries fit the 16 KB, the index alone for the large instantiation
     constexpr bool QXYZ = (MAXN / GR_QSPLIT) * 4 <= GR_CELLS;
@@ -239,6 +257,7 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
         idx[j] = bestk;
     }
     __syncthreads();
+    GA_STAMP(1, 4);
     // ---- far queries: one wave per query, all targets ----
     const int lane = t & 63, wave = t >> 6;
     const int nf = n_far;
@@ -279,6 +298,22 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
         wave_lexmin(best, bestk);
         if (lane == 0) { dist[j] = best; idx[j] = bestk; }
     }
+}
+
+// The search's workgroups as extra blocks of another kernel's launch (blocks first_block .. of a 1-D grid, GR_THREADS threads
+// or more -- surplus waves leave): blocks == 0 = none.  Block order: (cloud, direction, slice), slice fastest.
+struct GridRider { GridArgs g; int first_block, blocks; };
+template <int MAXN>
+__device__ __forceinline__ bool grid_rider_block(const GridRider &r) {   // true: this workgroup belonged to the rider and is done
+    if (r.blocks == 0 || (int)blockIdx.x < r.first_block || (int)blockIdx.x >= r.first_block + r.blocks) return false;
+    if (threadIdx.x < GR_THREADS) {
+        __builtin_amdgcn_s_setprio(3);                     // short and latency-bound beside a VALU-dense host kernel: never starve it
+        const int g = blockIdx.x - r.first_block;
+        GA_STAMP(1, 0);
+        grid_nn_block<MAXN>(r.g, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
+        GA_STAMP(1, 7);
+    }
+    return true;
 }
 
 inline size_t chamfer_grid_lds_bytes(int n) { return sizeof(float4) * (size_t)n + sizeof(unsigned) * GR_CELLS + sizeof(unsigned short) * (GR_CELLS + 2); }

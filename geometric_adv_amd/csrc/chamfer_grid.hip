@@ -48,7 +48,7 @@ int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, floa
                         const float *box, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
     GA_REQUIRE(chamfer_grid_supports(n, n), "chamfer_grid: needs 1 <= n <= %d", GR_MAX_N_BIG);
-    const GridArgs a{P, Q, d1, i1, d2, i2, n, need, call, box};
+    const GridArgs a{P, Q, d1, i1, d2, i2, n, need, nullptr, call, box};
     return n <= GR_MAX_N ? launch_grid<GR_MAX_N>(a, b, stream) : launch_grid<GR_MAX_N_BIG>(a, b, stream);
 }
 

@@ -18,6 +18,7 @@
 // attaining it; then only the 64 rows of that tile's winning quarter are re-evaluated to find the lowest row index
 // with d == minimum (exactly the reference's tie rule): 1/32 of a scan at n = 2048.
 #include "common.h"
+#include "chamfer_grid.h"
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -41,6 +42,7 @@ struct ChamferSymArgs {
     int *rowpart_i;
     const int *need[2];        // per pair: null = every cloud; else int[8 * clouds], cloud c is computed only if one of
                                // its 8 flags is set (a workgroup of the paired grid search, chamfer_grid.hip, gave up)
+    GridRider rider;           // the attack loop: the paired grid search of (adv, source) as extra workgroups of the scan launch
 };
 
 __device__ __forceinline__ bool sym_needed(const int *need, int c) {
@@ -64,9 +66,13 @@ __device__ __forceinline__ float sqdist_s(float tx, float ty, float tz, float qx
     return (xx + yy) + zz;
 }
 
+constexpr size_t CS_LDS_BYTES = sizeof(float) * (3 * CS_STAGE + CS_WAVES * CS_ROUND * CS_TSTRIDE);   // stage planes + transpose buffers
+
 __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymArgs a) {
     constexpr int R = CS_R;
-    const int lin = blockIdx.x;                            // XCD-aware mapping, see chamfer_scan_kernel
+    if (grid_rider_block<GR_MAX_N>(a.rider)) return;
+    GA_STAMP(0, 0);
+    const int lin = blockIdx.x - a.rider.blocks;           // (the rider's workgroups come first); XCD-aware mapping, see chamfer_scan_kernel
     const int xcd = lin & 7, slot = lin >> 3;
     const int per = a.tiles * a.csplit;                    // workgroups per (pair, cloud) group
     const int group = (slot / per) * 8 + xcd, sub = slot % per;
@@ -86,8 +92,10 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     const float *Q = pr.q + (size_t)cq * m * 3;
     float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * a.tiles + tile) * m * 4;      // [m][4 quarters]
 
-    __shared__ __attribute__((aligned(16))) float stage[3 * CS_STAGE];
-    __shared__ __attribute__((aligned(16))) float tbuf[CS_WAVES][CS_ROUND * CS_TSTRIDE];
+    // all of it in the DYNAMIC region (CS_LDS_BYTES, or the rider's need if larger): a launch that hosts the grid search's
+    // workgroups is charged max(scan, search) of LDS per workgroup, not the sum
+    extern __shared__ __attribute__((aligned(16))) float stage[];
+    float (*tbuf)[CS_ROUND * CS_TSTRIDE] = reinterpret_cast<float (*)[CS_ROUND * CS_TSTRIDE]>(stage + 3 * CS_STAGE);
     float *sx = stage, *sy = stage + CS_STAGE, *sz = stage + 2 * CS_STAGE;
     static_assert(2 * CS_WAVES * CS_ROWS <= 3 * CS_STAGE, "merge arrays must fit in the stage buffer");
     float (*mdist)[CS_ROWS] = reinterpret_cast<float (*)[CS_ROWS]>(stage);
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
             __builtin_amdgcn_wave_barrier();              // the buffer is rewritten by the next round
         }
     }
+    GA_STAMP(0, 1);
     // row minima: first index attaining the minimum inside the winning chunk, then merge the waves.  With a single LDS
     // stage (m <= 2048 per slice: the attack's shape) the chunk is still in the stage buffer; otherwise it is re-read from
     // global memory.  The stage buffer becomes the merge arrays afterwards, hence the barrier between the two loops.
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
             }
         }
     }
+    GA_STAMP(0, 7);
 }
 
 // grid = (column slices, clouds * pairs).  Every workgroup takes an equal slice of COLUMNS (so the work is
@@ -282,6 +292,7 @@ __device__ __forceinline__ int finish_quarter(const float *sx, const float *sy, 
 
 __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferSymArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    GA_STAMP(2, 0);
     const int tiles = a.tiles;
     float *rx = lds, *ry = lds + tiles * CF_SEG, *rz = lds + 2 * tiles * CF_SEG;
     const int group = blockIdx.y;
@@ -365,6 +376,7 @@ __global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferS
             qx = Q[3 * (size_t)kc]; qy = Q[3 * (size_t)kc + 1]; qz = Q[3 * (size_t)kc + 2];
         }
     }
+    GA_STAMP(2, 7);
 }
 
 constexpr int CS_MAX_SPLIT = 4;
@@ -374,7 +386,7 @@ size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
 
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
-                          int q_clouds, const int *need1, hipStream_t stream);
+                          int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider = nullptr);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream) {
     return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, nullptr, stream);
 }
@@ -383,9 +395,14 @@ int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, in
                               hipStream_t stream) {
     return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream);
 }
+// ... and with the paired grid search (rider->n <= GR_MAX_N) as 8 * b extra workgroups of the scan launch
+int launch_chamfer_sym_rider(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
+                             const GridArgs *rider, hipStream_t stream) {
+    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider);
+}
 
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
-                          int q_clouds, const int *need1, hipStream_t stream) {
+                          int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider) {
     if (b <= 0 || np <= 0) return GEOADV_OK;
     ChamferSymArgs a;
     a.need[0] = nullptr; a.need[1] = need1;
@@ -401,10 +418,21 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     if (int rc = attr.run([]() -> int {
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_finish_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)std::max(CS_LDS_BYTES, chamfer_grid_lds_bytes(GR_MAX_N))));
             return GEOADV_OK;
         })) return rc;
-    const unsigned grid = (unsigned)(a.tiles * a.csplit * 8 * cdiv(b * np, 8));
-    chamfer_sym_kernel<<<grid, CS_THREADS, 0, stream>>>(a);
+    unsigned grid = (unsigned)(a.tiles * a.csplit * 8 * cdiv(b * np, 8));
+    a.rider.blocks = 0; a.rider.first_block = 0;
+    size_t scan_lds = CS_LDS_BYTES;
+    if (rider) {
+        a.rider.g = *rider;
+        a.rider.first_block = 0;                           // dispatched first: its latency-bound workgroups start at once
+        a.rider.blocks = b * 2 * GR_QSPLIT;
+        grid += (unsigned)a.rider.blocks;
+        scan_lds = std::max(scan_lds, chamfer_grid_lds_bytes(rider->n));
+    }
+    chamfer_sym_kernel<<<grid, CS_THREADS, scan_lds, stream>>>(a);
     GA_LAUNCH_CHECK();
     const size_t lds = sizeof(float) * 3 * (size_t)a.tiles * CF_SEG;
     GA_REQUIRE(lds <= 150 * 1024, "chamfer_sym: too many rows (%d)", n);
@@ -475,3 +503,4 @@ extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *
     }
     return GEOADV_OK;
 }
+GA_STAMPS_GETTER(geoadv_debug_stamps_chamfer_sym)

@@ -53,6 +53,30 @@ struct DeviceOnce {
 };
 
 #ifdef __HIPCC__
+// In-kernel stamps for a DIAGNOSTIC build only (-DGA_STAMPS, tools/debug/build_variants.sh; the shipped library contains none
+// of this): thread 0 of a workgroup writes the 100 MHz wall clock (s_memrealtime) at phase boundaries into a per-translation-unit
+// array -- kernel slot K, linear block id, stamp index 0..7 -- read back through the getter GA_STAMPS_GETTER defines.
+#ifdef GA_STAMPS
+#define GA_STAMP_BLOCKS 1024
+static __device__ unsigned long long ga_stamps[8 * GA_STAMP_BLOCKS * 8];
+#define GA_STAMP(K, I)                                                                                   \
+    do {                                                                                                 \
+        const unsigned blk_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);            \
+        if (threadIdx.x == 0 && blk_ < GA_STAMP_BLOCKS) {                                                \
+            unsigned long long t_;                                                                       \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            ga_stamps[(((K) & 7) * GA_STAMP_BLOCKS + blk_) * 8 + (I)] = t_;                               \
+        }                                                                                                \
+    } while (0)
+#define GA_STAMPS_GETTER(NAME)                                                                           \
+    extern "C" int NAME(unsigned long long *host_out) {                                                  \
+        return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(::geoadv::ga_stamps), sizeof(unsigned long long) * 8 * GA_STAMP_BLOCKS * 8) == hipSuccess ? 0 : 1; \
+    }
+#else
+#define GA_STAMP(K, I)
+#define GA_STAMPS_GETTER(NAME)
+#endif
+
 // Lexicographic (value, index) minimum over the 64 lanes of a wave; every lane ends up with the result.  Four DPP steps
 // reduce each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- register-to-register, a few cycles
 // each, where a __shfl_xor is a ds_bpermute round trip of ~150), v_readlane collects the four rows.

@@ -59,32 +59,53 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
     __shared__ float part[4][256];
     __shared__ int tie;
     const int t = threadIdx.x;
+    GA_STAMP(0, 0);
     if (t == 0) tie = 0;
-    // 8 contiguous tile groups x 128 channels; ascending tiles inside a group, groups merged in order
+    // 8 contiguous tile groups x 128 channels; ascending tiles inside a group, groups merged in order.  Every merge is
+    // BRANCH-FREE: with `if (pm > m) { a = pa; k = pk; }` the compiler makes the arg / count loads lazy -- one dependent
+    // global round trip per tile and array, 8-16 in a row (4.4 us of this kernel's 9.8 at B = 4, in-kernel stamps) -- where
+    // selects need every operand, so all loads of a batch are requested together.
     for (int g = t >> 7; g < 8; g += THREADS / 128) {
         const int c = t & 127;
         const int tb = tiles * g / 8, te = tiles * (g + 1) / 8;
         float m = -1.f;
         int a = INT_MAX, k = 0;
-#pragma unroll 4
-        for (int tl = tb; tl < te; ++tl) {
-            const size_t o = ((size_t)b * tiles + tl) * 128 + c;
-            const float pm = pmax[o];
-            const int pa = parg[o], pk = pcnt[o];
-            if (pm > m) { m = pm; a = pa; k = pk; }
-            else if (pm == m) k += pk;
+        constexpr int U = 8;                                   // tiles per batch: 24 loads in flight per thread
+        for (int t0 = tb; t0 < te; t0 += U) {
+            float pm[U];
+            int pa[U], pk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int tl = t0 + u < te ? t0 + u : te - 1;  // (a repeated last tile is masked out below)
+                const size_t o = ((size_t)b * tiles + tl) * 128 + c;
+                pm[u] = pmax[o]; pa[u] = parg[o]; pk[u] = pcnt[o];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = t0 + u < te;
+                const bool gt = live && pm[u] > m, eq = live && pm[u] == m;
+                k = gt ? pk[u] : (eq ? k + pk[u] : k);
+                a = gt ? pa[u] : a;
+                m = gt ? pm[u] : m;
+            }
         }
         gm[g][c] = m; ga[g][c] = a; gk[g][c] = k;
     }
     __syncthreads();
+    GA_STAMP(0, 1);
     if (t < 128) {
-        float m = gm[0][t];
-        int a = ga[0][t], k = gk[0][t];
+        float gmv[8];
+        int gav[8], gkv[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { gmv[g] = gm[g][t]; gav[g] = ga[g][t]; gkv[g] = gk[g][t]; }
+        float m = gmv[0];
+        int a = gav[0], k = gkv[0];
 #pragma unroll
         for (int g = 1; g < 8; ++g) {
-            const float pm = gm[g][t];
-            if (pm > m) { m = pm; a = ga[g][t]; k = gk[g][t]; }
-            else if (pm == m) k += gk[g][t];
+            const bool gt = gmv[g] > m, eq = gmv[g] == m;
+            k = gt ? gkv[g] : (eq ? k + gkv[g] : k);
+            a = gt ? gav[g] : a;
+            m = gt ? gmv[g] : m;
         }
         zs[t] = m;
         z[(size_t)b * 128 + t] = m;
@@ -94,6 +115,7 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
     }
     __syncthreads();
     if (t == 0) dense[b] = tie;
+    GA_STAMP(0, 2);
     if (!d1) return;
     {   // FC0 + ReLU: 128 -> 256
         const float s = fc256_split4<128, THREADS>(zs, A.v0, part);
@@ -104,10 +126,12 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
         }
     }
     __syncthreads();
+    GA_STAMP(0, 3);
     {   // FC1 + ReLU: 256 -> 256
         const float s = fc256_split4<256, THREADS>(hs, A.v1, part);
         if (t < 256) d2[(size_t)b * 256 + t] = fmaxf(s + A.c1[t], 0.f);
     }
+    GA_STAMP(0, 7);
 }
 
 __global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
@@ -133,7 +157,9 @@ __global__ __launch_bounds__(THREADS) void latent_decode_and_grid_kernel(DeviceA
     }
     if (THREADS > GR_THREADS && threadIdx.x >= GR_THREADS) return;
     const int g = blockIdx.x - batch;                   // (cloud, direction, slice), slice fastest
+    GA_STAMP(1, 0);
     grid_nn_block<GR_MAX_N>(G, g / (2 * GR_QSPLIT), (g / GR_QSPLIT) % 2, g % GR_QSPLIT);
+    GA_STAMP(1, 7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -142,6 +168,7 @@ __global__ __launch_bounds__(THREADS) void latent_decode_and_grid_kernel(DeviceA
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void decoder_fc2_block(const DeviceAE &A, int batch, const float *d2, float *out, const int cb, const int rb) {
     __shared__ float part[3][16][64];
+    GA_STAMP(2, 0);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int h = lane >> 5, i = lane & 31;
     const PackedLayer &L = A.dec2_fwd;
@@ -185,6 +212,7 @@ __device__ __forceinline__ void decoder_fc2_block(const DeviceAE &A, int batch, 
             if (row < batch && col < ncols) out[(size_t)row * ncols + col] = v;
         }
     }
+    GA_STAMP(2, 7);
 }
 
 __global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch, const float *d2, float *out) {
@@ -199,6 +227,7 @@ constexpr int DB_KC = 64;
 
 __global__ __launch_bounds__(512) void decoder_fc2_bwd_kernel(DeviceAE A, int batch, const float *g_out, float *partial) {
     __shared__ __attribute__((aligned(16))) float as[32 * (DB_KC + 4)];
+    GA_STAMP(3, 0);
     const int ch = blockIdx.x, rb = blockIdx.y;
     const int ncols = A.dec_dims[GEOADV_DEC_LAYERS];   // 3N = K of this product
     const PackedLayer &L = A.dec2_bwd;
@@ -238,6 +267,7 @@ __global__ __launch_bounds__(512) void decoder_fc2_bwd_kernel(DeviceAE A, int ba
         const int row = rb * 32 + acc_row16(r, h);
         if (row < batch) partial[((size_t)ch * batch + row) * 256 + col] = acc[r];
     }
+    GA_STAMP(3, 7);
 }
 
 // dd2 = sum of partials, masked by d2 > 0; dd1 = dd2 @ V1^T masked by d1 > 0; dz = dd1 @ V0^T.
@@ -250,6 +280,7 @@ __global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A
     __shared__ float g1[256];
     __shared__ float part[8][256];
     const int b = blockIdx.x, t = threadIdx.x, o = t & 255, ks = t >> 8;
+    GA_STAMP(4, 0);
     {   // split-K partials: 4 contiguous chunk groups, ascending inside, merged in order
         const int cb = chunks * ks / 4, ce = chunks * (ks + 1) / 4;
         float s = 0.f;
@@ -263,12 +294,14 @@ __global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A
         g2[t] = d2[(size_t)b * 256 + t] > 0.f ? s : 0.f;
     }
     __syncthreads();
+    GA_STAMP(4, 1);
     {
         const float s = fc256_split4<256>(g2, A.v1t, part);
         __syncthreads();
         if (t < 256) g1[t] = d1[(size_t)b * 256 + t] > 0.f ? s : 0.f;
     }
     __syncthreads();
+    GA_STAMP(4, 2);
     {   // dz: 128 outputs x 8 K-slices of 32
         const int c = t & 127, k8 = t >> 7;
         float w[32];
@@ -286,6 +319,7 @@ __global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A
             dz[(size_t)b * 128 + t] = r;
         }
     }
+    GA_STAMP(4, 7);
 }
 
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
@@ -309,7 +343,7 @@ int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, c
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)chamfer_grid_lds_bytes(GR_MAX_N)));
             return GEOADV_OK;
         })) return rc;
-    const GridArgs G{P, Q, gd1, gi1, gd2, gi2, n, need, call, box};
+    const GridArgs G{P, Q, gd1, gi1, gd2, gi2, n, need, nullptr, call, box};
     const int blocks = b + b * 2 * GR_QSPLIT;
     if (blocks <= kCUs)     // one workgroup per CU is enough: keep the latent blocks at their 16 waves
         latent_decode_and_grid_kernel<LD_THREADS><<<blocks, LD_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
@@ -342,3 +376,4 @@ int launch_decoder_bwd(const DeviceAE &A, int b, const float *g_recon, const flo
 }
 
 }  // namespace geoadv
+GA_STAMPS_GETTER(geoadv_debug_stamps_decoder)

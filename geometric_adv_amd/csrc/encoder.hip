@@ -178,6 +178,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, i
                                                                   unsigned *masks, FusedAdam fa) {
     constexpr int THREADS = Fwd2<ROWS>::THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    GA_STAMP(0, 0);
     float *bufA = lds;
     float *bufB = bufA + Fwd2<ROWS>::BUF_FLOATS;
     float *pts = bufB + Fwd2<ROWS>::BUF_FLOATS;       // [ROWS][3]
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, i
         if (MASKS) reinterpret_cast<unsigned char *>(mtile)[row * (4 * MASK_WORDS) + (threadIdx.x & 7)] = (unsigned char)bits;
     }
     __syncthreads();
+    GA_STAMP(0, 1);
     const int mrow = orow_of(rb) + (lane & 3) + 8 * ((lane & 15) >> 2);    // lanes 0-15: row acc_row(lane, 0) of this wave's block
 
     const int orow = orow_of(rb);                     // accumulator rows of this wave: orow + acc_row(r, h)
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, i
         }
         if (half == 0) __syncthreads();               // bufB is rewritten by the second half of layer 3
     }
+    GA_STAMP(0, 2);
     // BN + ReLU and the max-pool from the registers: maximum, FIRST row attaining it, number of rows attaining it.
     // Two branch-free passes (max, then compare) -- a third of the VALU instructions of the if / else-if form.
     const int col = ccol;
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(ROWS * 8, 4) void encoder_fwd2_kernel(DeviceAE A, i
         unsigned *dst = masks + ((size_t)b * n + n0) * MASK_WORDS;
         for (int e = threadIdx.x; e < live * MASK_WORDS; e += THREADS) dst[e] = mtile[e];
     }
+    GA_STAMP(0, 7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -699,9 +703,11 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_merged_kernel(DeviceA
                                                                         float *g_enc, int rows16) {
     const int per = rows16 ? 128 / BWM_ROWS : 128 / BWM32_ROWS;
     const int nm = per * batch;
+    GA_STAMP(1, 0);
     if ((int)blockIdx.x < nm) {
         if (rows16) encoder_bwd_masked_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % per, blockIdx.x / per);
         else encoder_bwd_masked32_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % per, blockIdx.x / per);
+        GA_STAMP(1, 7);
         return;
     }
     const int d = blockIdx.x - nm, tiles = (n + 63) / 64, tile = d % tiles, slot = d / tiles;
@@ -817,3 +823,4 @@ int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *cr
 }
 
 }  // namespace geoadv
+GA_STAMPS_GETTER(geoadv_debug_stamps_encoder)
