@@ -36,7 +36,8 @@ B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
+PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r03_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep: ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- what each rank of the strong-scaling leg runs
 SWEEP_SRC = "profiles/r02_attack_sweep.json"
@@ -190,6 +191,77 @@ def pmc_encoder():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
         util = k["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / (k["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
     return traffic, util, "profiles/%s: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes" % os.path.basename(PMC_FILE)
+
+
+def pmc_chamfer(alg_bytes):
+    """Counter-measured HBM-side traffic of nn_distance(recon, target) in the loop: chamfer_sym_kernel + chamfer_sym_finish_kernel,
+    (2 * FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 halves wide reads; separate --pmc passes of tools/attack_breakdown.py 32,
+    i.e. ONE leg: the pruned loop) and the profiled kernel times of the same passes.  Dropped when the kernel sources changed."""
+    try:
+        d = json.load(open(PMC_CHAMFER_FILE))
+    except Exception as e:
+        return {"traffic": None, "traffic_source": "no PMC profile (%s)" % e}
+    want = d.get("_source_sha1", {})
+    if not want or source_hashes(sorted(want)) != want:
+        return {"traffic": None, "traffic_source": "%s was taken at different kernel sources: dropped" % os.path.basename(PMC_CHAMFER_FILE)}
+    tot, us, per = 0.0, 0.0, {}
+    for key in ("chamfer_sym_kernel", "chamfer_sym_finish_kernel"):
+        names = [n for n in d if n.endswith(key)]
+        if not names or "FETCH_SIZE" not in d[names[0]] or "WRITE_SIZE" not in d[names[0]]:
+            return {"traffic": None, "traffic_source": "%s lacks FETCH_SIZE / WRITE_SIZE for %s" % (os.path.basename(PMC_CHAMFER_FILE), key)}
+        k = d[names[0]]
+        b = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
+        per[key] = {"bytes_per_launch": b, "avg_us_profiled": k.get("avg_us_profiled")}
+        tot += b
+        us += k.get("avg_us_profiled") or 0.0
+    return {"traffic": tot, "traffic_over_algorithmic": tot / alg_bytes, "achieved_hbm_GBps_counters": (tot / (us * 1e-6) / 1e9) if us else None,
+            "per_kernel": per, "traffic_source": "profiles/%s: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of both kernels, separate --pmc passes "
+                                                 "of tools/attack_breakdown.py 32 (the pruned loop only)" % os.path.basename(PMC_CHAMFER_FILE)}
+
+
+def surface_clouds(seed, b, n):
+    """Non-uniform stand-ins for ShapeNet surfaces (in_out.py:156-218 loads unit-scaled CAD surfaces; the dataset is absent here):
+    60 % of a cloud on a sphere shell of radius 0.4, 35 % on a tilted plane patch through it, 5 % outliers in the unit cube."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    k1, k2 = int(0.6 * n), int(0.35 * n)
+    v = rng.standard_normal((b, k1, 3))
+    shell = 0.4 * v / np.linalg.norm(v, axis=2, keepdims=True)
+    uv = rng.random((b, k2, 2)) - 0.5
+    plane = np.stack([0.8 * uv[..., 0], 0.8 * uv[..., 1], 0.3 * uv[..., 0] - 0.2 * uv[..., 1] + 0.05], axis=2)
+    out = rng.random((b, n - k1 - k2, 3)) - 0.5
+    pts = np.concatenate([shell, plane, out], axis=1)
+    perm = rng.permuted(np.tile(np.arange(n), (b, 1)), axis=1)                      # no ordering by part
+    return np.take_along_axis(pts, perm[:, :, None].repeat(3, 2), axis=1).astype(np.float32)
+
+
+def surfaces_leg(dev, weights, ae, steps, warmup):
+    """secondary.surface_clouds: the headline loop on surface-like clouds instead of uniform cubes, with the paired grid search
+    on and off, and how many of the 32 clouds the search hands back to the all-pairs kernel (sampled every 25 iterations)."""
+    import torch
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    x, gt = surface_clouds(4001, B, N), surface_clouds(4002, B, N)
+    out = {"clouds": "60 % sphere shell r = 0.4, 35 % tilted plane patch, 5 % uniform outliers; seeds 4001 / 4002"}
+    for label, prune in (("grid_search", True), ("all_pairs", False)):
+        at = AdvAE("adversary", Configuration(batch_size=B, n_points=N, weights=weights, num_iterations=warmup + steps,
+                                              num_iterations_thresh=10 ** 6, learning_rate=0.01, chamfer_prune=prune), device=dev, ae=ae)
+        at.set_inputs(x, gt, ae.transform(gt), 1.0)
+        at.init_pert(None, reset_optimizer=True)
+        at.run(0, warmup, 10 ** 6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        at.run(warmup, steps, 10 ** 6)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[label] = {"attack_iterations_per_sec": steps / dt, "ms_per_step": dt / steps * 1e3}
+        if prune:                       # untimed: the hand-back verdicts along a further stretch of the attack
+            hb = []
+            for k in range(8):
+                at.run(warmup + steps + 25 * k, 25, 10 ** 6)
+                hb.append(at.search_state()[1])
+            out[label]["clouds_handed_back_of_%d_every_25_iterations" % B] = hb
+            out[label]["mean_fraction_handed_back"] = sum(hb) / (len(hb) * float(B))
+    return out
 
 
 class TimedOracle:
@@ -624,11 +696,12 @@ def main():
                                "timed windows" % ("" if stride == 1 else {2: "2nd", 3: "3rd"}.get(stride, "%d-th" % stride))},
         "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel: nn_distance(recon, target), both "
                                                          "directions from one distance evaluation per pair; nn_distance(adv, x) is answered "
-                                                         "exactly by the paired grid search inside the latent_decode launch (decoder_fwd class)",
+                                                         "exactly by the paired grid search, whose workgroups ride in the scan's launch",
                              "avg_class_ms": ch_avg_ms, "launches_timed": 50,
                              "achieved_Tpair_per_s": ch_pairs / (ch_avg_ms * 1e-3) / 1e12,
                              "algorithmic_bytes_per_launch": ch_bytes,
-                             "achieved_hbm_GBps": ch_bytes / (ch_avg_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS},
+                             "achieved_hbm_GBps": ch_bytes / (ch_avg_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS,
+                             **pmc_chamfer(ch_bytes)},
         "kernel_ms_per_iteration": breakdown,
         "kernel_ms_note": "bracketing events per class (dispatch gaps included), untimed 50-iteration pass; encoder_fwd here is kernel-timed",
         "final_mean_target_recon_error": float(leg.gathered[0, :, 4].mean().item()),
@@ -636,7 +709,8 @@ def main():
     if world == 1:                  # no collective ran at N = 1: show in a child process that RCCL comes up on this box
         out["config"]["rccl_selftest"] = rccl_selftest()
     if world == 1:                  # the widened row f-4, measured beside the headline (not part of `value`)
-        out["secondary"] = {"ae_training_step": training_leg(dev), "roofline_emd": emd_leg(dev)}
+        out["secondary"] = {"ae_training_step": training_leg(dev), "roofline_emd": emd_leg(dev),
+                            "surface_clouds": surfaces_leg(dev, weights, ae, min(K, 200), Wm)}
         if args.slots > 1:
             out["secondary"]["batch_slots"] = slots_leg(dev, weights, ae, args.slots)
     if world == 1 and not args.no_cpu_baseline:

@@ -43,7 +43,10 @@ class Configuration:
         self.emd_weight = float(emd_weight)
         self.verbose = verbose
         self.batch_slots = int(batch_slots)      # batches attacked concurrently on this GPU (AdvAE.attack); 1 = the reference's order
-        self.chamfer_prune = bool(chamfer_prune) # False: nn_distance(adv, x) always by the all-pairs kernel (same results)
+        if chamfer_prune not in (True, False, "always"):
+            raise ValueError("chamfer_prune must be True (grid search except for tiny batches), False or 'always'")
+        self.chamfer_prune = chamfer_prune       # False: nn_distance(adv, x) always by the all-pairs kernel; "always": the paired
+                                                 # grid search at every batch size (same results either way)
         self.emd_reference_weights = bool(emd_reference_weights)   # True: the EMD term's plan from the CPU op's expf arguments (ops.approx_match)
         # alternative code paths with the same results (geoadv_attack_config; the parity tests run each against the default)
         self.recompute_backward = bool(recompute_backward)   # encoder backward re-runs the forward instead of reading ReLU masks
@@ -84,7 +87,7 @@ class AdvAE:
         self.B = c.batch_size
         cfg = _AttackConfig(self.B, 1 if c.loss_adv_type == "latent" else 0, 1 if c.loss_dist_type == "pert" else 0,
                             c.max_point_pert_weight, c.max_point_dist_weight, c.learning_rate, c.emd_weight,
-                            0 if getattr(c, "chamfer_prune", True) else 1, 1 if getattr(c, "emd_reference_weights", False) else 0,
+                            {True: 0, False: 1, "always": 2}[getattr(c, "chamfer_prune", True)], 1 if getattr(c, "emd_reference_weights", False) else 0,
                             1 if getattr(c, "recompute_backward", False) else 0, 1 if getattr(c, "separate_adam", False) else 0,
                             CHAMFER_KERNELS[getattr(c, "chamfer_kernel", "auto")])
         self._h = C.c_void_p()
@@ -126,6 +129,14 @@ class AdvAE:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_attack_init_pert(self._h, _lib.ptr(p), int(bool(reset_optimizer)),
                                                           _lib.stream_handle()), "attack_init_pert")
+
+    def search_state(self):
+        """(searched, handed_back): whether nn_distance(adv, x) goes through the paired grid search, and how many clouds of the
+        batch it currently hands back to the all-pairs kernel (synchronises)."""
+        a, b = C.c_int(0), C.c_int(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_attack_search_state(self._h, C.byref(a), C.byref(b), _lib.stream_handle()), "attack_search_state")
+        return bool(a.value), b.value
 
     def run(self, first_iteration, iterations, thresh, history=None):
         """Enqueue `iterations` attack iterations (no host sync).  history: optional GPU tensor

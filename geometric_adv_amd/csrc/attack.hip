@@ -578,7 +578,9 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     // longer half (in-kernel stamps: 16.1 against 11.5 us at B = 32).  The scans of (adv, source) in that same launch therefore
     // follow the verdicts of the PREVIOUS call (GridArgs::need_prev).  Small batches (two-scan kernel: 16-wave workgroups that
     // fill a CU's registers, so the search's workgroups would only start when the scans are done) keep it beside
-    // latent_decode; clouds of more than GR_MAX_N points keep the search in a launch of its own, ahead of the scans.
+    // latent_decode (a second stream for it, forked after the encoder and joined before the scans, was measured: + 25 us per
+    // iteration at B = 1 ... 16 -- each cross-stream event costs more than the whole search); clouds of more than GR_MAX_N
+    // points keep the search in a launch of its own, ahead of the scans.
     const bool rides_scan = pruned && chamfer_grid_rides(n) && at->chamfer_sym;
     const bool rides_latent = pruned && chamfer_grid_rides(n) && !at->chamfer_sym;
     const int call = at->grid_calls;
@@ -757,6 +759,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     GA_REQUIRE(cfg->emd_weight >= 0.f, "attack_create: emd_weight must be >= 0");
     GA_REQUIRE(cfg->emd_weight_mode == GEOADV_EMD_FAST || cfg->emd_weight_mode == GEOADV_EMD_REFERENCE,
                "attack_create: unknown emd_weight_mode %d", cfg->emd_weight_mode);
+    GA_REQUIRE(cfg->all_pairs_source_dist >= 0 && cfg->all_pairs_source_dist <= 2, "attack_create: all_pairs_source_dist must be 0, 1 or 2");
     GA_REQUIRE(cfg->chamfer_kernel >= GEOADV_CHAMFER_AUTO && cfg->chamfer_kernel <= GEOADV_CHAMFER_SYMMETRIC,
                "attack_create: unknown chamfer_kernel %d", cfg->chamfer_kernel);
     GA_REQUIRE(cfg->emd_weight == 0.f || cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER,
@@ -812,7 +815,11 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->need_adv[0] = I(4 * 8 * B); at->need_adv[1] = I(4 * 8 * B);
     at->grid_calls = 0;
     at->x_box = F(4 * 6 * B);
-    at->chamfer_prune = cfg->all_pairs_source_dist == 0;
+    // Tiny batches (<= 10 K points: B <= 4 at N = 2048): the search's own latency (~11-14 us per workgroup beside a 6 us
+    // latent_decode) costs what the two extra all-pairs scans cost on a mostly idle chip -- measured 0.0673 / 0.0725 ms at
+    // B = 1 and 0.0758 / 0.0767 at B = 4 without / with it, 0.0977 / 0.0929 at B = 8 -- so it is only used above that.
+    // (all_pairs_source_dist 2 = the search whatever the size: the parity tests' small shapes)
+    at->chamfer_prune = cfg->all_pairs_source_dist == 2 || (cfg->all_pairs_source_dist == 0 && (long)at->B * at->n > 10240);
     {
         // Small batches (<= 34 K points in all: B <= 17 at N = 2048 -- what a GPU holds when ONE batch of 32 is split over 2, 4
         // or 8): the public op's plain scans in ONE launch -- both directions of (recon, target), and of (adv, source) only
@@ -946,6 +953,26 @@ extern "C" int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, fl
     if (idx_r2) GA_HIP(hipMemcpyAsync(idx_r2, at->ir2, bn, hipMemcpyDeviceToDevice, st));
     if (idx_a1) GA_HIP(hipMemcpyAsync(idx_a1, at->ia1, bn, hipMemcpyDeviceToDevice, st));
     if (idx_a2) GA_HIP(hipMemcpyAsync(idx_a2, at->ia2, bn, hipMemcpyDeviceToDevice, st));
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_search_state(geoadv_attack *at, int *searched, int *handed_back, void *stream) {
+    GA_REQUIRE(at && searched && handed_back, "attack_search_state: null argument");
+    const bool pruned = at->chamfer_prune && chamfer_grid_supports(at->n, at->n);
+    *searched = pruned ? 1 : 0;
+    *handed_back = 0;
+    if (!pruned) return GEOADV_OK;
+    hipStream_t st = as_stream(stream);
+    const bool two = chamfer_grid_rides(at->n) && at->chamfer_sym;                 // (two flag arrays: the last call wrote this one)
+    const int *flags = at->need_adv[two ? at->grid_calls & 1 : 0];
+    std::vector<int> h(8 * (size_t)at->B);
+    GA_HIP(hipMemcpyAsync(h.data(), flags, sizeof(int) * h.size(), hipMemcpyDeviceToHost, st));
+    GA_HIP(hipStreamSynchronize(st));
+    for (int c = 0; c < at->B; ++c) {
+        int any = 0;
+        for (int k = 0; k < 8; ++k) any |= h[8 * (size_t)c + k];
+        *handed_back += any ? 1 : 0;
+    }
     return GEOADV_OK;
 }
 

@@ -301,6 +301,17 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const 
     }
 }
 
+// loss 'emd': loss = inv * sum_b cost[b] (fixed order, fp64), g[e] *= inv -- block 0 also writes the loss
+__global__ __launch_bounds__(256) void emd_loss_scale_kernel(const float *cost, int batch, double inv, float *loss, float *g, size_t count) {
+    const float s = (float)inv;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (size_t)gridDim.x * 256) g[e] *= s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int b = 0; b < batch; ++b) acc += (double)cost[b];
+        *loss = (float)(acc * inv);
+    }
+}
+
 // loss = (sum dist1 + sum dist2) / (B * N): tf.reduce_mean over all elements of each direction (pointnet_ae.py:77);
 // one workgroup of 256 threads, fixed summation order
 __device__ __forceinline__ void chamfer_loss_block(const float *d1, const float *d2, size_t count, double inv, float *loss) {
@@ -920,6 +931,8 @@ struct geoadv_trainer {
     float *dist1, *dist2; int *idx1, *idx2;
     float *dw_partial, *db_partial;
     float *loss;
+    int loss_type;                     // GEOADV_TRAIN_LOSS_*
+    float *emd_temp, *emd_cost;        // loss 'emd': scratch of geoadv_emd_cost_grad1, per-cloud match costs
     int world;                         // ranks sharing the batch statistics (synchronised BN); 1 = local
     double *xbuf, *lbuf;               // [10][512] per-phase totals: exchanged (all-reduced by the host) / local copy
 };
@@ -952,6 +965,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     GA_REQUIRE(hw->dec_dims[0] == 128 && hw->dec_dims[1] == 256 && hw->dec_dims[2] == 256 && hw->dec_dims[3] == 3 * n,
                "trainer_create: decoder widths must be 128,256,256,3*n_points (src/ae_templates.py:29)");
     GA_REQUIRE(cfg->learning_rate > 0.f && cfg->bn_decay >= 0.f && cfg->bn_decay <= 1.f, "trainer_create: bad learning rate / decay");
+    GA_REQUIRE(cfg->loss == GEOADV_TRAIN_LOSS_CHAMFER || cfg->loss == GEOADV_TRAIN_LOSS_EMD, "trainer_create: unknown loss %d", cfg->loss);
     geoadv_trainer *t = new geoadv_trainer();
     t->B = B; t->N = n; t->R = B * n; t->tiles = t->R / TR_ROWS; t->n3 = 3 * n;
     t->lr = cfg->learning_rate; t->one_minus_decay = 1.f - cfg->bn_decay;
@@ -984,6 +998,8 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     const size_t o_di1 = take(4 * (size_t)B * n), o_di2 = take(4 * (size_t)B * n), o_i1 = take(4 * (size_t)B * n), o_i2 = take(4 * (size_t)B * n);
     const size_t o_dwp = take(4 * (size_t)t->grid_bwd * 256 * 128), o_dbp = take(4 * (size_t)t->grid_bwd * 256);
     const size_t o_loss = take(256);
+    const bool emd = cfg->loss == GEOADV_TRAIN_LOSS_EMD;
+    const size_t o_et = take(emd ? 4 * geoadv_emd_cost_grad1_temp_floats(B, n, n) + 8 : 0), o_ec = take(emd ? 4 * (size_t)B : 0);
     const size_t o_xb = take(8 * 10 * 512), o_lb = take(8 * 10 * 512);
     t->arena_bytes = off;
     if (hipMalloc(reinterpret_cast<void **>(&t->arena), off) != hipSuccess) {
@@ -1006,6 +1022,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     t->dd2 = F(o_dd2); t->dd1 = F(o_dd1); t->dz = F(o_dz);
     t->dist1 = F(o_di1); t->dist2 = F(o_di2); t->idx1 = reinterpret_cast<int *>(F(o_i1)); t->idx2 = reinterpret_cast<int *>(F(o_i2));
     t->dw_partial = F(o_dwp); t->db_partial = F(o_dbp); t->loss = F(o_loss);
+    t->loss_type = cfg->loss; t->emd_temp = emd ? F(o_et) : nullptr; t->emd_cost = emd ? F(o_ec) : nullptr;
     t->world = 1;
     t->xbuf = reinterpret_cast<double *>(t->arena + o_xb); t->lbuf = reinterpret_cast<double *>(t->arena + o_lb);
     // upload parameters
@@ -1178,19 +1195,29 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         fc_fwd_kernel<256, true><<<B, 256, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2, 256);
         fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
         GA_LAUNCH_CHECK();
-        // ---- Chamfer loss and its gradient w.r.t. the reconstruction ----
-        // one distance evaluation per pair serves both directions (chamfer_sym.hip); dist/idx bit-identical to nn_distance
-        const ChamferPair cp{t->recon, gt, t->dist1, t->idx1, t->dist2, t->idx2};
-        if (int rc = launch_chamfer_sym(&cp, 1, B, n, n, t->cham_ws, st)) return rc;
-        // NnDistanceGrad w.r.t. the reconstruction only (order-independent fixed-point accumulation, attack.hip)
-        const CGradProblem gp{t->recon, gt, t->idx1, t->idx2, t->g_recon, t->gd, nullptr, 0.f};
-        if (int rc = launch_chamfer_grad(&gp, 1, B, n, st)) return rc;
-        // ---- decoder backward: three launches, each = weight gradient + data gradient of one layer side by side ----
         DecOutBwdArgs da;
-        da.d2 = t->d2; da.g = t->g_recon; da.V2 = V2; da.dV2 = t->grads + t->L.v[2]; da.dc2 = t->grads + t->L.c[2]; da.dd2 = t->dd2;
-        da.batch = B; da.n3 = n3; da.dist1 = t->dist1; da.dist2 = t->dist2; da.count = (size_t)B * n;
         da.inv = 1.0 / ((double)B * t->world * n);   // reduce_mean over the batch of ALL ranks (the host adds the ranks up)
-        da.loss = t->loss;
+        da.loss = t->loss; da.count = (size_t)B * n;
+        if (t->loss_type == GEOADV_TRAIN_LOSS_EMD) {
+            // ---- approx-EMD loss (pointnet_ae.py:77-79): reduce_mean over the clouds of match_cost(recon, gt, match), and
+            // d loss / d recon = match_cost_grad's grad1 / clouds with the match held constant (tf_approxmatch.py:19, 44-50).
+            // The plan is never stored (geoadv_emd_cost_grad1: levels + cost + gradient fused). ----
+            if (int rc = geoadv_emd_cost_grad1_mode(GEOADV_EMD_FAST, B, n, n, t->recon, gt, t->emd_cost, t->g_recon, t->emd_temp, st)) return rc;
+            emd_loss_scale_kernel<<<256, 256, 0, st>>>(t->emd_cost, B, 1.0 / ((double)B * t->world), t->loss, t->g_recon, (size_t)B * n3);
+            GA_LAUNCH_CHECK();
+            da.count = 0; da.loss = t->loss + 1;     // (the loss block of the launch below then writes a zero beside the real loss)
+        } else {
+            // ---- Chamfer loss and its gradient w.r.t. the reconstruction ----
+            // one distance evaluation per pair serves both directions (chamfer_sym.hip); dist/idx bit-identical to nn_distance
+            const ChamferPair cp{t->recon, gt, t->dist1, t->idx1, t->dist2, t->idx2};
+            if (int rc = launch_chamfer_sym(&cp, 1, B, n, n, t->cham_ws, st)) return rc;
+            // NnDistanceGrad w.r.t. the reconstruction only (order-independent fixed-point accumulation, attack.hip)
+            const CGradProblem gp{t->recon, gt, t->idx1, t->idx2, t->g_recon, t->gd, nullptr, 0.f};
+            if (int rc = launch_chamfer_grad(&gp, 1, B, n, st)) return rc;
+        }
+        // ---- decoder backward: three launches, each = weight gradient + data gradient of one layer side by side ----
+        da.d2 = t->d2; da.g = t->g_recon; da.V2 = V2; da.dV2 = t->grads + t->L.v[2]; da.dc2 = t->grads + t->L.c[2]; da.dd2 = t->dd2;
+        da.batch = B; da.n3 = n3; da.dist1 = t->dist1; da.dist2 = t->dist2;
         dec_out_bwd_kernel<<<cdiv(n3, 128) * 8 + 64 * cdiv(B, 8) + 1, 256, sizeof(float) * B * 32, st>>>(da);
         fc_bwd_kernel<true><<<256 + B, 256, 0, st>>>(t->d1, t->dd2, V1, t->grads + t->L.v[1], t->grads + t->L.c[1], t->dd1, B, 256);
         fc_bwd_kernel<false><<<128 + B, 256, 0, st>>>(z, t->dd1, V0, t->grads + t->L.v[0], t->grads + t->L.c[0], t->dz, B, 128);

@@ -23,7 +23,7 @@ from .autoencoder import _AEWeights
 
 
 class _TrainConfig(C.Structure):
-    _fields_ = [("batch", C.c_int), ("learning_rate", C.c_float), ("bn_decay", C.c_float)]
+    _fields_ = [("batch", C.c_int), ("learning_rate", C.c_float), ("bn_decay", C.c_float), ("loss", C.c_int)]
 
 
 def _fill_weights_struct(hw, canon, n_points):
@@ -76,7 +76,7 @@ class PointNetAETrainer:
     GROUPS = ("enc_w", "enc_b", "gamma", "beta", "dec_w", "dec_b")
 
     def __init__(self, weights, n_points, batch_size=50, learning_rate=0.0005, bn_decay=0.9, ae_name=W.AE_NAME,
-                 device=None, sync_bn=True):
+                 device=None, sync_bn=True, loss="chamfer"):
         if isinstance(weights, str):
             weights = W.load(weights, ae_name)
         self.n_points, self.batch_size, self.ae_name = int(n_points), int(batch_size), ae_name
@@ -84,7 +84,10 @@ class PointNetAETrainer:
         canon = W.canonical(weights, self.n_points, ae_name)
         hw = _AEWeights()
         _fill_weights_struct(hw, canon, self.n_points)
-        cfg = _TrainConfig(self.batch_size, float(learning_rate), float(bn_decay))
+        if loss not in ("chamfer", "emd"):                       # conf.loss (src/pointnet_ae.py:74-79)
+            raise ValueError("loss must be 'chamfer' or 'emd'")
+        self.loss = loss
+        cfg = _TrainConfig(self.batch_size, float(learning_rate), float(bn_decay), 1 if loss == "emd" else 0)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_trainer_create(C.byref(self._h), C.byref(hw), C.byref(cfg)), "trainer_create")

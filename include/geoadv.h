@@ -207,7 +207,9 @@ typedef struct geoadv_attack_config {
     float learning_rate;            /* conf.learning_rate (adv_ae.py:146,152)                 */
     float emd_weight;               /* build-defined: loss_adv += emd_weight*match_cost/N; 0 = off */
     int   all_pairs_source_dist;    /* 0 (default): nn_distance(adv, x) by the exact paired grid search, falling back per
-                                     * cloud to the all-pairs kernel; 1: always the all-pairs kernel.  Same results.     */
+                                     * cloud to the all-pairs kernel, except for tiny batches (<= 10 K points) where the
+                                     * all-pairs kernel alone is as fast; 1: always the all-pairs kernel; 2: the grid search
+                                     * at every size.  Same results.                                                      */
     int   emd_weight_mode;          /* GEOADV_EMD_FAST (0, default) or GEOADV_EMD_REFERENCE for the EMD term's plan       */
     /* Alternative code paths with the same results, selected explicitly (never by the environment); all 0 = defaults.
      * The parity tests run every one of them against the default path.                                                */
@@ -258,12 +260,18 @@ int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_loss_ref,
 int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, float *recon, float *latent,
                        float *grad, int *idx_r1, int *idx_r2, int *idx_a1, int *idx_a2, void *stream);
 
+/* How nn_distance(adv, x) is being answered: *searched = 1 if the paired grid search is in use for this handle (0: all-pairs
+ * kernel, by configuration or batch size), *handed_back = number of clouds of the batch whose pairing the search currently
+ * judges too poor (they go through the all-pairs kernel; verdicts of the last forward).  Synchronises the stream. */
+int geoadv_attack_search_state(geoadv_attack *at, int *searched, int *handed_back, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Victim auto-encoder TRAINING step: PointNetAutoEncoder._create_loss / _setup_optimizer
  * (src/pointnet_ae.py:71-99) driven by AutoEncoder.partial_fit (src/autoencoder.py:105-125) with the
  * architecture of src/ae_templates.py:22-33: encoder BN in TRAINING mode (tflearn batch_normalization:
  * batch statistics over all batch*n_points rows, differentiated through; moving averages updated with
- * `bn_decay`, zero_debias=False), loss = reduce_mean(dist1) + reduce_mean(dist2) of nn_distance(recon, gt),
+ * `bn_decay`, zero_debias=False), loss = reduce_mean(dist1) + reduce_mean(dist2) of nn_distance(recon, gt) or the approx-EMD
+ * match cost (geoadv_train_config.loss),
  * Adam (TF 1.13 ApplyAdam form, beta1 .9, beta2 .999, eps 1e-8) on every trainable variable.
  * One handle = one model replica with a fixed batch size; everything is device resident.
  * ---------------------------------------------------------------------------------------- */
@@ -272,7 +280,13 @@ typedef struct geoadv_train_config {
     int   batch;            /* conf.batch_size (default_train_params: 50)          */
     float learning_rate;    /* conf.learning_rate (0.0005)                         */
     float bn_decay;         /* encoder b_norm_decay (encoders_decoders.py:20: 0.9) */
+    int   loss;             /* conf.loss (pointnet_ae.py:74-79): GEOADV_TRAIN_LOSS_CHAMFER (0) = reduce_mean(dist1) +
+                             * reduce_mean(dist2) of nn_distance(recon, gt); GEOADV_TRAIN_LOSS_EMD (1) =
+                             * reduce_mean(match_cost(recon, gt, approx_match(recon, gt))), the match held constant in the
+                             * backward (approx_match is registered NoGradient, tf_approxmatch.py:19)                  */
 } geoadv_train_config;
+#define GEOADV_TRAIN_LOSS_CHAMFER 0
+#define GEOADV_TRAIN_LOSS_EMD     1
 
 /* init: HOST weights (the initial variable values; bn_mean / bn_var = the moving averages).  n_points % 64 == 0. */
 int  geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weights *init, const geoadv_train_config *cfg);

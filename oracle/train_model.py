@@ -1,7 +1,8 @@
 """numpy model of one TRAINING step of the victim auto-encoder -- TEST INFRASTRUCTURE.
 
 Restates `PointNetAutoEncoder` (src/pointnet_ae.py:71-99: loss = reduce_mean(dist1) + reduce_mean(dist2) of
-nn_distance(x_reconstr, gt); AdamOptimizer(lr).minimize(loss) over every trainable variable) and
+nn_distance(x_reconstr, gt), or with conf.loss == 'emd' reduce_mean(match_cost(x_reconstr, gt, approx_match(x_reconstr, gt)));
+AdamOptimizer(lr).minimize(loss) over every trainable variable) and
 `AutoEncoder.partial_fit` (src/autoencoder.py:105-125: one sess.run of (train_step, loss, x_reconstr) with
 tflearn's is_training(True)), with the architecture of src/ae_templates.py:22-33 and the defaults of
 default_train_params (:43-51: batch 50, lr 0.0005).
@@ -25,8 +26,9 @@ PARAM_GROUPS = ("enc_w", "enc_b", "gamma", "beta", "dec_w", "dec_b")      # trai
 
 
 class TrainModel:
-    def __init__(self, canon, n_points, lr=0.0005, decay=0.9, dtype=np.float64):
-        self.n, self.lr, self.decay, self.dt = n_points, lr, decay, dtype
+    def __init__(self, canon, n_points, lr=0.0005, decay=0.9, dtype=np.float64, loss="chamfer"):
+        assert loss in ("chamfer", "emd")                          # conf.loss, src/pointnet_ae.py:74-79
+        self.n, self.lr, self.decay, self.dt, self.loss = n_points, lr, decay, dtype, loss
         self.p = {k: [np.asarray(a, dtype=dtype).copy() for a in canon[k]] for k in canon}
         self.m = {k: [np.zeros_like(a) for a in self.p[k]] for k in PARAM_GROUPS}
         self.v = {k: [np.zeros_like(a) for a in self.p[k]] for k in PARAM_GROUPS}
@@ -72,18 +74,29 @@ class TrainModel:
         B, N, _ = gt.shape
         c = self.forward(x)
         recon = c["recon"]
-        if idx is None:
-            _, i1, _, i2 = _o().nn_distance(recon.astype(np.float32), gt)
-            idx = (i1.astype(np.int64), i2.astype(np.int64))
-        i1, i2 = idx
-        gt64 = gt.astype(dt)
-        loss = self.chamfer_loss_fixed(recon, gt64, i1, i2)
-        ar = np.arange(B)[:, None]
-        # NnDistanceGrad w.r.t. xyz1 = recon with grad_dist = 1/(B*N) (tf_nndistance.cpp:130-163)
-        g = 2.0 / (B * N) * (recon - gt64[ar, i1])
-        t2 = 2.0 / (B * N) * (gt64 - recon[ar, i2])              # scattered with a minus sign onto recon[idx2]
-        for b in range(B):
-            np.subtract.at(g[b], i2[b], t2[b])
+        if self.loss == "emd":
+            # src/pointnet_ae.py:77-79: match = approx_match(x_reconstr, gt); loss = reduce_mean(match_cost(x_reconstr, gt, match)).
+            # approx_match is NoGradient (external/structural_losses/tf_approxmatch.py:19) and MatchCost's registered gradient is
+            # match_cost_grad times the upstream gradient (:44-50): d loss / d recon = grad1 / B with the match held constant.
+            # All three are the PINNED C restatements of the reference's CPU ops (oracle/geoadv_oracle.c), fed the fp32 clouds.
+            r32 = recon.astype(np.float32)
+            match = _o().approx_match(r32, gt)
+            loss = float(_o().match_cost(r32, gt, match).astype(np.float64).mean())
+            g1, _ = _o().match_cost_grad(r32, gt, match)
+            g = g1.astype(dt) / B
+        else:
+            if idx is None:
+                _, i1, _, i2 = _o().nn_distance(recon.astype(np.float32), gt)
+                idx = (i1.astype(np.int64), i2.astype(np.int64))
+            i1, i2 = idx
+            gt64 = gt.astype(dt)
+            loss = self.chamfer_loss_fixed(recon, gt64, i1, i2)
+            ar = np.arange(B)[:, None]
+            # NnDistanceGrad w.r.t. xyz1 = recon with grad_dist = 1/(B*N) (tf_nndistance.cpp:130-163)
+            g = 2.0 / (B * N) * (recon - gt64[ar, i1])
+            t2 = 2.0 / (B * N) * (gt64 - recon[ar, i2])              # scattered with a minus sign onto recon[idx2]
+            for b in range(B):
+                np.subtract.at(g[b], i2[b], t2[b])
         G = {k: [None] * len(P[k]) for k in PARAM_GROUPS}
         g = g.reshape(B, 3 * N)
         G["dec_w"][2] = c["d2"].T @ g; G["dec_b"][2] = g.sum(0)

@@ -271,11 +271,12 @@ def test_odd_sizes_all_code_paths_agree():
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_paths_child.py")
     sizes = ["1", "2", "31", "64", "65", "255", "257", "1023", "2049", "4097"]
     got = {}
-    for name, cfg in [("default", {}), ("all-pairs source distance", {"chamfer_prune": False}),
-                      ("Adam in its own launch", {"separate_adam": True}),
-                      ("two-scan Chamfer", {"chamfer_kernel": "two_scan"}),
+    for name, cfg in [("default", {"chamfer_prune": "always"}), ("all-pairs source distance", {"chamfer_prune": False}),
+                      ("Adam in its own launch", {"separate_adam": True, "chamfer_prune": "always"}),
+                      ("two-scan Chamfer", {"chamfer_kernel": "two_scan", "chamfer_prune": "always"}),
                       ("two-scan Chamfer, all-pairs source distance", {"chamfer_kernel": "two_scan", "chamfer_prune": False}),
-                      ("symmetric Chamfer + grid search", {"chamfer_kernel": "symmetric"}),
+                      ("symmetric Chamfer + grid search", {"chamfer_kernel": "symmetric", "chamfer_prune": "always"}),
+                      ("auto (tiny batch: all-pairs)", {}),
                       ("symmetric Chamfer, all-pairs source distance", {"chamfer_kernel": "symmetric", "chamfer_prune": False})]:
         o = subprocess.run([sys.executable, child, json.dumps(cfg)] + sizes, capture_output=True, text=True, timeout=600)
         lines = [ln for ln in o.stdout.splitlines() if ln.startswith("HASHES ")]
@@ -367,7 +368,7 @@ def test_pruned_source_distance_equals_all_pairs(setup, lr, n, sym):
     b = 3
     x, gt = _clouds(81, b, n)
     outs = []
-    for prune in (True, False):
+    for prune in ("always", False):
         at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=12, num_iterations_thresh=3,
                                               learning_rate=lr, chamfer_kernel=sym, chamfer_prune=prune), ae=ae)
         at.set_inputs(x, gt, None, 1.0)

@@ -66,7 +66,7 @@ def test_paired_grid_search_on_shapes(kind, n, scale):
 
 @pytest.mark.parametrize("kind", ["sphere", "clusters", "duplicates", "lattice"])
 @pytest.mark.parametrize("b", [32, 4])
-@pytest.mark.parametrize("prune", [True, False])
+@pytest.mark.parametrize("prune", ["always", False])
 def test_attack_loop_indices_on_shapes(kind, b, prune):
     """The loop's four index arrays after a few iterations on non-uniform clouds equal ops.nn_distance on the loop's own clouds:
     B = 32 runs the symmetric scan + finish, B = 4 the gated two-scan kernel; prune on / off = grid search / all-pairs."""

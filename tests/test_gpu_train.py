@@ -25,13 +25,13 @@ def _clouds(seed, b, n):
     return (rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
 
 
-def _setup(n, b, seed=11, lr=0.0005):
+def _setup(n, b, seed=11, lr=0.0005, loss="chamfer"):
     from geometric_adv_amd import weights as W
     from geometric_adv_amd.trainer import PointNetAETrainer
     from oracle.train_model import TrainModel
     w = W.randomized_weights(n, seed=seed)
-    tr = PointNetAETrainer(w, n, batch_size=b, learning_rate=lr)
-    tm = TrainModel(W.canonical(w, n), n, lr=lr)
+    tr = PointNetAETrainer(w, n, batch_size=b, learning_rate=lr, loss=loss)
+    tm = TrainModel(W.canonical(w, n), n, lr=lr, loss=loss)
     return w, tr, tm
 
 
@@ -86,6 +86,32 @@ def test_loss_recon_and_gradients_match_the_oracle(n, b):
                 continue
             assert g_gpu[k][j].shape == G[k][j].shape
             assert _rel(g_gpu[k][j], G[k][j]) <= 5e-5, (k, j, _rel(g_gpu[k][j], G[k][j]))
+
+
+@pytest.mark.parametrize("n,b", [(128, 4), (256, 3), (512, 2)])
+def test_emd_loss_step_matches_the_oracle(n, b):
+    """conf.loss == 'emd' (src/pointnet_ae.py:77-79): loss = reduce_mean(match_cost(recon, gt, approx_match(recon, gt))) and every
+    variable's gradient against the fp64 model, whose EMD pieces are the pinned C restatements of the reference's CPU ops
+    (approxmatch_cpu / matchcost_cpu / matchcostgrad_cpu).  The kernel's plan uses fp32 pair weights: loss 2e-5
+    relative, gradients 2e-4 of each variable's norm."""
+    from oracle.train_model import PARAM_GROUPS
+    w, tr, tm = _setup(n, b, loss="emd")
+    x = _batch(tm, b, n, 3)
+    gt = _clouds(77, b, n)                                   # a denoising-style target: recon is matched against other clouds
+    recon, loss = tr.forward_backward(x, gt)
+    g_gpu = tr.gradients()
+    loss_ref, G, c = tm.loss_and_grads(x, gt)
+    assert abs(float(loss.item()) - loss_ref) <= 2e-5 * abs(loss_ref)
+    for k in PARAM_GROUPS:
+        for j in range(len(G[k])):
+            if k == "enc_b":
+                continue
+            assert _rel(g_gpu[k][j], G[k][j]) <= 2e-4, (k, j, _rel(g_gpu[k][j], G[k][j]))
+    # and a step moves the weights: the loss of the next forward on the same batch is lower
+    first = float(tr.partial_fit(x, gt)[1])
+    for _ in range(5):
+        last = float(tr.partial_fit(x, gt)[1])
+    assert last < first
 
 
 def test_one_adam_step_and_moving_averages():

@@ -1,19 +1,34 @@
 #!/bin/bash
-# PMC passes of the bench command and of the EMD timing tool (run on the GPU box through gpurun; counters in separate
-# passes, --kernel-trace only beside --pmc: MI355X_MICROARCH.md / rocprofv3 PMC slots).  Usage: tools/collect_pmc.sh OUTDIR
+# The round's counter evidence (run on the GPU box through gpurun; counters in separate passes, --kernel-trace only beside
+# --pmc: MI355X_MICROARCH.md / rocprofv3 PMC slots).  Usage: tools/collect_pmc.sh OUTDIR [ROUND]
+#   <ROUND>_pmc_encoder.json      bench command: SQ issue counters, MFMA busy + GRBM, FETCH_SIZE, WRITE_SIZE (hashes encoder.hip, mfma_tile.h)
+#   <ROUND>_pmc_chamfer_hbm.json  tools/attack_breakdown.py 32 (the pruned loop, ONE leg): FETCH_SIZE, WRITE_SIZE, SQ issue counters
+#                                 of chamfer_sym_kernel / chamfer_sym_finish_kernel (hashes chamfer_sym.hip, chamfer_grid.h)
+#   <ROUND>_pmc_emd.json          tools/emd_attack_time.py 32: SQ issue counters
+#   <ROUND>_bench_kernel_stats.csv, <ROUND>_loop_b32_kernel_stats.csv   --kernel-trace --stats of the two commands
 set -u
 OUT=${1:-gpurun_out/pmc}
+R=${2:-r03}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 BENCH="python3 bench.py --steps 40 --warmup 5 --windows 1 --no-cpu-baseline"
+LOOP="python3 tools/attack_breakdown.py 32"
 i=0
 for set in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/bench_$i" -- $BENCH > "$OUT/bench_$i.log" 2>&1
 done
-python3 tools/pmc_summary.py "$OUT"/bench_* > "$OUT/r02_pmc_encoder.json"
+python3 tools/pmc_summary.py "$OUT"/bench_* > "$OUT/${R}_pmc_encoder.json"
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/loop_$i" -- $LOOP > "$OUT/loop_$i.log" 2>&1
+done
+python3 tools/pmc_summary.py --hash chamfer_sym.hip,chamfer_grid.h "$OUT"/loop_* > "$OUT/${R}_pmc_chamfer_hbm.json"
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/emd_1" -- python3 tools/emd_attack_time.py 32 > "$OUT/emd_1.log" 2>&1
-python3 tools/pmc_summary.py "$OUT"/emd_1 > "$OUT/r02_pmc_emd.json"
+python3 tools/pmc_summary.py --hash emd.hip "$OUT"/emd_1 > "$OUT/${R}_pmc_emd.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- $BENCH > "$OUT/bench_stats.log" 2>&1
-cp "$OUT"/bench_stats/*/*_kernel_stats.csv "$OUT/r02_bench_kernel_stats.csv" 2>/dev/null
+cp "$OUT"/bench_stats/*/*_kernel_stats.csv "$OUT/${R}_bench_kernel_stats.csv" 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/loop_stats" -- $LOOP > "$OUT/loop_stats.log" 2>&1
+cp "$OUT"/loop_stats/*/*_kernel_stats.csv "$OUT/${R}_loop_b32_kernel_stats.csv" 2>/dev/null
 tail -2 "$OUT/bench_stats.log"

@@ -8,9 +8,14 @@ from collections import defaultdict
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geometric_adv_amd", "csrc")
 HASHED = ("encoder.hip", "mfma_tile.h")      # bench.py drops counters taken at other sources of the dominant kernel
+                                             # (--hash a,b,c selects other files: the Chamfer summary hashes its own)
 
 
 def main(dirs):
+    global HASHED
+    if dirs and dirs[0] == "--hash":
+        HASHED = tuple(dirs[1].split(","))
+        dirs = dirs[2:]
     acc = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(list)
     for d in dirs:
