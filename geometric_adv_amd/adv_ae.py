@@ -25,7 +25,7 @@ class Configuration:
                  max_point_dist_weight=0.0, num_iterations=500, num_iterations_thresh=400,
                  learning_rate=0.01, ae_name="autoencoder", emd_weight=0.0, verbose=False, batch_slots=1,
                  chamfer_prune=True, emd_reference_weights=False, recompute_backward=False, separate_adam=False,
-                 chamfer_kernel="auto"):
+                 chamfer_kernel="auto", encoder_backward="auto"):
         self.batch_size = int(batch_size)
         self.n_input = [int(n_points), 3]
         self.n_output = [int(n_points), 3]
@@ -54,17 +54,21 @@ class Configuration:
         if chamfer_kernel not in CHAMFER_KERNELS:
             raise ValueError("chamfer_kernel must be one of %s" % sorted(CHAMFER_KERNELS))
         self.chamfer_kernel = chamfer_kernel                 # "auto" (by batch size), "two_scan" or "symmetric"
+        if encoder_backward not in ENCODER_BACKWARDS:
+            raise ValueError("encoder_backward must be one of %s" % sorted(ENCODER_BACKWARDS))
+        self.encoder_backward = encoder_backward             # "auto", "masked" (back-propagate dz) or "jacobian" (pool Jacobian)
 
 
 CHAMFER_KERNELS = {"auto": 0, "two_scan": 1, "symmetric": 2}
+ENCODER_BACKWARDS = {"auto": 0, "masked": 1, "jacobian": 2}
 
 
 class _AttackConfig(C.Structure):
     _fields_ = [("batch", C.c_int), ("loss_adv_type", C.c_int), ("loss_dist_type", C.c_int),
                 ("max_point_pert_weight", C.c_float), ("max_point_dist_weight", C.c_float),
                 ("learning_rate", C.c_float), ("emd_weight", C.c_float), ("all_pairs_source_dist", C.c_int),
-                ("emd_weight_mode", C.c_int), ("recompute_backward", C.c_int), ("separate_adam", C.c_int),
-                ("chamfer_kernel", C.c_int)]
+                ("emd_weight_mode", C.c_int), ("recompute_backward", C.c_int), ("encoder_backward", C.c_int),
+                ("separate_adam", C.c_int), ("chamfer_kernel", C.c_int)]
 
 
 PROF_NAMES = ["encoder_fwd", "decoder_fwd", "chamfer_fwd", "loss_grad", "decoder_bwd", "encoder_bwd", "adam"]
@@ -88,7 +92,8 @@ class AdvAE:
         cfg = _AttackConfig(self.B, 1 if c.loss_adv_type == "latent" else 0, 1 if c.loss_dist_type == "pert" else 0,
                             c.max_point_pert_weight, c.max_point_dist_weight, c.learning_rate, c.emd_weight,
                             {True: 0, False: 1, "always": 2}[getattr(c, "chamfer_prune", True)], 1 if getattr(c, "emd_reference_weights", False) else 0,
-                            1 if getattr(c, "recompute_backward", False) else 0, 1 if getattr(c, "separate_adam", False) else 0,
+                            1 if getattr(c, "recompute_backward", False) else 0, ENCODER_BACKWARDS[getattr(c, "encoder_backward", "auto")],
+                            1 if getattr(c, "separate_adam", False) else 0,
                             CHAMFER_KERNELS[getattr(c, "chamfer_kernel", "auto")])
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):

@@ -10,6 +10,7 @@
 #include "ae.h"
 #include "chamfer_grad.h"
 #include "chamfer_grid.h"
+#include "encoder_jac.h"
 #include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
@@ -29,7 +30,10 @@ int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, fl
 int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
                               hipStream_t stream);
 int launch_chamfer_sym_rider(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
-                             const GridArgs *rider, hipStream_t stream);
+                             const GridArgs *rider, const JacRider *jac, hipStream_t stream);
+int launch_encoder_jac(const DeviceAE &A, int b, const JacArgs &a, hipStream_t stream);
+int launch_encoder_bwd_dense(const DeviceAE &A, int b, const float *adv, const float *z, const int *zcnt, const float *dz,
+                             const int *dense_flag, float *g_enc, hipStream_t stream);
 bool chamfer_grid_rides(int n);
 int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call, const float *box,
                         hipStream_t stream);
@@ -50,7 +54,8 @@ int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int 
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
 int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
 int launch_decoder_bwd(const DeviceAE &A, int b, const float *g_recon, const float *d1, const float *d2, float *partial,
-                       float *dz, hipStream_t stream);
+                       float *dz, hipStream_t stream, const int *crit = nullptr, const float *jac = nullptr, const int *dense = nullptr,
+                       float *g_enc = nullptr);
 int decoder_bwd_chunks(const DeviceAE &A);
 int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *crit_rows, const float *z,
                        const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, const unsigned *masks,
@@ -296,6 +301,7 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
     const int j_lo = h * range, j_hi = min(n, j_lo + range);
     for (int e = threadIdx.x; e < 3 * (j_hi - j_lo); e += CGA_THREADS) acc[e] = 0ull;
     __syncthreads();
+    GA_STAMP(1, 1);
     // Four points per thread and pass, index loads first, then all the dependent gathers: the launch is latency-bound
     // (one workgroup per cloud, problem and part), and a loop of "load index, gather, add" pays two global round trips per point.
     constexpr int U = 4;
@@ -323,6 +329,7 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
         }
     }
     __syncthreads();
+    GA_STAMP(1, 2);
     for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += U * CGA_THREADS) {
         int mj[U];
 #pragma unroll
@@ -362,7 +369,9 @@ __global__ __launch_bounds__(CGA_THREADS) void loss_cgrad_kernel(LossArgs la, CG
     if (blockIdx.y == 0) {
         if (threadIdx.x < 256) loss_metrics_body(la, blockIdx.x, gridDim.x);
     } else {
+        GA_STAMP(1, 0);
         cgrad_fx_body(ca, (blockIdx.y - 1) / H, blockIdx.x, (blockIdx.y - 1) % H, H);
+        GA_STAMP(1, 7);
     }
     GA_STAMP(0, 7);
 }
@@ -465,6 +474,9 @@ struct geoadv_attack {
     float *x_box;                    // [B][6] bounding boxes of the source clouds (the grid of the paired search)
     int grid_calls;                  // running number of grid-search launches (paces the retries of clouds that gave up)
     unsigned *masks;                 // [B][n][mask words] ReLU masks of the cached forward, or null (backward recomputes)
+    float *jac;                      // [B][128][3] pool Jacobian of the cached forward (encoder_jac.h), or null: the output-space
+                                     // attack's encoder backward is then 128 x 3 multiply-adds in the decoder backward's tail
+    bool jac_valid;                  // ... computed for the cached forward
     bool chamfer_sym;
     // host state
     float beta1_pow, beta2_pow;
@@ -600,14 +612,29 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
                                                  at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
         if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
     }
+    // The pool Jacobian of THIS forward (the next step's encoder backward, encoder_jac.h) beside the symmetric scan.  Where the
+    // two-scan kernel runs instead (small batches) there is no launch long enough to hide it in, and as a launch of its own
+    // (8.2 us + the 3.6 us look for tied clouds + two boundaries) it costs what the masked backward costs (11.6 us + one): those
+    // batches keep the masked backward.
+    const JacArgs jargs{n, at->masks, at->fs.crit, at->fs.z, at->fs.dense, at->jac};
+    const bool jac_rides = at->jac && at->chamfer_sym;
+    at->jac_valid = jac_rides;
+    if (at->jac && !jac_rides && at->cfg.encoder_backward == GEOADV_ENC_BWD_JACOBIAN) {   // forced: a launch of its own
+        ProfScope ps(at, GEOADV_PROF_ENCODER_BWD, st);
+        if (int rc = launch_encoder_jac(A, B, jargs, st)) return rc;
+        at->jac_valid = true;
+    }
     {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
         if (at->chamfer_sym) {   // one distance evaluation per pair serves both directions
             const ChamferPair pairs[2] = {{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2},
                                           {at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2}};
-            if (rides_scan) {
-                const GridArgs rider{at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, n, need_new, need_scan, call, at->x_box};
-                if (int rc = launch_chamfer_sym_rider(pairs, 2, B, n, n, at->sym_ws, need_scan, &rider, st)) return rc;
+            const GridArgs rider{at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, n, need_new, need_scan, call, at->x_box};
+            if (rides_scan || jac_rides) {
+                JacRider jr;
+                jr.j = jargs; jr.A = A; jr.first_block = 0; jr.blocks = 0;
+                if (int rc = launch_chamfer_sym_rider(pairs, 2, B, n, n, at->sym_ws, pruned ? need_scan : nullptr, rides_scan ? &rider : nullptr,
+                                                      jac_rides ? &jr : nullptr, st)) return rc;
             } else if (pruned) {
                 if (int rc = launch_chamfer_sym_needed(pairs, 2, B, n, n, at->sym_ws, need_scan, st)) return rc;
             } else if (int rc = launch_chamfer_sym(pairs, 2, B, n, n, at->sym_ws, st)) return rc;
@@ -698,11 +725,15 @@ int do_step(geoadv_attack *at, hipStream_t st) {
     }
     if (adv_chamfer) {
         ProfScope ps(at, GEOADV_PROF_DECODER_BWD, st);
-        if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st)) return rc;
+        const bool jm = at->jac_valid;
+        if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st, jm ? at->fs.crit : nullptr,
+                                        jm ? at->jac : nullptr, jm ? at->fs.dense : nullptr, jm ? at->g_enc : nullptr)) return rc;
     }
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_BWD, st);
-        if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, at->masks, st))
+        if (adv_chamfer && at->jac_valid) {   // the tail above applied the Jacobian; only clouds with a tied pool maximum are left
+            if (int rc = launch_encoder_bwd_dense(A, B, at->adv, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, st)) return rc;
+        } else if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, at->masks, st))
             return rc;
     }
     {
@@ -760,6 +791,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     GA_REQUIRE(cfg->emd_weight_mode == GEOADV_EMD_FAST || cfg->emd_weight_mode == GEOADV_EMD_REFERENCE,
                "attack_create: unknown emd_weight_mode %d", cfg->emd_weight_mode);
     GA_REQUIRE(cfg->all_pairs_source_dist >= 0 && cfg->all_pairs_source_dist <= 2, "attack_create: all_pairs_source_dist must be 0, 1 or 2");
+    GA_REQUIRE(cfg->encoder_backward >= GEOADV_ENC_BWD_AUTO && cfg->encoder_backward <= GEOADV_ENC_BWD_JACOBIAN,
+               "attack_create: unknown encoder_backward %d", cfg->encoder_backward);
     GA_REQUIRE(cfg->chamfer_kernel >= GEOADV_CHAMFER_AUTO && cfg->chamfer_kernel <= GEOADV_CHAMFER_SYMMETRIC,
                "attack_create: unknown chamfer_kernel %d", cfg->chamfer_kernel);
     GA_REQUIRE(cfg->emd_weight == 0.f || cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER,
@@ -784,6 +817,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * sym_floats);
     const size_t mask_words = cfg->recompute_backward ? 0 : (size_t)encoder_mask_words() * bn;   // ReLU masks of the cached forward
     need(4 * mask_words);
+    const bool use_jac = mask_words != 0 && cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER && cfg->encoder_backward != GEOADV_ENC_BWD_MASKED;
+    need(use_jac ? 4 * B * 128 * 3 : 0);
     need(4 * 8 * B); need(4 * 8 * B);                     // need_adv[2]
     need(4 * 6 * B);                                      // x_box
     const bool emd = cfg->emd_weight > 0.f;
@@ -812,6 +847,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
     at->sym_ws = F(4 * sym_floats);
     at->masks = mask_words ? reinterpret_cast<unsigned *>(take(4 * mask_words)) : nullptr;
+    at->jac = use_jac ? F(4 * B * 128 * 3) : nullptr;
+    at->jac_valid = false;
     at->need_adv[0] = I(4 * 8 * B); at->need_adv[1] = I(4 * 8 * B);
     at->grid_calls = 0;
     at->x_box = F(4 * 6 * B);
@@ -821,13 +858,12 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     // (all_pairs_source_dist 2 = the search whatever the size: the parity tests' small shapes)
     at->chamfer_prune = cfg->all_pairs_source_dist == 2 || (cfg->all_pairs_source_dist == 0 && (long)at->B * at->n > 10240);
     {
-        // Small batches (<= 34 K points in all: B <= 17 at N = 2048 -- what a GPU holds when ONE batch of 32 is split over 2, 4
-        // or 8): the public op's plain scans in ONE launch -- both directions of (recon, target), and of (adv, source) only
-        // for the clouds the grid search riding in the latent launch handed back -- beat the symmetric scan + its finish
-        // launch: launches are fixed latency there, not arithmetic (measured ms per iteration, plain / symmetric: B = 8:
-        // 0.096 / 0.105, 12: 0.127 / 0.130, 16: 0.129 / 0.141, 18: 0.168 / 0.163, 20: 0.167 / 0.164, 24: 0.170 / 0.164).  Same bits either way.
-        // cfg->chamfer_kernel forces one form (the A/B of tests/test_gpu_attack.py).
-        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n > 34816
+        // The symmetric scan + its finish launch against the public op's plain scans in ONE launch (both directions of (recon,
+        // target), and of (adv, source) only for clouds the grid search handed back).  Since the grid search and the encoder's
+        // pool Jacobian ride in the symmetric scan's launch (round 3) it wins from B = 8 on (ms per iteration, plain /
+        // symmetric: B = 4: 0.0748 / 0.0757, 8: 0.0935 / 0.0925, 12: 0.1143 / 0.1055, 16: 0.1263 / 0.1252, 24: 0.1673 / 0.1529,
+        // 32: 0.1913 / 0.1773); below, launches are fixed latency and the plain form has one fewer.  Same bits either way.
+        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n >= 12288
                                                                      : cfg->chamfer_kernel == GEOADV_CHAMFER_SYMMETRIC;
     }
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;

@@ -19,6 +19,7 @@
 // with d == minimum (exactly the reference's tie rule): 1/32 of a scan at n = 2048.
 #include "common.h"
 #include "chamfer_grid.h"
+#include "encoder_jac.h"
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -43,6 +44,7 @@ struct ChamferSymArgs {
     const int *need[2];        // per pair: null = every cloud; else int[8 * clouds], cloud c is computed only if one of
                                // its 8 flags is set (a workgroup of the paired grid search, chamfer_grid.hip, gave up)
     GridRider rider;           // the attack loop: the paired grid search of (adv, source) as extra workgroups of the scan launch
+    JacRider jac;              // ... and the encoder's pool Jacobian (encoder_jac.h): needed by the NEXT step's backward only
 };
 
 __device__ __forceinline__ bool sym_needed(const int *need, int c) {
@@ -70,9 +72,11 @@ constexpr size_t CS_LDS_BYTES = sizeof(float) * (3 * CS_STAGE + CS_WAVES * CS_RO
 
 __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymArgs a) {
     constexpr int R = CS_R;
+    extern __shared__ __attribute__((aligned(16))) float stage[];
     if (grid_rider_block<GR_MAX_N>(a.rider)) return;
+    if (jac_rider_block(a.jac, stage)) return;
     GA_STAMP(0, 0);
-    const int lin = blockIdx.x - a.rider.blocks;           // (the rider's workgroups come first); XCD-aware mapping, see chamfer_scan_kernel
+    const int lin = blockIdx.x - a.rider.blocks;           // (the search's workgroups come first); XCD-aware mapping, see chamfer_scan_kernel
     const int xcd = lin & 7, slot = lin >> 3;
     const int per = a.tiles * a.csplit;                    // workgroups per (pair, cloud) group
     const int group = (slot / per) * 8 + xcd, sub = slot % per;
@@ -92,9 +96,8 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     const float *Q = pr.q + (size_t)cq * m * 3;
     float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * a.tiles + tile) * m * 4;      // [m][4 quarters]
 
-    // all of it in the DYNAMIC region (CS_LDS_BYTES, or the rider's need if larger): a launch that hosts the grid search's
+    // all of it in the DYNAMIC region (CS_LDS_BYTES, or a rider's need if larger): a launch that hosts the grid search's
     // workgroups is charged max(scan, search) of LDS per workgroup, not the sum
-    extern __shared__ __attribute__((aligned(16))) float stage[];
     float (*tbuf)[CS_ROUND * CS_TSTRIDE] = reinterpret_cast<float (*)[CS_ROUND * CS_TSTRIDE]>(stage + 3 * CS_STAGE);
     float *sx = stage, *sy = stage + CS_STAGE, *sz = stage + 2 * CS_STAGE;
     static_assert(2 * CS_WAVES * CS_ROWS <= 3 * CS_STAGE, "merge arrays must fit in the stage buffer");
@@ -386,7 +389,8 @@ size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
 
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
-                          int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider = nullptr);
+                          int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider = nullptr,
+                          const JacRider *jac = nullptr);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream) {
     return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, nullptr, stream);
 }
@@ -396,13 +400,14 @@ int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, in
     return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream);
 }
 // ... and with the paired grid search (rider->n <= GR_MAX_N) as 8 * b extra workgroups of the scan launch
+// jac (or null): the pool Jacobian's 8 * b workgroups as well (jac->first_block / blocks are set here)
 int launch_chamfer_sym_rider(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
-                             const GridArgs *rider, hipStream_t stream) {
-    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider);
+                             const GridArgs *rider, const JacRider *jac, hipStream_t stream) {
+    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider, jac);
 }
 
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
-                          int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider) {
+                          int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider, const JacRider *jac) {
     if (b <= 0 || np <= 0) return GEOADV_OK;
     ChamferSymArgs a;
     a.need[0] = nullptr; a.need[1] = need1;
@@ -431,6 +436,17 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
         a.rider.blocks = b * 2 * GR_QSPLIT;
         grid += (unsigned)a.rider.blocks;
         scan_lds = std::max(scan_lds, chamfer_grid_lds_bytes(rider->n));
+    }
+    a.jac.blocks = 0; a.jac.first_block = 0;
+    if (jac) {
+        // LAST in the grid: every workgroup of the launch is charged the scan's 59 KB of LDS, so a CU holds two -- the search
+        // and the scan from the start; the Jacobian's workgroups take the search's places as those finish (~13 us into a 30 us
+        // scan).  Ahead of the scan they delayed it by their whole run time (51 instead of 33 us).
+        a.jac = *jac;
+        a.jac.first_block = (int)grid;
+        a.jac.blocks = b * (128 / JAC_ROWS);
+        grid += (unsigned)a.jac.blocks;
+        scan_lds = std::max(scan_lds, JAC_LDS_BYTES);
     }
     chamfer_sym_kernel<<<grid, CS_THREADS, scan_lds, stream>>>(a);
     GA_LAUNCH_CHECK();

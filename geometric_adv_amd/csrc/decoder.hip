@@ -274,13 +274,29 @@ __global__ __launch_bounds__(512) void decoder_fc2_bwd_kernel(DeviceAE A, int ba
 // grid = clouds, 1024 threads.  TF ReluGrad masks by the layer OUTPUT being > 0.
 // (Requesting V1^T / V0^T ahead of the partial sums was measured and lost, 7.8 vs 7.2 us: a workgroup streams ~480 KB through
 // ONE CU, so the early weights only delay the partials the chain starts with.)
+// ja.jac != null: the encoder's part of the backward happens here too -- g_enc[b][p] = sum over the channels c with
+// crit[b][c] == p of dz[b][c] * J[b][c] (encoder_jac.h), channels in ascending order; every channel of a point writes the
+// same total.  Clouds with a tied pool maximum are left to the dense recomputing kernel.
+struct JacApply { const int *crit; const float *jac; const int *dense; float *g_enc; int n; };
+
 __global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A, int batch, int chunks, const float *partial,
-                                                                     const float *d1, const float *d2, float *dz) {
+                                                                     const float *d1, const float *d2, float *dz, JacApply ja) {
     __shared__ float g2[256];
     __shared__ float g1[256];
     __shared__ float part[8][256];
+    __shared__ __attribute__((aligned(16))) float dzs[128], jxs[128], jys[128], jzs[128];
+    __shared__ __attribute__((aligned(16))) int crs[128];
     const int b = blockIdx.x, t = threadIdx.x, o = t & 255, ks = t >> 8;
     GA_STAMP(4, 0);
+    // the Jacobian rows and critical points of this cloud do not depend on anything computed here: requested first
+    float jx = 0.f, jy = 0.f, jz = 0.f;
+    int my_crit = -1, is_dense = 0;
+    if (ja.jac && t < 128) {
+        const float *jp = ja.jac + ((size_t)b * 128 + t) * 3;
+        jx = jp[0]; jy = jp[1]; jz = jp[2];
+        my_crit = ja.crit[(size_t)b * 128 + t];
+        is_dense = ja.dense[b];
+    }
     {   // split-K partials: 4 contiguous chunk groups, ascending inside, merged in order
         const int cb = chunks * ks / 4, ce = chunks * (ks + 1) / 4;
         float s = 0.f;
@@ -312,11 +328,59 @@ __global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A
         for (int k = 0; k < 32; ++k) s = fmaf(g1[k8 * 32 + k], w[k], s);
         part[k8][c] = s;
         __syncthreads();
+        float r = 0.f;
         if (t < 128) {
-            float r = part[0][t];
+            r = part[0][t];
 #pragma unroll
             for (int q = 1; q < 8; ++q) r += part[q][t];
             dz[(size_t)b * 128 + t] = r;
+        }
+        GA_STAMP(4, 3);
+        if (ja.jac) {
+            if (t < 128) { dzs[t] = r; crs[t] = my_crit; jxs[t] = jx; jys[t] = jy; jzs[t] = jz; }
+            __syncthreads();
+            // g(point of channel ch) = sum over the channels c of that point of dz[c] * J[c]: thread (ch, part) adds the 16 channels
+            // [16 part, 16 part + 16) in ascending order (all LDS reads of a thread requested at once: vector reads, broadcast),
+            // the 8 parts are then added in ascending order -- a fixed order, so every channel of a point writes the same bits
+            {
+                const int ch = t & 127, pq = t >> 7, mine = crs[ch];
+                float gx = 0.f, gy = 0.f, gz = 0.f;
+                const int4 *c4 = reinterpret_cast<const int4 *>(crs) + 4 * pq;
+                const float4 *d4 = reinterpret_cast<const float4 *>(dzs) + 4 * pq, *x4 = reinterpret_cast<const float4 *>(jxs) + 4 * pq;
+                const float4 *y4 = reinterpret_cast<const float4 *>(jys) + 4 * pq, *z4 = reinterpret_cast<const float4 *>(jzs) + 4 * pq;
+                int4 cc[4]; float4 dd[4], xx[4], yy[4], zz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { cc[q] = c4[q]; dd[q] = d4[q]; xx[q] = x4[q]; yy[q] = y4[q]; zz[q] = z4[q]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ci[4] = {cc[q].x, cc[q].y, cc[q].z, cc[q].w};
+                    const float di[4] = {dd[q].x, dd[q].y, dd[q].z, dd[q].w}, xi[4] = {xx[q].x, xx[q].y, xx[q].z, xx[q].w};
+                    const float yi[4] = {yy[q].x, yy[q].y, yy[q].z, yy[q].w}, zi[4] = {zz[q].x, zz[q].y, zz[q].z, zz[q].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float d = ci[u] == mine ? di[u] : 0.f;
+                        gx = fmaf(d, xi[u], gx); gy = fmaf(d, yi[u], gy); gz = fmaf(d, zi[u], gz);
+                    }
+                }
+                __syncthreads();                                   // (part[][] is free: the dz partials were consumed above)
+                part[pq][ch] = gx; part[pq][128 + ch] = gy;
+                __syncthreads();
+                float sx = 0.f, sy = 0.f;
+                if (t < 128) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { sx += part[q][t]; sy += part[q][128 + t]; }
+                }
+                __syncthreads();
+                part[pq][ch] = gz;
+                __syncthreads();
+                if (t < 128 && !is_dense) {
+                    float sz = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sz += part[q][t];
+                    float *g = ja.g_enc + ((size_t)b * ja.n + my_crit) * 3;
+                    g[0] = sx; g[1] = sy; g[2] = sz;
+                }
+            }
         }
     }
     GA_STAMP(4, 7);
@@ -365,12 +429,12 @@ int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, 
 int decoder_bwd_chunks(const DeviceAE &A) { return cdiv(A.dec2_bwd.K, DB_KC); }
 
 int launch_decoder_bwd(const DeviceAE &A, int b, const float *g_recon, const float *d1, const float *d2, float *partial,
-                       float *dz, hipStream_t stream) {
+                       float *dz, hipStream_t stream, const int *crit, const float *jac, const int *dense, float *g_enc) {
     if (b <= 0) return GEOADV_OK;
     const int chunks = decoder_bwd_chunks(A);
     decoder_fc2_bwd_kernel<<<dim3(chunks, cdiv(b, 32)), 512, 0, stream>>>(A, b, g_recon, partial);
     GA_LAUNCH_CHECK();
-    decoder_bwd_tail_kernel<<<b, LD_THREADS, 0, stream>>>(A, b, chunks, partial, d1, d2, dz);
+    decoder_bwd_tail_kernel<<<b, LD_THREADS, 0, stream>>>(A, b, chunks, partial, d1, d2, dz, JacApply{crit, jac, dense, g_enc, A.n_points});
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

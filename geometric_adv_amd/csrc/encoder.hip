@@ -22,6 +22,7 @@
 // (half0 + half1), layers 3 and 4 run one chain in ascending k.
 #include "ae.h"
 #include "mfma_tile.h"
+#include "encoder_jac.h"
 #include <hip/hip_ext.h>
 #include <limits.h>
 #include <stdlib.h>
@@ -87,8 +88,7 @@ __device__ __forceinline__ void fwd_layer0(const float *pts /*LDS [ROWS][3]*/, f
 // ReLU masks of h1..h4 for the sparse backward (which then needs no forward recompute): MASK_WORDS 32-bit words per
 // point, bit c&31 of word OFF_L + (c>>5) = [h_L[c] > 0]; h1: words 0-1, h2: 2-5, h3: 6-9, h4: 10-17.  The h5 mask is
 // implied (the arg-max of a channel with z > 0 is positive).  Staged per tile in LDS, written out coalesced.
-constexpr int MASK_WORDS = 18;
-constexpr int MASK_OFF2 = 2, MASK_OFF3 = 6, MASK_OFF4 = 10;
+// (MASK_WORDS, MASK_OFF2..4: encoder_jac.h)
 // ROWS = 64: 8 waves, two workgroups per CU (the B = 32 shape).  ROWS = 32: 4 waves owning one row block -- the same chains,
 // the same bits -- for launches that would otherwise leave CUs without a tile (batch * n / 64 < 256, i.e. B <= 7 at
 // N = 2048: what each GPU sees when ONE batch of 32 is split over 8): a tile's five dependent layers are ~19 us of MFMA
@@ -551,6 +551,7 @@ __device__ __forceinline__ void encoder_bwd_masked_body(const DeviceAE &A, int n
         sc3[threadIdx.x - 128] = A.scale[3][threadIdx.x - 128];
     }
     __syncthreads();
+    GA_STAMP(1, 1);
     if (threadIdx.x < ROWS) rowid[threadIdx.x] = crit[r0 + threadIdx.x];
     __syncthreads();
     for (int e = threadIdx.x; e < ROWS * MASK_WORDS; e += ENC_THREADS)
@@ -560,22 +561,27 @@ __device__ __forceinline__ void encoder_bwd_masked_body(const DeviceAE &A, int n
         bufQ[s * 132 + c] = crit[c] == rowid[s] ? dzs[c] : 0.f;
     }
     __syncthreads();
+    GA_STAMP(1, 2);
     auto bit = [&](int row, int off, int c) { return (mw[row * MASK_WORDS + off + (c >> 5)] >> (c & 31)) & 1u; };
     // dh4 = da4 @ W4^T (128 -> 256); da3 = dh4 * mask4 * scale3   into bufP
     frag16_load(f3, A.enc_bwd16[3]);
     layer_gemm16(bufQ, 132, f4, [&](int row, int c, float a) { bufP[row * 260 + c] = bit(row, MASK_OFF4, c) ? a * sc3[c] : 0.f; });
     __syncthreads();
+    GA_STAMP(1, 3);
     // dh3 = da3 @ W3^T (256 -> 128); da2 = dh3 * mask3 * scale2   into bufQ
     frag16_load(f2, A.enc_bwd16[2]);
     layer_gemm16(bufP, 260, f3, [&](int row, int c, float a) { bufQ[row * 132 + c] = bit(row, MASK_OFF3, c) ? a * sc2[c] : 0.f; });
     __syncthreads();
+    GA_STAMP(1, 4);
     // dh2 = da2 @ W2^T (128 -> 128); da1 = dh2 * mask2 * scale1   into bufP (stride 132)
     frag16_load(f1, A.enc_bwd16[1]);
     layer_gemm16(bufQ, 132, f2, [&](int row, int c, float a) { bufP[row * 132 + c] = bit(row, MASK_OFF2, c) ? a * sc1[c] : 0.f; });
     __syncthreads();
+    GA_STAMP(1, 5);
     // dh1 = da1 @ W1^T (128 -> 64); da0 = dh1 * mask1 * scale0   into bufQ (stride 68)
     layer_gemm16(bufP, 132, f1, [&](int row, int c, float a) { bufQ[row * 68 + c] = bit(row, 0, c) ? a * sc0[c] : 0.f; });
     __syncthreads();
+    GA_STAMP(1, 6);
     if (threadIdx.x < ROWS * 3) {   // dh0 = da0 @ W0^T (64 -> 3) on the VALU
         const int r = threadIdx.x / 3, a = threadIdx.x % 3;
         float s = 0.f;
@@ -749,7 +755,10 @@ static int set_lds_attr_once() {
 }
 
 // Tile height of the forward for a batch of b clouds: 32 rows when 64-row tiles would not even give every CU one tile.
-int encoder_fwd_rows(int b, int n) { return (long)b * cdiv(n, 64) < kCUs ? 32 : 64; }
+#ifndef ENC_ROWS32_BELOW
+#define ENC_ROWS32_BELOW 2      // 32-row tiles while 64-row ones give a CU fewer than two workgroups (measured at B = 12: 0.1235 -> 0.1135 ms per iteration; B = 8, 16: unchanged)
+#endif
+int encoder_fwd_rows(int b, int n) { return (long)b * cdiv(n, 64) < ENC_ROWS32_BELOW * kCUs ? 32 : 64; }
 int encoder_tiles(int b, int n) { return cdiv(n, encoder_fwd_rows(b, n)); }
 int encoder_tiles_max(int n) { return cdiv(n, 32); }              // what the pool-partial buffers are sized for
 
@@ -790,6 +799,31 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
         if (small) launch_fwd2<false, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, nullptr, stream, start, stop, fa);
         else launch_fwd2<false, 64>(A, b, x, pert, adv_out, pmax, parg, pcnt, nullptr, stream, start, stop, fa);
     }
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+// The pool Jacobian (encoder_jac.h) as a launch of its own: grid = 8 workgroups per cloud.
+__global__ __launch_bounds__(ENC_THREADS) void encoder_jac_kernel(DeviceAE A, JacArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    GA_STAMP(2, 0);
+    encoder_jac_block<true>(A, a, lds, blockIdx.x % (128 / JAC_ROWS), blockIdx.x / (128 / JAC_ROWS));
+    GA_STAMP(2, 7);
+}
+int launch_encoder_jac(const DeviceAE &A, int b, const JacArgs &a, hipStream_t stream) {
+    if (b <= 0) return GEOADV_OK;
+    encoder_jac_kernel<<<b * (128 / JAC_ROWS), ENC_THREADS, JAC_LDS_BYTES, stream>>>(A, a);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+// The dense, recomputing backward alone: only clouds with a tied pool maximum do work (their gradient cannot come from the
+// Jacobian); with no such cloud the 2 x n / 64 workgroups leave after one look at the flags.
+int launch_encoder_bwd_dense(const DeviceAE &A, int b, const float *adv, const float *z, const int *zcnt, const float *dz,
+                             const int *dense_flag, float *g_enc, hipStream_t stream) {
+    if (int st = set_lds_attr_once()) return st;
+    if (b <= 0) return GEOADV_OK;
+    encoder_bwd_kernel<BWD_DENSE_ROWS, true><<<dim3(cdiv(A.n_points, BWD_DENSE_ROWS), BWD_DENSE_SLOTS), ENC_THREADS, EncLds<BWD_DENSE_ROWS>::bwd_bytes, stream>>>(
+        A, A.n_points, b, adv, nullptr, 0, z, zcnt, dz, dense_flag, g_enc);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -215,11 +215,18 @@ typedef struct geoadv_attack_config {
      * The parity tests run every one of them against the default path.                                                */
     int   recompute_backward;       /* 1: the sparse encoder backward re-runs the forward for the critical rows instead
                                      * of reading the ReLU masks the forward kept (the path tied clouds always take)    */
+    int   encoder_backward;         /* how the masks are used: GEOADV_ENC_BWD_AUTO (0) = the pool Jacobian (encoder_jac.h) where
+                                     * it can be evaluated beside the symmetric Chamfer scan, else the masked backward;
+                                     * _MASKED (1) = always back-propagate dz through the critical rows; _JACOBIAN (2) = always
+                                     * the Jacobian (a launch of its own where nothing hosts it).  Equal to rounding.       */
     int   separate_adam;            /* 1: the Adam step is its own launch (the path loss_dist_type 'pert' always takes)
                                      * instead of riding in the next forward's point loaders                           */
     int   chamfer_kernel;           /* GEOADV_CHAMFER_AUTO (0: by batch size), _TWO_SCAN (the public op's kernel),
                                      * _SYMMETRIC (one evaluation per pair serves both directions)                      */
 } geoadv_attack_config;
+#define GEOADV_ENC_BWD_AUTO      0
+#define GEOADV_ENC_BWD_MASKED    1
+#define GEOADV_ENC_BWD_JACOBIAN  2
 #define GEOADV_CHAMFER_AUTO      0
 #define GEOADV_CHAMFER_TWO_SCAN  1
 #define GEOADV_CHAMFER_SYMMETRIC 2

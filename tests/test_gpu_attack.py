@@ -271,19 +271,24 @@ def test_odd_sizes_all_code_paths_agree():
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_paths_child.py")
     sizes = ["1", "2", "31", "64", "65", "255", "257", "1023", "2049", "4097"]
     got = {}
-    for name, cfg in [("default", {"chamfer_prune": "always"}), ("all-pairs source distance", {"chamfer_prune": False}),
-                      ("Adam in its own launch", {"separate_adam": True, "chamfer_prune": "always"}),
-                      ("two-scan Chamfer", {"chamfer_kernel": "two_scan", "chamfer_prune": "always"}),
-                      ("two-scan Chamfer, all-pairs source distance", {"chamfer_kernel": "two_scan", "chamfer_prune": False}),
-                      ("symmetric Chamfer + grid search", {"chamfer_kernel": "symmetric", "chamfer_prune": "always"}),
-                      ("auto (tiny batch: all-pairs)", {}),
-                      ("symmetric Chamfer, all-pairs source distance", {"chamfer_kernel": "symmetric", "chamfer_prune": False})]:
+    M = {"encoder_backward": "masked"}        # (the two backward forms agree to rounding, not bit for bit: each group fixes one)
+    J = {"encoder_backward": "jacobian"}
+    for name, cfg in [("default", {"chamfer_prune": "always", **M}), ("all-pairs source distance", {"chamfer_prune": False, **M}),
+                      ("Adam in its own launch", {"separate_adam": True, "chamfer_prune": "always", **M}),
+                      ("two-scan Chamfer", {"chamfer_kernel": "two_scan", "chamfer_prune": "always", **M}),
+                      ("two-scan Chamfer, all-pairs source distance", {"chamfer_kernel": "two_scan", "chamfer_prune": False, **M}),
+                      ("symmetric Chamfer + grid search", {"chamfer_kernel": "symmetric", "chamfer_prune": "always", **M}),
+                      ("auto (tiny batch: all-pairs)", M),
+                      ("symmetric Chamfer, all-pairs source distance", {"chamfer_kernel": "symmetric", "chamfer_prune": False, **M}),
+                      ("jacobian: default", {"chamfer_kernel": "symmetric", "chamfer_prune": "always", **J}),
+                      ("jacobian: in a launch of its own", {"chamfer_kernel": "two_scan", "chamfer_prune": False, **J}),
+                      ("jacobian: beside the scan, Adam in its own launch", {"chamfer_kernel": "symmetric", "separate_adam": True, **J})]:
         o = subprocess.run([sys.executable, child, json.dumps(cfg)] + sizes, capture_output=True, text=True, timeout=600)
         lines = [ln for ln in o.stdout.splitlines() if ln.startswith("HASHES ")]
         assert o.returncode == 0 and lines, (name, o.stderr[-400:])
         got[name] = json.loads(lines[-1][7:])
     for name, h in got.items():
-        assert h == got["default"], name
+        assert h == got["jacobian: default" if name.startswith("jacobian") else "default"], name
 
 
 @pytest.mark.parametrize("reference_weights", [False, True])
@@ -349,6 +354,44 @@ def test_masked_backward_equals_recomputing_backward(setup, n):
     torch.testing.assert_close(grads[0] / sc, grads[1] / sc, rtol=0, atol=2e-6)
     assert outs[0].abs().max() > 0
     torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-4 * outs[1].abs().max().item())
+
+
+@pytest.mark.parametrize("kernel", ["symmetric", "two_scan"])
+@pytest.mark.parametrize("n,b", [(N, 3), (N, 32), (200, 3), (1, 2), (65, 5), (257, 3)])
+def test_jacobian_backward_equals_masked_backward(kernel, n, b):
+    """The encoder backward as the pool Jacobian evaluated beside the forward (encoder_jac.h: J[c] = d z[c] / d adv[crit[c]], then
+    g = sum dz[c] J[c] in the decoder backward's tail) against back-propagating dz through the critical rows: the same
+    products summed per channel first instead of per point first -- the first iteration's gradient agrees to 2e-6 of its
+    largest component, the perturbation after 6 Adam steps to 1e-4 of its size (but for a few elements in ten thousand).  Both hosts: beside the symmetric scan and as
+    a launch of its own (two-scan kernel); clouds with duplicated points (tied pool maxima) take the dense path in both."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    w = W.randomized_weights(n)
+    ae = PointNetAE(w, n)
+    x, gt = _clouds(71, b, n)
+    if n >= 64:
+        x = x.copy(); x[0, 1] = x[0, 0]                    # one cloud with a duplicated point: an exact tie in its pool
+    grads, outs = [], []
+    for form in ("masked", "jacobian"):
+        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=6, num_iterations_thresh=3,
+                                              encoder_backward=form, chamfer_kernel=kernel), ae=ae)
+        at.set_inputs(x, gt, None, 1.0)
+        at.init_pert(np.zeros((b, n, 3), np.float32), reset_optimizer=True)      # zero pert: the duplicate stays a tie in iteration 1
+        at.run(0, 1, 3)
+        grads.append(at.peek()["grad"].clone())
+        at.run(1, 5, 3)
+        outs.append(at.peek()["pert"].clone())
+    sc = grads[0].abs().amax((1, 2), keepdim=True)
+    assert (sc > 0).all()
+    torch.testing.assert_close(grads[1] / sc, grads[0] / sc, rtol=0, atol=2e-6)
+    top = outs[0].abs().max().item()
+    assert top > 0
+    diff = (outs[1] - outs[0]).abs()
+    # six Adam steps amplify a rounding difference where a coordinate's gradient is itself rounding noise (the step is
+    # lr * m / (sqrt(v) + 1e-8)): all but a few elements per ten thousand stay within 1e-4 of the largest perturbation
+    assert (diff <= 1e-4 * top).float().mean().item() >= 0.9995 and diff.max().item() <= 0.05 * top
 
 
 @pytest.mark.parametrize("sym", ["symmetric", "two_scan"])

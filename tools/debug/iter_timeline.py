@@ -18,8 +18,8 @@ at.run(0, 60, 10**6)
 torch.cuda.synchronize()
 NB = 1024
 names = {"decoder": {0: "latent_decode", 1: "grid_search blocks (in latent_decode)", 2: "decoder_fc2", 3: "decoder_fc2_bwd", 4: "decoder_bwd_tail"},
-         "encoder": {0: "encoder_fwd", 1: "encoder_bwd (masked blocks)"}, "chamfer": {0: "chamfer_scan"},
-         "chamfer_sym": {0: "chamfer_sym", 1: "grid_search blocks (in chamfer_sym)", 2: "chamfer_sym_finish"}, "attack": {0: "loss_cgrad"}}
+         "encoder": {0: "encoder_fwd", 1: "encoder_bwd (masked blocks)", 2: "encoder_jac"}, "chamfer": {0: "chamfer_scan"},
+         "chamfer_sym": {0: "chamfer_sym", 1: "grid_search blocks (in chamfer_sym)", 2: "chamfer_sym_finish"}, "attack": {0: "loss_cgrad (all blocks)", 1: "loss_cgrad: gradient blocks"}}
 rows = []
 for tu, slots in names.items():
     buf = (C.c_ulonglong * (8 * NB * 8))()
