@@ -416,7 +416,9 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     a.n = n; a.m = m; a.tiles = cdiv(n, CS_ROWS); a.clouds = b; a.pairs = np; a.colpart = workspace;
     // column slices so that the grid fills the chip (4 workgroups per CU resident): 1, 2 or 4
     a.csplit = 1;
-    while (a.csplit < CS_MAX_SPLIT && (long)a.tiles * a.csplit * b * np < 256 && m / (a.csplit * 2) >= 256) a.csplit *= 2;   // measured: slicing only pays when the grid would not even cover the CUs
+    // (a second pair gated by `need1` usually has no work at all -- the grid search answers it -- so it does not count)
+    const int np_live = need1 ? 1 : np;
+    while (a.csplit < CS_MAX_SPLIT && (long)a.tiles * a.csplit * b * np_live < 256 && m / (a.csplit * 2) >= 256) a.csplit *= 2;   // measured: slicing only pays when the grid would not even cover the CUs
     a.rowpart_d = workspace + 4 * (size_t)np * b * a.tiles * m;
     a.rowpart_i = reinterpret_cast<int *>(a.rowpart_d + (size_t)np * b * CS_MAX_SPLIT * n);
     static DeviceOnce attr;

@@ -591,83 +591,6 @@ __device__ __forceinline__ void encoder_bwd_masked_body(const DeviceAE &A, int n
     }
 }
 
-// The same on 32-row tiles and the 32x32x2 shape (layer_gemm): the throughput form, for batches whose 16-row workgroups
-// would need more than one round of the chip (B > 32).  A workgroup handles 32 of the
-// cloud's 128 critical rows (slot c = the arg-max row of channel c; a row listed several times is computed several times
-// with the same result).  da4[slot][c] = dz[c] * scale4[c] where that slot's row IS the arg-max of channel c and z > 0
-// (clouds with a tied maximum are flagged and go through the dense, recomputing launch instead).
-constexpr int BWM32_ROWS = 32;
-constexpr size_t BWM32_LDS_BYTES = sizeof(float) * (BWM32_ROWS * 260 + BWM32_ROWS * 132 + 3 * 2 * 16 * 64 + 128) +
-                                 sizeof(int) * (BWM32_ROWS + 128) + sizeof(unsigned) * BWM32_ROWS * MASK_WORDS;
-
-__device__ __forceinline__ void encoder_bwd_masked32_body(const DeviceAE &A, int n, const unsigned *masks, const int *rows,
-                                                        const float *z, const float *dz, const int *dense_flag,
-                                                        float *g_enc, const int bx, const int b) {
-    if (dense_flag[b] != 0) return;
-    constexpr int ROWS = BWM32_ROWS;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *bufP = lds;                                  // [32][260]
-    float *bufQ = bufP + ROWS * 260;                    // [32][132]
-    float *scratch = bufQ + ROWS * 132;                 // K-part hand-off of layer_gemm
-    float *dzs = scratch + 3 * 2 * 16 * 64;             // [128] dz * scale4 where z > 0
-    int *rowid = reinterpret_cast<int *>(dzs + 128);    // [32]
-    int *crit = rowid + ROWS;                           // [128]
-    unsigned *mw = reinterpret_cast<unsigned *>(crit + 128);   // [32][MASK_WORDS]
-    const int r0 = bx * ROWS;
-    if (threadIdx.x < 128) {
-        const int c = threadIdx.x;
-        crit[c] = rows[(size_t)b * 128 + c];
-        dzs[c] = z[(size_t)b * 128 + c] > 0.f ? dz[(size_t)b * 128 + c] * A.scale[4][c] : 0.f;
-    }
-    __syncthreads();
-    if (threadIdx.x < ROWS) rowid[threadIdx.x] = crit[r0 + threadIdx.x];
-    __syncthreads();
-    for (int e = threadIdx.x; e < ROWS * MASK_WORDS; e += ENC_THREADS)
-        mw[e] = masks[((size_t)b * n + rowid[e / MASK_WORDS]) * MASK_WORDS + e % MASK_WORDS];
-    for (int e = threadIdx.x; e < ROWS * 128; e += ENC_THREADS) {
-        const int s = e >> 7, c = e & 127;
-        bufQ[s * 132 + c] = crit[c] == rowid[s] ? dzs[c] : 0.f;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto bit = [&](int row, int off, int c) { return (mw[row * MASK_WORDS + off + (c >> 5)] >> (c & 31)) & 1u; };
-    {   // dh4 = da4 @ W4^T (128 -> 256); da3 = dh4 * mask4 * scale3   into bufP
-        const int col = (wave % 8) * 32 + (lane & 31);
-        const float sc = A.scale[3][col];
-        layer_gemm<ROWS, 256, 0>(bufQ, 132, A.enc_bwd[4], scratch,
-                                 [&](int row, int c, float a) { bufP[row * 260 + c] = bit(row, MASK_OFF4, c) ? a * sc : 0.f; });
-    }
-    __syncthreads();
-    {   // dh3 = da3 @ W3^T (256 -> 128); da2 = dh3 * mask3 * scale2   into bufQ
-        const int col = (wave % 4) * 32 + (lane & 31);
-        const float sc = A.scale[2][col];
-        layer_gemm<ROWS, 128, 0>(bufP, 260, A.enc_bwd[3], scratch,
-                                 [&](int row, int c, float a) { bufQ[row * 132 + c] = bit(row, MASK_OFF3, c) ? a * sc : 0.f; });
-    }
-    __syncthreads();
-    {   // dh2 = da2 @ W2^T (128 -> 128); da1 = dh2 * mask2 * scale1   into bufP (stride 132)
-        const int col = (wave % 4) * 32 + (lane & 31);
-        const float sc = A.scale[1][col];
-        layer_gemm<ROWS, 128, 0>(bufQ, 132, A.enc_bwd[2], scratch,
-                                 [&](int row, int c, float a) { bufP[row * 132 + c] = bit(row, MASK_OFF2, c) ? a * sc : 0.f; });
-    }
-    __syncthreads();
-    {   // dh1 = da1 @ W1^T (128 -> 64); da0 = dh1 * mask1 * scale0   into bufQ (stride 68)
-        const int col = (wave % 2) * 32 + (lane & 31);
-        const float sc = A.scale[0][col];
-        layer_gemm<ROWS, 64, 0>(bufP, 132, A.enc_bwd[1], scratch,
-                                [&](int row, int c, float a) { bufQ[row * 68 + c] = bit(row, 0, c) ? a * sc : 0.f; });
-    }
-    __syncthreads();
-    if (threadIdx.x < ROWS * 3) {   // dh0 = da0 @ W0^T (64 -> 3) on the VALU
-        const int r = threadIdx.x / 3, a = threadIdx.x % 3;
-        float s = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) s = fmaf(bufQ[r * 68 + c], A.w0[a * 64 + c], s);
-        g_enc[((size_t)b * n + rowid[r]) * 3 + a] = s;
-    }
-}
-
 // Sparse launch: grid (128 / ROWS, batch): block (tile, b) handles 32 of cloud b's 128 critical rows; flagged clouds
 // (exact tie in the max-pool) are skipped.  Dense launch: grid (n / ROWS, DENSE_SLOTS): the flagged clouds -- almost
 // never any -- are dealt round-robin to the DENSE_SLOTS block rows, which process every point of them; with no flagged
@@ -706,13 +629,12 @@ constexpr int BWD_MERGED_DENSE_SLOTS = 2;
 __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_merged_kernel(DeviceAE A, int n, int batch, const unsigned *masks,
                                                                         const int *rows, const float *z, const int *zcnt,
                                                                         const float *dz, const int *dense_flag, const float *adv,
-                                                                        float *g_enc, int rows16) {
-    const int per = rows16 ? 128 / BWM_ROWS : 128 / BWM32_ROWS;
+                                                                        float *g_enc) {
+    const int per = 128 / BWM_ROWS;
     const int nm = per * batch;
     GA_STAMP(1, 0);
     if ((int)blockIdx.x < nm) {
-        if (rows16) encoder_bwd_masked_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % per, blockIdx.x / per);
-        else encoder_bwd_masked32_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % per, blockIdx.x / per);
+        encoder_bwd_masked_body(A, n, masks, rows, z, dz, dense_flag, g_enc, blockIdx.x % per, blockIdx.x / per);
         GA_STAMP(1, 7);
         return;
     }
@@ -838,12 +760,12 @@ int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *cr
     if (int st = set_lds_attr_once()) return st;
     if (b <= 0) return GEOADV_OK;
     if (masks) {
-        // 16-row workgroups (8 per cloud) while they fit the chip in one round, else the 32-row throughput form
-        // (ms per iteration, 16 / 32 rows: B = 4: 0.079 / 0.086, 32: 0.192 / 0.197, 64: 0.327 / 0.322, 256: 1.129 / 1.109)
-        const int rows16 = (128 / BWM_ROWS) * b <= kCUs;
-        const size_t lds = std::max(std::max(BWM_LDS_BYTES, BWM32_LDS_BYTES), EncLds<64>::bwd_bytes);
-        const int grid = (rows16 ? 128 / BWM_ROWS : 128 / BWM32_ROWS) * b + cdiv(A.n_points, 64) * BWD_MERGED_DENSE_SLOTS;
-        encoder_bwd_merged_kernel<<<grid, ENC_THREADS, lds, stream>>>(A, A.n_points, b, masks, crit_rows, z, zcnt, dz, dense_flag, adv, g_enc, rows16);
+        // 16-row workgroups (8 per cloud) at EVERY batch size: the tile shape fixes the summation order, so a cloud's gradient
+        // bits do not depend on the batch it sits in (a 32-row throughput form for B > 32 was 1.5 % faster at
+        // B = 256 and is gone -- large batches of the output-space attack use the pool Jacobian anyway, encoder_jac.h)
+        const size_t lds = std::max(BWM_LDS_BYTES, EncLds<64>::bwd_bytes);
+        const int grid = (128 / BWM_ROWS) * b + cdiv(A.n_points, 64) * BWD_MERGED_DENSE_SLOTS;
+        encoder_bwd_merged_kernel<<<grid, ENC_THREADS, lds, stream>>>(A, A.n_points, b, masks, crit_rows, z, zcnt, dz, dense_flag, adv, g_enc);
         GA_LAUNCH_CHECK();
         return GEOADV_OK;
     }

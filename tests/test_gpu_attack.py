@@ -356,6 +356,35 @@ def test_masked_backward_equals_recomputing_backward(setup, n):
     torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-4 * outs[1].abs().max().item())
 
 
+@pytest.mark.parametrize("n,form", [(2048, "auto"), (256, "masked"), (256, "jacobian")])
+def test_trajectory_of_a_cloud_does_not_depend_on_its_batch(n, form):
+    """which batch a cloud sits in must not change its trajectory.  Every kernel of the loop sums a cloud's numbers
+    in an order fixed by the cloud alone -- the forward's 32- and 64-row tiles run the same chains, the backward (masked or
+    pool Jacobian) uses 16-row tiles at every batch size, the Chamfer results are exact -- so the perturbation of a cloud after
+    8 iterations is bit-identical whether it is attacked in a batch of 8, 32 or 40.  (What does change the bits: the backward
+    FORM -- masked vs Jacobian agree to rounding, test_jacobian_backward_equals_masked_backward -- which `auto` picks by
+    batch size below / above 6 clouds of 2048 points; the bit-for-bit statements of dist.py / run_attack.py hold at equal
+    configuration.)"""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    w = W.randomized_weights(n)
+    ae = PointNetAE(w, n)
+    x, gt = _clouds(91, 40, n)
+    p0 = (1e-3 * np.random.default_rng(3).standard_normal((40, n, 3))).astype(np.float32)
+    outs = {}
+    for b in (8, 32, 40):
+        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=8, num_iterations_thresh=3,
+                                              encoder_backward=form), ae=ae)
+        at.set_inputs(x[:b], gt[:b], None, 1.0)
+        at.init_pert(p0[:b], reset_optimizer=True)
+        at.run(0, 8, 3)
+        outs[b] = at.peek()["pert"][:8].clone()
+    assert outs[8].abs().max() > 0
+    assert torch.equal(outs[8], outs[32]) and torch.equal(outs[8], outs[40])
+
+
 @pytest.mark.parametrize("kernel", ["symmetric", "two_scan"])
 @pytest.mark.parametrize("n,b", [(N, 3), (N, 32), (200, 3), (1, 2), (65, 5), (257, 3)])
 def test_jacobian_backward_equals_masked_backward(kernel, n, b):
