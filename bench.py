@@ -40,8 +40,8 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_encoder.json")     # tools/pm
 PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r03_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep: ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- what each rank of the strong-scaling leg runs
-SWEEP_SRC = "profiles/r02_attack_sweep.json"
-SWEEP_MS = {32: 0.1871, 16: 0.1256, 8: 0.0927, 4: 0.0762}
+SWEEP_SRC = "profiles/r03_attack_sweep.json"
+SWEEP_MS = {32: 0.1768, 16: 0.1160, 8: 0.0880, 4: 0.0739}
 
 
 def parse_args():
@@ -397,10 +397,11 @@ def emd_leg(dev):
         xs, ys = torch.as_tensor(clouds(31, b, N)).to(dev), torch.as_tensor(clouds(32, b, N)).to(dev)
 
         def timed(f, reps):
-            f(); torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r = f(); r = None; torch.cuda.synchronize()      # (released before the next call: the 2 GB plan of B = 128 is then
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # re-used from the allocator's cache, not malloc'ed in the timed region)
             e0.record()
             for _ in range(reps):
+                r = None
                 r = f()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps, r
