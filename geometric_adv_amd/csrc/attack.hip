@@ -11,6 +11,7 @@
 #include "chamfer_grad.h"
 #include "chamfer_grid.h"
 #include "encoder_jac.h"
+#include "decoder_tail.h"
 #include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
@@ -34,6 +35,8 @@ int launch_chamfer_sym_rider(const ChamferPair *pairs, int np, int b, int n, int
 int launch_encoder_jac(const DeviceAE &A, int b, const JacArgs &a, hipStream_t stream);
 int launch_encoder_bwd_dense(const DeviceAE &A, int b, const float *adv, const float *z, const int *zcnt, const float *dz,
                              const int *dense_flag, float *g_enc, hipStream_t stream);
+int launch_decoder_fc2_bwd(const DeviceAE &A, int b, const float *g_recon, float *partial, hipStream_t stream);
+int launch_decoder_tail_dense(const DeviceAE &A, const TailDenseArgs &a, hipStream_t stream);
 bool chamfer_grid_rides(int n);
 int launch_chamfer_grid(const float *P, const float *Q, float *d1, int *i1, float *d2, int *i2, int b, int n, int *need, int call, const float *box,
                         hipStream_t stream);
@@ -477,6 +480,8 @@ struct geoadv_attack {
     float *jac;                      // [B][128][3] pool Jacobian of the cached forward (encoder_jac.h), or null: the output-space
                                      // attack's encoder backward is then 128 x 3 multiply-adds in the decoder backward's tail
     bool jac_valid;                  // ... computed for the cached forward
+    unsigned *tail_ready;            // [B] + 1 word: hand-off flags of the merged tail + dense launch, the spin-timeout word
+    unsigned tail_epoch;             // (host) steps launched so far: the flag value of the current one
     bool chamfer_sym;
     // host state
     float beta1_pow, beta2_pow;
@@ -725,15 +730,22 @@ int do_step(geoadv_attack *at, hipStream_t st) {
     }
     if (adv_chamfer) {
         ProfScope ps(at, GEOADV_PROF_DECODER_BWD, st);
-        const bool jm = at->jac_valid;
-        if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st, jm ? at->fs.crit : nullptr,
-                                        jm ? at->jac : nullptr, jm ? at->fs.dense : nullptr, jm ? at->g_enc : nullptr)) return rc;
+        if (at->jac_valid) {
+            // the tail applies the Jacobian; the dense recomputing backward for clouds with a tied pool maximum shares its launch
+            // (decoder_tail_dense_kernel) and waits, for such clouds only, on the tail block's flag
+            if (int rc = launch_decoder_fc2_bwd(A, B, at->g_recon, at->dec_partial, st)) return rc;
+            TailDenseArgs ta;
+            ta.batch = B; ta.chunks = decoder_bwd_chunks(A); ta.n = n;
+            ta.partial = at->dec_partial; ta.d1 = at->fs.d1; ta.d2 = at->fs.d2; ta.dz = at->dz;
+            ta.ja = JacApply{at->fs.crit, at->jac, at->fs.dense, at->g_enc, n};
+            ta.adv = at->adv; ta.z = at->fs.z; ta.zcnt = at->fs.zcnt; ta.dense_flag = at->fs.dense; ta.g_enc = at->g_enc;
+            ta.ready = at->tail_ready; ta.epoch = ++at->tail_epoch; ta.spin_timeout = reinterpret_cast<int *>(at->tail_ready + B);
+            if (int rc = launch_decoder_tail_dense(A, ta, st)) return rc;
+        } else if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st)) return rc;
     }
-    {
+    if (!(adv_chamfer && at->jac_valid)) {
         ProfScope ps(at, GEOADV_PROF_ENCODER_BWD, st);
-        if (adv_chamfer && at->jac_valid) {   // the tail above applied the Jacobian; only clouds with a tied pool maximum are left
-            if (int rc = launch_encoder_bwd_dense(A, B, at->adv, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, st)) return rc;
-        } else if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, at->masks, st))
+        if (int rc = launch_encoder_bwd(A, B, at->adv, at->fs.crit, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, at->masks, st))
             return rc;
     }
     {
@@ -819,6 +831,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * mask_words);
     const bool use_jac = mask_words != 0 && cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER && cfg->encoder_backward != GEOADV_ENC_BWD_MASKED;
     need(use_jac ? 4 * B * 128 * 3 : 0);
+    need(4 * (B + 1));
     need(4 * 8 * B); need(4 * 8 * B);                     // need_adv[2]
     need(4 * 6 * B);                                      // x_box
     const bool emd = cfg->emd_weight > 0.f;
@@ -849,6 +862,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->masks = mask_words ? reinterpret_cast<unsigned *>(take(4 * mask_words)) : nullptr;
     at->jac = use_jac ? F(4 * B * 128 * 3) : nullptr;
     at->jac_valid = false;
+    at->tail_ready = reinterpret_cast<unsigned *>(take(4 * (B + 1)));      // (the arena is zeroed above)
+    at->tail_epoch = 0;
     at->need_adv[0] = I(4 * 8 * B); at->need_adv[1] = I(4 * 8 * B);
     at->grid_calls = 0;
     at->x_box = F(4 * 6 * B);

@@ -7,6 +7,7 @@
 // it runs on v_mfma_f32_32x32x2_f32 with the weights pre-packed in fragment order, each workgroup
 // streaming one 32-column block once (HBM/L2-bandwidth shaped, as SURVEY 8(a5) notes).
 #include "ae.h"
+#include "decoder_tail.h"
 #include "chamfer_grid.h"
 #include <limits.h>
 
@@ -24,30 +25,6 @@ __device__ __forceinline__ int acc_row16(int reg, int h) { return (reg & 3) + 8 
 //   crit[b][c]  = lowest point index attaining it; zcnt[b][c] = number of points attaining it
 //   dense[b]    = 1 if some channel has a positive maximum attained more than once (exact tie)
 // ------------------------------------------------------------------------------------------
-constexpr int LD_THREADS = 1024;
-
-// out[o] (o < 256) = sum_k in[k] * Wt[k][256 + ...]: K split over 4 thread groups, partials in LDS,
-// summed in a fixed order by the first 256 threads.
-// THREADS = 1024: one K quarter per thread; 512: two (quarters ks and ks + 2, one after the other) -- the four partial sums
-// and their order are the same either way, so both give the same bits.
-template <int K, int THREADS = LD_THREADS>
-__device__ __forceinline__ float fc256_split4(const float *in_lds, const float *W /*[K][256]*/, float (*part)[256]) {
-    const int t = threadIdx.x, o = t & 255;
-    constexpr int PER = K / 4;
-#pragma unroll
-    for (int ks = t >> 8; ks < 4; ks += THREADS / 256) {
-        float w[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) w[k] = W[(size_t)(ks * PER + k) * 256 + o];
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) s = fmaf(in_lds[ks * PER + k], w[k], s);
-        part[ks][o] = s;
-    }
-    __syncthreads();
-    return ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];     // meaningful for t < 256
-}
-
 template <int THREADS>
 __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles, const float *pmax, const int *parg,
                                                     const int *pcnt, float *z, int *crit, int *zcnt,
@@ -270,120 +247,10 @@ __global__ __launch_bounds__(512) void decoder_fc2_bwd_kernel(DeviceAE A, int ba
     GA_STAMP(3, 7);
 }
 
-// dd2 = sum of partials, masked by d2 > 0; dd1 = dd2 @ V1^T masked by d1 > 0; dz = dd1 @ V0^T.
-// grid = clouds, 1024 threads.  TF ReluGrad masks by the layer OUTPUT being > 0.
-// (Requesting V1^T / V0^T ahead of the partial sums was measured and lost, 7.8 vs 7.2 us: a workgroup streams ~480 KB through
-// ONE CU, so the early weights only delay the partials the chain starts with.)
-// ja.jac != null: the encoder's part of the backward happens here too -- g_enc[b][p] = sum over the channels c with
-// crit[b][c] == p of dz[b][c] * J[b][c] (encoder_jac.h), channels in ascending order; every channel of a point writes the
-// same total.  Clouds with a tied pool maximum are left to the dense recomputing kernel.
-struct JacApply { const int *crit; const float *jac; const int *dense; float *g_enc; int n; };
-
+// the decoder backward's tail (decoder_tail.h) as a launch of its own: grid = clouds, 1024 threads
 __global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A, int batch, int chunks, const float *partial,
                                                                      const float *d1, const float *d2, float *dz, JacApply ja) {
-    __shared__ float g2[256];
-    __shared__ float g1[256];
-    __shared__ float part[8][256];
-    __shared__ __attribute__((aligned(16))) float dzs[128], jxs[128], jys[128], jzs[128];
-    __shared__ __attribute__((aligned(16))) int crs[128];
-    const int b = blockIdx.x, t = threadIdx.x, o = t & 255, ks = t >> 8;
-    GA_STAMP(4, 0);
-    // the Jacobian rows and critical points of this cloud do not depend on anything computed here: requested first
-    float jx = 0.f, jy = 0.f, jz = 0.f;
-    int my_crit = -1, is_dense = 0;
-    if (ja.jac && t < 128) {
-        const float *jp = ja.jac + ((size_t)b * 128 + t) * 3;
-        jx = jp[0]; jy = jp[1]; jz = jp[2];
-        my_crit = ja.crit[(size_t)b * 128 + t];
-        is_dense = ja.dense[b];
-    }
-    {   // split-K partials: 4 contiguous chunk groups, ascending inside, merged in order
-        const int cb = chunks * ks / 4, ce = chunks * (ks + 1) / 4;
-        float s = 0.f;
-#pragma unroll 8
-        for (int ch = cb; ch < ce; ++ch) s += partial[((size_t)ch * batch + b) * 256 + o];
-        part[ks][o] = s;
-    }
-    __syncthreads();
-    if (t < 256) {
-        const float s = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
-        g2[t] = d2[(size_t)b * 256 + t] > 0.f ? s : 0.f;
-    }
-    __syncthreads();
-    GA_STAMP(4, 1);
-    {
-        const float s = fc256_split4<256>(g2, A.v1t, part);
-        __syncthreads();
-        if (t < 256) g1[t] = d1[(size_t)b * 256 + t] > 0.f ? s : 0.f;
-    }
-    __syncthreads();
-    GA_STAMP(4, 2);
-    {   // dz: 128 outputs x 8 K-slices of 32
-        const int c = t & 127, k8 = t >> 7;
-        float w[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) w[k] = A.v0t[(size_t)(k8 * 32 + k) * 128 + c];
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) s = fmaf(g1[k8 * 32 + k], w[k], s);
-        part[k8][c] = s;
-        __syncthreads();
-        float r = 0.f;
-        if (t < 128) {
-            r = part[0][t];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) r += part[q][t];
-            dz[(size_t)b * 128 + t] = r;
-        }
-        GA_STAMP(4, 3);
-        if (ja.jac) {
-            if (t < 128) { dzs[t] = r; crs[t] = my_crit; jxs[t] = jx; jys[t] = jy; jzs[t] = jz; }
-            __syncthreads();
-            // g(point of channel ch) = sum over the channels c of that point of dz[c] * J[c]: thread (ch, part) adds the 16 channels
-            // [16 part, 16 part + 16) in ascending order (all LDS reads of a thread requested at once: vector reads, broadcast),
-            // the 8 parts are then added in ascending order -- a fixed order, so every channel of a point writes the same bits
-            {
-                const int ch = t & 127, pq = t >> 7, mine = crs[ch];
-                float gx = 0.f, gy = 0.f, gz = 0.f;
-                const int4 *c4 = reinterpret_cast<const int4 *>(crs) + 4 * pq;
-                const float4 *d4 = reinterpret_cast<const float4 *>(dzs) + 4 * pq, *x4 = reinterpret_cast<const float4 *>(jxs) + 4 * pq;
-                const float4 *y4 = reinterpret_cast<const float4 *>(jys) + 4 * pq, *z4 = reinterpret_cast<const float4 *>(jzs) + 4 * pq;
-                int4 cc[4]; float4 dd[4], xx[4], yy[4], zz[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { cc[q] = c4[q]; dd[q] = d4[q]; xx[q] = x4[q]; yy[q] = y4[q]; zz[q] = z4[q]; }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ci[4] = {cc[q].x, cc[q].y, cc[q].z, cc[q].w};
-                    const float di[4] = {dd[q].x, dd[q].y, dd[q].z, dd[q].w}, xi[4] = {xx[q].x, xx[q].y, xx[q].z, xx[q].w};
-                    const float yi[4] = {yy[q].x, yy[q].y, yy[q].z, yy[q].w}, zi[4] = {zz[q].x, zz[q].y, zz[q].z, zz[q].w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float d = ci[u] == mine ? di[u] : 0.f;
-                        gx = fmaf(d, xi[u], gx); gy = fmaf(d, yi[u], gy); gz = fmaf(d, zi[u], gz);
-                    }
-                }
-                __syncthreads();                                   // (part[][] is free: the dz partials were consumed above)
-                part[pq][ch] = gx; part[pq][128 + ch] = gy;
-                __syncthreads();
-                float sx = 0.f, sy = 0.f;
-                if (t < 128) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { sx += part[q][t]; sy += part[q][128 + t]; }
-                }
-                __syncthreads();
-                part[pq][ch] = gz;
-                __syncthreads();
-                if (t < 128 && !is_dense) {
-                    float sz = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) sz += part[q][t];
-                    float *g = ja.g_enc + ((size_t)b * ja.n + my_crit) * 3;
-                    g[0] = sx; g[1] = sy; g[2] = sz;
-                }
-            }
-        }
-    }
-    GA_STAMP(4, 7);
+    decoder_bwd_tail_body(A, batch, chunks, partial, d1, d2, dz, ja, blockIdx.x, nullptr, 0u);
 }
 
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
@@ -427,6 +294,14 @@ int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, 
 }
 
 int decoder_bwd_chunks(const DeviceAE &A) { return cdiv(A.dec2_bwd.K, DB_KC); }
+
+// the first of the decoder backward's two launches alone (the second then comes from encoder.hip: launch_decoder_tail_dense)
+int launch_decoder_fc2_bwd(const DeviceAE &A, int b, const float *g_recon, float *partial, hipStream_t stream) {
+    if (b <= 0) return GEOADV_OK;
+    decoder_fc2_bwd_kernel<<<dim3(decoder_bwd_chunks(A), cdiv(b, 32)), 512, 0, stream>>>(A, b, g_recon, partial);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
 
 int launch_decoder_bwd(const DeviceAE &A, int b, const float *g_recon, const float *d1, const float *d2, float *partial,
                        float *dz, hipStream_t stream, const int *crit, const float *jac, const int *dense, float *g_enc) {

@@ -23,6 +23,7 @@
 #include "ae.h"
 #include "mfma_tile.h"
 #include "encoder_jac.h"
+#include "decoder_tail.h"
 #include <hip/hip_ext.h>
 #include <limits.h>
 #include <stdlib.h>
@@ -738,6 +739,62 @@ int launch_encoder_jac(const DeviceAE &A, int b, const JacArgs &a, hipStream_t s
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
+// The decoder backward's tail (dd2 -> dd1 -> dz + the pool Jacobian's apply, decoder_tail.h) and the dense recomputing
+// backward for clouds with a tied pool maximum in ONE launch: blocks [0, batch) = one cloud's tail each (1024 threads);
+// blocks [batch, ...) = 32-row dense tiles (their upper eight waves leave at once) dealt to DENSE_SLOTS block rows.  A dense
+// block needs dz of its cloud, which a tail block of the SAME launch produces: it waits for that block's flag -- only where a
+// cloud IS tied (duplicated points; almost never), otherwise it leaves after one look at the flags and the launch costs what
+// the tail alone costs, where a dense launch of its own was 4.1 us + a boundary on every step.  No deadlock by construction:
+// tail blocks never wait, and the dense blocks (<= 2 n / 32) each need a whole CU's LDS, so they cannot occupy the chip.
+constexpr int TD_DENSE_ROWS = 32, TD_DENSE_SLOTS = 2;
+
+__global__ __launch_bounds__(LD_THREADS) void decoder_tail_dense_kernel(DeviceAE A, TailDenseArgs a) {
+    if ((int)blockIdx.x < a.batch) {
+        decoder_bwd_tail_body(A, a.batch, a.chunks, a.partial, a.d1, a.d2, a.dz, a.ja, blockIdx.x, a.ready, a.epoch);
+        return;
+    }
+    if (threadIdx.x >= ENC_THREADS) return;
+    __shared__ int any_flag;                           // fast path: one parallel look at the flags, usually all zero
+    if (threadIdx.x == 0) any_flag = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < a.batch; b += ENC_THREADS)
+        if (a.dense_flag[b] != 0) atomicOr(&any_flag, 1);
+    __syncthreads();
+    if (!any_flag) return;
+    const int d = blockIdx.x - a.batch, tiles = (a.n + TD_DENSE_ROWS - 1) / TD_DENSE_ROWS, tile = d % tiles, slot = d / tiles;
+    int rank = 0;
+    for (int b = 0; b < a.batch; ++b) {
+        if (a.dense_flag[b] == 0) continue;
+        if ((rank++ % TD_DENSE_SLOTS) != slot) continue;
+        if (threadIdx.x == 0) {                        // ONE lane polls the cloud's flag (relaxed, agent scope), bounded
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1u << 24)) { *a.spin_timeout = 1; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ONE acquire after the match ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                               // ... which the barrier holds for the other waves' loads of dz
+        encoder_bwd_tile<TD_DENSE_ROWS>(A, a.n, a.adv, nullptr, 0, a.z, a.zcnt, a.dz, a.g_enc, b, tile * TD_DENSE_ROWS);
+        __syncthreads();                               // LDS is reused for the next flagged cloud
+    }
+}
+
+int launch_decoder_tail_dense(const DeviceAE &A, const TailDenseArgs &a, hipStream_t stream) {
+    if (a.batch <= 0) return GEOADV_OK;
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decoder_tail_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)EncLds<TD_DENSE_ROWS>::bwd_bytes));
+            return GEOADV_OK;
+        })) return rc;
+    const int grid = a.batch + cdiv(a.n, TD_DENSE_ROWS) * TD_DENSE_SLOTS;
+    decoder_tail_dense_kernel<<<grid, LD_THREADS, EncLds<TD_DENSE_ROWS>::bwd_bytes, stream>>>(A, a);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
 // The dense, recomputing backward alone: only clouds with a tied pool maximum do work (their gradient cannot come from the
 // Jacobian); with no such cloud the 2 x n / 64 workgroups leave after one look at the flags.
 int launch_encoder_bwd_dense(const DeviceAE &A, int b, const float *adv, const float *z, const int *zcnt, const float *dz,
