@@ -439,9 +439,15 @@ __global__ void fill_kernel(float *p, float v, size_t count) {
 }
 
 // metrics[B][5] = loss_adv, loss_dist, source_chamfer_dist, target_nre, target_recon_error
-__global__ void best_metrics_kernel(int B, const float *best_metrics, const float *best_err, const float *ref, float *out) {
+// `failed`: the spin-timeout word of the merged tail + dense launch (never set in any run so far): a result computed after a
+// hand-off gave up must not look like a result
+__global__ void best_metrics_kernel(int B, const float *best_metrics, const float *best_err, const float *ref, float *out, const int *failed) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (failed && *failed) {
+        for (int k = 0; k < 5; ++k) out[b * 5 + k] = NAN;
+        return;
+    }
     out[b * 5 + 0] = best_metrics[b * 4 + 0];
     out[b * 5 + 1] = best_metrics[b * 4 + 1];
     out[b * 5 + 2] = best_metrics[b * 4 + 2];
@@ -978,7 +984,8 @@ extern "C" int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_
     const size_t bn3 = (size_t)at->B * at->n * 3;
     if (metrics) {
         GA_REQUIRE(target_ae_loss_ref, "attack_get_best: target_ae_loss_ref is required for the metrics");
-        best_metrics_kernel<<<(at->B + 63) / 64, 64, 0, st>>>(at->B, at->best_metrics, at->best_err, target_ae_loss_ref, metrics);
+        best_metrics_kernel<<<(at->B + 63) / 64, 64, 0, st>>>(at->B, at->best_metrics, at->best_err, target_ae_loss_ref, metrics,
+                                                              reinterpret_cast<const int *>(at->tail_ready + at->B));
         GA_LAUNCH_CHECK();
     }
     if (adv) GA_HIP(hipMemcpyAsync(adv, at->best_adv, 4 * bn3, hipMemcpyDeviceToDevice, st));
