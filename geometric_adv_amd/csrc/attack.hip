@@ -873,18 +873,19 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->need_adv[0] = I(4 * 8 * B); at->need_adv[1] = I(4 * 8 * B);
     at->grid_calls = 0;
     at->x_box = F(4 * 6 * B);
-    // Tiny batches (<= 10 K points: B <= 4 at N = 2048): the search's own latency (~11-14 us per workgroup beside a 6 us
+    // Tiny batches (< 10 K points: B <= 4 at N = 2048): the search's own latency (~11-14 us per workgroup beside a 6 us
     // latent_decode) costs what the two extra all-pairs scans cost on a mostly idle chip -- measured 0.0673 / 0.0725 ms at
-    // B = 1 and 0.0758 / 0.0767 at B = 4 without / with it, 0.0977 / 0.0929 at B = 8 -- so it is only used above that.
+    // B = 1 and 0.0758 / 0.0767 at B = 4 without / with it, 0.0977 / 0.0929 at B = 8 -- so it is only used above that
+    // (at B = 5 the two-scan launch needs a third round of workgroups: 0.0908 without, 0.0846 with the search + symmetric scan).
     // (all_pairs_source_dist 2 = the search whatever the size: the parity tests' small shapes)
-    at->chamfer_prune = cfg->all_pairs_source_dist == 2 || (cfg->all_pairs_source_dist == 0 && (long)at->B * at->n > 10240);
+    at->chamfer_prune = cfg->all_pairs_source_dist == 2 || (cfg->all_pairs_source_dist == 0 && (long)at->B * at->n >= 10240);
     {
         // The symmetric scan + its finish launch against the public op's plain scans in ONE launch (both directions of (recon,
         // target), and of (adv, source) only for clouds the grid search handed back).  Since the grid search and the encoder's
-        // pool Jacobian ride in the symmetric scan's launch (round 3) it wins from B = 8 on (ms per iteration, plain /
+        // pool Jacobian ride in the symmetric scan's launch (round 3) it wins from B = 5 on (ms per iteration, plain /
         // symmetric: B = 4: 0.0748 / 0.0757, 8: 0.0935 / 0.0925, 12: 0.1143 / 0.1055, 16: 0.1263 / 0.1252, 24: 0.1673 / 0.1529,
-        // 32: 0.1913 / 0.1773); below, launches are fixed latency and the plain form has one fewer.  Same bits either way.
-        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n >= 12288
+        // 32: 0.1913 / 0.1773; later build, B = 4: 0.0749 / 0.0743, 5: 0.0909 / 0.0846, 6: 0.0916 / 0.0850); below, launches are fixed latency and the plain form has one fewer.  Same bits either way.
+        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n >= 10240
                                                                      : cfg->chamfer_kernel == GEOADV_CHAMFER_SYMMETRIC;
     }
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;

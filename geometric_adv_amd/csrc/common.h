@@ -59,10 +59,11 @@ struct DeviceOnce {
 #ifdef GA_STAMPS
 #define GA_STAMP_BLOCKS 1024
 static __device__ unsigned long long ga_stamps[8 * GA_STAMP_BLOCKS * 8];
-#define GA_STAMP(K, I)                                                                                   \
+#define GA_STAMP(K, I) GA_STAMP_T(K, I, 0)
+#define GA_STAMP_T(K, I, TID)                                                                            \
     do {                                                                                                 \
         const unsigned blk_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);            \
-        if (threadIdx.x == 0 && blk_ < GA_STAMP_BLOCKS) {                                                \
+        if (threadIdx.x == (TID) && blk_ < GA_STAMP_BLOCKS) {                                                \
             unsigned long long t_;                                                                       \
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
             ga_stamps[(((K) & 7) * GA_STAMP_BLOCKS + blk_) * 8 + (I)] = t_;                               \
@@ -74,6 +75,7 @@ static __device__ unsigned long long ga_stamps[8 * GA_STAMP_BLOCKS * 8];
     }
 #else
 #define GA_STAMP(K, I)
+#define GA_STAMP_T(K, I, TID)
 #define GA_STAMPS_GETTER(NAME)
 #endif
 

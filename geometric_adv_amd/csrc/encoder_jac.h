@@ -125,7 +125,9 @@ struct JacRider { JacArgs j; DeviceAE A; int first_block, blocks; };
 __device__ __forceinline__ bool jac_rider_block(const JacRider &r, float *lds) {
     if (r.blocks == 0 || (int)blockIdx.x < r.first_block || (int)blockIdx.x >= r.first_block + r.blocks) return false;
     const int g = blockIdx.x - r.first_block;
+    GA_STAMP(3, 0);
     encoder_jac_block<false>(r.A, r.j, lds, g % (128 / JAC_ROWS), g / (128 / JAC_ROWS));
+    GA_STAMP(3, 7);
     return true;
 }
 

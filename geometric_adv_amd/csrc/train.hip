@@ -112,8 +112,11 @@ __global__ __launch_bounds__(TR_THREADS) void train_fwd_kernel(FwdArgs A) {
     float *tile = lds;                                   // [64][CIN + 4]
     float2 *red = reinterpret_cast<float2 *>(lds + TR_ROWS * (CIN + 4));   // [2][COUT]
     const size_t row0 = (size_t)blockIdx.x * TR_ROWS;
+    [[maybe_unused]] constexpr int SK = (CIN == 128 && COUT == 256) ? 0 : (CIN == 256 ? 1 : (CIN == 128 ? 2 : 3));   // stamp slot (diagnostic builds)
+    GA_STAMP(SK, 0);
     load_activated_tile<CIN>(A.in, row0, A.pscale, A.pshift, tile);
     __syncthreads();
+    GA_STAMP(SK, 1);
     const int col = layer_gemm_lane_col<TR_ROWS, COUT>();
     const float b = A.bias[col];
     float s1 = 0.f, s2 = 0.f;
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(TR_THREADS) void train_fwd_kernel(FwdArgs A) {
         s2 = fmaf(a, a, s2);
         rb_seen = row >> 5;
     });
+    GA_STAMP(SK, 2);
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     constexpr bool BOTH = (COUT / 32) * 2 > 8;            // one wave covers both row blocks (COUT = 256)
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(TR_THREADS) void train_fwd_kernel(FwdArgs A) {
             A.psum[(size_t)blockIdx.x * COUT + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
         }
     }
+    GA_STAMP(SK, 7);
 }
 
 // Batch statistics of one layer from the per-tile partials (fixed order, double), the folded BN constants,
@@ -658,14 +663,22 @@ __global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs 
         for (int m = 0; m < S::MBW; ++m) { hs[m] = A.pscale[(mb0 + m) * 32 + li]; hsh[m] = A.pshift[(mb0 + m) * 32 + li]; }
         float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
+        if (CIN == 128 && COUT == 256) GA_STAMP(4, 0);
+        // Tile order: workgroup w takes the 64-row tiles w, w + nw, ... (as two 32-row halves each).  The data-gradient
+        // workgroup of 64-row tile t is block nw + t; with nw a multiple of 8 both sit on XCD t % 8 (workgroups are dealt
+        // round-robin over the XCDs) and reach tile t at about the same time, so the second read of dy_i / a_i / a_{i-1}
+        // is served by that XCD's L2: FETCH_SIZE of the <128, 256> launch 570 -> 390 MiB (the launch is not bound by it: same time).
         const int tiles32 = A.tiles * 2;
-        for (int tile = blockIdx.x; tile < tiles32; tile += nw) {
+        for (int it = 0;; ++it) {
+            const int tile = 2 * (blockIdx.x + (it >> 1) * nw) + (it & 1);
+            if (tile >= tiles32) break;
             const size_t row0 = (size_t)tile * ROWS;
             load_da_tile<COUT, ROWS>(A, row0, cc, da, dbacc);
             // h = relu(a_{i-1} * s + t) once per element on the way into LDS, not once per use in the MFMA loop (every
             // element feeds COUT / 64 waves, and VALU instructions in that loop cost matrix-pipe time): same arithmetic
             load_activated_tile<CIN, ROWS>(A.aprev, row0, A.pscale, A.pshift, ht);
             __syncthreads();
+            if (CIN == 128 && COUT == 256 && it == 0) GA_STAMP(4, 1);
 #pragma unroll 8
             for (int kk = 0; kk < ROWS / 2; ++kk) {
                 const int row = 2 * kk + hh;
@@ -681,7 +694,10 @@ __global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs 
                         dw[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], dw[m][n], 0, 0, 0);
             }
             __syncthreads();
+            if (CIN == 128 && COUT == 256 && it == 0) GA_STAMP(4, 2);
+            if (CIN == 128 && COUT == 256 && it == 1) GA_STAMP(4, 3);
         }
+        if (CIN == 128 && COUT == 256) GA_STAMP(4, 4);
         float *dst = A.dw_partial + (size_t)blockIdx.x * CIN * COUT;
 #pragma unroll
         for (int m = 0; m < S::MBW; ++m)
@@ -700,6 +716,7 @@ __global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs 
             for (int g = 1; g < G; ++g) s += dbred[g * COUT + threadIdx.x];
             A.db_partial[(size_t)blockIdx.x * COUT + threadIdx.x] = s;
         }
+        if (CIN == 128 && COUT == 256) GA_STAMP(4, 7);
         return;
     }
     // ---------------- data-gradient workgroup: one 64-row tile ----------------
@@ -716,8 +733,10 @@ __global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs 
     const size_t row0 = (size_t)tile * ROWS;
     float4 unused = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    if (CIN == 128 && COUT == 256) GA_STAMP(5, 0);
     load_da_tile<COUT, ROWS>(A, row0, cc, da, unused);
     __syncthreads();
+    if (CIN == 128 && COUT == 256) GA_STAMP(5, 1);
     float q1 = 0.f, q2 = 0.f;
     int rb_seen = 0;
     bool ran = false;
@@ -730,6 +749,7 @@ __global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs 
         rb_seen = row >> 5;
         ran = true;
     });
+    if (CIN == 128 && COUT == 256) GA_STAMP(5, 2);
     if (ran) {   // all a_{i-1} values of this lane first (L2: the weight-gradient workgroups stream the same rows), then the stores
 #pragma unroll
         for (int j = 0; j < NV; ++j) apv[j] = A.aprev[(row0 + rows[j]) * CIN + ocol];
@@ -755,6 +775,7 @@ __global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs 
             A.qsum_out[(size_t)tile * CIN + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
         }
     }
+    if (CIN == 128 && COUT == 256) GA_STAMP(5, 7);
 }
 
 // layer 0: dW0[k][c] = sum_r x[r][k] * da0[r][c], db0[c] = sum_r da0[r][c]; persistent, thread = (column, 8-row group)
@@ -1366,3 +1387,4 @@ extern "C" int geoadv_trainer_layout(const geoadv_trainer *t, size_t *offsets26)
     for (int k = 0; k < 3; ++k) { offsets26[20 + k] = t->L.v[k]; offsets26[23 + k] = t->L.c[k]; }
     return GEOADV_OK;
 }
+GA_STAMPS_GETTER(geoadv_debug_stamps_train)

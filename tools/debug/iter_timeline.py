@@ -1,7 +1,7 @@
 """Timeline of ONE attack iteration from in-kernel stamps (diagnostic build: bash tools/debug/build_variants.sh all stamps:-DGA_STAMPS,
 swapped in by tools/debug/ab_cmd.sh).  Per kernel: when its first / last workgroup started and ended (us, 100 MHz s_memrealtime,
 relative to the first stamp of the iteration) and the median time between its phase stamps.
-    python tools/debug/iter_timeline.py B [N]"""
+    python tools/debug/iter_timeline.py B [N]          (GEOADV_TOOL_CFG='{"chamfer_kernel": "symmetric"}' overrides Configuration fields)"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -12,14 +12,14 @@ B = int(sys.argv[1]); N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 rng = np.random.default_rng(B)
 x = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5); gt = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)
 w = W.synthetic_weights(N, seed=7); ae = PointNetAE(w, N)
-at = AdvAE("a", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=400, num_iterations_thresh=10**6), ae=ae)
+at = AdvAE("a", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=400, num_iterations_thresh=10**6, **json.loads(os.environ.get("GEOADV_TOOL_CFG", "{}"))), ae=ae)
 at.set_inputs(x, gt, ae.transform(gt), 1.0); at.init_pert(None, reset_optimizer=True)
 at.run(0, 60, 10**6)
 torch.cuda.synchronize()
 NB = 1024
 names = {"decoder": {0: "latent_decode", 1: "grid_search blocks (in latent_decode)", 2: "decoder_fc2", 3: "decoder_fc2_bwd", 4: "decoder_bwd_tail"},
-         "encoder": {0: "encoder_fwd", 1: "encoder_bwd (masked blocks)", 2: "encoder_jac"}, "chamfer": {0: "chamfer_scan"},
-         "chamfer_sym": {0: "chamfer_sym", 1: "grid_search blocks (in chamfer_sym)", 2: "chamfer_sym_finish"}, "attack": {0: "loss_cgrad (all blocks)", 1: "loss_cgrad: gradient blocks"}}
+         "encoder": {0: "encoder_fwd", 1: "encoder_bwd blocks (masked / dense)", 2: "encoder_jac", 4: "decoder_bwd_tail blocks (in tail+dense)"}, "chamfer": {0: "chamfer_scan"},
+         "chamfer_sym": {0: "chamfer_sym", 1: "grid_search blocks (in chamfer_sym)", 2: "chamfer_sym_finish", 3: "pool Jacobian blocks (in chamfer_sym)"}, "attack": {0: "loss_cgrad (all blocks)", 1: "loss_cgrad: gradient blocks"}}
 rows = []
 for tu, slots in names.items():
     buf = (C.c_ulonglong * (8 * NB * 8))()
