@@ -28,7 +28,7 @@ python3 tools/pmc_summary.py --hash chamfer_sym.hip,chamfer_grid.h "$OUT"/loop_*
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/emd_1" -- python3 tools/emd_attack_time.py 32 > "$OUT/emd_1.log" 2>&1
 python3 tools/pmc_summary.py --hash emd.hip "$OUT"/emd_1 > "$OUT/${R}_pmc_emd.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- $BENCH > "$OUT/bench_stats.log" 2>&1
-cp "$OUT"/bench_stats/*/*_kernel_stats.csv "$OUT/${R}_bench_kernel_stats.csv" 2>/dev/null
+cp "$(grep -l encoder_fwd2 "$OUT"/bench_stats/*/*_kernel_stats.csv | head -1)" "$OUT/${R}_bench_kernel_stats.csv" 2>/dev/null   # (the RCCL self-test child writes a file of its own)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/loop_stats" -- $LOOP > "$OUT/loop_stats.log" 2>&1
-cp "$OUT"/loop_stats/*/*_kernel_stats.csv "$OUT/${R}_loop_b32_kernel_stats.csv" 2>/dev/null
+cp "$(grep -l encoder_fwd2 "$OUT"/loop_stats/*/*_kernel_stats.csv | head -1)" "$OUT/${R}_loop_b32_kernel_stats.csv" 2>/dev/null
 tail -2 "$OUT/bench_stats.log"
