@@ -778,6 +778,229 @@ __global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs 
     if (CIN == 128 && COUT == 256) GA_STAMP(5, 7);
 }
 
+// One backward layer as ONE kind of workgroup (16 waves, one per CU, persistent over 32-row tiles): the split form above
+// stages every tile twice -- once for the weight gradient, once for the data gradient -- and both of its workgroup kinds
+// leave the matrix pipe idle while they wait for their own loads (in-kernel stamps: a weight-gradient workgroup spends 12.5 us
+// per 32-row tile of which ~3.5 are MFMAs; a data-gradient workgroup 6.0 us loading, 14.3 multiplying (weight ring starved at
+// one row block per fragment), 5.4 storing).  Here
+//   waves 8-15 ("W"): stage the tile -- da = f(dy, a), h = relu(BN(a_prev)), raw a_prev -- and accumulate dW += h^T @ da in
+//                     registers.  Their MFMA loop reads LDS only, so the NEXT tile's global loads are issued before it and
+//                     land in registers while both halves multiply (vmcnt retires in order: the data-gradient waves could
+//                     not do that, their weight-fragment waits would wait for the tile too);
+//   waves 0-7 ("X"):  dy_prev = (da @ W^T) * [h > 0] with the BN sums of the layer below, K split over the waves so that all
+//                     eight work on a 32-row tile.
+// Two barriers per tile: B (every LDS read of the tile is done; X's K partials are in scratch) and A (the next tile is in LDS).
+// Between B and A the W waves write the staged tile while the X waves finish their epilogue from registers.
+// Tiles are dealt round-robin (tile = workgroup + k * workgroups): a workgroup's dW partial sums over a fixed set of tiles in
+// a fixed order, so the step stays deterministic.
+// XW = number of X waves: 8 (16 waves, 128 VGPRs each) where the W waves' 64 accumulator + 40 staging registers leave room,
+// 4 (12 waves, 168 VGPRs) for the two wide layers, where they do not (54 / 81 spilled registers made those launches slower
+// than the split form); an X wave then owns a whole K chain (and two column blocks at CIN = 256).
+constexpr int BF_ROWS = 32, BF_WTHREADS = 512;
+template <int CIN, int COUT> struct FusedShape {
+    static constexpr int MB = CIN / 32, NB = COUT / 32;
+    static constexpr int MBW = (MB * NB >= 32) ? 2 : 1, NBW = (MB * NB >= 16) ? 2 : 1, WCOLS = NB / NBW;
+    static_assert((MB / MBW) * (NB / NBW) == 8, "dW blocks must map onto 8 waves");
+    static constexpr int XW = (MB * NB >= 32) ? 4 : 8;                     // X waves
+    static constexpr int THREADS = (XW + 8) * 64;
+    static constexpr int UNITS = MB;                                       // X: column blocks of dy_prev
+    static constexpr int CPW = UNITS >= XW ? UNITS / XW : 1, KC = UNITS >= XW ? 1 : XW / UNITS;   // column blocks per wave / K parts
+    static_assert((COUT / 8 / KC) % 4 == 0, "bad K split");
+    static constexpr int DA_FLOATS = BF_ROWS * (COUT + 4), H_FLOATS = BF_ROWS * (CIN + 4);
+    static constexpr int TILE_FLOATS = DA_FLOATS + 2 * H_FLOATS;           // one staged tile: da, h = relu(BN(a_prev)), raw a_prev
+    static constexpr int SCRATCH_FLOATS = (KC - 1) * UNITS * 16 * 64, CC_FLOATS = 5 * COUT;
+    static_assert(DA_FLOATS >= (BF_WTHREADS / (COUT / 4)) * COUT, "bias-gradient reduction aliases the da tile");
+    // two tile buffers where they fit (all but CIN = 256): the W waves then stage tile k + 1 while tile k is still being read
+    // and a tile costs ONE barrier; with one buffer they stage between two barriers
+    static constexpr bool DB = sizeof(float) * (2 * TILE_FLOATS + SCRATCH_FLOATS + CC_FLOATS) <= 160 * 1024;
+    static constexpr size_t lds_bytes = sizeof(float) * ((DB ? 2 : 1) * TILE_FLOATS + SCRATCH_FLOATS + CC_FLOATS);
+    // staging: float4s per W thread and tile
+    static constexpr int QO = COUT / 4, SO = BF_WTHREADS / QO, NO = BF_ROWS / SO;      // dy, a
+    static constexpr int QI = CIN / 4, SI = BF_WTHREADS / QI, NI = (BF_ROWS + SI - 1) / SI;   // a_prev (CIN = 64: one pass covers the 32 rows)
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__((FusedShape<CIN, COUT>::THREADS)) void train_bwd_fused_kernel(BwdArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    using S = FusedShape<CIN, COUT>;
+    float *scratch = lds + (S::DB ? 2 : 1) * S::TILE_FLOATS, *cc = scratch + S::SCRATCH_FLOATS;   // tile buffer b at lds + b * TILE_FLOATS: da, h, raw a_prev
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int hh = lane >> 5, li = lane & 31;
+    const int tiles32 = A.tiles * (64 / BF_ROWS), G = gridDim.x;
+    for (int e = threadIdx.x; e < COUT; e += S::THREADS) {
+        cc[e] = A.mean[e]; cc[COUT + e] = A.inv_std[e]; cc[2 * COUT + e] = A.gamma[e] * A.inv_std[e];
+        cc[3 * COUT + e] = A.m1[e]; cc[4 * COUT + e] = A.m2[e];
+    }
+    __syncthreads();
+    if (wave >= S::XW) {
+        // ---------------- W waves: staging + weight gradient ----------------
+        const int tw = threadIdx.x - S::XW * 64;
+        const int oc4 = tw % S::QO, or0 = tw / S::QO, ic4 = tw % S::QI, ir0 = tw / S::QI;
+        const int w8 = wave - S::XW, mb0 = (w8 / S::WCOLS) * S::MBW, nb0 = (w8 % S::WCOLS) * S::NBW;
+        // h = relu(a_prev * s + t) once per element on the way into LDS, not once per use in the MFMA loop: VALU instructions in
+        // that loop cost matrix-pipe time (measured: 7.9 -> 10.1 us for a tile's products with the activation on the operand)
+        const float4 ps = reinterpret_cast<const float4 *>(A.pscale)[ic4], pt = reinterpret_cast<const float4 *>(A.pshift)[ic4];
+        f32x16 dw[S::MBW][S::NBW] = {};
+        float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 rdy[S::NO], ra[S::NO], rp[S::NI];
+        auto request = [&](int tile) {
+            const size_t row0 = (size_t)tile * BF_ROWS;
+#pragma unroll
+            for (int j = 0; j < S::NO; ++j) {
+                rdy[j] = reinterpret_cast<const float4 *>(A.dy + (row0 + or0 + j * S::SO) * COUT)[oc4];
+                ra[j] = reinterpret_cast<const float4 *>(A.a + (row0 + or0 + j * S::SO) * COUT)[oc4];
+            }
+#pragma unroll
+            for (int j = 0; j < S::NI; ++j)
+                if (ir0 + j * S::SI < BF_ROWS) rp[j] = reinterpret_cast<const float4 *>(A.aprev + (row0 + ir0 + j * S::SI) * CIN)[ic4];
+        };
+        auto stage = [&](float *da) {
+            float *ht = da + S::DA_FLOATS, *araw = ht + S::H_FLOATS;
+            const float4 mu = reinterpret_cast<const float4 *>(cc)[oc4], is = reinterpret_cast<const float4 *>(cc + COUT)[oc4];
+            const float4 gi = reinterpret_cast<const float4 *>(cc + 2 * COUT)[oc4];
+            const float4 m1 = reinterpret_cast<const float4 *>(cc + 3 * COUT)[oc4], m2 = reinterpret_cast<const float4 *>(cc + 4 * COUT)[oc4];
+#pragma unroll
+            for (int j = 0; j < S::NO; ++j) {
+                const float4 d = rdy[j], a = ra[j];
+                float4 o;
+                o.x = gi.x * ((d.x - m1.x) - (a.x - mu.x) * is.x * m2.x); o.y = gi.y * ((d.y - m1.y) - (a.y - mu.y) * is.y * m2.y);
+                o.z = gi.z * ((d.z - m1.z) - (a.z - mu.z) * is.z * m2.z); o.w = gi.w * ((d.w - m1.w) - (a.w - mu.w) * is.w * m2.w);
+                *reinterpret_cast<float4 *>(da + (or0 + j * S::SO) * (COUT + 4) + 4 * oc4) = o;
+                dbacc.x += o.x; dbacc.y += o.y; dbacc.z += o.z; dbacc.w += o.w;
+            }
+#pragma unroll
+            for (int j = 0; j < S::NI; ++j) {
+                if (ir0 + j * S::SI >= BF_ROWS) continue;
+                const float4 v = rp[j];
+                float4 h;
+                h.x = fmaxf(fmaf(v.x, ps.x, pt.x), 0.f); h.y = fmaxf(fmaf(v.y, ps.y, pt.y), 0.f);
+                h.z = fmaxf(fmaf(v.z, ps.z, pt.z), 0.f); h.w = fmaxf(fmaf(v.w, ps.w, pt.w), 0.f);
+                *reinterpret_cast<float4 *>(ht + (ir0 + j * S::SI) * (CIN + 4) + 4 * ic4) = h;
+                *reinterpret_cast<float4 *>(araw + (ir0 + j * S::SI) * (CIN + 4) + 4 * ic4) = v;
+            }
+        };
+        // Two buffers (DB): tile k + 1 is staged at the START of iteration k -- while the X waves' chains have the matrix pipe --
+        // from registers requested one iteration earlier, then tile k + 2 is requested, then the products of tile k: ONE barrier
+        // per tile and no phase in which nobody multiplies.  One buffer: request, products, barrier B, stage, barrier A.
+        int tile = blockIdx.x;
+        if (tile < tiles32) { request(tile); stage(lds); }
+        if (S::DB && tile + G < tiles32) request(tile + G);
+        __syncthreads();                                   // A: the first tile is in buffer 0
+        [[maybe_unused]] const bool st_on = CIN == 128 && COUT == 256;   // stamps (diagnostic builds): the second tile's phases
+        for (int it = 0; tile < tiles32; tile += G, ++it) {
+            const bool more = tile + G < tiles32;
+            if (st_on && it == 1) GA_STAMP_T(6, 0, S::XW * 64);
+            if (S::DB) {
+                if (more) stage(lds + ((it + 1) & 1) * S::TILE_FLOATS);   // the OTHER buffer: its tile was consumed before the last barrier
+                if (tile + 2 * G < tiles32) request(tile + 2 * G);
+            } else if (more) request(tile + G);
+            __builtin_amdgcn_sched_barrier(0);             // (the requests stay ahead of the products)
+            if (st_on && it == 1) GA_STAMP_T(6, 1, S::XW * 64);
+            const float *da = lds + (S::DB ? it & 1 : 0) * S::TILE_FLOATS, *ht = da + S::DA_FLOATS;
+#pragma unroll 8
+            for (int kk = 0; kk < BF_ROWS / 2; ++kk) {
+                const int row = 2 * kk + hh;
+                float av[S::MBW], bv[S::NBW];
+#pragma unroll
+                for (int m = 0; m < S::MBW; ++m) av[m] = ht[row * (CIN + 4) + (mb0 + m) * 32 + li];
+#pragma unroll
+                for (int n = 0; n < S::NBW; ++n) bv[n] = da[row * (COUT + 4) + (nb0 + n) * 32 + li];
+#pragma unroll
+                for (int m = 0; m < S::MBW; ++m)
+#pragma unroll
+                    for (int n = 0; n < S::NBW; ++n)
+                        dw[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], dw[m][n], 0, 0, 0);
+            }
+            if (st_on && it == 1) GA_STAMP_T(6, 2, S::XW * 64);
+            if (S::KC > 1 || !S::DB) __syncthreads();      // B: the X waves' K partials are in scratch / every read of the only buffer is done
+            if (!S::DB && more) stage(lds);
+            if (st_on && it == 1) GA_STAMP_T(6, 3, S::XW * 64);
+            __syncthreads();                               // A: tile it is consumed, tile it + 1 is staged
+            if (st_on && it == 1) GA_STAMP_T(6, 7, S::XW * 64);
+        }
+        float *dst = A.dw_partial + (size_t)blockIdx.x * CIN * COUT;
+#pragma unroll
+        for (int m = 0; m < S::MBW; ++m)
+#pragma unroll
+            for (int n = 0; n < S::NBW; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[(size_t)((mb0 + m) * 32 + acc_row(r, hh)) * COUT + (nb0 + n) * 32 + li] = dw[m][n][r];
+        // bias gradient: this workgroup's column sums, exchanged through the da tile (nobody reads it any more: the X waves
+        // have left the loop behind the same last barrier A, and take part in the barrier below)
+        float *dbred = lds;
+        *reinterpret_cast<float4 *>(dbred + or0 * COUT + 4 * oc4) = dbacc;
+        __syncthreads();
+        if (tw < COUT) {
+            float sacc = dbred[tw];
+#pragma unroll
+            for (int g = 1; g < S::SO; ++g) sacc += dbred[g * COUT + tw];
+            A.db_partial[(size_t)blockIdx.x * COUT + tw] = sacc;
+        }
+        return;
+    }
+    // ---------------- X waves: data gradient ----------------
+    const int unit = wave % S::UNITS, ks = S::KC > 1 ? wave / S::UNITS : 0;
+    constexpr int kg = COUT >> 3;
+    float pps[S::CPW], ppt[S::CPW], ppm[S::CPW], ppis[S::CPW];         // the previous layer's BN constants of this lane's column(s)
+#pragma unroll
+    for (int j = 0; j < S::CPW; ++j) {
+        const int oc = (S::CPW > 1 ? wave + j * S::XW : unit) * 32 + li;
+        pps[j] = A.pscale[oc]; ppt[j] = A.pshift[oc]; ppm[j] = A.pmean[oc]; ppis[j] = A.pinv_std[oc];
+    }
+    __syncthreads();                                       // A: the first tile is in LDS
+    [[maybe_unused]] const bool st_on = CIN == 128 && COUT == 256;
+    for (int tile = blockIdx.x, it = 0; tile < tiles32; tile += G, ++it) {
+        const size_t row0 = (size_t)tile * BF_ROWS;
+        if (st_on && it == 1) GA_STAMP(7, 0);
+        const float *da = lds + (S::DB ? it & 1 : 0) * S::TILE_FLOATS, *araw = da + S::DA_FLOATS + S::H_FLOATS;
+#pragma unroll
+        for (int j = 0; j < S::CPW; ++j) {
+            const int cb = S::CPW > 1 ? wave + j * S::XW : unit;
+            const int ocol = cb * 32 + li;
+            float apv[16];
+            if (ks == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) apv[r] = araw[acc_row(r, hh) * (CIN + 4) + ocol];
+            }
+            f32x16 acc[1] = {};
+            gemm_chain<1>(da, COUT + 4, 0, A.WT, cb, ks * kg / S::KC, (ks + 1) * kg / S::KC, acc);
+            if (st_on && it == 1) GA_STAMP(7, 1);
+            if (S::KC == 1 && !S::DB && j == S::CPW - 1) __syncthreads();   // B (one buffer: this wave's last read of the tile is done; the epilogue runs from registers)
+            if (S::KC > 1) {
+                if (ks > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) scratch[(((ks - 1) * S::UNITS + unit) * 16 + r) * 64 + lane] = acc[0][r];
+                }
+                __syncthreads();                           // B (KC > 1: the K partials are in scratch)
+                if (ks == 0) {
+#pragma unroll
+                    for (int p = 1; p < S::KC; ++p)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[0][r] += scratch[(((p - 1) * S::UNITS + unit) * 16 + r) * 64 + lane];
+                }
+            }
+            if (ks == 0) {
+                float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dyv = fmaf(apv[r], pps[j], ppt[j]) > 0.f ? acc[0][r] : 0.f;
+                    A.dy_out[(row0 + acc_row(r, hh)) * CIN + ocol] = dyv;
+                    q1 += dyv;
+                    q2 = fmaf(dyv, (apv[r] - ppm[j]) * ppis[j], q2);
+                }
+                q1 += __shfl_xor(q1, 32);
+                q2 += __shfl_xor(q2, 32);
+                if (hh == 0) A.qsum_out[(size_t)tile * CIN + ocol] = make_float2(q1, q2);
+            }
+        }
+        if (st_on && it == 1) GA_STAMP(7, 2);
+        __syncthreads();                                   // A
+        if (st_on && it == 1) GA_STAMP(7, 7);
+    }
+    __syncthreads();                                       // (the W waves' bias-gradient exchange)
+}
+
 // layer 0: dW0[k][c] = sum_r x[r][k] * da0[r][c], db0[c] = sum_r da0[r][c]; persistent, thread = (column, 8-row group)
 __global__ __launch_bounds__(TR_THREADS) void train_bwd0_kernel(BwdArgs A) {
     __shared__ float pts[TR_ROWS * 3];
@@ -1009,7 +1232,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
         o_act[i] = take(4 * (size_t)t->R * ENC[i + 1]);
     }
     const size_t o_dy0 = take(4 * (size_t)t->R * 256), o_dy1 = take(4 * (size_t)t->R * 256);
-    const size_t o_ps = take(8 * (size_t)t->tiles * 256), o_qs = take(8 * (size_t)(t->R / BWD_ROWS) * 256);
+    const size_t o_ps = take(8 * (size_t)t->tiles * 256), o_qs = take(8 * (size_t)(t->R / BF_ROWS) * 256);
     const size_t o_z = take(4 * (size_t)B * 128), o_cnt = take(4 * (size_t)B * 128);   // adjacent: B * 512 B is a multiple of 256
     const size_t o_d1 = take(4 * (size_t)B * 256), o_d2 = take(4 * (size_t)B * 256);
     const size_t o_rec = take(4 * (size_t)B * t->n3), o_gr = take(4 * (size_t)B * t->n3);
@@ -1121,6 +1344,15 @@ static int launch_bn(geoadv_trainer *t, int i, int mode, int slot, hipStream_t s
     return GEOADV_OK;
 }
 
+// persistent backward workgroups (one per CU) = dW / db partials per layer; rows per BN-gradient partial of the layer below
+#ifdef GEOADV_BWD_SPLIT
+static int bwd_workgroups(const geoadv_trainer *t) { return (t->R / BWD_ROWS) < t->grid_bwd ? (t->R / BWD_ROWS) : t->grid_bwd; }
+constexpr int BWD_QROWS = BWD_ROWS;
+#else
+static int bwd_workgroups(const geoadv_trainer *t) { return (t->R / BF_ROWS) < t->grid_bwd ? (t->R / BF_ROWS) : t->grid_bwd; }
+constexpr int BWD_QROWS = BF_ROWS;
+#endif
+
 template <int CIN, int COUT>
 static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, hipStream_t st) {
     BwdArgs a;
@@ -1130,7 +1362,8 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
     a.pscale = t->bn_scale[i - 1]; a.pshift = t->bn_shift[i - 1]; a.pmean = t->bn_mean[i - 1]; a.pinv_std = t->bn_istd[i - 1];
     a.WT = PackedLayer{t->packed_bwd[i], COUT, CIN};
     a.dy_out = dy_out; a.qsum_out = t->qsum; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
-    static_assert(BWD_ROWS == 64, "the split backward is built on 64-row data-gradient tiles");
+    static_assert(BWD_ROWS == 64, "BwdArgs::tiles counts 64-row tiles");
+#ifdef GEOADV_BWD_SPLIT
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_split_kernel<CIN, COUT>),
@@ -1139,6 +1372,16 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
         })) return rc;
     const int grid = a.tiles < t->grid_bwd ? a.tiles : t->grid_bwd;
     train_bwd_split_kernel<CIN, COUT><<<grid + a.tiles, TR_THREADS, SplitShape<CIN, COUT>::lds_bytes, st>>>(a, grid);
+#else
+    using S = FusedShape<CIN, COUT>;
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_fused_kernel<CIN, COUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes));
+            return GEOADV_OK;
+        })) return rc;
+    train_bwd_fused_kernel<CIN, COUT><<<bwd_workgroups(t), S::THREADS, S::lds_bytes, st>>>(a);
+#endif
     GA_LAUNCH_CHECK();
     return GEOADV_OK;                                   // its partials are reduced by post_layer (next launch)
 }
@@ -1159,12 +1402,12 @@ static int launch_bn_bwd(geoadv_trainer *t, int i, int partial_rows, int mode, i
 
 // after the backward kernel of layer i (>= 1): BN-gradient sums of layer i - 1 (mode as in BnBwdArgs) + dW_i + db_i
 static int launch_post_layer(geoadv_trainer *t, int i, int mode, int slot, hipStream_t st) {
-    const int parts = (t->R / BWD_ROWS) < t->grid_bwd ? (t->R / BWD_ROWS) : t->grid_bwd;
+    const int parts = bwd_workgroups(t);
     const size_t cnt = (size_t)ENC[i] * ENC[i + 1];
     const ReduceArgs dw{t->dw_partial, parts, cnt, t->grads + t->L.w[i]};
     const ReduceArgs db{t->db_partial, parts, (size_t)ENC[i + 1], t->grads + t->L.b[i]};
     const int bn_blocks = ENC[i] / 32, dw_blocks = (int)((cnt + 255) / 256), db_blocks = cdiv(ENC[i + 1], 256);
-    post_layer_kernel<<<bn_blocks + dw_blocks + db_blocks, 1024, 0, st>>>(bn_bwd_args(t, i - 1, BWD_ROWS, mode, slot), bn_blocks, dw,
+    post_layer_kernel<<<bn_blocks + dw_blocks + db_blocks, 1024, 0, st>>>(bn_bwd_args(t, i - 1, BWD_QROWS, mode, slot), bn_blocks, dw,
                                                                          dw_blocks, db);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
@@ -1253,7 +1496,7 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
     if (phase <= 9) {
         const int i = 10 - phase;                                  // layer whose backward runs: 4, 3, 2, 1
         if (sync)
-            if (int rc = launch_bn_bwd(t, i, i == 4 ? TR_ROWS : BWD_ROWS, 2, phase - 1, st)) return rc;
+            if (int rc = launch_bn_bwd(t, i, i == 4 ? TR_ROWS : BWD_QROWS, 2, phase - 1, st)) return rc;
         int rc;
         if (i == 4) rc = launch_bwd<256, 128>(t, 4, t->dybuf[0], t->dybuf[1], st);
         else if (i == 3) rc = launch_bwd<128, 256>(t, 3, t->dybuf[1], t->dybuf[0], st);
@@ -1263,7 +1506,7 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         return launch_post_layer(t, i, end_mode, phase, st);
     }
     if (sync)
-        if (int rc = launch_bn_bwd(t, 0, BWD_ROWS, 2, 9, st)) return rc;
+        if (int rc = launch_bn_bwd(t, 0, BWD_QROWS, 2, 9, st)) return rc;
     BwdArgs a = {};
     a.tiles = t->tiles; a.dy = t->dybuf[0]; a.a = t->act[0];
     a.mean = t->bn_mean[0]; a.inv_std = t->bn_istd[0]; a.gamma = t->params + t->L.gamma[0]; a.m1 = t->bn_m1[0]; a.m2 = t->bn_m2[0];
