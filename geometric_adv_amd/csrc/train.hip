@@ -96,16 +96,6 @@ __device__ __forceinline__ void load_activated_tile(const float *a, size_t row0,
     }
 }
 
-// raw tile -> LDS [ROWS][C + 4]
-template <int C, int ROWS>
-__device__ __forceinline__ void load_raw_tile(const float *a, size_t row0, float *lds) {
-    constexpr int Q = C / 4;
-    const int c4 = threadIdx.x % Q, r0 = threadIdx.x / Q;
-#pragma unroll
-    for (int r = r0; r < ROWS; r += TR_THREADS / Q)
-        *reinterpret_cast<float4 *>(lds + r * (C + 4) + 4 * c4) = reinterpret_cast<const float4 *>(a + (row0 + r) * C)[c4];
-}
-
 template <int CIN, int COUT>
 __global__ __launch_bounds__(TR_THREADS) void train_fwd_kernel(FwdArgs A) {
     extern __shared__ __align__(16) float lds[];
@@ -586,216 +576,32 @@ struct BwdArgs {
     float *db_partial;               // [grid][COUT]
 };
 
-// da tile = gamma * inv_std * (dy - m1 - xhat * m2), xhat = (a - mean) * inv_std -> LDS [64][C + 4]; returns this
-// thread's column sums (bias gradient; mathematically zero behind a BN, kept because TF computes it)
-template <int C, int ROWS>
-__device__ __forceinline__ void load_da_tile(const BwdArgs &A, size_t row0, const float *cc /*LDS [5][C]*/, float *lds, float4 &dbacc) {
-    constexpr int Q = C / 4;
-    const int c4 = threadIdx.x % Q, r0 = threadIdx.x / Q;
-    const float4 mu = reinterpret_cast<const float4 *>(cc)[c4], is = reinterpret_cast<const float4 *>(cc + C)[c4];
-    const float4 gi = reinterpret_cast<const float4 *>(cc + 2 * C)[c4];
-    const float4 m1 = reinterpret_cast<const float4 *>(cc + 3 * C)[c4], m2 = reinterpret_cast<const float4 *>(cc + 4 * C)[c4];
-#pragma unroll
-    for (int r = r0; r < ROWS; r += TR_THREADS / Q) {
-        const float4 d = reinterpret_cast<const float4 *>(A.dy + (row0 + r) * C)[c4];
-        const float4 a = reinterpret_cast<const float4 *>(A.a + (row0 + r) * C)[c4];
-        float4 o;
-        o.x = gi.x * ((d.x - m1.x) - (a.x - mu.x) * is.x * m2.x); o.y = gi.y * ((d.y - m1.y) - (a.y - mu.y) * is.y * m2.y);
-        o.z = gi.z * ((d.z - m1.z) - (a.z - mu.z) * is.z * m2.z); o.w = gi.w * ((d.w - m1.w) - (a.w - mu.w) * is.w * m2.w);
-        *reinterpret_cast<float4 *>(lds + r * (C + 4) + 4 * c4) = o;
-        dbacc.x += o.x; dbacc.y += o.y; dbacc.z += o.z; dbacc.w += o.w;
-    }
-}
-
-// ROWS = 32: two workgroups share a CU (one loads / stores while the other runs its MFMA chains); the tile is one
-// row block high, so every dy_out column lives in exactly one wave.
-constexpr int BWD_ROWS = 64;     // measured: 32-row tiles (two workgroups per CU, 128 VGPRs) are 10-20 % slower
-
-template <int CIN, int COUT, int ROWS> struct BwdShape {
-    static constexpr int MB = CIN / 32, NB = COUT / 32;
-    static constexpr int MBW = (MB * NB >= 32) ? 2 : 1;                 // blocks of dW per wave: MBW x NBW
-    static constexpr int NBW = (MB * NB >= 16) ? 2 : 1;
-    static constexpr int WCOLS = NB / NBW;                                // waves along the COUT axis
-    static_assert((MB / MBW) * (NB / NBW) == 8, "dW blocks must map onto 8 waves");
-    static constexpr int DA_FLOATS = ROWS * (COUT + 4), H_FLOATS = ROWS * (CIN + 4);
-    static constexpr int UNITS = (MB * (ROWS / 32) > 8) ? MB : MB * (ROWS / 32);      // of layer_gemm<ROWS, CIN, 0>
-    static constexpr int KC = 8 / UNITS;
-    static constexpr int SCRATCH_FLOATS = (KC - 1) * UNITS * 16 * 64;     // K-part hand-off
-    static constexpr int CC_FLOATS = 5 * COUT;
-    static constexpr int RED_FLOATS = 4 * CIN;                            // qsum [2][CIN] float2 (64-row tiles)
-    static_assert(DA_FLOATS >= (TR_THREADS / (COUT / 4)) * COUT, "bias-gradient reduction aliases the da tile");
-    static constexpr size_t lds_bytes = sizeof(float) * (DA_FLOATS + H_FLOATS + SCRATCH_FLOATS + CC_FLOATS + RED_FLOATS);
-};
-
-// One backward layer as TWO kinds of workgroups in one launch, so that a CU holds one of each and their phases overlap
-// (a single fused 115 KB workgroup per CU would run tile loads, the dW GEMM, the dy GEMM and the epilogue strictly one after
-// the other):
-//   blocks [0, nw)      : weight gradient only -- persistent over 32-row tiles, dW accumulated in registers (64 VGPRs);
-//   blocks [nw, nw + T) : data gradient only -- one 64-row tile each: da @ W^T, ReLU mask, dy_{i-1} and its BN sums.
-// Both form da = f(dy, a) on load, i.e. dy_i and a_i are read twice (+ 2 * 4 * R * COUT bytes of HBM traffic per layer); that
-// buys two resident workgroups per CU (<= 128 VGPRs, <= 74 KB LDS each) and a shared MFMA pipe that rarely idles.
-template <int CIN, int COUT> struct SplitShape {
-    using W32 = BwdShape<CIN, COUT, 32>;
-    using D64 = BwdShape<CIN, COUT, 64>;
-    static constexpr int W_FLOATS = W32::DA_FLOATS + W32::H_FLOATS + W32::CC_FLOATS;
-    static constexpr int D_FLOATS = D64::DA_FLOATS + D64::SCRATCH_FLOATS + D64::CC_FLOATS + D64::RED_FLOATS;
-    static constexpr size_t lds_bytes = sizeof(float) * (W_FLOATS > D_FLOATS ? W_FLOATS : D_FLOATS);
-};
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__(TR_THREADS, 4) void train_bwd_split_kernel(BwdArgs A, int nw) {
-    extern __shared__ __align__(16) float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int hh = lane >> 5, li = lane & 31;
-    if ((int)blockIdx.x < nw) {
-        // ---------------- weight-gradient workgroup ----------------
-        using S = BwdShape<CIN, COUT, 32>;
-        constexpr int ROWS = 32;
-        float *da = lds, *ht = da + S::DA_FLOATS, *cc = ht + S::H_FLOATS;
-        for (int e = threadIdx.x; e < COUT; e += TR_THREADS) {
-            cc[e] = A.mean[e]; cc[COUT + e] = A.inv_std[e]; cc[2 * COUT + e] = A.gamma[e] * A.inv_std[e];
-            cc[3 * COUT + e] = A.m1[e]; cc[4 * COUT + e] = A.m2[e];
-        }
-        const int mb0 = (wave / S::WCOLS) * S::MBW, nb0 = (wave % S::WCOLS) * S::NBW;
-        f32x16 dw[S::MBW][S::NBW] = {};
-        float hs[S::MBW], hsh[S::MBW];
-#pragma unroll
-        for (int m = 0; m < S::MBW; ++m) { hs[m] = A.pscale[(mb0 + m) * 32 + li]; hsh[m] = A.pshift[(mb0 + m) * 32 + li]; }
-        float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        if (CIN == 128 && COUT == 256) GA_STAMP(4, 0);
-        // Tile order: workgroup w takes the 64-row tiles w, w + nw, ... (as two 32-row halves each).  The data-gradient
-        // workgroup of 64-row tile t is block nw + t; with nw a multiple of 8 both sit on XCD t % 8 (workgroups are dealt
-        // round-robin over the XCDs) and reach tile t at about the same time, so the second read of dy_i / a_i / a_{i-1}
-        // is served by that XCD's L2: FETCH_SIZE of the <128, 256> launch 570 -> 390 MiB (the launch is not bound by it: same time).
-        const int tiles32 = A.tiles * 2;
-        for (int it = 0;; ++it) {
-            const int tile = 2 * (blockIdx.x + (it >> 1) * nw) + (it & 1);
-            if (tile >= tiles32) break;
-            const size_t row0 = (size_t)tile * ROWS;
-            load_da_tile<COUT, ROWS>(A, row0, cc, da, dbacc);
-            // h = relu(a_{i-1} * s + t) once per element on the way into LDS, not once per use in the MFMA loop (every
-            // element feeds COUT / 64 waves, and VALU instructions in that loop cost matrix-pipe time): same arithmetic
-            load_activated_tile<CIN, ROWS>(A.aprev, row0, A.pscale, A.pshift, ht);
-            __syncthreads();
-            if (CIN == 128 && COUT == 256 && it == 0) GA_STAMP(4, 1);
-#pragma unroll 8
-            for (int kk = 0; kk < ROWS / 2; ++kk) {
-                const int row = 2 * kk + hh;
-                float av[S::MBW], bv[S::NBW];
-#pragma unroll
-                for (int m = 0; m < S::MBW; ++m) av[m] = ht[row * (CIN + 4) + (mb0 + m) * 32 + li];
-#pragma unroll
-                for (int n = 0; n < S::NBW; ++n) bv[n] = da[row * (COUT + 4) + (nb0 + n) * 32 + li];
-#pragma unroll
-                for (int m = 0; m < S::MBW; ++m)
-#pragma unroll
-                    for (int n = 0; n < S::NBW; ++n)
-                        dw[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], dw[m][n], 0, 0, 0);
-            }
-            __syncthreads();
-            if (CIN == 128 && COUT == 256 && it == 0) GA_STAMP(4, 2);
-            if (CIN == 128 && COUT == 256 && it == 1) GA_STAMP(4, 3);
-        }
-        if (CIN == 128 && COUT == 256) GA_STAMP(4, 4);
-        float *dst = A.dw_partial + (size_t)blockIdx.x * CIN * COUT;
-#pragma unroll
-        for (int m = 0; m < S::MBW; ++m)
-#pragma unroll
-            for (int n = 0; n < S::NBW; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dst[(size_t)((mb0 + m) * 32 + acc_row(r, hh)) * COUT + (nb0 + n) * 32 + li] = dw[m][n][r];
-        constexpr int Q = COUT / 4, G = TR_THREADS / Q;
-        float *dbred = da;
-        *reinterpret_cast<float4 *>(dbred + (threadIdx.x / Q) * COUT + 4 * (threadIdx.x % Q)) = dbacc;
-        __syncthreads();
-        if (threadIdx.x < COUT) {
-            float s = dbred[threadIdx.x];
-#pragma unroll
-            for (int g = 1; g < G; ++g) s += dbred[g * COUT + threadIdx.x];
-            A.db_partial[(size_t)blockIdx.x * COUT + threadIdx.x] = s;
-        }
-        if (CIN == 128 && COUT == 256) GA_STAMP(4, 7);
-        return;
-    }
-    // ---------------- data-gradient workgroup: one 64-row tile ----------------
-    using S = BwdShape<CIN, COUT, 64>;
-    constexpr int ROWS = 64;
-    float *da = lds, *scratch = da + S::DA_FLOATS, *cc = scratch + S::SCRATCH_FLOATS, *red = cc + S::CC_FLOATS;
-    for (int e = threadIdx.x; e < COUT; e += TR_THREADS) {
-        cc[e] = A.mean[e]; cc[COUT + e] = A.inv_std[e]; cc[2 * COUT + e] = A.gamma[e] * A.inv_std[e];
-        cc[3 * COUT + e] = A.m1[e]; cc[4 * COUT + e] = A.m2[e];
-    }
-    const int ocol = layer_gemm_lane_col<ROWS, CIN>();
-    const float ps = A.pscale[ocol], pt = A.pshift[ocol], pm = A.pmean[ocol], pis = A.pinv_std[ocol];
-    const int tile = blockIdx.x - nw;
-    const size_t row0 = (size_t)tile * ROWS;
-    float4 unused = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    if (CIN == 128 && COUT == 256) GA_STAMP(5, 0);
-    load_da_tile<COUT, ROWS>(A, row0, cc, da, unused);
-    __syncthreads();
-    if (CIN == 128 && COUT == 256) GA_STAMP(5, 1);
-    float q1 = 0.f, q2 = 0.f;
-    int rb_seen = 0;
-    bool ran = false;
-    constexpr int NV = (CIN / 32) * (ROWS / 32) > 8 ? 32 : 16;
-    float vals[NV], apv[NV];
-    int rows[NV];
-    int cnt = 0;
-    layer_gemm<ROWS, CIN, 0>(da, COUT + 4, A.WT, scratch, [&](int row, int c, float v) {
-        vals[cnt] = v; rows[cnt] = row; ++cnt;
-        rb_seen = row >> 5;
-        ran = true;
-    });
-    if (CIN == 128 && COUT == 256) GA_STAMP(5, 2);
-    if (ran) {   // all a_{i-1} values of this lane first (L2: the weight-gradient workgroups stream the same rows), then the stores
-#pragma unroll
-        for (int j = 0; j < NV; ++j) apv[j] = A.aprev[(row0 + rows[j]) * CIN + ocol];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const float dyv = fmaf(apv[j], ps, pt) > 0.f ? vals[j] : 0.f;
-            A.dy_out[(row0 + rows[j]) * CIN + ocol] = dyv;
-            q1 += dyv;
-            q2 = fmaf(dyv, (apv[j] - pm) * pis, q2);
-        }
-    }
-    q1 += __shfl_xor(q1, 32);
-    q2 += __shfl_xor(q2, 32);
-    constexpr bool WHOLE = (CIN / 32) * 2 > 8;
-    float2 *qred = reinterpret_cast<float2 *>(red);
-    if (WHOLE) {
-        if (ran && hh == 0) A.qsum_out[(size_t)tile * CIN + ocol] = make_float2(q1, q2);
-    } else {
-        if (ran && hh == 0) qred[rb_seen * CIN + ocol] = make_float2(q1, q2);
-        __syncthreads();
-        if (threadIdx.x < CIN) {
-            const float2 p = qred[threadIdx.x], q = qred[CIN + threadIdx.x];
-            A.qsum_out[(size_t)tile * CIN + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
-        }
-    }
-    if (CIN == 128 && COUT == 256) GA_STAMP(5, 7);
-}
-
-// One backward layer as ONE kind of workgroup (16 waves, one per CU, persistent over 32-row tiles): the split form above
-// stages every tile twice -- once for the weight gradient, once for the data gradient -- and both of its workgroup kinds
-// leave the matrix pipe idle while they wait for their own loads (in-kernel stamps: a weight-gradient workgroup spends 12.5 us
-// per 32-row tile of which ~3.5 are MFMAs; a data-gradient workgroup 6.0 us loading, 14.3 multiplying (weight ring starved at
-// one row block per fragment), 5.4 storing).  Here
-//   waves 8-15 ("W"): stage the tile -- da = f(dy, a), h = relu(BN(a_prev)), raw a_prev -- and accumulate dW += h^T @ da in
-//                     registers.  Their MFMA loop reads LDS only, so the NEXT tile's global loads are issued before it and
-//                     land in registers while both halves multiply (vmcnt retires in order: the data-gradient waves could
-//                     not do that, their weight-fragment waits would wait for the tile too);
-//   waves 0-7 ("X"):  dy_prev = (da @ W^T) * [h > 0] with the BN sums of the layer below, K split over the waves so that all
-//                     eight work on a 32-row tile.
-// Two barriers per tile: B (every LDS read of the tile is done; X's K partials are in scratch) and A (the next tile is in LDS).
-// Between B and A the W waves write the staged tile while the X waves finish their epilogue from registers.
+// One backward layer = one launch of persistent workgroups, one per CU, over 32-row tiles.  Inputs of a tile: dy_i, a_i (the
+// layer's BN gradient is formed on load: da = gamma * inv_std * (dy - m1 - xhat * m2), xhat = (a - mean) * inv_std) and a_{i-1}.
+// Until round 3 a layer was two KINDS of workgroups in one launch (weight gradient / data gradient), each staging its own copy
+// of every tile and each leaving the matrix pipe idle while it waited for its own loads (in-kernel stamps: 12.5 us per 32-row
+// tile for ~3.5 us of MFMAs in a weight-gradient workgroup; 6.0 us loading, 14.3 multiplying, 5.4 storing in a data-gradient
+// one): 180 / 177 / 98 / 57 us for the four layers against 85 / 85 / 43 / 21 us of MFMA issue.  Now a workgroup stages a tile
+// ONCE and has two kinds of waves:
+//   "W" (8 waves): stage the tile -- da, h = relu(BN(a_prev)), raw a_prev -- and accumulate dW += h^T @ da in registers.
+//                  Their MFMA loop reads LDS only, so the global loads of a later tile are issued before it and land in
+//                  registers while everybody multiplies (vmcnt retires in order: the X waves could not do that, their
+//                  weight-fragment waits would wait for the tile too);
+//   "X" (4 or 8):  dy_prev = (da @ W^T) * [h > 0] with the BN sums of the layer below; their epilogue runs from registers.
+// With two tile buffers (all shapes but CIN = 256) tile k + 1 is staged at the START of iteration k -- while the X waves' chains
+// have the matrix pipe to themselves -- from registers requested during iteration k - 1, then tile k + 2 is requested, then the
+// products of tile k: ONE barrier per tile and no phase in which nobody multiplies.  With one buffer: request, products,
+// barrier B (all reads done), stage, barrier A.  Where the X waves split K, B also hands their partials over.
+// Measured 128.5 / 128.2 / 73.2 / 47.1 us.  What is left: a tile's loads are a bandwidth-bound burst (every workgroup asks at
+// once; ~8 us until the data is there) and one tile (80 KB per CU) in flight does not cover that -- a second register set does
+// not fit (dedicated loader waves holding the next tile in 80 registers were measured: 141 us, they serialise on that latency;
+// tools/experiments/train_bwd_fused_loader_waves.patch).
 // Tiles are dealt round-robin (tile = workgroup + k * workgroups): a workgroup's dW partial sums over a fixed set of tiles in
 // a fixed order, so the step stays deterministic.
 // XW = number of X waves: 8 (16 waves, 128 VGPRs each) where the W waves' 64 accumulator + 40 staging registers leave room,
 // 4 (12 waves, 168 VGPRs) for the two wide layers, where they do not (54 / 81 spilled registers made those launches slower
 // than the split form); an X wave then owns a whole K chain (and two column blocks at CIN = 256).
+constexpr int BWD_ROWS = 64;     // BwdArgs::tiles counts 64-row tiles
 constexpr int BF_ROWS = 32, BF_WTHREADS = 512;
 template <int CIN, int COUT> struct FusedShape {
     static constexpr int MB = CIN / 32, NB = COUT / 32;
@@ -1345,13 +1151,8 @@ static int launch_bn(geoadv_trainer *t, int i, int mode, int slot, hipStream_t s
 }
 
 // persistent backward workgroups (one per CU) = dW / db partials per layer; rows per BN-gradient partial of the layer below
-#ifdef GEOADV_BWD_SPLIT
-static int bwd_workgroups(const geoadv_trainer *t) { return (t->R / BWD_ROWS) < t->grid_bwd ? (t->R / BWD_ROWS) : t->grid_bwd; }
-constexpr int BWD_QROWS = BWD_ROWS;
-#else
 static int bwd_workgroups(const geoadv_trainer *t) { return (t->R / BF_ROWS) < t->grid_bwd ? (t->R / BF_ROWS) : t->grid_bwd; }
 constexpr int BWD_QROWS = BF_ROWS;
-#endif
 
 template <int CIN, int COUT>
 static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, hipStream_t st) {
@@ -1362,17 +1163,6 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
     a.pscale = t->bn_scale[i - 1]; a.pshift = t->bn_shift[i - 1]; a.pmean = t->bn_mean[i - 1]; a.pinv_std = t->bn_istd[i - 1];
     a.WT = PackedLayer{t->packed_bwd[i], COUT, CIN};
     a.dy_out = dy_out; a.qsum_out = t->qsum; a.dw_partial = t->dw_partial; a.db_partial = t->db_partial;
-    static_assert(BWD_ROWS == 64, "BwdArgs::tiles counts 64-row tiles");
-#ifdef GEOADV_BWD_SPLIT
-    static DeviceOnce attr;
-    if (int rc = attr.run([]() -> int {
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_bwd_split_kernel<CIN, COUT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitShape<CIN, COUT>::lds_bytes));
-            return GEOADV_OK;
-        })) return rc;
-    const int grid = a.tiles < t->grid_bwd ? a.tiles : t->grid_bwd;
-    train_bwd_split_kernel<CIN, COUT><<<grid + a.tiles, TR_THREADS, SplitShape<CIN, COUT>::lds_bytes, st>>>(a, grid);
-#else
     using S = FusedShape<CIN, COUT>;
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
@@ -1381,7 +1171,6 @@ static int launch_bwd(geoadv_trainer *t, int i, const float *dy, float *dy_out, 
             return GEOADV_OK;
         })) return rc;
     train_bwd_fused_kernel<CIN, COUT><<<bwd_workgroups(t), S::THREADS, S::lds_bytes, st>>>(a);
-#endif
     GA_LAUNCH_CHECK();
     return GEOADV_OK;                                   // its partials are reduced by post_layer (next launch)
 }

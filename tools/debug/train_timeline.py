@@ -14,9 +14,8 @@ for _ in range(5):
 torch.cuda.synchronize()
 NB = 1024
 names = {0: "train_fwd<128,256>", 1: "train_fwd<256,128>", 2: "train_fwd<128,128>", 3: "train_fwd<64,128>",
-         4: "bwd_split<128,256> weight-gradient workgroups", 5: "bwd_split<128,256> data-gradient workgroups (blocks < 1024)",
-         6: "bwd_fused<128,256> W waves, second tile: 0 start 1 staged + requested 2 products done 3 (barrier B, one-buffer staging) 7 barrier A",
-         7: "bwd_fused<128,256> X waves, second tile: 0 start 1 chain done 2 epilogue done 3 barrier B 7 barrier A"}
+         6: "train_bwd_fused<128,256> W waves, second tile: 0 start 1 next tile staged + the one after requested 2 products done 3 (barrier B, one-buffer staging) 7 barrier A",
+         7: "train_bwd_fused<128,256> X waves, second tile: 0 start 1 chain done 2 epilogue done 7 barrier A"}
 buf = (C.c_ulonglong * (8 * NB * 8))()
 fn = getattr(_lib.lib(), "geoadv_debug_stamps_train", None)
 if fn is None:
