@@ -135,6 +135,53 @@ __global__ __launch_bounds__(TR_THREADS) void train_fwd_kernel(FwdArgs A) {
     GA_STAMP(SK, 7);
 }
 
+// Per-channel totals of per-tile partials (sum, sum of squares -- or the two BN-gradient sums) in a FIXED order, in double.
+// A block = RED_CH channels x RED_GROUPS tile groups (1024 threads): thread (c, g) adds the tiles g, g + RED_GROUPS, ... in
+// ascending order with all its loads in flight at once (<= 32 per thread at the step's sizes; more go in batches of 16), the
+// groups are then folded 16 at a time and the eight folds added front to back.  8 channels per block instead of 32: four times
+// the workgroups and a quarter of the tiles per thread -- these launches are a handful of workgroups wide and pure latency
+// (9.7 -> ~5 us each, ten of them per step).  Returns true in the threads that hold a channel's totals (g == 0).
+constexpr int RED_CH = 8, RED_GROUPS = 1024 / RED_CH;
+__device__ __forceinline__ bool tile_partial_totals(const float2 *part, int tiles, int C, int block, double &s1, double &s2) {
+    __shared__ double r1[RED_GROUPS][RED_CH], r2[RED_GROUPS][RED_CH];
+    __shared__ double f1[8][RED_CH], f2[8][RED_CH];
+    const int cl = threadIdx.x % RED_CH, g = threadIdx.x / RED_CH, c = block * RED_CH + cl;
+    s1 = 0.0; s2 = 0.0;
+    int t = g;
+    for (; t + 15 * RED_GROUPS < tiles; t += 16 * RED_GROUPS) {
+        float2 p[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) p[u] = part[(size_t)(t + RED_GROUPS * u) * C + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s1 += p[u].x; s2 += p[u].y; }
+    }
+    {   // the rest (< 16 per thread): requested together, the ones beyond the end masked out
+        float2 p[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int tt = t + RED_GROUPS * u;
+            p[u] = part[(size_t)(tt < tiles ? tt : (tiles - 1)) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (t + RED_GROUPS * u < tiles) { s1 += p[u].x; s2 += p[u].y; }
+    }
+    r1[g][cl] = s1; r2[g][cl] = s2;
+    __syncthreads();
+    if (g < 8) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < RED_GROUPS / 8; ++k) { a1 += r1[g * (RED_GROUPS / 8) + k][cl]; a2 += r2[g * (RED_GROUPS / 8) + k][cl]; }
+        f1[g][cl] = a1; f2[g][cl] = a2;
+    }
+    __syncthreads();
+    if (g != 0) return false;
+    s1 = f1[0][cl]; s2 = f2[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { s1 += f1[k][cl]; s2 += f2[k][cl]; }
+    return true;
+}
+
 // Batch statistics of one layer from the per-tile partials (fixed order, double), the folded BN constants,
 // and tflearn's moving-average update (assign_moving_average, zero_debias=False).
 // mode 0: per-tile partials -> statistics in one go (single GPU).  Synchronised batch norm over several ranks splits it:
@@ -149,35 +196,15 @@ struct BnArgs {
 };
 
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnArgs A) {
-    __shared__ double r1[32][32], r2[32][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+    const int c = blockIdx.x * RED_CH + threadIdx.x % RED_CH;
     double s1 = 0.0, s2 = 0.0;
+    bool mine = threadIdx.x < RED_CH;
     if (A.mode != 2) {
-        int t = g;
-        for (; t + 15 * 32 < A.tiles; t += 16 * 32) {              // sixteen loads in flight (the kernel is a handful of workgroups:
-            float2 p[16];                                          // pure latency), summed in ascending tile order
-#pragma unroll
-            for (int u = 0; u < 16; ++u) p[u] = A.psum[(size_t)(t + 32 * u) * A.C + c];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { s1 += p[u].x; s2 += p[u].y; }
-        }
-        for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight
-            const float2 p0 = A.psum[(size_t)t * A.C + c], p1 = A.psum[(size_t)(t + 32) * A.C + c];
-            const float2 p2 = A.psum[(size_t)(t + 64) * A.C + c], p3 = A.psum[(size_t)(t + 96) * A.C + c];
-            s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
-        }
-        for (; t < A.tiles; t += 32) {
-            const float2 p = A.psum[(size_t)t * A.C + c];
-            s1 += p.x; s2 += p.y;
-        }
-        r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
-    }
-    __syncthreads();
-    if (g == 0) {
-        if (A.mode != 2) {
-            for (int k = 1; k < 32; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
-            if (A.mode == 1) { A.totals[c] = s1; A.totals[A.C + c] = s2; return; }
-        } else { s1 = A.totals[c]; s2 = A.totals[A.C + c]; }
+        mine = tile_partial_totals(A.psum, A.tiles, A.C, blockIdx.x, s1, s2);
+        if (mine && A.mode == 1) { A.totals[c] = s1; A.totals[A.C + c] = s2; }
+        if (A.mode == 1) return;
+    } else if (mine) { s1 = A.totals[c]; s2 = A.totals[A.C + c]; }
+    if (mine) {
         const double mean = s1 * A.inv_rows;
         double var = s2 * A.inv_rows - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -521,43 +548,23 @@ __global__ __launch_bounds__(256) void train_pool_bwd_kernel(PoolBwdArgs A) {
 struct BnBwdArgs { int mode; double *totals, *local_totals; const float2 *qsum; int tiles; int C; double inv_rows; float *dbeta, *dgamma, *m1, *m2; };
 
 __device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdArgs &A, const int block) {
-    __shared__ double r1[32][32], r2[32][32];
-    const int c = block * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
-    double s1 = 0.0, s2 = 0.0;
+    const int c = block * RED_CH + threadIdx.x % RED_CH;
+    double s1 = 0.0, s2 = 0.0, l1, l2;
+    bool mine = threadIdx.x < RED_CH;
     if (A.mode != 2) {
-        int t = g;
-        for (; t + 15 * 32 < A.tiles; t += 16 * 32) {              // sixteen loads in flight, summed in ascending tile order
-            float2 p[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) p[u] = A.qsum[(size_t)(t + 32 * u) * A.C + c];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { s1 += p[u].x; s2 += p[u].y; }
+        mine = tile_partial_totals(A.qsum, A.tiles, A.C, block, s1, s2);
+        if (!mine) return;
+        if (A.mode == 1) {
+            A.totals[c] = s1; A.totals[A.C + c] = s2; A.local_totals[c] = s1; A.local_totals[A.C + c] = s2;
+            return;
         }
-        for (; t + 96 < A.tiles; t += 128) {                       // four loads in flight
-            const float2 p0 = A.qsum[(size_t)t * A.C + c], p1 = A.qsum[(size_t)(t + 32) * A.C + c];
-            const float2 p2 = A.qsum[(size_t)(t + 64) * A.C + c], p3 = A.qsum[(size_t)(t + 96) * A.C + c];
-            s1 += p0.x; s2 += p0.y; s1 += p1.x; s2 += p1.y; s1 += p2.x; s2 += p2.y; s1 += p3.x; s2 += p3.y;
-        }
-        for (; t < A.tiles; t += 32) {
-            const float2 p = A.qsum[(size_t)t * A.C + c];
-            s1 += p.x; s2 += p.y;
-        }
-        r1[g][threadIdx.x & 31] = s1; r2[g][threadIdx.x & 31] = s2;
+        l1 = s1; l2 = s2;
+    } else {
+        if (!mine) return;
+        s1 = A.totals[c]; s2 = A.totals[A.C + c]; l1 = A.local_totals[c]; l2 = A.local_totals[A.C + c];
     }
-    __syncthreads();
-    if (g == 0) {
-        double l1, l2;
-        if (A.mode != 2) {
-            for (int k = 1; k < 32; ++k) { s1 += r1[k][threadIdx.x]; s2 += r2[k][threadIdx.x]; }
-            if (A.mode == 1) {
-                A.totals[c] = s1; A.totals[A.C + c] = s2; A.local_totals[c] = s1; A.local_totals[A.C + c] = s2;
-                return;
-            }
-            l1 = s1; l2 = s2;
-        } else { s1 = A.totals[c]; s2 = A.totals[A.C + c]; l1 = A.local_totals[c]; l2 = A.local_totals[A.C + c]; }
-        A.dbeta[c] = (float)l1; A.dgamma[c] = (float)l2;
-        A.m1[c] = (float)(s1 * A.inv_rows); A.m2[c] = (float)(s2 * A.inv_rows);
-    }
+    A.dbeta[c] = (float)l1; A.dgamma[c] = (float)l2;
+    A.m1[c] = (float)(s1 * A.inv_rows); A.m2[c] = (float)(s2 * A.inv_rows);
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs A) { bn_bwd_finalize_block(A, blockIdx.x); }
@@ -595,7 +602,8 @@ struct BwdArgs {
 // Measured 128.5 / 128.2 / 73.2 / 47.1 us.  What is left: a tile's loads are a bandwidth-bound burst (every workgroup asks at
 // once; ~8 us until the data is there) and one tile (80 KB per CU) in flight does not cover that -- a second register set does
 // not fit (dedicated loader waves holding the next tile in 80 registers were measured: 141 us, they serialise on that latency;
-// tools/experiments/train_bwd_fused_loader_waves.patch).
+// tools/experiments/train_bwd_fused_loader_waves.patch).  Skewing the workgroups' phases against each other (starts delayed by
+// 0 / 1 / 2 / 3 x 3.4 us, every XCD holding all four phases) only adds the delay: 132 / 131 / 75 / 48 -> 140 / 135 / 83 / 56 us.
 // Tiles are dealt round-robin (tile = workgroup + k * workgroups): a workgroup's dW partial sums over a fixed set of tiles in
 // a fixed order, so the step stays deterministic.
 // XW = number of X waves: 8 (16 waves, 128 VGPRs each) where the W waves' 64 accumulator + 40 staging registers leave room,
@@ -1145,7 +1153,7 @@ static int launch_bn(geoadv_trainer *t, int i, int mode, int slot, hipStream_t s
     a.gamma = t->params + t->L.gamma[i]; a.beta = t->params + t->L.beta[i];
     a.mean = t->bn_mean[i]; a.inv_std = t->bn_istd[i]; a.scale = t->bn_scale[i]; a.shift = t->bn_shift[i];
     a.mov_mean = t->mov_mean[i]; a.mov_var = t->mov_var[i]; a.one_minus_decay = t->one_minus_decay;
-    bn_finalize_kernel<<<ENC[i + 1] / 32, 1024, 0, st>>>(a);
+    bn_finalize_kernel<<<ENC[i + 1] / RED_CH, 1024, 0, st>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -1184,7 +1192,7 @@ static BnBwdArgs bn_bwd_args(geoadv_trainer *t, int i, int partial_rows, int mod
 }
 
 static int launch_bn_bwd(geoadv_trainer *t, int i, int partial_rows, int mode, int slot, hipStream_t st) {
-    bn_bwd_finalize_kernel<<<ENC[i + 1] / 32, 1024, 0, st>>>(bn_bwd_args(t, i, partial_rows, mode, slot));
+    bn_bwd_finalize_kernel<<<ENC[i + 1] / RED_CH, 1024, 0, st>>>(bn_bwd_args(t, i, partial_rows, mode, slot));
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -1195,7 +1203,7 @@ static int launch_post_layer(geoadv_trainer *t, int i, int mode, int slot, hipSt
     const size_t cnt = (size_t)ENC[i] * ENC[i + 1];
     const ReduceArgs dw{t->dw_partial, parts, cnt, t->grads + t->L.w[i]};
     const ReduceArgs db{t->db_partial, parts, (size_t)ENC[i + 1], t->grads + t->L.b[i]};
-    const int bn_blocks = ENC[i] / 32, dw_blocks = (int)((cnt + 255) / 256), db_blocks = cdiv(ENC[i + 1], 256);
+    const int bn_blocks = ENC[i] / RED_CH, dw_blocks = (int)((cnt + 255) / 256), db_blocks = cdiv(ENC[i + 1], 256);
     post_layer_kernel<<<bn_blocks + dw_blocks + db_blocks, 1024, 0, st>>>(bn_bwd_args(t, i - 1, BWD_QROWS, mode, slot), bn_blocks, dw,
                                                                          dw_blocks, db);
     GA_LAUNCH_CHECK();
