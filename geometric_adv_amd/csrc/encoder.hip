@@ -125,10 +125,7 @@ __device__ __forceinline__ void writelane16(unsigned &dst, unsigned src, int lan
 // slots are refilled with the first four fragments of the NEXT chain (weights do not depend on the
 // activations, so the request may cross the epilogue and the barrier).  Without it every chain start
 // exposes one L2 round trip (~900 cycles, 8 chains per tile = 13 % of the tile).
-struct BRing { float4 b[4]; };
-__device__ __forceinline__ void ring_fill(BRing &r, const FragSrc &f, unsigned lb) {
-    r.b[0] = ld_frag(f, 0, lb); r.b[1] = ld_frag(f, 1, lb); r.b[2] = ld_frag(f, 2, lb); r.b[3] = ld_frag(f, 3, lb);
-}
+// (BRing, ring_fill: mfma_tile.h, shared with the training kernels)
 // NT (chain length in k-groups) is a compile-time constant -- the encoder widths are fixed (ae_create checks them) -- so
 // the chain is fully unrolled: the first MFMA takes the inline constant 0 as its accumulator (no 16 x v_mov per chain),
 // every A / B address is base + immediate, and no select survives.  That matters more than it looks: plain VALU

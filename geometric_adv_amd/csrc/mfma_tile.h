@@ -105,6 +105,64 @@ __device__ __forceinline__ void gemm_chain(const float *in, int s_in, int row0, 
     }
 }
 
+// B-fragment ring carried ACROSS chains: while the last four k-groups of a chain run, the freed
+// slots are refilled with the first four fragments of the NEXT chain (weights do not depend on the
+// activations, so the request may cross the epilogue and the barrier).  Without it every chain start
+// exposes one L2 round trip (~900 cycles, 8 chains per tile = 13 % of the attack encoder's tile).
+struct BRing { float4 b[4]; };
+__device__ __forceinline__ void ring_fill(BRing &r, const FragSrc &f, unsigned lb) {
+    r.b[0] = ld_frag(f, 0, lb); r.b[1] = ld_frag(f, 1, lb); r.b[2] = ld_frag(f, 2, lb); r.b[3] = ld_frag(f, 3, lb);
+}
+// NT (chain length in k-groups) is a compile-time constant -- the encoder widths are fixed (ae_create checks them) -- so
+// the chain is fully unrolled: the first MFMA takes the inline constant 0 as its accumulator (no 16 x v_mov per chain),
+// every A / B address is base + immediate, and no select survives.  That matters more than it looks: plain VALU
+// instructions do NOT overlap with the matrix pipe on this part (tools/mfma_probe.py: 4 MFMA + 16 v_add_f32 per group
+// runs 14 % slower than the MFMAs alone), so every VALU instruction of such a kernel is paid in MFMA time.
+// (encoder.hip keeps its own one-row-block form, chain_ring; this is the same chain for the training kernels:)
+// RM row blocks share each B fragment (ar[rm] = the lane's row of block rm); HAS_NEXT = false refills the ring with the
+// chain's OWN first fragments -- what a persistent workgroup that runs the same chain on tile after tile wants.
+template <int NT, bool HAS_NEXT, int RM>
+__device__ __forceinline__ void chain_ring_rm(const float *const (&ar)[RM], int at0, const FragSrc &cur, unsigned lb, BRing &ring,
+                                           const FragSrc &next, f32x16 (&acc)[RM]) {
+    static_assert(NT % 4 == 0, "chain lengths are multiples of four k-groups");
+    float4 a0[RM], a1[RM];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * at0);
+#pragma unroll
+    for (int t = 0; t < NT; t += 4) {
+        // every refill is UNCONDITIONAL (an always valid address: the chain's own first fragments if nothing follows):
+        // with a branch around a load the compiler can no longer count outstanding loads and degrades the
+        // s_waitcnt vmcnt(3) below to vmcnt(2)/(1)/(0)
+        const bool more = t + 4 < NT;
+        const FragSrc &src = more ? cur : (HAS_NEXT ? next : cur);
+        const int g = more ? t + 4 : 0;
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (at0 + t + 1));
+        __builtin_amdgcn_sched_barrier(0);       // the next A fragment is requested BEFORE this group's MFMAs issue
+        mfma_group<RM>(a0, ring.b[0], acc);
+        ring.b[0] = ld_frag(src, g + 0, lb);
+        __builtin_amdgcn_sched_barrier(0);       // keep the refill HERE (the scheduler would sink all four to the loop end)
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (at0 + t + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<RM>(a1, ring.b[1], acc);
+        ring.b[1] = ld_frag(src, g + 1, lb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a1[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (at0 + t + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<RM>(a0, ring.b[2], acc);
+        ring.b[2] = ld_frag(src, g + 2, lb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm) a0[rm] = *reinterpret_cast<const float4 *>(ar[rm] + 8 * (at0 + (more ? t + 4 : t)));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group<RM>(a1, ring.b[3], acc);
+        ring.b[3] = ld_frag(src, g + 3, lb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // out tile [ROWS][NOUT] = in tile [ROWS][K] @ W, handed element-wise to epi(row, col, value).
 // KC = number of canonical K parts (independent chains summed part0 + part1 + ...); KC == 0
 // picks whatever keeps all 8 waves busy.  Must be called by every wave of the workgroup.

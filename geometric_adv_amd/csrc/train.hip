@@ -49,6 +49,7 @@ struct FwdArgs {
     const float *bias;           // b_i
     float *out;                  // a_i [R][COUT]
     float2 *psum;                // [tiles][COUT] (sum a, sum a^2) over the 64 rows of the tile
+    int tiles;                   // 64-row tiles (the persistent forward kernel deals them round-robin)
 };
 
 __global__ __launch_bounds__(TR_THREADS) void train_fwd0_kernel(FwdArgs A) {
@@ -96,41 +97,143 @@ __device__ __forceinline__ void load_activated_tile(const float *a, size_t row0,
     }
 }
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(TR_THREADS) void train_fwd_kernel(FwdArgs A) {
-    extern __shared__ __align__(16) float lds[];
-    float *tile = lds;                                   // [64][CIN + 4]
-    float2 *red = reinterpret_cast<float2 *>(lds + TR_ROWS * (CIN + 4));   // [2][COUT]
-    const size_t row0 = (size_t)blockIdx.x * TR_ROWS;
-    [[maybe_unused]] constexpr int SK = (CIN == 128 && COUT == 256) ? 0 : (CIN == 256 ? 1 : (CIN == 128 ? 2 : 3));   // stamp slot (diagnostic builds)
-    GA_STAMP(SK, 0);
-    load_activated_tile<CIN>(A.in, row0, A.pscale, A.pshift, tile);
-    __syncthreads();
-    GA_STAMP(SK, 1);
-    const int col = layer_gemm_lane_col<TR_ROWS, COUT>();
-    const float b = A.bias[col];
-    float s1 = 0.f, s2 = 0.f;
-    int rb_seen = 0;
-    layer_gemm<TR_ROWS, COUT, 1>(tile, CIN + 4, A.W, nullptr, [&](int row, int c, float v) {
-        const float a = v + b;
-        A.out[(row0 + row) * COUT + c] = a;
-        s1 += a;
-        s2 = fmaf(a, a, s2);
-        rb_seen = row >> 5;
-    });
-    GA_STAMP(SK, 2);
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    constexpr bool BOTH = (COUT / 32) * 2 > 8;            // one wave covers both row blocks (COUT = 256)
-    if (BOTH) {
-        if ((threadIdx.x & 63) < 32) A.psum[(size_t)blockIdx.x * COUT + col] = make_float2(s1, s2);
-    } else {
-        if ((threadIdx.x & 63) < 32) red[rb_seen * COUT + col] = make_float2(s1, s2);
-        __syncthreads();
-        if (threadIdx.x < COUT) {
-            const float2 p = red[threadIdx.x], q = red[COUT + threadIdx.x];
-            A.psum[(size_t)blockIdx.x * COUT + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
+// The loader waves' side of a tile: ROWS x C floats, global -> registers -> (activation) -> LDS [ROWS][C + 4], by the
+// LOADER_THREADS threads [TR_THREADS, TR_THREADS + LOADER_THREADS) of the workgroup.
+constexpr int LOADER_THREADS = 256;
+template <int C, int ROWS> struct LoaderTile {
+    static constexpr int Q = C / 4, STEP = LOADER_THREADS / Q, NP = ROWS / STEP;
+    float4 v[NP];
+    __device__ __forceinline__ void request(const float *a, size_t row0) {
+        const int l = threadIdx.x - TR_THREADS, c4 = l % Q, r0 = l / Q;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) v[j] = reinterpret_cast<const float4 *>(a + (row0 + r0 + j * STEP) * C)[c4];
+    }
+    // h = relu(a * s + t)   (s, t: this thread's four channels of the folded BN)
+    __device__ __forceinline__ void store_activated(const float4 s, const float4 t, float *lds) const {
+        const int l = threadIdx.x - TR_THREADS, c4 = l % Q, r0 = l / Q;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            float4 h;
+            h.x = fmaxf(fmaf(v[j].x, s.x, t.x), 0.f); h.y = fmaxf(fmaf(v[j].y, s.y, t.y), 0.f);
+            h.z = fmaxf(fmaf(v[j].z, s.z, t.z), 0.f); h.w = fmaxf(fmaf(v[j].w, s.w, t.w), 0.f);
+            *reinterpret_cast<float4 *>(lds + (r0 + j * STEP) * (C + 4) + 4 * c4) = h;
         }
+    }
+};
+
+// One forward layer, persistent and wave-specialised: 8 matrix waves + 4 loader waves per workgroup, two LDS tile buffers,
+// and -- what makes it pay -- the weight ring carried from tile to tile and TWO tiles of loads in flight.
+// What it replaces (one 64-row tile per workgroup, 1600 workgroups) ran at 0.49-0.56 of the MFMA peak: in-kernel stamps showed
+// lockstep rounds (everyone loads, then everyone multiplies) and a near-empty third round, but compiling the loads and stores
+// out left 65 of 84 us: a fixed ~2.3 us per tile and CU were weight-ring priming out of L2 at every tile start (one exposed L2
+// round trip per chain, 11-22 % of these short chains), the epilogue and barrier skew.  A first persistent version without the
+// carried ring gained nothing (84 us), which is how the ring was found.  Here a matrix wave's chain ends by refilling its ring
+// with its own first four fragments (the next tile multiplies by the same weights): stamps then show the chain AT the pipe's
+// rate (6.7 us for 7.0 us of MFMA issue per tile and CU at CIN = 256) -- and the matrix waves waiting ~3 us per tile for the
+// loaders, whose requests take ~8 us to come back under this load.  So the loaders keep two register sets: tile j + 2 is
+// requested while tile j is multiplied and staged (BN + ReLU -> the other LDS buffer) while tile j + 1 is.  One barrier per tile
+// (two where the partial sums of two row blocks meet in LDS).  vmcnt retires in order, so the matrix waves themselves cannot
+// prefetch tiles: their weight-fragment waits would wait for the tile's HBM round trip too.
+// Tiles are dealt round-robin (tile = workgroup + j * workgroups): 1600 tiles over 512 workgroups leave the same 7-against-6.25
+// imbalance per CU a dynamic queue would, and the loaders know their tiles two ahead.
+constexpr int FW_THREADS = TR_THREADS + LOADER_THREADS;
+template <int CIN, int COUT> struct FwdShape {
+    static constexpr int TILE_FLOATS = TR_ROWS * (CIN + 4);
+    static constexpr size_t lds_bytes = sizeof(float) * (2 * TILE_FLOATS + 4 * COUT);
+    static constexpr int WGS_PER_CU = lds_bytes * 2 <= 158 * 1024 ? 2 : 1;
+    static constexpr int RM = COUT == 256 ? 2 : 1;          // row blocks per matrix wave (8 waves: 8 column blocks x 2, or 4 x 2 units)
+};
+template <int CIN, int COUT>
+__global__ __launch_bounds__(FW_THREADS, (FwdShape<CIN, COUT>::WGS_PER_CU * 3)) void train_fwd_kernel(FwdArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    using S = FwdShape<CIN, COUT>;
+    static_assert(COUT == 128 || COUT == 256, "eight matrix waves cover 64 x 128 or 64 x 256 outputs");
+    float2 *red = reinterpret_cast<float2 *>(lds + 2 * S::TILE_FLOATS);   // [2][COUT]
+    [[maybe_unused]] constexpr int SK = (CIN == 128 && COUT == 256) ? 0 : (CIN == 256 ? 1 : (CIN == 128 ? 2 : 3));   // stamp slot (diagnostic builds)
+    constexpr bool BOTH = S::RM == 2;                        // one matrix wave covers both row blocks
+    GA_STAMP(SK, 0);
+    const int G = gridDim.x, tiles = A.tiles;
+    if ((int)blockIdx.x >= tiles) return;
+    if (threadIdx.x >= TR_THREADS) {
+        // ---------------- loader waves ----------------
+        LoaderTile<CIN, TR_ROWS> P0, P1;                     // tile j lives in set j & 1
+        const int c4 = (threadIdx.x - TR_THREADS) % (CIN / 4);
+        const float4 ps = reinterpret_cast<const float4 *>(A.pscale)[c4], pt = reinterpret_cast<const float4 *>(A.pshift)[c4];
+        int t = blockIdx.x;                                  // tile of iteration j
+        P0.request(A.in, (size_t)t * TR_ROWS);
+        if (t + G < tiles) P1.request(A.in, (size_t)(t + G) * TR_ROWS);
+        P0.store_activated(ps, pt, lds);
+        if (t + 2 * G < tiles) P0.request(A.in, (size_t)(t + 2 * G) * TR_ROWS);
+        __syncthreads();                                     // P: tile 0 is in buffer 0
+        for (;; t += 2 * G) {
+            // even iteration j: tile j + 1 (set 1) -> buffer 1, then tile j + 3 -> set 1
+            if (t + G < tiles) {
+                P1.store_activated(ps, pt, lds + S::TILE_FLOATS);
+                if (t + 3 * G < tiles) P1.request(A.in, (size_t)(t + 3 * G) * TR_ROWS);
+            }
+            if (!BOTH) __syncthreads();                      // X (the matrix waves' partial-sum exchange)
+            __syncthreads();                                 // Y: tile j is consumed, tile j + 1 is staged
+            if (t + G >= tiles) break;
+            // odd iteration j + 1: tile j + 2 (set 0) -> buffer 0, then tile j + 4 -> set 0
+            if (t + 2 * G < tiles) {
+                P0.store_activated(ps, pt, lds);
+                if (t + 4 * G < tiles) P0.request(A.in, (size_t)(t + 4 * G) * TR_ROWS);
+            }
+            if (!BOTH) __syncthreads();                      // X
+            __syncthreads();                                 // Y
+            if (t + 2 * G >= tiles) break;
+        }
+        return;
+    }
+    // ---------------- matrix waves ----------------
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, i = lane & 31;
+    const int cb = BOTH ? wave : wave & 3, rb = BOTH ? 0 : wave >> 2;
+    const int col = cb * 32 + i;
+    const float b = A.bias[col];
+    constexpr int kg = CIN >> 3;
+    const FragSrc w = frag_src(A.W.w, cb * kg);
+    const unsigned lb = (unsigned)lane * 16u;
+    BRing ring;
+    ring_fill(ring, w, lb);                                  // once: every chain refills it with its own first fragments
+    __syncthreads();                                         // P
+    GA_STAMP(SK, 1);
+    for (int cur = blockIdx.x, it = 0; cur < tiles; cur += G, ++it) {
+        const float *tile = lds + (it & 1) * S::TILE_FLOATS;
+        const size_t row0 = (size_t)cur * TR_ROWS;
+        const float *ar[S::RM];
+#pragma unroll
+        for (int rm = 0; rm < S::RM; ++rm) ar[rm] = tile + ((rb + rm) * 32 + i) * (CIN + 4) + 4 * h;
+        f32x16 acc[S::RM] = {};
+        if (it == 2) GA_STAMP(SK, 3);
+        chain_ring_rm<kg, false, S::RM>(ar, 0, w, lb, ring, w, acc);
+        if (it == 2) GA_STAMP(SK, 4);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int rm = 0; rm < S::RM; ++rm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = acc[rm][r] + b;
+                A.out[(row0 + (rb + rm) * 32 + acc_row(r, h)) * COUT + col] = a;
+                s1 += a;
+                s2 = fmaf(a, a, s2);
+            }
+        if (it == 0) GA_STAMP(SK, 2);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (BOTH) {
+            if (lane < 32) A.psum[(size_t)cur * COUT + col] = make_float2(s1, s2);
+        } else {
+            if (lane < 32) red[rb * COUT + col] = make_float2(s1, s2);
+            if (it == 2) GA_STAMP(SK, 5);
+            __syncthreads();                                 // X
+            if (threadIdx.x < COUT) {
+                const float2 p = red[threadIdx.x], q = red[COUT + threadIdx.x];
+                A.psum[(size_t)cur * COUT + threadIdx.x] = make_float2(p.x + q.x, p.y + q.y);
+            }
+        }
+        __syncthreads();                                     // Y
+        if (it == 2) GA_STAMP(SK, 6);
     }
     GA_STAMP(SK, 7);
 }
@@ -971,7 +1074,7 @@ Layout make_layout(int n_points) {
 }  // namespace
 
 struct geoadv_trainer {
-    int B, N, R, tiles, n3, grid_bwd;
+    int B, N, R, tiles, n3, grid_bwd, cus;
     float lr, one_minus_decay;
     float b1p, b2p;
     Layout L;
@@ -1033,6 +1136,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     t->grid_bwd = cus * (64 / BWD_ROWS);                  // persistent backward workgroups
+    t->cus = cus;
     // carve
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) / 256 * 256; return r; };
@@ -1132,14 +1236,17 @@ static int launch_fwd(geoadv_trainer *t, int i, hipStream_t st) {
     a.in = t->act[i - 1]; a.pscale = t->bn_scale[i - 1]; a.pshift = t->bn_shift[i - 1];
     a.W = PackedLayer{t->packed_fwd[i], CIN, COUT};
     a.bias = t->params + t->L.b[i]; a.out = t->act[i]; a.psum = t->psum;
-    const size_t lds = sizeof(float) * (TR_ROWS * (CIN + 4) + 4 * COUT);
+    using S = FwdShape<CIN, COUT>;
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(train_fwd_kernel<CIN, COUT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes));
             return GEOADV_OK;
         })) return rc;
-    train_fwd_kernel<CIN, COUT><<<t->tiles, TR_THREADS, lds, st>>>(a);
+    // persistent workgroups (as many as stay resident), tiles dealt round-robin
+    const int grid = t->tiles < S::WGS_PER_CU * t->cus ? t->tiles : S::WGS_PER_CU * t->cus;
+    a.tiles = t->tiles;
+    train_fwd_kernel<CIN, COUT><<<grid, FW_THREADS, S::lds_bytes, st>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
