@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const 
     const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int n = min(blockIdx.x * 64 + col, n3 - 1);
     float acc[16] = {};
-#pragma unroll 2
-    for (int k = ks * 64; k < ks * 64 + 64; k += 4) {
+#pragma unroll 8
+    for (int k = ks * 64; k < ks * 64 + 64; k += 4) {   // (32 weight loads in flight: the launch is L2 round trips, not arithmetic)
         const float w0 = V2[(size_t)k * n3 + n], w1 = V2[(size_t)(k + 1) * n3 + n];
         const float w2 = V2[(size_t)(k + 2) * n3 + n], w3 = V2[(size_t)(k + 3) * n3 + n];
 #pragma unroll
@@ -484,14 +484,22 @@ __device__ __forceinline__ void fc_out_bwd_w_block(const float *d2, const float 
     if (n >= n3) return;
     float acc[32] = {};
     float gs = 0.f;
-    for (int b = 0; b < batch; ++b) {
-        const float gv = g[(size_t)b * n3 + n];
-        gs += gv;
+    for (int b0 = 0; b0 < batch; b0 += 10) {               // ten rows' gradients requested at once (ascending order kept)
+        float gvv[10];
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 4) {
-            const float4 xv = *reinterpret_cast<const float4 *>(&xs[b * 32 + kk]);
-            acc[kk] = fmaf(xv.x, gv, acc[kk]); acc[kk + 1] = fmaf(xv.y, gv, acc[kk + 1]);
-            acc[kk + 2] = fmaf(xv.z, gv, acc[kk + 2]); acc[kk + 3] = fmaf(xv.w, gv, acc[kk + 3]);
+        for (int u = 0; u < 10; ++u) gvv[u] = g[(size_t)min(b0 + u, batch - 1) * n3 + n];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            if (b0 + u >= batch) break;
+            const int b = b0 + u;
+            const float gv = gvv[u];
+            gs += gv;
+#pragma unroll
+            for (int kk = 0; kk < 32; kk += 4) {
+                const float4 xv = *reinterpret_cast<const float4 *>(&xs[b * 32 + kk]);
+                acc[kk] = fmaf(xv.x, gv, acc[kk]); acc[kk + 1] = fmaf(xv.y, gv, acc[kk + 1]);
+                acc[kk + 2] = fmaf(xv.z, gv, acc[kk + 2]); acc[kk + 3] = fmaf(xv.w, gv, acc[kk + 3]);
+            }
         }
     }
 #pragma unroll
@@ -505,6 +513,7 @@ __device__ __forceinline__ void fc_out_bwd_x_block(const float *g, const float *
     __shared__ float red[4][32];
     const int k0 = bx * 4, b0 = by * 8;
     float acc[4][8] = {};
+#pragma unroll 4
     for (int n = threadIdx.x; n < n3; n += 256) {
         float w[4], gv[8];
 #pragma unroll
