@@ -716,6 +716,9 @@ struct BwdArgs {
 // not fit (dedicated loader waves holding the next tile in 80 registers were measured: 141 us, they serialise on that latency;
 // tools/experiments/train_bwd_fused_loader_waves.patch).  Skewing the workgroups' phases against each other (starts delayed by
 // 0 / 1 / 2 / 3 x 3.4 us, every XCD holding all four phases) only adds the delay: 132 / 131 / 75 / 48 -> 140 / 135 / 83 / 56 us.
+// Two staging register sets in the W waves (64 accumulators + 2 x 40) spill 256-288 registers at the 168 cap; touching one
+// dword per line of the tile after next so that it waits in L2 made everything slower (164 / 150 / 90 / 58 us: the touched
+// lines are fetched twice or push the weights out).
 // Tiles are dealt round-robin (tile = workgroup + k * workgroups): a workgroup's dW partial sums over a fixed set of tiles in
 // a fixed order, so the step stays deterministic.
 // XW = number of X waves: 8 (16 waves, 128 VGPRs each) where the W waves' 64 accumulator + 40 staging registers leave room,
