@@ -41,7 +41,7 @@ PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r03_pmc_chamfer_hbm.json")   
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep: ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- what each rank of the strong-scaling leg runs
 SWEEP_SRC = "profiles/r03_attack_sweep.json"
-SWEEP_MS = {32: 0.1750, 16: 0.1140, 8: 0.0860, 4: 0.0744}
+SWEEP_MS = {32: 0.1738, 16: 0.1141, 8: 0.0860, 4: 0.0748}
 
 
 def parse_args():
