@@ -1086,7 +1086,7 @@ Layout make_layout(int n_points) {
 }  // namespace
 
 struct geoadv_trainer {
-    int B, N, R, tiles, n3, grid_bwd, cus;
+    int B, N, R, tiles, n3, grid_bwd, cus, max_wgs;
     float lr, one_minus_decay;
     float b1p, b2p;
     Layout L;
@@ -1134,6 +1134,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
         GA_REQUIRE(hw->enc_dims[i] == ENC[i], "trainer_create: encoder widths must be 3,64,128,128,256,128 (src/ae_templates.py:22)");
     const int n = hw->n_points, B = cfg->batch;
     GA_REQUIRE(n >= 64 && n % 64 == 0 && n <= 32768, "trainer_create: n_points %d must be a multiple of 64 in [64, 32768]", n);
+    GA_REQUIRE(cfg->max_workgroups >= 0, "trainer_create: max_workgroups %d must be >= 0", cfg->max_workgroups);
     GA_REQUIRE(B >= 1 && B <= 4096, "trainer_create: batch %d out of range [1, 4096]", B);
     GA_REQUIRE(hw->dec_dims[0] == 128 && hw->dec_dims[1] == 256 && hw->dec_dims[2] == 256 && hw->dec_dims[3] == 3 * n,
                "trainer_create: decoder widths must be 128,256,256,3*n_points (src/ae_templates.py:29)");
@@ -1147,7 +1148,9 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    t->grid_bwd = cus * (64 / BWD_ROWS);                  // persistent backward workgroups
+    t->max_wgs = cfg->max_workgroups;
+    t->grid_bwd = cus * (64 / BWD_ROWS);                  // persistent backward workgroups (one per CU)
+    if (t->max_wgs > 0 && t->grid_bwd > t->max_wgs) t->grid_bwd = t->max_wgs;
     t->cus = cus;
     // carve
     size_t off = 0;
@@ -1256,7 +1259,8 @@ static int launch_fwd(geoadv_trainer *t, int i, hipStream_t st) {
             return GEOADV_OK;
         })) return rc;
     // persistent workgroups (as many as stay resident), tiles dealt round-robin
-    const int grid = t->tiles < S::WGS_PER_CU * t->cus ? t->tiles : S::WGS_PER_CU * t->cus;
+    int grid = t->tiles < S::WGS_PER_CU * t->cus ? t->tiles : S::WGS_PER_CU * t->cus;
+    if (t->max_wgs > 0 && grid > t->max_wgs) grid = t->max_wgs;
     a.tiles = t->tiles;
     train_fwd_kernel<CIN, COUT><<<grid, FW_THREADS, S::lds_bytes, st>>>(a);
     GA_LAUNCH_CHECK();

@@ -23,7 +23,8 @@ from .autoencoder import _AEWeights
 
 
 class _TrainConfig(C.Structure):
-    _fields_ = [("batch", C.c_int), ("learning_rate", C.c_float), ("bn_decay", C.c_float), ("loss", C.c_int)]
+    _fields_ = [("batch", C.c_int), ("learning_rate", C.c_float), ("bn_decay", C.c_float), ("loss", C.c_int),
+                ("max_workgroups", C.c_int)]
 
 
 def _fill_weights_struct(hw, canon, n_points):
@@ -76,7 +77,7 @@ class PointNetAETrainer:
     GROUPS = ("enc_w", "enc_b", "gamma", "beta", "dec_w", "dec_b")
 
     def __init__(self, weights, n_points, batch_size=50, learning_rate=0.0005, bn_decay=0.9, ae_name=W.AE_NAME,
-                 device=None, sync_bn=True, loss="chamfer"):
+                 device=None, sync_bn=True, loss="chamfer", max_workgroups=0):
         if isinstance(weights, str):
             weights = W.load(weights, ae_name)
         self.n_points, self.batch_size, self.ae_name = int(n_points), int(batch_size), ae_name
@@ -87,7 +88,7 @@ class PointNetAETrainer:
         if loss not in ("chamfer", "emd"):                       # conf.loss (src/pointnet_ae.py:74-79)
             raise ValueError("loss must be 'chamfer' or 'emd'")
         self.loss = loss
-        cfg = _TrainConfig(self.batch_size, float(learning_rate), float(bn_decay), 1 if loss == "emd" else 0)
+        cfg = _TrainConfig(self.batch_size, float(learning_rate), float(bn_decay), 1 if loss == "emd" else 0, int(max_workgroups))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_trainer_create(C.byref(self._h), C.byref(hw), C.byref(cfg)), "trainer_create")

@@ -291,6 +291,10 @@ typedef struct geoadv_train_config {
                              * reduce_mean(dist2) of nn_distance(recon, gt); GEOADV_TRAIN_LOSS_EMD (1) =
                              * reduce_mean(match_cost(recon, gt, approx_match(recon, gt))), the match held constant in the
                              * backward (approx_match is registered NoGradient, tf_approxmatch.py:19)                  */
+    int   max_workgroups;   /* 0 = as many persistent workgroups as the device holds (the layer kernels deal their 64- / 32-row
+                             * tiles round-robin over them); > 0 caps them.  Results do not depend on it beyond the order of
+                             * the per-workgroup weight-gradient partial sums; the parity tests use small values so that
+                             * small shapes run the kernels' multi-tile pipelines                                       */
 } geoadv_train_config;
 #define GEOADV_TRAIN_LOSS_CHAMFER 0
 #define GEOADV_TRAIN_LOSS_EMD     1

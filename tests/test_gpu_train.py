@@ -25,12 +25,12 @@ def _clouds(seed, b, n):
     return (rng.random((b, n, 3), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
 
 
-def _setup(n, b, seed=11, lr=0.0005, loss="chamfer"):
+def _setup(n, b, seed=11, lr=0.0005, loss="chamfer", max_workgroups=0):
     from geometric_adv_amd import weights as W
     from geometric_adv_amd.trainer import PointNetAETrainer
     from oracle.train_model import TrainModel
     w = W.randomized_weights(n, seed=seed)
-    tr = PointNetAETrainer(w, n, batch_size=b, learning_rate=lr, loss=loss)
+    tr = PointNetAETrainer(w, n, batch_size=b, learning_rate=lr, loss=loss, max_workgroups=max_workgroups)
     tm = TrainModel(W.canonical(w, n), n, lr=lr, loss=loss)
     return w, tr, tm
 
@@ -68,10 +68,14 @@ def _rel(a, b):
     return float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))
 
 
-@pytest.mark.parametrize("n,b", [(128, 4), (256, 3), (64, 1)])
-def test_loss_recon_and_gradients_match_the_oracle(n, b):
+# max_workgroups: the layer kernels are persistent (tiles dealt round-robin over the workgroups; two LDS tile buffers, loads
+# requested one or two tiles ahead).  At these shapes the device has more workgroups than there are tiles, so the default
+# runs one tile per workgroup; 1 / 2 / 3 workgroups walk 4-24 tiles each through every stage of those pipelines (odd and
+# even tile counts per workgroup, workgroups with one tile fewer than their neighbours).
+@pytest.mark.parametrize("n,b,max_workgroups", [(128, 4, 0), (256, 3, 0), (64, 1, 0), (256, 3, 1), (256, 3, 2), (128, 4, 3), (256, 3, 5)])
+def test_loss_recon_and_gradients_match_the_oracle(n, b, max_workgroups):
     from oracle.train_model import PARAM_GROUPS
-    w, tr, tm = _setup(n, b)
+    w, tr, tm = _setup(n, b, max_workgroups=max_workgroups)
     x = _batch(tm, b, n, 3)
     recon, loss = tr.forward_backward(x)
     g_gpu = tr.gradients()
@@ -149,6 +153,22 @@ def test_loss_trajectory_tracks_the_oracle():
     assert ref[-1] < 0.7 * ref[0]                                           # it trains
     assert np.abs(gpu[:4] - ref[:4]).max() <= 1e-4 * ref[0]
     assert np.abs(gpu - ref).max() <= 2e-2 * ref[0]                         # sign-like Adam updates amplify rounding slowly
+
+
+def test_results_do_not_depend_on_the_number_of_workgroups():
+    """Everything but the weight gradients (whose per-workgroup partial sums regroup) is bit-identical for any cap."""
+    n, b = 256, 3
+    outs = []
+    for cap in (0, 1, 4):
+        w, tr, tm = _setup(n, b, max_workgroups=cap)
+        x = _batch(tm, b, n, 3)
+        recon, loss = tr.forward_backward(x)
+        g = tr.gradients()
+        outs.append((recon.cpu().numpy().copy(), float(loss.item()), g))
+    for r, l, g in outs[1:]:
+        assert np.array_equal(r, outs[0][0]) and l == outs[0][1]
+        for j in range(len(g["enc_w"])):
+            assert _rel(g["enc_w"][j], np.asarray(outs[0][2]["enc_w"][j], np.float64)) <= 2e-6
 
 
 def test_step_is_deterministic():
