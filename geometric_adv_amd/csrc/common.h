@@ -79,6 +79,22 @@ static __device__ unsigned long long ga_stamps[8 * GA_STAMP_BLOCKS * 8];
 #define GA_STAMPS_GETTER(NAME)
 #endif
 
+// Sum over the 64 lanes of a wave in a FIXED order (every lane gets the result): four DPP steps fold each row of 16 lanes
+// (xor 1, xor 2, half mirror, mirror -- register to register), v_readlane collects the four rows.
+__device__ __forceinline__ float wave_sum(float v) {
+#define GA_SUM_DPP(CTRL) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false))
+    GA_SUM_DPP(0xB1);      // quad_perm [1,0,3,2]
+    GA_SUM_DPP(0x4E);      // quad_perm [2,3,0,1]
+    GA_SUM_DPP(0x141);     // row_half_mirror
+    GA_SUM_DPP(0x140);     // row_mirror
+#undef GA_SUM_DPP
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // Lexicographic (value, index) minimum over the 64 lanes of a wave; every lane ends up with the result.  Four DPP steps
 // reduce each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- register-to-register, a few cycles
 // each, where a __shfl_xor is a ds_bpermute round trip of ~150), v_readlane collects the four rows.

@@ -395,22 +395,27 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const 
     __shared__ __align__(16) float x[16][256];
     __shared__ float red[3][16][64];
     const int b0 = blockIdx.y * 16;
-    for (int e = threadIdx.x; e < 16 * 256; e += 256) {
-        const int bb = e >> 8;
-        x[bb][e & 255] = b0 + bb < batch ? d2[(size_t)(b0 + bb) * 256 + (e & 255)] : 0.f;
-    }
-    __syncthreads();
     const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int n = min(blockIdx.x * 64 + col, n3 - 1);
+    // Everything this thread needs from memory is requested before anything is waited for: the 64 weights of its column and
+    // K slice, its 16 inputs of the row tile, the bias.  The launch is L2 round trips, not arithmetic: with eight weight
+    // loads in flight per thread it took 22 us, with all of them 14, and with the row tile's request under them too ...
+    float wv[64], xin[16];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wv[k] = V2[(size_t)(ks * 64 + k) * n3 + n];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xin[q] = b0 + q < batch ? d2[(size_t)(b0 + q) * 256 + threadIdx.x] : 0.f;
+    const float c = c2[n];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q][threadIdx.x] = xin[q];
+    __syncthreads();
     float acc[16] = {};
-#pragma unroll 8
-    for (int k = ks * 64; k < ks * 64 + 64; k += 4) {   // (32 weight loads in flight: the launch is L2 round trips, not arithmetic)
-        const float w0 = V2[(size_t)k * n3 + n], w1 = V2[(size_t)(k + 1) * n3 + n];
-        const float w2 = V2[(size_t)(k + 2) * n3 + n], w3 = V2[(size_t)(k + 3) * n3 + n];
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb) {
-            const float4 xv = *reinterpret_cast<const float4 *>(&x[bb][k]);
-            acc[bb] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[bb]))));
+            const float4 xv = *reinterpret_cast<const float4 *>(&x[bb][ks * 64 + k]);
+            acc[bb] = fmaf(xv.w, wv[k + 3], fmaf(xv.z, wv[k + 2], fmaf(xv.y, wv[k + 1], fmaf(xv.x, wv[k], acc[bb]))));
         }
     }
     if (ks > 0) {
@@ -419,7 +424,6 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const 
     }
     __syncthreads();
     if (ks == 0 && blockIdx.x * 64 + col < n3) {
-        const float c = c2[n];
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb)
             if (b0 + bb < batch) out[(size_t)(b0 + bb) * n3 + n] = (((acc[bb] + red[0][bb][col]) + red[1][bb][col]) + red[2][bb][col]) + c;
@@ -484,12 +488,13 @@ __device__ __forceinline__ void fc_out_bwd_w_block(const float *d2, const float 
     if (n >= n3) return;
     float acc[32] = {};
     float gs = 0.f;
-    for (int b0 = 0; b0 < batch; b0 += 10) {               // ten rows' gradients requested at once (ascending order kept)
-        float gvv[10];
+    constexpr int GB = 64;                                 // rows' gradients requested at once (ascending order kept): one round
+    for (int b0 = 0; b0 < batch; b0 += GB) {               // trip for the default batch of 50
+        float gvv[GB];
 #pragma unroll
-        for (int u = 0; u < 10; ++u) gvv[u] = g[(size_t)min(b0 + u, batch - 1) * n3 + n];
+        for (int u = 0; u < GB; ++u) gvv[u] = g[(size_t)min(b0 + u, batch - 1) * n3 + n];
 #pragma unroll
-        for (int u = 0; u < 10; ++u) {
+        for (int u = 0; u < GB; ++u) {
             if (b0 + u >= batch) break;
             const int b = b0 + u;
             const float gv = gvv[u];
@@ -530,9 +535,7 @@ __device__ __forceinline__ void fc_out_bwd_x_block(const float *g, const float *
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) {
-            float v = acc[kk][bb];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            const float v = wave_sum(acc[kk][bb]);         // (DPP: 32 x six ds_bpermute round trips were ~5 us of this block)
             if (lane == 0) red[wave][kk * 8 + bb] = v;
         }
     __syncthreads();
