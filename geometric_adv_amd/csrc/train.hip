@@ -382,6 +382,30 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float *in, const floa
     fc_fwd_block<K, RELU>(in, W, bias, out, nout, blockIdx.x);
 }
 
+// The middle decoder layer (256 -> 256, ReLU) on 1024 threads per cloud: thread = (output, K quarter), its 64 weights requested at
+// once, the four partial sums added in a fixed order.  (One thread per output walking all 256 weights in batches of 16 loads was
+// 16 dependent L2 round trips: 11.5 us for 64 K multiply-adds per cloud.)
+__global__ __launch_bounds__(1024) void fc1_fwd_kernel(const float *in, const float *W, const float *bias, float *out) {
+    __shared__ float x[256];
+    __shared__ float part[4][256];
+    const int t = threadIdx.x, o = t & 255, ks = t >> 8, b = blockIdx.x;
+    float w[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) w[k] = W[(size_t)(ks * 64 + k) * 256 + o];
+    const float bv = bias[o];
+    if (t < 256) x[t] = in[(size_t)b * 256 + t];
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; k += 2) {
+        s0 = fmaf(x[ks * 64 + k], w[k], s0);
+        s1 = fmaf(x[ks * 64 + k + 1], w[k + 1], s1);
+    }
+    part[ks][o] = s0 + s1;
+    __syncthreads();
+    if (t < 256) out[(size_t)b * 256 + t] = fmaxf((((part[0][t] + part[1][t]) + part[2][t]) + part[3][t]) + bv, 0.f);
+}
+
 // First decoder layer (blocks [0, batch)) and the tie counts of the max-pool (the remaining blocks, one per tile): both
 // need only the pooled maxima, neither needs the other.
 __global__ __launch_bounds__(256) void fc0_and_pool_count_kernel(const float *z, const float *W, const float *bias, float *out, int batch,
@@ -399,7 +423,7 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const 
     const int n = min(blockIdx.x * 64 + col, n3 - 1);
     // Everything this thread needs from memory is requested before anything is waited for: the 64 weights of its column and
     // K slice, its 16 inputs of the row tile, the bias.  The launch is L2 round trips, not arithmetic: with eight weight
-    // loads in flight per thread it took 22 us, with all of them 14, and with the row tile's request under them too ...
+    // loads in flight per thread it took 22.7 us, with all of them 14.3, and with the row tile's request under them too 11.5.
     float wv[64], xin[16];
 #pragma unroll
     for (int k = 0; k < 64; ++k) wv[k] = V2[(size_t)(ks * 64 + k) * n3 + n];
@@ -1379,7 +1403,7 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         // ---- decoder forward ----
         const float *V0 = t->params + t->L.v[0], *V1 = t->params + t->L.v[1], *V2 = t->params + t->L.v[2];
         fc0_and_pool_count_kernel<<<B + t->tiles, 256, 0, st>>>(z, V0, t->params + t->L.c[0], t->d1, B, pa);
-        fc_fwd_kernel<256, true><<<B, 256, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2, 256);
+        fc1_fwd_kernel<<<B, 1024, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2);
         fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
         GA_LAUNCH_CHECK();
         DecOutBwdArgs da;
