@@ -167,16 +167,39 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
         px[r] = own[3 * i]; py[r] = own[3 * i + 1]; pz[r] = own[3 * i + 2];
     }
     double acc[NF][SW_R] = {};
+    // A tile of the other cloud travels global -> registers -> LDS, and the NEXT tile's loads are issued before the walk over the
+    // current one (the walk reads LDS only, so they land while it runs): at m = 2048 the second tile's round trip (~2 us of a
+    // ~40 us workgroup) is no longer exposed.
+    constexpr int SW_PER = SW_TILE / SW_THREADS;            // points per thread and tile
+    float qx[SW_PER], qy[SW_PER], qz[SW_PER];
+    double qf0[SW_PER], qf1[SW_PER];
+    auto request = [&](int t0) {
+        const int cnt = min(SW_TILE, n_oth - t0);
+#pragma unroll
+        for (int k = 0; k < SW_PER; ++k) {
+            int e = threadIdx.x + k * SW_THREADS;
+            e = e < cnt ? e : cnt - 1;                       // (clamped: loaded, never stored)
+            const float *q = oth + 3 * (size_t)(t0 + e);
+            qx[k] = q[0]; qy[k] = q[1]; qz[k] = q[2];
+            qf0[k] = fac0[t0 + e];
+            qf1[k] = NF == 2 ? fac1[t0 + e] : 0.0;
+        }
+    };
+    request(0);
     for (int t0 = 0; t0 < n_oth; t0 += SW_TILE) {
         const int cnt = min(SW_TILE, n_oth - t0);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += SW_THREADS) {
-            const float *q = oth + 3 * (size_t)(t0 + e);
-            st[e] = Pt{(C)q[0], (C)q[1], (C)q[2], (C)0};
-            sf[0][e] = fac0[t0 + e];
-            if (NF == 2) sf[1][e] = fac1[t0 + e];
+#pragma unroll
+        for (int k = 0; k < SW_PER; ++k) {
+            const int e = threadIdx.x + k * SW_THREADS;
+            if (e < cnt) {
+                st[e] = Pt{(C)qx[k], (C)qy[k], (C)qz[k], (C)0};
+                sf[0][e] = qf0[k];
+                if (NF == 2) sf[1][e] = qf1[k];
+            }
         }
         __syncthreads();
+        if (t0 + SW_TILE < n_oth) request(t0 + SW_TILE);
         const int per = (cnt + SW_WAVES - 1) / SW_WAVES;
         const int lo = wave * per, hi = min(cnt, lo + per);
 #pragma unroll 4
@@ -350,18 +373,38 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int 
     for (int j = 0; j < EMD_LEVELS; ++j) fl[j] = (F)t[(size_t)(n + m) * (1 + j) + k];
     float gx = 0.f, gy = 0.f, gz = 0.f;
     double cost = 0.0;
+    // A tile of the other cloud (coordinates + its eleven factors per point) travels global -> registers -> LDS, and the NEXT
+    // tile's loads are issued before the walk over the current one, which reads LDS only (as in the level sweeps above).
+    constexpr int PER = TILE / SW_THREADS;                  // points per thread and tile
+    float rqx[PER], rqy[PER], rqz[PER];
+    F rfr[PER][EMD_LEVELS];
+    auto request = [&](int t0) {
+        const int cnt = min(TILE, m - t0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            int e = threadIdx.x + u * SW_THREADS;
+            e = e < cnt ? e : cnt - 1;                       // (clamped: loaded, never stored)
+            const float *q = xyz2 + ((size_t)c * m + t0 + e) * 3;
+            rqx[u] = q[0]; rqy[u] = q[1]; rqz[u] = q[2];
+#pragma unroll
+            for (int j = 0; j < EMD_LEVELS; ++j) rfr[u][j] = (F)t[(size_t)(n + m) * (1 + j) + n + t0 + e];
+        }
+    };
+    request(0);
     for (int t0 = 0; t0 < m; t0 += TILE) {
         const int cnt = min(TILE, m - t0);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += SW_THREADS) {
-            const float *q = xyz2 + ((size_t)c * m + t0 + e) * 3;
-            qx[e] = q[0]; qy[e] = q[1]; qz[e] = q[2];
-        }
-        for (int e = threadIdx.x; e < cnt * EMD_LEVELS; e += SW_THREADS) {
-            const int j = e / cnt, l = e % cnt;
-            fr[j][l] = (F)t[(size_t)(n + m) * (1 + j) + n + t0 + l];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = threadIdx.x + u * SW_THREADS;
+            if (e < cnt) {
+                qx[e] = rqx[u]; qy[e] = rqy[u]; qz[e] = rqz[u];
+#pragma unroll
+                for (int j = 0; j < EMD_LEVELS; ++j) fr[j][e] = rfr[u][j];
+            }
         }
         __syncthreads();
+        if (t0 + TILE < m) request(t0 + TILE);
         const int per = (cnt + SW_WAVES - 1) / SW_WAVES;
         const int lo = wave * per, hi = min(cnt, lo + per);
         float cs = 0.f;
