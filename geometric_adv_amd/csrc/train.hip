@@ -500,17 +500,19 @@ __global__ void fill_f32_kernel(float *p, float v, size_t count) {
     if (e < count) p[e] = v;
 }
 
-// dV2[k][n] = sum_b d2[b][k] * g[b][n]; dc2[n] = sum_b g[b][n].  Block (bx, by) of (ceil(n3/128), 256/32), 128 threads
+// dV2[k][n] = sum_b d2[b][k] * g[b][n]; dc2[n] = sum_b g[b][n].  Block (bx, by) of (ceil(n3/64), 256/32), 256 threads = 64 columns x 4
+// groups of 8 k (was: 128 columns x 32 k on HALF the block's threads -- under one wave per SIMD, 20 us of pure latency)
+constexpr int DOW_COLS = 64;
 __device__ __forceinline__ void fc_out_bwd_w_block(const float *d2, const float *g, float *dV2, float *dc2, int batch, int n3,
                                                    const int bx, const int by) {
     extern __shared__ __align__(16) float xs[];            // [batch][32]
-    if (threadIdx.x >= 128) return;                         // (whole waves)
     const int k0 = by * 32;
-    for (int e = threadIdx.x; e < batch * 32; e += 128) xs[e] = d2[(size_t)(e >> 5) * 256 + k0 + (e & 31)];
+    for (int e = threadIdx.x; e < batch * 32; e += 256) xs[e] = d2[(size_t)(e >> 5) * 256 + k0 + (e & 31)];
     __syncthreads();
-    const int n = bx * 128 + threadIdx.x;
+    const int col = threadIdx.x & 63, kq = threadIdx.x >> 6;     // this thread: column n, k in [k0 + 8 kq, k0 + 8 kq + 8)
+    const int n = bx * DOW_COLS + col;
     if (n >= n3) return;
-    float acc[32] = {};
+    float acc[8] = {};
     float gs = 0.f;
     constexpr int GB = 64;                                 // rows' gradients requested at once (ascending order kept): one round
     for (int b0 = 0; b0 < batch; b0 += GB) {               // trip for the default batch of 50
@@ -523,48 +525,48 @@ __device__ __forceinline__ void fc_out_bwd_w_block(const float *d2, const float 
             const int b = b0 + u;
             const float gv = gvv[u];
             gs += gv;
-#pragma unroll
-            for (int kk = 0; kk < 32; kk += 4) {
-                const float4 xv = *reinterpret_cast<const float4 *>(&xs[b * 32 + kk]);
-                acc[kk] = fmaf(xv.x, gv, acc[kk]); acc[kk + 1] = fmaf(xv.y, gv, acc[kk + 1]);
-                acc[kk + 2] = fmaf(xv.z, gv, acc[kk + 2]); acc[kk + 3] = fmaf(xv.w, gv, acc[kk + 3]);
-            }
+            const float4 x0 = *reinterpret_cast<const float4 *>(&xs[b * 32 + 8 * kq]), x1 = *reinterpret_cast<const float4 *>(&xs[b * 32 + 8 * kq + 4]);
+            acc[0] = fmaf(x0.x, gv, acc[0]); acc[1] = fmaf(x0.y, gv, acc[1]); acc[2] = fmaf(x0.z, gv, acc[2]); acc[3] = fmaf(x0.w, gv, acc[3]);
+            acc[4] = fmaf(x1.x, gv, acc[4]); acc[5] = fmaf(x1.y, gv, acc[5]); acc[6] = fmaf(x1.z, gv, acc[6]); acc[7] = fmaf(x1.w, gv, acc[7]);
         }
     }
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) dV2[(size_t)(k0 + kk) * n3 + n] = acc[kk];
-    if (by == 0) dc2[n] = gs;
+    for (int kk = 0; kk < 8; ++kk) dV2[(size_t)(k0 + 8 * kq + kk) * n3 + n] = acc[kk];
+    if (by == 0 && kq == 0) dc2[n] = gs;
 }
 
-// dd2[b][k] = [d2[b][k] > 0] * sum_n g[b][n] * V2[k][n]; block (bx, by) of (256/4, ceil(B/8)), 256 threads
+// dd2[b][k] = [d2[b][k] > 0] * sum_n g[b][n] * V2[k][n]; block (bx, by) of (256/DOX_K, ceil(B/DOX_B)), 256 threads striding n.
+// A block streams DOX_K rows of V2 and DOX_B rows of g: 8 x 8 tiles move 88 MB through L2 in all, the earlier 4 x 8 tiles 131 MB
+// (8 x 16: 75 MB but 128 accumulators per thread on 128 blocks: 40 us).
+constexpr int DOX_K = 8, DOX_B = 8;
 __device__ __forceinline__ void fc_out_bwd_x_block(const float *g, const float *V2, const float *d2, float *dd2, int batch, int n3,
                                                    const int bx, const int by) {
-    __shared__ float red[4][32];
-    const int k0 = bx * 4, b0 = by * 8;
-    float acc[4][8] = {};
-#pragma unroll 4
+    __shared__ float red[4][DOX_K * DOX_B];
+    const int k0 = bx * DOX_K, b0 = by * DOX_B;
+    float acc[DOX_K][DOX_B] = {};
+#pragma unroll 2
     for (int n = threadIdx.x; n < n3; n += 256) {
-        float w[4], gv[8];
+        float w[DOX_K], gv[DOX_B];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) w[kk] = V2[(size_t)(k0 + kk) * n3 + n];
+        for (int kk = 0; kk < DOX_K; ++kk) w[kk] = V2[(size_t)(k0 + kk) * n3 + n];
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) gv[bb] = b0 + bb < batch ? g[(size_t)(b0 + bb) * n3 + n] : 0.f;
+        for (int bb = 0; bb < DOX_B; ++bb) gv[bb] = g[(size_t)min(b0 + bb, batch - 1) * n3 + n];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < DOX_K; ++kk)
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) acc[kk][bb] = fmaf(w[kk], gv[bb], acc[kk][bb]);
+            for (int bb = 0; bb < DOX_B; ++bb) acc[kk][bb] = fmaf(w[kk], gv[bb], acc[kk][bb]);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int kk = 0; kk < DOX_K; ++kk)
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            const float v = wave_sum(acc[kk][bb]);         // (DPP: 32 x six ds_bpermute round trips were ~5 us of this block)
-            if (lane == 0) red[wave][kk * 8 + bb] = v;
+        for (int bb = 0; bb < DOX_B; ++bb) {
+            const float v = wave_sum(acc[kk][bb]);         // (DPP: six ds_bpermute round trips per value were ~5 us of this block)
+            if (lane == 0) red[wave][kk * DOX_B + bb] = v;
         }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        const int kk = threadIdx.x >> 3, bb = threadIdx.x & 7;
+    if (threadIdx.x < DOX_K * DOX_B) {
+        const int kk = threadIdx.x / DOX_B, bb = threadIdx.x % DOX_B;
         if (b0 + bb < batch) {
             const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
             const size_t o = (size_t)(b0 + bb) * 256 + k0 + kk;
@@ -581,10 +583,10 @@ struct DecOutBwdArgs {
 };
 
 __global__ __launch_bounds__(256) void dec_out_bwd_kernel(DecOutBwdArgs A) {
-    const int wx = cdiv_dev(A.n3, 128), nw = wx * 8, nx = 64 * cdiv_dev(A.batch, 8);
+    const int wx = cdiv_dev(A.n3, DOW_COLS), nw = wx * 8, nxk = 256 / DOX_K, nx = nxk * cdiv_dev(A.batch, DOX_B);
     const int blk = blockIdx.x;
     if (blk < nw) fc_out_bwd_w_block(A.d2, A.g, A.dV2, A.dc2, A.batch, A.n3, blk % wx, blk / wx);
-    else if (blk < nw + nx) fc_out_bwd_x_block(A.g, A.V2, A.d2, A.dd2, A.batch, A.n3, (blk - nw) % 64, (blk - nw) / 64);
+    else if (blk < nw + nx) fc_out_bwd_x_block(A.g, A.V2, A.d2, A.dd2, A.batch, A.n3, (blk - nw) % nxk, (blk - nw) / nxk);
     else chamfer_loss_block(A.dist1, A.dist2, A.count, A.inv, A.loss);
 }
 
@@ -1429,7 +1431,7 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         // ---- decoder backward: three launches, each = weight gradient + data gradient of one layer side by side ----
         da.d2 = t->d2; da.g = t->g_recon; da.V2 = V2; da.dV2 = t->grads + t->L.v[2]; da.dc2 = t->grads + t->L.c[2]; da.dd2 = t->dd2;
         da.batch = B; da.n3 = n3; da.dist1 = t->dist1; da.dist2 = t->dist2;
-        dec_out_bwd_kernel<<<cdiv(n3, 128) * 8 + 64 * cdiv(B, 8) + 1, 256, sizeof(float) * B * 32, st>>>(da);
+        dec_out_bwd_kernel<<<cdiv(n3, DOW_COLS) * 8 + (256 / DOX_K) * cdiv(B, DOX_B) + 1, 256, sizeof(float) * B * 32, st>>>(da);
         fc_bwd_kernel<true><<<256 + B, 256, 0, st>>>(t->d1, t->dd2, V1, t->grads + t->L.v[1], t->grads + t->L.c[1], t->dd1, B, 256);
         fc_bwd_kernel<false><<<128 + B, 256, 0, st>>>(z, t->dd1, V0, t->grads + t->L.v[0], t->grads + t->L.c[0], t->dz, B, 128);
         GA_LAUNCH_CHECK();
