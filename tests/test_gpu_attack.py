@@ -448,6 +448,13 @@ def test_pruned_source_distance_equals_all_pairs(setup, lr, n, sym):
         at.run(0, 12, 3)
         p = at.peek()
         outs.append((p["pert"].clone(), p["idx_a1"].clone(), p["idx_a2"].clone()))
+        # geoadv_attack_search_state: is the paired search in use, and how many clouds does it currently hand back
+        searched, handed_back = at.search_state()
+        assert searched == (prune == "always") and 0 <= handed_back <= b
+        if not searched:
+            assert handed_back == 0
+        elif lr >= 0.3:
+            assert handed_back > 0, "a step of 0.3 per iteration scatters the points out of their cells: clouds must hand themselves back"
     assert outs[0][0].abs().max() > 0
     for a, c in zip(outs[0], outs[1]):
         assert torch.equal(a, c)
