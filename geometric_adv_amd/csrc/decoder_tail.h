@@ -99,6 +99,8 @@ __device__ __forceinline__ void decoder_bwd_tail_body(const DeviceAE &A, int bat
             for (int q = 1; q < 8; ++q) r += part[q][t];
             dz[(size_t)b * 128 + t] = r;
         }
+        // (The fences are not decoration: the dense blocks may run on another XCD, whose L2 is not coherent with this one inside a
+        // launch -- tools/handoff_probe.py: plain loads across XCDs returned stale data in 32 736 of 32 768 reads.)
         if (ready && is_dense_all(ja, b)) {   // rare: a tied cloud -- publish dz for the dense blocks of this launch (agent scope)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
             __syncthreads();                                       // ... before ONE lane releases and raises the flag
