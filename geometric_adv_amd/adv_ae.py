@@ -163,6 +163,11 @@ class AdvAE:
                                                          _lib.ptr(recon), _lib.stream_handle()), "attack_get_best")
         return metrics, adv, recon
 
+    def status(self):
+        """Raises GeoAdvError if an in-launch hand-off of the loop timed out since the last set_inputs / init_pert (synchronises)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_attack_status(self._h, _lib.stream_handle()), "attack_status")
+
     def peek(self):
         """Current device state (test introspection): dict of GPU tensors."""
         B, n, dev = self.B, self.n, self.device
@@ -293,7 +298,8 @@ class AdvAE:
             self.init_pert(init_pert)
             self.run(0, c.num_iterations, c.num_iterations_thresh, hist)
             m_, a_, r_ = self.get_best(target_ae_loss_ref)
-            h = hist.cpu().numpy()                                   # the only host sync of the run
+            self.status()                                            # the host sync of the run; raises if a hand-off ever timed out
+            h = hist.cpu().numpy()
             self.last_history.append(h)
             step = (c.num_iterations // 10) or 1
             for it in range(c.num_iterations):

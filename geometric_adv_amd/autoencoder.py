@@ -120,6 +120,71 @@ class PointNetAE:
 
     get_latent_vectors = transform
 
+    def decode(self, z):
+        """autoencoder.py:191-194: latent codes (k,128) or one code (128,) -> reconstructions (k,n,3) as numpy.  Decoder half of
+        the fused forward through geoadv_ae_decode: decode(transform(X)) == reconstruct(X)[0] bit for bit."""
+        return self.decode_tensor(z).cpu().numpy()
+
+    def decode_tensor(self, z):
+        z = torch.as_tensor(np.asarray(z, dtype=np.float32)) if not isinstance(z, torch.Tensor) else z
+        z = z.to(self.device, dtype=torch.float32)
+        if z.dim() == 1:                                          # single example
+            z = z[None]
+        z = z.contiguous()
+        if z.dim() != 2 or z.shape[1] != self.bneck:
+            raise ValueError("latent codes must be of shape (batch, %d); got %s" % (self.bneck, tuple(z.shape)))
+        b = z.shape[0]
+        recon = torch.empty((b, self.n_points, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            need = _lib.lib().geoadv_ae_workspace_bytes(self._h, b)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            st = _lib.lib().geoadv_ae_decode(self._h, b, _lib.ptr(z), _lib.ptr(recon), _lib.ptr(self._ws), _lib.stream_handle())
+        _lib.check(st, "ae_decode")
+        return recon
+
+    def interpolate(self, x, y, steps):
+        """autoencoder.py:178-189: decode `steps + 2` codes on the segment between the codes of clouds x and y (n,3).
+        The reference forms the codes in a float64 numpy array and feeds them to the float32 placeholder; so does this."""
+        z1, z2 = self.transform(np.stack([np.asarray(x, np.float32), np.asarray(y, np.float32)]))
+        all_z = np.zeros((steps + 2, len(z1)))
+        for i, alpha in enumerate(np.linspace(0, 1, steps + 2)):
+            all_z[i, :] = (alpha * z2) + ((1.0 - alpha) * z1)
+        return self.decode(all_z.astype(np.float32))
+
+    def get_reconstructions(self, pclouds, batch_size=50):
+        """autoencoder.py:296-307: reconstructions of (N,K,3) clouds, fed `batch_size` at a time like the reference (the result
+        does not depend on the chunking: every cloud is reconstructed on its own)."""
+        out = [self.forward(pclouds[s:s + batch_size])[0].cpu().numpy() for s in range(0, len(pclouds), batch_size)]
+        return np.vstack(out)
+
+    def get_loss(self, X, GT=None):
+        """autoencoder.py:140-148 with the loss of pointnet_ae.py:75-79: reduce_mean(dist1) + reduce_mean(dist2) of
+        nn_distance(reconstruct(X), GT or X) over the whole batch, a python float."""
+        recon, _ = self.forward(X)
+        d1, _, d2, _ = ops.nn_distance(recon, self._as_dev(X if GT is None else GT))
+        return float((d1.mean() + d2.mean()).item())
+
+    def gradient_of_input_wrt_loss(self, in_points, gt_points=None):
+        """pointnet_ae.py:140-143: tf.gradients(self.loss, self.x) -- d [reduce_mean(dist1) + reduce_mean(dist2)] / d in_points,
+        a list with one (b,n,3) array.  Evaluated by the attack loop's own backward (one iteration at learning rate 0 with a
+        zero perturbation and zero distance weight: its gradient of sum_b loss_ae[b], divided by the batch)."""
+        from .adv_ae import AdvAE, Configuration
+        x = self._as_dev(in_points)
+        gt = x if gt_points is None else self._as_dev(gt_points)
+        b = x.shape[0]
+        if not hasattr(self, "_grad_handles"):
+            self._grad_handles = {}
+        at = self._grad_handles.get(b)
+        if at is None:
+            at = AdvAE("gradient", Configuration(batch_size=b, n_points=self.n_points, weights=None, learning_rate=0.0,
+                                                 num_iterations=1, num_iterations_thresh=2), device=self.device, ae=self)
+            self._grad_handles[b] = at
+        at.set_inputs(x, gt, None, 0.0)
+        at.init_pert(torch.zeros_like(x), reset_optimizer=True)
+        at.run(0, 1, 2)
+        return [(at.peek()["grad"] / float(b)).cpu().numpy()]
+
     def loss_per_pc_tensor(self, recon, gt):
         d1, _, d2, _ = ops.nn_distance(recon, gt)
         return d1.mean(1) + d2.mean(1)                      # pointnet_ae.py:75-79 / adv_ae.py:120-121

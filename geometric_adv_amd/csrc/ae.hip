@@ -13,6 +13,7 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
 int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
+int launch_latent_fc(const DeviceAE &A, int b, const float *z, float *d2, hipStream_t stream);
 int encoder_tiles_max(int n);
 
 static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -224,4 +225,16 @@ extern "C" int geoadv_ae_critical(const geoadv_ae *ae, int b, const float *pc, f
     if (latent) GA_HIP(hipMemcpyAsync(latent, s.z, sizeof(float) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
     if (arg_idx) GA_HIP(hipMemcpyAsync(arg_idx, s.crit, sizeof(int) * (size_t)b * 128, hipMemcpyDeviceToDevice, st));
     return GEOADV_OK;
+}
+
+extern "C" int geoadv_ae_decode(const geoadv_ae *ae, int b, const float *latent, float *recon, void *workspace, void *stream) {
+    GA_REQUIRE(ae && b >= 0, "ae_decode: bad arguments");
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(latent && recon && workspace, "ae_decode: null pointer");
+    GA_REQUIRE(b <= 65535, "ae_decode: batch %d exceeds 65535", b);
+    hipStream_t st = as_stream(stream);
+    void *aligned = reinterpret_cast<void *>(rup(reinterpret_cast<size_t>(workspace), 256));
+    ForwardScratch s = carve_forward_scratch(aligned, b, ae->d.n_points);
+    if (int rc = launch_latent_fc(ae->d, b, latent, s.d2, st)) return rc;
+    return launch_decoder_fc2(ae->d, b, s.d2, recon, st);
 }

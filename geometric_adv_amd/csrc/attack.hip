@@ -739,6 +739,14 @@ int do_step(geoadv_attack *at, hipStream_t st) {
         if (at->jac_valid) {
             // the tail applies the Jacobian; the dense recomputing backward for clouds with a tied pool maximum shares its launch
             // (decoder_tail_dense_kernel) and waits, for such clouds only, on the tail block's flag
+            // -- as long as the launch's dense blocks (2 n / 32, a CU's LDS each) and tail blocks all fit the chip at once: a
+            // dense block spins on a flag only a tail block raises, and nothing orders their dispatch in general.  Larger
+            // clouds take the two plain launches (tail with the Jacobian's apply, then the dense blocks: + one boundary).
+            if (B + 2 * cdiv(n, 32) > kCUs) {
+                if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st, at->fs.crit, at->jac,
+                                                at->fs.dense, at->g_enc)) return rc;
+                if (int rc = launch_encoder_bwd_dense(A, B, at->adv, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, st)) return rc;
+            } else {
             if (int rc = launch_decoder_fc2_bwd(A, B, at->g_recon, at->dec_partial, st)) return rc;
             TailDenseArgs ta;
             ta.batch = B; ta.chunks = decoder_bwd_chunks(A); ta.n = n;
@@ -747,6 +755,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
             ta.adv = at->adv; ta.z = at->fs.z; ta.zcnt = at->fs.zcnt; ta.dense_flag = at->fs.dense; ta.g_enc = at->g_enc;
             ta.ready = at->tail_ready; ta.epoch = ++at->tail_epoch; ta.spin_timeout = reinterpret_cast<int *>(at->tail_ready + B);
             if (int rc = launch_decoder_tail_dense(A, ta, st)) return rc;
+            }
         } else if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st)) return rc;
     }
     if (!(adv_chamfer && at->jac_valid)) {
@@ -878,14 +887,14 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     // B = 1 and 0.0758 / 0.0767 at B = 4 without / with it, 0.0977 / 0.0929 at B = 8 -- so it is only used above that
     // (at B = 5 the two-scan launch needs a third round of workgroups: 0.0908 without, 0.0846 with the search + symmetric scan).
     // (all_pairs_source_dist 2 = the search whatever the size: the parity tests' small shapes)
-    at->chamfer_prune = cfg->all_pairs_source_dist == 2 || (cfg->all_pairs_source_dist == 0 && (long)at->B * at->n >= 10240);
+    at->chamfer_prune = cfg->all_pairs_source_dist == 2 || (cfg->all_pairs_source_dist == 0 && (long)at->B * at->n >= GEOADV_SMALL_BATCH_POINTS);
     {
         // The symmetric scan + its finish launch against the public op's plain scans in ONE launch (both directions of (recon,
         // target), and of (adv, source) only for clouds the grid search handed back).  Since the grid search and the encoder's
         // pool Jacobian ride in the symmetric scan's launch (round 3) it wins from B = 5 on (ms per iteration, plain /
         // symmetric: B = 4: 0.0748 / 0.0757, 8: 0.0935 / 0.0925, 12: 0.1143 / 0.1055, 16: 0.1263 / 0.1252, 24: 0.1673 / 0.1529,
         // 32: 0.1913 / 0.1773; later build, B = 4: 0.0749 / 0.0743, 5: 0.0909 / 0.0846, 6: 0.0916 / 0.0850); below, launches are fixed latency and the plain form has one fewer.  Same bits either way.
-        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n >= 10240
+        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n >= GEOADV_SMALL_BATCH_POINTS
                                                                      : cfg->chamfer_kernel == GEOADV_CHAMFER_SYMMETRIC;
     }
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;
@@ -935,6 +944,7 @@ extern "C" int geoadv_attack_set_inputs(geoadv_attack *at, const float *source_p
     if (int rc = launch_chamfer_grid_box(at->x, at->B, at->n, at->x_box, st)) return rc;   // grid of the paired nn search
     for (int i = 0; i < 2; ++i)                                                            // new clouds: every verdict is open again
         GA_HIP(hipMemsetAsync(at->need_adv[i], 0, sizeof(int) * 8 * (size_t)at->B, st));
+    GA_HIP(hipMemsetAsync(at->tail_ready + at->B, 0, sizeof(unsigned), st));               // a new run starts without a failure on record
     at->fwd_valid = false; at->adv_valid = false;
     return GEOADV_OK;
 }
@@ -944,6 +954,7 @@ extern "C" int geoadv_attack_init_pert(geoadv_attack *at, const float *init_pert
     hipStream_t st = as_stream(stream);
     const size_t bn3 = (size_t)at->B * at->n * 3;
     at->adam_pending = false;                          // (a step that never reached its forward is dropped with the old pert)
+    GA_HIP(hipMemsetAsync(at->tail_ready + at->B, 0, sizeof(unsigned), st));
     GA_HIP(hipMemcpyAsync(at->pert, init_pert, 4 * bn3, hipMemcpyDeviceToDevice, st));
     if (reset_optimizer) {
         GA_HIP(hipMemsetAsync(at->m, 0, 4 * bn3, st));
@@ -991,6 +1002,21 @@ extern "C" int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_
     }
     if (adv) GA_HIP(hipMemcpyAsync(adv, at->best_adv, 4 * bn3, hipMemcpyDeviceToDevice, st));
     if (recon) GA_HIP(hipMemcpyAsync(recon, at->best_recon, 4 * bn3, hipMemcpyDeviceToDevice, st));
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_attack_status(geoadv_attack *at, void *stream) {
+    GA_REQUIRE(at, "attack_status: null handle");
+    hipStream_t st = as_stream(stream);
+    int failed = 0;
+    GA_HIP(hipMemcpyAsync(&failed, at->tail_ready + at->B, sizeof(int), hipMemcpyDeviceToHost, st));
+    GA_HIP(hipStreamSynchronize(st));
+    if (failed) {
+        set_error("attack: an in-launch hand-off (decoder backward tail -> dense encoder backward of a cloud with a tied pool "
+                  "maximum) timed out since the last set_inputs / init_pert; iterations after it used a stale latent gradient -- "
+                  "the results of this run are invalid");
+        return GEOADV_EHIP;
+    }
     return GEOADV_OK;
 }
 

@@ -111,6 +111,26 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
     GA_STAMP(0, 7);
 }
 
+// AutoEncoder.decode (src/autoencoder.py:191-194): the decoder fed with a GIVEN latent code -- FC0 + FC1 exactly as in
+// latent_decode_block (same split, same order of the partial sums: decode(transform(x)) equals reconstruct(x) bit for bit).
+__global__ __launch_bounds__(LD_THREADS) void latent_fc_kernel(DeviceAE A, const float *z, float *d2) {
+    __shared__ float zs[128];
+    __shared__ float hs[256];
+    __shared__ float part[4][256];
+    const int t = threadIdx.x, b = blockIdx.x;
+    if (t < 128) zs[t] = z[(size_t)b * 128 + t];
+    __syncthreads();
+    {
+        const float s = fc256_split4<128, LD_THREADS>(zs, A.v0, part);
+        if (t < 256) hs[t] = fmaxf(s + A.c0[t], 0.f);
+    }
+    __syncthreads();
+    {
+        const float s = fc256_split4<256, LD_THREADS>(hs, A.v1, part);
+        if (t < 256) d2[(size_t)b * 256 + t] = fmaxf(s + A.c1[t], 0.f);
+    }
+}
+
 __global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
                                                                    const int *pcnt, float *z, int *crit, int *zcnt,
                                                                    int *dense, float *d1, float *d2) {
@@ -282,6 +302,13 @@ int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, c
     else
         latent_decode_and_grid_kernel<GR_THREADS><<<blocks, GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
             A, encoder_tiles(b, A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+int launch_latent_fc(const DeviceAE &A, int b, const float *z, float *d2, hipStream_t stream) {
+    if (b <= 0) return GEOADV_OK;
+    latent_fc_kernel<<<b, LD_THREADS, 0, stream>>>(A, z, d2);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -741,8 +741,10 @@ int launch_encoder_jac(const DeviceAE &A, int b, const JacArgs &a, hipStream_t s
 // blocks [batch, ...) = 32-row dense tiles (their upper eight waves leave at once) dealt to DENSE_SLOTS block rows.  A dense
 // block needs dz of its cloud, which a tail block of the SAME launch produces: it waits for that block's flag -- only where a
 // cloud IS tied (duplicated points; almost never), otherwise it leaves after one look at the flags and the launch costs what
-// the tail alone costs, where a dense launch of its own was 4.1 us + a boundary on every step.  No deadlock by construction:
-// tail blocks never wait, and the dense blocks (<= 2 n / 32) each need a whole CU's LDS, so they cannot occupy the chip.
+// the tail alone costs, where a dense launch of its own was 4.1 us + a boundary on every step.  Progress: tail blocks never
+// wait; a dense block holds a whole CU's LDS, and the caller (attack.hip, do_step) only uses this launch while batch + 2 n / 32
+// workgroups fit the 256 CUs at once, so every tail block is resident whatever the dispatch order -- larger clouds take two
+// plain launches.  The spin is bounded all the same; a timeout sets a word that geoadv_attack_status reports as GEOADV_EHIP.
 constexpr int TD_DENSE_ROWS = 32, TD_DENSE_SLOTS = 2;
 
 __global__ __launch_bounds__(LD_THREADS) void decoder_tail_dense_kernel(DeviceAE A, TailDenseArgs a) {

@@ -134,20 +134,33 @@ __global__ __launch_bounds__(64) void knn_redo_kernel(int n, int m, int k, const
 // reference's whatever it does with ties (the sorted k smallest distances are what they are); the INDICES are the
 // reference's whenever no two of the k + 1 smallest distances are equal -- then the selection is unique.  A query with
 // such a tie (duplicated points), or one that meets a NaN / infinite distance, is put on a list and redone by the
-// selection-sort kernel below, which reproduces the reference's swap order.  Visiting the dataset in ascending index
+// selection-sort kernel above, which reproduces the reference's swap order.  Visiting the dataset in ascending index
 // with strict '<' keeps equal distances in index order, so the tie test only has to look at neighbours in the list.
 //   MODE 0: val/idx of the k nearest (S >= k + 1: one extra slot for the tie test).
 //   MODE 1: sqrt of sorted distances 1..k-1 (the defender's graph; independent of the order among ties, S >= k).
-// The ~k ln(n/k) insertions per query are rare per lane but not per wave (64 lanes), so the insertion is a branch-free
-// shift of all S slots behind one wave-level branch.
+//
+// DEFERRED insertion (round 4).  A lane meets ~k ln(n/k) list updates along the scan, the 64 lanes of a wave meet them at
+// different points: with the update inline (rounds 1-3) two steps of three ran the whole S-slot shift for one or two live
+// lanes -- 2.7 x the cost of the distances themselves (0.63 ms at 256 x 2048 x 2048, k = 8).  Now a lane only APPENDS a
+// candidate (distance below its threshold `thr`, which is the list's last entry as of the last drain) to its own LDS queue --
+// one masked ds_write -- and the queues are DRAINED into the lists together: every KF_DRAIN points, and whenever some lane's
+// queue is nearly full.  A drain step runs the shift once for up to 64 lanes that all have work.  The result is the inline
+// form's bit for bit: a lane's queue holds its candidates in ascending index, the drain applies the same strict '<' to each,
+// and a candidate admitted by a stale threshold that the current list no longer admits is dropped by that test.
+// `!(d >= thr)` admits NaN distances too (they mark the query for the redo kernel at the drain); the LDS pad is +inf
+// coordinates: distance +inf, never admitted.
 // ------------------------------------------------------------------------------------------
 constexpr int KF_THREADS = 256;
 constexpr int KF_TILE = 1024;
+constexpr int KF_QCAP = 16;                // queue slots per lane
+constexpr int KF_DRAIN = 128;              // scheduled drain period (points)
 
 template <int MODE, int S>
 __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int k, const float *xyz1, const float *xyz2,
                                                               float *val_out, int *idx_out, int *redo) {
     __shared__ __attribute__((aligned(16))) float sx[KF_TILE], sy[KF_TILE], sz[KF_TILE];
+    __shared__ float qd[KF_QCAP * KF_THREADS];                       // slot-major: lane-consecutive addresses, no bank conflicts
+    __shared__ int qi[MODE == 0 ? KF_QCAP * KF_THREADS : 1];
     const int c = blockIdx.y;
     const float *data = xyz1 + (size_t)c * n * 3;
     const int q = blockIdx.x * KF_THREADS + threadIdx.x;
@@ -159,37 +172,77 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
 #pragma unroll
     for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
     bool odd = false;                                      // met a NaN distance
+    float thr = INFINITY;                                  // v[S - 1] as of the last drain
+    int qn = 0;                                            // candidates waiting in this lane's queue
+
+    auto drain = [&]() {
+        for (int j = 0; __any(j < qn); ++j) {
+            const bool has = j < qn;
+            const float d = has ? qd[j * KF_THREADS + threadIdx.x] : INFINITY;
+            int id = 0;
+            if (MODE == 0) id = has ? qi[j * KF_THREADS + threadIdx.x] : 0;
+            odd |= d != d;
+            if (MODE == 1) {                               // values only: a compare-exchange chain on the BIT PATTERNS -- distances are
+                unsigned x = __float_as_uint(d);           // sums of squares (>= +0, or +inf), for which unsigned order = float order; no
+#pragma unroll                                             // selects, no moves, no canonicalising v_max (a NaN only ever marks the query `odd`)
+                for (int i = 0; i < S; ++i) {
+                    const unsigned vi = __float_as_uint(v[i]);
+                    const unsigned lo = min(vi, x);
+                    x = max(vi, x);
+                    v[i] = __uint_as_float(lo);
+                }
+            } else if (__any(d < v[S - 1])) {
+                bool cl[S];
+#pragma unroll
+                for (int i = 0; i < S; ++i) cl[i] = d < v[i];
+#pragma unroll
+                for (int i = S - 1; i > 0; --i) {
+                    v[i] = cl[i - 1] ? v[i - 1] : (cl[i] ? d : v[i]);
+                    if (MODE == 0) ix[i] = cl[i - 1] ? ix[i - 1] : (cl[i] ? id : ix[i]);
+                }
+                if (cl[0]) { v[0] = d; if (MODE == 0) ix[0] = id; }
+            }
+        }
+        qn = 0;
+        thr = v[S - 1];
+    };
+
     for (int t0 = 0; t0 < n; t0 += KF_TILE) {
         const int cnt = min(KF_TILE, n - t0);
         __syncthreads();
         for (int e = threadIdx.x; e < KF_TILE; e += KF_THREADS) {
-            const bool in = e < cnt;                       // the pad never enters a list: NaN compares false
-            sx[e] = in ? data[3 * (size_t)(t0 + e)] : NAN; sy[e] = in ? data[3 * (size_t)(t0 + e) + 1] : NAN;
-            sz[e] = in ? data[3 * (size_t)(t0 + e) + 2] : NAN;
+            const bool in = e < cnt;                       // the pad is never admitted: its distance is +inf
+            sx[e] = in ? data[3 * (size_t)(t0 + e)] : INFINITY; sy[e] = in ? data[3 * (size_t)(t0 + e) + 1] : INFINITY;
+            sz[e] = in ? data[3 * (size_t)(t0 + e) + 2] : INFINITY;
         }
         __syncthreads();
-        for (int e0 = 0; e0 < cnt; e0 += 4) {
-            const float4 xa = *reinterpret_cast<const float4 *>(&sx[e0]);
-            const float4 ya = *reinterpret_cast<const float4 *>(&sy[e0]);
-            const float4 za = *reinterpret_cast<const float4 *>(&sz[e0]);
-            const float tx[4] = {xa.x, xa.y, xa.z, xa.w}, ty[4] = {ya.x, ya.y, ya.z, ya.w}, tz[4] = {za.x, za.y, za.z, za.w};
+        for (int e1 = 0; e1 < cnt; e1 += KF_DRAIN) {
+            const int e1_end = min(cnt, e1 + KF_DRAIN);
+            for (int e0 = e1; e0 < e1_end; e0 += 4) {
+                const float4 xa = *reinterpret_cast<const float4 *>(&sx[e0]);
+                const float4 ya = *reinterpret_cast<const float4 *>(&sy[e0]);
+                const float4 za = *reinterpret_cast<const float4 *>(&sz[e0]);
+                const float tx[4] = {xa.x, xa.y, xa.z, xa.w}, ty[4] = {ya.x, ya.y, ya.z, ya.w}, tz[4] = {za.x, za.y, za.z, za.w};
+                float d[4];
+                bool adm[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float dx = tx[u] - qx, dy = ty[u] - qy, dz = tz[u] - qz;
-                const float d = (dx * dx + dy * dy) + dz * dz;                      // tf_grouping.py:68, left to right
-                if (e0 + u < cnt) odd |= d != d;
-                if (d < v[S - 1]) {
-                    bool cl[S];
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = tx[u] - qx, dy = ty[u] - qy, dz = tz[u] - qz;
+                    d[u] = (dx * dx + dy * dy) + dz * dz;                            // tf_grouping.py:68, left to right
+                    adm[u] = !(d[u] >= thr);
+                }
+                if (__any(adm[0] | adm[1] | adm[2] | adm[3])) {
 #pragma unroll
-                    for (int i = 0; i < S; ++i) cl[i] = d < v[i];
-#pragma unroll
-                    for (int i = S - 1; i > 0; --i) {
-                        v[i] = cl[i - 1] ? v[i - 1] : (cl[i] ? d : v[i]);
-                        if (MODE == 0) ix[i] = cl[i - 1] ? ix[i - 1] : (cl[i] ? t0 + e0 + u : ix[i]);
-                    }
-                    if (cl[0]) { v[0] = d; if (MODE == 0) ix[0] = t0 + e0 + u; }
+                    for (int u = 0; u < 4; ++u)
+                        if (adm[u]) {
+                            qd[qn * KF_THREADS + threadIdx.x] = d[u];
+                            if (MODE == 0) qi[qn * KF_THREADS + threadIdx.x] = t0 + e0 + u;
+                            ++qn;
+                        }
+                    if (__any(qn > KF_QCAP - 4)) drain();
                 }
             }
+            drain();
         }
     }
     if (!live) return;

@@ -21,13 +21,25 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+_EXERCISE_ONE_RANK = False      # init(single_rank_group=True): the caller WANTS a one-rank group's collectives to run through the backend
+
+
+def _active():
+    """True where a collective has something to do: several ranks, or a one-rank group brought up to exercise the backend.  A
+    one-rank group somebody else initialised (world == 1) keeps the no-op fast path."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _EXERCISE_ONE_RANK)
+
+
 def init(backend=None, single_rank_group=False, timeout_s=None):
     """Initialise torch.distributed from the environment if WORLD_SIZE > 1.  Returns (rank, world, local_rank).
 
-    single_rank_group: also create a group when WORLD_SIZE is 1 (rendezvous on a private TCP port of 127.0.0.1) -- the
+    single_rank_group: also create a group when WORLD_SIZE is 1 (file-store rendezvous in a fresh temporary directory) -- the
     collectives below then really run through the backend (RCCL accepts ONE rank per device, so this is how a 1-GPU box
     exercises librccl: tests/test_gpu_dist_rccl.py, bench.py at --gpus 1).  timeout_s: collective / rendezvous timeout."""
+    global _EXERCISE_ONE_RANK
     rank, world, local = env_rank()
+    if single_rank_group and world == 1:
+        _EXERCISE_ONE_RANK = True
     if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -40,11 +52,10 @@ def init(backend=None, single_rank_group=False, timeout_s=None):
             import datetime
             kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
         if world == 1 and "MASTER_PORT" not in os.environ:
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            kw["init_method"] = "tcp://127.0.0.1:%d" % port
+            # a one-rank group needs no network rendezvous: a file store in a fresh temporary directory (no port to pick, so no
+            # race with another process taking it between the pick and the bind)
+            import tempfile
+            kw["init_method"] = "file://" + os.path.join(tempfile.mkdtemp(prefix="geoadv_pg_"), "store")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
@@ -72,21 +83,22 @@ def shard_batches(n_batches, rank, world):
 
 
 def barrier():
-    if dist.is_initialized():
+    if _active():
         dist.barrier()
 
 
 def max_over_ranks(value, device="cpu"):
+    if not _active():
+        return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def all_reduce_sum_(t):
     """In-place sum over the ranks of a (GPU) tensor: RCCL directly; a gloo group (CPU tests, or several ranks sharing
     one GPU) stages through host memory."""
-    if not dist.is_initialized():
+    if not _active():
         return t
     if dist.get_backend() == "gloo" and t.is_cuda:
         h = t.detach().cpu()
@@ -100,7 +112,7 @@ def all_reduce_sum_(t):
 def all_gather_examples(local, counts=None, axis=1):
     """all-gather a tensor whose `axis` is the example axis, concatenated in rank order.
     Ranks may hold different numbers of examples (pads to the maximum, trims after)."""
-    if not dist.is_initialized():
+    if not _active():
         return local
     world = dist.get_world_size()
     n_local = torch.tensor([local.shape[axis]], dtype=torch.int64, device=local.device)
@@ -134,7 +146,8 @@ def attack_sharded(adv_ae, source_pc, target_latent, target_pc, target_ae_loss_r
     other slots.  Every batch's optimum is the same problem either way; only the trajectory differs.
     "Bit for bit" holds at equal Configuration: every kernel sums a cloud's numbers in an order fixed by the cloud alone
     (tests/test_gpu_attack.py::test_trajectory_of_a_cloud_does_not_depend_on_its_batch), but encoder_backward="auto"
-    picks the masked backward for batches under 5 clouds of 2048 points and the pool Jacobian above, and those two forms
+    picks the masked backward while batch * n_points < 10240 (GEOADV_SMALL_BATCH_POINTS, include/geoadv.h: up to 4 clouds of 2048
+    points) and the pool Jacobian from there on, and those two forms
     agree to rounding only: pin encoder_backward when shards of different batch size must reproduce each other exactly."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     c = adv_ae.configuration

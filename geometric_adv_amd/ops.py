@@ -233,6 +233,60 @@ def knn_dists(pc, num_knn):
 
 
 # ---------------------------------------------------------------------------------------------
+# the defenses' per-cloud bookkeeping (src/adversary_utils.py:149-178, src/ae_utils.py:12-80), device side
+# ---------------------------------------------------------------------------------------------
+def outlier_filter(point_clouds, knn_dists, knn_dist_thresh, top_k=None, want_outliers=True):
+    """get_outlier_pc_inlier_pc(point_clouds, knn_dists, knn_dist_thresh) (adversary_utils.py:149-178) on GPU tensors ->
+    (outlier_pc (b,n,3), outlier_idx (b,n) int16, outlier_num (b,) int16, inlier_pc (b,n,3)).
+    knn_dists (b,n): the per-point scalar the reference function thresholds; or (b,n,k) with top_k: the kernel then forms
+    the mean of the first top_k distances itself, as run_defense_surface.py:187-191 does with numpy.
+    want_outliers=False skips the three outlier outputs (None)."""
+    pc = _f32(point_clouds, "point_clouds", 3)
+    if pc.shape[2] != 3:
+        raise ValueError("outlier_filter only accepts 3d point sets")
+    b, n, _ = pc.shape
+    if knn_dists.dim() == 2:
+        kd, stride, top_k = _f32(knn_dists, "knn_dists", 2), 1, 1
+    else:
+        kd = _f32(knn_dists, "knn_dists", 3)
+        stride = kd.shape[2]
+        top_k = stride if top_k is None else int(top_k)
+    if tuple(kd.shape[:2]) != (b, n):
+        raise ValueError("knn_dists must be of shape (batch, num_points[, k]); got %s for clouds %s" % (tuple(kd.shape), tuple(pc.shape)))
+    inlier = torch.empty_like(pc)
+    o_pc = torch.empty_like(pc) if want_outliers else None
+    o_idx = torch.empty((b, n), dtype=torch.int16, device=pc.device) if want_outliers else None
+    o_num = torch.empty((b,), dtype=torch.int16, device=pc.device) if want_outliers else None
+    with torch.cuda.device(pc.device):
+        _call("geoadv_outlier_filter", b, n, _lib.ptr(pc), _lib.ptr(kd), int(stride), int(top_k), C.c_float(float(knn_dist_thresh)),
+              _lib.ptr(o_pc), _lib.ptr(o_idx), _lib.ptr(o_num), _lib.ptr(inlier))
+    return o_pc, o_idx, o_num, inlier
+
+
+def critical_split(point_clouds, max_val, max_idx):
+    """get_critical_pc_non_critical_pc (ae_utils.py:51-80) from (np.max, np.argmax)(pre_symmetry, axis=1) on GPU tensors ->
+    (critical_points (b,c,3), critical_idx (b,c) int16, critical_num (b,) int16, critical_pc (b,n,3), non_critical_pc (b,n,3)).
+    Critical points owning equally many channels come in descending point index (include/geoadv.h)."""
+    pc = _f32(point_clouds, "point_clouds", 3)
+    if pc.shape[2] != 3:
+        raise ValueError("critical_split only accepts 3d point sets")
+    b, n, _ = pc.shape
+    mv = _f32(max_val, "max_val", 2)
+    c = mv.shape[1]
+    if mv.shape[0] != b:
+        raise ValueError("max_val must be of shape (batch, channels)")
+    mi = _i32(max_idx, "max_idx", (b, c))
+    cp = torch.empty((b, c, 3), dtype=torch.float32, device=pc.device)
+    ci = torch.empty((b, c), dtype=torch.int16, device=pc.device)
+    cn = torch.empty((b,), dtype=torch.int16, device=pc.device)
+    cpc, ncpc = torch.empty_like(pc), torch.empty_like(pc)
+    with torch.cuda.device(pc.device):
+        _call("geoadv_critical_split", b, n, c, _lib.ptr(pc), _lib.ptr(mv), _lib.ptr(mi), _lib.ptr(cp), _lib.ptr(ci), _lib.ptr(cn),
+              _lib.ptr(cpc), _lib.ptr(ncpc))
+    return cp, ci, cn, cpc, ncpc
+
+
+# ---------------------------------------------------------------------------------------------
 # external/structural_losses/tf_approxmatch.py
 # ---------------------------------------------------------------------------------------------
 EMD_FAST, EMD_REFERENCE = 0, 1          # include/geoadv.h: how the pair weight expf(level * d2) is evaluated

@@ -143,6 +143,26 @@ int geoadv_knn_point(int b, int n, int m, int k, const float *xyz1, const float 
  * gather, euclidean distance.  out is (b,n,k). */
 int geoadv_knn_dists(int b, int n, int k, const float *pc, float *out, void *stream);
 
+/* get_outlier_pc_inlier_pc (src/adversary_utils.py:149-178) on the device, fused with the score its caller forms
+ * (defender/run_defense_surface.py:187-191: the mean of the first top_k kNN distances of a point): a point is an outlier if
+ * mean(knn_dists[b,p,0:top_k]) > thresh, an inlier if <= thresh (a NaN score is neither, as with np.where).  knn_dists is
+ * (b,n,knn_stride), 1 <= top_k <= min(knn_stride, 7); with knn_stride = top_k = 1 it is the reference function's own
+ * per-point scalar.  Outputs as the reference's: inlier_pc / outlier_pc (b,n,3) packed in point order and padded with the last
+ * packed point (zeros if none), outlier_idx (b,n) int16 zero-padded, outlier_num (b) int16.  outlier_pc / outlier_idx /
+ * outlier_num may be NULL. */
+int geoadv_outlier_filter(int b, int n, const float *pc, const float *knn_dists, int knn_stride, int top_k, float thresh,
+                          float *outlier_pc, short *outlier_idx, short *outlier_num, float *inlier_pc, void *stream);
+/* get_critical_points + get_critical_pc_non_critical_pc (src/ae_utils.py:12-80) on the device, from (max_val, max_idx) =
+ * (np.max, np.argmax)(pre_symmetry, axis=1) as geoadv_ae_critical returns them: (b,c) each.  critical_points (b,c,3) /
+ * critical_idx (b,c) int16: the distinct arg-max points of the channels with max_val > 0, the point owning most channels first,
+ * zero-padded; critical_num (b) int16; critical_pc (b,n,3): those points padded with the last of them; non_critical_pc (b,n,3):
+ * every other point in point order, padded with the last.  Points owning EQUALLY many channels come in descending point
+ * index (what a stable sort makes of the reference's np.argsort(counts)[::-1]; numpy's default sort leaves that order to the
+ * build).  Any output may be NULL.  c <= 1024, n <= 32768. */
+int geoadv_critical_split(int b, int n, int c, const float *pc, const float *max_val, const int *max_idx,
+                          float *critical_points, short *critical_idx, short *critical_num, float *critical_pc,
+                          float *non_critical_pc, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Victim auto-encoder: src/encoders_decoders.py:19-147 with the architecture of
  * src/ae_templates.py:11-39 (5 x [conv1d k=1, BN(inference), ReLU], max over points,
@@ -185,6 +205,10 @@ int geoadv_ae_critical(const geoadv_ae *ae, int b, const float *pc, float *laten
                        void *workspace, void *stream);
 int geoadv_ae_forward(const geoadv_ae *ae, int b, const float *pc, float *latent, float *recon,
                       void *workspace, void *stream);
+/* AutoEncoder.decode (src/autoencoder.py:191-194; used by interpolate, :178-189): latent[b,bneck] -> recon[b,n,3].
+ * Same arithmetic as the decoder half of geoadv_ae_forward: decode(transform(x)) == reconstruct(x) bit for bit.
+ * Same workspace as geoadv_ae_forward. */
+int geoadv_ae_decode(const geoadv_ae *ae, int b, const float *latent, float *recon, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * The attack loop: AdvAE (src/adv_ae.py:30-251) + Adversary (src/adversary.py:9-57).
@@ -207,8 +231,9 @@ typedef struct geoadv_attack_config {
     float learning_rate;            /* conf.learning_rate (adv_ae.py:146,152)                 */
     float emd_weight;               /* build-defined: loss_adv += emd_weight*match_cost/N; 0 = off */
     int   all_pairs_source_dist;    /* 0 (default): nn_distance(adv, x) by the exact paired grid search, falling back per
-                                     * cloud to the all-pairs kernel, except for tiny batches (<= 10 K points) where the
-                                     * all-pairs kernel alone is as fast; 1: always the all-pairs kernel; 2: the grid search
+                                     * cloud to the all-pairs kernel, except for tiny batches -- batch * n_points < 10240, i.e.
+                                     * up to 4 clouds of 2048 points (GEOADV_SMALL_BATCH_POINTS: the ONE threshold that also switches
+                                     * encoder_backward = AUTO and chamfer_kernel = AUTO) -- where the all-pairs kernel alone is as fast; 1: always the all-pairs kernel; 2: the grid search
                                      * at every size.  Same results.                                                      */
     int   emd_weight_mode;          /* GEOADV_EMD_FAST (0, default) or GEOADV_EMD_REFERENCE for the EMD term's plan       */
     /* Alternative code paths with the same results, selected explicitly (never by the environment); all 0 = defaults.
@@ -224,6 +249,7 @@ typedef struct geoadv_attack_config {
     int   chamfer_kernel;           /* GEOADV_CHAMFER_AUTO (0: by batch size), _TWO_SCAN (the public op's kernel),
                                      * _SYMMETRIC (one evaluation per pair serves both directions)                      */
 } geoadv_attack_config;
+#define GEOADV_SMALL_BATCH_POINTS 10240  /* batch * n_points below this: two-scan Chamfer kernel, masked encoder backward, no grid search */
 #define GEOADV_ENC_BWD_AUTO      0
 #define GEOADV_ENC_BWD_MASKED    1
 #define GEOADV_ENC_BWD_JACOBIAN  2
@@ -260,6 +286,12 @@ int geoadv_attack_run(geoadv_attack *at, int first_iteration, int iterations, in
  * (target_nre = target_recon_error / target_ae_loss_ref[b]), adv[B,N,3], recon[B,N,3]. */
 int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_loss_ref,
                            float *metrics, float *adv, float *recon, void *stream);
+
+/* Health of the run since the last set_inputs / init_pert: synchronises the stream and returns GEOADV_EHIP (message in
+ * geoadv_last_error) if an in-launch hand-off of the loop ever gave up waiting -- the bounded spin of the dense encoder backward
+ * on its cloud's decoder-tail flag; never observed, but a run after it would have used a stale gradient.  geoadv_attack_get_best
+ * additionally NaN-fills the metrics of such a run.  Callers that synchronise anyway (to download results) call this first. */
+int geoadv_attack_status(geoadv_attack *at, void *stream);
 
 /* Introspection for tests: copies of the current device state (any pointer may be NULL).
  * pert/adv/recon/grad [B,N,3]; latent [B,bneck]; idx_* [B,N] of the last forward:

@@ -363,7 +363,8 @@ def test_trajectory_of_a_cloud_does_not_depend_on_its_batch(n, form):
     pool Jacobian) uses 16-row tiles at every batch size, the Chamfer results are exact -- so the perturbation of a cloud after
     8 iterations is bit-identical whether it is attacked in a batch of 8, 32 or 40.  (What does change the bits: the backward
     FORM -- masked vs Jacobian agree to rounding, test_jacobian_backward_equals_masked_backward -- which `auto` picks by
-    batch size below / above 6 clouds of 2048 points; the bit-for-bit statements of dist.py / run_attack.py hold at equal
+    batch size -- batch * n_points below / from GEOADV_SMALL_BATCH_POINTS = 10240 (include/geoadv.h), i.e. up to 4 / from 5 clouds
+    of 2048 points; the bit-for-bit statements of dist.py / run_attack.py hold at equal
     configuration.)"""
     import torch
     from geometric_adv_amd import weights as W

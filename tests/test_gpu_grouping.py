@@ -154,10 +154,14 @@ def test_knn_dists_vs_oracle_and_defense(oracle):
     assert np.array_equal(out["defended_pc"][:, :n - 10], adv[:, 10:])
     assert np.array_equal(out["defended_pc"][:, n - 10:], np.repeat(adv[:, -1:], 10, axis=1))   # last inlier duplicated
     assert out["recon_error_vs_source"].shape == (6,)
-    # host-side packing against a direct restatement on one cloud
+    # the fused score + packing kernel against the pinned numpy restatement fed with numpy's own mean
+    from oracle.host_defense import outlier_inlier
     score = out["knn_dists"][:, :, :2].mean(2)
-    _, _, _, inl = get_outlier_pc_inlier_pc(adv, score, 0.5)
-    assert np.array_equal(inl, out["defended_pc"])
+    want = outlier_inlier(adv, score, 0.5)
+    assert np.array_equal(want[3], out["defended_pc"]) and np.array_equal(want[1], out["outlier_idx"])
+    got = get_outlier_pc_inlier_pc(adv, score, 0.5)                    # the reference function's own signature (per-point scalar)
+    for a, b_ in zip(got, want):
+        assert a.dtype == b_.dtype and np.array_equal(a, b_)
 
 
 def test_knn_full_size_properties():

@@ -56,7 +56,6 @@ def test_critical_points_match_pre_symmetry_argmax():
     (src/ae_utils.py:19-20), and the host-side bookkeeping reproduces ae_utils' outputs."""
     from geometric_adv_amd import weights as W
     from geometric_adv_amd.autoencoder import PointNetAE
-    from geometric_adv_amd.defense import get_critical_points
     from oracle.attack_model import AEModel
     from conftest import cloud
     n = 512
@@ -76,14 +75,14 @@ def test_critical_points_match_pre_symmetry_argmax():
     assert clear.sum() > 0.9 * live.sum() and live.mean() > 0.3
     assert np.array_equal(mv > 0, live)
     assert np.array_equal(mi[clear], want_idx[clear])
-    # reference bookkeeping on the model's tensor vs ours on (max, argmax)
-    cp, ci, cn = get_critical_points(pcs, mv, mi)
-    for i in range(len(pcs)):
-        nz = mi[i][mv[i] > 0]
-        u, c = np.unique(nz, return_counts=True)
-        assert cn[i] == len(u) and set(ci[i, :cn[i]].tolist()) == set(u.tolist())
-        assert np.array_equal(cp[i, :cn[i]], pcs[i][ci[i, :cn[i]]])
-        assert (np.diff(c[np.argsort(c)[::-1]]) <= 0).all()
+    # the device bookkeeping on (max, argmax) against the pinned numpy restatement, bit for bit (stable tie order)
+    from geometric_adv_amd.defense import get_critical_pc_non_critical_pc
+    from oracle.host_defense import critical_and_rest
+    got = get_critical_pc_non_critical_pc(pcs, mv, mi)
+    want = critical_and_rest(pcs, mv, mi)
+    for a, b_ in zip(got, want):
+        assert a.dtype == b_.dtype and np.array_equal(a, b_)
+    assert (got[2] > 20).all()
 
 
 def test_critical_cloud_reconstructs_identically_and_defense_runs():

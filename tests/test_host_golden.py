@@ -1,4 +1,4 @@
-"""CPU: the host-side numpy bookkeeping (attack_data.py, defense.py) against golden vectors produced by the
+"""CPU: the host-side numpy bookkeeping (attack_data.py; oracle/host_defense.py, the checker of csrc/defense.hip) against golden vectors produced by the
 reference's own function bodies (oracle/make_golden_host.py)."""
 import os
 
@@ -31,20 +31,31 @@ def test_get_quantity_at_index(g):
 
 
 def test_outlier_inlier_packing(g):
-    from geometric_adv_amd.defense import get_outlier_pc_inlier_pc
-    o_pc, o_idx, o_num, i_pc = get_outlier_pc_inlier_pc(g["out_pc"], g["out_knn"], float(g["out_thresh"]))
+    """oracle/host_defense.py (the checker of the device packing kernels) against the reference's own function body."""
+    from oracle.host_defense import outlier_inlier
+    o_pc, o_idx, o_num, i_pc = outlier_inlier(g["out_pc"], g["out_knn"], float(g["out_thresh"]))
     assert np.array_equal(o_pc, g["out_outlier_pc"]) and np.array_equal(o_idx, g["out_outlier_idx"])
     assert np.array_equal(o_num, g["out_outlier_num"]) and np.array_equal(i_pc, g["out_inlier_pc"])
     assert o_idx.dtype == np.int16 and o_num.dtype == np.int16
 
 
 def test_critical_points_bookkeeping(g):
-    from geometric_adv_amd.defense import get_critical_pc_non_critical_pc
+    """The critical-point restatement against the reference's function bodies.  The reference orders points that own equally
+    many channels with numpy's default (unstable) argsort: everything that does not depend on that order is compared bit
+    for bit, the order itself up to permutations inside a group of equal counts -- and, with the SAME sort as the fixture's
+    (kind=None on the same numpy build), bit for bit as well."""
+    from oracle.host_defense import critical_and_rest, same_critical_sets
     pre = g["crit_pre"]
-    cp, ci, cn, crit_pc, non = get_critical_pc_non_critical_pc(g["crit_in_pc"], pre.max(1), pre.argmax(1))
-    assert np.array_equal(cn, g["crit_num"]) and np.array_equal(ci, g["crit_idx"])
-    assert np.array_equal(cp, g["crit_points"]) and np.array_equal(crit_pc, g["crit_pc"])
-    assert np.array_equal(non, g["crit_noncrit_pc"])
+    mv, mi = pre.max(1), pre.argmax(1)
+    cp, ci, cn, crit_pc, non = critical_and_rest(g["crit_in_pc"], mv, mi)
+    assert np.array_equal(cn, g["crit_num"]) and np.array_equal(non, g["crit_noncrit_pc"])
+    assert same_critical_sets(ci, cn, g["crit_idx"], g["crit_num"], mv, mi)
+    for i in range(len(cn)):
+        assert np.array_equal(cp[i, :cn[i]], g["crit_in_pc"][i][ci[i, :cn[i]]]) and not cp[i, cn[i]:].any()
+        assert np.array_equal(crit_pc[i, :cn[i]], cp[i, :cn[i]]) and (crit_pc[i, cn[i]:] == cp[i, cn[i] - 1]).all()
+    bad = ci.copy()
+    bad[0, [0, int(cn[0]) - 1]] = bad[0, [int(cn[0]) - 1, 0]]          # most-owning point moved to the end: not a tie permutation
+    assert not same_critical_sets(bad, cn, g["crit_idx"], g["crit_num"], mv, mi)
 
 
 def test_load_data_by_basename(tmp_path):

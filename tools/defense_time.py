@@ -24,7 +24,13 @@ out["query_ball_point_r0.1_ns32_ms"] = timed(lambda: ops.query_ball_point(0.1, 3
 idx = ops.knn_point(8, xs, xs)[1]
 out["group_point_k8_ms"] = timed(lambda: ops.group_point(xs, idx))
 w = W.synthetic_weights(N, seed=7); ae = PointNetAE(w, N)
-out["defend_surface_ms"] = timed(lambda: defense.defend_surface(ae, x, x), reps=2)
-out["defend_critical_ms"] = timed(lambda: defense.defend_critical(ae, x, x), reps=2)
+out["defend_surface_device_ms"] = timed(lambda: defense.defend_surface_device(ae, xs, xs), reps=5)      # GPU tensors in and out
+out["defend_critical_device_ms"] = timed(lambda: defense.defend_critical_device(ae, xs, xs), reps=5)
+kn = ops.knn_dists(xs, 8)
+out["outlier_filter_ms"] = timed(lambda: ops.outlier_filter(xs, kn, 0.04, top_k=2))
+mv, mi = ae.max_and_argmax(xs)
+out["critical_split_ms"] = timed(lambda: ops.critical_split(xs, mv, mi))
+out["defend_surface_numpy_in_out_ms"] = timed(lambda: defense.defend_surface(ae, x, x), reps=2)        # + upload, + 6 result downloads
+out["defend_critical_numpy_in_out_ms"] = timed(lambda: defense.defend_critical(ae, x, x), reps=2)
 out["pairs_G"] = B * N * N / 1e9
 print(json.dumps(out))
