@@ -61,6 +61,13 @@ def parse_args():
     ap.add_argument("--rccl-selftest", action="store_true",
                     help="(internal) child mode: bring up a ONE-rank RCCL group on cuda:0, run the collectives of the N > 1 path "
                          "on device tensors, print one JSON line")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip every secondary leg (other BASELINE configs, trained victim, training step, EMD, surfaces): the "
+                         "headline, its roofline and the CPU baseline only -- what the counter passes of tools/collect_pmc.sh run")
+    ap.add_argument("--only-leg", choices=["config2", "config3", "config4", "trained_victim", "training", "emd", "surfaces"],
+                    help="run ONE secondary leg alone on cuda:0 and print its JSON (what `rocprofv3 --kernel-trace --stats -- python3 "
+                         "bench.py --only-leg X` profiles: tools/collect_legs.sh -> profiles/r04_leg_*_kernel_stats.csv)")
+    ap.add_argument("--no-rccl-selftest", action="store_true", help="do not start the one-rank RCCL child at N = 1")
     ap.add_argument("--slots", type=int, default=0,
                     help="also measure S concurrent batch slots (secondary.batch_slots; off by default: its overlapping "
                          "launches would distort the per-kernel averages of a rocprofv3 run of this command)")
@@ -455,6 +462,243 @@ def slots_leg(dev, weights, ae, slots=2, iters=300):
             "ms_per_iteration_per_slot": dt / iters * 1e3}
 
 
+VALU_CYC = 2.65                            # issue cycles of an fp32 add / sub / mul wave instruction (profiles/r01_probe_valu_v2.json)
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+
+
+def _timed(f, reps):
+    import torch
+    f(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps * 1e3
+
+
+def _timed_attack(at, warm, iters):
+    """ms per iteration of an attack handle: `warm` untimed iterations, then `iters` between synchronisations."""
+    import torch
+    at.run(0, warm, 10 ** 6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    at.run(warm, iters, 10 ** 6)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def _encoder_frac(at, b, n, first, iters):
+    """(avg launch ms, fraction of the fp32 MFMA peak) of the encoder forward from its own begin / end stamps."""
+    import torch
+    at.profile(["encoder_fwd"], stride=max(1, iters // 32))
+    at.run(first, iters, 10 ** 6)
+    torch.cuda.synchronize()
+    cnt, ms = at.profile_read()["encoder_fwd"]
+    at.profile(False)
+    avg = ms / max(cnt, 1)
+    return avg, ENC_FLOP_PER_POINT * b * n / (avg * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS
+
+
+def pmc_file_traffic(path, kernels, hashed):
+    """(2 * FETCH_SIZE + WRITE_SIZE) KiB per launch summed over `kernels` from a committed tools/pmc_summary.py file, or the
+    reason it is not reported (missing, or taken at other kernel sources)."""
+    try:
+        d = json.load(open(path))
+    except Exception as e:
+        return None, "no PMC profile (%s)" % e
+    want = d.get("_source_sha1", {})
+    if not want or source_hashes(sorted(want)) != want or not set(hashed) <= set(want):
+        return None, "%s was taken at different kernel sources: dropped" % os.path.basename(path)
+    tot = 0.0
+    for key in kernels:
+        names = [k for k in d if k.endswith(key)]
+        if not names or "FETCH_SIZE" not in d[names[0]] or "WRITE_SIZE" not in d[names[0]]:
+            return None, "%s lacks FETCH_SIZE / WRITE_SIZE for %s" % (os.path.basename(path), key)
+        tot += (2.0 * d[names[0]]["FETCH_SIZE"]["mean"] + d[names[0]]["WRITE_SIZE"]["mean"]) * 1024.0
+    return tot, "profiles/%s: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes" % os.path.basename(path)
+
+
+def config2_leg(dev):
+    """BASELINE configs[2]: B = 256, N = 2048, latent-space attack (loss_adv 'latent', distance weight 150: adv_ae.py:107-116) followed
+    by the k-NN off-surface defense (defender/get_knn_dists_per_point.py:74-83 + run_defense_surface.py:187-207)."""
+    import torch
+    from geometric_adv_amd import defense, ops, weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    b = 256
+    w = W.synthetic_weights(N, seed=7)
+    ae = PointNetAE(w, N, device=dev)
+    x, gt = clouds(1003, b, N), clouds(2003, b, N)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=N, weights=w, loss_adv_type="latent", loss_dist_type="chamfer",
+                                          dist_weight_list=[150.0], num_iterations=60, num_iterations_thresh=10 ** 6), device=dev, ae=ae)
+    at.set_inputs(x, gt, ae.transform(gt), 150.0)
+    at.init_pert(None, reset_optimizer=True)
+    ms_it = _timed_attack(at, 5, 20)
+    enc_ms, enc_frac = _encoder_frac(at, b, N, 25, 16)
+    adv = at.peek()["adv"]
+    xs = torch.as_tensor(x).to(dev)
+    t_knn = _timed(lambda: ops.knn_dists(adv, 8), 5)
+    t_knn_point = _timed(lambda: ops.knn_point(9, adv, adv), 3)
+    t_def = _timed(lambda: defense.defend_surface_device(ae, adv, xs), 5)
+    t_def_np = _timed(lambda: defense.defend_surface(ae, adv, xs), 2)
+    pairs = float(b) * N * N
+    bound_ms = pairs / 64.0 * 8 * VALU_CYC / (SIMDS * CLOCK_HZ) * 1e3
+    out = {"workload": "BASELINE configs[2]: B=256 x N=2048, latent attack (dist weight 150) + kNN defense (k=8, 2-NN mean > 0.04)",
+           "attack_ms_per_iteration": ms_it, "attack_iterations_per_sec": 1e3 / ms_it,
+           "encoder_fwd": {"avg_launch_ms": enc_ms, "frac_of_fp32_mfma_peak": enc_frac},
+           "knn_dists_k8_ms": t_knn, "knn_point_k9_ms": t_knn_point,
+           "defend_surface_ms": t_def, "defend_surface_numpy_in_out_ms": t_def_np,
+           "roofline_knn": {"bound": "valu issue", "kernel": "knn_fast_kernel<1, 9> (+ knn_redo_kernel for tied / non-finite queries)",
+                            "pairs_per_launch": pairs, "achieved_Tpair_per_s": pairs / (t_knn * 1e-3) / 1e12,
+                            "issue_bound_ms": bound_ms, "frac": bound_ms / t_knn,
+                            "bound_note": "distance only: 8 fp32 VALU instructions per pair (3 sub, 3 mul, 2 add -- unfused, the reference's "
+                                          "rounding) at %.2f issue cycles per wave instruction, %d SIMDs, %.1f GHz; the compare and the "
+                                          "top-k bookkeeping are overhead against this bound" % (VALU_CYC, SIMDS, CLOCK_HZ / 1e9),
+                            "algorithmic_bytes_per_launch": 12.0 * b * N + 4.0 * b * N * 8}}
+    del at
+    return out
+
+
+def config3_leg(dev, emd):
+    """BASELINE configs[3] per GPU: B = 128 (1024 over 8 GPUs), N = 2048, loss_adv = Chamfer + approx-EMD / N (SURVEY a15;
+    tf_approxmatch.cpp:23-84)."""
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    b = 128
+    w = W.synthetic_weights(N, seed=7)
+    ae = PointNetAE(w, N, device=dev)
+    x, gt = clouds(1004, b, N), clouds(2004, b, N)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=N, weights=w, num_iterations=20, num_iterations_thresh=10 ** 6,
+                                          emd_weight=1.0), device=dev, ae=ae)
+    at.set_inputs(x, gt, ae.transform(gt), 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    ms_it = _timed_attack(at, 2, 6)
+    e = (emd or {}).get("B128", {})
+    out = {"workload": "BASELINE configs[3] per GPU: B=128 x N=2048, loss_adv = Chamfer + approx-EMD/N (lambda 1), dist chamfer w=1",
+           "attack_ms_per_iteration": ms_it, "attack_iterations_per_sec": 1e3 / ms_it,
+           "emd_levels_cost_grad1_fused_ms": e.get("levels_cost_grad1_fused_ms"),
+           "emd_share_of_iteration": (e.get("levels_cost_grad1_fused_ms") / ms_it) if e.get("levels_cost_grad1_fused_ms") else None,
+           "roofline_emd": {"bound": "valu issue", "approx_match_ms": e.get("approx_match_ms"), "issue_bound_ms": e.get("issue_bound_ms"),
+                            "frac": e.get("frac"), "see": "secondary.roofline_emd"}}
+    del at
+    return out
+
+
+PMC_CHAMFER_8192 = os.path.join(ROOT, "profiles", "r04_pmc_chamfer_n8192.json")
+
+
+def config4_leg(dev):
+    """BASELINE configs[4] per GPU: B = 32 (256 over 8 GPUs), N = 8192 dense clouds, output-space attack (chamfer / chamfer)."""
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    b, n = 32, 8192
+    w = W.synthetic_weights(n, seed=7)
+    ae = PointNetAE(w, n, device=dev)
+    x, gt = clouds(1005, b, n), clouds(2005, b, n)
+    out = {"workload": "BASELINE configs[4] per GPU: B=32 x N=8192, output-space attack (chamfer/chamfer, w=1)"}
+    for label, prune in (("grid_search", True), ("all_pairs", False)):
+        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=100, num_iterations_thresh=10 ** 6,
+                                              chamfer_prune=prune), device=dev, ae=ae)
+        at.set_inputs(x, gt, ae.transform(gt), 1.0)
+        at.init_pert(None, reset_optimizer=True)
+        ms_it = _timed_attack(at, 4, 16)
+        out[label] = {"attack_ms_per_iteration": ms_it, "attack_iterations_per_sec": 1e3 / ms_it}
+        if prune:
+            enc_ms, enc_frac = _encoder_frac(at, b, n, 20, 16)
+            at.profile(True)
+            at.run(36, 10, 10 ** 6)
+            br = {k: (ms / max(c_, 1)) for k, (c_, ms) in at.profile_read().items()}
+            at.profile(False)
+            ch_ms = br["chamfer_fwd"]
+            alg = 20.0 * b * (n + n)
+            traffic, note = pmc_file_traffic(PMC_CHAMFER_8192, ("chamfer_sym_kernel", "chamfer_sym_finish_kernel"), ("chamfer_sym.hip",))
+            pairs = 2.0 * b * n * n
+            bound_ms = (pairs / 2) / 64.0 * 8 * VALU_CYC / (SIMDS * CLOCK_HZ) * 1e3     # one distance evaluation serves both directions
+            out["encoder_fwd"] = {"avg_launch_ms": enc_ms, "frac_of_fp32_mfma_peak": enc_frac}
+            out["kernel_ms_per_iteration"] = br
+            out["roofline_chamfer"] = {"bound": "valu issue", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel: nn_distance(recon, target) at N = 8192 "
+                                       "(the paired search for nn_distance(adv, x) in a launch of its own at this size)",
+                                       "scan_plus_finish_class_ms": ch_ms, "achieved_Tpair_per_s": pairs / (ch_ms * 1e-3) / 1e12,
+                                       "issue_bound_ms": bound_ms, "frac": bound_ms / ch_ms,
+                                       "bound_note": "8 fp32 VALU instructions per distance, every distance evaluated once for both directions",
+                                       "algorithmic_bytes_per_launch": alg, "traffic": traffic, "traffic_source": note,
+                                       "traffic_over_algorithmic": (traffic / alg) if traffic else None}
+        del at
+    return out
+
+
+def victim_shapes(rng, count, n):
+    """Ellipsoid and box surfaces of random aspect (tools/trained_victim_attack.py): what the stand-in victim is trained on."""
+    import numpy as np
+    u = rng.standard_normal((count, n, 3)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=2, keepdims=True)
+    scale = rng.uniform(0.15, 0.45, size=(count, 1, 3)).astype(np.float32)
+    box = rng.random((count, 1, 1)) < 0.5
+    return (np.where(box, np.clip(u * 3.0, -1.0, 1.0), u) * scale).astype(np.float32)
+
+
+def trained_victim_leg(dev, steps, warmup, train_steps=320):
+    """The headline loop against a TRAINED victim (the reference attacks a trained AE: attacker/run_attack.py:80-137 with the
+    model of autoencoder/train_ae.py:43-79; the headline's victim has random-init weights).  The AE is trained here, untimed and
+    seeded, with the repo's own trainer on synthetic surfaces; then the standard window runs with the paired grid search on, off,
+    and in the adaptive default (off once most of the batch is handed back), with the hand-back rate along the attack and an
+    index-parity check of nn_distance(adv, x) against the pinned oracle on 4 clouds."""
+    import numpy as np
+    import torch
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.trainer import PointNetAETrainer, initial_weights
+    rng = np.random.default_rng(0)
+    tr = PointNetAETrainer(initial_weights(N, seed=2), N, batch_size=50, learning_rate=0.001, device=dev)
+    data = victim_shapes(rng, 400, N)
+    loss = None
+    for ep in range(train_steps // 8):
+        loss, _ = tr._single_epoch_train(data)
+    w = tr.export_weights()
+    del tr
+    ae = PointNetAE(w, N, device=dev)
+    src, tgt = victim_shapes(rng, B, N), victim_shapes(rng, B, N)
+    out = {"victim": "this package's trainer, %d steps of batch 50 on 400 synthetic ellipsoid / box surfaces (seed 0), lr 0.001; "
+                     "final epoch loss %.5f" % (train_steps // 8 * 8, float(loss)),
+           "attack": "B=32 x N=2048, chamfer/chamfer, w=1, lr 0.01, %d warm-up + %d timed iterations" % (warmup, steps)}
+    for label, prune in (("grid_search", True), ("all_pairs", False)):
+        at = AdvAE("adversary", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=warmup + steps,
+                                              num_iterations_thresh=10 ** 6, learning_rate=0.01, chamfer_prune=prune), device=dev, ae=ae)
+        at.set_inputs(src, tgt, ae.transform(tgt), 1.0)
+        at.init_pert(None, reset_optimizer=True)
+        hb = []
+        if prune:                                    # untimed first pass: the verdicts along the attack
+            for k in range(8):
+                at.run(k * (warmup + steps) // 8, (warmup + steps) // 8, 10 ** 6)
+                hb.append(at.search_state()[1])
+            at.init_pert(None, reset_optimizer=True)
+        ms_it = _timed_attack(at, warmup, steps)
+        out[label] = {"attack_iterations_per_sec": 1e3 / ms_it, "ms_per_step": ms_it}
+        if prune:
+            out[label]["clouds_handed_back_of_%d_along_the_attack" % B] = hb
+            out["mean_fraction_handed_back"] = sum(hb) / (len(hb) * float(B))
+            handed = at.adapt_source_search()        # the default policy's decision at the end of a run (AdvAE._attack_one_batch)
+            out["adaptive_default"] = {"search_switched_off": not getattr(at, "_search_on", True), "clouds_handed_back_at_decision": handed}
+            if not getattr(at, "_search_on", True):
+                at.init_pert(None, reset_optimizer=True)
+                ms_ad = _timed_attack(at, warmup, steps)
+                out["adaptive_default"].update({"attack_iterations_per_sec": 1e3 / ms_ad, "ms_per_step": ms_ad})
+            # parity of what the search answered (or handed to the all-pairs kernel) on the moved clouds, against the oracle
+            from oracle.cpu_oracle import Oracle
+            p = at.peek()
+            adv4 = p["adv"][:4].cpu().numpy()
+            _, oi1, _, oi2 = Oracle().nn_distance(adv4, src[:4])
+            out["index_parity_4_clouds"] = bool(np.array_equal(p["idx_a1"][:4].cpu().numpy(), oi1) and
+                                                np.array_equal(p["idx_a2"][:4].cpu().numpy(), oi2))
+            pn = p["pert"].norm(dim=2).flatten()
+            out["pert_norm_median"] = float(pn.median().item())
+            out["pert_norm_p99"] = float(torch.quantile(pn[:1000000], 0.99).item())
+        del at
+    return out
+
+
 class Leg:
     """One attack handle on this rank + the timed-window protocol."""
 
@@ -603,6 +847,12 @@ def main():
     K, Wm, R = args.steps, args.warmup, max(1, args.windows)
     weights = W.synthetic_weights(N, seed=7)
     ae = PointNetAE(weights, N, device=dev)
+    if args.only_leg:
+        leg_out = {"config2": lambda: config2_leg(dev), "config3": lambda: config3_leg(dev, emd_leg(dev)), "config4": lambda: config4_leg(dev),
+                   "trained_victim": lambda: trained_victim_leg(dev, min(K, 200), Wm), "training": lambda: training_leg(dev),
+                   "emd": lambda: emd_leg(dev), "surfaces": lambda: surfaces_leg(dev, weights, ae, min(K, 200), Wm)}[args.only_leg]()
+        print(json.dumps({"leg": args.only_leg, **leg_out}))
+        return
     x = clouds(1000 + 2 + 17 * rank, B, N)            # source batch of this rank
     gt = clouds(2000 + 2 + 17 * rank, B, N)           # target batch of this rank
 
@@ -707,10 +957,20 @@ def main():
         "kernel_ms_note": "bracketing events per class (dispatch gaps included), untimed 50-iteration pass; encoder_fwd here is kernel-timed",
         "final_mean_target_recon_error": float(leg.gathered[0, :, 4].mean().item()),
     }
-    if world == 1:                  # no collective ran at N = 1: show in a child process that RCCL comes up on this box
+    hb_headline = leg.at.search_state()
+    out["paired_search"] = {"in_use": hb_headline[0], "clouds_handed_back_of_%d_at_the_end" % B: hb_headline[1],
+                            "note": "`value` has nn_distance(adv, x) answered by the exact paired grid search; on this victim (random-init "
+                                    "weights, as the metric's config prescribes) no cloud is handed back.  A trained victim moves points "
+                                    "out of the grid cells: secondary.trained_victim reports what it gets (= value_all_pairs' path; the "
+                                    "default policy switches the search off by itself)"}
+    if world == 1 and not args.no_rccl_selftest:   # no collective ran at N = 1: show in a child process that RCCL comes up on this box
         out["config"]["rccl_selftest"] = rccl_selftest()
-    if world == 1:                  # the widened row f-4, measured beside the headline (not part of `value`)
-        out["secondary"] = {"ae_training_step": training_leg(dev), "roofline_emd": emd_leg(dev),
+    if world == 1 and not args.no_secondary:       # the other BASELINE configs and the widened rows, beside the headline (not part of `value`)
+        emd = emd_leg(dev)
+        out["secondary"] = {"configs": {"config2_latent_knn_b256": config2_leg(dev), "config3_chamfer_emd_b128": config3_leg(dev, emd),
+                                        "config4_n8192_b32": config4_leg(dev)},
+                            "trained_victim": trained_victim_leg(dev, min(K, 200), Wm),
+                            "ae_training_step": training_leg(dev), "roofline_emd": emd,
                             "surface_clouds": surfaces_leg(dev, weights, ae, min(K, 200), Wm)}
         if args.slots > 1:
             out["secondary"]["batch_slots"] = slots_leg(dev, weights, ae, args.slots)

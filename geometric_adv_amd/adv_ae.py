@@ -163,6 +163,25 @@ class AdvAE:
                                                          _lib.ptr(recon), _lib.stream_handle()), "attack_get_best")
         return metrics, adv, recon
 
+    def set_source_search(self, on):
+        """nn_distance(adv, x) from the next forward on: paired grid search (True) or all-pairs kernel (False); same results."""
+        _lib.check(_lib.lib().geoadv_attack_set_source_search(self._h, int(bool(on))), "attack_set_source_search")
+        self._search_on = bool(on)
+
+    def adapt_source_search(self):
+        """Configuration.chamfer_prune=True is a default, not a promise: when the search hands more than half of the batch back to
+        the all-pairs kernel (a victim whose perturbations leave the 1/16-box cells -- every trained victim measured so far), its
+        workgroups only cost time; switch it off for the rest of this handle's life.  Called where the host synchronises anyway
+        (end of a dist-weight run).  Returns the number of clouds handed back, or None if the search is not in use."""
+        if self.configuration.chamfer_prune is not True or not getattr(self, "_search_on", True):
+            return None
+        searched, handed_back = self.search_state()
+        if not searched:
+            return None
+        if 2 * handed_back > self.B:
+            self.set_source_search(False)
+        return handed_back
+
     def status(self):
         """Raises GeoAdvError if an in-launch hand-off of the loop timed out since the last set_inputs / init_pert (synchronises)."""
         with torch.cuda.device(self.device):
@@ -299,6 +318,7 @@ class AdvAE:
             self.run(0, c.num_iterations, c.num_iterations_thresh, hist)
             m_, a_, r_ = self.get_best(target_ae_loss_ref)
             self.status()                                            # the host sync of the run; raises if a hand-off ever timed out
+            self.adapt_source_search()
             h = hist.cpu().numpy()
             self.last_history.append(h)
             step = (c.num_iterations // 10) or 1

@@ -1005,6 +1005,12 @@ extern "C" int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_
     return GEOADV_OK;
 }
 
+extern "C" int geoadv_attack_set_source_search(geoadv_attack *at, int on) {
+    GA_REQUIRE(at, "attack_set_source_search: null handle");
+    at->chamfer_prune = on != 0;           // read by every forward (do_forward); the verdict flags keep their state
+    return GEOADV_OK;
+}
+
 extern "C" int geoadv_attack_status(geoadv_attack *at, void *stream) {
     GA_REQUIRE(at, "attack_status: null handle");
     hipStream_t st = as_stream(stream);

@@ -173,14 +173,15 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
     for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
     bool odd = false;                                      // met a NaN distance
     float thr = INFINITY;                                  // v[S - 1] as of the last drain
-    int qn = 0;                                            // candidates waiting in this lane's queue
+    unsigned qw = 4u * threadIdx.x;                        // BYTE offset of this lane's next queue entry: slot-major, (slot * KF_THREADS + lane) * 4
+                                                           // (a running offset: a push is one ds_write and one add)
 
     auto drain = [&]() {
-        for (int j = 0; __any(j < qn); ++j) {
-            const bool has = j < qn;
-            const float d = has ? qd[j * KF_THREADS + threadIdx.x] : INFINITY;
+        for (unsigned jo = 4u * threadIdx.x; __any(jo < qw); jo += 4u * KF_THREADS) {
+            const bool has = jo < qw;
+            const float d = has ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(qd) + jo) : INFINITY;
             int id = 0;
-            if (MODE == 0) id = has ? qi[j * KF_THREADS + threadIdx.x] : 0;
+            if (MODE == 0) id = has ? *reinterpret_cast<const int *>(reinterpret_cast<const char *>(qi) + jo) : 0;
             odd |= d != d;
             if (MODE == 1) {                               // values only: a compare-exchange chain on the BIT PATTERNS -- distances are
                 unsigned x = __float_as_uint(d);           // sums of squares (>= +0, or +inf), for which unsigned order = float order; no
@@ -191,19 +192,19 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
                     x = max(vi, x);
                     v[i] = __uint_as_float(lo);
                 }
-            } else if (__any(d < v[S - 1])) {
-                bool cl[S];
+            } else {                                       // (value, index): the candidate sinks past every entry it is strictly below;
+                float x = d;                               // an equal entry -- earlier index -- stays ahead of it.  Selects only, no branch.
+                int xi = id;
 #pragma unroll
-                for (int i = 0; i < S; ++i) cl[i] = d < v[i];
-#pragma unroll
-                for (int i = S - 1; i > 0; --i) {
-                    v[i] = cl[i - 1] ? v[i - 1] : (cl[i] ? d : v[i]);
-                    if (MODE == 0) ix[i] = cl[i - 1] ? ix[i - 1] : (cl[i] ? id : ix[i]);
+                for (int i = 0; i < S; ++i) {
+                    const bool c = x < v[i];
+                    const float lo = c ? x : v[i], hi = c ? v[i] : x;
+                    const int loi = c ? xi : ix[i], hii = c ? ix[i] : xi;
+                    v[i] = lo; ix[i] = loi; x = hi; xi = hii;
                 }
-                if (cl[0]) { v[0] = d; if (MODE == 0) ix[0] = id; }
             }
         }
-        qn = 0;
+        qw = 4u * threadIdx.x;
         thr = v[S - 1];
     };
 
@@ -235,11 +236,11 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (adm[u]) {
-                            qd[qn * KF_THREADS + threadIdx.x] = d[u];
-                            if (MODE == 0) qi[qn * KF_THREADS + threadIdx.x] = t0 + e0 + u;
-                            ++qn;
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(qd) + qw) = d[u];
+                            if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = t0 + e0 + u;
+                            qw += 4u * KF_THREADS;
                         }
-                    if (__any(qn > KF_QCAP - 4)) drain();
+                    if (__any(qw >= 4u * (KF_QCAP - 3) * KF_THREADS)) drain();
                 }
             }
             drain();

@@ -287,6 +287,12 @@ int geoadv_attack_run(geoadv_attack *at, int first_iteration, int iterations, in
 int geoadv_attack_get_best(geoadv_attack *at, const float *target_ae_loss_ref,
                            float *metrics, float *adv, float *recon, void *stream);
 
+/* From the next forward on: on != 0 -- nn_distance(adv, x) through the paired grid search (where the handle's size supports it);
+ * 0 -- the all-pairs kernel for every cloud.  Same results either way; a caller that sees most clouds handed back
+ * (geoadv_attack_search_state: a victim whose perturbations leave the grid cells) switches the search off and saves its cost.
+ * Overrides geoadv_attack_config.all_pairs_source_dist, including its small-batch rule. */
+int geoadv_attack_set_source_search(geoadv_attack *at, int on);
+
 /* Health of the run since the last set_inputs / init_pert: synchronises the stream and returns GEOADV_EHIP (message in
  * geoadv_last_error) if an in-launch hand-off of the loop ever gave up waiting -- the bounded spin of the dense encoder backward
  * on its cloud's decoder-tail flag; never observed, but a run after it would have used a stale gradient.  geoadv_attack_get_best

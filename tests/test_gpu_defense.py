@@ -118,7 +118,7 @@ def test_defenses_stay_on_the_device():
     n = 512
     ae = PointNetAE(W.randomized_weights(n, seed=3), n)
     adv, src = cloud(1, 5, n), cloud(2, 5, n)
-    adv[:, :7] += 2.0
+    adv[:, :7] += 3.0 * (np.arange(7, dtype=np.float32)[None, :, None] + 1)      # each far from everything else
     for dev_fn, np_fn in ((defense.defend_surface_device, defense.defend_surface), (defense.defend_critical_device, defense.defend_critical)):
         d = dev_fn(ae, _t(adv), _t(src))
         h = np_fn(ae, adv, src)
