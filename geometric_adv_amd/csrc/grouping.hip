@@ -152,7 +152,10 @@ __global__ __launch_bounds__(64) void knn_redo_kernel(int n, int m, int k, const
 // ------------------------------------------------------------------------------------------
 constexpr int KF_THREADS = 256;
 constexpr int KF_TILE = 1024;
-constexpr int KF_QCAP = 16;                // queue slots per lane
+#ifndef KF_QCAP_V
+#define KF_QCAP_V 16
+#endif
+constexpr int KF_QCAP = KF_QCAP_V;         // queue slots per lane
 constexpr int KF_DRAIN = 128;              // scheduled drain period (points)
 
 template <int MODE, int S>
@@ -262,6 +265,411 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
         for (int i = 1; i < S; ++i)
             if (i < k) val_out[((size_t)c * m + q) * (k - 1) + i - 1] = sqrtf(v[i]);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Grid k-NN (round 4): the same per-lane lists and queues as knn_fast_kernel, but a wave only visits the cells of a uniform
+// grid that can hold neighbours of ITS 64 queries.  Exact: a lane is finished when the last entry of its list is strictly
+// below the squared distance to the nearest face of the box of cells visited so far (faces on the grid's boundary do not
+// count: nothing lies beyond them), with a slack for the rounding of cell assignment; until every lane is finished the box
+// grows by one shell of cells, in the worst case to the whole grid (= the all-points scan, plus the build).
+//   build (one workgroup per cloud): bounding box, G cells per non-degenerate axis, counting sort of the dataset into
+//     row-major cells (x fastest: a run of cells along x is a contiguous range of the sorted array) -> sorted[b][n] float4
+//     (x, y, z, original index) + cell_start; the QUERIES are ordered along a Hilbert curve through their cells (qorder), so 64
+//     consecutive ones sit in a compact block of cells.  A cloud with a non-finite coordinate gets the 1 x 1 x 1 grid: every
+//     query then meets every point, as the all-points kernel would (NaN distances send the query to the redo kernel).
+//   search: every workgroup stages the whole sorted cloud in LDS (<= 4096 points); control flow is wave-uniform -- the wave's
+//     box of cells, shell by shell, row by row -- and the points of a row come out of LDS as broadcast ds_read_b128, the data
+//     path of knn_fast_kernel.  (First form, measured: scalar loads straight from the sorted array, s_load_dwordx8 feeding
+//     the VALU as SGPR operands -- no faster than the all-points scan, every group of four points waited for its own load.)
+// The order in which a lane meets its candidates is no longer the index order; the results do not depend on it (the k + 1
+// smallest distinct distances are what they are, ties among them go to knn_redo_kernel as before).
+// ------------------------------------------------------------------------------------------
+#ifndef KNN_GRID_MIN_N
+#define KNN_GRID_MIN_N 512                 // smaller datasets: the all-points kernel
+#endif
+#ifndef KNN_GRID_G_SMALL
+#define KNN_GRID_G_SMALL 4                 // n <  KNN_GRID_N_MID
+#define KNN_GRID_N_MID 1024
+#define KNN_GRID_G_MID 8                   // n <  KNN_GRID_N_BIG
+#define KNN_GRID_N_BIG 3072
+#define KNN_GRID_G_BIG 16
+#endif
+constexpr int KG_MAX_G = 16, KG_MAX_CELLS = KG_MAX_G * KG_MAX_G * KG_MAX_G;
+constexpr int KG_BUILD_THREADS = 1024;
+
+struct KnnGrid {
+    float lo[3], ih[3], h[3], eps[3];       // origin, 1 / cell size, cell size, slack on a face distance (rounding of the cell assignment)
+    int g[3], cells;
+};
+
+__device__ __forceinline__ int kg_cell1(float v, float lo, float ih, int g) {
+    const float t = fminf(fmaxf((v - lo) * ih, 0.f), (float)(g - 1));       // NaN -> 0; monotone in v
+    return (int)t;
+}
+
+// Hilbert index (Skilling's transpose form, 4 bits per axis) of a query's cell on a 16-per-axis grid over the dataset's box
+// (finer than the cell grid where that has fewer cells: the order only has to make 64 consecutive queries compact).  A Morton
+// order was measured first: its runs jump across the cloud wherever a high bit flips, the boxes of those waves cover most of
+// the grid, and a workgroup waits for its slowest wave (in-kernel stamps: median 75 us per workgroup, worst 189).
+__device__ __forceinline__ unsigned kg_hilbert(const KnnGrid &g, float x, float y, float z) {
+    const float s0 = g.g[0] > 1 ? 16.f / (float)g.g[0] : 0.f, s1 = g.g[1] > 1 ? 16.f / (float)g.g[1] : 0.f, s2 = g.g[2] > 1 ? 16.f / (float)g.g[2] : 0.f;
+    unsigned X[3] = {(unsigned)kg_cell1(x, g.lo[0], g.ih[0] * s0, 16), (unsigned)kg_cell1(y, g.lo[1], g.ih[1] * s1, 16),
+                     (unsigned)kg_cell1(z, g.lo[2], g.ih[2] * s2, 16)};
+#pragma unroll
+    for (unsigned Q = 8; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned t = 0;
+#pragma unroll
+    for (unsigned Q = 8; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    unsigned h = 0;
+#pragma unroll
+    for (int b = 3; b >= 0; --b)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) h = (h << 1) | ((X[i] >> b) & 1u);
+    return h;
+}
+
+// in-place exclusive scan of a[0 .. KG_MAX_CELLS) (LDS), 4 entries per thread; returns nothing (a[i] = sum of a[0..i))
+__device__ __forceinline__ void kg_scan(int *a, int *wsum) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int v[4], s = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u] = a[4 * t + u]; s += v[u]; }
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = inc - s;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[4 * t + u] = before; before += v[u]; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n, int m, int G, const float *xyz1, const float *xyz2,
+                                                                          float4 *sorted, int *cell_start, int *qorder, KnnGrid *info) {
+    __shared__ int cnt[KG_MAX_CELLS], qcnt[KG_MAX_CELLS];
+    __shared__ float red[7][KG_BUILD_THREADS / 64];
+    __shared__ int wsum[KG_BUILD_THREADS / 64];
+    __shared__ KnnGrid g;
+    const int c = blockIdx.x, t = threadIdx.x;
+    const float *data = xyz1 + (size_t)c * n * 3;
+    const float *qry = xyz2 + (size_t)c * m * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0.f;
+    for (int i = t; i < n; i += KG_BUILD_THREADS)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = data[3 * (size_t)i + a];
+            lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v);
+            bad = fabsf(v) < INFINITY ? bad : 1.f;                      // NaN or +-inf
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+        bad = fmaxf(bad, __shfl_xor(bad, off));
+    }
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { red[a][t >> 6] = lo[a]; red[3 + a][t >> 6] = hi[a]; }
+        red[6][t >> 6] = bad;
+    }
+    for (int i = t; i < KG_MAX_CELLS; i += KG_BUILD_THREADS) { cnt[i] = 0; qcnt[i] = 0; }
+    __syncthreads();
+    if (t == 0) {
+        float b = 0.f;
+        for (int w = 0; w < KG_BUILD_THREADS / 64; ++w) b = fmaxf(b, red[6][w]);
+        for (int a = 0; a < 3; ++a) {
+            float l = red[a][0], h = red[3 + a][0];
+            for (int w = 1; w < KG_BUILD_THREADS / 64; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+            const float ext = h - l;
+            const int ga = (b == 0.f && ext > 0.f && ext < INFINITY) ? G : 1;
+            g.g[a] = ga; g.lo[a] = b == 0.f ? l : 0.f;
+            g.h[a] = ga > 1 ? ext / (float)ga : 0.f;
+            g.ih[a] = ga > 1 ? (float)ga / ext : 0.f;
+            g.eps[a] = 8.f * 1.2e-7f * fmaxf(fabsf(l), fabsf(h));
+        }
+        g.cells = g.g[0] * g.g[1] * g.g[2];
+        info[c] = g;
+    }
+    __syncthreads();
+    const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
+    for (int i = t; i < n; i += KG_BUILD_THREADS) {
+        const float x = data[3 * (size_t)i], y = data[3 * (size_t)i + 1], z = data[3 * (size_t)i + 2];
+        const int cell = (kg_cell1(z, g.lo[2], g.ih[2], gz) * gy + kg_cell1(y, g.lo[1], g.ih[1], gy)) * gx + kg_cell1(x, g.lo[0], g.ih[0], gx);
+        atomicAdd(&cnt[cell], 1);
+    }
+    for (int j = t; j < m; j += KG_BUILD_THREADS) {
+        const float x = qry[3 * (size_t)j], y = qry[3 * (size_t)j + 1], z = qry[3 * (size_t)j + 2];
+        const unsigned mc = kg_hilbert(g, x, y, z);
+        atomicAdd(&qcnt[mc], 1);
+    }
+    __syncthreads();
+    kg_scan(cnt, wsum);
+    kg_scan(qcnt, wsum);
+    int *cs = cell_start + (size_t)c * (KG_MAX_CELLS + 1);
+    for (int i = t; i < KG_MAX_CELLS; i += KG_BUILD_THREADS) cs[i] = cnt[i];         // (cells past g.cells hold n: empty)
+    if (t == 0) cs[KG_MAX_CELLS] = n;
+    __syncthreads();
+    for (int i = t; i < n; i += KG_BUILD_THREADS) {
+        const float x = data[3 * (size_t)i], y = data[3 * (size_t)i + 1], z = data[3 * (size_t)i + 2];
+        const int cell = (kg_cell1(z, g.lo[2], g.ih[2], gz) * gy + kg_cell1(y, g.lo[1], g.ih[1], gy)) * gx + kg_cell1(x, g.lo[0], g.ih[0], gx);
+        const int pos = atomicAdd(&cnt[cell], 1);
+        sorted[(size_t)c * n + pos] = make_float4(x, y, z, __int_as_float(i));
+    }
+    for (int j = t; j < m; j += KG_BUILD_THREADS) {
+        const float x = qry[3 * (size_t)j], y = qry[3 * (size_t)j + 1], z = qry[3 * (size_t)j + 2];
+        const unsigned mc = kg_hilbert(g, x, y, z);
+        const int pos = atomicAdd(&qcnt[mc], 1);
+        qorder[(size_t)c * m + pos] = j;
+    }
+}
+
+// min / max over the 64 lanes, result uniform (as an SGPR value)
+__device__ __forceinline__ int kg_wave_min(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int kg_wave_max(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// LDS of the search kernel (dynamic): the sorted cloud as planes x[n4] y[n4] z[n4] (+ original index [n4] for MODE 0), n4 = n
+// rounded up to a multiple of 4 plus one group of padding; then the candidate queues (distance [, index]) of THREADS lanes.
+__host__ __device__ inline int kg_n4(int n) { return ((n + 3) & ~3) + 4; }
+template <int MODE> __host__ __device__ inline size_t kg_lds_bytes(int n, int threads) {
+    return (size_t)kg_n4(n) * 4 * (MODE == 0 ? 4 : 3) + (size_t)KF_QCAP * threads * 4 * (MODE == 0 ? 2 : 1);
+}
+constexpr int KG_MAX_N = 4096;             // the whole sorted cloud sits in LDS (48 / 64 KB at 4096 points)
+#ifndef KG_THREADS_V
+#define KG_THREADS_V 512
+#endif
+#ifndef KG_TASKS_PER_WAVE
+#define KG_TASKS_PER_WAVE 2
+#endif
+constexpr int KG_THREADS = KG_THREADS_V;
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+#ifdef KG_DIAG                             // diagnostic build only (tools/debug/build_variants.sh): per-wave work counters
+__device__ unsigned long long kg_diag[8];
+#define KG_COUNT(I, V) do { if ((threadIdx.x & 63) == 0) atomicAdd(&kg_diag[I], (unsigned long long)(V)); } while (0)
+#else
+#define KG_COUNT(I, V)
+#endif
+
+// One workgroup = the whole sorted cloud in LDS + THREADS / 64 waves that pull TASKS (64 consecutive queries of the Hilbert
+// order) from a counter in LDS until the workgroup's share [task0, task1) of the cloud's tasks is done: a task costs between
+// a few cells and the whole grid, so a fixed assignment leaves a workgroup waiting for its unluckiest wave.
+template <int MODE, int S, int THREADS>
+__global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, int split, const float4 *__restrict__ sorted,
+                                                           const int *__restrict__ cell_start, const int *__restrict__ qorder,
+                                                           const KnnGrid *__restrict__ info, const float *__restrict__ xyz2,
+                                                           float *val_out, int *idx_out, int *redo) {
+    extern __shared__ __attribute__((aligned(16))) float kg_lds[];
+    __shared__ int next_task;
+    GA_STAMP(0, 0);
+    const int n4 = kg_n4(n);
+    float *sx = kg_lds, *sy = sx + n4, *sz = sy + n4;
+    int *si = reinterpret_cast<int *>(sz + n4);
+    float *qd = sz + n4 + (MODE == 0 ? n4 : 0);
+    int *qi = reinterpret_cast<int *>(qd + KF_QCAP * THREADS);
+    const int c = blockIdx.y;
+    const float4 *pts = sorted + (size_t)c * n;
+    const int *cs = cell_start + (size_t)c * (KG_MAX_CELLS + 1);
+    const KnnGrid g = info[c];
+    const int tasks = cdiv_dev(m, 64);
+    const int task0 = (int)((long)tasks * blockIdx.x / split), task1 = (int)((long)tasks * (blockIdx.x + 1) / split);
+    if (threadIdx.x == 0) next_task = task0 + THREADS / 64;          // (every wave starts with the task of its own number)
+    {   // the cloud: all requests of a thread first, then the LDS writes (one round trip instead of one per 1024 points)
+        constexpr int PER = (KG_MAX_N + 4 + THREADS - 1) / THREADS;
+        float4 pt[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = threadIdx.x + u * THREADS;
+            pt[u] = e < n ? pts[e] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);      // the pad is never admitted (and it is masked)
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = threadIdx.x + u * THREADS;
+            if (e < n4) {
+                sx[e] = pt[u].x; sy[e] = pt[u].y; sz[e] = pt[u].z;
+                if (MODE == 0) si[e] = __float_as_int(pt[u].w);
+            }
+        }
+    }
+    const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
+    const int lane = threadIdx.x & 63;
+    GA_STAMP(0, 1);
+    __syncthreads();                                        // the only workgroup barrier: from here on the waves go their own ways
+    GA_STAMP(0, 2);
+
+    for (int task = task0 + (threadIdx.x >> 6); task < task1;) {
+        const int slot = task * 64 + lane;
+        const bool live = slot < m;
+        const int q = qorder[(size_t)c * m + (live ? slot : m - 1)];
+        const float *qp = xyz2 + ((size_t)c * m + q) * 3;
+        const float qx = qp[0], qy = qp[1], qz = qp[2];
+        const int ccx = kg_cell1(qx, g.lo[0], g.ih[0], gx), ccy = kg_cell1(qy, g.lo[1], g.ih[1], gy), ccz = kg_cell1(qz, g.lo[2], g.ih[2], gz);
+        // the wave's box of cells
+        const int bx0 = kg_wave_min(ccx), bx1 = kg_wave_max(ccx), by0 = kg_wave_min(ccy), by1 = kg_wave_max(ccy);
+        const int bz0 = kg_wave_min(ccz), bz1 = kg_wave_max(ccz);
+        float v[S];
+        int ix[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
+        bool odd = false;
+        float thr = INFINITY;
+        unsigned qw = 4u * threadIdx.x;
+
+        auto drain = [&]() {
+            KG_COUNT(5, 1);
+            for (unsigned jo = 4u * threadIdx.x; __any(jo < qw); jo += 4u * THREADS) {
+                KG_COUNT(2, 1);
+                const bool has = jo < qw;
+                const float d = has ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(qd) + jo) : INFINITY;
+                int id = 0;
+                if (MODE == 0) id = has ? *reinterpret_cast<const int *>(reinterpret_cast<const char *>(qi) + jo) : 0;
+                odd |= d != d;
+                if (MODE == 1) {
+                    unsigned x = __float_as_uint(d);
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const unsigned vi = __float_as_uint(v[i]);
+                        const unsigned lo = min(vi, x);
+                        x = max(vi, x);
+                        v[i] = __uint_as_float(lo);
+                    }
+                } else {
+                    float x = d;
+                    int xi = id;
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const bool cc = x < v[i];
+                        const float lo = cc ? x : v[i], hi = cc ? v[i] : x;
+                        const int loi = cc ? xi : ix[i], hii = cc ? ix[i] : xi;
+                        v[i] = lo; ix[i] = loi; x = hi; xi = hii;
+                    }
+                }
+            }
+            qw = 4u * threadIdx.x;
+            thr = v[S - 1];
+        };
+        // the points [lo, hi) of the sorted cloud: wave-uniform bounds, broadcast LDS reads of aligned groups of four (the
+        // neighbours of a misaligned first / last group belong to other rows: masked, or a point would enter a list twice)
+        auto run = [&](int lo, int hi) {
+            KG_COUNT(0, hi - lo);
+            for (int p = lo & ~3; p < hi; p += 4) {
+                KG_COUNT(3, 1);
+                const float4 xa = *reinterpret_cast<const float4 *>(&sx[p]);
+                const float4 ya = *reinterpret_cast<const float4 *>(&sy[p]);
+                const float4 za = *reinterpret_cast<const float4 *>(&sz[p]);
+                const float tx[4] = {xa.x, xa.y, xa.z, xa.w}, ty[4] = {ya.x, ya.y, ya.z, ya.w}, tz[4] = {za.x, za.y, za.z, za.w};
+                float d[4];
+                bool adm[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = tx[u] - qx, dy = ty[u] - qy, dz = tz[u] - qz;
+                    d[u] = (dx * dx + dy * dy) + dz * dz;                            // tf_grouping.py:68, left to right
+                    adm[u] = (p + u >= lo) && (p + u < hi) && !(d[u] >= thr);
+                }
+                if (__any(adm[0] | adm[1] | adm[2] | adm[3])) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (adm[u]) {
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(qd) + qw) = d[u];
+                            if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = si[p + u];
+                            qw += 4u * THREADS;
+                        }
+                    if (__any(qw >= 4u * (KF_QCAP - 3) * THREADS)) drain();
+                }
+            }
+        };
+
+        int px0 = 1, px1 = 0, py0 = 1, py1 = 0, pz0 = 1, pz1 = 0;              // the box visited so far (empty)
+        bool fin = false;
+        for (int s = 0;; ++s) {
+            const int x0 = max(0, bx0 - s), x1 = min(gx - 1, bx1 + s), y0 = max(0, by0 - s), y1 = min(gy - 1, by1 + s);
+            const int z0 = max(0, bz0 - s), z1 = min(gz - 1, bz1 + s);
+            // rows of the shell: lane r of a batch looks up the bounds of row r (all rows of a batch in one round trip)
+            const int ny = y1 - y0 + 1, rows = ny * (z1 - z0 + 1);
+            for (int r0 = 0; r0 < rows; r0 += 64) {
+                const int r = r0 + lane;
+                int a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+                if (r < rows) {
+                    const int z = z0 + r / ny, y = y0 + r % ny;
+                    const int *row = cs + (z * gy + y) * gx;
+                    const bool seen = z >= pz0 && z <= pz1 && y >= py0 && y <= py1;     // the middle of this row was walked in an earlier shell
+                    if (!seen) { a_lo = row[x0]; a_hi = row[x1 + 1]; }
+                    else {
+                        if (x0 < px0) { a_lo = row[x0]; a_hi = row[px0]; }
+                        if (x1 > px1) { b_lo = row[px1 + 1]; b_hi = row[x1 + 1]; }
+                    }
+                }
+                const int cnt_rows = min(64, rows - r0);
+                for (int i = 0; i < cnt_rows; ++i) {
+                    const int alo = __builtin_amdgcn_readlane(a_lo, i), ahi = __builtin_amdgcn_readlane(a_hi, i);
+                    const int blo = __builtin_amdgcn_readlane(b_lo, i), bhi = __builtin_amdgcn_readlane(b_hi, i);
+                    run(alo, ahi);
+                    run(blo, bhi);
+                }
+            }
+            drain();
+            // finished lanes: every point not met yet lies beyond a face of the box, i.e. at least `mg` away
+            float mg = INFINITY;
+            if (x0 > 0) mg = fminf(mg, (qx - (g.lo[0] + (float)x0 * g.h[0])) * 0.999f - g.eps[0]);
+            if (x1 < gx - 1) mg = fminf(mg, ((g.lo[0] + (float)(x1 + 1) * g.h[0]) - qx) * 0.999f - g.eps[0]);
+            if (y0 > 0) mg = fminf(mg, (qy - (g.lo[1] + (float)y0 * g.h[1])) * 0.999f - g.eps[1]);
+            if (y1 < gy - 1) mg = fminf(mg, ((g.lo[1] + (float)(y1 + 1) * g.h[1]) - qy) * 0.999f - g.eps[1]);
+            if (z0 > 0) mg = fminf(mg, (qz - (g.lo[2] + (float)z0 * g.h[2])) * 0.999f - g.eps[2]);
+            if (z1 < gz - 1) mg = fminf(mg, ((g.lo[2] + (float)(z1 + 1) * g.h[2]) - qz) * 0.999f - g.eps[2]);
+            fin = fin || (mg > 0.f && v[S - 1] < mg * mg);
+            const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == gx - 1 && y1 == gy - 1 && z1 == gz - 1;
+            KG_COUNT(1, 1); KG_COUNT(6, rows);
+            if (whole || !__any(!fin)) { KG_COUNT(4, 1); KG_COUNT(7, whole ? 1 : 0); break; }
+            px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
+        }
+        if (live) {
+            if (MODE == 0) {
+                bool again = odd || ix[k - 1] < 0;
+#pragma unroll
+                for (int i = 0; i + 1 < S; ++i)
+                    if (i < k && v[i] == v[i + 1] && ix[i + 1] >= 0) again = true;
+                if (again) redo[1 + atomicAdd(redo, 1)] = c * m + q;
+                else {
+#pragma unroll
+                    for (int i = 0; i < S; ++i)
+                        if (i < k) { val_out[((size_t)c * m + q) * k + i] = v[i]; idx_out[((size_t)c * m + q) * k + i] = ix[i]; }
+                }
+            } else {
+                if (odd || !(v[k - 1] < INFINITY)) redo[1 + atomicAdd(redo, 1)] = c * m + q;
+                else {
+#pragma unroll
+                    for (int i = 1; i < S; ++i)
+                        if (i < k) val_out[((size_t)c * m + q) * (k - 1) + i - 1] = sqrtf(v[i]);
+                }
+            }
+        }
+        int nt = 0;
+        if (lane == 0) nt = atomicAdd(&next_task, 1);
+        task = __builtin_amdgcn_readfirstlane(nt);
+    }
+    GA_STAMP(0, 7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -488,16 +896,67 @@ extern "C" int geoadv_selection_sort(int b, int n, int m, int k, const float *di
     return GEOADV_OK;
 }
 
+static int g_knn_grid_mode = 0;           // 0 = by size, 1 = never, 2 = always (geoadv_knn_grid_mode: the parity tests run both kernels)
+
 template <int MODE, int S>
 static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx, hipStream_t st) {
-    int *redo = nullptr;                                  // stream-ordered scratch: counter + one entry per query at most
-    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&redo), sizeof(int) * ((size_t)b * m + 1), st));
+    const bool grid = n <= KG_MAX_N && (g_knn_grid_mode == 2 || (g_knn_grid_mode == 0 && n >= KNN_GRID_MIN_N && m >= 64));
+    // stream-ordered scratch: the redo list (counter + one entry per query at most) and, for the grid search, the sorted
+    // dataset (+ 4 entries of padding: the scalar loads read four points at a time), cell offsets, query order, grid
+    const size_t redo_b = sizeof(int) * ((size_t)b * m + 1), sorted_b = sizeof(float4) * ((size_t)b * n + 4);
+    const size_t cs_b = sizeof(int) * (size_t)b * (KG_MAX_CELLS + 1), qo_b = sizeof(int) * (size_t)b * m, info_b = sizeof(KnnGrid) * (size_t)b;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    char *scratch = nullptr;
+    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), up(redo_b) + (grid ? up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b) : 0), st));
+    int *redo = reinterpret_cast<int *>(scratch);
     GA_HIP(hipMemsetAsync(redo, 0, sizeof(int), st));
-    knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
+    if (grid) {
+        float4 *sorted = reinterpret_cast<float4 *>(scratch + up(redo_b));
+        int *cs = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b));
+        int *qo = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b));
+        KnnGrid *info = reinterpret_cast<KnnGrid *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b));
+        const int G = n < KNN_GRID_N_MID ? KNN_GRID_G_SMALL : (n < KNN_GRID_N_BIG ? KNN_GRID_G_MID : KNN_GRID_G_BIG);
+        GA_HIP(hipMemsetAsync(sorted + (size_t)b * n, 0, 4 * sizeof(float4), st));
+        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, 0, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info);
+        static DeviceOnce attr;
+        if (int rc = attr.run([]() -> int {
+                GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<MODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kg_lds_bytes<MODE>(KG_MAX_N, KG_THREADS)));
+                return GEOADV_OK;
+            })) { (void)hipFreeAsync(scratch, st); return rc; }
+        // workgroups per cloud: every wave should see KG_TASKS_PER_WAVE tasks or more (the counter balances them), and the launch
+        // about two workgroups per CU
+        const int tasks = cdiv(m, 64), waves = KG_THREADS / 64;
+        const int split = std::max(1, std::min(std::max(1, tasks / (waves * KG_TASKS_PER_WAVE)), cdiv(2 * kCUs, b)));
+        knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE>(n, KG_THREADS), st>>>(n, m, k, split, sorted, cs, qo, info,
+                                                                                                                   xyz2, val, idx, redo);
+    } else {
+        knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
+    }
     knn_redo_kernel<MODE><<<1024, 64, (size_t)n * 8, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
     const hipError_t launched = hipGetLastError();
-    GA_HIP(hipFreeAsync(redo, st));
+    GA_HIP(hipFreeAsync(scratch, st));
     GA_HIP(launched);
+    return GEOADV_OK;
+}
+
+#ifdef KG_DIAG
+extern "C" int geoadv_debug_knn_occupancy(int n, int *blocks256, int *blocks512, int *blocks_fast) {
+    *blocks256 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks512, knn_grid_kernel<1, 9, KG_THREADS>, KG_THREADS, kg_lds_bytes<1>(n, KG_THREADS)) != hipSuccess) return 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_fast, knn_fast_kernel<1, 9>, 256, 0) != hipSuccess) return 1;
+    return 0;
+}
+extern "C" int geoadv_debug_knn_diag(unsigned long long *host_out, int reset) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(geoadv::kg_diag), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(geoadv::kg_diag), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
+extern "C" int geoadv_knn_grid_mode(int mode) {
+    GA_REQUIRE(mode >= 0 && mode <= 2, "knn_grid_mode: 0 = by size, 1 = all-points kernel only, 2 = grid search at every size");
+    g_knn_grid_mode = mode;
     return GEOADV_OK;
 }
 
@@ -623,3 +1082,4 @@ extern "C" int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, 
     GA_HIP(err);
     return GEOADV_OK;
 }
+GA_STAMPS_GETTER(geoadv_debug_stamps_grouping)

@@ -219,6 +219,11 @@ def knn_point(k, xyz1, xyz2):
     return val, idx
 
 
+def knn_grid_mode(mode):
+    """Process-wide choice of the k-NN kernel (include/geoadv.h: geoadv_knn_grid_mode): "auto" (by size), "all_points", "grid"."""
+    _lib.check(_lib.lib().geoadv_knn_grid_mode({"auto": 0, "all_points": 1, "grid": 2}[mode]), "knn_grid_mode")
+
+
 def knn_dists(pc, num_knn):
     """The graph of defender/get_knn_dists_per_point.py:78-81 fused: distances (not squared) from
     every point to its num_knn nearest neighbours, self dropped.  pc (b,n,3) -> (b,n,num_knn)."""

@@ -139,6 +139,10 @@ int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, const float
  * matrix or the two tiled (b,m,n,3) operands.  val, idx are (b,m,k).  1 <= k <= 64. */
 int geoadv_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2,
                      float *val, int *idx, void *stream);
+/* Which kernel answers geoadv_knn_point / geoadv_knn_dists for k <= 16 -- PROCESS-WIDE, meant for the parity tests and the
+ * measurements, which run both on the same inputs: 0 (default) = by size (datasets of >= 512 points: the exact grid search,
+ * smaller ones: the all-points kernel), 1 = the all-points kernel only, 2 = the grid search at every size.  Same results. */
+int geoadv_knn_grid_mode(int mode);
 /* defender/get_knn_dists_per_point.py:78-81 fused: knn_point(k+1, pc, pc), drop the first column,
  * gather, euclidean distance.  out is (b,n,k). */
 int geoadv_knn_dists(int b, int n, int k, const float *pc, float *out, void *stream);

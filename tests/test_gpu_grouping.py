@@ -93,9 +93,18 @@ def test_query_ball_radius_boundary_and_large(oracle):
         assert np.array_equal(idx.cpu().numpy()[hit], want_idx[hit])
 
 
+@pytest.fixture(params=["all_points", "grid"])
+def knn_kernel(request):
+    """Both k-NN kernels on the same inputs: the all-points scan and the exact grid search (ops.knn_grid_mode)."""
+    from geometric_adv_amd import ops
+    ops.knn_grid_mode(request.param)
+    yield request.param
+    ops.knn_grid_mode("auto")
+
+
 @pytest.mark.parametrize("b,n,m,k", [(2, 200, 77, 9), (1, 2048, 64, 9), (3, 64, 64, 64), (2, 500, 10, 1), (2, 3000, 300, 16),
                                      (2, 1500, 257, 4), (1, 5, 5, 5), (2, 2048, 100, 2), (1, 1100, 40, 17)])
-def test_knn_point_vs_oracle(oracle, b, n, m, k):
+def test_knn_point_vs_oracle(oracle, knn_kernel, b, n, m, k):
     from geometric_adv_amd import ops
     from conftest import cloud
     x1, x2 = cloud(10 + n, b, n), cloud(20 + m, b, m)
@@ -105,7 +114,7 @@ def test_knn_point_vs_oracle(oracle, b, n, m, k):
     assert np.array_equal(val.cpu().numpy(), want_val)
 
 
-def test_knn_point_exact_ties_follow_the_swap_rule(oracle):
+def test_knn_point_exact_ties_follow_the_swap_rule(oracle, knn_kernel):
     """Lattice clouds: many exactly equal distances; the order among them is the reference's."""
     from geometric_adv_amd import ops
     rng = np.random.default_rng(3)
@@ -116,7 +125,7 @@ def test_knn_point_exact_ties_follow_the_swap_rule(oracle):
     assert np.array_equal(val.cpu().numpy(), want_val)
 
 
-def test_knn_mixed_ties_and_infinities(oracle):
+def test_knn_mixed_ties_and_infinities(oracle, knn_kernel):
     """One launch, both paths: most queries have a unique answer (register top-k), the ones with duplicated neighbours or
     non-finite distances are handed to the selection-sort kernel -- the results are the reference's throughout."""
     from geometric_adv_amd import ops
@@ -135,7 +144,7 @@ def test_knn_mixed_ties_and_infinities(oracle):
     assert np.array_equal(ops.knn_dists(_t(x), 8).cpu().numpy(), oracle.knn_dists(x, 8))
 
 
-def test_knn_dists_vs_oracle_and_defense(oracle):
+def test_knn_dists_vs_oracle_and_defense(oracle, knn_kernel):
     from geometric_adv_amd import ops, weights as W
     from geometric_adv_amd.autoencoder import PointNetAE
     from geometric_adv_amd.defense import defend_surface, get_outlier_pc_inlier_pc
@@ -164,7 +173,7 @@ def test_knn_dists_vs_oracle_and_defense(oracle):
         assert a.dtype == b_.dtype and np.array_equal(a, b_)
 
 
-def test_knn_full_size_properties():
+def test_knn_full_size_properties(knn_kernel):
     """Config-3 size (n = 2048): properties instead of a CPU re-run -- the self distance is 0 and
     comes first, columns ascend, and the result is invariant to where in the batch a cloud sits."""
     import torch
@@ -179,6 +188,65 @@ def test_knn_full_size_properties():
     assert torch.equal(v2, val[3:5]) and torch.equal(i2, idx[3:5])
     d = ops.knn_dists(pc, 8)
     torch.testing.assert_close(d, val[:, :, 1:].sqrt(), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("kind", ["surface", "planar", "line", "clustered_with_outliers", "far_queries", "shifted", "tiny_extent"])
+def test_knn_grid_on_awkward_geometry(oracle, kind):
+    """The grid search where a uniform grid is a poor fit -- bit-exact against the oracle all the same: a thin shell, a flat
+    cloud (one degenerate axis: a single layer of cells), a line (two), one tight cluster plus a few far outliers (nearly all
+    points in one cell: the search degenerates to the all-points scan), queries far outside the dataset's box, coordinates
+    around 1000 (the slack on the face distances follows the magnitude), and an extent of 1e-4."""
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(len(kind))
+    b, n, m = 2, 1500, 700
+    x = rng.standard_normal((b, n, 3)).astype(np.float32)
+    if kind == "surface":
+        x = (0.4 * x / np.linalg.norm(x, axis=2, keepdims=True)).astype(np.float32)
+    elif kind == "planar":
+        x[:, :, 2] = np.float32(0.25)
+    elif kind == "line":
+        x[:, :, 1:] = np.float32(-0.5)
+    elif kind == "clustered_with_outliers":
+        x *= np.float32(0.01)
+        x[:, :5] += np.float32(50.0) * (np.arange(5, dtype=np.float32)[None, :, None] + 1)
+    elif kind == "shifted":
+        x = (x * np.float32(0.2) + np.float32(1000.0)).astype(np.float32)
+    elif kind == "tiny_extent":
+        x = (x * np.float32(1e-4)).astype(np.float32)
+    q = x[:, :m].copy() if kind != "far_queries" else (rng.standard_normal((b, m, 3)) * 30).astype(np.float32)
+    q[:, ::2] += (rng.standard_normal((b, (m + 1) // 2, 3)) * 0.01).astype(np.float32)
+    ops.knn_grid_mode("grid")
+    try:
+        for k in (1, 9, 16):
+            want_val, want_idx = oracle.knn_point(k, x, q)
+            val, idx = ops.knn_point(k, _t(x), _t(q))
+            assert np.array_equal(val.cpu().numpy(), want_val), (kind, k)
+            assert np.array_equal(idx.cpu().numpy(), want_idx), (kind, k)
+        assert np.array_equal(ops.knn_dists(_t(x), 8).cpu().numpy(), oracle.knn_dists(x, 8))
+    finally:
+        ops.knn_grid_mode("auto")
+
+
+def test_knn_grid_equals_all_points_at_config_size():
+    """B = 24 x N = 2048 (config 2's cloud size), uniform and surface-like clouds with a few far outliers -- the defense's
+    input: the two kernels agree bit for bit (values and indices), and so does the 4096-point grid (16 cells per axis, 512-thread
+    workgroups)."""
+    import torch
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    for n, b in ((2048, 24), (4096, 5)):
+        pc = cloud(77, b, n)
+        v = np.random.default_rng(1).standard_normal((b // 2, n, 3)).astype(np.float32)
+        pc[: b // 2] = 0.4 * v / np.linalg.norm(v, axis=2, keepdims=True)
+        pc[:, :20] *= 3.0
+        pc = _t(pc)
+        out = {}
+        for mode in ("all_points", "grid"):
+            ops.knn_grid_mode(mode)
+            out[mode] = (ops.knn_dists(pc, 8), ) + tuple(ops.knn_point(9, pc, pc))
+        ops.knn_grid_mode("auto")
+        for a, g in zip(out["all_points"], out["grid"]):
+            assert torch.equal(a, g)
 
 
 def test_grouping_argument_errors():

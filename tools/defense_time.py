@@ -18,8 +18,16 @@ def timed(f, reps=5):
 
 
 out = {"batch": B, "n_points": N}
-out["knn_dists_k8_ms"] = timed(lambda: ops.knn_dists(xs, 8))
-out["knn_point_k8_ms"] = timed(lambda: ops.knn_point(8, xs, xs))
+for mode in ("all_points", "grid"):
+    ops.knn_grid_mode(mode)
+    out["knn_dists_k8_ms_" + mode] = timed(lambda: ops.knn_dists(xs, 8))
+    out["knn_point_k8_ms_" + mode] = timed(lambda: ops.knn_point(8, xs, xs))
+    out["knn_point_k9_ms_" + mode] = timed(lambda: ops.knn_point(9, xs, xs))
+ops.knn_grid_mode("auto")
+v = rng.standard_normal((B, N, 3)).astype(np.float32)
+sh = torch.as_tensor((0.4 * v / np.linalg.norm(v, axis=2, keepdims=True)).astype(np.float32)).cuda()
+sh[:, :100] = torch.as_tensor(x[:, :100]).cuda()          # a sphere shell with 5 % uniform outliers
+out["knn_dists_k8_ms_shell_with_outliers"] = timed(lambda: ops.knn_dists(sh, 8))
 out["query_ball_point_r0.1_ns32_ms"] = timed(lambda: ops.query_ball_point(0.1, 32, xs, xs))
 idx = ops.knn_point(8, xs, xs)[1]
 out["group_point_k8_ms"] = timed(lambda: ops.group_point(xs, idx))
