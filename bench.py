@@ -36,8 +36,8 @@ B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
-PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r03_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
+PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r04_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep: ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- what each rank of the strong-scaling leg runs
 SWEEP_SRC = "profiles/r03_attack_sweep.json"

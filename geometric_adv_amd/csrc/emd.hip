@@ -126,6 +126,225 @@ __global__ void emd_init_kernel(int n, int m, double *temp) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Sparse levels (round 4).  exp(level * d2) is EXACTLY zero in float beyond a reach that is small at the first levels
+// (level = -4^8, -4^7, -4^6: reach 0.040, 0.080, 0.160 -- glibc's expf returns 0 below -103.97, v_exp_f32 of an argument below
+// -150 likewise), and a zero weight adds nothing to any of the fp64 sums.  The first sweeps (A and B of level 8, C8 + A7, B7;
+// with SP_LEVELS = 3 also C7 + A6, B6) therefore only have to meet the pairs within reach: both clouds are binned per call on a
+// common uniform grid per sparse level (cells no smaller than 1.01 x the reach, at most 16 per axis), in a stable order (cell,
+// then point index: the sums stay reproducible run to run), and an own point walks the 3 x 3 x 3 cells around its own -- a dozen
+// candidates at level 8, thirty at level 7 on 2048-point clouds in the unit cube, instead of all 2048.  Same pair arithmetic
+// (PairWeight), same epilogues; the sums differ from the dense sweep's only in the order of their fp64 additions.  Where the
+// cells would not thin the pairs out enough -- a box of a few cells, points piled into a few cells, clouds of very different
+// extent -- a level keeps its dense sweeps: the choice is made per cloud pair and level on the device (SparseGrid::use,
+// emd_sparse_bin_kernel), both kinds of workgroups are in every such launch.
+// Measured (B = 32 / 128, N = 2048, uniform clouds; per launch under rocprofv3): A8 8.0 / 21 us, B8 9.2 / 24, C8 + A7 11.1 / 33,
+// B7 10.3 / 27, C7 + A6 32.7 / 105, B6 24.6 / 76 against 45 / 153 (passes A, B) and 65 / 230 (C + A) dense, binning 36 / 63 us:
+// approx_match 1.24 -> 1.09 ms and 4.45 -> 3.79 ms (reference weights: 4.21 -> 3.94 ms at B = 32).  A sparse pair costs 4 (long
+// candidate lists) to 10 (short ones) dense pairs -- gathers, an fp64 fma chain per lane, the dense sweep's broadcast LDS reads
+// gone -- hence the device-side test SP_COST_RATIO * (pairs within the cells) <= n * m, and two bounds that keep a sparse launch
+// from lasting longer than a dense one whatever the clouds look like: no own point may face more than SP_MAX_CANDIDATES
+// candidates (W is an average; a cloud with a dense core makes a few lanes walk thousands), no cell hold more than
+// SP_MAX_CELL_POINTS points (the stable in-cell ranking is quadratic).  The attack's reconstruction of a random-init decoder is
+// such a core (extent 0.15 inside a unit target cloud): its levels stay dense and the call pays the binning kernel (+ 1-3 %).
+// Dead ends on the way, all measured: one lane per own point walking one candidate at a time (a chain of dependent L2 round
+// trips: level 6 in 127 / 66 us at B = 32); four lanes and batches of loads but factors gathered by original index (91 / 59: the
+// scattered 8-byte loads saturate the CU's address path); a loop per cell run instead of one flat candidate list (A8 78 us at
+// B = 128: a run holds 1.5 points, the sweep was bound by its number of memory instructions); and the two forms' workgroups
+// interleaved per cloud pair in dispatch order (a launch that stayed dense: 265 instead of 140 us -- see emd_sweep_kernel).
+// ------------------------------------------------------------------------------------------
+#ifndef SP_LEVELS_V
+#define SP_LEVELS_V 3
+#endif
+constexpr int SP_LEVELS = SP_LEVELS_V;          // li = 0, 1 (, 2)  <->  j = 8, 7 (, 6)
+constexpr int SP_MAX_G = 16, SP_MAX_CELLS = SP_MAX_G * SP_MAX_G * SP_MAX_G;
+constexpr int SP_MAX_N = 8192;                  // points per cloud the binning kernel sorts in LDS (keys: 16 bits of index)
+constexpr int SP_BIN_THREADS = 1024;
+
+struct SparseGrid { float lo[3], ih[3]; int g[3], use; };
+// per cloud pair, 16-byte aligned pieces: SparseGrid[SP_LEVELS]; then per level and cloud X in {1, 2}: float4 sorted[nX]
+// (x, y, z, original index), int cell_start[SP_MAX_CELLS + 4], int inv[nX] (original index -> place in `sorted`), and two
+// arrays of nX doubles: the factors the sparse sweeps of this level read for THIS cloud as the "other" one, in `sorted`'s
+// order (cloud 1: fL; cloud 2: fR and remR) -- written by the epilogue of the sweep that produces them (through inv), so a
+// candidate costs two sequential loads instead of a point and a dependent gather by original index
+__host__ __device__ inline size_t sp_up(size_t v) { return (v + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t sp_grid_bytes() { return sp_up(sizeof(SparseGrid) * SP_LEVELS); }
+__host__ __device__ inline size_t sp_cloud_bytes(int nx) {
+    return sp_up(sizeof(float4) * (size_t)nx) + sp_up(sizeof(int) * (SP_MAX_CELLS + 4)) + sp_up(sizeof(int) * (size_t)nx) + 2 * sp_up(sizeof(double) * (size_t)nx);
+}
+__host__ __device__ inline size_t sp_bytes_per_pair(int n, int m) { return sp_grid_bytes() + SP_LEVELS * (sp_cloud_bytes(n) + sp_cloud_bytes(m)); }
+struct SparseView { const SparseGrid *grid; const float4 *sorted[2]; const int *cell_start[2]; int *inv[2]; double *fac[2][2]; };
+__host__ __device__ inline SparseView sp_view(char *base, int n, int m, int level) {
+    SparseView v;
+    v.grid = reinterpret_cast<const SparseGrid *>(base) + level;
+    char *p = base + sp_grid_bytes() + (size_t)level * (sp_cloud_bytes(n) + sp_cloud_bytes(m));
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int nx = w ? m : n;
+        char *q = p;
+        v.sorted[w] = reinterpret_cast<const float4 *>(q); q += sp_up(sizeof(float4) * (size_t)nx);
+        v.cell_start[w] = reinterpret_cast<const int *>(q); q += sp_up(sizeof(int) * (SP_MAX_CELLS + 4));
+        v.inv[w] = reinterpret_cast<int *>(q); q += sp_up(sizeof(int) * (size_t)nx);
+        v.fac[w][0] = reinterpret_cast<double *>(q); q += sp_up(sizeof(double) * (size_t)nx);
+        v.fac[w][1] = reinterpret_cast<double *>(q);
+        p += sp_cloud_bytes(nx);
+    }
+    return v;
+}
+__device__ __forceinline__ int sp_cell1(float v, float lo, float ih, int g) {
+    const float t = fminf(fmaxf((v - lo) * ih, 0.f), (float)(g - 1));       // NaN -> 0; monotone in v
+    return (int)t;
+}
+
+// grid = (SP_LEVELS, b): one workgroup bins BOTH clouds of a pair on the level's grid and decides whether the level's sparse
+// sweeps pay: they meet W = sum over cells of (own points in the cell) x (other points in the 27 cells around it) pairs -- the
+// same number whichever cloud is "own" -- at several times the dense sweep's cost per pair (gathers, four lanes per own point),
+// so `use` needs SP_COST_RATIO * W <= n * m; clouds piled into a few cells (the attack's reconstruction of a random-init
+// decoder is one small blob) keep the dense sweeps.  LDS (dynamic): cntA, cntB, cursor [SP_MAX_CELLS + 4] ints, perm [SP_MAX_N].
+#ifndef SP_COST_RATIO_V
+#define SP_COST_RATIO_V 6
+#endif
+constexpr int SP_COST_RATIO = SP_COST_RATIO_V;
+constexpr int SP_MAX_CELL_POINTS = 256;         // the in-cell ranking below is quadratic in a cell's population
+#ifndef SP_MAX_CANDIDATES_V
+#define SP_MAX_CANDIDATES_V 400
+#endif
+constexpr int SP_MAX_CANDIDATES = SP_MAX_CANDIDATES_V;          // ... and a launch lasts as long as its longest candidate list: W is an average, a cloud with a
+                                                // dense core (the reconstruction of a random-init decoder is one) makes a few workgroups walk thousands
+constexpr size_t SP_BIN_LDS = sizeof(int) * (3 * (SP_MAX_CELLS + 4) + SP_MAX_N);
+
+__global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, int m, const float *xyz1, const float *xyz2, char *sparse,
+                                                                        float reach0) {
+    extern __shared__ __attribute__((aligned(16))) int sp_lds[];
+    int *cntA = sp_lds, *cntB = cntA + SP_MAX_CELLS + 4, *cur = cntB + SP_MAX_CELLS + 4, *perm = cur + SP_MAX_CELLS + 4;
+    __shared__ float red[6][SP_BIN_THREADS / 64];
+    __shared__ int wsum[SP_BIN_THREADS / 64];
+    __shared__ unsigned long long work;
+    __shared__ int maxcnt, maxnb;
+    __shared__ SparseGrid g;
+    const int level = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
+    char *base = sparse + (size_t)c * sp_bytes_per_pair(n, m);
+    const float *p1 = xyz1 + (size_t)c * n * 3, *p2 = xyz2 + (size_t)c * m * 3;
+    // the box of BOTH clouds
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = t; i < n + m; i += SP_BIN_THREADS) {
+        const float *q = i < n ? p1 + 3 * (size_t)i : p2 + 3 * (size_t)(i - n);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], q[a]); hi[a] = fmaxf(hi[a], q[a]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off)); }
+    if ((t & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { red[a][t >> 6] = lo[a]; red[3 + a][t >> 6] = hi[a]; }
+    for (int i = t; i < 2 * (SP_MAX_CELLS + 4); i += SP_BIN_THREADS) cntA[i] = 0;       // (cntA and cntB are adjacent)
+    if (t == 0) { work = 0ull; maxcnt = 0; maxnb = 0; }
+    __syncthreads();
+    if (t == 0) {
+        const float reach = reach0 * (float)(1 << level) * 1.01f;       // the reach doubles from level to level (level = -4^j)
+        for (int a = 0; a < 3; ++a) {
+            float l = red[a][0], h = red[3 + a][0];
+            for (int w = 1; w < SP_BIN_THREADS / 64; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+            const float ext = h - l;
+            int ga = 1;
+            if (ext > 0.f && ext < INFINITY) ga = (int)fminf(fmaxf(floorf(ext / reach), 1.f), (float)SP_MAX_G);
+            g.g[a] = ga; g.lo[a] = (l > -INFINITY && l < INFINITY) ? l : 0.f;
+            g.ih[a] = ga > 1 ? (float)ga / ext : 0.f;
+        }
+        g.use = 0;
+    }
+    __syncthreads();
+    const int gx = g.g[0], gy = g.g[1], gz = g.g[2], cells = gx * gy * gz;
+    auto cell_of = [&](const float *px, int i) {
+        const float x = px[3 * (size_t)i], y = px[3 * (size_t)i + 1], z = px[3 * (size_t)i + 2];
+        return (sp_cell1(z, g.lo[2], g.ih[2], gz) * gy + sp_cell1(y, g.lo[1], g.ih[1], gy)) * gx + sp_cell1(x, g.lo[0], g.ih[0], gx);
+    };
+    for (int i = t; i < n; i += SP_BIN_THREADS) atomicAdd(&cntA[cell_of(p1, i)], 1);
+    for (int i = t; i < m; i += SP_BIN_THREADS) atomicAdd(&cntB[cell_of(p2, i)], 1);
+    __syncthreads();
+    {   // the pairs the sparse sweeps would meet, and the fullest cell
+        unsigned long long w = 0ull;
+        int mc = 0;
+        int mnb = 0;
+        for (int cell = t; cell < cells; cell += SP_BIN_THREADS) {
+            const int a = cntA[cell], bq = cntB[cell];
+            mc = max(mc, max(a, bq));
+            if (a == 0 && bq == 0) continue;
+            const int x = cell % gx, y = (cell / gx) % gy, z = cell / (gx * gy);
+            int nbA = 0, nbB = 0;
+            for (int zz = max(z - 1, 0); zz <= min(z + 1, gz - 1); ++zz)
+                for (int yy = max(y - 1, 0); yy <= min(y + 1, gy - 1); ++yy)
+                    for (int xx = max(x - 1, 0); xx <= min(x + 1, gx - 1); ++xx) {
+                        nbA += cntA[(zz * gy + yy) * gx + xx];
+                        nbB += cntB[(zz * gy + yy) * gx + xx];
+                    }
+            w += (unsigned long long)a * (unsigned long long)nbB;
+            mnb = max(mnb, max(a ? nbB : 0, bq ? nbA : 0));   // the longest candidate list any own point of either cloud would walk
+        }
+        atomicAdd(&work, w);                                  // (integers: the sum does not depend on the order)
+        atomicMax(&maxcnt, mc);
+        atomicMax(&maxnb, mnb);
+    }
+    __syncthreads();
+    if (t == 0) {
+        g.use = (work * (unsigned long long)SP_COST_RATIO <= (unsigned long long)n * (unsigned long long)m && maxcnt <= SP_MAX_CELL_POINTS &&
+                 maxnb <= SP_MAX_CANDIDATES && max(n, m) <= SP_MAX_N) ? 1 : 0;
+        reinterpret_cast<SparseGrid *>(base)[level] = g;
+    }
+    __syncthreads();
+    if (!g.use) return;                                     // (uniform; nothing else of this level's data is read then)
+    const SparseView v = sp_view(base, n, m, level);
+    for (int which = 0; which < 2; ++which) {
+        const int nx = which ? m : n;
+        const float *px = which ? p2 : p1;
+        int *cnt = which ? cntB : cntA;
+        float4 *sorted = const_cast<float4 *>(v.sorted[which]);
+        int *cs = const_cast<int *>(v.cell_start[which]);
+        {   // exclusive scan of cnt[0 .. SP_MAX_CELLS): 4 entries per thread
+            const int lane = t & 63, wave = t >> 6;
+            int vv[4], sm = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { vv[u] = cnt[4 * t + u]; sm += vv[u]; }
+            int inc = sm;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            int before = inc - sm;
+            for (int w = 0; w < wave; ++w) before += wsum[w];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { cnt[4 * t + u] = before; cur[4 * t + u] = before; before += vv[u]; }
+        }
+        __syncthreads();
+        for (int i = t; i < SP_MAX_CELLS; i += SP_BIN_THREADS) cs[i] = cnt[i];
+        if (t < 4) cs[SP_MAX_CELLS + t] = nx;
+        for (int i = t; i < nx; i += SP_BIN_THREADS) perm[atomicAdd(&cur[cell_of(px, i)], 1)] = i;   // (scheduling order inside a cell)
+        __syncthreads();
+        // stable order: a point's place in its cell = the number of the cell's points with a smaller index (cur[cell] is now the
+        // cell's end), so the order -- and with it the order of every fp64 sum of the sparse sweeps -- does not depend on scheduling
+        for (int i = t; i < nx; i += SP_BIN_THREADS) {
+            const int cell = cell_of(px, i);
+            const int b0 = cnt[cell], b1 = cur[cell];
+            int r = 0;
+            for (int j = b0; j < b1; ++j) r += perm[j] < i ? 1 : 0;
+            sorted[b0 + r] = make_float4(px[3 * (size_t)i], px[3 * (size_t)i + 1], px[3 * (size_t)i + 2], __int_as_float(i));
+            v.inv[which][i] = b0 + r;
+            // pass A of the first level reads remR of cloud 2 before any sweep has written it: its initial value (:26), everywhere
+            if (level == 0 && which == 1) v.fac[1][1][i] = (double)((n > m ? n : m) / m);
+        }
+        __syncthreads();
+    }
+}
+
+// What the sweep kernel needs to know about the sparse form of its launch: null base = a dense launch.
+// `cons_level`: the level whose sparse sweep reads what this sweep's epilogue produces (-1: a dense one does)
+struct SparseArgs { char *base; int level, dense_blocks, cons_level, sparse_blocks; };   // blocks: per cloud pair
+
+// ------------------------------------------------------------------------------------------
 // One level sweep.  A workgroup = 8 waves owns 128 "own" points (two per lane, the same in every wave); the "other" cloud
 // is staged through LDS 1024 points at a time (coordinates fp32, factors fp64) and each wave walks one eighth of every tile, so a
 // B = 32 x N = 2048 sweep is 512 workgroups = 4 waves per SIMD (round 1: thread per own point over the WHOLE other cloud,
@@ -136,10 +355,137 @@ __global__ void emd_init_kernel(int n, int m, double *temp) {
 constexpr int SW_WAVES = 8, SW_THREADS = 64 * SW_WAVES, SW_TILE = 1024;
 constexpr int SW_R = 2, SW_OWN = 64 * SW_R;   // own points per lane: 1 is 8 % slower (LDS reads per pair double), 4 the same (measured)
 
+// what a sweep does with the pair sums of one own point (the CPU loop's row / column normalisations, :49-72)
+// copies of an epilogue's results for the sparse sweep that reads them next, in that sweep's order of this cloud (inv == null: none)
+struct EpiCopy { const int *inv; double *d0, *d1; };
+template <int PASS>
+__device__ __forceinline__ EpiCopy epi_copy(const SparseArgs &sp, char *base, int n, int m) {
+    EpiCopy e{nullptr, nullptr, nullptr};
+    if (!sp.base || sp.cons_level < 0 || PASS == 2) return e;
+    if (!reinterpret_cast<const SparseGrid *>(base)[sp.cons_level].use) return e;
+    const SparseView cv = sp_view(base, n, m, sp.cons_level);
+    const int w = PASS == 1 ? 1 : 0;                         // the cloud this sweep owns: 2 in pass B, else 1
+    e.inv = cv.inv[w]; e.d0 = cv.fac[w][0]; e.d1 = cv.fac[w][1];
+    return e;
+}
+template <int PASS>
+__device__ __forceinline__ void sweep_epilogue(int i, double tot0, double tot1, double *remL, double *remR, double *fL, double *fR, double *fL_next,
+                                               const EpiCopy &ec) {
+    if (PASS == 0) {
+        const double f = remL[i] / (1e-9 + tot0);           // the CPU starts its row sum at 1e-9 (:49)
+        fL[i] = f;
+        if (ec.inv) ec.d0[ec.inv[i]] = f;
+    } else if (PASS == 1) {
+        const double rr = remR[i];
+        const double ss = 1e-9 + rr * tot0;
+        double r = rr / ss;
+        r = r < 1.0 ? r : 1.0;
+        const double f = rr * r;
+        fR[i] = f;
+        const double left = rr - f * tot0;
+        const double rn = left > 0.0 ? left : 0.0;
+        remR[i] = rn;
+        if (ec.inv) { const int q = ec.inv[i]; ec.d0[q] = f; ec.d1[q] = rn; }
+    } else {
+        const double left = remL[i] - fL[i] * tot0;
+        const double rl = left > 0.0 ? left : 0.0;
+        remL[i] = rl;
+        if (PASS == 3) {
+            const double f = rl / (1e-9 + tot1);
+            fL_next[i] = f;
+            if (ec.inv) ec.d0[ec.inv[i]] = f;
+        }
+    }
+}
+
+// The sparse form of a sweep for one workgroup: SP_LANES adjacent lanes share one own point (taken in its cloud's cell order:
+// neighbouring points sit in the same or adjacent cells and meet the same candidates) and walk the three-cell runs along x of
+// the 3 x 3 rows around its cell, each lane every SP_LANES-th candidate, SP_BATCH of them per round: a candidate costs two
+// DEPENDENT loads (the sorted point, then its factor by original index), so all of a round's points are requested before any of
+// its factors, and those before any arithmetic (the first form -- one lane per point, one candidate at a time -- ran the level-6
+// sweeps in 127 / 66 us against 65 / 45 dense: a chain of L2 round trips, one wave per SIMD at B = 32; with four lanes and
+// batches but the factors still gathered by original index: 91 / 59 us, the scattered 8-byte loads saturate the CU's address
+// path -- hence the factors in sorted order, SparseView::fac).  The lanes' sums are folded in a fixed order.
+constexpr int SP_LANES = 4, SP_BATCH = 4;
+template <int PASS, bool REF>
+__device__ __forceinline__ void sweep_sparse_body(int n, int m, typename PairWeight<REF>::L c0, typename PairWeight<REF>::L c1,
+                                                  const SparseView &sv, double *remL, double *remR, double *fL, double *fR, double *fL_next,
+                                                  const EpiCopy &ec, const int block, const unsigned long long *etab) {
+    using PW = PairWeight<REF>;
+    using C = typename PW::C;
+    constexpr int NF = PASS == 3 ? 2 : 1;
+    const bool own_is_1 = PASS != 1;
+    const int n_own = own_is_1 ? n : m;
+    const int sub = threadIdx.x & (SP_LANES - 1);
+    int s = block * (SW_THREADS / SP_LANES) + (threadIdx.x / SP_LANES);
+    const bool live = s < n_own;
+    s = live ? s : n_own - 1;                               // (a dead group computes a valid point and stores nothing: the fold below shuffles)
+    const SparseGrid g = *sv.grid;
+    const float4 P = sv.sorted[own_is_1 ? 0 : 1][s];
+    const float4 *oth = sv.sorted[own_is_1 ? 1 : 0];
+    const int *cs = sv.cell_start[own_is_1 ? 1 : 0];
+    // the other cloud's factors in ITS sorted order: pass A reads remR of cloud 2, pass B fL of cloud 1, pass C + A fR and remR of cloud 2
+    const double *sf0 = PASS == 0 ? sv.fac[1][1] : (PASS == 1 ? sv.fac[0][0] : sv.fac[1][0]);
+    const double *sf1 = sv.fac[1][1];
+    const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
+    const int cx = sp_cell1(P.x, g.lo[0], g.ih[0], gx), cy = sp_cell1(P.y, g.lo[1], g.ih[1], gy), cz = sp_cell1(P.z, g.lo[2], g.ih[2], gz);
+    const C px = (C)P.x, py = (C)P.y, pz = (C)P.z;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gx - 1);
+    // the bounds of the (up to) nine rows first: one round trip for all of them
+    int rlo[9], rhi[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool in = z >= 0 && z < gz && y >= 0 && y < gy;
+        const int row = in ? (z * gy + y) * gx : 0;
+        rlo[r] = in ? cs[row + x0] : 0;
+        rhi[r] = in ? cs[row + x1 + 1] : 0;
+    }
+    // the nine runs as ONE list of T candidates (a loop per run would issue its loads for one or two candidates at a time: at
+    // the first levels a run holds 1.5 points on average, and the sweep was bound by the number of memory instructions):
+    // candidate k sits at sorted position k + off[r] for the run r with pre[r] <= k < pre[r + 1]
+    int pre[10], off[9];
+    pre[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { off[r] = rlo[r] - pre[r]; pre[r + 1] = pre[r] + (rhi[r] - rlo[r]); }
+    const int T = pre[9];
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int k0 = sub; k0 < T; k0 += SP_LANES * SP_BATCH) {
+        float4 O[SP_BATCH];
+        double f0[SP_BATCH], f1[SP_BATCH];
+        bool ok[SP_BATCH];
+#pragma unroll
+        for (int u = 0; u < SP_BATCH; ++u) {
+            const int k = k0 + SP_LANES * u;
+            ok[u] = k < T;
+            const int kk = ok[u] ? k : 0;
+            int o = off[0];
+#pragma unroll
+            for (int r = 1; r < 9; ++r) o = kk >= pre[r] ? off[r] : o;
+            const int ee = T > 0 ? kk + o : 0;
+            O[u] = oth[ee];
+            f0[u] = sf0[ee];
+            f1[u] = NF == 2 ? sf1[ee] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < SP_BATCH; ++u) {
+            const C d2 = PW::d2(px, py, pz, (C)O[u].x, (C)O[u].y, (C)O[u].z);
+            acc0 = fma(ok[u] ? (double)PW::w(d2, c0, etab) : 0.0, f0[u], acc0);
+            if (NF == 2) acc1 = fma(ok[u] ? (double)PW::w(d2, c1, etab) : 0.0, f1[u], acc1);
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < SP_LANES; off <<= 1) {          // (a + b is the same double on both sides: every lane ends with the same total)
+        acc0 += __shfl_xor(acc0, off);
+        if (NF == 2) acc1 += __shfl_xor(acc1, off);
+    }
+    if (live && sub == 0) sweep_epilogue<PASS>(__float_as_int(P.w), acc0, acc1, remL, remR, fL, fR, fL_next, ec);
+}
+
 template <int PASS, bool REF>
 __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, int li, typename PairWeight<REF>::L c0,
                                                                  typename PairWeight<REF>::L c1, const float *xyz1,
-                                                                 const float *xyz2, double *temp) {
+                                                                 const float *xyz2, double *temp, SparseArgs sp) {
     using PW = PairWeight<REF>;
     using C = typename PW::C;
     struct alignas(16) Pt { C x, y, z, pad; };
@@ -149,7 +495,14 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
     __shared__ double part[NF][SW_WAVES][SW_OWN];
     __shared__ unsigned long long etab[REF ? 32 : 1];
     if (REF && threadIdx.x < 32) etab[threadIdx.x] = EXPF_TAB[threadIdx.x];       // (the tile loop's barrier orders it)
-    const int c = blockIdx.y;
+    // 1-D grid: the sparse form's workgroups of ALL cloud pairs first, then the dense form's -- whichever kind a pair does not use
+    // leaves at once, and such workgroups must not sit BETWEEN working ones in dispatch order: with (kind, pair) interleaved per
+    // pair a launch that stayed dense took 265 instead of 140 us at B = 128 (2048 leaving workgroups among 2048 working ones)
+    const int n_sparse_all = sp.sparse_blocks * (int)gridDim.y;          // (gridDim.y = batch; gridDim.x = blocks per pair of both kinds)
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const bool sparse_wg = lin < n_sparse_all;
+    const int c = sparse_wg ? lin / max(sp.sparse_blocks, 1) : (lin - n_sparse_all) / sp.dense_blocks;
+    const int blk = sparse_wg ? lin % max(sp.sparse_blocks, 1) : (lin - n_sparse_all) % sp.dense_blocks;
     double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
     double *remL = t, *remR = t + n, *fL = t + (size_t)(n + m) * (1 + li), *fR = fL + n, *fL_next = fL + (n + m);
     const bool own_is_1 = PASS != 1;
@@ -158,11 +511,24 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
     const float *oth = (own_is_1 ? xyz2 : xyz1) + (size_t)c * n_oth * 3;
     const double *fac0 = PASS == 0 ? remR : (PASS == 1 ? fL : fR);      // PASS 3: C's factor fR_li ...
     const double *fac1 = remR;                                           // ... and A's factor remR
+    EpiCopy ec{nullptr, nullptr, nullptr};
+    if (sp.base) {   // a launch with both forms: this cloud pair's grid says which workgroups work (uniform per workgroup)
+        char *base = sp.base + (size_t)c * sp_bytes_per_pair(n, m);
+        ec = epi_copy<PASS>(sp, base, n, m);
+        const int use = sp.level >= 0 ? reinterpret_cast<const SparseGrid *>(base)[sp.level].use : 0;
+        if (sparse_wg) {
+            if (!use) return;
+            if (REF) __syncthreads();                       // etab
+            sweep_sparse_body<PASS, REF>(n, m, c0, c1, sp_view(base, n, m, sp.level), remL, remR, fL, fR, fL_next, ec, blk, etab);
+            return;
+        }
+        if (use) return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     C px[SW_R], py[SW_R], pz[SW_R];
 #pragma unroll
     for (int r = 0; r < SW_R; ++r) {
-        int i = blockIdx.x * SW_OWN + r * 64 + lane;
+        int i = blk * SW_OWN + r * 64 + lane;
         i = i < n_own ? i : n_own - 1;                       // (clamped lanes compute a valid point and are not stored)
         px[r] = own[3 * i]; py[r] = own[3 * i + 1]; pz[r] = own[3 * i + 2];
     }
@@ -221,7 +587,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
         for (int r = 0; r < SW_R; ++r) part[f][wave][r * 64 + lane] = acc[f][r];
     __syncthreads();
     if (threadIdx.x >= SW_OWN) return;
-    const int i = blockIdx.x * SW_OWN + threadIdx.x;
+    const int i = blk * SW_OWN + threadIdx.x;
     if (i >= n_own) return;
     double tot[NF];
 #pragma unroll
@@ -231,23 +597,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
         for (int w = 1; w < SW_WAVES; ++w) v += part[f][w][threadIdx.x];
         tot[f] = v;
     }
-    if (PASS == 0) {
-        fL[i] = remL[i] / (1e-9 + tot[0]);                   // the CPU starts its row sum at 1e-9 (:49)
-    } else if (PASS == 1) {
-        const double rr = remR[i];
-        const double ss = 1e-9 + rr * tot[0];
-        double r = rr / ss;
-        r = r < 1.0 ? r : 1.0;
-        const double f = rr * r;
-        fR[i] = f;
-        const double left = rr - f * tot[0];
-        remR[i] = left > 0.0 ? left : 0.0;
-    } else {
-        const double left = remL[i] - fL[i] * tot[0];
-        const double rl = left > 0.0 ? left : 0.0;
-        remL[i] = rl;
-        if (PASS == 3) fL_next[i] = rl / (1e-9 + tot[NF - 1]);
-    }
+    sweep_epilogue<PASS>(i, tot[0], tot[NF - 1], remL, remR, fL, fR, fL_next, ec);
 }
 
 // Level j = -2: level = 0, every pair weight is expf(0) = 1, so the row sums are the same for every point:
@@ -551,9 +901,12 @@ __global__ __launch_bounds__(64) void emd_grad2_kernel(int n, int m, const float
 
 using namespace geoadv;
 
+// scratch of the sparse levels behind the doubles (0 where the clouds are too large for the binning kernel's LDS sort)
+static size_t emd_sparse_floats(int b, int n, int m) { return std::max(n, m) <= SP_MAX_N ? (size_t)b * sp_bytes_per_pair(n, m) / 4 + 8 : 0; }
+
 extern "C" size_t geoadv_approx_match_temp_floats(int b, int n, int m) {
     if (b <= 0 || n + m <= 0) return 16;
-    return 2 * (size_t)b * emd_temp_doubles_per_cloud(n, m) + 16;
+    return 2 * (size_t)b * emd_temp_doubles_per_cloud(n, m) + emd_sparse_floats(b, n, m) + 16;
 }
 
 static int emd_check(const char *op, int b, int n, int m) {
@@ -564,23 +917,54 @@ static int emd_check(const char *op, int b, int n, int m) {
 }
 
 // the eleven levels: capacities and factors into temp (fp64), no plan yet
+static int g_emd_sparse = 1;               // geoadv_emd_sparse_levels: 0 = every sweep dense (the parity tests run both)
+
+// `sparse`: scratch of emd_sparse_floats(b, n, m) floats, 16-byte aligned, or null (clouds too large / switched off)
 template <bool REF>
-static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, double *t, EmdLevels<REF> &lv, hipStream_t st) {
+static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, double *t, char *sparse, EmdLevels<REF> &lv,
+                          hipStream_t st) {
     emd_init_kernel<<<dim3(cdiv(n + m, 256), b), 256, 0, st>>>(n, m, t);
     GA_LAUNCH_CHECK();
     for (int li = 0; li < EMD_LEVELS; ++li) lv.c[li] = PairWeight<REF>::level(li);
-    const dim3 g1(cdiv(n, SW_OWN), b), g2(cdiv(m, SW_OWN), b);
-    emd_sweep_kernel<0, REF><<<g1, SW_THREADS, 0, st>>>(n, m, 0, lv.c[0], 0, xyz1, xyz2, t);
+    if (!g_emd_sparse) sparse = nullptr;
+    if (sparse) {
+        // reach of level 8: beyond it both weight forms are exactly 0 -- glibc's expf below -103.97 (REF: float(level * d2)), v_exp_f32
+        // of an argument below -150 (fast: d2 * level * log2 e) -- i.e. level * d2 <= -104.7 covers both; the reach doubles per level
+        const float reach0 = sqrtf(104.7f / 65536.0f);
+        static DeviceOnce attr;
+        if (int rc = attr.run([]() -> int {
+                GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(emd_sparse_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_BIN_LDS));
+                return GEOADV_OK;
+            })) return rc;
+        emd_sparse_bin_kernel<<<dim3(SP_LEVELS, b), SP_BIN_THREADS, SP_BIN_LDS, st>>>(n, m, xyz1, xyz2, sparse, reach0);
+        GA_LAUNCH_CHECK();
+    }
+    const int d1 = cdiv(n, SW_OWN), d2 = cdiv(m, SW_OWN);
+    // a sweep whose larger level is a sparse one gets the sparse workgroups behind the dense ones (one of the two kinds leaves at once)
+    // (blocks per pair of both kinds in x, pairs in y: the kernel linearises them itself, sparse form first)
+    auto nsp = [&](int n_own, int level) { return sparse && level < SP_LEVELS ? cdiv(n_own, SW_THREADS / SP_LANES) : 0; };
+    auto grid = [&](int dense, int n_own, int level) { return dim3(dense + nsp(n_own, level), b); };
+    // (own level: the grid this sweep walks in its sparse form; consumer level: the sparse sweep that reads what its epilogue writes)
+    auto spa = [&](int dense, int n_own, int level, int cons) {
+        const bool any = sparse && (level < SP_LEVELS || cons < SP_LEVELS);
+        return SparseArgs{any ? sparse : nullptr, level < SP_LEVELS ? level : -1, dense, cons < SP_LEVELS ? cons : -1, nsp(n_own, level)};
+    };
+    emd_sweep_kernel<0, REF><<<grid(d1, n, 0), SW_THREADS, 0, st>>>(n, m, 0, lv.c[0], 0, xyz1, xyz2, t, spa(d1, n, 0, 0));
     for (int li = 0; li < EMD_LEVELS - 1; ++li) {
-        emd_sweep_kernel<1, REF><<<g2, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0, xyz1, xyz2, t);
-        if (li + 2 < EMD_LEVELS)                       // pass C of this level with pass A of the next
-            emd_sweep_kernel<3, REF><<<g1, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], lv.c[li + 1], xyz1, xyz2, t);
+        emd_sweep_kernel<1, REF><<<grid(d2, m, li), SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0, xyz1, xyz2, t, spa(d2, m, li, li + 1));
+        if (li + 2 < EMD_LEVELS)                       // pass C of this level with pass A of the next (whose reach is the larger one)
+            emd_sweep_kernel<3, REF><<<grid(d1, n, li + 1), SW_THREADS, 0, st>>>(n, m, li, lv.c[li], lv.c[li + 1], xyz1, xyz2, t, spa(d1, n, li + 1, li + 1));
         else                                           // the next level is the weightless one: it forms its own fL
-            emd_sweep_kernel<2, REF><<<g1, SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0, xyz1, xyz2, t);
+            emd_sweep_kernel<2, REF><<<dim3(d1, b), SW_THREADS, 0, st>>>(n, m, li, lv.c[li], 0, xyz1, xyz2, t, SparseArgs{nullptr, -1, d1, -1, 0});
         GA_LAUNCH_CHECK();
     }
     emd_level0_kernel<<<b, 1024, 0, st>>>(n, m, EMD_LEVELS - 1, t);
     GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_emd_sparse_levels(int on) {
+    g_emd_sparse = on ? 1 : 0;
     return GEOADV_OK;
 }
 
@@ -592,7 +976,8 @@ static int emd_mode_check(const char *op, int mode) {
 template <bool REF>
 static int approx_match_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, double *t, hipStream_t st) {
     EmdLevels<REF> lv;
-    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, lv, st)) return rc;
+    char *sparse = emd_sparse_floats(b, n, m) ? reinterpret_cast<char *>((reinterpret_cast<size_t>(t + (size_t)b * emd_temp_doubles_per_cloud(n, m)) + 15) & ~(size_t)15) : nullptr;
+    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, sparse, lv, st)) return rc;
     emd_match_kernel<REF><<<dim3(cdiv(n, 256), cdiv(m, EMD_LT), b), 256, 0, st>>>(n, m, lv, xyz1, xyz2, t, match);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
@@ -625,7 +1010,8 @@ static int emd_cost_grad1_impl(int b, int n, int m, const float *xyz1, const flo
                                hipStream_t st) {
     double *partial = t + (size_t)b * emd_temp_doubles_per_cloud(n, m);
     EmdLevels<REF> lv;
-    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, lv, st)) return rc;
+    char *sparse = emd_sparse_floats(b, n, m) ? reinterpret_cast<char *>((reinterpret_cast<size_t>(partial + (size_t)b * cdiv(n, 64)) + 15) & ~(size_t)15) : nullptr;
+    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, sparse, lv, st)) return rc;
     const int parts = cdiv(n, 64);
     emd_plan_cost_grad1_kernel<REF><<<dim3(parts, b), SW_THREADS, 0, st>>>(n, m, lv, xyz1, xyz2, t, partial, grad1);
     GA_LAUNCH_CHECK();

@@ -297,6 +297,11 @@ def critical_split(point_clouds, max_val, max_idx):
 EMD_FAST, EMD_REFERENCE = 0, 1          # include/geoadv.h: how the pair weight expf(level * d2) is evaluated
 
 
+def emd_sparse_levels(on):
+    """Process-wide: the sparse (cell-grid) form of the first three EMD levels' sweeps on (default) / off (include/geoadv.h)."""
+    _lib.check(_lib.lib().geoadv_emd_sparse_levels(int(bool(on))), "emd_sparse_levels")
+
+
 def approx_match(xyz1, xyz2, reference_weights=False):
     """tf_approxmatch.py:10-18.  xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n): match[b,l,k] is the
     soft assignment between xyz2 point l and xyz1 point k (the reference GPU op's layout; the CPU

@@ -98,6 +98,10 @@ int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz
 #define GEOADV_EMD_REFERENCE 1
 int geoadv_approx_match_mode(int mode, int b, int n, int m, const float *xyz1, const float *xyz2,
                              float *match, float *temp, void *stream);
+/* The first three levels' sweeps (level = -4^8, -4^7, -4^6: weights exactly 0 beyond 0.04 / 0.08 / 0.16) walk a cell grid instead
+ * of every pair (csrc/emd.hip, "Sparse levels"); on != 0 (default) / 0 = every sweep dense.  PROCESS-WIDE, for the parity tests and
+ * measurements, which run both: the results differ only in the order of fp64 additions. */
+int geoadv_emd_sparse_levels(int on);
 /* matchcostLauncher (tf_approxmatch.cpp:142; tf_approxmatch_g.cu:183-227): out[b]. */
 int geoadv_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *out, void *stream);

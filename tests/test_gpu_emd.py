@@ -150,3 +150,45 @@ def test_approx_match_deterministic_and_order_free():
     p1, p2 = torch.randperm(700, device="cuda:0"), torch.randperm(900, device="cuda:0")
     c = ops.approx_match(x1[:, p1], x2[:, p2])
     torch.testing.assert_close(c, a[:, p2][:, :, p1], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("reference_weights", [False, True])
+@pytest.mark.parametrize("kind,b,n,m", [("uniform", 3, 2048, 2048), ("uniform", 2, 700, 1300), ("shell", 2, 1024, 2048),
+                                         ("tiny_box", 2, 512, 512), ("flat", 2, 1024, 1024), ("far_apart", 2, 600, 600)])
+def test_sparse_levels_equal_dense_sweeps(kind, b, n, m, reference_weights):
+    """Round 4: the first three levels' sweeps on a cell grid (weights exactly 0 beyond 0.04 / 0.08 / 0.16) against every sweep
+    dense -- the same non-zero terms in another order of fp64 additions, so the plans agree to the conditioning of the
+    algorithm on that order (the bound the reference mode is held to against the CPU op: 2 float ulps) and mostly bit for bit;
+    cost and gradient of the fused form likewise.  Clouds: uniform cubes (different point counts), a sphere shell, a box so
+    small that the device keeps the dense sweeps (nothing to thin out), a flat cloud (one degenerate axis), and two clouds a
+    whole box apart (no pair within reach at the first levels)."""
+    import torch
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(n + m)
+    x1 = rng.random((b, n, 3)).astype(np.float32) - np.float32(0.5)
+    x2 = rng.random((b, m, 3)).astype(np.float32) - np.float32(0.5)
+    if kind == "shell":
+        v = rng.standard_normal((b, n, 3)); x1 = (0.4 * v / np.linalg.norm(v, axis=2, keepdims=True)).astype(np.float32)
+        v = rng.standard_normal((b, m, 3)); x2 = (0.41 * v / np.linalg.norm(v, axis=2, keepdims=True)).astype(np.float32)
+    elif kind == "tiny_box":
+        x1 *= np.float32(0.2); x2 *= np.float32(0.2)
+    elif kind == "flat":
+        x1[:, :, 2] = np.float32(0.1); x2[:, :, 2] = np.float32(0.1)
+    elif kind == "far_apart":
+        x2 += np.float32(1.5)
+    out = {}
+    for sparse in (False, True):
+        ops.emd_sparse_levels(sparse)
+        try:
+            out[sparse] = (ops.approx_match(_t(x1), _t(x2), reference_weights),) + ops.emd_cost_grad1(_t(x1), _t(x2), reference_weights)
+        finally:
+            ops.emd_sparse_levels(True)
+    md, cd, gd = out[False]
+    ms, cs_, gs = out[True]
+    torch.testing.assert_close(ms, md, rtol=2e-6, atol=2e-8)
+    torch.testing.assert_close(cs_, cd, rtol=1e-6, atol=0)
+    torch.testing.assert_close(gs, gd, rtol=1e-5, atol=1e-7)
+    if kind == "tiny_box":
+        assert torch.equal(ms, md)                                      # the device kept the dense sweeps: the same launches
+    again = ops.approx_match(_t(x1), _t(x2), reference_weights)         # reproducible run to run (stable binning order)
+    assert torch.equal(again, ms)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 if sys.argv[1] == "run":
     import numpy as np, torch
     from geometric_adv_amd import ops
-    B, N = 32, 2048
+    B, N = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 2048
     rng = np.random.default_rng(B)
     x = torch.as_tensor(rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)).cuda()
     y = torch.as_tensor(rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)).cuda()

@@ -26,12 +26,16 @@ for B, iters in ([(int(a), CASES.get(int(a), 10)) for a in sys.argv[1:]] or list
         torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
     tc = timed(lambda: ops.match_cost(xs, ys, m)); tg = timed(lambda: ops.match_cost_grad(xs, ys, m))
     tf = timed(lambda: ops.emd_cost_grad1(xs, ys))
+    ops.emd_sparse_levels(False)
+    tm_dense = timed(lambda: ops.approx_match(xs, ys), 3); tf_dense = timed(lambda: ops.emd_cost_grad1(xs, ys))
+    ops.emd_sparse_levels(True)
     tm = timed(lambda: ops.approx_match(xs, ys), 3) * 1e-3
     tmr = timed(lambda: ops.approx_match(xs, ys, reference_weights=True), 3)
     tfr = timed(lambda: ops.emd_cost_grad1(xs, ys, reference_weights=True))
     pw = 21.4 * B * N * N                    # pair-weights per approx_match: 10 levels x (B + C + A) sweeps, minus the missing first C / last A
     print(json.dumps({"batch": B, "ms_per_iteration_chamfer_plus_emd": dt * 1e3, "approx_match_ms": tm * 1e3,
                       "match_cost_ms": tc, "match_cost_grad_ms": tg, "fused_levels_cost_grad1_ms": tf,
+                      "every_sweep_dense": {"approx_match_ms": tm_dense, "fused_levels_cost_grad1_ms": tf_dense},
                       "reference_weights": {"approx_match_ms": tmr, "fused_levels_cost_grad1_ms": tfr},
                       "sweep_Tpair_weights_per_s_incl_plan_write": pw / tm / 1e12,
                       "match_bytes_GB": B * N * N * 4 / 1e9}))
