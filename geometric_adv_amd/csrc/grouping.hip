@@ -455,7 +455,7 @@ __device__ __forceinline__ int kg_wave_max(int v) {
 // rounded up to a multiple of 4 plus one group of padding; then the candidate queues (distance [, index]) of THREADS lanes.
 __host__ __device__ inline int kg_n4(int n) { return ((n + 3) & ~3) + 4; }
 template <int MODE> __host__ __device__ inline size_t kg_lds_bytes(int n, int threads) {
-    return (size_t)kg_n4(n) * 4 * (MODE == 0 ? 4 : 3) + (size_t)KF_QCAP * threads * 4 * (MODE == 0 ? 2 : 1);
+    return (size_t)kg_n4(n) * 4 * (MODE == 0 ? 4 : 3) + (size_t)KF_QCAP * threads * 4 * (MODE == 0 ? 2 : 1) + sizeof(int) * (KG_MAX_CELLS + 4);
 }
 constexpr int KG_MAX_N = 4096;             // the whole sorted cloud sits in LDS (48 / 64 KB at 4096 points)
 #ifndef KG_THREADS_V
@@ -489,9 +489,16 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
     int *si = reinterpret_cast<int *>(sz + n4);
     float *qd = sz + n4 + (MODE == 0 ? n4 : 0);
     int *qi = reinterpret_cast<int *>(qd + KF_QCAP * THREADS);
+#ifndef KG_LDS_CS
+#define KG_LDS_CS 1
+#endif
+#ifndef KG_PREFETCH
+#define KG_PREFETCH 0          // measured: 280 against 244 us -- the task taken one ahead is a task the counter can no longer balance
+#endif
+    int *cs_l = qi + (MODE == 0 ? KF_QCAP * THREADS : 0);   // the cell offsets too: every shell of every task looks rows up in them
     const int c = blockIdx.y;
     const float4 *pts = sorted + (size_t)c * n;
-    const int *cs = cell_start + (size_t)c * (KG_MAX_CELLS + 1);
+    const int *cs_g = cell_start + (size_t)c * (KG_MAX_CELLS + 1);
     const KnnGrid g = info[c];
     const int tasks = cdiv_dev(m, 64);
     const int task0 = (int)((long)tasks * blockIdx.x / split), task1 = (int)((long)tasks * (blockIdx.x + 1) / split);
@@ -514,17 +521,37 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
         }
     }
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
+    if (KG_LDS_CS) for (int e = threadIdx.x; e <= gx * gy * gz; e += THREADS) cs_l[e] = cs_g[e];
+    const int *cs = KG_LDS_CS ? cs_l : cs_g;
     const int lane = threadIdx.x & 63;
     GA_STAMP(0, 1);
     __syncthreads();                                        // the only workgroup barrier: from here on the waves go their own ways
     GA_STAMP(0, 2);
 
-    for (int task = task0 + (threadIdx.x >> 6); task < task1;) {
+    // (KG_PREFETCH: a task's queries requested one task ahead -- index, then coordinates, two dependent round trips that otherwise
+    // open every task; off, see above: what bounds this kernel is the spread of the tasks' costs, not their opening latency)
+    struct Query { int q; float x, y, z; };
+    auto load_query = [&](int task) {
         const int slot = task * 64 + lane;
-        const bool live = slot < m;
-        const int q = qorder[(size_t)c * m + (live ? slot : m - 1)];
-        const float *qp = xyz2 + ((size_t)c * m + q) * 3;
-        const float qx = qp[0], qy = qp[1], qz = qp[2];
+        Query r;
+        r.q = qorder[(size_t)c * m + (slot < m ? slot : m - 1)];
+        const float *qp = xyz2 + ((size_t)c * m + r.q) * 3;
+        r.x = qp[0]; r.y = qp[1]; r.z = qp[2];
+        return r;
+    };
+    int task = task0 + (threadIdx.x >> 6);
+    Query cur = load_query(task < task1 ? task : task0);
+    while (task < task1) {
+        int nt = 0;
+        Query nxt = cur;
+        if (KG_PREFETCH) {
+            if (lane == 0) nt = atomicAdd(&next_task, 1);
+            nt = __builtin_amdgcn_readfirstlane(nt);
+            nxt = load_query(nt < task1 ? nt : task);
+        }
+        const bool live = task * 64 + lane < m;
+        const int q = cur.q;
+        const float qx = cur.x, qy = cur.y, qz = cur.z;
         const int ccx = kg_cell1(qx, g.lo[0], g.ih[0], gx), ccy = kg_cell1(qy, g.lo[1], g.ih[1], gy), ccz = kg_cell1(qz, g.lo[2], g.ih[2], gz);
         // the wave's box of cells
         const int bx0 = kg_wave_min(ccx), bx1 = kg_wave_max(ccx), by0 = kg_wave_min(ccy), by1 = kg_wave_max(ccy);
@@ -665,9 +692,13 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
                 }
             }
         }
-        int nt = 0;
-        if (lane == 0) nt = atomicAdd(&next_task, 1);
-        task = __builtin_amdgcn_readfirstlane(nt);
+        if (!KG_PREFETCH) {
+            if (lane == 0) nt = atomicAdd(&next_task, 1);
+            nt = __builtin_amdgcn_readfirstlane(nt);
+            nxt = load_query(nt < task1 ? nt : task);
+        }
+        task = nt;
+        cur = nxt;
     }
     GA_STAMP(0, 7);
 }
