@@ -212,6 +212,10 @@ constexpr int SP_MAX_CANDIDATES = SP_MAX_CANDIDATES_V;          // ... and a lau
                                                 // dense core (the reconstruction of a random-init decoder is one) makes a few workgroups walk thousands
 constexpr size_t SP_BIN_LDS = sizeof(int) * (3 * (SP_MAX_CELLS + 4) + SP_MAX_N);
 
+// PER: points of a cloud per thread (n, m <= PER * SP_BIN_THREADS): every point is loaded ONCE, all requests of a thread in
+// flight together, and stays in registers with its cell through the five passes (box, count, scatter, rank, write) -- the first
+// form re-read the clouds in every pass, a dependent round trip each: 36 us per call at B = 32, all of it latency.
+template <int PER>
 __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, int m, const float *xyz1, const float *xyz2, char *sparse,
                                                                         float reach0) {
     extern __shared__ __attribute__((aligned(16))) int sp_lds[];
@@ -223,14 +227,29 @@ __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, i
     __shared__ SparseGrid g;
     const int level = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
     char *base = sparse + (size_t)c * sp_bytes_per_pair(n, m);
-    const float *p1 = xyz1 + (size_t)c * n * 3, *p2 = xyz2 + (size_t)c * m * 3;
+    const float *pc[2] = {xyz1 + (size_t)c * n * 3, xyz2 + (size_t)c * m * 3};
+    const int nn[2] = {n, m};
+    float px[2][PER], py[2][PER], pz[2][PER];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * SP_BIN_THREADS;
+            const bool in = i < nn[w];
+            const float *q = pc[w] + 3 * (size_t)(in ? i : 0);
+            px[w][u] = q[0]; py[w][u] = q[1]; pz[w][u] = q[2];
+        }
     // the box of BOTH clouds
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = t; i < n + m; i += SP_BIN_THREADS) {
-        const float *q = i < n ? p1 + 3 * (size_t)i : p2 + 3 * (size_t)(i - n);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], q[a]); hi[a] = fmaxf(hi[a], q[a]); }
-    }
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (t + u * SP_BIN_THREADS < nn[w]) {
+                lo[0] = fminf(lo[0], px[w][u]); hi[0] = fmaxf(hi[0], px[w][u]);
+                lo[1] = fminf(lo[1], py[w][u]); hi[1] = fmaxf(hi[1], py[w][u]);
+                lo[2] = fminf(lo[2], pz[w][u]); hi[2] = fmaxf(hi[2], pz[w][u]);
+            }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
@@ -256,17 +275,19 @@ __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, i
     }
     __syncthreads();
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2], cells = gx * gy * gz;
-    auto cell_of = [&](const float *px, int i) {
-        const float x = px[3 * (size_t)i], y = px[3 * (size_t)i + 1], z = px[3 * (size_t)i + 2];
-        return (sp_cell1(z, g.lo[2], g.ih[2], gz) * gy + sp_cell1(y, g.lo[1], g.ih[1], gy)) * gx + sp_cell1(x, g.lo[0], g.ih[0], gx);
-    };
-    for (int i = t; i < n; i += SP_BIN_THREADS) atomicAdd(&cntA[cell_of(p1, i)], 1);
-    for (int i = t; i < m; i += SP_BIN_THREADS) atomicAdd(&cntB[cell_of(p2, i)], 1);
+    int cid[2][PER];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            cid[w][u] = (sp_cell1(pz[w][u], g.lo[2], g.ih[2], gz) * gy + sp_cell1(py[w][u], g.lo[1], g.ih[1], gy)) * gx +
+                        sp_cell1(px[w][u], g.lo[0], g.ih[0], gx);
+            if (t + u * SP_BIN_THREADS < nn[w]) atomicAdd(&(w ? cntB : cntA)[cid[w][u]], 1);
+        }
     __syncthreads();
-    {   // the pairs the sparse sweeps would meet, and the fullest cell
+    {   // the pairs the sparse sweeps would meet, the fullest cell, the longest candidate list
         unsigned long long w = 0ull;
-        int mc = 0;
-        int mnb = 0;
+        int mc = 0, mnb = 0;
         for (int cell = t; cell < cells; cell += SP_BIN_THREADS) {
             const int a = cntA[cell], bq = cntB[cell];
             mc = max(mc, max(a, bq));
@@ -295,9 +316,9 @@ __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, i
     __syncthreads();
     if (!g.use) return;                                     // (uniform; nothing else of this level's data is read then)
     const SparseView v = sp_view(base, n, m, level);
+#pragma unroll
     for (int which = 0; which < 2; ++which) {
-        const int nx = which ? m : n;
-        const float *px = which ? p2 : p1;
+        const int nx = nn[which];
         int *cnt = which ? cntB : cntA;
         float4 *sorted = const_cast<float4 *>(v.sorted[which]);
         int *cs = const_cast<int *>(v.cell_start[which]);
@@ -320,27 +341,34 @@ __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, i
             for (int u = 0; u < 4; ++u) { cnt[4 * t + u] = before; cur[4 * t + u] = before; before += vv[u]; }
         }
         __syncthreads();
-        for (int i = t; i < SP_MAX_CELLS; i += SP_BIN_THREADS) cs[i] = cnt[i];
-        if (t < 4) cs[SP_MAX_CELLS + t] = nx;
-        for (int i = t; i < nx; i += SP_BIN_THREADS) perm[atomicAdd(&cur[cell_of(px, i)], 1)] = i;   // (scheduling order inside a cell)
+        for (int i = t; i < cells; i += SP_BIN_THREADS) cs[i] = cnt[i];
+        if (t == 0) cs[cells] = nx;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * SP_BIN_THREADS;
+            if (i < nx) perm[atomicAdd(&cur[cid[which][u]], 1)] = i;            // (scheduling order inside a cell)
+        }
         __syncthreads();
         // stable order: a point's place in its cell = the number of the cell's points with a smaller index (cur[cell] is now the
         // cell's end), so the order -- and with it the order of every fp64 sum of the sparse sweeps -- does not depend on scheduling
-        for (int i = t; i < nx; i += SP_BIN_THREADS) {
-            const int cell = cell_of(px, i);
-            const int b0 = cnt[cell], b1 = cur[cell];
-            int r = 0;
-            for (int j = b0; j < b1; ++j) r += perm[j] < i ? 1 : 0;
-            sorted[b0 + r] = make_float4(px[3 * (size_t)i], px[3 * (size_t)i + 1], px[3 * (size_t)i + 2], __int_as_float(i));
-            v.inv[which][i] = b0 + r;
-            // pass A of the first level reads remR of cloud 2 before any sweep has written it: its initial value (:26), everywhere
-            if (level == 0 && which == 1) v.fac[1][1][i] = (double)((n > m ? n : m) / m);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = t + u * SP_BIN_THREADS;
+            if (i < nx) {
+                const int cell = cid[which][u];
+                const int b0 = cnt[cell], b1 = cur[cell];
+                int r = 0;
+                for (int j = b0; j < b1; ++j) r += perm[j] < i ? 1 : 0;
+                sorted[b0 + r] = make_float4(px[which][u], py[which][u], pz[which][u], __int_as_float(i));
+                v.inv[which][i] = b0 + r;
+                // pass A of the first level reads remR of cloud 2 before any sweep has written it: its initial value (:26), everywhere
+                if (level == 0 && which == 1) v.fac[1][1][i] = (double)((n > m ? n : m) / m);
+            }
         }
         __syncthreads();
     }
 }
 
-// What the sweep kernel needs to know about the sparse form of its launch: null base = a dense launch.
 // `cons_level`: the level whose sparse sweep reads what this sweep's epilogue produces (-1: a dense one does)
 struct SparseArgs { char *base; int level, dense_blocks, cons_level, sparse_blocks; };   // blocks: per cloud pair
 
@@ -933,10 +961,16 @@ static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *x
         const float reach0 = sqrtf(104.7f / 65536.0f);
         static DeviceOnce attr;
         if (int rc = attr.run([]() -> int {
-                GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(emd_sparse_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_BIN_LDS));
+                GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(emd_sparse_bin_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_BIN_LDS));
+                GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(emd_sparse_bin_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_BIN_LDS));
+                GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(emd_sparse_bin_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SP_BIN_LDS));
                 return GEOADV_OK;
             })) return rc;
-        emd_sparse_bin_kernel<<<dim3(SP_LEVELS, b), SP_BIN_THREADS, SP_BIN_LDS, st>>>(n, m, xyz1, xyz2, sparse, reach0);
+        const dim3 bg(SP_LEVELS, b);
+        const int big = std::max(n, m);
+        if (big <= 2 * SP_BIN_THREADS) emd_sparse_bin_kernel<2><<<bg, SP_BIN_THREADS, SP_BIN_LDS, st>>>(n, m, xyz1, xyz2, sparse, reach0);
+        else if (big <= 4 * SP_BIN_THREADS) emd_sparse_bin_kernel<4><<<bg, SP_BIN_THREADS, SP_BIN_LDS, st>>>(n, m, xyz1, xyz2, sparse, reach0);
+        else emd_sparse_bin_kernel<8><<<bg, SP_BIN_THREADS, SP_BIN_LDS, st>>>(n, m, xyz1, xyz2, sparse, reach0);
         GA_LAUNCH_CHECK();
     }
     const int d1 = cdiv(n, SW_OWN), d2 = cdiv(m, SW_OWN);

@@ -15,6 +15,6 @@ python3 - "$OUT/pmc_train.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 for k, v in d.items():
-    if "train_bwd_split" in k or "train_fwd_kernel" in k:
+    if "train_bwd_fused" in k or "train_fwd_kernel" in k or "post_layer" in k or "bn_finalize" in k or "dec_out_bwd" in k or "fc_out_fwd" in k:
         print(k[:60], {c: (round(x["mean"]) if isinstance(x, dict) else round(x, 1)) for c, x in v.items()})
 PY
