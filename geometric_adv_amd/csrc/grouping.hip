@@ -360,8 +360,21 @@ __device__ __forceinline__ void kg_scan(int *a, int *wsum) {
     __syncthreads();
 }
 
+// min / max over the 64 lanes, result uniform (as an SGPR value)
+__device__ __forceinline__ int kg_wave_min(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int kg_wave_max(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n, int m, int G, const float *xyz1, const float *xyz2,
-                                                                          float4 *sorted, int *cell_start, int *qorder, KnnGrid *info) {
+                                                                          float4 *sorted, int *cell_start, int *qorder, KnnGrid *info,
+                                                                          int *task_order) {
     __shared__ int cnt[KG_MAX_CELLS], qcnt[KG_MAX_CELLS];
     __shared__ float red[7][KG_BUILD_THREADS / 64];
     __shared__ int wsum[KG_BUILD_THREADS / 64];
@@ -437,18 +450,35 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
         const int pos = atomicAdd(&qcnt[mc], 1);
         qorder[(size_t)c * m + pos] = j;
     }
-}
-
-// min / max over the 64 lanes, result uniform (as an SGPR value)
-__device__ __forceinline__ int kg_wave_min(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-__device__ __forceinline__ int kg_wave_max(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return __builtin_amdgcn_readfirstlane(v);
+    // The order in which the search hands out its tasks (64 consecutive queries of qorder each): the ones with the largest
+    // boxes of cells first -- a task costs between a few cells and the whole grid, and a workgroup's last tasks should be cheap
+    // ones (longest-processing-time-first; the estimate is the box of the task's cells grown by two cells a side).
+    __threadfence_block();
+    __syncthreads();
+    const int tasks = (m + 63) / 64;
+    int *tord = task_order + (size_t)c * tasks;
+    if (tasks > KG_BUILD_THREADS) {
+        for (int i = t; i < tasks; i += KG_BUILD_THREADS) tord[i] = i;
+        return;
+    }
+    int *tkey = cnt;                                           // (the cell counters are no longer needed)
+    for (int task = t >> 6; task < tasks; task += KG_BUILD_THREADS / 64) {
+        const int slot = task * 64 + (t & 63);
+        const int j = qorder[(size_t)c * m + (slot < m ? slot : m - 1)];
+        const float x = qry[3 * (size_t)j], y = qry[3 * (size_t)j + 1], z = qry[3 * (size_t)j + 2];
+        const int cx = kg_cell1(x, g.lo[0], g.ih[0], gx), cy = kg_cell1(y, g.lo[1], g.ih[1], gy), cz = kg_cell1(z, g.lo[2], g.ih[2], gz);
+        const int ex = min(gx - 1, kg_wave_max(cx) + 2) - max(0, kg_wave_min(cx) - 2) + 1;
+        const int ey = min(gy - 1, kg_wave_max(cy) + 2) - max(0, kg_wave_min(cy) - 2) + 1;
+        const int ez = min(gz - 1, kg_wave_max(cz) + 2) - max(0, kg_wave_min(cz) - 2) + 1;
+        if ((t & 63) == 0) tkey[task] = ex * ey * ez;
+    }
+    __syncthreads();
+    if (t < tasks) {
+        const int key = tkey[t];
+        int rank = 0;
+        for (int j = 0; j < tasks; ++j) rank += (tkey[j] > key || (tkey[j] == key && j < t)) ? 1 : 0;
+        tord[rank] = t;
+    }
 }
 
 // LDS of the search kernel (dynamic): the sorted cloud as planes x[n4] y[n4] z[n4] (+ original index [n4] for MODE 0), n4 = n
@@ -479,8 +509,8 @@ __device__ unsigned long long kg_diag[8];
 template <int MODE, int S, int THREADS>
 __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, int split, const float4 *__restrict__ sorted,
                                                            const int *__restrict__ cell_start, const int *__restrict__ qorder,
-                                                           const KnnGrid *__restrict__ info, const float *__restrict__ xyz2,
-                                                           float *val_out, int *idx_out, int *redo) {
+                                                           const KnnGrid *__restrict__ info, const int *__restrict__ task_order,
+                                                           const float *__restrict__ xyz2, float *val_out, int *idx_out, int *redo) {
     extern __shared__ __attribute__((aligned(16))) float kg_lds[];
     __shared__ int next_task;
     GA_STAMP(0, 0);
@@ -501,8 +531,11 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
     const int *cs_g = cell_start + (size_t)c * (KG_MAX_CELLS + 1);
     const KnnGrid g = info[c];
     const int tasks = cdiv_dev(m, 64);
-    const int task0 = (int)((long)tasks * blockIdx.x / split), task1 = (int)((long)tasks * (blockIdx.x + 1) / split);
-    if (threadIdx.x == 0) next_task = task0 + THREADS / 64;          // (every wave starts with the task of its own number)
+    // this workgroup's tasks: places blockIdx.x, blockIdx.x + split, ... of the cloud's task order (heaviest first, dealt round the
+    // cloud's workgroups), taken in that order through the counter
+    const int *tord = task_order + (size_t)c * tasks;
+    const int task0 = 0, task1 = (tasks - (int)blockIdx.x + split - 1) / split;       // (counted in places of this workgroup)
+    if (threadIdx.x == 0) next_task = task0 + THREADS / 64;          // (every wave starts with the place of its own number)
     {   // the cloud: all requests of a thread first, then the LDS writes (one round trip instead of one per 1024 points)
         constexpr int PER = (KG_MAX_N + 4 + THREADS - 1) / THREADS;
         float4 pt[PER];
@@ -531,8 +564,8 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
     // (KG_PREFETCH: a task's queries requested one task ahead -- index, then coordinates, two dependent round trips that otherwise
     // open every task; off, see above: what bounds this kernel is the spread of the tasks' costs, not their opening latency)
     struct Query { int q; float x, y, z; };
-    auto load_query = [&](int task) {
-        const int slot = task * 64 + lane;
+    auto load_query = [&](int place) {
+        const int slot = tord[blockIdx.x + place * split] * 64 + lane;
         Query r;
         r.q = qorder[(size_t)c * m + (slot < m ? slot : m - 1)];
         const float *qp = xyz2 + ((size_t)c * m + r.q) * 3;
@@ -549,7 +582,7 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
             nt = __builtin_amdgcn_readfirstlane(nt);
             nxt = load_query(nt < task1 ? nt : task);
         }
-        const bool live = task * 64 + lane < m;
+        const bool live = tord[blockIdx.x + task * split] * 64 + lane < m;
         const int q = cur.q;
         const float qx = cur.x, qy = cur.y, qz = cur.z;
         const int ccx = kg_cell1(qx, g.lo[0], g.ih[0], gx), ccy = kg_cell1(qy, g.lo[1], g.ih[1], gy), ccz = kg_cell1(qz, g.lo[2], g.ih[2], gz);
@@ -936,9 +969,10 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
     // dataset (+ 4 entries of padding: the scalar loads read four points at a time), cell offsets, query order, grid
     const size_t redo_b = sizeof(int) * ((size_t)b * m + 1), sorted_b = sizeof(float4) * ((size_t)b * n + 4);
     const size_t cs_b = sizeof(int) * (size_t)b * (KG_MAX_CELLS + 1), qo_b = sizeof(int) * (size_t)b * m, info_b = sizeof(KnnGrid) * (size_t)b;
+    const size_t to_b = sizeof(int) * (size_t)b * cdiv(m, 64);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     char *scratch = nullptr;
-    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), up(redo_b) + (grid ? up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b) : 0), st));
+    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), up(redo_b) + (grid ? up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b) + up(to_b) : 0), st));
     int *redo = reinterpret_cast<int *>(scratch);
     GA_HIP(hipMemsetAsync(redo, 0, sizeof(int), st));
     if (grid) {
@@ -946,9 +980,10 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         int *cs = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b));
         int *qo = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b));
         KnnGrid *info = reinterpret_cast<KnnGrid *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b));
+        int *tord = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b));
         const int G = n < KNN_GRID_N_MID ? KNN_GRID_G_SMALL : (n < KNN_GRID_N_BIG ? KNN_GRID_G_MID : KNN_GRID_G_BIG);
         GA_HIP(hipMemsetAsync(sorted + (size_t)b * n, 0, 4 * sizeof(float4), st));
-        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, 0, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info);
+        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, 0, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord);
         static DeviceOnce attr;
         if (int rc = attr.run([]() -> int {
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<MODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -960,7 +995,7 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         const int tasks = cdiv(m, 64), waves = KG_THREADS / 64;
         const int split = std::max(1, std::min(std::max(1, tasks / (waves * KG_TASKS_PER_WAVE)), cdiv(2 * kCUs, b)));
         knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE>(n, KG_THREADS), st>>>(n, m, k, split, sorted, cs, qo, info,
-                                                                                                                   xyz2, val, idx, redo);
+                                                                                                                   tord, xyz2, val, idx, redo);
     } else {
         knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
     }
