@@ -192,3 +192,28 @@ def test_sparse_levels_equal_dense_sweeps(kind, b, n, m, reference_weights):
         assert torch.equal(ms, md)                                      # the device kept the dense sweeps: the same launches
     again = ops.approx_match(_t(x1), _t(x2), reference_weights)         # reproducible run to run (stable binning order)
     assert torch.equal(again, ms)
+
+
+def test_sparse_levels_equal_dense_sweeps_randomised():
+    """Twelve random cloud pairs (n != m, anisotropic boxes from 0.05 to 4 wide, offsets, one cloud inside the other, clusters):
+    whatever the device decides per level -- sparse or dense -- the plan, the cost and the gradient agree with the all-dense run
+    to the order of fp64 additions."""
+    import torch
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(77)
+    for trial in range(12):
+        b = int(rng.integers(1, 4)); n = int(rng.integers(40, 1500)); m = int(rng.integers(40, 1500))
+        x1 = ((rng.random((b, n, 3)) - 0.5) * rng.uniform(0.05, 4.0, size=(b, 1, 3))).astype(np.float32)
+        x2 = ((rng.random((b, m, 3)) - 0.5) * rng.uniform(0.05, 4.0, size=(b, 1, 3)) + rng.uniform(-0.5, 0.5, size=(b, 1, 3))).astype(np.float32)
+        if trial % 3 == 0:
+            x1[:, : n // 3] = (x1[:, : n // 3] * 0.05).astype(np.float32)
+        out = {}
+        for sparse in (False, True):
+            ops.emd_sparse_levels(sparse)
+            try:
+                out[sparse] = (ops.approx_match(_t(x1), _t(x2)),) + ops.emd_cost_grad1(_t(x1), _t(x2))
+            finally:
+                ops.emd_sparse_levels(True)
+        torch.testing.assert_close(out[True][0], out[False][0], rtol=2e-6, atol=2e-8, msg=lambda s: "trial %d: %s" % (trial, s))
+        torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-6, atol=0)
+        torch.testing.assert_close(out[True][2], out[False][2], rtol=1e-5, atol=1e-7)

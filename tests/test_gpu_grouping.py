@@ -259,3 +259,31 @@ def test_grouping_argument_errors():
         ops.select_top_k(0, torch.rand((2, 3, 5), device="cuda:0"))
     with pytest.raises(ValueError):
         ops.knn_point(11, x, x)
+
+
+def test_knn_grid_equals_all_points_randomised():
+    """Thirty random problems -- batch, point counts (dataset != queries, not multiples of anything), k, anisotropic scales,
+    clusters, duplicated points (ties: both kernels hand those queries to the same redo kernel), a NaN coordinate in one cloud --:
+    the grid search and the all-points kernel return the same values and indices, bit for bit."""
+    import torch
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(2024)
+    for trial in range(30):
+        b = int(rng.integers(1, 5)); n = int(rng.integers(70, 4097)); m = int(rng.integers(1, 1500)); k = int(rng.integers(1, min(16, n) + 1))
+        x = rng.standard_normal((b, n, 3)).astype(np.float32) * rng.uniform(0.01, 3.0, size=(b, 1, 3)).astype(np.float32)
+        if trial % 3 == 0:
+            x[:, : n // 2] = (x[:, : n // 2] * 0.02 + rng.standard_normal((b, 1, 3))).astype(np.float32)      # a tight cluster
+        if trial % 4 == 1:
+            x[:, 10:30] = x[:, 40:60]                                                                       # duplicated points
+        q = np.concatenate([x[:, : m // 2], rng.standard_normal((b, m - m // 2, 3)).astype(np.float32) * 2.0], axis=1)
+        if trial == 7:
+            x[0, 3, 1] = np.nan
+        out = {}
+        for mode in ("all_points", "grid"):
+            ops.knn_grid_mode(mode)
+            try:
+                out[mode] = ops.knn_point(k, _t(x), _t(q))
+            finally:
+                ops.knn_grid_mode("auto")
+        for a, g in zip(out["all_points"], out["grid"]):
+            assert torch.equal(a.nan_to_num(nan=-1.0), g.nan_to_num(nan=-1.0)), (trial, b, n, m, k)
