@@ -141,11 +141,12 @@ __global__ void emd_init_kernel(int n, int m, double *temp) {
 // B7 10.3 / 27, C7 + A6 32.7 / 105, B6 24.6 / 76 against 45 / 153 (passes A, B) and 65 / 230 (C + A) dense, binning 36 / 63 us:
 // approx_match 1.24 -> 1.09 ms and 4.45 -> 3.79 ms (reference weights: 4.21 -> 3.94 ms at B = 32).  A sparse pair costs 4 (long
 // candidate lists) to 10 (short ones) dense pairs -- gathers, an fp64 fma chain per lane, the dense sweep's broadcast LDS reads
-// gone -- hence the device-side test SP_COST_RATIO * (pairs within the cells) <= n * m, and two bounds that keep a sparse launch
-// from lasting longer than a dense one whatever the clouds look like: no own point may face more than SP_MAX_CANDIDATES
-// candidates (W is an average; a cloud with a dense core makes a few lanes walk thousands), no cell hold more than
-// SP_MAX_CELL_POINTS points (the stable in-cell ranking is quadratic).  The attack's reconstruction of a random-init decoder is
-// such a core (extent 0.15 inside a unit target cloud): its levels stay dense and the call pays the binning kernel (+ 1-3 %).
+// gone -- hence the device-side test SP_COST_RATIO * (pairs met) <= n * m.  W is an average, though, and a sparse launch lasts as
+// long as its longest candidate list: a cloud with a dense core (the attack's reconstruction of a random-init decoder: extent
+// 0.15 inside a unit target cloud) puts thousands of candidates in front of the few points of the other cloud inside it.  So an
+// own point whose 27 cells hold more than SP_HEAVY candidates is HEAVY: the binning kernel lists such points per level and cloud,
+// the sparse form skips them, and the dense form's workgroups -- present in the launch anyway -- take the list instead of
+// leaving: the same dense arithmetic against the whole other cloud for just those points, 128 per workgroup.
 // Dead ends on the way, all measured: one lane per own point walking one candidate at a time (a chain of dependent L2 round
 // trips: level 6 in 127 / 66 us at B = 32); four lanes and batches of loads but factors gathered by original index (91 / 59: the
 // scattered 8-byte loads saturate the CU's address path); a loop per cell run instead of one flat candidate list (A8 78 us at
@@ -165,14 +166,16 @@ struct SparseGrid { float lo[3], ih[3]; int g[3], use; };
 // (x, y, z, original index), int cell_start[SP_MAX_CELLS + 4], int inv[nX] (original index -> place in `sorted`), and two
 // arrays of nX doubles: the factors the sparse sweeps of this level read for THIS cloud as the "other" one, in `sorted`'s
 // order (cloud 1: fL; cloud 2: fR and remR) -- written by the epilogue of the sweep that produces them (through inv), so a
-// candidate costs two sequential loads instead of a point and a dependent gather by original index
+// candidate costs two sequential loads instead of a point and a dependent gather by original index; and int heavy[nX + 4]: the
+// own points of this cloud whose candidate list would exceed SP_HEAVY (they take the dense form, see emd_sweep_kernel)
 __host__ __device__ inline size_t sp_up(size_t v) { return (v + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t sp_grid_bytes() { return sp_up(sizeof(SparseGrid) * SP_LEVELS); }
 __host__ __device__ inline size_t sp_cloud_bytes(int nx) {
-    return sp_up(sizeof(float4) * (size_t)nx) + sp_up(sizeof(int) * (SP_MAX_CELLS + 4)) + sp_up(sizeof(int) * (size_t)nx) + 2 * sp_up(sizeof(double) * (size_t)nx);
+    return sp_up(sizeof(float4) * (size_t)nx) + sp_up(sizeof(int) * (SP_MAX_CELLS + 4)) + sp_up(sizeof(int) * (size_t)nx) + 2 * sp_up(sizeof(double) * (size_t)nx) +
+           sp_up(sizeof(int) * ((size_t)nx + 4));
 }
 __host__ __device__ inline size_t sp_bytes_per_pair(int n, int m) { return sp_grid_bytes() + SP_LEVELS * (sp_cloud_bytes(n) + sp_cloud_bytes(m)); }
-struct SparseView { const SparseGrid *grid; const float4 *sorted[2]; const int *cell_start[2]; int *inv[2]; double *fac[2][2]; };
+struct SparseView { const SparseGrid *grid; const float4 *sorted[2]; const int *cell_start[2]; int *inv[2]; double *fac[2][2]; int *heavy[2]; };
 __host__ __device__ inline SparseView sp_view(char *base, int n, int m, int level) {
     SparseView v;
     v.grid = reinterpret_cast<const SparseGrid *>(base) + level;
@@ -185,7 +188,8 @@ __host__ __device__ inline SparseView sp_view(char *base, int n, int m, int leve
         v.cell_start[w] = reinterpret_cast<const int *>(q); q += sp_up(sizeof(int) * (SP_MAX_CELLS + 4));
         v.inv[w] = reinterpret_cast<int *>(q); q += sp_up(sizeof(int) * (size_t)nx);
         v.fac[w][0] = reinterpret_cast<double *>(q); q += sp_up(sizeof(double) * (size_t)nx);
-        v.fac[w][1] = reinterpret_cast<double *>(q);
+        v.fac[w][1] = reinterpret_cast<double *>(q); q += sp_up(sizeof(double) * (size_t)nx);
+        v.heavy[w] = reinterpret_cast<int *>(q);            // [0] = count, then the original indices of this cloud's HEAVY own points, ascending
         p += sp_cloud_bytes(nx);
     }
     return v;
@@ -204,13 +208,13 @@ __device__ __forceinline__ int sp_cell1(float v, float lo, float ih, int g) {
 #define SP_COST_RATIO_V 6
 #endif
 constexpr int SP_COST_RATIO = SP_COST_RATIO_V;
-constexpr int SP_MAX_CELL_POINTS = 256;         // the in-cell ranking below is quadratic in a cell's population
-#ifndef SP_MAX_CANDIDATES_V
-#define SP_MAX_CANDIDATES_V 400
+#ifndef SP_HEAVY_V
+#define SP_HEAVY_V 384
 #endif
-constexpr int SP_MAX_CANDIDATES = SP_MAX_CANDIDATES_V;          // ... and a launch lasts as long as its longest candidate list: W is an average, a cloud with a
-                                                // dense core (the reconstruction of a random-init decoder is one) makes a few workgroups walk thousands
-constexpr size_t SP_BIN_LDS = sizeof(int) * (3 * (SP_MAX_CELLS + 4) + SP_MAX_N);
+constexpr int SP_HEAVY = SP_HEAVY_V;            // an own point whose 27 cells hold more candidates than this takes the DENSE form: W is an average, a cloud
+                                                // with a dense core (the reconstruction of a random-init decoder is one) puts thousands of candidates in front of
+                                                // the few points of the other cloud inside it, and a sparse launch lasts as long as its longest list
+constexpr size_t SP_BIN_LDS = sizeof(int) * (5 * (SP_MAX_CELLS + 4) + SP_MAX_N);     // cntA, cntB, cursor, nbA, nbB, perm
 
 // PER: points of a cloud per thread (n, m <= PER * SP_BIN_THREADS): every point is loaded ONCE, all requests of a thread in
 // flight together, and stays in registers with its cell through the five passes (box, count, scatter, rank, write) -- the first
@@ -219,11 +223,12 @@ template <int PER>
 __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, int m, const float *xyz1, const float *xyz2, char *sparse,
                                                                         float reach0) {
     extern __shared__ __attribute__((aligned(16))) int sp_lds[];
-    int *cntA = sp_lds, *cntB = cntA + SP_MAX_CELLS + 4, *cur = cntB + SP_MAX_CELLS + 4, *perm = cur + SP_MAX_CELLS + 4;
+    int *cntA = sp_lds, *cntB = cntA + SP_MAX_CELLS + 4, *cur = cntB + SP_MAX_CELLS + 4, *nbA = cur + SP_MAX_CELLS + 4, *nbB = nbA + SP_MAX_CELLS + 4;
+    int *perm = nbB + SP_MAX_CELLS + 4;
     __shared__ float red[6][SP_BIN_THREADS / 64];
     __shared__ int wsum[SP_BIN_THREADS / 64];
-    __shared__ unsigned long long work;
-    __shared__ int maxcnt, maxnb;
+    __shared__ unsigned long long work, work2;
+    __shared__ int hcount;
     __shared__ SparseGrid g;
     const int level = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
     char *base = sparse + (size_t)c * sp_bytes_per_pair(n, m);
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, i
 #pragma unroll
         for (int a = 0; a < 3; ++a) { red[a][t >> 6] = lo[a]; red[3 + a][t >> 6] = hi[a]; }
     for (int i = t; i < 2 * (SP_MAX_CELLS + 4); i += SP_BIN_THREADS) cntA[i] = 0;       // (cntA and cntB are adjacent)
-    if (t == 0) { work = 0ull; maxcnt = 0; maxnb = 0; }
+    if (t == 0) { work = 0ull; work2 = 0ull; }
     __syncthreads();
     if (t == 0) {
         const float reach = reach0 * (float)(1 << level) * 1.01f;       // the reach doubles from level to level (level = -4^j)
@@ -285,32 +290,30 @@ __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, i
             if (t + u * SP_BIN_THREADS < nn[w]) atomicAdd(&(w ? cntB : cntA)[cid[w][u]], 1);
         }
     __syncthreads();
-    {   // the pairs the sparse sweeps would meet, the fullest cell, the longest candidate list
-        unsigned long long w = 0ull;
-        int mc = 0, mnb = 0;
+    {   // per cell: the points of either cloud in the 27 cells around it (= the candidate list of an own point of the OTHER cloud in
+        // this cell); W = the pairs the sparse sweeps would meet if no point were heavy
+        unsigned long long w = 0ull, w2 = 0ull;
         for (int cell = t; cell < cells; cell += SP_BIN_THREADS) {
-            const int a = cntA[cell], bq = cntB[cell];
-            mc = max(mc, max(a, bq));
-            if (a == 0 && bq == 0) continue;
             const int x = cell % gx, y = (cell / gx) % gy, z = cell / (gx * gy);
-            int nbA = 0, nbB = 0;
+            int sa = 0, sb = 0;
             for (int zz = max(z - 1, 0); zz <= min(z + 1, gz - 1); ++zz)
                 for (int yy = max(y - 1, 0); yy <= min(y + 1, gy - 1); ++yy)
                     for (int xx = max(x - 1, 0); xx <= min(x + 1, gx - 1); ++xx) {
-                        nbA += cntA[(zz * gy + yy) * gx + xx];
-                        nbB += cntB[(zz * gy + yy) * gx + xx];
+                        sa += cntA[(zz * gy + yy) * gx + xx];
+                        sb += cntB[(zz * gy + yy) * gx + xx];
                     }
-            w += (unsigned long long)a * (unsigned long long)nbB;
-            mnb = max(mnb, max(a ? nbB : 0, bq ? nbA : 0));   // the longest candidate list any own point of either cloud would walk
+            nbA[cell] = sa; nbB[cell] = sb;
+            // the cost of this cell's own points in dense-pair units, for either cloud as "own": a sparse pair costs SP_COST_RATIO
+            // dense ones, a heavy point a dense row (m or n pairs)
+            w += (unsigned long long)cntA[cell] * (unsigned long long)(sb <= SP_HEAVY ? SP_COST_RATIO * sb : m);
+            w2 += (unsigned long long)cntB[cell] * (unsigned long long)(sa <= SP_HEAVY ? SP_COST_RATIO * sa : n);
         }
-        atomicAdd(&work, w);                                  // (integers: the sum does not depend on the order)
-        atomicMax(&maxcnt, mc);
-        atomicMax(&maxnb, mnb);
+        atomicAdd(&work, w);                                  // (integers: the sums do not depend on the order)
+        atomicAdd(&work2, w2);
     }
     __syncthreads();
     if (t == 0) {
-        g.use = (work * (unsigned long long)SP_COST_RATIO <= (unsigned long long)n * (unsigned long long)m && maxcnt <= SP_MAX_CELL_POINTS &&
-                 maxnb <= SP_MAX_CANDIDATES && max(n, m) <= SP_MAX_N) ? 1 : 0;
+        g.use = (max(work, work2) <= (unsigned long long)n * (unsigned long long)m && max(n, m) <= SP_MAX_N) ? 1 : 0;
         reinterpret_cast<SparseGrid *>(base)[level] = g;
     }
     __syncthreads();
@@ -343,27 +346,57 @@ __global__ __launch_bounds__(SP_BIN_THREADS) void emd_sparse_bin_kernel(int n, i
         __syncthreads();
         for (int i = t; i < cells; i += SP_BIN_THREADS) cs[i] = cnt[i];
         if (t == 0) cs[cells] = nx;
+        int spos[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int i = t + u * SP_BIN_THREADS;
-            if (i < nx) perm[atomicAdd(&cur[cid[which][u]], 1)] = i;            // (scheduling order inside a cell)
+            spos[u] = 0;
+            if (i < nx) { spos[u] = atomicAdd(&cur[cid[which][u]], 1); perm[spos[u]] = i; }      // (scheduling order inside a cell)
         }
         __syncthreads();
         // stable order: a point's place in its cell = the number of the cell's points with a smaller index (cur[cell] is now the
-        // cell's end), so the order -- and with it the order of every fp64 sum of the sparse sweeps -- does not depend on scheduling
+        // cell's end), so the order -- and with it the order of every fp64 sum of the sparse sweeps -- does not depend on
+        // scheduling.  Cells fuller than SP_HEAVY keep the scatter's order: every list such a cell would be part of is longer than
+        // SP_HEAVY, i.e. belongs to a heavy point, which does not read the sorted arrays at all.
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int i = t + u * SP_BIN_THREADS;
             if (i < nx) {
                 const int cell = cid[which][u];
                 const int b0 = cnt[cell], b1 = cur[cell];
-                int r = 0;
-                for (int j = b0; j < b1; ++j) r += perm[j] < i ? 1 : 0;
-                sorted[b0 + r] = make_float4(px[which][u], py[which][u], pz[which][u], __int_as_float(i));
-                v.inv[which][i] = b0 + r;
+                int place = spos[u];                         // (a full cell: the scatter's place)
+                if (b1 - b0 <= SP_HEAVY) {
+                    int r = 0;
+                    for (int j = b0; j < b1; ++j) r += perm[j] < i ? 1 : 0;
+                    place = b0 + r;
+                }
+                sorted[place] = make_float4(px[which][u], py[which][u], pz[which][u], __int_as_float(i));
+                v.inv[which][i] = place;
                 // pass A of the first level reads remR of cloud 2 before any sweep has written it: its initial value (:26), everywhere
                 if (level == 0 && which == 1) v.fac[1][1][i] = (double)((n > m ? n : m) / m);
             }
+        }
+        // this cloud's heavy own points (candidate list = the OTHER cloud's points around the point's cell), ascending index
+        {
+            const int *nbo = which ? nbA : nbB;
+            int *hl = v.heavy[which];
+            if (t == 0) hcount = 0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int i = t + u * SP_BIN_THREADS;
+                const bool hv = i < nx && nbo[cid[which][u]] > SP_HEAVY;
+                const unsigned long long bal = __ballot(hv);
+                if ((t & 63) == 0) wsum[t >> 6] = __popcll(bal);
+                __syncthreads();
+                int before = hcount, total = 0;
+                for (int w = 0; w < SP_BIN_THREADS / 64; ++w) { before += w < (t >> 6) ? wsum[w] : 0; total += wsum[w]; }
+                if (hv) hl[1 + before + __popcll(bal & ((1ull << (t & 63)) - 1ull))] = i;
+                __syncthreads();
+                if (t == 0) hcount += total;
+                __syncthreads();
+            }
+            if (t == 0) hl[0] = hcount;
         }
         __syncthreads();
     }
@@ -477,6 +510,8 @@ __device__ __forceinline__ void sweep_sparse_body(int n, int m, typename PairWei
 #pragma unroll
     for (int r = 0; r < 9; ++r) { off[r] = rlo[r] - pre[r]; pre[r + 1] = pre[r] + (rhi[r] - rlo[r]); }
     const int T = pre[9];
+    if (T > SP_HEAVY) return;                               // a heavy point: the dense form's workgroups take it (the same count the binning kernel saw;
+                                                            // uniform in the four lanes of the point, and nothing below crosses points)
     double acc0 = 0.0, acc1 = 0.0;
     for (int k0 = sub; k0 < T; k0 += SP_LANES * SP_BATCH) {
         float4 O[SP_BATCH];
@@ -529,8 +564,11 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
     const int n_sparse_all = sp.sparse_blocks * (int)gridDim.y;          // (gridDim.y = batch; gridDim.x = blocks per pair of both kinds)
     const int lin = blockIdx.y * gridDim.x + blockIdx.x;
     const bool sparse_wg = lin < n_sparse_all;
-    const int c = sparse_wg ? lin / max(sp.sparse_blocks, 1) : (lin - n_sparse_all) / sp.dense_blocks;
-    const int blk = sparse_wg ? lin % max(sp.sparse_blocks, 1) : (lin - n_sparse_all) % sp.dense_blocks;
+    // (the dense form's workgroups block-major -- block 0 of every pair, then block 1 of every pair ... --: where a level is sparse
+    // they only take the pair's heavy points, a few blocks per pair, and the ones that leave must again not sit between the ones
+    // that work: pair-major, pass B of a blob / uniform pair took 150 us for ONE working block per pair)
+    const int c = sparse_wg ? lin / max(sp.sparse_blocks, 1) : (lin - n_sparse_all) % (int)gridDim.y;
+    const int blk = sparse_wg ? lin % max(sp.sparse_blocks, 1) : (lin - n_sparse_all) / (int)gridDim.y;
     double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
     double *remL = t, *remR = t + n, *fL = t + (size_t)(n + m) * (1 + li), *fR = fL + n, *fL_next = fL + (n + m);
     const bool own_is_1 = PASS != 1;
@@ -540,6 +578,8 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
     const double *fac0 = PASS == 0 ? remR : (PASS == 1 ? fL : fR);      // PASS 3: C's factor fR_li ...
     const double *fac1 = remR;                                           // ... and A's factor remR
     EpiCopy ec{nullptr, nullptr, nullptr};
+    const int *hlist = nullptr;                             // non-null: own points = hlist[1 .. hcnt] instead of blk * SW_OWN + ...
+    int hcnt = 0;
     if (sp.base) {   // a launch with both forms: this cloud pair's grid says which workgroups work (uniform per workgroup)
         char *base = sp.base + (size_t)c * sp_bytes_per_pair(n, m);
         ec = epi_copy<PASS>(sp, base, n, m);
@@ -550,13 +590,18 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
             sweep_sparse_body<PASS, REF>(n, m, c0, c1, sp_view(base, n, m, sp.level), remL, remR, fL, fR, fL_next, ec, blk, etab);
             return;
         }
-        if (use) return;
+        if (use) {   // this level is sparse for the pair: the dense form only takes the HEAVY own points (the binning kernel's list)
+            hlist = sp_view(base, n, m, sp.level).heavy[own_is_1 ? 0 : 1];
+            hcnt = hlist[0];
+            if (blk * SW_OWN >= hcnt) return;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     C px[SW_R], py[SW_R], pz[SW_R];
 #pragma unroll
     for (int r = 0; r < SW_R; ++r) {
         int i = blk * SW_OWN + r * 64 + lane;
+        if (hlist) i = hlist[1 + (i < hcnt ? i : hcnt - 1)];
         i = i < n_own ? i : n_own - 1;                       // (clamped lanes compute a valid point and are not stored)
         px[r] = own[3 * i]; py[r] = own[3 * i + 1]; pz[r] = own[3 * i + 2];
     }
@@ -615,7 +660,11 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_sweep_kernel(int n, int m, 
         for (int r = 0; r < SW_R; ++r) part[f][wave][r * 64 + lane] = acc[f][r];
     __syncthreads();
     if (threadIdx.x >= SW_OWN) return;
-    const int i = blk * SW_OWN + threadIdx.x;
+    int i = blk * SW_OWN + threadIdx.x;
+    if (hlist) {
+        if (i >= hcnt) return;
+        i = hlist[1 + i];
+    }
     if (i >= n_own) return;
     double tot[NF];
 #pragma unroll

@@ -154,14 +154,18 @@ def test_approx_match_deterministic_and_order_free():
 
 @pytest.mark.parametrize("reference_weights", [False, True])
 @pytest.mark.parametrize("kind,b,n,m", [("uniform", 3, 2048, 2048), ("uniform", 2, 700, 1300), ("shell", 2, 1024, 2048),
-                                         ("tiny_box", 2, 512, 512), ("flat", 2, 1024, 1024), ("far_apart", 2, 600, 600)])
+                                         ("tiny_box", 2, 512, 512), ("flat", 2, 1024, 1024), ("far_apart", 2, 600, 600),
+                                         ("blob_in_cube", 3, 2048, 2048), ("cube_in_blob", 2, 1500, 900)])
 def test_sparse_levels_equal_dense_sweeps(kind, b, n, m, reference_weights):
     """Round 4: the first three levels' sweeps on a cell grid (weights exactly 0 beyond 0.04 / 0.08 / 0.16) against every sweep
     dense -- the same non-zero terms in another order of fp64 additions, so the plans agree to the conditioning of the
     algorithm on that order (the bound the reference mode is held to against the CPU op: 2 float ulps) and mostly bit for bit;
     cost and gradient of the fused form likewise.  Clouds: uniform cubes (different point counts), a sphere shell, a box so
-    small that the device keeps the dense sweeps (nothing to thin out), a flat cloud (one degenerate axis), and two clouds a
-    whole box apart (no pair within reach at the first levels)."""
+    small that the device keeps the dense sweeps (nothing to thin out), a flat cloud (one degenerate axis), two clouds a
+    whole box apart (no pair within reach at the first levels), and a Gaussian blob of width 0.02 inside a unit cube either way
+    round (the attack's random-init reconstruction: the cube's points next to the blob are HEAVY -- thousands of candidates --
+    and go through the dense form's workgroups inside the sparse launch; the blob's cells are fuller than the in-cell ranking
+    handles)."""
     import torch
     from geometric_adv_amd import ops
     rng = np.random.default_rng(n + m)
@@ -176,6 +180,10 @@ def test_sparse_levels_equal_dense_sweeps(kind, b, n, m, reference_weights):
         x1[:, :, 2] = np.float32(0.1); x2[:, :, 2] = np.float32(0.1)
     elif kind == "far_apart":
         x2 += np.float32(1.5)
+    elif kind == "blob_in_cube":
+        x1 = (rng.standard_normal((b, n, 3)) * 0.022).astype(np.float32)
+    elif kind == "cube_in_blob":
+        x2 = (rng.standard_normal((b, m, 3)) * 0.022 + 0.1).astype(np.float32)
     out = {}
     for sparse in (False, True):
         ops.emd_sparse_levels(sparse)

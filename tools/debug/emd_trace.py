@@ -7,7 +7,8 @@ if sys.argv[1] == "run":
     from geometric_adv_amd import ops
     B, N = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 2048
     rng = np.random.default_rng(B)
-    x = torch.as_tensor(rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)).cuda()
+    blob = len(sys.argv) > 3 and sys.argv[3] == "blob"          # cloud 1 = a Gaussian blob (std 0.022) inside the unit cloud 2: the attack's random-init reconstruction
+    x = torch.as_tensor((rng.standard_normal((B, N, 3)) * 0.022).astype(np.float32) if blob else rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)).cuda()
     y = torch.as_tensor(rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)).cuda()
     for _ in range(3):
         ops.emd_cost_grad1(x, y)
