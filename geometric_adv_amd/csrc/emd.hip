@@ -137,16 +137,20 @@ __global__ void emd_init_kernel(int n, int m, double *temp) {
 // cells would not thin the pairs out enough -- a box of a few cells, points piled into a few cells, clouds of very different
 // extent -- a level keeps its dense sweeps: the choice is made per cloud pair and level on the device (SparseGrid::use,
 // emd_sparse_bin_kernel), both kinds of workgroups are in every such launch.
-// Measured (B = 32 / 128, N = 2048, uniform clouds; per launch under rocprofv3): A8 8.0 / 21 us, B8 9.2 / 24, C8 + A7 11.1 / 33,
-// B7 10.3 / 27, C7 + A6 32.7 / 105, B6 24.6 / 76 against 45 / 153 (passes A, B) and 65 / 230 (C + A) dense, binning 36 / 63 us:
-// approx_match 1.24 -> 1.09 ms and 4.45 -> 3.79 ms (reference weights: 4.21 -> 3.94 ms at B = 32).  A sparse pair costs 4 (long
-// candidate lists) to 10 (short ones) dense pairs -- gathers, an fp64 fma chain per lane, the dense sweep's broadcast LDS reads
+// Measured (B = 32 / 128, N = 2048, uniform clouds; per launch under rocprofv3, profiles/r04_emd_trace_b32.txt / _b128.txt):
+// A8 8.2 / 23 us, B8 9.2 / 25, C8 + A7 11.2 / 35, B7 10.4 / 29, C7 + A6 32.9 / 107, B6 24.5 / 79 against 46 / 160 (passes A, B) and
+// 65 / 235 (C + A) dense, binning 32 / 57 us: approx_match 1.23 -> 1.08 ms and 4.40 -> 3.77 ms (reference weights: 4.21 -> 3.94 ms at
+// B = 32).  A sparse pair costs 4 (long candidate lists) to 10 (short ones) dense pairs -- gathers, an fp64 fma chain per lane, the dense sweep's broadcast LDS reads
 // gone -- hence the device-side test SP_COST_RATIO * (pairs met) <= n * m.  W is an average, though, and a sparse launch lasts as
 // long as its longest candidate list: a cloud with a dense core (the attack's reconstruction of a random-init decoder: extent
 // 0.15 inside a unit target cloud) puts thousands of candidates in front of the few points of the other cloud inside it.  So an
 // own point whose 27 cells hold more than SP_HEAVY candidates is HEAVY: the binning kernel lists such points per level and cloud,
 // the sparse form skips them, and the dense form's workgroups -- present in the launch anyway -- take the list instead of
 // leaving: the same dense arithmetic against the whole other cloud for just those points, 128 per workgroup.
+// On the attack's own pairs (a blob of extent 0.15 in a unit cube, r04_emd_trace_blob_b32.txt / _b128.txt) the sweeps whose own
+// cloud is the wide one stay as above (A8 7.7 / 21 us, C8 + A7 11 / 33, C7 + A6 33 / 111) and the ones whose own cloud is the blob
+// run at their heavy points' pace (B8 33 / 66 us, B7 33 / 66, B6 34 / 99 -- still below the dense 46 / 160), binning 53 / 91 us:
+// configs[3]'s attack iteration 5.41 -> 4.89 ms at B = 128.
 // Dead ends on the way, all measured: one lane per own point walking one candidate at a time (a chain of dependent L2 round
 // trips: level 6 in 127 / 66 us at B = 32); four lanes and batches of loads but factors gathered by original index (91 / 59: the
 // scattered 8-byte loads saturate the CU's address path); a loop per cell run instead of one flat candidate list (A8 78 us at
@@ -202,8 +206,8 @@ __device__ __forceinline__ int sp_cell1(float v, float lo, float ih, int g) {
 // grid = (SP_LEVELS, b): one workgroup bins BOTH clouds of a pair on the level's grid and decides whether the level's sparse
 // sweeps pay: they meet W = sum over cells of (own points in the cell) x (other points in the 27 cells around it) pairs -- the
 // same number whichever cloud is "own" -- at several times the dense sweep's cost per pair (gathers, four lanes per own point),
-// so `use` needs SP_COST_RATIO * W <= n * m; clouds piled into a few cells (the attack's reconstruction of a random-init
-// decoder is one small blob) keep the dense sweeps.  LDS (dynamic): cntA, cntB, cursor [SP_MAX_CELLS + 4] ints, perm [SP_MAX_N].
+// so `use` needs SP_COST_RATIO * W' <= n * m, W' = W without the HEAVY own points' share plus n (m) dense pairs for each of
+// those (they go to the dense form's workgroups); a level whose cells do not thin the pairs out keeps the dense sweeps.  LDS (dynamic): cntA, cntB, cursor [SP_MAX_CELLS + 4] ints, perm [SP_MAX_N].
 #ifndef SP_COST_RATIO_V
 #define SP_COST_RATIO_V 6
 #endif

@@ -1036,11 +1036,14 @@ static int launch_knn(int mode, int b, int n, int m, int k, const float *xyz1, c
             if (slots <= 3) return launch_knn_fast<0, 3>(b, n, m, k, xyz1, xyz2, val, idx, st);
             if (slots <= 5) return launch_knn_fast<0, 5>(b, n, m, k, xyz1, xyz2, val, idx, st);
             if (slots <= 9) return launch_knn_fast<0, 9>(b, n, m, k, xyz1, xyz2, val, idx, st);
+            if (slots <= 11) return launch_knn_fast<0, 11>(b, n, m, k, xyz1, xyz2, val, idx, st);     // k = 9 (the defender's knn_point call), 10
+            if (slots <= 13) return launch_knn_fast<0, 13>(b, n, m, k, xyz1, xyz2, val, idx, st);
             return launch_knn_fast<0, 17>(b, n, m, k, xyz1, xyz2, val, idx, st);
         }
         if (slots <= 3) return launch_knn_fast<1, 3>(b, n, m, k, xyz1, xyz2, val, idx, st);
         if (slots <= 5) return launch_knn_fast<1, 5>(b, n, m, k, xyz1, xyz2, val, idx, st);
         if (slots <= 9) return launch_knn_fast<1, 9>(b, n, m, k, xyz1, xyz2, val, idx, st);
+        if (slots <= 13) return launch_knn_fast<1, 13>(b, n, m, k, xyz1, xyz2, val, idx, st);
         return launch_knn_fast<1, 17>(b, n, m, k, xyz1, xyz2, val, idx, st);
     }
     // enough workgroups to fill the chip, a few queries each to amortise the launch
