@@ -793,7 +793,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int 
     if (REF && threadIdx.x < 32) etab[threadIdx.x] = EXPF_TAB[threadIdx.x];
     const int c = blockIdx.y;
     const double *t = temp + (size_t)c * emd_temp_doubles_per_cloud(n, m);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int k = blockIdx.x * 64 + lane;
     const bool live = k < n;
     k = live ? k : n - 1;
@@ -837,15 +837,49 @@ __global__ __launch_bounds__(SW_THREADS, 2) void emd_plan_cost_grad1_kernel(int 
         __syncthreads();
         if (t0 + TILE < m) request(t0 + TILE);
         const int per = (cnt + SW_WAVES - 1) / SW_WAVES;
-        const int lo = wave * per, hi = min(cnt, lo + per);
+        const int lo = wave * per, hi = min(cnt, lo + per);  // (wave: an SGPR, so the walk is a scalar loop)
         float cs = 0.f;
-        for (int l = lo; l < hi; ++l) {
-            const float ox = qx[l] - px, oy = qy[l] - py, oz = qz[l] - pz;          // q - p, like the CPU loops
-            const float w = plan_value<REF>(lv, PW::d2(px, py, pz, qx[l], qy[l], qz[l]), fl, &fr[0][l], TILE, etab);
-            const float d = sqrtf(ox * ox + oy * oy + oz * oz);                     // matchcost_cpu's own float distance (:93-96)
-            cs += d * w;                                                            // (:97-99) float product, summed below in double
-            const float inv = 1.0f / fmaxf(d, 1e-20f);
-            gx = fmaf(-w, ox * inv, gx); gy = fmaf(-w, oy * inv, gy); gz = fmaf(-w, oz * inv, gz);
+        if constexpr (REF) {
+            for (int l = lo; l < hi; ++l) {
+                const float ox = qx[l] - px, oy = qy[l] - py, oz = qz[l] - pz;          // q - p, like the CPU loops
+                const float w = plan_value<REF>(lv, PW::d2(px, py, pz, qx[l], qy[l], qz[l]), fl, &fr[0][l], TILE, etab);
+                const float d = sqrtf(ox * ox + oy * oy + oz * oz);                     // matchcost_cpu's own float distance (:93-96)
+                cs += d * w;                                                            // (:97-99) float product, summed below in double
+                const float inv = 1.0f / fmaxf(d, 1e-20f);
+                gx = fmaf(-w, ox * inv, gx); gy = fmaf(-w, oy * inv, gy); gz = fmaf(-w, oz * inv, gz);
+            }
+        } else {
+            // The fast mode's walk is bound by VALU issue, and half of what it issued was not the plan: correctly rounded sqrtf and
+            // 1 / d (8 + 10 instructions), a second distance beside the weight's, a vector loop counter.  Here one distance serves
+            // both (q - p and p - q have the same squares: d2 is PairWeight::d2's bits), d = d2 * rsq(d2) and 1 / d = rsq(d2) (1 ulp
+            // each), products fused.  Same sums up to rounding: the fused op is held to the three ops by tolerance, not bit for bit.
+            // v_rsq_f32 is no good below ~1e-38 (coincident points: 0 * inf; denormal d2; the clamp of d at 1e-20): a wave that
+            // met such a pair in a tile walks the tile again with the exact forms -- one v_cmp per pair buys that.
+            const float gx0 = gx, gy0 = gy, gz0 = gz;
+            unsigned long long tiny = 0ull;
+#pragma unroll 2
+            for (int l = lo; l < hi; ++l) {
+                const float ox = qx[l] - px, oy = qy[l] - py, oz = qz[l] - pz;
+                const float d2 = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
+                const float w = plan_value<REF>(lv, d2, fl, &fr[0][l], TILE, etab);
+                tiny |= __builtin_amdgcn_ballot_w64(d2 < 1e-30f);
+                const float inv = __builtin_amdgcn_rsqf(d2);
+                cs = fmaf(d2 * inv, w, cs);
+                const float wi = w * inv;
+                gx = fmaf(-wi, ox, gx); gy = fmaf(-wi, oy, gy); gz = fmaf(-wi, oz, gz);
+            }
+            if (__builtin_expect(tiny != 0ull, 0)) {
+                cs = 0.f; gx = gx0; gy = gy0; gz = gz0;
+                for (int l = lo; l < hi; ++l) {
+                    const float ox = qx[l] - px, oy = qy[l] - py, oz = qz[l] - pz;
+                    const float d2 = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
+                    const float w = plan_value<REF>(lv, d2, fl, &fr[0][l], TILE, etab);
+                    const float d = sqrtf(d2);
+                    const float wi = w * (1.0f / fmaxf(d, 1e-20f));
+                    cs = fmaf(d, w, cs);
+                    gx = fmaf(-wi, ox, gx); gy = fmaf(-wi, oy, gy); gz = fmaf(-wi, oz, gz);
+                }
+            }
         }
         cost += (double)cs;
     }
