@@ -134,13 +134,19 @@ template <int C, int ROWS> struct LoaderTile {
 // requested while tile j is multiplied and staged (BN + ReLU -> the other LDS buffer) while tile j + 1 is.  One barrier per tile
 // (two where the partial sums of two row blocks meet in LDS).  vmcnt retires in order, so the matrix waves themselves cannot
 // prefetch tiles: their weight-fragment waits would wait for the tile's HBM round trip too.
-// Tiles are dealt round-robin (tile = workgroup + j * workgroups): 1600 tiles over 512 workgroups leave the same 7-against-6.25
+// Tiles are dealt round-robin (tile = workgroup + j * workgroups): 1600 tiles over 256 workgroups leave the same 7-against-6.25
 // imbalance per CU a dynamic queue would, and the loaders know their tiles two ahead.
 constexpr int FW_THREADS = TR_THREADS + LOADER_THREADS;
 template <int CIN, int COUT> struct FwdShape {
     static constexpr int TILE_FLOATS = TR_ROWS * (CIN + 4);
     static constexpr size_t lds_bytes = sizeof(float) * (2 * TILE_FLOATS + 4 * COUT);
-    static constexpr int WGS_PER_CU = lds_bytes * 2 <= 158 * 1024 ? 2 : 1;
+    // ONE workgroup per CU for every shape.  Two fit for CIN <= 128 and were used until round 4, but they buy nothing: with global
+    // loads, stores, sums and barriers compiled out (tools/debug/prof_train_fwd.sh on -D variants) the four launches still take
+    // 18 / 30 / 56 / 56 us whether one or two workgroups share a CU -- the chains already run at the matrix pipe's rate
+    // (tools/feed_probe.py: this loop shape sustains 0.96-0.98 of the fp32 peak), what is left is the launch's ramp and the 7-against-
+    // 6.25 tiles per CU -- and the second workgroup's own weight ring and loads cost: 25.5 / 42.5 / 75.3 us with two, 24.9 / 40.3 /
+    // 68.7 us with one (CIN = 256 never had room for two).
+    static constexpr int WGS_PER_CU = 1;
     static constexpr int RM = COUT == 256 ? 2 : 1;          // row blocks per matrix wave (8 waves: 8 column blocks x 2, or 4 x 2 units)
 };
 template <int CIN, int COUT>

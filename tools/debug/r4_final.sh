@@ -9,6 +9,7 @@ timeout 600 python tools/emd_attack_time.py 8 32 128 > $O/r04_emd_times.jsonl 2>
 timeout 900 python tools/attack_sweep.py > $O/r04_attack_sweep.json 2>/dev/null
 timeout 600 python tools/scorer_time.py > $O/r04_scorer.jsonl 2>/dev/null
 timeout 600 python tools/train_bench.py > $O/r04_train_bench.json 2>/dev/null
+timeout 300 python tools/feed_probe.py > $O/r04_feed_probe.jsonl 2>/dev/null
 python3 - <<'PY'
 import json
 for f in ("r04_bench_k20.json", "r04_bench_default.json"):
