@@ -138,6 +138,35 @@ def test_fused_cost_grad1_equals_the_three_ops(b, n, m, reference_weights):
     torch.testing.assert_close(g1 / sc, want_g1 / sc, rtol=0, atol=1e-5)          # 2048-term fp32 sums in a different order
 
 
+@pytest.mark.parametrize("reference_weights", [False, True])
+def test_fused_cost_grad1_with_coincident_and_nearly_coincident_points(reference_weights):
+    """Pairs at distance 0 (the same point in both clouds, duplicated padding points) and at distances around 1e-19 .. 1e-16
+    (denormal squared distances, the 1e-20 clamp of matchcostgrad_cpu :117): the fast mode's walk takes d and 1 / d from
+    v_rsq_f32, which is no good there, and must fall back to the exact forms for the waves that meet such a pair."""
+    import torch
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    rng = np.random.default_rng(77)
+    b, n, m = 3, 1100, 900
+    x1 = cloud(21, b, n).astype(np.float32)
+    x2 = cloud(22, b, m).astype(np.float32)
+    x2[0, :300] = x1[0, rng.permutation(n)[:300]]                   # exact copies
+    x2[1, 50:60] = x2[1, 50]                                         # padding-style duplicates inside a cloud
+    x1[1, 7] = x2[1, 50]
+    x1[2, :40] *= 1e-20                                              # a knot of points within ~1e-20 .. 1e-19 of the origin
+    x2[2, :40] = x1[2, :40][::-1] * np.float32(1.5)
+    x2[2, 40:60] = rng.standard_normal((20, 3)).astype(np.float32) * np.float32(3e-17)
+    t1, t2 = _t(x1), _t(x2)
+    match = ops.approx_match(t1, t2, reference_weights)
+    want_cost = ops.match_cost(t1, t2, match)
+    want_g1, _ = ops.match_cost_grad(t1, t2, match)
+    cost, g1 = ops.emd_cost_grad1(t1, t2, reference_weights)
+    assert torch.isfinite(cost).all() and torch.isfinite(g1).all()
+    torch.testing.assert_close(cost, want_cost, rtol=2e-6, atol=0)
+    sc = want_g1.abs().amax((1, 2), keepdim=True)
+    torch.testing.assert_close(g1 / sc, want_g1 / sc, rtol=0, atol=1e-5)
+
+
 def test_approx_match_deterministic_and_order_free():
     """Two runs give the same bits (fixed-order folds, no atomics); permuting the clouds permutes the plan (sums run in a
     different order: 1e-5)."""
