@@ -99,6 +99,97 @@ static int run(int wgs_per_cu, int iters, float *ms, double *tflops) {
     return 0;
 }
 
+// Layer-shaped probe: chains of KG k-groups separated by what a fused MLP layer puts between them -- an epilogue of NV VALU
+// instructions per accumulator register on the 16 accumulators, 16 ds_write_b32 of the results into the tile the next chain
+// reads, and (BAR) a workgroup barrier.  How much of the matrix pipe does that cost with one and with two workgroups per CU?
+template <int KG, int NV, bool BAR>
+__global__ __launch_bounds__(512) void feed_layers_kernel(float *out, const float *wts, int chains, int skew) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int STRIDE = 260;
+    for (int e = threadIdx.x; e < 64 * STRIDE; e += 512) lds[e] = 1.0f + 1e-6f * e;
+    __syncthreads();
+    const float *ar = lds + ((wave >> 2) * 32 + (lane & 31)) * STRIDE + 4 * (lane >> 5);
+    float *wr = lds + ((wave >> 2) * 32 + 4 * (lane >> 5)) * STRIDE + (wave & 3) * 32 + (lane & 31);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wts), 0, 0x7fffffff, 0x00020000);
+    const unsigned lb = lane * 16u;
+    const int base = (wave & 3) * 32 * 1024;
+    float4 ring[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const u4v t = __builtin_amdgcn_raw_buffer_load_b128(rs, lb, base + u * 1024, 0);
+        ring[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+    }
+    float sc = 1.0001f, sh = 0.001f;
+    // skew: start some workgroups half a chain late (which ones share a CU is the question: 1 = odd workgroups, 2 = the second
+    // half of the grid, 3 = bit 3 of the index, i.e. every other workgroup of an XCD)
+    const bool late = skew == 1 ? (blockIdx.x & 1) : skew == 2 ? (blockIdx.x >= gridDim.x / 2) : skew == 3 ? ((blockIdx.x >> 3) & 1) : false;
+    if (late) { __builtin_amdgcn_s_sleep(KG * 2); }          // KG * 2 * 64 cycles = half of the chain's 2 x KG x 4 x 64
+    for (int c = 0; c < chains; ++c) {
+        f16v acc = {};
+        float4 a = *reinterpret_cast<const float4 *>(ar);
+#pragma unroll
+        for (int t = 0; t < KG; t += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 an = *reinterpret_cast<const float4 *>(ar + 8 * ((t + u + 1) % KG));
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 b = ring[u];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                const int g = (t + u + 4) % KG;
+                const u4v tt = __builtin_amdgcn_raw_buffer_load_b128(rs, lb, base + g * 1024, 0);
+                ring[u] = make_float4(__uint_as_float(tt.x), __uint_as_float(tt.y), __uint_as_float(tt.z), __uint_as_float(tt.w));
+                __builtin_amdgcn_sched_barrier(0);
+                a = an;
+            }
+        }
+        if (BAR) __syncthreads();                            // every wave has read the tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v = fmaf(v, sc, sh);
+            v = fminf(v, 2.0f);
+            wr[((r & 3) + 8 * (r >> 2)) * STRIDE] = v;
+        }
+        if (BAR) __syncthreads();                            // the next chain's tile is written
+    }
+    if (lds[threadIdx.x] == 123.456f) out[0] = 1.f;
+}
+
+template <int KG, int NV, bool BAR>
+static int run_layers(int wgs_per_cu, int chains, int skew, float *ms, double *tflops) {
+    float *out = nullptr, *wts = nullptr;
+    if (hipMalloc(&out, 64) != hipSuccess || hipMalloc(&wts, 4 * 32 * 1024 + 4096) != hipSuccess) return 1;
+    (void)hipMemset(wts, 0, 4 * 32 * 1024 + 4096);
+    const size_t lds = wgs_per_cu == 1 ? 100 * 1024 : 72 * 1024;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(feed_layers_kernel<KG, NV, BAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 3;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int grid = 256 * wgs_per_cu;                      // ONE round: the workgroups that start together stay together
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        feed_layers_kernel<KG, NV, BAR><<<grid, 512, lds, 0>>>(out, wts, chains, skew);
+        (void)hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) return 4;
+    }
+    (void)hipEventElapsedTime(ms, e0, e1);
+    *tflops = (double)grid * 8 * chains * KG * 4 * 4096.0 / (*ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(out); (void)hipFree(wts);
+    return 0;
+}
+
+extern "C" int geoadv_probe_feed_layers(int kg, int nv, int bar, int wgs_per_cu, int chains, int skew, float *ms, double *tflops) {
+#define LCASE(K, V, B) if (kg == K && nv == V && bar == B) return run_layers<K, V, (B != 0)>(wgs_per_cu, chains, skew, ms, tflops);
+    LCASE(16, 0, 0) LCASE(16, 0, 1) LCASE(16, 2, 0) LCASE(16, 2, 1) LCASE(16, 6, 1) LCASE(32, 2, 1) LCASE(8, 2, 1) LCASE(32, 6, 1) LCASE(8, 6, 1)
+#undef LCASE
+    return 9;
+}
+
 extern "C" int geoadv_probe_feed(int mode, int rm, int depth, int wgs_per_cu, int iters, float *ms, double *tflops) {
 #define CASE(M, R, D) if (mode == M && rm == R && depth == D) return run<M, R, D>(wgs_per_cu, iters, ms, tflops);
     CASE(0, 1, 4) CASE(0, 2, 4) CASE(0, 4, 4) CASE(0, 1, 8) CASE(0, 2, 8)
