@@ -41,7 +41,7 @@ PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r04_pmc_chamfer_hbm.json")   
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 # measured batch sweep: ms per iteration at B = 32 / 16 / 8 / 4 on ONE GPU -- what each rank of the strong-scaling leg runs
 SWEEP_SRC = "profiles/r04_attack_sweep.json"
-SWEEP_MS = {32: 0.1748, 16: 0.1146, 8: 0.0858, 4: 0.0750}
+SWEEP_MS = {32: 0.1749, 16: 0.1139, 8: 0.0862, 4: 0.0745}
 
 
 def parse_args():
