@@ -186,15 +186,10 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
             int id = 0;
             if (MODE == 0) id = has ? *reinterpret_cast<const int *>(reinterpret_cast<const char *>(qi) + jo) : 0;
             odd |= d != d;
-            if (MODE == 1) {                               // values only: a compare-exchange chain on the BIT PATTERNS -- distances are
-                unsigned x = __float_as_uint(d);           // sums of squares (>= +0, or +inf), for which unsigned order = float order; no
-#pragma unroll                                             // selects, no moves, no canonicalising v_max (a NaN only ever marks the query `odd`)
-                for (int i = 0; i < S; ++i) {
-                    const unsigned vi = __float_as_uint(v[i]);
-                    const unsigned lo = min(vi, x);
-                    x = max(vi, x);
-                    v[i] = __uint_as_float(lo);
-                }
+            if (MODE == 1) {                               // values only: sorted insertion is a median per slot, v[i] <- med3(v[i - 1], d, v[i])
+#pragma unroll                                             // from the top down (the OLD v[i - 1]): S instructions where a compare-exchange chain
+                for (int i = S - 1; i > 0; --i) v[i] = __builtin_amdgcn_fmed3f(v[i - 1], d, v[i]);      // takes 2 S (a NaN only ever marks
+                v[0] = fminf(v[0], d);                                                                    // the query `odd`: its list is not used)
             } else {                                       // (value, index): the candidate sinks past every entry it is strictly below;
                 float x = d;                               // an equal entry -- earlier index -- stays ahead of it.  Selects only, no branch.
                 int xi = id;
@@ -278,10 +273,24 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
 //     (x, y, z, original index) + cell_start; the QUERIES are ordered along a Hilbert curve through their cells (qorder), so 64
 //     consecutive ones sit in a compact block of cells.  A cloud with a non-finite coordinate gets the 1 x 1 x 1 grid: every
 //     query then meets every point, as the all-points kernel would (NaN distances send the query to the redo kernel).
-//   search: every workgroup stages the whole sorted cloud in LDS (<= 4096 points); control flow is wave-uniform -- the wave's
-//     box of cells, shell by shell, row by row -- and the points of a row come out of LDS as broadcast ds_read_b128, the data
-//     path of knn_fast_kernel.  (First form, measured: scalar loads straight from the sorted array, s_load_dwordx8 feeding
-//     the VALU as SGPR operands -- no faster than the all-points scan, every group of four points waited for its own load.)
+//   search: every workgroup stages the whole sorted cloud in LDS (<= 4096 points, (x, y, z, index) per point: one ds_read_b128 a
+//     candidate).  A task = 64 consecutive queries of the Hilbert order, one per lane, in two stages:
+//     (1) lane-private: the lane walks the 3 x 3 x 3 cells around ITS query -- nine runs of the sorted cloud, nearest rows first,
+//         four candidates a step, gathered at per-lane addresses -- and is done if the face-distance test on its own block closes
+//         its list (at 2048 uniform points in 8^3 cells: ~110 candidates a lane, 99.97 % of the lanes);
+//     (2) the lanes it leaves over (a sparse corner, an outlier) are listed per workgroup and, when the tasks are done, searched
+//         64 at a time by ALL the workgroup's waves: they are scattered, their common box is the grid, so every wave scans an
+//         eighth of the cloud for them (broadcast reads) and wave 0 merges the eight lists.
+//     The wave-uniform shell walk (the round's first form: the wave's common box of cells, shell by shell, row by row, broadcast
+//     reads; 400 candidates a lane at the same size because the box is the UNION of 64 neighbourhoods) stays as
+//     geoadv_knn_grid_mode(3) and for lists too long for the merge (k > 15).  Measured at 256 x 2048, k = 8 (rocprofv3): 174 us
+//     (1) + (2), 191 us shells only, 366 us all points; before the cloud went into LDS as float4 (SoA planes, and 16 KB reserved for cell
+//     offsets of which 2 are used: one workgroup per CU instead of two) the shell walk took 220 us.
+//     What bounds (1) now is the queues' drain, not the walk: ~115 drain steps a task against 42 walk steps -- a drain runs as long
+//     as its fullest queue, and 64 lanes fill at different rates.  Each lane therefore tightens its own threshold while it pushes
+//     (once S values are queued, their maximum bounds the S-th smallest); without that: 140 steps.
+//     (First form of all, measured: scalar loads straight from the sorted array, s_load_dwordx8 feeding the VALU as SGPR operands
+//     -- no faster than the all-points scan, every group of four points waited for its own load.)
 // The order in which a lane meets its candidates is no longer the index order; the results do not depend on it (the k + 1
 // smallest distinct distances are what they are, ties among them go to knn_redo_kernel as before).
 // ------------------------------------------------------------------------------------------
@@ -484,8 +493,8 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
 // LDS of the search kernel (dynamic): the sorted cloud as planes x[n4] y[n4] z[n4] (+ original index [n4] for MODE 0), n4 = n
 // rounded up to a multiple of 4 plus one group of padding; then the candidate queues (distance [, index]) of THREADS lanes.
 __host__ __device__ inline int kg_n4(int n) { return ((n + 3) & ~3) + 4; }
-template <int MODE> __host__ __device__ inline size_t kg_lds_bytes(int n, int threads) {
-    return (size_t)kg_n4(n) * 4 * (MODE == 0 ? 4 : 3) + (size_t)KF_QCAP * threads * 4 * (MODE == 0 ? 2 : 1) + sizeof(int) * (KG_MAX_CELLS + 4);
+template <int MODE> __host__ __device__ inline size_t kg_lds_bytes(int n, int threads, int cells = KG_MAX_CELLS) {
+    return (size_t)kg_n4(n) * 16 + (size_t)KF_QCAP * threads * 4 * (MODE == 0 ? 2 : 1) + sizeof(int) * (cells + 4);
 }
 constexpr int KG_MAX_N = 4096;             // the whole sorted cloud sits in LDS (48 / 64 KB at 4096 points)
 #ifndef KG_THREADS_V
@@ -495,9 +504,10 @@ constexpr int KG_MAX_N = 4096;             // the whole sorted cloud sits in LDS
 #define KG_TASKS_PER_WAVE 2
 #endif
 constexpr int KG_THREADS = KG_THREADS_V;
+constexpr int KG_LEFT_CAP = 512;          // queries a workgroup can hold back for the wave-uniform search (more: the redo list)
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 #ifdef KG_DIAG                             // diagnostic build only (tools/debug/build_variants.sh): per-wave work counters
-__device__ unsigned long long kg_diag[8];
+__device__ unsigned long long kg_diag[16];
 #define KG_COUNT(I, V) do { if ((threadIdx.x & 63) == 0) atomicAdd(&kg_diag[I], (unsigned long long)(V)); } while (0)
 #else
 #define KG_COUNT(I, V)
@@ -510,14 +520,16 @@ template <int MODE, int S, int THREADS>
 __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, int split, const float4 *__restrict__ sorted,
                                                            const int *__restrict__ cell_start, const int *__restrict__ qorder,
                                                            const KnnGrid *__restrict__ info, const int *__restrict__ task_order,
-                                                           const float *__restrict__ xyz2, float *val_out, int *idx_out, int *redo) {
+                                                           const float *__restrict__ xyz2, float *val_out, int *idx_out, int *redo,
+                                                           int lane_first) {
     extern __shared__ __attribute__((aligned(16))) float kg_lds[];
-    __shared__ int next_task;
+    __shared__ int next_task, left_n;
+    __shared__ int left_q[KG_LEFT_CAP];
     GA_STAMP(0, 0);
     const int n4 = kg_n4(n);
-    float *sx = kg_lds, *sy = sx + n4, *sz = sy + n4;
-    int *si = reinterpret_cast<int *>(sz + n4);
-    float *qd = sz + n4 + (MODE == 0 ? n4 : 0);
+    float4 *sp = reinterpret_cast<float4 *>(kg_lds);       // the sorted cloud, (x, y, z, original index) per point: ONE ds_read_b128 per candidate
+                                                           // whether the address is the wave's (broadcast) or the lane's own (gather)
+    float *qd = kg_lds + 4 * (size_t)n4;
     int *qi = reinterpret_cast<int *>(qd + KF_QCAP * THREADS);
 #ifndef KG_LDS_CS
 #define KG_LDS_CS 1
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
     // cloud's workgroups), taken in that order through the counter
     const int *tord = task_order + (size_t)c * tasks;
     const int task0 = 0, task1 = (tasks - (int)blockIdx.x + split - 1) / split;       // (counted in places of this workgroup)
-    if (threadIdx.x == 0) next_task = task0 + THREADS / 64;          // (every wave starts with the place of its own number)
+    if (threadIdx.x == 0) { next_task = task0 + THREADS / 64; left_n = 0; }   // (every wave starts with the place of its own number)
     {   // the cloud: all requests of a thread first, then the LDS writes (one round trip instead of one per 1024 points)
         constexpr int PER = (KG_MAX_N + 4 + THREADS - 1) / THREADS;
         float4 pt[PER];
@@ -547,10 +559,7 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int e = threadIdx.x + u * THREADS;
-            if (e < n4) {
-                sx[e] = pt[u].x; sy[e] = pt[u].y; sz[e] = pt[u].z;
-                if (MODE == 0) si[e] = __float_as_int(pt[u].w);
-            }
+            if (e < n4) sp[e] = pt[u];
         }
     }
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
@@ -572,19 +581,61 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
         r.x = qp[0]; r.y = qp[1]; r.z = qp[2];
         return r;
     };
-    int task = task0 + (threadIdx.x >> 6);
-    Query cur = load_query(task < task1 ? task : task0);
-    while (task < task1) {
-        int nt = 0;
-        Query nxt = cur;
-        if (KG_PREFETCH) {
-            if (lane == 0) nt = atomicAdd(&next_task, 1);
-            nt = __builtin_amdgcn_readfirstlane(nt);
-            nxt = load_query(nt < task1 ? nt : task);
+    // what a lane's finished list leaves behind (a tie among the k + 1 smallest, a NaN, fewer than k finite distances: the redo list)
+    auto emit = [&](const int q, const float (&v)[S], const int (&ix)[S], const bool odd) {
+        if (MODE == 0) {
+            bool again = odd || ix[k - 1] < 0;
+#pragma unroll
+            for (int i = 0; i + 1 < S; ++i)
+                if (i < k && v[i] == v[i + 1] && ix[i + 1] >= 0) again = true;
+            if (again) redo[1 + atomicAdd(redo, 1)] = c * m + q;
+            else {
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+                    if (i < k) { val_out[((size_t)c * m + q) * k + i] = v[i]; idx_out[((size_t)c * m + q) * k + i] = ix[i]; }
+            }
+        } else {
+            if (odd || !(v[k - 1] < INFINITY)) redo[1 + atomicAdd(redo, 1)] = c * m + q;
+            else {
+#pragma unroll
+                for (int i = 1; i < S; ++i)
+                    if (i < k) val_out[((size_t)c * m + q) * (k - 1) + i - 1] = sqrtf(v[i]);
+            }
         }
-        const bool live = tord[blockIdx.x + task * split] * 64 + lane < m;
-        const int q = cur.q;
-        const float qx = cur.x, qy = cur.y, qz = cur.z;
+    };
+    // the queues' drain into the lists (see knn_fast_kernel)
+    auto drain_into = [&](float (&v)[S], int (&ix)[S], bool &odd, float &thr, unsigned &qw) {
+        KG_COUNT(5, 1);
+        for (unsigned jo = 4u * threadIdx.x; __any(jo < qw); jo += 4u * THREADS) {
+            KG_COUNT(2, 1);
+            const bool has = jo < qw;
+            const float d = has ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(qd) + jo) : INFINITY;
+            int id = 0;
+            if (MODE == 0) id = has ? *reinterpret_cast<const int *>(reinterpret_cast<const char *>(qi) + jo) : 0;
+            odd |= d != d;
+            if (MODE == 1) {                               // values only: sorted insertion is a median per slot, v[i] <- med3(v[i - 1], d, v[i])
+#pragma unroll                                             // from the top down (the OLD v[i - 1]); half the instructions of a compare-exchange chain
+                for (int i = S - 1; i > 0; --i) v[i] = __builtin_amdgcn_fmed3f(v[i - 1], d, v[i]);
+                v[0] = fminf(v[0], d);                     // (a NaN only ever marks the query `odd`: its list is not used)
+            } else {                                       // (value, index): the candidate goes in front of the first entry it is STRICTLY below
+                bool below[S];                             // (an equal entry stays ahead of it); `below` is monotone along the sorted list
+#pragma unroll
+                for (int i = 0; i < S; ++i) below[i] = d < v[i];
+#pragma unroll
+                for (int i = S - 1; i > 0; --i) {
+                    v[i] = __builtin_amdgcn_fmed3f(v[i - 1], d, v[i]);
+                    ix[i] = below[i - 1] ? ix[i - 1] : (below[i] ? id : ix[i]);
+                }
+                v[0] = fminf(v[0], d);
+                ix[0] = below[0] ? id : ix[0];
+            }
+        }
+        qw = 4u * threadIdx.x;
+        thr = v[S - 1];
+    };
+
+    // ---- wave-uniform search: the wave's box of cells, shell by shell, until every (live) lane's list is closed ----
+    auto uniform_search = [&](const int q, const float qx, const float qy, const float qz, const bool live) {
         const int ccx = kg_cell1(qx, g.lo[0], g.ih[0], gx), ccy = kg_cell1(qy, g.lo[1], g.ih[1], gy), ccz = kg_cell1(qz, g.lo[2], g.ih[2], gz);
         // the wave's box of cells
         const int bx0 = kg_wave_min(ccx), bx1 = kg_wave_max(ccx), by0 = kg_wave_min(ccy), by1 = kg_wave_max(ccy);
@@ -596,73 +647,38 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
         bool odd = false;
         float thr = INFINITY;
         unsigned qw = 4u * threadIdx.x;
-
-        auto drain = [&]() {
-            KG_COUNT(5, 1);
-            for (unsigned jo = 4u * threadIdx.x; __any(jo < qw); jo += 4u * THREADS) {
-                KG_COUNT(2, 1);
-                const bool has = jo < qw;
-                const float d = has ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(qd) + jo) : INFINITY;
-                int id = 0;
-                if (MODE == 0) id = has ? *reinterpret_cast<const int *>(reinterpret_cast<const char *>(qi) + jo) : 0;
-                odd |= d != d;
-                if (MODE == 1) {
-                    unsigned x = __float_as_uint(d);
-#pragma unroll
-                    for (int i = 0; i < S; ++i) {
-                        const unsigned vi = __float_as_uint(v[i]);
-                        const unsigned lo = min(vi, x);
-                        x = max(vi, x);
-                        v[i] = __uint_as_float(lo);
-                    }
-                } else {
-                    float x = d;
-                    int xi = id;
-#pragma unroll
-                    for (int i = 0; i < S; ++i) {
-                        const bool cc = x < v[i];
-                        const float lo = cc ? x : v[i], hi = cc ? v[i] : x;
-                        const int loi = cc ? xi : ix[i], hii = cc ? ix[i] : xi;
-                        v[i] = lo; ix[i] = loi; x = hi; xi = hii;
-                    }
-                }
-            }
-            qw = 4u * threadIdx.x;
-            thr = v[S - 1];
-        };
-        // the points [lo, hi) of the sorted cloud: wave-uniform bounds, broadcast LDS reads of aligned groups of four (the
-        // neighbours of a misaligned first / last group belong to other rows: masked, or a point would enter a list twice)
+        // the points [lo, hi) of the sorted cloud: wave-uniform bounds, broadcast LDS reads, four points a step (the ones past hi
+        // belong to other rows: masked, or a point would enter a list twice)
         auto run = [&](int lo, int hi) {
             KG_COUNT(0, hi - lo);
-            for (int p = lo & ~3; p < hi; p += 4) {
+            for (int p = lo; p < hi; p += 4) {
                 KG_COUNT(3, 1);
-                const float4 xa = *reinterpret_cast<const float4 *>(&sx[p]);
-                const float4 ya = *reinterpret_cast<const float4 *>(&sy[p]);
-                const float4 za = *reinterpret_cast<const float4 *>(&sz[p]);
-                const float tx[4] = {xa.x, xa.y, xa.z, xa.w}, ty[4] = {ya.x, ya.y, ya.z, ya.w}, tz[4] = {za.x, za.y, za.z, za.w};
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = sp[p + u];                        // (reads past hi stay inside the padded array and are masked)
                 float d[4];
                 bool adm[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float dx = tx[u] - qx, dy = ty[u] - qy, dz = tz[u] - qz;
+                    const float dx = t[u].x - qx, dy = t[u].y - qy, dz = t[u].z - qz;
                     d[u] = (dx * dx + dy * dy) + dz * dz;                            // tf_grouping.py:68, left to right
-                    adm[u] = (p + u >= lo) && (p + u < hi) && !(d[u] >= thr);
+                    adm[u] = (p + u < hi) && !(d[u] >= thr);
                 }
                 if (__any(adm[0] | adm[1] | adm[2] | adm[3])) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (adm[u]) {
                             *reinterpret_cast<float *>(reinterpret_cast<char *>(qd) + qw) = d[u];
-                            if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = si[p + u];
+                            if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = __float_as_int(t[u].w);
                             qw += 4u * THREADS;
                         }
-                    if (__any(qw >= 4u * (KF_QCAP - 3) * THREADS)) drain();
+                    if (__any(qw >= 4u * (KF_QCAP - 3) * THREADS)) drain_into(v, ix, odd, thr, qw);
                 }
             }
         };
 
         int px0 = 1, px1 = 0, py0 = 1, py1 = 0, pz0 = 1, pz1 = 0;              // the box visited so far (empty)
-        bool fin = false;
+        bool fin = !live;
         for (int s = 0;; ++s) {
             const int x0 = max(0, bx0 - s), x1 = min(gx - 1, bx1 + s), y0 = max(0, by0 - s), y1 = min(gy - 1, by1 + s);
             const int z0 = max(0, bz0 - s), z1 = min(gz - 1, bz1 + s);
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
                     run(blo, bhi);
                 }
             }
-            drain();
+            drain_into(v, ix, odd, thr, qw);
             // finished lanes: every point not met yet lies beyond a face of the box, i.e. at least `mg` away
             float mg = INFINITY;
             if (x0 > 0) mg = fminf(mg, (qx - (g.lo[0] + (float)x0 * g.h[0])) * 0.999f - g.eps[0]);
@@ -704,27 +720,117 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
             if (whole || !__any(!fin)) { KG_COUNT(4, 1); KG_COUNT(7, whole ? 1 : 0); break; }
             px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
         }
-        if (live) {
-            if (MODE == 0) {
-                bool again = odd || ix[k - 1] < 0;
+        if (live) emit(q, v, ix, odd);
+    };
+
+    // ---- lane-private search (round 4, second form): every lane walks the 3 x 3 x 3 cells around ITS query -- nine runs of the
+    // sorted cloud, gathered from LDS at per-lane addresses -- and is finished if that closes its list (the same face-distance test,
+    // on the lane's own block).  The 64 queries of a task share a neighbourhood, but the UNION of their neighbourhoods, which the
+    // wave-uniform search walks for all of them, is several times one lane's 27 cells (at 2048 points in 8^3 cells: ~110 candidates
+    // a lane against 500-800 for the wave).  Lanes it does not finish (a sparse corner, an outlier) go to a list in LDS and are
+    // searched the wave-uniform way, 64 at a time, when the workgroup's tasks are done.  Returns true where the lane is done.
+    auto lane_search = [&](const int q, const float qx, const float qy, const float qz, const bool live) -> bool {
+        const int ccx = kg_cell1(qx, g.lo[0], g.ih[0], gx), ccy = kg_cell1(qy, g.lo[1], g.ih[1], gy), ccz = kg_cell1(qz, g.lo[2], g.ih[2], gz);
+        const int x0 = max(ccx - 1, 0), x1 = min(ccx + 1, gx - 1), y0 = max(ccy - 1, 0), y1 = min(ccy + 1, gy - 1);
+        const int z0 = max(ccz - 1, 0), z1 = min(ccz + 1, gz - 1);
+        int rlo[9], rhi[9];
 #pragma unroll
-                for (int i = 0; i + 1 < S; ++i)
-                    if (i < k && v[i] == v[i + 1] && ix[i + 1] >= 0) again = true;
-                if (again) redo[1 + atomicAdd(redo, 1)] = c * m + q;
-                else {
+        for (int r = 0; r < 9; ++r) {
+            const int z = ccz + r / 3 - 1, y = ccy + r % 3 - 1;
+            const bool in = live && z >= 0 && z < gz && y >= 0 && y < gy;
+            const int row = in ? (z * gy + y) * gx : 0;
+            rlo[r] = in ? cs[row + x0] : 0;
+            rhi[r] = in ? cs[row + x1 + 1] : 0;
+        }
+        float v[S];
+        int ix[S];
 #pragma unroll
-                    for (int i = 0; i < S; ++i)
-                        if (i < k) { val_out[((size_t)c * m + q) * k + i] = v[i]; idx_out[((size_t)c * m + q) * k + i] = ix[i]; }
+        for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
+        bool odd = false;
+        float thr = INFINITY;
+        unsigned qw = 4u * threadIdx.x;
+        // Between two drains `thr` is stale, and a stale threshold admits most of what comes (the 9th of the first 16 candidates
+        // lets every second one through): the queues filled 13 times a task and the drains cost twice the walk.  So a lane
+        // tightens its own threshold as it pushes: once S values below `thr` are queued, the S-th smallest seen so far is at most
+        // their maximum -- that becomes `thr` (the drain then sets it exactly).  Rows nearest first (own row, the four that
+        // share a face with it, the corners): the first S pushes are already close.
+        float pmax = 0.f;
+        int pcnt = 0;
+        constexpr int ORDER[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+#pragma unroll
+        for (int ro = 0; ro < 9; ++ro) {
+            const int r = ORDER[ro];
+            int p = rlo[r];
+            const int hi = rhi[r];
+            while (__any(p < hi)) {                          // four candidates a step: the step's gathers are in flight together
+                KG_COUNT(9, 1);
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = sp[min(p + u, n4 - 1)];
+                float d[4];
+                bool adm[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = t[u].x - qx, dy = t[u].y - qy, dz = t[u].z - qz;
+                    d[u] = (dx * dx + dy * dy) + dz * dz;                            // tf_grouping.py:68, left to right
+                    adm[u] = (p + u < hi) && !(d[u] >= thr);
                 }
-            } else {
-                if (odd || !(v[k - 1] < INFINITY)) redo[1 + atomicAdd(redo, 1)] = c * m + q;
-                else {
+                if (__any(adm[0] | adm[1] | adm[2] | adm[3])) {
 #pragma unroll
-                    for (int i = 1; i < S; ++i)
-                        if (i < k) val_out[((size_t)c * m + q) * (k - 1) + i - 1] = sqrtf(v[i]);
+                    for (int u = 0; u < 4; ++u)
+                        if (adm[u]) {
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(qd) + qw) = d[u];
+                            if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = __float_as_int(t[u].w);
+                            qw += 4u * THREADS;
+                            pmax = fmaxf(pmax, d[u]);
+                            pcnt += 1;
+                        }
+                    if (pcnt >= S) { thr = fminf(thr, pmax); pmax = 0.f; pcnt = 0; }
+                    if (__any(qw >= 4u * (KF_QCAP - 3) * THREADS)) { drain_into(v, ix, odd, thr, qw); pmax = 0.f; pcnt = 0; }
                 }
+                p += 4;
             }
         }
+        drain_into(v, ix, odd, thr, qw);
+        float mg = INFINITY;
+        if (x0 > 0) mg = fminf(mg, (qx - (g.lo[0] + (float)x0 * g.h[0])) * 0.999f - g.eps[0]);
+        if (x1 < gx - 1) mg = fminf(mg, ((g.lo[0] + (float)(x1 + 1) * g.h[0]) - qx) * 0.999f - g.eps[0]);
+        if (y0 > 0) mg = fminf(mg, (qy - (g.lo[1] + (float)y0 * g.h[1])) * 0.999f - g.eps[1]);
+        if (y1 < gy - 1) mg = fminf(mg, ((g.lo[1] + (float)(y1 + 1) * g.h[1]) - qy) * 0.999f - g.eps[1]);
+        if (z0 > 0) mg = fminf(mg, (qz - (g.lo[2] + (float)z0 * g.h[2])) * 0.999f - g.eps[2]);
+        if (z1 < gz - 1) mg = fminf(mg, ((g.lo[2] + (float)(z1 + 1) * g.h[2]) - qz) * 0.999f - g.eps[2]);
+        const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == gx - 1 && y1 == gy - 1 && z1 == gz - 1;
+        const bool fin = whole || (mg > 0.f && v[S - 1] < mg * mg);
+        KG_COUNT(8, 1); KG_COUNT(10, __popcll(__ballot(live && !fin)));
+        if (live && fin) emit(q, v, ix, odd);
+        return fin || !live;
+    };
+
+    int task = task0 + (threadIdx.x >> 6);
+    Query cur = load_query(task < task1 ? task : task0);
+    while (task < task1) {
+        int nt = 0;
+        Query nxt = cur;
+        if (KG_PREFETCH) {
+            if (lane == 0) nt = atomicAdd(&next_task, 1);
+            nt = __builtin_amdgcn_readfirstlane(nt);
+            nxt = load_query(nt < task1 ? nt : task);
+        }
+        const bool live = tord[blockIdx.x + task * split] * 64 + lane < m;
+        if (lane_first) {
+            const bool done = lane_search(cur.q, cur.x, cur.y, cur.z, live);
+            const unsigned long long nb = __ballot(!done);
+            if (nb) {                                       // the lanes left over: into the workgroup's list (overflow: the redo list, exact as well)
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&left_n, __popcll(nb));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = base + __popcll(nb & ((1ull << lane) - 1ull));
+                if (!done) {
+                    if (pos < KG_LEFT_CAP) left_q[pos] = cur.q;
+                    else redo[1 + atomicAdd(redo, 1)] = c * m + cur.q;
+                }
+            }
+        } else uniform_search(cur.q, cur.x, cur.y, cur.z, live);
         if (!KG_PREFETCH) {
             if (lane == 0) nt = atomicAdd(&next_task, 1);
             nt = __builtin_amdgcn_readfirstlane(nt);
@@ -732,6 +838,100 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
         }
         task = nt;
         cur = nxt;
+    }
+    if (lane_first) {
+        // The leftovers, 64 at a time.  They are scattered over the cloud, so their common box of cells is the grid: an all-points scan.
+        // Left to ONE wave that is ~100 K instructions behind which the other waves idle (measured: it doubled the kernel's time for a
+        // handful of leftover queries per workgroup); so every wave scans an EIGHTH of the cloud for the same 64 queries (broadcast
+        // reads, the lists and queues as everywhere), leaves its list in its queue slots, and wave 0 merges the eight lists.
+        __syncthreads();                                    // every wave's leftovers are listed
+        const int left = min(left_n, KG_LEFT_CAP);
+        constexpr bool COOP = S <= KF_QCAP;                 // (a list must fit the lane's queue slots; longer ones: one wave, the shell walk)
+        const int wave = threadIdx.x >> 6;
+        for (int chunk = 0; chunk * 64 < left; ++chunk) {
+            const int slot = chunk * 64 + lane;
+            const bool lv = slot < left;
+            const int q = left_q[lv ? slot : chunk * 64];   // (a dead lane repeats the chunk's first query)
+            const float *qp = xyz2 + ((size_t)c * m + q) * 3;
+            const float qx = qp[0], qy = qp[1], qz = qp[2];
+            KG_COUNT(11, 1);
+            if (!COOP) {
+                if (chunk % (THREADS / 64) == wave) uniform_search(q, qx, qy, qz, lv);
+                continue;
+            }
+            float v[S];
+            int ix[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
+            bool odd = false;
+            float thr = INFINITY;
+            unsigned qw = 4u * threadIdx.x;
+            const int per = (((n + THREADS / 64 - 1) / (THREADS / 64)) + 3) & ~3;
+            const int lo = min(n, wave * per), hi = min(n, lo + per);
+            for (int p = lo; p < hi; p += 4) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = sp[p + u];
+                float d[4];
+                bool adm[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = t[u].x - qx, dy = t[u].y - qy, dz = t[u].z - qz;
+                    d[u] = (dx * dx + dy * dy) + dz * dz;                            // tf_grouping.py:68, left to right
+                    adm[u] = (p + u < hi) && !(d[u] >= thr);
+                }
+                if (__any(adm[0] | adm[1] | adm[2] | adm[3])) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (adm[u]) {
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(qd) + qw) = d[u];
+                            if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = __float_as_int(t[u].w);
+                            qw += 4u * THREADS;
+                        }
+                    if (__any(qw >= 4u * (KF_QCAP - 3) * THREADS)) drain_into(v, ix, odd, thr, qw);
+                }
+            }
+            drain_into(v, ix, odd, thr, qw);
+            if (wave > 0) {                                 // publish: list -> the lane's own queue slots, NaN flag -> slot 0's sign of life
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    qd[i * THREADS + threadIdx.x] = (i == 0 && odd) ? NAN : v[i];
+                    if (MODE == 0) qi[i * THREADS + threadIdx.x] = ix[i];
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                for (int w = 1; w < THREADS / 64; ++w) {
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const float d = qd[i * THREADS + w * 64 + lane];
+                        odd |= d != d;
+                        if (MODE == 1) {
+                            unsigned x = __float_as_uint(d);
+#pragma unroll
+                            for (int j = 0; j < S; ++j) {
+                                const unsigned vj = __float_as_uint(v[j]);
+                                const unsigned lo2 = min(vj, x);
+                                x = max(vj, x);
+                                v[j] = __uint_as_float(lo2);
+                            }
+                        } else {
+                            float x = d;
+                            int xi = qi[i * THREADS + w * 64 + lane];
+#pragma unroll
+                            for (int j = 0; j < S; ++j) {
+                                const bool cc = x < v[j];
+                                const float lo2 = cc ? x : v[j], hi2 = cc ? v[j] : x;
+                                const int loi = cc ? xi : ix[j], hii = cc ? ix[j] : xi;
+                                v[j] = lo2; ix[j] = loi; x = hi2; xi = hii;
+                            }
+                        }
+                    }
+                }
+                if (lv) emit(q, v, ix, odd);
+            }
+            __syncthreads();                                // the queues are free again
+        }
     }
     GA_STAMP(0, 7);
 }
@@ -961,6 +1161,9 @@ extern "C" int geoadv_selection_sort(int b, int n, int m, int k, const float *di
 }
 
 static int g_knn_grid_mode = 0;           // 0 = by size, 1 = never, 2 = always (geoadv_knn_grid_mode: the parity tests run both kernels)
+static int g_knn_lane_first = 1;          // grid search: lane-private 27-cell walk first (0: the wave-uniform shells only); same results.
+                                          // Values-only lists (knn_dists) only: with (value, index) lists the queues leave room for ONE workgroup per
+                                          // CU, and two waves per SIMD do not hide the gathers' latency -- 378 against 343 us for knn_point(8) at 256 x 2048
 
 template <int MODE, int S>
 static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx, hipStream_t st) {
@@ -994,8 +1197,8 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         // about two workgroups per CU
         const int tasks = cdiv(m, 64), waves = KG_THREADS / 64;
         const int split = std::max(1, std::min(std::max(1, tasks / (waves * KG_TASKS_PER_WAVE)), cdiv(2 * kCUs, b)));
-        knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE>(n, KG_THREADS), st>>>(n, m, k, split, sorted, cs, qo, info,
-                                                                                                                   tord, xyz2, val, idx, redo);
+        knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE>(n, KG_THREADS, G * G * G), st>>>(n, m, k, split, sorted, cs, qo, info,
+                                                                                                                   tord, xyz2, val, idx, redo, (MODE == 1 && g_knn_lane_first) ? 1 : 0);
     } else {
         knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
     }
@@ -1014,15 +1217,17 @@ extern "C" int geoadv_debug_knn_occupancy(int n, int *blocks256, int *blocks512,
     return 0;
 }
 extern "C" int geoadv_debug_knn_diag(unsigned long long *host_out, int reset) {
-    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(geoadv::kg_diag), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(geoadv::kg_diag), z, sizeof(z)) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(geoadv::kg_diag), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(geoadv::kg_diag), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #endif
 
 extern "C" int geoadv_knn_grid_mode(int mode) {
-    GA_REQUIRE(mode >= 0 && mode <= 2, "knn_grid_mode: 0 = by size, 1 = all-points kernel only, 2 = grid search at every size");
-    g_knn_grid_mode = mode;
+    GA_REQUIRE(mode >= 0 && mode <= 3, "knn_grid_mode: 0 = by size, 1 = all-points kernel only, 2 = grid search at every size, "
+                                       "3 = as 2 with the wave-uniform shell search only (no lane-private first pass)");
+    g_knn_grid_mode = mode == 3 ? 2 : mode;
+    g_knn_lane_first = mode == 3 ? 0 : 1;
     return GEOADV_OK;
 }
 

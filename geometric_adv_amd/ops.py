@@ -220,8 +220,9 @@ def knn_point(k, xyz1, xyz2):
 
 
 def knn_grid_mode(mode):
-    """Process-wide choice of the k-NN kernel (include/geoadv.h: geoadv_knn_grid_mode): "auto" (by size), "all_points", "grid"."""
-    _lib.check(_lib.lib().geoadv_knn_grid_mode({"auto": 0, "all_points": 1, "grid": 2}[mode]), "knn_grid_mode")
+    """Process-wide choice of the k-NN kernel (include/geoadv.h: geoadv_knn_grid_mode): "auto" (by size), "all_points", "grid",
+    "grid_shells" (the grid search without its lane-private first pass: the wave-uniform shell walk for every query)."""
+    _lib.check(_lib.lib().geoadv_knn_grid_mode({"auto": 0, "all_points": 1, "grid": 2, "grid_shells": 3}[mode]), "knn_grid_mode")
 
 
 def knn_dists(pc, num_knn):

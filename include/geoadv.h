@@ -145,7 +145,8 @@ int geoadv_knn_point(int b, int n, int m, int k, const float *xyz1, const float 
                      float *val, int *idx, void *stream);
 /* Which kernel answers geoadv_knn_point / geoadv_knn_dists for k <= 16 -- PROCESS-WIDE, meant for the parity tests and the
  * measurements, which run both on the same inputs: 0 (default) = by size (datasets of >= 512 points: the exact grid search,
- * smaller ones: the all-points kernel), 1 = the all-points kernel only, 2 = the grid search at every size.  Same results. */
+ * smaller ones: the all-points kernel), 1 = the all-points kernel only, 2 = the grid search at every size, 3 = as 2 without the
+ * search's lane-private first pass (every query by the wave-uniform shell walk).  Same results. */
 int geoadv_knn_grid_mode(int mode);
 /* defender/get_knn_dists_per_point.py:78-81 fused: knn_point(k+1, pc, pc), drop the first column,
  * gather, euclidean distance.  out is (b,n,k). */

@@ -93,9 +93,10 @@ def test_query_ball_radius_boundary_and_large(oracle):
         assert np.array_equal(idx.cpu().numpy()[hit], want_idx[hit])
 
 
-@pytest.fixture(params=["all_points", "grid"])
+@pytest.fixture(params=["all_points", "grid", "grid_shells"])
 def knn_kernel(request):
-    """Both k-NN kernels on the same inputs: the all-points scan and the exact grid search (ops.knn_grid_mode)."""
+    """The k-NN kernels on the same inputs: the all-points scan, the exact grid search (lane-private pass + leftovers) and the
+    grid search's wave-uniform shell walk alone (ops.knn_grid_mode)."""
     from geometric_adv_amd import ops
     ops.knn_grid_mode(request.param)
     yield request.param
@@ -215,14 +216,15 @@ def test_knn_grid_on_awkward_geometry(oracle, kind):
         x = (x * np.float32(1e-4)).astype(np.float32)
     q = x[:, :m].copy() if kind != "far_queries" else (rng.standard_normal((b, m, 3)) * 30).astype(np.float32)
     q[:, ::2] += (rng.standard_normal((b, (m + 1) // 2, 3)) * 0.01).astype(np.float32)
-    ops.knn_grid_mode("grid")
     try:
-        for k in (1, 9, 16):
-            want_val, want_idx = oracle.knn_point(k, x, q)
-            val, idx = ops.knn_point(k, _t(x), _t(q))
-            assert np.array_equal(val.cpu().numpy(), want_val), (kind, k)
-            assert np.array_equal(idx.cpu().numpy(), want_idx), (kind, k)
-        assert np.array_equal(ops.knn_dists(_t(x), 8).cpu().numpy(), oracle.knn_dists(x, 8))
+        for mode in ("grid", "grid_shells"):
+            ops.knn_grid_mode(mode)
+            for k in (1, 9, 16):
+                want_val, want_idx = oracle.knn_point(k, x, q)
+                val, idx = ops.knn_point(k, _t(x), _t(q))
+                assert np.array_equal(val.cpu().numpy(), want_val), (kind, k, mode)
+                assert np.array_equal(idx.cpu().numpy(), want_idx), (kind, k, mode)
+            assert np.array_equal(ops.knn_dists(_t(x), 8).cpu().numpy(), oracle.knn_dists(x, 8)), (kind, mode)
     finally:
         ops.knn_grid_mode("auto")
 
@@ -241,12 +243,13 @@ def test_knn_grid_equals_all_points_at_config_size():
         pc[:, :20] *= 3.0
         pc = _t(pc)
         out = {}
-        for mode in ("all_points", "grid"):
+        for mode in ("all_points", "grid", "grid_shells"):
             ops.knn_grid_mode(mode)
             out[mode] = (ops.knn_dists(pc, 8), ) + tuple(ops.knn_point(9, pc, pc))
         ops.knn_grid_mode("auto")
-        for a, g in zip(out["all_points"], out["grid"]):
-            assert torch.equal(a, g)
+        for other in ("grid", "grid_shells"):
+            for a, g in zip(out["all_points"], out[other]):
+                assert torch.equal(a, g), other
 
 
 def test_grouping_argument_errors():
@@ -279,11 +282,12 @@ def test_knn_grid_equals_all_points_randomised():
         if trial == 7:
             x[0, 3, 1] = np.nan
         out = {}
-        for mode in ("all_points", "grid"):
+        for mode in ("all_points", "grid", "grid_shells"):
             ops.knn_grid_mode(mode)
             try:
                 out[mode] = ops.knn_point(k, _t(x), _t(q))
             finally:
                 ops.knn_grid_mode("auto")
-        for a, g in zip(out["all_points"], out["grid"]):
-            assert torch.equal(a.nan_to_num(nan=-1.0), g.nan_to_num(nan=-1.0)), (trial, b, n, m, k)
+        for other in ("grid", "grid_shells"):
+            for a, g in zip(out["all_points"], out[other]):
+                assert torch.equal(a.nan_to_num(nan=-1.0), g.nan_to_num(nan=-1.0)), (trial, b, n, m, k, other)

@@ -18,7 +18,7 @@ def timed(f, reps=5):
 
 
 out = {"batch": B, "n_points": N}
-for mode in ("all_points", "grid"):
+for mode in ("all_points", "grid", "grid_shells"):
     ops.knn_grid_mode(mode)
     out["knn_dists_k8_ms_" + mode] = timed(lambda: ops.knn_dists(xs, 8))
     out["knn_point_k8_ms_" + mode] = timed(lambda: ops.knn_point(8, xs, xs))
