@@ -475,13 +475,18 @@ SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def _timed(f, reps):
+    """ms per call: the median of three windows of `reps` calls after one untimed call (sub-millisecond ops on a box that has just
+    run other legs scatter by +- 10 % from window to window)."""
     import torch
     f(); torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(reps):
-        f()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / reps * 1e3
+    w = []
+    for _ in range(3):
+        t = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        w.append((time.perf_counter() - t) / reps * 1e3)
+    return sorted(w)[1]
 
 
 def _timed_attack(at, warm, iters):
@@ -556,7 +561,7 @@ def config2_leg(dev):
            "encoder_fwd": {"avg_launch_ms": enc_ms, "frac_of_fp32_mfma_peak": enc_frac},
            "knn_dists_k8_ms": t_knn, "knn_point_k9_ms": t_knn_point,
            "defend_surface_ms": t_def, "defend_surface_numpy_in_out_ms": t_def_np,
-           "roofline_knn": {"bound": "valu issue", "kernel": "knn_fast_kernel<1, 9> (+ knn_redo_kernel for tied / non-finite queries)",
+           "roofline_knn": {"bound": "valu issue", "kernel": "knn_grid_build_kernel + knn_grid_kernel<1, 9, 512> (exact grid search: lane-private 27-cell walk, leftovers by a cooperative all-points scan) + knn_redo_kernel for tied / non-finite queries",
                             "pairs_per_launch": pairs, "achieved_Tpair_per_s": pairs / (t_knn * 1e-3) / 1e12,
                             "issue_bound_ms": bound_ms, "frac": bound_ms / t_knn,
                             "bound_note": "distance only: 8 fp32 VALU instructions per pair (3 sub, 3 mul, 2 add -- unfused, the reference's "

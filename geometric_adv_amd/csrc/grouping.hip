@@ -306,6 +306,7 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
 #endif
 constexpr int KG_MAX_G = 16, KG_MAX_CELLS = KG_MAX_G * KG_MAX_G * KG_MAX_G;
 constexpr int KG_BUILD_THREADS = 1024;
+constexpr int KG_MAX_N = 4096;             // the whole sorted cloud sits in the search kernel's LDS (64 KB at 4096 points)
 
 struct KnnGrid {
     float lo[3], ih[3], h[3], eps[3];       // origin, 1 / cell size, cell size, slack on a face distance (rounding of the cell assignment)
@@ -383,7 +384,7 @@ __device__ __forceinline__ int kg_wave_max(int v) {
 
 __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n, int m, int G, const float *xyz1, const float *xyz2,
                                                                           float4 *sorted, int *cell_start, int *qorder, KnnGrid *info,
-                                                                          int *task_order) {
+                                                                          int *task_order, int lpt) {
     __shared__ int cnt[KG_MAX_CELLS], qcnt[KG_MAX_CELLS];
     __shared__ float red[7][KG_BUILD_THREADS / 64];
     __shared__ int wsum[KG_BUILD_THREADS / 64];
@@ -391,14 +392,29 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
     const int c = blockIdx.x, t = threadIdx.x;
     const float *data = xyz1 + (size_t)c * n * 3;
     const float *qry = xyz2 + (size_t)c * m * 3;
+    // The cloud (n <= KG_MAX_N = 4 x 1024) and the first 4096 queries are read ONCE and kept in registers through the three passes
+    // (box, count, scatter): a pass over global memory is a round trip of ~3 us on this one-workgroup-per-cloud kernel, and there
+    // were three of them (22 us for what is a few thousand LDS atomics).
+    constexpr int PT = KG_MAX_N / KG_BUILD_THREADS;
+    float dx[PT], dy[PT], dz[PT], ux[PT], uy[PT], uz[PT];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int i = t + u * KG_BUILD_THREADS;
+        const size_t e = 3 * (size_t)(i < n ? i : n - 1);
+        dx[u] = data[e]; dy[u] = data[e + 1]; dz[u] = data[e + 2];
+        const size_t f = 3 * (size_t)(i < m ? i : m - 1);
+        ux[u] = qry[f]; uy[u] = qry[f + 1]; uz[u] = qry[f + 2];
+    }
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0.f;
-    for (int i = t; i < n; i += KG_BUILD_THREADS)
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {                                       // (clamped copies of the last point change nothing)
+        const float v3[3] = {dx[u], dy[u], dz[u]};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float v = data[3 * (size_t)i + a];
-            lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v);
-            bad = fabsf(v) < INFINITY ? bad : 1.f;                      // NaN or +-inf
+            lo[a] = fminf(lo[a], v3[a]); hi[a] = fmaxf(hi[a], v3[a]);
+            bad = fabsf(v3[a]) < INFINITY ? bad : 1.f;                  // NaN or +-inf
         }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -430,16 +446,18 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
     }
     __syncthreads();
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
-    for (int i = t; i < n; i += KG_BUILD_THREADS) {
-        const float x = data[3 * (size_t)i], y = data[3 * (size_t)i + 1], z = data[3 * (size_t)i + 2];
-        const int cell = (kg_cell1(z, g.lo[2], g.ih[2], gz) * gy + kg_cell1(y, g.lo[1], g.ih[1], gy)) * gx + kg_cell1(x, g.lo[0], g.ih[0], gx);
-        atomicAdd(&cnt[cell], 1);
+    int dcell[PT];
+    unsigned qh[PT];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int i = t + u * KG_BUILD_THREADS;
+        dcell[u] = (kg_cell1(dz[u], g.lo[2], g.ih[2], gz) * gy + kg_cell1(dy[u], g.lo[1], g.ih[1], gy)) * gx + kg_cell1(dx[u], g.lo[0], g.ih[0], gx);
+        if (i < n) atomicAdd(&cnt[dcell[u]], 1);
+        qh[u] = kg_hilbert(g, ux[u], uy[u], uz[u]);
+        if (i < m) atomicAdd(&qcnt[qh[u]], 1);
     }
-    for (int j = t; j < m; j += KG_BUILD_THREADS) {
-        const float x = qry[3 * (size_t)j], y = qry[3 * (size_t)j + 1], z = qry[3 * (size_t)j + 2];
-        const unsigned mc = kg_hilbert(g, x, y, z);
-        atomicAdd(&qcnt[mc], 1);
-    }
+    for (int j = t + PT * KG_BUILD_THREADS; j < m; j += KG_BUILD_THREADS)         // (more than 4096 queries: the rest from memory)
+        atomicAdd(&qcnt[kg_hilbert(g, qry[3 * (size_t)j], qry[3 * (size_t)j + 1], qry[3 * (size_t)j + 2])], 1);
     __syncthreads();
     kg_scan(cnt, wsum);
     kg_scan(qcnt, wsum);
@@ -447,17 +465,15 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
     for (int i = t; i < KG_MAX_CELLS; i += KG_BUILD_THREADS) cs[i] = cnt[i];         // (cells past g.cells hold n: empty)
     if (t == 0) cs[KG_MAX_CELLS] = n;
     __syncthreads();
-    for (int i = t; i < n; i += KG_BUILD_THREADS) {
-        const float x = data[3 * (size_t)i], y = data[3 * (size_t)i + 1], z = data[3 * (size_t)i + 2];
-        const int cell = (kg_cell1(z, g.lo[2], g.ih[2], gz) * gy + kg_cell1(y, g.lo[1], g.ih[1], gy)) * gx + kg_cell1(x, g.lo[0], g.ih[0], gx);
-        const int pos = atomicAdd(&cnt[cell], 1);
-        sorted[(size_t)c * n + pos] = make_float4(x, y, z, __int_as_float(i));
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int i = t + u * KG_BUILD_THREADS;
+        if (i < n) sorted[(size_t)c * n + atomicAdd(&cnt[dcell[u]], 1)] = make_float4(dx[u], dy[u], dz[u], __int_as_float(i));
+        if (i < m) qorder[(size_t)c * m + atomicAdd(&qcnt[qh[u]], 1)] = i;
     }
-    for (int j = t; j < m; j += KG_BUILD_THREADS) {
-        const float x = qry[3 * (size_t)j], y = qry[3 * (size_t)j + 1], z = qry[3 * (size_t)j + 2];
-        const unsigned mc = kg_hilbert(g, x, y, z);
-        const int pos = atomicAdd(&qcnt[mc], 1);
-        qorder[(size_t)c * m + pos] = j;
+    for (int j = t + PT * KG_BUILD_THREADS; j < m; j += KG_BUILD_THREADS) {
+        const unsigned mc = kg_hilbert(g, qry[3 * (size_t)j], qry[3 * (size_t)j + 1], qry[3 * (size_t)j + 2]);
+        qorder[(size_t)c * m + atomicAdd(&qcnt[mc], 1)] = j;
     }
     // The order in which the search hands out its tasks (64 consecutive queries of qorder each): the ones with the largest
     // boxes of cells first -- a task costs between a few cells and the whole grid, and a workgroup's last tasks should be cheap
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
     __syncthreads();
     const int tasks = (m + 63) / 64;
     int *tord = task_order + (size_t)c * tasks;
-    if (tasks > KG_BUILD_THREADS) {
+    if (tasks > KG_BUILD_THREADS || !lpt) {                     // (the lane-private search's tasks cost the same: no order to find)
         for (int i = t; i < tasks; i += KG_BUILD_THREADS) tord[i] = i;
         return;
     }
@@ -490,13 +506,12 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
     }
 }
 
-// LDS of the search kernel (dynamic): the sorted cloud as planes x[n4] y[n4] z[n4] (+ original index [n4] for MODE 0), n4 = n
-// rounded up to a multiple of 4 plus one group of padding; then the candidate queues (distance [, index]) of THREADS lanes.
+// LDS of the search kernel (dynamic): the sorted cloud as float4 (x, y, z, original index) [n4], n4 = n rounded up to a multiple of 4
+// plus one group of padding; the candidate queues (distance [, index]) of THREADS lanes; the cell offsets of the cloud's grid.
 __host__ __device__ inline int kg_n4(int n) { return ((n + 3) & ~3) + 4; }
 template <int MODE> __host__ __device__ inline size_t kg_lds_bytes(int n, int threads, int cells = KG_MAX_CELLS) {
     return (size_t)kg_n4(n) * 16 + (size_t)KF_QCAP * threads * 4 * (MODE == 0 ? 2 : 1) + sizeof(int) * (cells + 4);
 }
-constexpr int KG_MAX_N = 4096;             // the whole sorted cloud sits in LDS (48 / 64 KB at 4096 points)
 #ifndef KG_THREADS_V
 #define KG_THREADS_V 512
 #endif
@@ -1186,7 +1201,8 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         int *tord = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b));
         const int G = n < KNN_GRID_N_MID ? KNN_GRID_G_SMALL : (n < KNN_GRID_N_BIG ? KNN_GRID_G_MID : KNN_GRID_G_BIG);
         GA_HIP(hipMemsetAsync(sorted + (size_t)b * n, 0, 4 * sizeof(float4), st));
-        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, 0, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord);
+        const int lane_first = (MODE == 1 && g_knn_lane_first) ? 1 : 0;
+        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, 0, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord, lane_first ? 0 : 1);
         static DeviceOnce attr;
         if (int rc = attr.run([]() -> int {
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<MODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1198,7 +1214,7 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         const int tasks = cdiv(m, 64), waves = KG_THREADS / 64;
         const int split = std::max(1, std::min(std::max(1, tasks / (waves * KG_TASKS_PER_WAVE)), cdiv(2 * kCUs, b)));
         knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE>(n, KG_THREADS, G * G * G), st>>>(n, m, k, split, sorted, cs, qo, info,
-                                                                                                                   tord, xyz2, val, idx, redo, (MODE == 1 && g_knn_lane_first) ? 1 : 0);
+                                                                                                                   tord, xyz2, val, idx, redo, lane_first);
     } else {
         knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
     }

@@ -12,9 +12,14 @@ xs = torch.as_tensor(x).cuda()
 
 
 def timed(f, reps=5):
-    f(); torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(reps): f()
-    torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+    """ms per call: median of three windows of `reps` calls after one untimed call."""
+    f(); torch.cuda.synchronize()
+    w = []
+    for _ in range(3):
+        t = time.perf_counter()
+        for _ in range(reps): f()
+        torch.cuda.synchronize(); w.append((time.perf_counter() - t) / reps * 1e3)
+    return sorted(w)[1]
 
 
 out = {"batch": B, "n_points": N}
