@@ -386,6 +386,10 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
                                                                           float4 *sorted, int *cell_start, int *qorder, KnnGrid *info,
                                                                           int *task_order, int lpt) {
     __shared__ int cnt[KG_MAX_CELLS], qcnt[KG_MAX_CELLS];
+    extern __shared__ __attribute__((aligned(16))) float kb_lds[];         // stage [KG_MAX_N] float4, qstage [KG_MAX_N] int
+    float4 *stage = reinterpret_cast<float4 *>(kb_lds);
+    int *qstage = reinterpret_cast<int *>(kb_lds + 4 * KG_MAX_N);
+    const bool qlds = m <= KG_MAX_N;
     __shared__ float red[7][KG_BUILD_THREADS / 64];
     __shared__ int wsum[KG_BUILD_THREADS / 64];
     __shared__ KnnGrid g;
@@ -465,27 +469,38 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
     for (int i = t; i < KG_MAX_CELLS; i += KG_BUILD_THREADS) cs[i] = cnt[i];         // (cells past g.cells hold n: empty)
     if (t == 0) cs[KG_MAX_CELLS] = n;
     __syncthreads();
+    // the two permutations are formed in LDS and leave in order: scattered 16-byte stores straight to memory were 6 of the kernel's 21 us
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
         const int i = t + u * KG_BUILD_THREADS;
-        if (i < n) sorted[(size_t)c * n + atomicAdd(&cnt[dcell[u]], 1)] = make_float4(dx[u], dy[u], dz[u], __int_as_float(i));
-        if (i < m) qorder[(size_t)c * m + atomicAdd(&qcnt[qh[u]], 1)] = i;
+        if (i < n) stage[atomicAdd(&cnt[dcell[u]], 1)] = make_float4(dx[u], dy[u], dz[u], __int_as_float(i));
+        if (i < m) {
+            const int pos = atomicAdd(&qcnt[qh[u]], 1);
+            if (qlds) qstage[pos] = i; else qorder[(size_t)c * m + pos] = i;
+        }
     }
-    for (int j = t + PT * KG_BUILD_THREADS; j < m; j += KG_BUILD_THREADS) {
+    for (int j = t + PT * KG_BUILD_THREADS; j < m; j += KG_BUILD_THREADS) {       // (m > KG_MAX_N: the order does not fit the stage)
         const unsigned mc = kg_hilbert(g, qry[3 * (size_t)j], qry[3 * (size_t)j + 1], qry[3 * (size_t)j + 2]);
         qorder[(size_t)c * m + atomicAdd(&qcnt[mc], 1)] = j;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const int i = t + u * KG_BUILD_THREADS;
+        if (i < n) sorted[(size_t)c * n + i] = stage[i];
+        if (qlds && i < m) qorder[(size_t)c * m + i] = qstage[i];
     }
     // The order in which the search hands out its tasks (64 consecutive queries of qorder each): the ones with the largest
     // boxes of cells first -- a task costs between a few cells and the whole grid, and a workgroup's last tasks should be cheap
     // ones (longest-processing-time-first; the estimate is the box of the task's cells grown by two cells a side).
-    __threadfence_block();
-    __syncthreads();
     const int tasks = (m + 63) / 64;
     int *tord = task_order + (size_t)c * tasks;
     if (tasks > KG_BUILD_THREADS || !lpt) {                     // (the lane-private search's tasks cost the same: no order to find)
         for (int i = t; i < tasks; i += KG_BUILD_THREADS) tord[i] = i;
         return;
     }
+    __threadfence_block();
+    __syncthreads();
     int *tkey = cnt;                                           // (the cell counters are no longer needed)
     for (int task = t >> 6; task < tasks; task += KG_BUILD_THREADS / 64) {
         const int slot = task * 64 + (t & 63);
@@ -1202,7 +1217,13 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         const int G = n < KNN_GRID_N_MID ? KNN_GRID_G_SMALL : (n < KNN_GRID_N_BIG ? KNN_GRID_G_MID : KNN_GRID_G_BIG);
         GA_HIP(hipMemsetAsync(sorted + (size_t)b * n, 0, 4 * sizeof(float4), st));
         const int lane_first = (MODE == 1 && g_knn_lane_first) ? 1 : 0;
-        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, 0, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord, lane_first ? 0 : 1);
+        constexpr size_t KB_LDS = (size_t)KG_MAX_N * 20;
+        static DeviceOnce battr;
+        if (int rc = battr.run([]() -> int {
+                GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_LDS));
+                return GEOADV_OK;
+            })) { (void)hipFreeAsync(scratch, st); return rc; }
+        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, KB_LDS, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord, lane_first ? 0 : 1);
         static DeviceOnce attr;
         if (int rc = attr.run([]() -> int {
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<MODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
