@@ -190,16 +190,17 @@ __global__ __launch_bounds__(KF_THREADS) void knn_fast_kernel(int n, int m, int 
 #pragma unroll                                             // from the top down (the OLD v[i - 1]): S instructions where a compare-exchange chain
                 for (int i = S - 1; i > 0; --i) v[i] = __builtin_amdgcn_fmed3f(v[i - 1], d, v[i]);      // takes 2 S (a NaN only ever marks
                 v[0] = fminf(v[0], d);                                                                    // the query `odd`: its list is not used)
-            } else {                                       // (value, index): the candidate sinks past every entry it is strictly below;
-                float x = d;                               // an equal entry -- earlier index -- stays ahead of it.  Selects only, no branch.
-                int xi = id;
+            } else {                                       // (value, index): the candidate goes in front of the first entry it is STRICTLY below
+                bool below[S];                             // (an equal entry -- earlier index -- stays ahead of it); monotone along the list
 #pragma unroll
-                for (int i = 0; i < S; ++i) {
-                    const bool c = x < v[i];
-                    const float lo = c ? x : v[i], hi = c ? v[i] : x;
-                    const int loi = c ? xi : ix[i], hii = c ? ix[i] : xi;
-                    v[i] = lo; ix[i] = loi; x = hi; xi = hii;
+                for (int i = 0; i < S; ++i) below[i] = d < v[i];
+#pragma unroll
+                for (int i = S - 1; i > 0; --i) {
+                    v[i] = __builtin_amdgcn_fmed3f(v[i - 1], d, v[i]);
+                    ix[i] = below[i - 1] ? ix[i - 1] : (below[i] ? id : ix[i]);
                 }
+                v[0] = fminf(v[0], d);
+                ix[0] = below[0] ? id : ix[0];
             }
         }
         qw = 4u * threadIdx.x;
