@@ -252,6 +252,39 @@ def test_knn_grid_equals_all_points_at_config_size():
                 assert torch.equal(a, g), other
 
 
+def test_knn_grid_many_leftover_queries():
+    """knn_dists-style searches (values only: the lane-private walk) where most queries are NOT closed by the 27 cells around
+    them -- queries far outside the cloud, a cloud that is two distant clusters plus stragglers --: more leftovers than a
+    workgroup's list holds (the overflow goes to the exact redo kernel), several cooperative all-points chunks per workgroup.
+    Same values as the all-points kernel, bit for bit."""
+    import torch
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(99)
+    b, n = 3, 2048
+    x = rng.random((b, n, 3), dtype=np.float32)
+    x[:, : n // 2] = x[:, : n // 2] * np.float32(0.05)                       # cluster A
+    x[:, n // 2: n - 40] = x[:, n // 2: n - 40] * np.float32(0.05) + np.float32(5.0)   # cluster B, far away
+    x[:, n - 40:] = rng.standard_normal((b, 40, 3)).astype(np.float32) * np.float32(20.0)   # stragglers
+    out = {}
+    for mode in ("all_points", "grid", "grid_shells"):
+        ops.knn_grid_mode(mode)
+        try:
+            out[mode] = ops.knn_dists(_t(x), 8)
+        finally:
+            ops.knn_grid_mode("auto")
+    assert torch.equal(out["all_points"], out["grid"]) and torch.equal(out["all_points"], out["grid_shells"])
+    # queries far from everything, many more than KG_LEFT_CAP per workgroup (values + indices ride the shell walk; the values-only
+    # path is reached through knn_dists only, so the far queries go in as a second "cloud" of the same call)
+    y = np.concatenate([rng.random((b, 600, 3), dtype=np.float32), rng.standard_normal((b, n - 600, 3)).astype(np.float32) * np.float32(50.0)], axis=1)
+    for mode in ("all_points", "grid"):
+        ops.knn_grid_mode(mode)
+        try:
+            out[mode] = ops.knn_dists(_t(y), 8)
+        finally:
+            ops.knn_grid_mode("auto")
+    assert torch.equal(out["all_points"], out["grid"])
+
+
 def test_grouping_argument_errors():
     import torch
     from geometric_adv_amd import ops
