@@ -525,8 +525,12 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
 // LDS of the search kernel (dynamic): the sorted cloud as float4 (x, y, z, original index) [n4], n4 = n rounded up to a multiple of 4
 // plus one group of padding; the candidate queues (distance [, index]) of THREADS lanes; the cell offsets of the cloud's grid.
 __host__ __device__ inline int kg_n4(int n) { return ((n + 3) & ~3) + 4; }
-template <int MODE> __host__ __device__ inline size_t kg_lds_bytes(int n, int threads, int cells = KG_MAX_CELLS) {
-    return (size_t)kg_n4(n) * 16 + (size_t)KF_QCAP * threads * 4 * (MODE == 0 ? 2 : 1) + sizeof(int) * (cells + 4);
+// queue slots per lane in the grid search: (value, index) queues of 16 slots leave room for ONE 512-thread workgroup per CU at
+// 2048 points, and two waves per SIMD do not hide the lane-private walk's gathers; ten slots (lists of up to ten entries: k <= 9)
+// let two workgroups in
+template <int MODE, int S> constexpr int kg_qcap() { return (MODE == 0 && S <= 10) ? 10 : KF_QCAP; }
+template <int MODE, int S> __host__ __device__ inline size_t kg_lds_bytes(int n, int threads, int cells = KG_MAX_CELLS) {
+    return (size_t)kg_n4(n) * 16 + (size_t)kg_qcap<MODE, S>() * threads * 4 * (MODE == 0 ? 2 : 1) + sizeof(int) * (cells + 4);
 }
 #ifndef KG_THREADS_V
 #define KG_THREADS_V 512
@@ -548,7 +552,7 @@ __device__ unsigned long long kg_diag[16];
 // order) from a counter in LDS until the workgroup's share [task0, task1) of the cloud's tasks is done: a task costs between
 // a few cells and the whole grid, so a fixed assignment leaves a workgroup waiting for its unluckiest wave.
 template <int MODE, int S, int THREADS>
-__global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, int split, const float4 *__restrict__ sorted,
+__global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(int n, int m, int k, int split, const float4 *__restrict__ sorted,
                                                            const int *__restrict__ cell_start, const int *__restrict__ qorder,
                                                            const KnnGrid *__restrict__ info, const int *__restrict__ task_order,
                                                            const float *__restrict__ xyz2, float *val_out, int *idx_out, int *redo,
@@ -561,14 +565,15 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
     float4 *sp = reinterpret_cast<float4 *>(kg_lds);       // the sorted cloud, (x, y, z, original index) per point: ONE ds_read_b128 per candidate
                                                            // whether the address is the wave's (broadcast) or the lane's own (gather)
     float *qd = kg_lds + 4 * (size_t)n4;
-    int *qi = reinterpret_cast<int *>(qd + KF_QCAP * THREADS);
+    constexpr int QC = kg_qcap<MODE, S>();
+    int *qi = reinterpret_cast<int *>(qd + QC * THREADS);
 #ifndef KG_LDS_CS
 #define KG_LDS_CS 1
 #endif
 #ifndef KG_PREFETCH
 #define KG_PREFETCH 0          // measured: 280 against 244 us -- the task taken one ahead is a task the counter can no longer balance
 #endif
-    int *cs_l = qi + (MODE == 0 ? KF_QCAP * THREADS : 0);   // the cell offsets too: every shell of every task looks rows up in them
+    int *cs_l = qi + (MODE == 0 ? QC * THREADS : 0);   // the cell offsets too: every shell of every task looks rows up in them
     const int c = blockIdx.y;
     const float4 *pts = sorted + (size_t)c * n;
     const int *cs_g = cell_start + (size_t)c * (KG_MAX_CELLS + 1);
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
                             if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = __float_as_int(t[u].w);
                             qw += 4u * THREADS;
                         }
-                    if (__any(qw >= 4u * (KF_QCAP - 3) * THREADS)) drain_into(v, ix, odd, thr, qw);
+                    if (__any(qw >= 4u * (QC - 3) * THREADS)) drain_into(v, ix, odd, thr, qw);
                 }
             }
         };
@@ -817,7 +822,7 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
                             pcnt += 1;
                         }
                     if (pcnt >= S) { thr = fminf(thr, pmax); pmax = 0.f; pcnt = 0; }
-                    if (__any(qw >= 4u * (KF_QCAP - 3) * THREADS)) { drain_into(v, ix, odd, thr, qw); pmax = 0.f; pcnt = 0; }
+                    if (__any(qw >= 4u * (QC - 3) * THREADS)) { drain_into(v, ix, odd, thr, qw); pmax = 0.f; pcnt = 0; }
                 }
                 p += 4;
             }
@@ -877,7 +882,7 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
         // reads, the lists and queues as everywhere), leaves its list in its queue slots, and wave 0 merges the eight lists.
         __syncthreads();                                    // every wave's leftovers are listed
         const int left = min(left_n, KG_LEFT_CAP);
-        constexpr bool COOP = S <= KF_QCAP;                 // (a list must fit the lane's queue slots; longer ones: one wave, the shell walk)
+        constexpr bool COOP = S <= QC;                 // (a list must fit the lane's queue slots; longer ones: one wave, the shell walk)
         const int wave = threadIdx.x >> 6;
         for (int chunk = 0; chunk * 64 < left; ++chunk) {
             const int slot = chunk * 64 + lane;
@@ -919,7 +924,7 @@ __global__ __launch_bounds__(THREADS) void knn_grid_kernel(int n, int m, int k, 
                             if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = __float_as_int(t[u].w);
                             qw += 4u * THREADS;
                         }
-                    if (__any(qw >= 4u * (KF_QCAP - 3) * THREADS)) drain_into(v, ix, odd, thr, qw);
+                    if (__any(qw >= 4u * (QC - 3) * THREADS)) drain_into(v, ix, odd, thr, qw);
                 }
             }
             drain_into(v, ix, odd, thr, qw);
@@ -1193,8 +1198,8 @@ extern "C" int geoadv_selection_sort(int b, int n, int m, int k, const float *di
 
 static int g_knn_grid_mode = 0;           // 0 = by size, 1 = never, 2 = always (geoadv_knn_grid_mode: the parity tests run both kernels)
 static int g_knn_lane_first = 1;          // grid search: lane-private 27-cell walk first (0: the wave-uniform shells only); same results.
-                                          // Values-only lists (knn_dists) only: with (value, index) lists the queues leave room for ONE workgroup per
-                                          // CU, and two waves per SIMD do not hide the gathers' latency -- 378 against 343 us for knn_point(8) at 256 x 2048
+                                          // Values-only lists (knn_dists) only: with (value, index) lists the walk lost to the shells at either occupancy
+                                          // (knn_point(8) at 256 x 2048: 378 against 343 us at one workgroup per CU, 265 against 227 us at two)
 
 template <int MODE, int S>
 static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx, hipStream_t st) {
@@ -1228,14 +1233,14 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         static DeviceOnce attr;
         if (int rc = attr.run([]() -> int {
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<MODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kg_lds_bytes<MODE>(KG_MAX_N, KG_THREADS)));
+                                           (int)kg_lds_bytes<MODE, S>(KG_MAX_N, KG_THREADS)));
                 return GEOADV_OK;
             })) { (void)hipFreeAsync(scratch, st); return rc; }
         // workgroups per cloud: every wave should see KG_TASKS_PER_WAVE tasks or more (the counter balances them), and the launch
         // about two workgroups per CU
         const int tasks = cdiv(m, 64), waves = KG_THREADS / 64;
         const int split = std::max(1, std::min(std::max(1, tasks / (waves * KG_TASKS_PER_WAVE)), cdiv(2 * kCUs, b)));
-        knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE>(n, KG_THREADS, G * G * G), st>>>(n, m, k, split, sorted, cs, qo, info,
+        knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE, S>(n, KG_THREADS, G * G * G), st>>>(n, m, k, split, sorted, cs, qo, info,
                                                                                                                    tord, xyz2, val, idx, redo, lane_first);
     } else {
         knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
@@ -1250,7 +1255,7 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
 #ifdef KG_DIAG
 extern "C" int geoadv_debug_knn_occupancy(int n, int *blocks256, int *blocks512, int *blocks_fast) {
     *blocks256 = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks512, knn_grid_kernel<1, 9, KG_THREADS>, KG_THREADS, kg_lds_bytes<1>(n, KG_THREADS)) != hipSuccess) return 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks512, knn_grid_kernel<1, 9, KG_THREADS>, KG_THREADS, kg_lds_bytes<1, 9>(n, KG_THREADS)) != hipSuccess) return 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_fast, knn_fast_kernel<1, 9>, 256, 0) != hipSuccess) return 1;
     return 0;
 }
@@ -1279,7 +1284,8 @@ static int launch_knn(int mode, int b, int n, int m, int k, const float *xyz1, c
             if (slots <= 3) return launch_knn_fast<0, 3>(b, n, m, k, xyz1, xyz2, val, idx, st);
             if (slots <= 5) return launch_knn_fast<0, 5>(b, n, m, k, xyz1, xyz2, val, idx, st);
             if (slots <= 9) return launch_knn_fast<0, 9>(b, n, m, k, xyz1, xyz2, val, idx, st);
-            if (slots <= 11) return launch_knn_fast<0, 11>(b, n, m, k, xyz1, xyz2, val, idx, st);     // k = 9 (the defender's knn_point call), 10
+            if (slots <= 10) return launch_knn_fast<0, 10>(b, n, m, k, xyz1, xyz2, val, idx, st);     // k = 9: the defender's knn_point call
+            if (slots <= 11) return launch_knn_fast<0, 11>(b, n, m, k, xyz1, xyz2, val, idx, st);
             if (slots <= 13) return launch_knn_fast<0, 13>(b, n, m, k, xyz1, xyz2, val, idx, st);
             return launch_knn_fast<0, 17>(b, n, m, k, xyz1, xyz2, val, idx, st);
         }
