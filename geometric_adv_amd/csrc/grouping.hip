@@ -385,7 +385,7 @@ __device__ __forceinline__ int kg_wave_max(int v) {
 
 __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n, int m, int G, const float *xyz1, const float *xyz2,
                                                                           float4 *sorted, int *cell_start, int *qorder, KnnGrid *info,
-                                                                          int *task_order, int lpt) {
+                                                                          int *task_order, int lpt, int *redo) {
     __shared__ int cnt[KG_MAX_CELLS], qcnt[KG_MAX_CELLS];
     extern __shared__ __attribute__((aligned(16))) float kb_lds[];         // stage [KG_MAX_N] float4, qstage [KG_MAX_N] int
     float4 *stage = reinterpret_cast<float4 *>(kb_lds);
@@ -395,6 +395,7 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
     __shared__ int wsum[KG_BUILD_THREADS / 64];
     __shared__ KnnGrid g;
     const int c = blockIdx.x, t = threadIdx.x;
+    if (c == 0 && t == 0) redo[0] = 0;                                     // the redo list's counter (the search and redo launches follow)
     const float *data = xyz1 + (size_t)c * n * 3;
     const float *qry = xyz2 + (size_t)c * m * 3;
     // The cloud (n <= KG_MAX_N = 4 x 1024) and the first 4096 queries are read ONCE and kept in registers through the three passes
@@ -1213,7 +1214,7 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
     char *scratch = nullptr;
     GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), up(redo_b) + (grid ? up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b) + up(to_b) : 0), st));
     int *redo = reinterpret_cast<int *>(scratch);
-    GA_HIP(hipMemsetAsync(redo, 0, sizeof(int), st));
+    if (!grid) GA_HIP(hipMemsetAsync(redo, 0, sizeof(int), st));          // (the grid's build kernel clears the counter itself: one launch less)
     if (grid) {
         float4 *sorted = reinterpret_cast<float4 *>(scratch + up(redo_b));
         int *cs = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b));
@@ -1221,7 +1222,6 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         KnnGrid *info = reinterpret_cast<KnnGrid *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b));
         int *tord = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b));
         const int G = n < KNN_GRID_N_MID ? KNN_GRID_G_SMALL : (n < KNN_GRID_N_BIG ? KNN_GRID_G_MID : KNN_GRID_G_BIG);
-        GA_HIP(hipMemsetAsync(sorted + (size_t)b * n, 0, 4 * sizeof(float4), st));
         const int lane_first = (MODE == 1 && g_knn_lane_first) ? 1 : 0;
         constexpr size_t KB_LDS = (size_t)KG_MAX_N * 20;
         static DeviceOnce battr;
@@ -1229,7 +1229,7 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_LDS));
                 return GEOADV_OK;
             })) { (void)hipFreeAsync(scratch, st); return rc; }
-        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, KB_LDS, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord, lane_first ? 0 : 1);
+        knn_grid_build_kernel<<<b, KG_BUILD_THREADS, KB_LDS, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord, lane_first ? 0 : 1, redo);
         static DeviceOnce attr;
         if (int rc = attr.run([]() -> int {
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<MODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
