@@ -568,12 +568,6 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
     float *qd = kg_lds + 4 * (size_t)n4;
     constexpr int QC = kg_qcap<MODE, S>();
     int *qi = reinterpret_cast<int *>(qd + QC * THREADS);
-#ifndef KG_LDS_CS
-#define KG_LDS_CS 1
-#endif
-#ifndef KG_PREFETCH
-#define KG_PREFETCH 0          // measured: 280 against 244 us -- the task taken one ahead is a task the counter can no longer balance
-#endif
     int *cs_l = qi + (MODE == 0 ? QC * THREADS : 0);   // the cell offsets too: every shell of every task looks rows up in them
     const int c = blockIdx.y;
     const float4 *pts = sorted + (size_t)c * n;
@@ -600,15 +594,15 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
         }
     }
     const int gx = g.g[0], gy = g.g[1], gz = g.g[2];
-    if (KG_LDS_CS) for (int e = threadIdx.x; e <= gx * gy * gz; e += THREADS) cs_l[e] = cs_g[e];
-    const int *cs = KG_LDS_CS ? cs_l : cs_g;
+    for (int e = threadIdx.x; e <= gx * gy * gz; e += THREADS) cs_l[e] = cs_g[e];
+    const int *cs = cs_l;
     const int lane = threadIdx.x & 63;
     GA_STAMP(0, 1);
     __syncthreads();                                        // the only workgroup barrier: from here on the waves go their own ways
     GA_STAMP(0, 2);
 
-    // (KG_PREFETCH: a task's queries requested one task ahead -- index, then coordinates, two dependent round trips that otherwise
-    // open every task; off, see above: what bounds this kernel is the spread of the tasks' costs, not their opening latency)
+    // (a task's queries requested one task AHEAD -- index, then coordinates, two dependent round trips that otherwise open every
+    // task -- was measured on the shell walk: 280 against 244 us, the task taken ahead is one the counter can no longer balance)
     struct Query { int q; float x, y, z; };
     auto load_query = [&](int place) {
         const int slot = tord[blockIdx.x + place * split] * 64 + lane;
@@ -846,13 +840,6 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
     int task = task0 + (threadIdx.x >> 6);
     Query cur = load_query(task < task1 ? task : task0);
     while (task < task1) {
-        int nt = 0;
-        Query nxt = cur;
-        if (KG_PREFETCH) {
-            if (lane == 0) nt = atomicAdd(&next_task, 1);
-            nt = __builtin_amdgcn_readfirstlane(nt);
-            nxt = load_query(nt < task1 ? nt : task);
-        }
         const bool live = tord[blockIdx.x + task * split] * 64 + lane < m;
         if (lane_first) {
             const bool done = lane_search(cur.q, cur.x, cur.y, cur.z, live);
@@ -868,13 +855,11 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
                 }
             }
         } else uniform_search(cur.q, cur.x, cur.y, cur.z, live);
-        if (!KG_PREFETCH) {
-            if (lane == 0) nt = atomicAdd(&next_task, 1);
-            nt = __builtin_amdgcn_readfirstlane(nt);
-            nxt = load_query(nt < task1 ? nt : task);
-        }
+        int nt = 0;
+        if (lane == 0) nt = atomicAdd(&next_task, 1);
+        nt = __builtin_amdgcn_readfirstlane(nt);
+        cur = load_query(nt < task1 ? nt : task);
         task = nt;
-        cur = nxt;
     }
     if (lane_first) {
         // The leftovers, 64 at a time.  They are scattered over the cloud, so their common box of cells is the grid: an all-points scan.
