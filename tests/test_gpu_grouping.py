@@ -285,6 +285,26 @@ def test_knn_grid_many_leftover_queries():
     assert torch.equal(out["all_points"], out["grid"])
 
 
+def test_knn_grid_more_queries_than_the_build_kernel_keeps_in_registers():
+    """5000 queries against 1000 / 4096 points: the grid's build kernel holds the first 4096 queries in registers and orders them
+    through LDS, the rest goes the long way; values and indices as the all-points kernel's."""
+    import torch
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(5)
+    for n in (1000, 4096):
+        x = rng.random((2, n, 3), dtype=np.float32)
+        q = (rng.random((2, 5000, 3), dtype=np.float32) * np.float32(1.2) - np.float32(0.1))
+        out = {}
+        for mode in ("all_points", "grid"):
+            ops.knn_grid_mode(mode)
+            try:
+                out[mode] = ops.knn_point(4, _t(x), _t(q))
+            finally:
+                ops.knn_grid_mode("auto")
+        for a, g in zip(out["all_points"], out["grid"]):
+            assert torch.equal(a, g), n
+
+
 def test_grouping_argument_errors():
     import torch
     from geometric_adv_amd import ops
