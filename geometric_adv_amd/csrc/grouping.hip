@@ -27,17 +27,29 @@ __device__ __forceinline__ void wave_selection_sort(float *val, int *idx, int n,
         // => lexicographic min of (value, position)
         float bv = INFINITY;
         int bp = 0x7fffffff;
-        for (int t = s + lane; t < n; t += 64) {
-            const float v = val[t];
-            if (v < bv) { bv = v; bp = t; }     // per lane ascending t: first min kept
+        {   // four independent streams per lane (a single chain pays the LDS latency once per entry: 32 times per pass at n = 2048),
+            // merged lexicographically -- the minimum of (value, position) does not depend on the order it is taken in
+            float sv[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            int sq[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+            int t = s + lane;
+            for (; t + 3 * 64 < n; t += 4 * 64) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = val[t + 64 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (v[u] < sv[u]) { sv[u] = v[u]; sq[u] = t + 64 * u; }     // ascending positions within a stream: first min kept
+            }
+            for (; t < n; t += 64) {
+                const float v = val[t];
+                if (v < sv[0]) { sv[0] = v; sq[0] = t; }                       // (later positions than anything stream 0 has seen)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sv[u] < bv || (sv[u] == bv && sq[u] < bp)) { bv = sv[u]; bp = sq[u]; }
         }
         // a lane whose values are all NaN / that saw nothing keeps (inf, maxint)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off);
-            const int op = __shfl_xor(bp, off);
-            if (ov < bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
-        }
+        wave_lexmin(bv, bp);                      // (DPP + readlane: six ds_bpermute round trips per pass were half of a pass)
         // (bv, bp) = the first position of [s, n) attaining the minimum, exactly what the reference's
         // scan "min = s; if (p[t] < p[min]) min = t" finds; nothing comparable (all NaN) keeps s.
         const int mn = bp == 0x7fffffff ? s : bp;
@@ -82,7 +94,20 @@ __device__ __forceinline__ void knn_row(float *val, int *idx, int n, int m, int 
     const float *data = xyz1 + (size_t)c * n * 3;
     const float *qry = xyz2 + (size_t)c * m * 3;
     const float qx = qry[3 * q], qy = qry[3 * q + 1], qz = qry[3 * q + 2];
-    for (int t = threadIdx.x; t < n; t += 64) {
+    // (eight points' loads in flight per lane: one at a time, the 32 round trips of a 2048-point row were 16 of the redo kernel's 22 us)
+    int t = threadIdx.x;
+    for (; t + 7 * 64 < n; t += 8 * 64) {
+        float px[8], py[8], pz[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { px[u] = data[3 * (t + 64 * u)]; py[u] = data[3 * (t + 64 * u) + 1]; pz[u] = data[3 * (t + 64 * u) + 2]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float dx = px[u] - qx, dy = py[u] - qy, dz = pz[u] - qz;
+            val[t + 64 * u] = (dx * dx + dy * dy) + dz * dz;
+            idx[t + 64 * u] = t + 64 * u;
+        }
+    }
+    for (; t < n; t += 64) {
         const float dx = data[3 * t] - qx, dy = data[3 * t + 1] - qy, dz = data[3 * t + 2] - qz;
         val[t] = (dx * dx + dy * dy) + dz * dz;
         idx[t] = t;
