@@ -50,6 +50,7 @@ struct FwdArgs {
     float *out;                  // a_i [R][COUT]
     float2 *psum;                // [tiles][COUT] (sum a, sum a^2) over the 64 rows of the tile
     int tiles;                   // 64-row tiles (the persistent forward kernel deals them round-robin)
+    int *zero; int zero_count;   // layer 0 only: ints to clear on the way (the pool's maxima and tie counts: a memset launch less per step)
 };
 
 __global__ __launch_bounds__(TR_THREADS) void train_fwd0_kernel(FwdArgs A) {
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(TR_THREADS) void train_fwd0_kernel(FwdArgs A) {
     __shared__ float pts[TR_ROWS * 3];
     __shared__ float2 red[8][64];
     const size_t row0 = (size_t)blockIdx.x * TR_ROWS;
+    for (int e = blockIdx.x * TR_THREADS + threadIdx.x; e < A.zero_count; e += gridDim.x * TR_THREADS) A.zero[e] = 0;
     if (threadIdx.x < TR_ROWS * 3) pts[threadIdx.x] = A.in[row0 * 3 + threadIdx.x];
     __syncthreads();
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(256) void fc0_and_pool_count_kernel(const float *z,
 }
 
 // recon[b][n] = d2[b][:] @ V2[:, n] + c2[n]; grid = (ceil(n3/64), ceil(B/16)), block 256 = 64 columns x 4 K slices
-__global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const float *V2, const float *c2, float *out, int batch, int n3) {
+__global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const float *V2, const float *c2, float *out, float *out2, int batch,
+                                                         int n3) {
     __shared__ __align__(16) float x[16][256];
     __shared__ float red[3][16][64];
     const int b0 = blockIdx.y * 16;
@@ -456,24 +459,30 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *d2, const 
     if (ks == 0 && blockIdx.x * 64 + col < n3) {
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb)
-            if (b0 + bb < batch) out[(size_t)(b0 + bb) * n3 + n] = (((acc[bb] + red[0][bb][col]) + red[1][bb][col]) + red[2][bb][col]) + c;
+            if (b0 + bb < batch) {
+                const float r = (((acc[bb] + red[0][bb][col]) + red[1][bb][col]) + red[2][bb][col]) + c;
+                out[(size_t)(b0 + bb) * n3 + n] = r;
+                if (out2) out2[(size_t)(b0 + bb) * n3 + n] = r;         // the caller's copy (a 1.2 MB device-to-device copy launch less)
+            }
     }
 }
 
 // loss 'emd': loss = inv * sum_b cost[b] (fixed order, fp64), g[e] *= inv -- block 0 also writes the loss
-__global__ __launch_bounds__(256) void emd_loss_scale_kernel(const float *cost, int batch, double inv, float *loss, float *g, size_t count) {
+__global__ __launch_bounds__(256) void emd_loss_scale_kernel(const float *cost, int batch, double inv, float *loss, float *loss2, float *g,
+                                                             size_t count) {
     const float s = (float)inv;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (size_t)gridDim.x * 256) g[e] *= s;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double acc = 0.0;
         for (int b = 0; b < batch; ++b) acc += (double)cost[b];
         *loss = (float)(acc * inv);
+        if (loss2) *loss2 = (float)(acc * inv);
     }
 }
 
 // loss = (sum dist1 + sum dist2) / (B * N): tf.reduce_mean over all elements of each direction (pointnet_ae.py:77);
 // one workgroup of 256 threads, fixed summation order
-__device__ __forceinline__ void chamfer_loss_block(const float *d1, const float *d2, size_t count, double inv, float *loss) {
+__device__ __forceinline__ void chamfer_loss_block(const float *d1, const float *d2, size_t count, double inv, float *loss, float *loss2) {
     __shared__ double red[256];
     const float4 *a = reinterpret_cast<const float4 *>(d1), *b = reinterpret_cast<const float4 *>(d2);
     const size_t q = count / 4;                               // count = B * n is a multiple of 64
@@ -498,7 +507,10 @@ __device__ __forceinline__ void chamfer_loss_block(const float *d1, const float 
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss = (float)(red[0] * inv);
+    if (threadIdx.x == 0) {
+        *loss = (float)(red[0] * inv);
+        if (loss2) *loss2 = (float)(red[0] * inv);
+    }
 }
 
 __global__ void fill_f32_kernel(float *p, float v, size_t count) {
@@ -585,7 +597,7 @@ __device__ __forceinline__ void fc_out_bwd_x_block(const float *g, const float *
 // only on the Chamfer results, not on each other.  blocks [0, nw): dV2 / dc2, [nw, nw + nx): dd2, last block: loss.
 struct DecOutBwdArgs {
     const float *d2, *g, *V2; float *dV2, *dc2, *dd2; int batch, n3;
-    const float *dist1, *dist2; size_t count; double inv; float *loss;
+    const float *dist1, *dist2; size_t count; double inv; float *loss, *loss2;
 };
 
 __global__ __launch_bounds__(256) void dec_out_bwd_kernel(DecOutBwdArgs A) {
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(256) void dec_out_bwd_kernel(DecOutBwdArgs A) {
     const int blk = blockIdx.x;
     if (blk < nw) fc_out_bwd_w_block(A.d2, A.g, A.dV2, A.dc2, A.batch, A.n3, blk % wx, blk / wx);
     else if (blk < nw + nx) fc_out_bwd_x_block(A.g, A.V2, A.d2, A.dd2, A.batch, A.n3, (blk - nw) % nxk, (blk - nw) / nxk);
-    else chamfer_loss_block(A.dist1, A.dist2, A.count, A.inv, A.loss);
+    else chamfer_loss_block(A.dist1, A.dist2, A.count, A.inv, A.loss, A.loss2);
 }
 
 // Small dense layer backward: dW[k][n] = sum_b in[b][k] * dout[b][n] (grid.x = k), db[n] = sum_b dout[b][n]
@@ -1139,6 +1151,7 @@ struct geoadv_trainer {
     float *dist1, *dist2; int *idx1, *idx2;
     float *dw_partial, *db_partial;
     float *loss;
+    float *user_loss, *user_recon;     // during geoadv_trainer_forward_backward: the caller's buffers, written by the producing kernels
     int loss_type;                     // GEOADV_TRAIN_LOSS_*
     float *emd_temp, *emd_cost;        // loss 'emd': scratch of geoadv_emd_cost_grad1, per-cloud match costs
     int world;                         // ranks sharing the batch statistics (synchronised BN); 1 = local
@@ -1234,6 +1247,7 @@ extern "C" int geoadv_trainer_create(geoadv_trainer **out, const geoadv_ae_weigh
     t->dd2 = F(o_dd2); t->dd1 = F(o_dd1); t->dz = F(o_dz);
     t->dist1 = F(o_di1); t->dist2 = F(o_di2); t->idx1 = reinterpret_cast<int *>(F(o_i1)); t->idx2 = reinterpret_cast<int *>(F(o_i2));
     t->dw_partial = F(o_dwp); t->db_partial = F(o_dbp); t->loss = F(o_loss);
+    t->user_loss = nullptr; t->user_recon = nullptr;
     t->loss_type = cfg->loss; t->emd_temp = emd ? F(o_et) : nullptr; t->emd_cost = emd ? F(o_ec) : nullptr;
     t->world = 1;
     t->xbuf = reinterpret_cast<double *>(t->arena + o_xb); t->lbuf = reinterpret_cast<double *>(t->arena + o_lb);
@@ -1283,6 +1297,7 @@ extern "C" void geoadv_trainer_destroy(geoadv_trainer *t) {
 template <int CIN, int COUT>
 static int launch_fwd(geoadv_trainer *t, int i, hipStream_t st) {
     FwdArgs a;
+    a.zero = nullptr; a.zero_count = 0;
     a.in = t->act[i - 1]; a.pscale = t->bn_scale[i - 1]; a.pshift = t->bn_shift[i - 1];
     a.W = PackedLayer{t->packed_fwd[i], CIN, COUT};
     a.bias = t->params + t->L.b[i]; a.out = t->act[i]; a.psum = t->psum;
@@ -1390,6 +1405,7 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
             a.in = x; a.pscale = a.pshift = nullptr;
             a.W = PackedLayer{t->params + t->L.w[0], 3, 64};
             a.bias = t->params + t->L.b[0]; a.out = t->act[0]; a.psum = t->psum;
+            a.zero = t->zbits; a.zero_count = 2 * B * 128;           // zbits and cnt are adjacent; nothing reads them before phase 5
             train_fwd0_kernel<<<t->tiles, TR_THREADS, 0, st>>>(a);
             GA_LAUNCH_CHECK();
         } else if (i == 1) rc = launch_fwd<64, 128>(t, 1, st);
@@ -1403,7 +1419,6 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         if (sync)
             if (int rc = launch_bn(t, 4, 2, 4, st)) return rc;
         // ---- symmetric max-pool ----
-        GA_HIP(hipMemsetAsync(t->zbits, 0, 2 * sizeof(int) * (size_t)B * 128, st));      // zbits and cnt are adjacent
         PoolArgs pa{t->act[4], t->bn_scale[4], t->bn_shift[4], n, t->zbits, t->cnt};
         train_pool_kernel<false><<<t->tiles, 256, 0, st>>>(pa);
         GA_LAUNCH_CHECK();
@@ -1412,19 +1427,19 @@ static int run_phase(geoadv_trainer *t, int phase, const float *x, const float *
         const float *V0 = t->params + t->L.v[0], *V1 = t->params + t->L.v[1], *V2 = t->params + t->L.v[2];
         fc0_and_pool_count_kernel<<<B + t->tiles, 256, 0, st>>>(z, V0, t->params + t->L.c[0], t->d1, B, pa);
         fc1_fwd_kernel<<<B, 1024, 0, st>>>(t->d1, V1, t->params + t->L.c[1], t->d2);
-        fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, B, n3);
+        fc_out_fwd_kernel<<<dim3(cdiv(n3, 64), cdiv(B, 16)), 256, 0, st>>>(t->d2, V2, t->params + t->L.c[2], t->recon, t->user_recon, B, n3);
         GA_LAUNCH_CHECK();
         DecOutBwdArgs da;
         da.inv = 1.0 / ((double)B * t->world * n);   // reduce_mean over the batch of ALL ranks (the host adds the ranks up)
-        da.loss = t->loss; da.count = (size_t)B * n;
+        da.loss = t->loss; da.loss2 = t->user_loss; da.count = (size_t)B * n;
         if (t->loss_type == GEOADV_TRAIN_LOSS_EMD) {
             // ---- approx-EMD loss (pointnet_ae.py:77-79): reduce_mean over the clouds of match_cost(recon, gt, match), and
             // d loss / d recon = match_cost_grad's grad1 / clouds with the match held constant (tf_approxmatch.py:19, 44-50).
             // The plan is never stored (geoadv_emd_cost_grad1: levels + cost + gradient fused). ----
             if (int rc = geoadv_emd_cost_grad1_mode(GEOADV_EMD_FAST, B, n, n, t->recon, gt, t->emd_cost, t->g_recon, t->emd_temp, st)) return rc;
-            emd_loss_scale_kernel<<<256, 256, 0, st>>>(t->emd_cost, B, 1.0 / ((double)B * t->world), t->loss, t->g_recon, (size_t)B * n3);
+            emd_loss_scale_kernel<<<256, 256, 0, st>>>(t->emd_cost, B, 1.0 / ((double)B * t->world), t->loss, t->user_loss, t->g_recon, (size_t)B * n3);
             GA_LAUNCH_CHECK();
-            da.count = 0; da.loss = t->loss + 1;     // (the loss block of the launch below then writes a zero beside the real loss)
+            da.count = 0; da.loss = t->loss + 1; da.loss2 = nullptr;     // (the loss block of the launch below then writes a zero beside the real loss)
         } else {
             // ---- Chamfer loss and its gradient w.r.t. the reconstruction ----
             // one distance evaluation per pair serves both directions (chamfer_sym.hip); dist/idx bit-identical to nn_distance
@@ -1480,11 +1495,12 @@ extern "C" int geoadv_trainer_forward_backward(geoadv_trainer *t, const float *x
     GA_REQUIRE(t->world == 1, "trainer_forward_backward: synchronised batch norm is on (world %d): drive the phases", t->world);
     hipStream_t st = as_stream(stream);
     if (!gt) gt = x;
-    for (int p = 0; p < TRAIN_PHASES; ++p)
-        if (int rc = run_phase(t, p, x, gt, false, st)) return rc;
-    if (loss) GA_HIP(hipMemcpyAsync(loss, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (recon) GA_HIP(hipMemcpyAsync(recon, t->recon, sizeof(float) * (size_t)t->B * t->n3, hipMemcpyDeviceToDevice, st));
-    return GEOADV_OK;
+    // the caller's loss / reconstruction are written by the kernels that produce them (two copy launches less at the end of a step)
+    t->user_loss = loss; t->user_recon = recon;
+    int rc = GEOADV_OK;
+    for (int p = 0; p < TRAIN_PHASES && rc == GEOADV_OK; ++p) rc = run_phase(t, p, x, gt, false, st);
+    t->user_loss = nullptr; t->user_recon = nullptr;
+    return rc;
 }
 
 // ---- synchronised batch norm over `world` ranks: the caller runs the phases and all-reduces the exchange slots ----
