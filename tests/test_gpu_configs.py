@@ -146,6 +146,79 @@ def test_config1_full_shape_b32_n2048(oracle, prune):
     assert np.isfinite(m.cpu().numpy()).all() and (m[:, 4] > 0).all()
 
 
+@pytest.mark.parametrize("prune", [True, False])
+def test_config1_full_length_500_iterations_thresh_400(oracle, prune):
+    """configs[1] at its own shape AND length (run_attack.py:34-35: 500 iterations, keep-best from iteration 400; B = 32,
+    N = 2048, chamfer/chamfer), once with the paired grid search and once all-pairs.  After iterations 100 / 400 / 500 -- points
+    hundreds of Adam steps away from their sources -- from the GPU's own state: all four nearest-neighbour index arrays
+    np.array_equal to the pinned oracle for all 32 clouds, the six metric rows 1e-5 relative against the fp64 model evaluated at the
+    GPU's pert, reconstruction 2e-6.  Then keep-best (adv_ae.py:234-246): get_best's metrics equal the bookkeeping of the reference
+    loop fed the GPU's own per-iteration rows (strict '<' on loss_ae over iterations 400..500), and the kept clouds are the ones
+    of the winning iteration (their Chamfer loss, recomputed by the oracle, is the kept error)."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from oracle.attack_model import AEModel, AttackModel
+    from conftest import cloud
+    b, n, iters, thresh = 32, 2048, 500, 400
+    w = W.synthetic_weights(n, seed=7)                    # bench.py's weights and seeds
+    ae = PointNetAE(w, n)
+    model = AEModel(W.canonical(w, n), n, np.float64)
+    x, gt = cloud(1002, b, n), cloud(2002, b, n)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=iters, num_iterations_thresh=thresh,
+                                          learning_rate=0.01, chamfer_prune=prune), ae=ae)
+    at.set_inputs(x, gt, None, 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    am = AttackModel(model, x, gt, None, np.ones(b))
+    hist = torch.empty((iters, 6, b), device=ae.device)
+    first = 0
+    for upto in (100, 400, 500):
+        at.run(first, upto - first, thresh, hist[first:upto])
+        first = upto
+        s = {k: v.cpu().numpy() for k, v in at.peek().items()}
+        assert np.abs(s["pert"]).max() > (0.02 if upto >= 400 else 0.005)       # the clouds did move
+        am.pert = s["pert"].astype(np.float64)
+        f = am.forward()
+        np.testing.assert_allclose(s["adv"], f["adv"], atol=1e-7)
+        np.testing.assert_allclose(s["recon"], f["recon"], atol=2e-6)
+        _, i1, _, i2 = oracle.nn_distance(s["recon"], gt)
+        assert np.array_equal(s["idx_r1"], i1) and np.array_equal(s["idx_r2"], i2), upto
+        _, i1, _, i2 = oracle.nn_distance(s["adv"], x)
+        assert np.array_equal(s["idx_a1"], i1) and np.array_equal(s["idx_a2"], i2), upto
+        h = hist[upto - 1].cpu().numpy()
+        want = [f["loss_adv"], f["loss_dist"], f["loss_pert"], f["max_dist"], f["input_dist"], f["loss_ae"]]
+        for k, wv in enumerate(want):
+            np.testing.assert_allclose(h[k], wv, rtol=1e-5, atol=1e-12, err_msg="iteration %d metric %d" % (upto, k))
+    ref = ae.get_loss_per_pc(gt)
+    m, adv, recon = at.get_best(ref)
+    at.status()
+    m, adv, recon = m.cpu().numpy(), adv.cpu().numpy(), recon.cpu().numpy()
+    h = hist.cpu().numpy()
+    assert np.isfinite(h).all()
+    # the reference's bookkeeping (adv_ae.py:197-200, 234-246) on the GPU's own rows
+    best_err = np.full(b, 1e10, np.float32)
+    best = np.zeros((b, 4), np.float32)
+    best_it = np.full(b, -1)
+    for it in range(iters):
+        if it + 1 < thresh:
+            continue
+        take = h[it, 5] < best_err
+        best_err[take] = h[it, 5][take]
+        best[take] = np.stack([h[it, 0], h[it, 1], h[it, 4], h[it, 5]], axis=1)[take]
+        best_it[take] = it
+    assert (best_it >= thresh - 1).all()
+    refv = np.asarray(ref.cpu().numpy() if hasattr(ref, "cpu") else ref, np.float32)
+    assert np.array_equal(m[:, 0], best[:, 0]) and np.array_equal(m[:, 1], best[:, 1]) and np.array_equal(m[:, 2], best[:, 2])
+    assert np.array_equal(m[:, 3], (best[:, 3] / refv).astype(np.float32)) and np.array_equal(m[:, 4], best_err)
+    # the kept clouds belong to the kept error
+    r1, _, r2, _ = oracle.nn_distance(recon, gt)
+    np.testing.assert_allclose(r1.mean(1, dtype=np.float64) + r2.mean(1, dtype=np.float64), best_err, rtol=1e-5)
+    a1, _, a2, _ = oracle.nn_distance(adv, x)
+    np.testing.assert_allclose(a1.mean(1, dtype=np.float64) + a2.mean(1, dtype=np.float64), m[:, 2], rtol=1e-5)
+    np.testing.assert_allclose(recon, model.reconstruct(adv.astype(np.float64))[0], atol=2e-6)
+
+
 def test_config3_per_gpu_shape_b128_chamfer_plus_emd(oracle):
     """configs[3] at its per-GPU shape (B = 1024 over 8 GPUs => B = 128, N = 2048, loss_adv = Chamfer + EMD/N): one step.
     Gradient vs the fp64 model (pinned C approx_match / match_cost_grad inside) on 4 sampled clouds -- the batch is a sum of
