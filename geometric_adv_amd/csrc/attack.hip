@@ -8,6 +8,7 @@
 // i.e. exactly one forward per iteration (plus one after init_pert); the observable outputs are
 // index-aligned with the reference (metrics of iteration k describe the state after k+1 updates).
 #include "ae.h"
+#include "chamfer_sym.h"
 #include "chamfer_grad.h"
 #include "chamfer_grid.h"
 #include "encoder_jac.h"
@@ -25,13 +26,6 @@ namespace geoadv {
 // ---- from the other translation units ------------------------------------------------------
 struct ChamferScan { const float *query; const float *target; float *dist; int *idx; int nq, nt; const int *need; };
 int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t stream);
-struct ChamferPair { const float *p, *q; float *dist1; int *idx1; float *dist2; int *idx2; };
-size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
-int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
-int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
-                              hipStream_t stream);
-int launch_chamfer_sym_rider(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
-                             const GridArgs *rider, const JacRider *jac, hipStream_t stream);
 int launch_encoder_jac(const DeviceAE &A, int b, const JacArgs &a, hipStream_t stream);
 int launch_encoder_bwd_dense(const DeviceAE &A, int b, const float *adv, const float *z, const int *zcnt, const float *dz,
                              const int *dense_flag, float *g_enc, hipStream_t stream);
@@ -86,6 +80,12 @@ struct LossArgs {
     float *best_metrics;              // [B][4]
     const float *adv, *recon;         // [B][n][3]
     float *best_adv, *best_recon;     // [B][n][3]
+    // the symmetric scan's row minima still in one partial per column slice (chamfer_sym.h; slices <= 1: r1 / a1 are final):
+    // r1 of every cloud, a1 of the clouds the all-pairs kernel computed (a1_all, or their `a1_need` flags).  This block forms
+    // the minima on its way in and leaves them in r1 / a1 (mutable here for that reason).
+    SymPartials part;
+    const int *a1_need; int a1_all;
+    float *r1_out, *a1_out;
 };
 
 // One pass for everything: 5 sums and 2 (max, lowest index) pairs per thread, reduced across the
@@ -133,8 +133,27 @@ __device__ __forceinline__ float wave4_sum128(float v, float *sh2) {   // sum ov
     return sh2[0] + sh2[1];
 }
 
-// cloud b of B; executed by threads 0..255 of the workgroup (whole waves beyond that may have exited)
-__device__ __forceinline__ void loss_metrics_body(const LossArgs &a, const int b, const int B) {
+constexpr int LOSS_PRE_MAX_N = 2048;           // deferred row partials exist for clouds of one row super-tile only (chamfer_sym.hip)
+
+// The symmetric scan's row partials of cloud b folded by ALL threads of the workgroup (nthreads; one pass at n = 2048 on 512)
+// into LDS -- m1 = r1, m3 = a1 (only where the all-pairs kernel computed it) -- and left in r1 / a1 for later readers; the
+// caller puts a workgroup barrier between this and loss_metrics_body, which then sums them in its own fixed order.
+__device__ __forceinline__ void loss_premerge(const LossArgs &a, const int b, const int B, const int nthreads, float *m1, float *m3) {
+    const int n = a.n;
+    const bool part3 = a.a1_all || (a.a1_need && sym_needed(a.a1_need, b));
+    const size_t sl = (size_t)a.part.slices * n, o = (size_t)b * n;
+    const float *p1 = a.part.rowpart_d + (size_t)b * sl, *p3 = a.part.rowpart_d + ((size_t)B + b) * sl;
+    for (int j = threadIdx.x; j < n; j += nthreads) {
+        const float v1 = sym_merge_min(p1 + j, a.part.slices, n);
+        const float v3 = part3 ? sym_merge_min(p3 + j, a.part.slices, n) : 0.f;
+        m1[j] = v1; a.r1_out[o + j] = v1;
+        if (part3) { m3[j] = v3; a.a1_out[o + j] = v3; }
+    }
+}
+
+// cloud b of B; executed by threads 0..255 of the workgroup (whole waves beyond that may have exited).  m1 / m3: loss_premerge's
+// LDS arrays when a.part.deferred (else unused)
+__device__ __forceinline__ void loss_metrics_body(const LossArgs &a, const int b, const int B, const float *m1 = nullptr, const float *m3 = nullptr) {
     __shared__ float shf[4][8];
     __shared__ int shi[4][2];
     __shared__ float sh2[4];
@@ -145,13 +164,17 @@ __device__ __forceinline__ void loss_metrics_body(const LossArgs &a, const int b
     r.s1 = r.s2 = r.s3 = r.s4 = r.sp = 0.f;
     r.ma = r.mp = -1.f;
     r.ja = r.jp = INT_MAX;
+    const bool part1 = a.part.deferred;                                                  // (uniform)
+    const bool part3 = part1 && (a.a1_all || (a.a1_need && sym_needed(a.a1_need, b)));
     constexpr int U = 4;                                  // points per thread and pass: all 7 * U loads requested first
     for (int j0 = t; j0 < n; j0 += U * 256) {             // (same order of accumulation as one point per pass)
         float v1[U], v2[U], v3[U], v4[U], vx[U], vy[U], vz[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * 256 < n ? j0 + u * 256 : t;
-            v1[u] = a.r1[o + j]; v2[u] = a.r2[o + j]; v3[u] = a.a1[o + j]; v4[u] = a.a2[o + j];
+            v1[u] = part1 ? m1[j] : a.r1[o + j];
+            v3[u] = part3 ? m3[j] : a.a1[o + j];
+            v2[u] = a.r2[o + j]; v4[u] = a.a2[o + j];
             vx[u] = a.pert[(o + j) * 3]; vy[u] = a.pert[(o + j) * 3 + 1]; vz[u] = a.pert[(o + j) * 3 + 2];
         }
 #pragma unroll
@@ -246,14 +269,6 @@ __global__ __launch_bounds__(256) void chamfer_per_pc_kernel(int n, int m, const
 // accumulation as chamfer.hip (tf_nndistance.cpp:130-163): own term, then scatter terms in
 // ascending index.  grid = (clouds, problems).
 // ------------------------------------------------------------------------------------------
-struct CGradProblem {
-    const float *p, *q;          // [B][n][3] own / other cloud
-    const int *idx1, *idx2;      // [B][n] own->other matches, other->own matches
-    float *g;                    // [B][n][3]
-    const float *w;              // [B] or null: upstream factor (dist_weight)
-    const int *jstar;            // [B] or null: point receiving the extra max-term
-    float extra_w;               // max_point_dist_weight (0 = none)
-};
 struct CGradArgs { CGradProblem pr[2]; int n, P; };
 constexpr int CGA_THREADS = 512;
 
@@ -299,15 +314,41 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
     const float g2 = gd * 2;
     const float *p = pr.p + (size_t)b * n * 3, *q = pr.q + (size_t)b * n * 3;
     const int *i1 = pr.idx1 + (size_t)b * n, *i2 = pr.idx2 + (size_t)b * n;
+    const bool part = pr.part_d && (!pr.part_need || sym_needed(pr.part_need, b));          // (uniform)
+    const float *pd = pr.part_d + (size_t)b * pr.part_slices * n;
+    const int *pi_ = pr.part_i + (size_t)b * pr.part_slices * n;
     const int js = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
     const int range = (n + H - 1) / H;
     const int j_lo = h * range, j_hi = min(n, j_lo + range);
+    constexpr int U = 4;
+    // row partials of the symmetric scan: this workgroup's own points' matches are folded FIRST (their loads run beside the
+    // scatter phase below) when one pass covers them (n <= 2048 on 512 threads: always, where partials exist)
+    const bool pre = part && (j_hi - j_lo) <= U * CGA_THREADS;
+    int mpre[U];
+    if (pre) {
+        int sl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j_lo + threadIdx.x + u * CGA_THREADS;
+            sl[u] = 0;
+            if (j < j_hi) (void)sym_merge_pick(pd + j, pr.part_slices, n, sl[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j_lo + threadIdx.x + u * CGA_THREADS;
+            mpre[u] = j < j_hi ? pi_[(size_t)sl[u] * n + j] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j_lo + threadIdx.x + u * CGA_THREADS;
+            if (j < j_hi) pr.idx1_out[(size_t)b * n + j] = mpre[u];
+        }
+    }
     for (int e = threadIdx.x; e < 3 * (j_hi - j_lo); e += CGA_THREADS) acc[e] = 0ull;
     __syncthreads();
     GA_STAMP(1, 1);
     // Four points per thread and pass, index loads first, then all the dependent gathers: the launch is latency-bound
     // (one workgroup per cloud, problem and part), and a loop of "load index, gather, add" pays two global round trips per point.
-    constexpr int U = 4;
     for (int k0 = threadIdx.x; k0 < n; k0 += U * CGA_THREADS) {
         int jj[U];
 #pragma unroll
@@ -335,8 +376,23 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
     GA_STAMP(1, 2);
     for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += U * CGA_THREADS) {
         int mj[U];
+        if (pre) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) mj[u] = j0 + u * CGA_THREADS < j_hi ? i1[j0 + u * CGA_THREADS] : 0;
+            for (int u = 0; u < U; ++u) mj[u] = mpre[u];
+        } else if (part) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                mj[u] = 0;
+                if (j0 + u * CGA_THREADS < j_hi) {
+                    float d_;
+                    sym_merge_slices(pd + j0 + u * CGA_THREADS, pi_ + j0 + u * CGA_THREADS, pr.part_slices, n, d_, mj[u]);
+                    pr.idx1_out[(size_t)b * n + j0 + u * CGA_THREADS] = mj[u];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) mj[u] = j0 + u * CGA_THREADS < j_hi ? i1[j0 + u * CGA_THREADS] : 0;
+        }
         float qv[U][3], pv[U][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -370,7 +426,12 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGr
 __global__ __launch_bounds__(CGA_THREADS) void loss_cgrad_kernel(LossArgs la, CGradArgs ca, int H) {
     GA_STAMP(0, 0);
     if (blockIdx.y == 0) {
-        if (threadIdx.x < 256) loss_metrics_body(la, blockIdx.x, gridDim.x);
+        __shared__ float m1[LOSS_PRE_MAX_N], m3[LOSS_PRE_MAX_N];
+        if (la.part.deferred) {                            // (uniform) all eight waves fold the row partials, four sum them
+            loss_premerge(la, blockIdx.x, gridDim.x, CGA_THREADS, m1, m3);
+            __syncthreads();
+        }
+        if (threadIdx.x < 256) loss_metrics_body(la, blockIdx.x, gridDim.x, m1, m3);
     } else {
         GA_STAMP(1, 0);
         cgrad_fx_body(ca, (blockIdx.y - 1) / H, blockIdx.x, (blockIdx.y - 1) % H, H);
@@ -627,6 +688,12 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     // two-scan kernel runs instead (small batches) there is no launch long enough to hide it in, and as a launch of its own
     // (8.2 us + the 3.6 us look for tied clouds + two boundaries) it costs what the masked backward costs (11.6 us + one): those
     // batches keep the masked backward.
+    const bool adv_chamfer = at->cfg.loss_adv_type == GEOADV_LOSS_ADV_CHAMFER;
+    const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
+    const bool max_term = dist_chamfer && at->cfg.max_point_dist_weight > 0.f;   // the gradient needs the loss pass's arg-max first
+    const bool loss_fused = (adv_chamfer || dist_chamfer) && !max_term && n <= CG_FX_MAX_N_PLANE;   // loss_cgrad_kernel below
+    const bool merge_in_loss = loss_fused && adv_chamfer && dist_chamfer;
+    SymPartials part{nullptr, nullptr, 1, B, false};
     const JacArgs jargs{n, at->masks, at->fs.crit, at->fs.z, at->fs.dense, at->jac};
     const bool jac_rides = at->jac && at->chamfer_sym;
     at->jac_valid = jac_rides;
@@ -641,14 +708,12 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
             const ChamferPair pairs[2] = {{at->recon, at->gt, at->r1, at->ir1, at->r2, at->ir2},
                                           {at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2}};
             const GridArgs rider{at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, n, need_new, need_scan, call, at->x_box};
-            if (rides_scan || jac_rides) {
-                JacRider jr;
-                jr.j = jargs; jr.A = A; jr.first_block = 0; jr.blocks = 0;
-                if (int rc = launch_chamfer_sym_rider(pairs, 2, B, n, n, at->sym_ws, pruned ? need_scan : nullptr, rides_scan ? &rider : nullptr,
-                                                      jac_rides ? &jr : nullptr, st)) return rc;
-            } else if (pruned) {
-                if (int rc = launch_chamfer_sym_needed(pairs, 2, B, n, n, at->sym_ws, need_scan, st)) return rc;
-            } else if (int rc = launch_chamfer_sym(pairs, 2, B, n, n, at->sym_ws, st)) return rc;
+            JacRider jr;
+            jr.j = jargs; jr.A = A; jr.first_block = 0; jr.blocks = 0;
+            // the row minima leave the scan as one (distance, index) partial per column slice; when the loss launch below is the
+            // fused one with both Chamfer gradients inside, it merges them on its way in (no second Chamfer launch)
+            if (int rc = launch_chamfer_sym_loop(pairs, 2, B, n, n, at->sym_ws, pruned ? need_scan : nullptr, rides_scan ? &rider : nullptr,
+                                                 jac_rides ? &jr : nullptr, merge_in_loss ? &part : nullptr, st)) return rc;
         } else {
             ChamferScan all[4] = {sc_recon[0], sc_recon[1], sc_adv[0], sc_adv[1]};
             if (pruned) all[2].need = all[3].need = need_scan;         // only the clouds the grid search handed back
@@ -670,16 +735,29 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         la.dz_latent = at->dz; la.hist = hist_slot; la.keep = keep; la.best_err = at->best_err;
         la.best_metrics = at->best_metrics; la.adv = at->adv; la.recon = at->recon;
         la.best_adv = at->best_adv; la.best_recon = at->best_recon;
+        la.part = part; la.a1_need = pruned ? need_scan : nullptr; la.a1_all = pruned ? 0 : 1; la.r1_out = at->r1; la.a1_out = at->a1;
         // the Chamfer gradients the next step starts with ride in the same launch (see loss_cgrad_kernel)
-        const bool adv_chamfer = at->cfg.loss_adv_type == GEOADV_LOSS_ADV_CHAMFER;
-        const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
-        const bool max_term = dist_chamfer && at->cfg.max_point_dist_weight > 0.f;   // needs this pass's arg-max first
         CGradArgs ca;
         int np = 0;
-        if (adv_chamfer) ca.pr[np++] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
-        if (dist_chamfer) ca.pr[np++] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, 0.f};
+        if (adv_chamfer) {
+            ca.pr[np] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
+            if (part.deferred) {
+                ca.pr[np].part_d = part.rowpart_d; ca.pr[np].part_i = part.rowpart_i; ca.pr[np].part_slices = part.slices;
+                ca.pr[np].part_need = nullptr; ca.pr[np].idx1_out = at->ir1;
+            }
+            ++np;
+        }
+        if (dist_chamfer) {
+            ca.pr[np] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, 0.f};
+            if (part.deferred) {                          // pair 1's partials follow pair 0's B clouds
+                const size_t off = (size_t)B * part.slices * n;
+                ca.pr[np].part_d = part.rowpart_d + off; ca.pr[np].part_i = part.rowpart_i + off; ca.pr[np].part_slices = part.slices;
+                ca.pr[np].part_need = pruned ? need_scan : nullptr; ca.pr[np].idx1_out = at->ia1;
+            }
+            ++np;
+        }
         at->cgrad_done = false;
-        if (np && !max_term && n <= CG_FX_MAX_N_PLANE) {
+        if (loss_fused) {
             ca.n = n; ca.P = 0;
             const int H = cgrad_fx_parts(n);
             loss_cgrad_kernel<<<dim3(B, 1 + np * H), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(la, ca, H);

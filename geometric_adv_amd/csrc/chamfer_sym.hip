@@ -5,21 +5,27 @@
 // scans of the reference op produce (tf_nndistance.cpp:79-80).  Still brute force -- all n*m distances are
 // evaluated, none is skipped -- but 8 VALU ops per pair are now spent once instead of twice.
 //
-// Kernel 1 (chamfer_sym_kernel): as chamfer_scan_kernel, a workgroup of 4 waves owns 64*R rows (P points,
-// R per lane, in registers); wave w scans the w-th quarter of the columns (Q points, LDS-staged SoA planes,
-// broadcast reads).  Row minima: running min per chunk of 8 columns + re-scan of the winning chunk, as
-// before.  Column minima: every lane reduces its R rows in registers (v_min3), then the 64 lanes of the
-// wave are reduced through a 4 KB LDS transpose per 16 columns (16 ds_write_b32 + 4 ds_read_b128 per lane:
-// ~8 % on top of the distance arithmetic; a DPP butterfly per column would cost 19 %).
-// Each column is visited by exactly one wave of the workgroup, so the reduced value IS the column's
-// minimum over this row tile; the four partial minima it is folded from (one per 16 lanes = 64 rows) go to
-// colpart[tile][k][0..3].
-// Kernel 2 (chamfer_sym_finish_kernel): per column, minimum over the (tile, quarter) partials and the LOWEST tile
-// attaining it; then only the 64 rows of that tile's winning quarter are re-evaluated to find the lowest row index
-// with d == minimum (exactly the reference's tie rule): 1/32 of a scan at n = 2048.
+// Round 5 layout: a workgroup owns a SLICE OF COLUMNS (Q points, <= 256, LDS-staged SoA planes, broadcast reads) against
+// up to 2048 ROWS (P points): each of its 8 waves keeps its own 256 rows in registers (4 per lane) and walks the whole
+// slice.  Every column's minimum over those rows is therefore complete INSIDE the workgroup:
+//   * per round of 16 columns the 64 lanes of a wave are reduced through a 4 KB LDS transpose (16 ds_write_b32 + 4
+//     ds_read_b128 per lane: ~8 % on top of the distance arithmetic) to four quarter minima per column (rows 64 r + 16 q + i
+//     of the wave's 256), which stay in LDS (one ds_write_b32 per lane and round) -- until round 4 they went to HBM, 16 x the
+//     op's algorithmic bytes, and came back in a second launch;
+//   * after the scan the workgroup itself finds, per column, the minimum over its (wave, quarter) entries, the LOWEST
+//     wave attaining it, and re-evaluates only the 64 rows of that wave's winning quarter for the lowest row with
+//     d == minimum (exactly the reference's tie rule): 1/32 of the scan, two threads per column, rows out of LDS.
+//     dist2 / idx2 leave the kernel final (clouds of more than 2048 rows: one (d, i) partial per 2048-row super-tile).
+// Row minima: running min per chunk of 8 columns + a re-scan of the winning chunk, as before; a wave's rows meet only
+// the workgroup's slice, so every (slice, row) leaves as a (distance, index) partial -- 8 B per row and slice instead
+// of 16 B per column and row tile -- and the lexicographic minimum over the slices is taken by whoever reads them next:
+// chamfer_sym_merge_kernel (the operator form), or the attack loop's loss / gradient launch on its way in
+// (attack.hip: no second Chamfer launch in the iteration at all).
+// Clouds of <= 1024 rows put several waves on the same rows (rw row-waves x cw column-waves = 8).
 #include "common.h"
 #include "chamfer_grid.h"
 #include "encoder_jac.h"
+#include "chamfer_sym.h"
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -28,39 +34,33 @@
 
 namespace geoadv {
 
-struct ChamferPair {
-    const float *p, *q;        // [b][n][3] rows, [b][m][3] columns
-    float *dist1; int *idx1;   // [b][n]  row minima  (nn_distance outputs 0,1)
-    float *dist2; int *idx2;   // [b][m]  column minima (outputs 2,3)
-};
 struct ChamferSymArgs {
     ChamferPair pr[2];
-    int n, m, tiles, clouds, pairs, csplit;
-    int fin_reps;              // finish kernel: column sub-slices of CF_COLS a workgroup walks after staging the row cloud once
+    int n, m, clouds, pairs;
+    int rw, cw;                // row-waves x column-waves of a workgroup (rw * cw == 8)
+    int rtiles;                // row super-tiles of 256 * rw rows
+    int C, cslices;            // columns per workgroup (multiple of 16), column slices = cdiv(m, C)
     int pair_base, q_clouds;   // q_clouds > 0: cloud c is the pair (P cloud (pair_base+c)/q_clouds, Q cloud (pair_base+c)%q_clouds)
-    float *colpart;            // [pairs][clouds][tiles][m][4]: minima over the four 64-row quarters of a tile (rows 64 r + 16 q + i)
-    float *rowpart_d;          // [pairs][clouds][csplit][n]   row minima per column slice
+    float *rowpart_d;          // [pairs][clouds][cslices * cw][n]  row minima per column slice (absent when there is one slice)
     int *rowpart_i;
+    float *colpart_d;          // [pairs][clouds][rtiles][m]        column minima per row super-tile (rtiles > 1 only)
+    int *colpart_i;
     const int *need[2];        // per pair: null = every cloud; else int[8 * clouds], cloud c is computed only if one of
                                // its 8 flags is set (a workgroup of the paired grid search, chamfer_grid.hip, gave up)
     GridRider rider;           // the attack loop: the paired grid search of (adv, source) as extra workgroups of the scan launch
     JacRider jac;              // ... and the encoder's pool Jacobian (encoder_jac.h): needed by the NEXT step's backward only
 };
 
-__device__ __forceinline__ bool sym_needed(const int *need, int c) {
-    if (!need) return true;
-    const int4 lo = reinterpret_cast<const int4 *>(need)[2 * c], hi = reinterpret_cast<const int4 *>(need)[2 * c + 1];
-    return (lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0;
-}
-
-constexpr int CS_THREADS = 512;               // 8 waves share one row tile and split the columns 8 ways
+constexpr int CS_THREADS = 512;               // 8 waves
 constexpr int CS_WAVES = 8;
-constexpr int CS_R = 4;                      // rows per lane
-constexpr int CS_ROWS = kWave * CS_R;        // 256 rows per workgroup
-constexpr int CS_CHUNK = 8;                  // columns per arg-min chunk
-constexpr int CS_ROUND = 16;                 // columns per transpose round
-constexpr int CS_STAGE = 2048;               // columns per LDS stage
-constexpr int CS_TSTRIDE = 68;               // floats per column in the transpose buffer (64 lanes + pad)
+constexpr int CS_R = 4;                       // rows per lane
+constexpr int CS_WROWS = kWave * CS_R;        // 256 rows per wave
+constexpr int CS_CHUNK = 8;                   // columns per arg-min chunk
+constexpr int CS_ROUND = 16;                  // columns per transpose round
+constexpr int CS_CMAX = 256;                  // columns per workgroup at most
+constexpr int CS_CMIN = 64;
+constexpr int CS_TSTRIDE = 68;                // floats per column in the transpose buffer (64 lanes + pad)
+constexpr int CS_SEG = CS_WROWS + 4;          // floats per wave segment of the rows staged for the index search: 16-B aligned, staggers the banks
 
 __device__ __forceinline__ float sqdist_s(float tx, float ty, float tz, float qx, float qy, float qz) {
     const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
@@ -68,7 +68,32 @@ __device__ __forceinline__ float sqdist_s(float tx, float ty, float tz, float qx
     return (xx + yy) + zz;
 }
 
-constexpr size_t CS_LDS_BYTES = sizeof(float) * (3 * CS_STAGE + CS_WAVES * CS_ROUND * CS_TSTRIDE);   // stage planes + transpose buffers
+// stage planes | quarter minima [8 waves][CS_CMAX][4] | transpose buffers (later: the workgroup's rows, three planes of 8 segments)
+constexpr size_t CS_LDS_FLOATS = 3 * CS_CMAX + 4 * CS_WAVES * CS_CMAX + CS_WAVES * CS_ROUND * CS_TSTRIDE;
+constexpr size_t CS_LDS_BYTES = sizeof(float) * CS_LDS_FLOATS;
+static_assert(3 * CS_WAVES * CS_SEG <= CS_WAVES * CS_ROUND * CS_TSTRIDE, "the staged rows reuse the transpose buffers");
+
+// lowest row among {64 r + 16 q + i : r in {2 h, 2 h + 1}} of the wave segment staged at (sx, sy, sz) whose distance to the
+// column equals v, or INT_MAX
+__device__ __forceinline__ int sym_find_half(const float *sx, const float *sy, const float *sz, int q, int h, float qx, float qy, float qz, float v) {
+    int found = INT_MAX;
+#pragma unroll
+    for (int rr = 1; rr >= 0; --rr)                       // descending: the last hit kept is the lowest row
+#pragma unroll
+        for (int j4 = 3; j4 >= 0; --j4) {
+            const int o = 64 * (2 * h + rr) + 16 * q + 4 * j4;
+            const float4 xa = *reinterpret_cast<const float4 *>(sx + o);
+            const float4 ya = *reinterpret_cast<const float4 *>(sy + o);
+            const float4 za = *reinterpret_cast<const float4 *>(sz + o);
+            const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
+            const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
+            found = d3 == v ? o + 3 : found;
+            found = d2 == v ? o + 2 : found;
+            found = d1 == v ? o + 1 : found;
+            found = d0 == v ? o : found;
+        }
+    return found;
+}
 
 __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymArgs a) {
     constexpr int R = CS_R;
@@ -78,33 +103,28 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     GA_STAMP(0, 0);
     const int lin = blockIdx.x - a.rider.blocks;           // (the search's workgroups come first); XCD-aware mapping, see chamfer_scan_kernel
     const int xcd = lin & 7, slot = lin >> 3;
-    const int per = a.tiles * a.csplit;                    // workgroups per (pair, cloud) group
+    const int per = a.rtiles * a.cslices;                  // workgroups per (pair, cloud) group
     const int group = (slot / per) * 8 + xcd, sub = slot % per;
     if (group >= a.clouds * a.pairs) return;
-    const int tile = sub % a.tiles, cs = sub / a.tiles;    // row tile, column slice
+    const int rt = sub % a.rtiles, cs = sub / a.rtiles;    // row super-tile, column slice
     const int pi = group / a.clouds, c = group % a.clouds;
     if (!sym_needed(a.need[pi], c)) return;
     const ChamferPair pr = a.pr[pi];
     const int n = a.n, m = a.m;
-    const int q0 = tile * CS_ROWS;
-    // this workgroup's columns: [mbeg, mend), slices aligned to the transpose round
-    const int mround = (m + CS_ROUND - 1) / CS_ROUND;
-    const int mbeg = min(m, (mround * cs / a.csplit) * CS_ROUND), mend = min(m, (mround * (cs + 1) / a.csplit) * CS_ROUND);
     const int cp = a.q_clouds > 0 ? (a.pair_base + c) / a.q_clouds : c;
     const int cq = a.q_clouds > 0 ? (a.pair_base + c) % a.q_clouds : c;
     const float *P = pr.p + (size_t)cp * n * 3;
     const float *Q = pr.q + (size_t)cq * m * 3;
-    float *colpart = a.colpart + (((size_t)pi * a.clouds + c) * a.tiles + tile) * m * 4;      // [m][4 quarters]
 
     // all of it in the DYNAMIC region (CS_LDS_BYTES, or a rider's need if larger): a launch that hosts the grid search's
     // workgroups is charged max(scan, search) of LDS per workgroup, not the sum
-    float (*tbuf)[CS_ROUND * CS_TSTRIDE] = reinterpret_cast<float (*)[CS_ROUND * CS_TSTRIDE]>(stage + 3 * CS_STAGE);
-    float *sx = stage, *sy = stage + CS_STAGE, *sz = stage + 2 * CS_STAGE;
-    static_assert(2 * CS_WAVES * CS_ROWS <= 3 * CS_STAGE, "merge arrays must fit in the stage buffer");
-    float (*mdist)[CS_ROWS] = reinterpret_cast<float (*)[CS_ROWS]>(stage);
-    int (*midx)[CS_ROWS] = reinterpret_cast<int (*)[CS_ROWS]>(stage + CS_WAVES * CS_ROWS);
+    float *sx = stage, *sy = stage + CS_CMAX, *sz = stage + 2 * CS_CMAX;
+    unsigned *colq = reinterpret_cast<unsigned *>(stage + 3 * CS_CMAX);                   // [rw][CS_CMAX][4]
+    float *tbase = stage + 3 * CS_CMAX + 4 * CS_WAVES * CS_CMAX;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rwi = wave % a.rw, cwi = wave / a.rw;        // this wave's row block inside the workgroup, its share of the slice
+    const int q0 = (rt * a.rw + rwi) * CS_WROWS;
     float px[R], py[R], pz[R], best[R];
     int bestk[R];
 #pragma unroll
@@ -114,322 +134,257 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
         px[r] = P[3 * j]; py[r] = P[3 * j + 1]; pz[r] = P[3 * j + 2];   // so the column minima are unaffected
         best[r] = INFINITY; bestk[r] = -1;
     }
-    float *tb = tbuf[wave];
-    for (int t0 = mbeg; t0 < mend; t0 += CS_STAGE) {
-        const int cnt = min(CS_STAGE, mend - t0);
-        const int cntp = (cnt + CS_ROUND - 1) / CS_ROUND * CS_ROUND;
-        __syncthreads();
-        for (int e = threadIdx.x; e < cntp; e += CS_THREADS) {
-            float x = INFINITY, y = INFINITY, z = INFINITY;
-            if (e < cnt) { x = Q[3 * (size_t)(t0 + e)]; y = Q[3 * (size_t)(t0 + e) + 1]; z = Q[3 * (size_t)(t0 + e) + 2]; }
-            sx[e] = x; sy[e] = y; sz[e] = z;
-        }
-        __syncthreads();
-        const int nrounds = cntp / CS_ROUND;
-        const int rbeg = nrounds * wave / CS_WAVES, rend = nrounds * (wave + 1) / CS_WAVES;
-        if (rbeg < rend) {
+    const int cbeg = cs * a.C, cnt = min(a.C, m - cbeg);
+    const int cntp = (cnt + CS_ROUND - 1) / CS_ROUND * CS_ROUND;
+    for (int e = threadIdx.x; e < cntp; e += CS_THREADS) {
+        float x = INFINITY, y = INFINITY, z = INFINITY;
+        if (e < cnt) { x = Q[3 * (size_t)(cbeg + e)]; y = Q[3 * (size_t)(cbeg + e) + 1]; z = Q[3 * (size_t)(cbeg + e) + 2]; }
+        sx[e] = x; sy[e] = y; sz[e] = z;
+    }
+    __syncthreads();
+    float *tb = tbase + wave * (CS_ROUND * CS_TSTRIDE);
+    unsigned *cq4 = colq + (size_t)rwi * CS_CMAX * 4;
+    const int nrounds = cntp / CS_ROUND;
+    const int rbeg = nrounds * cwi / a.cw, rend = nrounds * (cwi + 1) / a.cw;
+    if (rbeg < rend) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (bestk[r] < 0) bestk[r] = t0 + rbeg * CS_ROUND;
-        }
-        for (int rd = rbeg; rd < rend; ++rd) {
-            const int k0 = rd * CS_ROUND;
-            float colp[CS_ROUND];
+        for (int r = 0; r < R; ++r) bestk[r] = rbeg * CS_ROUND;
+    }
+    for (int rd = rbeg; rd < rend; ++rd) {
+        const int k0 = rd * CS_ROUND;
+        float colp[CS_ROUND];
 #pragma unroll
-            for (int hf = 0; hf < CS_ROUND / CS_CHUNK; ++hf) {
-                float tx[CS_CHUNK], ty[CS_CHUNK], tz[CS_CHUNK];
+        for (int hf = 0; hf < CS_ROUND / CS_CHUNK; ++hf) {
+            float tx[CS_CHUNK], ty[CS_CHUNK], tz[CS_CHUNK];
 #pragma unroll
-                for (int v = 0; v < CS_CHUNK / 4; ++v) {
-                    const float4 xa = *reinterpret_cast<const float4 *>(&sx[k0 + hf * CS_CHUNK + 4 * v]);
-                    const float4 ya = *reinterpret_cast<const float4 *>(&sy[k0 + hf * CS_CHUNK + 4 * v]);
-                    const float4 za = *reinterpret_cast<const float4 *>(&sz[k0 + hf * CS_CHUNK + 4 * v]);
-                    tx[4 * v] = xa.x; tx[4 * v + 1] = xa.y; tx[4 * v + 2] = xa.z; tx[4 * v + 3] = xa.w;
-                    ty[4 * v] = ya.x; ty[4 * v + 1] = ya.y; ty[4 * v + 2] = ya.z; ty[4 * v + 3] = ya.w;
-                    tz[4 * v] = za.x; tz[4 * v + 1] = za.y; tz[4 * v + 2] = za.z; tz[4 * v + 3] = za.w;
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float cm = INFINITY;
-#pragma unroll
-                    for (int u = 0; u < CS_CHUNK; ++u) {
-                        const float d = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]);
-                        cm = fminf(cm, d);
-                        colp[hf * CS_CHUNK + u] = r == 0 ? d : fminf(colp[hf * CS_CHUNK + u], d);
-                    }
-                    if (cm < best[r]) { best[r] = cm; bestk[r] = t0 + k0 + hf * CS_CHUNK; }
-                    // one row's eight distances die here: left alone the scheduler evaluates all 64 of the round first and
-                    // folds the minima afterwards -- 54 VGPRs of live distances at the 128-register cap, spills around the
-                    // loop (measured 32.5 -> 31.2 us).  (Fetching the next half's columns ahead on top of this spills 36
-                    // registers: 56 us.)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int v = 0; v < CS_CHUNK / 4; ++v) {
+                const float4 xa = *reinterpret_cast<const float4 *>(&sx[k0 + hf * CS_CHUNK + 4 * v]);
+                const float4 ya = *reinterpret_cast<const float4 *>(&sy[k0 + hf * CS_CHUNK + 4 * v]);
+                const float4 za = *reinterpret_cast<const float4 *>(&sz[k0 + hf * CS_CHUNK + 4 * v]);
+                tx[4 * v] = xa.x; tx[4 * v + 1] = xa.y; tx[4 * v + 2] = xa.z; tx[4 * v + 3] = xa.w;
+                ty[4 * v] = ya.x; ty[4 * v + 1] = ya.y; ty[4 * v + 2] = ya.z; ty[4 * v + 3] = ya.w;
+                tz[4 * v] = za.x; tz[4 * v + 1] = za.y; tz[4 * v + 2] = za.z; tz[4 * v + 3] = za.w;
             }
-            // 64-lane reduction of the 16 column partials through LDS: [column][lane] -> 4 lanes per column
 #pragma unroll
-            for (int u = 0; u < CS_ROUND; ++u) tb[u * CS_TSTRIDE + lane] = colp[u];
-            __builtin_amdgcn_wave_barrier();
-            {
-                const int col = lane >> 2, quarter = lane & 3;
-                // squared distances are >= +0 (or +inf): their order as floats is their order as unsigned integers, and an
-                // integer minimum needs no canonicalising v_max in front of every value that comes back from LDS
-                const uint4 *src = reinterpret_cast<const uint4 *>(tb + col * CS_TSTRIDE + quarter * 16);
-                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                unsigned mb = min(min(min(v0.x, v0.y), min(v0.z, v0.w)), min(min(v1.x, v1.y), min(v1.z, v1.w)));
-                mb = min(mb, min(min(min(v2.x, v2.y), min(v2.z, v2.w)), min(min(v3.x, v3.y), min(v3.z, v3.w))));
-                // lane (col, quarter) now holds the minimum over lanes 16 quarter .. 16 quarter + 15, i.e. over the rows
-                // {64 r + 16 quarter + i} of this tile: all four quarter minima are kept (one coalesced 256-byte store per
-                // round) -- the finish kernel then re-evaluates 64 rows per column instead of 256
-                const int k = t0 + k0 + col;
-                if (k < mend) colpart[(size_t)k * 4 + quarter] = __uint_as_float(mb);
+            for (int r = 0; r < R; ++r) {
+                float cm = INFINITY;
+#pragma unroll
+                for (int u = 0; u < CS_CHUNK; ++u) {
+                    const float d = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]);
+                    cm = fminf(cm, d);
+                    colp[hf * CS_CHUNK + u] = r == 0 ? d : fminf(colp[hf * CS_CHUNK + u], d);
+                }
+                if (cm < best[r]) { best[r] = cm; bestk[r] = k0 + hf * CS_CHUNK; }
+                // one row's eight distances die here: left alone the scheduler evaluates all 64 of the round first and
+                // folds the minima afterwards -- 54 VGPRs of live distances at the 128-register cap, spills around the
+                // loop (measured 32.5 -> 31.2 us).  (Fetching the next half's columns ahead on top of this spills 36
+                // registers: 56 us.)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_wave_barrier();              // the buffer is rewritten by the next round
         }
+        // 64-lane reduction of the 16 column partials through LDS: [column][lane] -> 4 lanes per column
+#pragma unroll
+        for (int u = 0; u < CS_ROUND; ++u) tb[u * CS_TSTRIDE + lane] = colp[u];
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int col = lane >> 2, quarter = lane & 3;
+            // squared distances are >= +0 (or +inf): their order as floats is their order as unsigned integers, and an
+            // integer minimum needs no canonicalising v_max in front of every value that comes back from LDS
+            const uint4 *src = reinterpret_cast<const uint4 *>(tb + col * CS_TSTRIDE + quarter * 16);
+            const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+            unsigned mb = min(min(min(v0.x, v0.y), min(v0.z, v0.w)), min(min(v1.x, v1.y), min(v1.z, v1.w)));
+            mb = min(mb, min(min(min(v2.x, v2.y), min(v2.z, v2.w)), min(min(v3.x, v3.y), min(v3.z, v3.w))));
+            // lane (col, quarter) now holds the minimum over lanes 16 quarter .. 16 quarter + 15, i.e. over the rows
+            // {64 r + 16 quarter + i} of this wave: kept in LDS (consecutive lanes, consecutive words) for the index search below
+            cq4[(k0 + col) * 4 + quarter] = mb;
+        }
+        __builtin_amdgcn_wave_barrier();              // the buffer is rewritten by the next round
     }
     GA_STAMP(0, 1);
-    // row minima: first index attaining the minimum inside the winning chunk, then merge the waves.  With a single LDS
-    // stage (m <= 2048 per slice: the attack's shape) the chunk is still in the stage buffer; otherwise it is re-read from
-    // global memory.  The stage buffer becomes the merge arrays afterwards, hence the barrier between the two loops.
-    const bool staged = mend - mbeg <= CS_STAGE;            // uniform
-    int found[R];
-    if (staged) {
-        // branch-free: the chunk's eight columns come back as two ds_read_b128 per plane (chunks start at multiples of 8
-        // inside the stage; columns beyond the slice are staged as +inf and can never equal a finite minimum), and the
-        // hits are taken in DESCENDING order so that the last one kept is the lowest index -- a sixth of the
-        // instructions of the generic loop below, which every wave used to run for its four rows
+    // row minima: first index attaining the minimum inside the winning chunk -- branch-free: the chunk's eight columns come
+    // back as two ds_read_b128 per plane (chunks start at multiples of 8 inside the stage; columns beyond the slice are
+    // staged as +inf and can never equal a finite minimum), and the hits are taken in DESCENDING order so that the last one
+    // kept is the lowest index
+    const int rslices = a.cslices * a.cw;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            found[r] = INT_MAX;
-            if (bestk[r] < 0) continue;                   // (uniform: a wave either scanned columns or did not)
-            const int kb = bestk[r] - mbeg;
+    for (int r = 0; r < R; ++r) {
+        int f = INT_MAX;
+        if (bestk[r] >= 0) {                               // (uniform: a wave either scanned columns or did not)
+            const int kb = bestk[r];
             const float4 xa = *reinterpret_cast<const float4 *>(&sx[kb]), xb = *reinterpret_cast<const float4 *>(&sx[kb + 4]);
             const float4 ya = *reinterpret_cast<const float4 *>(&sy[kb]), yb = *reinterpret_cast<const float4 *>(&sy[kb + 4]);
             const float4 za = *reinterpret_cast<const float4 *>(&sz[kb]), zb = *reinterpret_cast<const float4 *>(&sz[kb + 4]);
             const float tx[CS_CHUNK] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
             const float ty[CS_CHUNK] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
             const float tz[CS_CHUNK] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
-            int f = bestk[r];
+            f = kb;
 #pragma unroll
             for (int u = CS_CHUNK - 1; u >= 0; --u)
-                f = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]) == best[r] ? bestk[r] + u : f;
-            found[r] = f;
+                f = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]) == best[r] ? kb + u : f;
+            f += cbeg;
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            found[r] = INT_MAX;
-            if (bestk[r] >= 0) {
-                found[r] = bestk[r];
-                bool hit = false;
-                for (int u = 0; u < CS_CHUNK; ++u) {
-                    const int k = bestk[r] + u;
-                    if (k < mend) {
-                        const float d = sqdist_s(Q[3 * (size_t)k], Q[3 * (size_t)k + 1], Q[3 * (size_t)k + 2], px[r], py[r], pz[r]);
-                        if (!hit && d == best[r]) { hit = true; found[r] = k; }
-                    }
-                }
+        const int j = q0 + r * kWave + lane;
+        if (j < n) {
+            if (rslices == 1) {
+                pr.dist1[(size_t)c * n + j] = best[r];
+                pr.idx1[(size_t)c * n + j] = f;
+            } else {   // lexicographic (distance, index) minimum over the slices: chamfer_sym_merge_kernel or the loop's loss launch
+                const size_t o = (((size_t)pi * a.clouds + c) * rslices + (cs * a.cw + cwi)) * n + j;
+                a.rowpart_d[o] = best[r];
+                a.rowpart_i[o] = f;
             }
         }
     }
-    __syncthreads();
+    __syncthreads();                                       // quarter minima complete; the transpose buffers are free
+    // the workgroup's rows into LDS, one padded segment per row-wave
+    float *rx = tbase, *ry = tbase + CS_WAVES * CS_SEG, *rz = tbase + 2 * CS_WAVES * CS_SEG;
+    if (cwi == 0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        mdist[wave][r * kWave + lane] = best[r];
-        midx[wave][r * kWave + lane] = found[r];
+        for (int r = 0; r < R; ++r) {
+            rx[rwi * CS_SEG + r * kWave + lane] = px[r];
+            ry[rwi * CS_SEG + r * kWave + lane] = py[r];
+            rz[rwi * CS_SEG + r * kWave + lane] = pz[r];
+        }
     }
     __syncthreads();
-    for (int qq = threadIdx.x; qq < CS_ROWS; qq += CS_THREADS) {
-        float d = mdist[0][qq];
-        int k = midx[0][qq];
+    GA_STAMP(0, 2);
+    // column minima: two threads per column.  Minimum over the (wave, quarter) entries and the LOWEST wave attaining it
+    // (strict compare); several quarters of that wave attaining it (exact ties between rows 16 apart or more) are rare:
+    // those columns walk their further quarters in a loop the other lanes sit out.
+    {
+        const int col = threadIdx.x >> 1, h = threadIdx.x & 1;
+        const int cc = col < cnt ? col : 0;
+        const float4 *cq = reinterpret_cast<const float4 *>(colq);
+        float4 cpv[CS_WAVES];                                // (all eight reads in flight; absent row-waves repeat wave 0)
+#pragma unroll
+        for (int w = 0; w < CS_WAVES; ++w) cpv[w] = cq[(w < a.rw ? w : 0) * CS_CMAX + cc];
+        float4 win = cpv[0];
+        float v = fminf(fminf(win.x, win.y), fminf(win.z, win.w));
+        int bt = 0;
 #pragma unroll
         for (int w = 1; w < CS_WAVES; ++w) {
-            const float dw = mdist[w][qq];
-            const int kw = midx[w][qq];
-            if (dw < d || (dw == d && kw < k)) { d = dw; k = kw; }
+            const float tv = fminf(fminf(cpv[w].x, cpv[w].y), fminf(cpv[w].z, cpv[w].w));
+            if (w < a.rw && tv < v) { v = tv; bt = w; win = cpv[w]; }
         }
-        if (q0 + qq < n) {
-            if (a.csplit == 1) {
-                pr.dist1[(size_t)c * n + q0 + qq] = d;
-                pr.idx1[(size_t)c * n + q0 + qq] = k;
-            } else {   // merged over the column slices by the finish kernel
-                const size_t o = (((size_t)pi * a.clouds + c) * a.csplit + cs) * n + q0 + qq;
-                a.rowpart_d[o] = d;
-                a.rowpart_i[o] = k;
+        const float qx = sx[cc], qy = sy[cc], qz = sz[cc];
+        const float *wx = rx + bt * CS_SEG, *wy = ry + bt * CS_SEG, *wz = rz + bt * CS_SEG;
+        const float qv[4] = {win.x, win.y, win.z, win.w};
+        int q1 = 3;                                           // lowest quarter attaining the minimum
+#pragma unroll
+        for (int q = 2; q >= 0; --q) q1 = qv[q] == v ? q : q1;
+        int found = sym_find_half(wx, wy, wz, q1, h, qx, qy, qz, v);
+        for (int q = q1 + 1; q < 4; ++q)                      // exact ties across quarters: rare
+            if (qv[q] == v) found = min(found, sym_find_half(wx, wy, wz, q, h, qx, qy, qz, v));
+        found = min(found, __builtin_amdgcn_update_dpp(INT_MAX, found, 0xB1, 0xf, 0xf, false));   // the pair's other half (quad_perm [1,0,3,2])
+        if (found == INT_MAX) found = 0;                      // only if v is NaN-tainted (out of contract)
+        if (col < cnt) {
+            const int k = cbeg + col;
+            const int row = (rt * a.rw + bt) * CS_WROWS + found;
+            if (a.rtiles == 1) {
+                if (h == 0) pr.dist2[(size_t)c * m + k] = v; else pr.idx2[(size_t)c * m + k] = row;
+            } else {
+                const size_t o = (((size_t)pi * a.clouds + c) * a.rtiles + rt) * m + k;
+                if (h == 0) a.colpart_d[o] = v; else a.colpart_i[o] = row;
             }
         }
     }
     GA_STAMP(0, 7);
 }
 
-// grid = (column slices, clouds * pairs).  Every workgroup takes an equal slice of COLUMNS (so the work is
-// balanced even when all column minima fall into one row tile, which is what a collapsed reconstruction
-// produces) and keeps the whole row cloud in LDS as SoA planes, one padded segment per row tile.  Thread =
-// one column: minimum over the (tile, quarter) partials + the lowest tile attaining it, then the 64 rows of that
-// tile's winning quarter are re-evaluated for the lowest one with d == minimum (exactly the reference's tie rule).
-// Several quarters of the tile attaining the minimum (exact ties between rows 16 apart or more) are rare: those
-// columns walk their further quarters in a loop the other lanes sit out.
-constexpr int CF_COLS = 512;                          // columns = threads per workgroup (measured: 128: 10.0, 256: 8.0, 512: 6.9, 1024: 8.9 us at B = 32, N = 2048 -- staging the rows per workgroup against workgroups per chip)
-constexpr int CF_THREADS = CF_COLS;
-constexpr int CF_SEG = CS_ROWS + 4;                   // floats per tile segment: 16-B aligned, and the pad staggers the banks
-
-// lowest row of quarter q (rows 64 r + 16 q + i) of the tile staged at (sx, sy, sz) whose distance to the column equals v
-__device__ __forceinline__ int finish_quarter(const float *sx, const float *sy, const float *sz, int q, float qx, float qy, float qz, float v) {
-    int found = INT_MAX;
-#pragma unroll
-    for (int r = CS_R - 1; r >= 0; --r)                   // descending: the last hit kept is the lowest row
-#pragma unroll
-        for (int j4 = 3; j4 >= 0; --j4) {
-            const int o = 64 * r + 16 * q + 4 * j4;
-            const float4 xa = *reinterpret_cast<const float4 *>(sx + o);
-            const float4 ya = *reinterpret_cast<const float4 *>(sy + o);
-            const float4 za = *reinterpret_cast<const float4 *>(sz + o);
-            const float d3 = sqdist_s(qx, qy, qz, xa.w, ya.w, za.w), d2 = sqdist_s(qx, qy, qz, xa.z, ya.z, za.z);
-            const float d1 = sqdist_s(qx, qy, qz, xa.y, ya.y, za.y), d0 = sqdist_s(qx, qy, qz, xa.x, ya.x, za.x);
-            const int j = 64 * r + 4 * j4;                // (+ 16 q, added by the caller: the selects keep inline constants)
-            found = d3 == v ? j + 3 : found;
-            found = d2 == v ? j + 2 : found;
-            found = d1 == v ? j + 1 : found;
-            found = d0 == v ? j : found;
-        }
-    return found == INT_MAX ? INT_MAX : found + 16 * q;
-}
-
-__global__ __launch_bounds__(CF_THREADS) void chamfer_sym_finish_kernel(ChamferSymArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    GA_STAMP(2, 0);
-    const int tiles = a.tiles;
-    float *rx = lds, *ry = lds + tiles * CF_SEG, *rz = lds + 2 * tiles * CF_SEG;
+// The operator form's second launch: lexicographic (distance, index) minimum over the row partials of the column slices
+// and, for clouds of several row super-tiles, over the column partials.  grid = (cdiv(max(n, m), 256), clouds * pairs).
+__global__ __launch_bounds__(256) void chamfer_sym_merge_kernel(ChamferSymArgs a) {
     const int group = blockIdx.y;
     const int pi = group / a.clouds, c = group % a.clouds;
     if (!sym_needed(a.need[pi], c)) return;
     const ChamferPair pr = a.pr[pi];
-    const int n = a.n, m = a.m;
-    const int cp = a.q_clouds > 0 ? (a.pair_base + c) / a.q_clouds : c;
-    const int cq = a.q_clouds > 0 ? (a.pair_base + c) % a.q_clouds : c;
-    const float *P = pr.p + (size_t)cp * n * 3;
-    const float *Q = pr.q + (size_t)cq * m * 3;
-    const float4 *colpart = reinterpret_cast<const float4 *>(a.colpart) + (((size_t)pi * a.clouds + c) * tiles) * m;
-    // this thread's column: its partial minima and coordinates are REQUESTED before the row cloud is staged, so that the
-    // two global round trips overlap (the kernel is latency-bound).  Large clouds (fin_reps > 1: staging the rows is
-    // ~100 KB per workgroup, one workgroup per CU) walk several column sub-slices per staging.
-    constexpr int CP = 8;                                 // tiles fetched up front (n <= 2048); further tiles in a loop
-    int k = (blockIdx.x * a.fin_reps) * CF_COLS + threadIdx.x;
-    int kc = k < m ? k : m - 1;
-    float4 cpv[CP];
-#pragma unroll
-    for (int t = 0; t < CP; ++t) cpv[t] = colpart[(size_t)(t < tiles ? t : 0) * m + kc];
-    float qx = Q[3 * (size_t)kc], qy = Q[3 * (size_t)kc + 1], qz = Q[3 * (size_t)kc + 2];
-    for (int e = threadIdx.x; e < tiles * CS_ROWS; e += CF_THREADS) {
-        const int o = (e / CS_ROWS) * CF_SEG + (e % CS_ROWS);
-        const int src = e < n ? e : n - 1;                // rows beyond the cloud: copies of its last row (a copy can only
-        rx[o] = P[3 * (size_t)src]; ry[o] = P[3 * (size_t)src + 1]; rz[o] = P[3 * (size_t)src + 2];   // tie with it, and it is lower)
+    const int n = a.n, m = a.m, e = blockIdx.x * 256 + threadIdx.x;
+    const int rslices = a.cslices * a.cw;
+    if (rslices > 1 && e < n) {
+        const size_t o = ((size_t)pi * a.clouds + c) * rslices * n + e;
+        float d; int i;
+        sym_merge_slices(a.rowpart_d + o, a.rowpart_i + o, rslices, n, d, i);
+        pr.dist1[(size_t)c * n + e] = d;
+        pr.idx1[(size_t)c * n + e] = i;
     }
-    __syncthreads();
-    if (a.csplit > 1) {   // row minima: lexicographic (distance, index) minimum over the column slices
-        for (int j = blockIdx.x * CF_THREADS + threadIdx.x; j < n; j += gridDim.x * CF_THREADS) {
-            const size_t o = ((size_t)pi * a.clouds + c) * a.csplit * n + j;
-            float d = a.rowpart_d[o];
-            int i = a.rowpart_i[o];
-            for (int s = 1; s < a.csplit; ++s) {
-                const float ds = a.rowpart_d[o + (size_t)s * n];
-                const int is = a.rowpart_i[o + (size_t)s * n];
-                if (ds < d || (ds == d && is < i)) { d = ds; i = is; }
-            }
-            pr.dist1[(size_t)c * n + j] = d;
-            pr.idx1[(size_t)c * n + j] = i;
-        }
+    if (a.rtiles > 1 && e < m) {
+        const size_t o = ((size_t)pi * a.clouds + c) * a.rtiles * m + e;
+        float d; int i;
+        sym_merge_slices(a.colpart_d + o, a.colpart_i + o, a.rtiles, m, d, i);
+        pr.dist2[(size_t)c * m + e] = d;
+        pr.idx2[(size_t)c * m + e] = i;
     }
-    for (int rep = 0; rep < a.fin_reps; ++rep) {
-        // minimum over the tiles and the LOWEST tile attaining it (strict compare), with that tile's four quarter minima
-        float4 win = cpv[0];
-        float v = fminf(fminf(win.x, win.y), fminf(win.z, win.w));
-        int bt = 0;
-#pragma unroll
-        for (int t = 1; t < CP; ++t) {
-            const float tv = fminf(fminf(cpv[t].x, cpv[t].y), fminf(cpv[t].z, cpv[t].w));
-            if (t < tiles && tv < v) { v = tv; bt = t; win = cpv[t]; }
-        }
-        for (int t0 = CP; t0 < tiles; t0 += CP) {             // larger clouds: eight tiles in flight per step
-            float4 w[CP];
-#pragma unroll
-            for (int t = 0; t < CP; ++t) w[t] = colpart[(size_t)(t0 + t < tiles ? t0 + t : 0) * m + kc];
-#pragma unroll
-            for (int t = 0; t < CP; ++t) {
-                const float tv = fminf(fminf(w[t].x, w[t].y), fminf(w[t].z, w[t].w));
-                if (t0 + t < tiles && tv < v) { v = tv; bt = t0 + t; win = w[t]; }
-            }
-        }
-        const float *sx = rx + bt * CF_SEG, *sy = ry + bt * CF_SEG, *sz = rz + bt * CF_SEG;
-        const float qv[4] = {win.x, win.y, win.z, win.w};
-        int q1 = 3;                                           // lowest quarter attaining the minimum
-#pragma unroll
-        for (int q = 2; q >= 0; --q) q1 = qv[q] == v ? q : q1;
-        int found = finish_quarter(sx, sy, sz, q1, qx, qy, qz, v);
-        for (int q = q1 + 1; q < 4; ++q)                      // exact ties across quarters: rare
-            if (qv[q] == v) found = min(found, finish_quarter(sx, sy, sz, q, qx, qy, qz, v));
-        if (found == INT_MAX) found = 0;                      // only if v is NaN-tainted (out of contract)
-        if (k < m) {
-            pr.dist2[(size_t)c * m + k] = v;
-            pr.idx2[(size_t)c * m + k] = bt * CS_ROWS + found;
-        }
-        if (rep + 1 < a.fin_reps) {                       // next sub-slice: its partial minima and coordinates
-            k += CF_COLS;
-            kc = k < m ? k : m - 1;
-#pragma unroll
-            for (int t = 0; t < CP; ++t) cpv[t] = colpart[(size_t)(t < tiles ? t : 0) * m + kc];
-            qx = Q[3 * (size_t)kc]; qy = Q[3 * (size_t)kc + 1]; qz = Q[3 * (size_t)kc + 2];
-        }
-    }
-    GA_STAMP(2, 7);
 }
 
-constexpr int CS_MAX_SPLIT = 4;
+// Launch shape of the symmetric scan: how the 8 waves of a workgroup are laid over rows and columns, and how many
+// columns a workgroup takes so that the grid fills the chip (256 / 128 / 64; `groups` = live (pair, cloud) groups).
+struct SymShape { int rw, cw, rtiles, C, cslices; };
+static SymShape sym_shape(long groups, int n, int m) {
+    SymShape s;
+    s.rw = n > 1024 ? 8 : n > 512 ? 4 : n > 256 ? 2 : 1;
+    s.cw = CS_WAVES / s.rw;
+    s.rtiles = cdiv(n, CS_WROWS * s.rw);
+    s.C = CS_CMAX;
+    const int cmin = std::max(CS_CMIN, 2 * CS_ROUND * s.cw);      // every column-wave keeps at least two rounds
+    while (s.C > cmin && (long)s.rtiles * cdiv(m, s.C) * groups < kCUs) s.C /= 2;   // measured: slicing only pays when the grid would not even cover the CUs
+    s.cslices = cdiv(m, s.C);
+    return s;
+}
+static size_t sym_group_floats(const SymShape &s, int n, int m) {
+    return 2 * (size_t)s.cslices * s.cw * n + (s.rtiles > 1 ? 2 * (size_t)s.rtiles * m : 0);
+}
+
+// Scratch for `pairs` problems of `b` clouds each, in floats: an upper bound over the shapes the launcher may choose for
+// any number of live groups <= pairs * b (fewer live groups = narrower slices = more row partials per group).
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
-    return 4 * (size_t)pairs * b * cdiv(n, CS_ROWS) * m + 2 * (size_t)pairs * b * CS_MAX_SPLIT * n + 64;
+    size_t per = 0;
+    for (long g = 1; g <= (long)pairs * b; g *= 2) per = std::max(per, sym_group_floats(sym_shape(g, n, m), n, m));
+    per = std::max(per, sym_group_floats(sym_shape((long)pairs * b, n, m), n, m));
+    return (size_t)pairs * b * per + 64;
 }
 
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
                           int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider = nullptr,
-                          const JacRider *jac = nullptr);
+                          const JacRider *jac = nullptr, SymPartials *defer = nullptr);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream) {
     return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, nullptr, stream);
 }
 // need1: per-cloud flags (int[8 * b], 16-byte aligned) restricting the SECOND pair to the clouds that still need the all-pairs kernel
-int launch_chamfer_sym_needed(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
-                              hipStream_t stream) {
-    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream);
-}
-// ... and with the paired grid search (rider->n <= GR_MAX_N) as 8 * b extra workgroups of the scan launch
-// jac (or null): the pool Jacobian's 8 * b workgroups as well (jac->first_block / blocks are set here)
-int launch_chamfer_sym_rider(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
-                             const GridArgs *rider, const JacRider *jac, hipStream_t stream) {
-    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider, jac);
+// rider (rider->n <= GR_MAX_N): the paired grid search as 8 * b extra workgroups of the scan launch; jac (or null): the pool
+// Jacobian's 8 * b workgroups as well (jac->first_block / blocks are set here); defer (or null): see SymPartials
+int launch_chamfer_sym_loop(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
+                            const GridArgs *rider, const JacRider *jac, SymPartials *defer, hipStream_t stream) {
+    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider, jac, defer);
 }
 
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
-                          int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider, const JacRider *jac) {
+                          int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider, const JacRider *jac,
+                          SymPartials *defer) {
+    if (defer) { defer->slices = 1; defer->rowpart_d = nullptr; defer->rowpart_i = nullptr; defer->clouds = b; defer->deferred = false; }
     if (b <= 0 || np <= 0) return GEOADV_OK;
     ChamferSymArgs a;
     a.need[0] = nullptr; a.need[1] = need1;
     a.pair_base = pair_base; a.q_clouds = q_clouds;
     for (int i = 0; i < np; ++i) a.pr[i] = pairs[i];
-    a.n = n; a.m = m; a.tiles = cdiv(n, CS_ROWS); a.clouds = b; a.pairs = np; a.colpart = workspace;
-    // column slices so that the grid fills the chip (4 workgroups per CU resident): 1, 2 or 4
-    a.csplit = 1;
+    a.n = n; a.m = m; a.clouds = b; a.pairs = np;
     // (a second pair gated by `need1` usually has no work at all -- the grid search answers it -- so it does not count)
     const int np_live = need1 ? 1 : np;
-    while (a.csplit < CS_MAX_SPLIT && (long)a.tiles * a.csplit * b * np_live < 256 && m / (a.csplit * 2) >= 256) a.csplit *= 2;   // measured: slicing only pays when the grid would not even cover the CUs
-    a.rowpart_d = workspace + 4 * (size_t)np * b * a.tiles * m;
-    a.rowpart_i = reinterpret_cast<int *>(a.rowpart_d + (size_t)np * b * CS_MAX_SPLIT * n);
+    const SymShape s = sym_shape((long)b * np_live, n, m);
+    a.rw = s.rw; a.cw = s.cw; a.rtiles = s.rtiles; a.C = s.C; a.cslices = s.cslices;
+    const int rslices = s.cslices * s.cw;
+    const size_t groups = (size_t)np * b;
+    a.rowpart_d = workspace;
+    a.rowpart_i = reinterpret_cast<int *>(workspace + groups * rslices * n);
+    a.colpart_d = workspace + 2 * groups * rslices * n;
+    a.colpart_i = reinterpret_cast<int *>(a.colpart_d + groups * s.rtiles * m);
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_finish_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)std::max(CS_LDS_BYTES, chamfer_grid_lds_bytes(GR_MAX_N))));
+                                       (int)std::max(std::max(CS_LDS_BYTES, chamfer_grid_lds_bytes(GR_MAX_N)), JAC_LDS_BYTES)));
             return GEOADV_OK;
         })) return rc;
-    unsigned grid = (unsigned)(a.tiles * a.csplit * 8 * cdiv(b * np, 8));
+    unsigned grid = (unsigned)(s.rtiles * s.cslices * 8 * cdiv(b * np, 8));
     a.rider.blocks = 0; a.rider.first_block = 0;
     size_t scan_lds = CS_LDS_BYTES;
     if (rider) {
@@ -441,7 +396,7 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     }
     a.jac.blocks = 0; a.jac.first_block = 0;
     if (jac) {
-        // LAST in the grid: every workgroup of the launch is charged the scan's 59 KB of LDS, so a CU holds two -- the search
+        // LAST in the grid: every workgroup of the launch is charged the scan's 70 KB of LDS, so a CU holds two -- the search
         // and the scan from the start; the Jacobian's workgroups take the search's places as those finish (~13 us into a 30 us
         // scan).  Ahead of the scan they delayed it by their whole run time (51 instead of 33 us).
         a.jac = *jac;
@@ -452,11 +407,14 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     }
     chamfer_sym_kernel<<<grid, CS_THREADS, scan_lds, stream>>>(a);
     GA_LAUNCH_CHECK();
-    const size_t lds = sizeof(float) * 3 * (size_t)a.tiles * CF_SEG;
-    GA_REQUIRE(lds <= 150 * 1024, "chamfer_sym: too many rows (%d)", n);
-    // large clouds stage ~100 KB of rows per workgroup: several column sub-slices per staging, as long as every CU still gets a workgroup
-    a.fin_reps = a.tiles > 8 ? std::max(1, std::min(4, (int)((long)cdiv(m, CF_COLS) * b * np / kCUs))) : 1;
-    chamfer_sym_finish_kernel<<<dim3(cdiv(m, CF_COLS * a.fin_reps), b * np), CF_THREADS, lds, stream>>>(a);
+    if (rslices == 1 && s.rtiles == 1) return GEOADV_OK;  // both sides left the scan final
+    // the caller's next launch merges the row partials on its way in -- up to 8 slices: a cloud's partials are read by ONE
+    // workgroup there (64 KB of distances at 8 slices, ~100 GB/s per CU); the narrow slices of small batches keep the merge launch
+    if (defer && s.rtiles == 1 && rslices <= 8) {
+        defer->slices = rslices; defer->rowpart_d = a.rowpart_d; defer->rowpart_i = a.rowpart_i; defer->deferred = true;
+        return GEOADV_OK;
+    }
+    chamfer_sym_merge_kernel<<<dim3(cdiv(std::max(n, m), 256), b * np), 256, 0, stream>>>(a);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
@@ -483,16 +441,17 @@ __global__ __launch_bounds__(256) void chamfer_pair_mean_kernel(int n, int m, co
 
 using namespace geoadv;
 
-// Per-pair scratch of geoadv_chamfer_matrix, in floats.
-static size_t matrix_floats_per_pair(int n, int m) {
-    return (size_t)2 * (n + m) + chamfer_sym_workspace_floats(1, 1, n, m) + 64;
+// Scratch of geoadv_chamfer_matrix for `cnt` pairs processed together, in floats: the four nn_distance outputs of every pair +
+// the symmetric scan's partials at the launch shape `cnt` groups get (fewer groups = narrower column slices = more row partials each).
+static size_t matrix_floats(size_t cnt, int n, int m) {
+    return cnt * 2 * ((size_t)n + m) + cnt * sym_group_floats(sym_shape((long)cnt, n, m), n, m) + 64;
 }
 
 extern "C" size_t geoadv_chamfer_matrix_workspace_floats(int na, int nb, int n, int m) {
     if (na <= 0 || nb <= 0 || n <= 0 || m <= 0) return 256;
     const size_t pairs = (size_t)na * nb;
     const size_t chunk = pairs < 8192 ? pairs : 8192;
-    return chunk * matrix_floats_per_pair(n, m) + 256;
+    return std::max(matrix_floats(chunk, n, m), matrix_floats(1, n, m)) + 256;
 }
 
 extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *A, const float *B, float *out,
@@ -500,25 +459,41 @@ extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *
     GA_REQUIRE(na >= 0 && nb >= 0 && n >= 1 && m >= 1, "chamfer_matrix: bad dimensions (na=%d nb=%d n=%d m=%d)", na, nb, n, m);
     if (na == 0 || nb == 0) return GEOADV_OK;
     GA_REQUIRE(A && B && out && workspace, "chamfer_matrix: null pointer");
-    const size_t per = matrix_floats_per_pair(n, m);
-    GA_REQUIRE(workspace_floats >= per + 256, "chamfer_matrix: workspace too small (%zu floats, need >= %zu)", workspace_floats, per + 256);
-    size_t chunk = (workspace_floats - 256) / per;
-    if (chunk > 32768) chunk = 32768;
+    GA_REQUIRE(workspace_floats >= matrix_floats(1, n, m) + 256, "chamfer_matrix: workspace too small (%zu floats, need >= %zu)",
+               workspace_floats, matrix_floats(1, n, m) + 256);
+    const size_t avail = workspace_floats - 256;
     hipStream_t st = as_stream(stream);
     const size_t pairs = (size_t)na * nb;
-    for (size_t base = 0; base < pairs; base += chunk) {
-        const int cnt = (int)((pairs - base) < chunk ? (pairs - base) : chunk);
+    for (size_t base = 0; base < pairs;) {
+        size_t cnt_ = std::min<size_t>(pairs - base, 32768);
+        while (cnt_ > 1 && matrix_floats(cnt_, n, m) > avail) cnt_ = cnt_ * 7 / 8;      // as many pairs per launch as the workspace holds
+        const int cnt = (int)cnt_;
         float *d1 = workspace, *d2 = d1 + (size_t)cnt * n;
         int *i1 = reinterpret_cast<int *>(d2 + (size_t)cnt * m), *i2 = i1 + (size_t)cnt * n;
         float *ws = reinterpret_cast<float *>(i2 + (size_t)cnt * m);
-        ws += (4 - ((size_t)cnt * 2 * (n + m)) % 4) % 4;       // the column partials are accessed as float4: keep them 16-byte aligned
-                                                               // (odd cnt * (n + m); the + 64 floats of slack per pair cover it)
         const ChamferPair pr{A, B, d1, i1, d2, i2};
         GA_REQUIRE(base <= 0x7fffffff, "chamfer_matrix: too many pairs");
         if (int rc = launch_chamfer_sym_ex(&pr, 1, cnt, n, m, ws, (int)base, nb, nullptr, st)) return rc;
         chamfer_pair_mean_kernel<<<cnt, 256, 0, st>>>(n, m, d1, d2, out + base);
         GA_LAUNCH_CHECK();
+        base += cnt_;
     }
     return GEOADV_OK;
+}
+
+// nn_distance through the symmetric scan as an operator: same outputs as geoadv_nn_distance, bit for bit.
+extern "C" size_t geoadv_nn_distance_sym_workspace_floats(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 64;
+    return chamfer_sym_workspace_floats(1, b, n, m);
+}
+extern "C" int geoadv_nn_distance_sym(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1, int *idx1,
+                                      float *dist2, int *idx2, float *workspace, size_t workspace_floats, void *stream) {
+    GA_REQUIRE(b >= 0 && n >= 1 && m >= 1, "nn_distance_sym: bad dimensions (b=%d n=%d m=%d)", b, n, m);
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(xyz1 && xyz2 && dist1 && idx1 && dist2 && idx2 && workspace, "nn_distance_sym: null pointer");
+    GA_REQUIRE(workspace_floats >= chamfer_sym_workspace_floats(1, b, n, m), "nn_distance_sym: workspace too small (%zu floats, need %zu)",
+               workspace_floats, chamfer_sym_workspace_floats(1, b, n, m));
+    const ChamferPair pr{xyz1, xyz2, dist1, idx1, dist2, idx2};
+    return launch_chamfer_sym(&pr, 1, b, n, m, workspace, as_stream(stream));
 }
 GA_STAMPS_GETTER(geoadv_debug_stamps_chamfer_sym)

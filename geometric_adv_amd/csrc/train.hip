@@ -16,6 +16,7 @@
 //                       of layer i-1 needs, all in ONE kernel per layer.
 // All reductions run in a fixed order (per-tile partials, then a double-precision pass), so a step is
 // deterministic.  Parity is checked by tests/test_gpu_train.py against a numpy fp64 model of the same step.
+#include "chamfer_sym.h"
 #include "ae.h"
 #include "mfma_tile.h"
 #include <math.h>
@@ -26,13 +27,6 @@
 namespace geoadv {
 
 // ---- from the other translation units (the Chamfer pieces of the attack loop) ----
-struct ChamferPair { const float *p, *q; float *dist1; int *idx1; float *dist2; int *idx2; };
-size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
-int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
-struct CGradProblem {
-    const float *p, *q; const int *idx1, *idx2; float *g; const float *w; const int *jstar; float extra_w;
-};
-int launch_chamfer_grad(const CGradProblem *pr, int np, int B, int n, hipStream_t st);
 
 constexpr int TR_THREADS = 512;
 constexpr int TR_ROWS = 64;

@@ -63,6 +63,27 @@ def nn_distance(xyz1, xyz2):
     return dist1, idx1, dist2, idx2
 
 
+def nn_distance_sym(xyz1, xyz2):
+    """nn_distance with every pair distance evaluated ONCE for both directions (the attack loop's kernel): identical outputs,
+    bit for bit; both clouds need at least one point."""
+    xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "NnDistance")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    if n < 1 or m < 1:
+        raise ValueError("nn_distance_sym needs non-empty clouds")
+    dist1 = torch.empty((b, n), dtype=torch.float32, device=xyz1.device)
+    idx1 = torch.empty((b, n), dtype=torch.int32, device=xyz1.device)
+    dist2 = torch.empty((b, m), dtype=torch.float32, device=xyz1.device)
+    idx2 = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    wf = int(_lib.lib().geoadv_nn_distance_sym_workspace_floats(b, n, m))
+    ws = torch.empty((wf,), dtype=torch.float32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        st = _lib.lib().geoadv_nn_distance_sym(b, n, _lib.ptr(xyz1), m, _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(idx1),
+                                               _lib.ptr(dist2), _lib.ptr(idx2), _lib.ptr(ws), C.c_size_t(wf), _lib.stream_handle())
+    _lib.check(st, "nn_distance_sym")
+    return dist1, idx1, dist2, idx2
+
+
 def chamfer_per_pc(dist1, dist2):
     """tf.reduce_mean(dist1, axis=1) + tf.reduce_mean(dist2, axis=1) of nn_distance's outputs (adv_ae.py:121,132;
     get_dists_per_point.py:75): (b,n), (b,m) -> (b,).  Summation order = the attack loop's own metrics, so a Chamfer

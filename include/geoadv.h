@@ -48,6 +48,15 @@ const char *geoadv_last_error(void);
 int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
                        float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
 
+/* The same outputs, bit for bit, from ONE evaluation of every pair distance for both directions (the attack loop's kernel,
+ * csrc/chamfer_sym.hip: the distance matrix is symmetric in the two clouds' roles down to the last bit).  n, m >= 1.  workspace:
+ * geoadv_nn_distance_sym_workspace_floats(b,n,m) floats of caller-owned scratch (row minima per column slice; the caller
+ * allocates, as with the temp tensor of tf_approxmatch.cpp:164-170). */
+size_t geoadv_nn_distance_sym_workspace_floats(int b, int n, int m);
+int geoadv_nn_distance_sym(int b, int n, const float *xyz1, int m, const float *xyz2,
+                           float *dist1, int *idx1, float *dist2, int *idx2,
+                           float *workspace, size_t workspace_floats, void *stream);
+
 /* chamfer_dist[b] = reduce_mean(dist1[b,:]) + reduce_mean(dist2[b,:]) -- the scalar every caller of nn_distance forms next
  * (adv_ae.py:121,132; get_dists_per_point.py:75; prepare_indices_for_attack.py:114) -- in the summation order of the
  * attack loop's own metrics, so that a Chamfer distance recomputed from saved clouds equals adversarial_metrics[:,:,2]

@@ -94,6 +94,56 @@ def test_nn_distance_random_shapes_vs_oracle(dev, oracle):
             assert np.array_equal(_bits(gt.cpu().numpy()), _bits(w)), (trial, b, n, m, what)
 
 
+def test_symmetric_scan_random_shapes_vs_oracle(dev, oracle):
+    """The attack loop's symmetric scan as an operator (geoadv_nn_distance_sym): sixty random (b, n, m) -- one point to a few
+    thousand rows and columns, so every layout of a workgroup's 8 waves over rows and columns (1 / 2 / 4 / 8 row-waves), one and
+    several row super-tiles (n > 2048), column slices of 64 / 128 / 256, ragged last rows, rounds and slices -- with exact
+    duplicates (rows AND columns: the lowest index must win on both sides) and lattice coordinates mixed in; bit for bit."""
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(515)
+    for trial in range(60):
+        b = int(rng.integers(1, 40)) if trial % 4 else int(rng.integers(1, 4))
+        n = int(rng.integers(1, 300)) if trial % 3 == 0 else int(rng.integers(1, 5000))
+        m = int(rng.integers(1, 300)) if trial % 5 == 0 else int(rng.integers(1, 5000))
+        if b * max(n, m) > 60000:
+            b = max(1, 60000 // max(n, m))
+        x1 = rng.random((b, n, 3), dtype=np.float32)
+        x2 = rng.random((b, m, 3), dtype=np.float32)
+        if trial % 2:                                                    # a coarse lattice: many exactly equal distances
+            x1, x2 = np.round(x1 * 4) / 4, np.round(x2 * 4) / 4
+        if trial % 7 == 0 and m > 1:                                     # duplicated columns
+            x2[:, m // 2:] = x2[:, : m - m // 2]
+        if trial % 7 == 3 and n > 1:                                     # duplicated rows, far apart (other waves / super-tiles)
+            x1[:, n // 2:] = x1[:, : n - n // 2]
+        x1, x2 = x1.astype(np.float32), x2.astype(np.float32)
+        want = oracle.nn_distance(x1, x2)
+        got = ops.nn_distance_sym(_t(x1, dev), _t(x2, dev))
+        for w, gt, what in zip(want, got, ["dist1", "idx1", "dist2", "idx2"]):
+            assert np.array_equal(_bits(gt.cpu().numpy()), _bits(w)), (trial, b, n, m, what)
+
+
+@pytest.mark.parametrize("b,n,m", [(32, 2048, 2048), (8, 2048, 2048), (2, 8192, 8192), (1, 2049, 4097), (64, 1024, 1024), (3, 300, 6000)])
+def test_symmetric_scan_attack_shapes_vs_oracle(dev, oracle, b, n, m):
+    """The shapes the loop and the scorer run it at (B = 32 / 8 x 2048: 256- and 64-column slices; 8192: four row super-tiles;
+    one row over a super-tile; four row-waves x two column-waves), near-coincident clouds where n == m (the regime of near ties)."""
+    from geometric_adv_amd import ops
+    from conftest import cloud
+    x1, x2 = cloud(300 + n, b, n), cloud(400 + m, b, m)
+    if n == m:
+        x2 = (x1 + np.float32(1e-4) * cloud(7, b, n)).astype(np.float32)
+    if b > 8:                                                            # (the oracle is a single-threaded scan: check 8 clouds)
+        sel = np.linspace(0, b - 1, 8).astype(int)
+    else:
+        sel = np.arange(b)
+    want = oracle.nn_distance(x1[sel], x2[sel])
+    got = ops.nn_distance_sym(_t(x1, dev), _t(x2, dev))
+    for w, gt, what in zip(want, got, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(_bits(gt.cpu().numpy()[sel]), _bits(w)), what
+    ref = ops.nn_distance(_t(x1, dev), _t(x2, dev))                      # and every cloud against the public op
+    for a_, b_ in zip(ref, got):
+        assert np.array_equal(_bits(a_.cpu().numpy()), _bits(b_.cpu().numpy()))
+
+
 def test_nn_distance_full_size_properties(dev):
     """Config-2 size (B=32, N=2048): size-independent properties instead of a CPU re-run:
     a cloud against itself gives idx = identity / dist = 0; against a permuted copy gives the
