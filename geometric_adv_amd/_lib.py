@@ -25,7 +25,8 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.geoadv_last_error.restype = C.c_char_p
         for name in ("geoadv_approx_match_temp_floats", "geoadv_ae_workspace_bytes", "geoadv_chamfer_matrix_workspace_floats",
-                     "geoadv_emd_cost_grad1_temp_floats", "geoadv_nn_distance_sym_workspace_floats"):
+                     "geoadv_emd_cost_grad1_temp_floats", "geoadv_nn_distance_sym_workspace_floats",
+                     "geoadv_knn_workspace_bytes", "geoadv_group_point_grad_workspace_bytes", "geoadv_match_cost_workspace_floats"):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

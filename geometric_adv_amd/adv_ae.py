@@ -25,7 +25,7 @@ class Configuration:
                  max_point_dist_weight=0.0, num_iterations=500, num_iterations_thresh=400,
                  learning_rate=0.01, ae_name="autoencoder", emd_weight=0.0, verbose=False, batch_slots=1,
                  chamfer_prune=True, emd_reference_weights=False, recompute_backward=False, separate_adam=False,
-                 chamfer_kernel="auto", encoder_backward="auto"):
+                 chamfer_kernel="auto", encoder_backward="auto", emd_dense_levels=False):
         self.batch_size = int(batch_size)
         self.n_input = [int(n_points), 3]
         self.n_output = [int(n_points), 3]
@@ -43,11 +43,15 @@ class Configuration:
         self.emd_weight = float(emd_weight)
         self.verbose = verbose
         self.batch_slots = int(batch_slots)      # batches attacked concurrently on this GPU (AdvAE.attack); 1 = the reference's order
-        if chamfer_prune not in (True, False, "always"):
-            raise ValueError("chamfer_prune must be True (grid search except for tiny batches), False or 'always'")
+        if chamfer_prune not in (True, False, "always", "pinned"):
+            raise ValueError("chamfer_prune must be True (grid search except for tiny batches; adaptive), 'pinned' (the same, never "
+                             "switched off by adapt_source_search), False or 'always'")
         self.chamfer_prune = chamfer_prune       # False: nn_distance(adv, x) always by the all-pairs kernel; "always": the paired
-                                                 # grid search at every batch size (same results either way)
+                                                 # grid search at every batch size (same results either way); True: the search, which
+                                                 # a batch that hands most clouds back switches off FOR THAT BATCH (adapt_source_search);
+                                                 # "pinned": True without that policy (timing independent of the data)
         self.emd_reference_weights = bool(emd_reference_weights)   # True: the EMD term's plan from the CPU op's expf arguments (ops.approx_match)
+        self.emd_dense_levels = bool(emd_dense_levels)             # True: this handle's EMD sweeps all dense (GEOADV_EMD_DENSE_LEVELS; per handle, nothing process-wide)
         # alternative code paths with the same results (geoadv_attack_config; the parity tests run each against the default)
         self.recompute_backward = bool(recompute_backward)   # encoder backward re-runs the forward instead of reading ReLU masks
         self.separate_adam = bool(separate_adam)             # Adam step as its own launch
@@ -91,7 +95,7 @@ class AdvAE:
         self.B = c.batch_size
         cfg = _AttackConfig(self.B, 1 if c.loss_adv_type == "latent" else 0, 1 if c.loss_dist_type == "pert" else 0,
                             c.max_point_pert_weight, c.max_point_dist_weight, c.learning_rate, c.emd_weight,
-                            {True: 0, False: 1, "always": 2}[getattr(c, "chamfer_prune", True)], 1 if getattr(c, "emd_reference_weights", False) else 0,
+                            {True: 0, "pinned": 0, False: 1, "always": 2}[getattr(c, "chamfer_prune", True)], (1 if getattr(c, "emd_reference_weights", False) else 0) | (0x100 if getattr(c, "emd_dense_levels", False) else 0),
                             1 if getattr(c, "recompute_backward", False) else 0, ENCODER_BACKWARDS[getattr(c, "encoder_backward", "auto")],
                             1 if getattr(c, "separate_adam", False) else 0,
                             CHAMFER_KERNELS[getattr(c, "chamfer_kernel", "auto")])
@@ -124,6 +128,9 @@ class AdvAE:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_attack_set_inputs(self._h, _lib.ptr(x), _lib.ptr(gt), _lib.ptr(tz), _lib.ptr(w),
                                                            _lib.stream_handle()), "attack_set_inputs")
+        # new clouds: an earlier batch's verdict says nothing about these -- the adaptive policy starts over with the search on
+        if self.configuration.chamfer_prune is True and not getattr(self, "_search_on", True):
+            self.set_source_search(True)
 
     def init_pert(self, init=None, reset_optimizer=False):
         """Adversary.init_pert (adversary.py:27-28).  Adam's slots are NOT reset by default: the
@@ -171,8 +178,10 @@ class AdvAE:
     def adapt_source_search(self):
         """Configuration.chamfer_prune=True is a default, not a promise: when the search hands more than half of the batch back to
         the all-pairs kernel (a victim whose perturbations leave the 1/16-box cells -- every trained victim measured so far), its
-        workgroups only cost time; switch it off for the rest of this handle's life.  Called where the host synchronises anyway
-        (end of a dist-weight run).  Returns the number of clouds handed back, or None if the search is not in use."""
+        workgroups only cost time; switch it off until the next set_inputs (new clouds start with the search on again; results
+        are identical either way, so ranks of a sharded run may decide differently).  Configuration(chamfer_prune="pinned")
+        disables the policy.  Called where the host synchronises anyway (end of a dist-weight run).  Returns the number of clouds
+        handed back, or None if the search is not in use."""
         if self.configuration.chamfer_prune is not True or not getattr(self, "_search_on", True):
             return None
         searched, handed_back = self.search_state()

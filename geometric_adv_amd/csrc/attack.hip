@@ -549,6 +549,8 @@ struct geoadv_attack {
     bool jac_valid;                  // ... computed for the cached forward
     unsigned *tail_ready;            // [B] + 1 word: hand-off flags of the merged tail + dense launch, the spin-timeout word
     unsigned tail_epoch;             // (host) steps launched so far: the flag value of the current one
+    int cus;                         // compute units of THIS device (hipDeviceAttributeMultiprocessorCount at create): the merged tail +
+                                     // dense launch spins on in-launch flags and needs all its workgroups resident at once
     bool chamfer_sym;
     // host state
     float beta1_pow, beta2_pow;
@@ -820,7 +822,7 @@ int do_step(geoadv_attack *at, hipStream_t st) {
             // -- as long as the launch's dense blocks (2 n / 32, a CU's LDS each) and tail blocks all fit the chip at once: a
             // dense block spins on a flag only a tail block raises, and nothing orders their dispatch in general.  Larger
             // clouds take the two plain launches (tail with the Jacobian's apply, then the dense blocks: + one boundary).
-            if (B + 2 * cdiv(n, 32) > kCUs) {
+            if (B + 2 * cdiv(n, 32) > at->cus) {
                 if (int rc = launch_decoder_bwd(A, B, at->g_recon, at->fs.d1, at->fs.d2, at->dec_partial, at->dz, st, at->fs.crit, at->jac,
                                                 at->fs.dense, at->g_enc)) return rc;
                 if (int rc = launch_encoder_bwd_dense(A, B, at->adv, at->fs.z, at->fs.zcnt, at->dz, at->fs.dense, at->g_enc, st)) return rc;
@@ -893,7 +895,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     GA_REQUIRE(cfg->loss_dist_type == GEOADV_LOSS_DIST_CHAMFER || cfg->loss_dist_type == GEOADV_LOSS_DIST_PERT,
                "attack_create: unknown loss_dist_type %d", cfg->loss_dist_type);
     GA_REQUIRE(cfg->emd_weight >= 0.f, "attack_create: emd_weight must be >= 0");
-    GA_REQUIRE(cfg->emd_weight_mode == GEOADV_EMD_FAST || cfg->emd_weight_mode == GEOADV_EMD_REFERENCE,
+    GA_REQUIRE((cfg->emd_weight_mode & ~GEOADV_EMD_DENSE_LEVELS) == GEOADV_EMD_FAST || (cfg->emd_weight_mode & ~GEOADV_EMD_DENSE_LEVELS) == GEOADV_EMD_REFERENCE,
                "attack_create: unknown emd_weight_mode %d", cfg->emd_weight_mode);
     GA_REQUIRE(cfg->all_pairs_source_dist >= 0 && cfg->all_pairs_source_dist <= 2, "attack_create: all_pairs_source_dist must be 0, 1 or 2");
     GA_REQUIRE(cfg->encoder_backward >= GEOADV_ENC_BWD_AUTO && cfg->encoder_backward <= GEOADV_ENC_BWD_JACOBIAN,
@@ -957,6 +959,11 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->jac_valid = false;
     at->tail_ready = reinterpret_cast<unsigned *>(take(4 * (B + 1)));      // (the arena is zeroed above)
     at->tail_epoch = 0;
+    {
+        int dev = 0, cus = 0;                               // unknown => 0: always the two plain launches
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) at->cus = cus;
+        else at->cus = 0;
+    }
     at->need_adv[0] = I(4 * 8 * B); at->need_adv[1] = I(4 * 8 * B);
     at->grid_calls = 0;
     at->x_box = F(4 * 6 * B);

@@ -34,7 +34,9 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;   // gfx950 wavefront
-constexpr int kCUs = 256;   // MI355X: 8 XCDs x 32 CUs (launch-shape decisions only; nothing is wrong on a smaller part, just slower)
+constexpr int kCUs = 256;   // MI355X: 8 XCDs x 32 CUs -- launch-SHAPE decisions only (grid sizes, slice widths): nothing is wrong on a smaller
+                            // part or partition, just slower.  Anything that needs workgroups RESIDENT together (in-launch flags) asks the
+                            // device instead (geoadv_attack::cus)
 
 // One-time kernel attribute setup (hipFuncSetAttribute applies to the CURRENT device only): run(f) calls f once per device
 // ordinal, under a lock, so handles created on cuda:1 after cuda:0, or from several host threads, all get their >64 KB LDS opt-in.

@@ -41,6 +41,7 @@
 // (2.0e-7 relative worst over 13 M entries; 40-80 % bit-equal).  3.7x the time of the fast mode (4.6 ms per approx_match
 // at B = 32 x 2048^2, round 1's speed).  The attack loop defaults to the fast mode.
 // Level j = -2 has level 0, i.e. w = 1 for every pair: its three sweeps are O(n + m) reductions, not O(n m) walks.
+#include <atomic>
 #include "common.h"
 #include <math.h>
 
@@ -1032,16 +1033,17 @@ static int emd_check(const char *op, int b, int n, int m) {
 }
 
 // the eleven levels: capacities and factors into temp (fp64), no plan yet
-static int g_emd_sparse = 1;               // geoadv_emd_sparse_levels: 0 = every sweep dense (the parity tests run both)
+static std::atomic<int> g_emd_sparse{1};   // geoadv_emd_sparse_levels: the process default of calls whose mode carries no GEOADV_EMD_DENSE_LEVELS
+                                           // flag (0 = every sweep dense); tests and measurements only -- per call, use the flag
 
 // `sparse`: scratch of emd_sparse_floats(b, n, m) floats, 16-byte aligned, or null (clouds too large / switched off)
 template <bool REF>
 static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, double *t, char *sparse, EmdLevels<REF> &lv,
-                          hipStream_t st) {
+                          bool dense_levels, hipStream_t st) {
     emd_init_kernel<<<dim3(cdiv(n + m, 256), b), 256, 0, st>>>(n, m, t);
     GA_LAUNCH_CHECK();
     for (int li = 0; li < EMD_LEVELS; ++li) lv.c[li] = PairWeight<REF>::level(li);
-    if (!g_emd_sparse) sparse = nullptr;
+    if (dense_levels || !g_emd_sparse.load()) sparse = nullptr;
     if (sparse) {
         // reach of level 8: beyond it both weight forms are exactly 0 -- glibc's expf below -103.97 (REF: float(level * d2)), v_exp_f32
         // of an argument below -150 (fast: d2 * level * log2 e) -- i.e. level * d2 <= -104.7 covers both; the reach doubles per level
@@ -1085,20 +1087,22 @@ static int emd_run_levels(int b, int n, int m, const float *xyz1, const float *x
 }
 
 extern "C" int geoadv_emd_sparse_levels(int on) {
-    g_emd_sparse = on ? 1 : 0;
+    g_emd_sparse.store(on ? 1 : 0);
     return GEOADV_OK;
 }
 
+// mode = weight mode (GEOADV_EMD_FAST / _REFERENCE), optionally | GEOADV_EMD_DENSE_LEVELS
 static int emd_mode_check(const char *op, int mode) {
-    GA_REQUIRE(mode == GEOADV_EMD_FAST || mode == GEOADV_EMD_REFERENCE, "%s: unknown weight mode %d", op, mode);
+    const int w = mode & ~GEOADV_EMD_DENSE_LEVELS;
+    GA_REQUIRE(w == GEOADV_EMD_FAST || w == GEOADV_EMD_REFERENCE, "%s: unknown weight mode %d", op, mode);
     return GEOADV_OK;
 }
 
 template <bool REF>
-static int approx_match_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, double *t, hipStream_t st) {
+static int approx_match_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, double *t, bool dense_levels, hipStream_t st) {
     EmdLevels<REF> lv;
     char *sparse = emd_sparse_floats(b, n, m) ? reinterpret_cast<char *>((reinterpret_cast<size_t>(t + (size_t)b * emd_temp_doubles_per_cloud(n, m)) + 15) & ~(size_t)15) : nullptr;
-    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, sparse, lv, st)) return rc;
+    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, sparse, lv, dense_levels, st)) return rc;
     emd_match_kernel<REF><<<dim3(cdiv(n, 256), cdiv(m, EMD_LT), b), 256, 0, st>>>(n, m, lv, xyz1, xyz2, t, match);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
@@ -1112,8 +1116,9 @@ extern "C" int geoadv_approx_match_mode(int mode, int b, int n, int m, const flo
     GA_REQUIRE(xyz1 && xyz2 && match && temp, "approx_match: null pointer");
     hipStream_t st = as_stream(stream);
     double *t = reinterpret_cast<double *>((reinterpret_cast<size_t>(temp) + 7) & ~(size_t)7);
-    return mode == GEOADV_EMD_REFERENCE ? approx_match_impl<true>(b, n, m, xyz1, xyz2, match, t, st)
-                                        : approx_match_impl<false>(b, n, m, xyz1, xyz2, match, t, st);
+    const bool dense = (mode & GEOADV_EMD_DENSE_LEVELS) != 0;
+    return (mode & ~GEOADV_EMD_DENSE_LEVELS) == GEOADV_EMD_REFERENCE ? approx_match_impl<true>(b, n, m, xyz1, xyz2, match, t, dense, st)
+                                                                    : approx_match_impl<false>(b, n, m, xyz1, xyz2, match, t, dense, st);
 }
 
 extern "C" int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
@@ -1128,11 +1133,11 @@ extern "C" size_t geoadv_emd_cost_grad1_temp_floats(int b, int n, int m) {
 
 template <bool REF>
 static int emd_cost_grad1_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, double *t,
-                               hipStream_t st) {
+                               bool dense_levels, hipStream_t st) {
     double *partial = t + (size_t)b * emd_temp_doubles_per_cloud(n, m);
     EmdLevels<REF> lv;
     char *sparse = emd_sparse_floats(b, n, m) ? reinterpret_cast<char *>((reinterpret_cast<size_t>(partial + (size_t)b * cdiv(n, 64)) + 15) & ~(size_t)15) : nullptr;
-    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, sparse, lv, st)) return rc;
+    if (int rc = emd_run_levels<REF>(b, n, m, xyz1, xyz2, t, sparse, lv, dense_levels, st)) return rc;
     const int parts = cdiv(n, 64);
     emd_plan_cost_grad1_kernel<REF><<<dim3(parts, b), SW_THREADS, 0, st>>>(n, m, lv, xyz1, xyz2, t, partial, grad1);
     GA_LAUNCH_CHECK();
@@ -1149,8 +1154,9 @@ extern "C" int geoadv_emd_cost_grad1_mode(int mode, int b, int n, int m, const f
     GA_REQUIRE(xyz1 && xyz2 && cost && grad1 && temp, "emd_cost_grad1: null pointer");
     hipStream_t st = as_stream(stream);
     double *t = reinterpret_cast<double *>((reinterpret_cast<size_t>(temp) + 7) & ~(size_t)7);
-    return mode == GEOADV_EMD_REFERENCE ? emd_cost_grad1_impl<true>(b, n, m, xyz1, xyz2, cost, grad1, t, st)
-                                        : emd_cost_grad1_impl<false>(b, n, m, xyz1, xyz2, cost, grad1, t, st);
+    const bool dense = (mode & GEOADV_EMD_DENSE_LEVELS) != 0;
+    return (mode & ~GEOADV_EMD_DENSE_LEVELS) == GEOADV_EMD_REFERENCE ? emd_cost_grad1_impl<true>(b, n, m, xyz1, xyz2, cost, grad1, t, dense, st)
+                                                                    : emd_cost_grad1_impl<false>(b, n, m, xyz1, xyz2, cost, grad1, t, dense, st);
 }
 
 extern "C" int geoadv_emd_cost_grad1(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
@@ -1158,21 +1164,43 @@ extern "C" int geoadv_emd_cost_grad1(int b, int n, int m, const float *xyz1, con
     return geoadv_emd_cost_grad1_mode(GEOADV_EMD_FAST, b, n, m, xyz1, xyz2, cost, grad1, temp, stream);
 }
 
+extern "C" size_t geoadv_match_cost_workspace_floats(int b, int n, int m) {
+    (void)n;
+    if (b <= 0 || m <= 0) return 4;
+    return 2 * (size_t)b * cdiv(m, EMD_COST_ROWS) + 4;     // one double per (cloud, part) + alignment slack
+}
+
+// workspace: geoadv_match_cost_workspace_floats(b, n, m) floats, caller-owned (the reference's pattern: temp tensors are the
+// caller's, tf_approxmatch.cpp:164-170)
+extern "C" int geoadv_match_cost_ws(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *out,
+                                    float *workspace, size_t workspace_floats, void *stream) {
+    if (int rc = emd_check("match_cost", b, n, m)) return rc;
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(xyz1 && xyz2 && match && out, "match_cost: null pointer");
+    GA_REQUIRE(workspace && workspace_floats >= geoadv_match_cost_workspace_floats(b, n, m), "match_cost: workspace too small (%zu floats, need %zu)",
+               workspace_floats, geoadv_match_cost_workspace_floats(b, n, m));
+    hipStream_t st = as_stream(stream);
+    const int parts = cdiv(m, EMD_COST_ROWS);
+    double *partial = reinterpret_cast<double *>((reinterpret_cast<size_t>(workspace) + 7) & ~(size_t)7);
+    emd_cost_partial_kernel<<<dim3(parts, b), 256, 0, st>>>(n, m, xyz1, xyz2, match, partial);
+    emd_cost_fold_kernel<<<b, 256, 0, st>>>(parts, partial, out);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+// reference-shaped (matchcostLauncher has no scratch argument): stream-ordered scratch of its own
 extern "C" int geoadv_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *out,
                                  void *stream) {
     if (int rc = emd_check("match_cost", b, n, m)) return rc;
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && match && out, "match_cost: null pointer");
     hipStream_t st = as_stream(stream);
-    const int parts = cdiv(m, EMD_COST_ROWS);
-    double *partial = nullptr;                        // stream-ordered scratch: concurrent callers never share it
-    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&partial), (size_t)b * parts * sizeof(double), st));
-    emd_cost_partial_kernel<<<dim3(parts, b), 256, 0, st>>>(n, m, xyz1, xyz2, match, partial);
-    emd_cost_fold_kernel<<<b, 256, 0, st>>>(parts, partial, out);
-    const hipError_t launched = hipGetLastError();
-    GA_HIP(hipFreeAsync(partial, st));
-    GA_HIP(launched);
-    return GEOADV_OK;
+    const size_t wf = geoadv_match_cost_workspace_floats(b, n, m);
+    float *ws = nullptr;                              // stream-ordered scratch: concurrent callers never share it
+    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&ws), wf * sizeof(float), st));
+    const int rc = geoadv_match_cost_ws(b, n, m, xyz1, xyz2, match, out, ws, wf, stream);
+    GA_HIP(hipFreeAsync(ws, st));
+    return rc;
 }
 
 extern "C" int geoadv_match_cost_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,

@@ -8,6 +8,7 @@
 // wave-wide lexicographic (value, position) arg-min followed by the same swap -- so the result,
 // including the reference's peculiar order among equal distances, is identical, and nothing of
 // size n*m ever touches HBM in the fused form.
+#include <atomic>
 #include "common.h"
 #include <math.h>
 #include <float.h>
@@ -1207,22 +1208,34 @@ extern "C" int geoadv_selection_sort(int b, int n, int m, int k, const float *di
     return GEOADV_OK;
 }
 
-static int g_knn_grid_mode = 0;           // 0 = by size, 1 = never, 2 = always (geoadv_knn_grid_mode: the parity tests run both kernels)
-static int g_knn_lane_first = 1;          // grid search: lane-private 27-cell walk first (0: the wave-uniform shells only); same results.
-                                          // Values-only lists (knn_dists) only: with (value, index) lists the walk lost to the shells at either occupancy
-                                          // (knn_point(8) at 256 x 2048: 378 against 343 us at one workgroup per CU, 265 against 227 us at two)
+// Which kernel answers a k-NN call (k <= 16): GEOADV_KNN_AUTO = by size (datasets of >= 512 points: the exact grid search,
+// smaller ones: the all-points kernel), _ALL_POINTS, _GRID = the grid search at every size, _GRID_SHELLS = as _GRID without the
+// lane-private first pass.  Per call (geoadv_knn_*_ws); the reference-shaped entry points use the process default below.
+static std::atomic<int> g_knn_default_mode{GEOADV_KNN_AUTO};   // geoadv_knn_grid_mode: tests and measurements only
 
-template <int MODE, int S>
-static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx, hipStream_t st) {
-    const bool grid = n <= KG_MAX_N && (g_knn_grid_mode == 2 || (g_knn_grid_mode == 0 && n >= KNN_GRID_MIN_N && m >= 64));
-    // stream-ordered scratch: the redo list (counter + one entry per query at most) and, for the grid search, the sorted
-    // dataset (+ 4 entries of padding: the scalar loads read four points at a time), cell offsets, query order, grid
+static bool knn_uses_grid(int kmode, int n, int m) {
+    return n <= KG_MAX_N && (kmode >= GEOADV_KNN_GRID || (kmode == GEOADV_KNN_AUTO && n >= KNN_GRID_MIN_N && m >= 64));
+}
+static size_t knn_up(size_t v) { return (v + 255) / 256 * 256; }
+// caller-owned scratch of the list kernels: the redo list (counter + one entry per query at most) and, for the grid search, the
+// sorted dataset (+ 4 entries of padding: the scalar loads read four points at a time), cell offsets, query order, grid
+static size_t knn_fast_scratch_bytes(int b, int n, int m) {
     const size_t redo_b = sizeof(int) * ((size_t)b * m + 1), sorted_b = sizeof(float4) * ((size_t)b * n + 4);
     const size_t cs_b = sizeof(int) * (size_t)b * (KG_MAX_CELLS + 1), qo_b = sizeof(int) * (size_t)b * m, info_b = sizeof(KnnGrid) * (size_t)b;
     const size_t to_b = sizeof(int) * (size_t)b * cdiv(m, 64);
-    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    char *scratch = nullptr;
-    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), up(redo_b) + (grid ? up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b) + up(to_b) : 0), st));
+    return knn_up(redo_b) + knn_up(sorted_b) + knn_up(cs_b) + knn_up(qo_b) + knn_up(info_b) + knn_up(to_b);
+}
+
+// kmode: GEOADV_KNN_*; scratch: knn_fast_scratch_bytes(b, n, m) bytes, 256-byte aligned
+// (lane-private 27-cell walk first -- values-only lists (knn_dists) only: with (value, index) lists the walk lost to the shells at
+// either occupancy: knn_point(8) at 256 x 2048: 378 against 343 us at one workgroup per CU, 265 against 227 us at two)
+template <int MODE, int S>
+static int launch_knn_fast(int kmode, int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx, char *scratch,
+                           hipStream_t st) {
+    const bool grid = knn_uses_grid(kmode, n, m);
+    const size_t redo_b = sizeof(int) * ((size_t)b * m + 1), sorted_b = sizeof(float4) * ((size_t)b * n + 4);
+    const size_t cs_b = sizeof(int) * (size_t)b * (KG_MAX_CELLS + 1), qo_b = sizeof(int) * (size_t)b * m, info_b = sizeof(KnnGrid) * (size_t)b;
+    auto up = knn_up;
     int *redo = reinterpret_cast<int *>(scratch);
     if (!grid) GA_HIP(hipMemsetAsync(redo, 0, sizeof(int), st));          // (the grid's build kernel clears the counter itself: one launch less)
     if (grid) {
@@ -1232,20 +1245,20 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         KnnGrid *info = reinterpret_cast<KnnGrid *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b));
         int *tord = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b));
         const int G = n < KNN_GRID_N_MID ? KNN_GRID_G_SMALL : (n < KNN_GRID_N_BIG ? KNN_GRID_G_MID : KNN_GRID_G_BIG);
-        const int lane_first = (MODE == 1 && g_knn_lane_first) ? 1 : 0;
+        const int lane_first = (MODE == 1 && kmode != GEOADV_KNN_GRID_SHELLS) ? 1 : 0;
         constexpr size_t KB_LDS = (size_t)KG_MAX_N * 20;
         static DeviceOnce battr;
         if (int rc = battr.run([]() -> int {
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KB_LDS));
                 return GEOADV_OK;
-            })) { (void)hipFreeAsync(scratch, st); return rc; }
+            })) return rc;
         knn_grid_build_kernel<<<b, KG_BUILD_THREADS, KB_LDS, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord, lane_first ? 0 : 1, redo);
         static DeviceOnce attr;
         if (int rc = attr.run([]() -> int {
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<MODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)kg_lds_bytes<MODE, S>(KG_MAX_N, KG_THREADS)));
                 return GEOADV_OK;
-            })) { (void)hipFreeAsync(scratch, st); return rc; }
+            })) return rc;
         // workgroups per cloud: every wave should see KG_TASKS_PER_WAVE tasks or more (the counter balances them), and the launch
         // about two workgroups per CU
         const int tasks = cdiv(m, 64), waves = KG_THREADS / 64;
@@ -1256,9 +1269,7 @@ static int launch_knn_fast(int b, int n, int m, int k, const float *xyz1, const 
         knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
     }
     knn_redo_kernel<MODE><<<1024, 64, (size_t)n * 8, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
-    const hipError_t launched = hipGetLastError();
-    GA_HIP(hipFreeAsync(scratch, st));
-    GA_HIP(launched);
+    GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }
 
@@ -1276,34 +1287,42 @@ extern "C" int geoadv_debug_knn_diag(unsigned long long *host_out, int reset) {
 }
 #endif
 
+static int knn_mode_check(const char *op, int mode) {
+    GA_REQUIRE(mode >= GEOADV_KNN_AUTO && mode <= GEOADV_KNN_GRID_SHELLS, "%s: kernel selection must be 0 = by size, 1 = all-points kernel only, "
+               "2 = grid search at every size, 3 = as 2 with the wave-uniform shell search only (no lane-private first pass)", op);
+    return GEOADV_OK;
+}
 extern "C" int geoadv_knn_grid_mode(int mode) {
-    GA_REQUIRE(mode >= 0 && mode <= 3, "knn_grid_mode: 0 = by size, 1 = all-points kernel only, 2 = grid search at every size, "
-                                       "3 = as 2 with the wave-uniform shell search only (no lane-private first pass)");
-    g_knn_grid_mode = mode == 3 ? 2 : mode;
-    g_knn_lane_first = mode == 3 ? 0 : 1;
+    if (int rc = knn_mode_check("knn_grid_mode", mode)) return rc;
+    g_knn_default_mode.store(mode);
     return GEOADV_OK;
 }
 
+static bool knn_list_kernels(int mode, int b, int m, int k) {   // the register-list kernels (else: the generic one-wave-per-query kernel, no scratch)
+    return (mode == 0 ? k + 1 : k) <= 17 && (size_t)b * m < ((size_t)1 << 31);
+}
+
 // mode 0: knn_point (k values + indices); mode 1: the defender's distances (k includes the dropped self column)
-static int launch_knn(int mode, int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
-                      hipStream_t st) {
+// kmode: GEOADV_KNN_*; scratch: caller-owned, knn_fast_scratch_bytes (unused by the generic kernel)
+static int launch_knn(int mode, int kmode, int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                      char *scratch, hipStream_t st) {
     if (int rc = row_lds_attr()) return rc;
     const int slots = mode == 0 ? k + 1 : k;              // register list of the fast kernel
-    if (slots <= 17 && (size_t)b * m < ((size_t)1 << 31)) {
+    if (knn_list_kernels(mode, b, m, k)) {
         if (mode == 0) {
-            if (slots <= 3) return launch_knn_fast<0, 3>(b, n, m, k, xyz1, xyz2, val, idx, st);
-            if (slots <= 5) return launch_knn_fast<0, 5>(b, n, m, k, xyz1, xyz2, val, idx, st);
-            if (slots <= 9) return launch_knn_fast<0, 9>(b, n, m, k, xyz1, xyz2, val, idx, st);
-            if (slots <= 10) return launch_knn_fast<0, 10>(b, n, m, k, xyz1, xyz2, val, idx, st);     // k = 9: the defender's knn_point call
-            if (slots <= 11) return launch_knn_fast<0, 11>(b, n, m, k, xyz1, xyz2, val, idx, st);
-            if (slots <= 13) return launch_knn_fast<0, 13>(b, n, m, k, xyz1, xyz2, val, idx, st);
-            return launch_knn_fast<0, 17>(b, n, m, k, xyz1, xyz2, val, idx, st);
+            if (slots <= 3) return launch_knn_fast<0, 3>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+            if (slots <= 5) return launch_knn_fast<0, 5>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+            if (slots <= 9) return launch_knn_fast<0, 9>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+            if (slots <= 10) return launch_knn_fast<0, 10>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);     // k = 9: the defender's knn_point call
+            if (slots <= 11) return launch_knn_fast<0, 11>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+            if (slots <= 13) return launch_knn_fast<0, 13>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+            return launch_knn_fast<0, 17>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
         }
-        if (slots <= 3) return launch_knn_fast<1, 3>(b, n, m, k, xyz1, xyz2, val, idx, st);
-        if (slots <= 5) return launch_knn_fast<1, 5>(b, n, m, k, xyz1, xyz2, val, idx, st);
-        if (slots <= 9) return launch_knn_fast<1, 9>(b, n, m, k, xyz1, xyz2, val, idx, st);
-        if (slots <= 13) return launch_knn_fast<1, 13>(b, n, m, k, xyz1, xyz2, val, idx, st);
-        return launch_knn_fast<1, 17>(b, n, m, k, xyz1, xyz2, val, idx, st);
+        if (slots <= 3) return launch_knn_fast<1, 3>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+        if (slots <= 5) return launch_knn_fast<1, 5>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+        if (slots <= 9) return launch_knn_fast<1, 9>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+        if (slots <= 13) return launch_knn_fast<1, 13>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+        return launch_knn_fast<1, 17>(kmode, b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
     }
     // enough workgroups to fill the chip, a few queries each to amortise the launch
     int qper = 1;
@@ -1315,25 +1334,73 @@ static int launch_knn(int mode, int b, int n, int m, int k, const float *xyz1, c
     return GEOADV_OK;
 }
 
-extern "C" int geoadv_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
-                                void *stream) {
+static int knn_point_check(int b, int n, int m, int k) {
     GA_REQUIRE(b >= 0 && n >= 1 && m >= 0, "knn_point: bad dimensions (b=%d n=%d m=%d)", b, n, m);
     GA_REQUIRE(k >= 1 && k <= n, "knn_point: k=%d must be in [1, n=%d]", k, n);
     GA_REQUIRE(n <= ROW_MAX_N, "knn_point: more than %d dataset points per cloud are not supported (n=%d)", ROW_MAX_N, n);
     GA_REQUIRE(b <= 65535, "knn_point: batch %d exceeds 65535", b);
-    if (b == 0 || m == 0) return GEOADV_OK;
-    GA_REQUIRE(xyz1 && xyz2 && val && idx, "knn_point: null pointer");
-    return launch_knn(0, b, n, m, k, xyz1, xyz2, val, idx, as_stream(stream));
+    return GEOADV_OK;
 }
-
-extern "C" int geoadv_knn_dists(int b, int n, int k, const float *pc, float *out, void *stream) {
+static int knn_dists_check(int b, int n, int k) {
     GA_REQUIRE(b >= 0 && n >= 2, "knn_dists: bad dimensions (b=%d n=%d)", b, n);
     GA_REQUIRE(k >= 1 && k + 1 <= n, "knn_dists: k=%d must be in [1, n-1=%d]", k, n - 1);
     GA_REQUIRE(n <= ROW_MAX_N, "knn_dists: more than %d points per cloud are not supported (n=%d)", ROW_MAX_N, n);
     GA_REQUIRE(b <= 65535, "knn_dists: batch %d exceeds 65535", b);
+    return GEOADV_OK;
+}
+
+extern "C" size_t geoadv_knn_workspace_bytes(int b, int n, int m, int k) {
+    if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return 256;
+    return knn_fast_scratch_bytes(b, n, m) + 256;          // (+ 256: the workspace pointer is aligned up here)
+}
+
+static char *ws_align(void *p) { return reinterpret_cast<char *>((reinterpret_cast<size_t>(p) + 255) & ~(size_t)255); }
+
+extern "C" int geoadv_knn_point_ws(int kernel, int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = knn_mode_check("knn_point", kernel)) return rc;
+    if (int rc = knn_point_check(b, n, m, k)) return rc;
+    if (b == 0 || m == 0) return GEOADV_OK;
+    GA_REQUIRE(xyz1 && xyz2 && val && idx, "knn_point: null pointer");
+    GA_REQUIRE(workspace && workspace_bytes >= geoadv_knn_workspace_bytes(b, n, m, k), "knn_point: workspace too small (%zu bytes, need %zu)",
+               workspace_bytes, geoadv_knn_workspace_bytes(b, n, m, k));
+    return launch_knn(0, kernel, b, n, m, k, xyz1, xyz2, val, idx, ws_align(workspace), as_stream(stream));
+}
+
+extern "C" int geoadv_knn_dists_ws(int kernel, int b, int n, int k, const float *pc, float *out, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
+    if (int rc = knn_mode_check("knn_dists", kernel)) return rc;
+    if (int rc = knn_dists_check(b, n, k)) return rc;
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(pc && out, "knn_dists: null pointer");
-    return launch_knn(1, b, n, n, k + 1, pc, pc, out, nullptr, as_stream(stream));
+    GA_REQUIRE(workspace && workspace_bytes >= geoadv_knn_workspace_bytes(b, n, n, k + 1), "knn_dists: workspace too small (%zu bytes, need %zu)",
+               workspace_bytes, geoadv_knn_workspace_bytes(b, n, n, k + 1));
+    return launch_knn(1, kernel, b, n, n, k + 1, pc, pc, out, nullptr, ws_align(workspace), as_stream(stream));
+}
+
+// The reference-shaped entry points (tf_grouping.py:48-75 has no scratch argument): thin conveniences over the _ws forms with
+// stream-ordered scratch (hipMallocAsync / hipFreeAsync on the caller's stream) and the process-default kernel selection.
+static int knn_with_own_scratch(int mode, int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx, hipStream_t st) {
+    char *scratch = nullptr;
+    if (knn_list_kernels(mode, b, m, k)) GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), knn_fast_scratch_bytes(b, n, m), st));
+    const int rc = launch_knn(mode, g_knn_default_mode.load(), b, n, m, k, xyz1, xyz2, val, idx, scratch, st);
+    if (scratch) GA_HIP(hipFreeAsync(scratch, st));
+    return rc;
+}
+
+extern "C" int geoadv_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                                void *stream) {
+    if (int rc = knn_point_check(b, n, m, k)) return rc;
+    if (b == 0 || m == 0) return GEOADV_OK;
+    GA_REQUIRE(xyz1 && xyz2 && val && idx, "knn_point: null pointer");
+    return knn_with_own_scratch(0, b, n, m, k, xyz1, xyz2, val, idx, as_stream(stream));
+}
+
+extern "C" int geoadv_knn_dists(int b, int n, int k, const float *pc, float *out, void *stream) {
+    if (int rc = knn_dists_check(b, n, k)) return rc;
+    if (b == 0) return GEOADV_OK;
+    GA_REQUIRE(pc && out, "knn_dists: null pointer");
+    return knn_with_own_scratch(1, b, n, n, k + 1, pc, pc, out, nullptr, as_stream(stream));
 }
 
 extern "C" int geoadv_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
@@ -1370,28 +1437,32 @@ extern "C" int geoadv_group_point(int b, int n, int c, int m, int nsample, const
     return GEOADV_OK;
 }
 
-extern "C" int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
-                                       float *grad_points, void *stream) {
+static void gpg_shape(int n, int m, int nsample, int &entries, int &segs, int &seg_len, int &passes) {
+    entries = m * nsample;
+    // segments of >= 16 groups of 64 entries, at most 64 of them per cloud
+    segs = std::max(1, std::min(64, entries / (64 * 16)));
+    seg_len = cdiv(cdiv(entries, segs), 64) * 64;
+    passes = 1;
+    while ((n >> (6 * passes)) != 0) ++passes;              // destinations 0 .. n (n = invalid)
+}
+// two (keys, perm) buffers, the (digit, segment) table, start[b][n + 1]
+static size_t gpg_scratch_ints(int b, int n, int m, int nsample) {
+    int entries, segs, seg_len, passes;
+    gpg_shape(n, m, nsample, entries, segs, seg_len, passes);
+    return 4 * (size_t)b * entries + (size_t)b * (64 * segs + 1) + (size_t)b * (n + 1);
+}
+static int gpg_check(int b, int n, int c, int m, int nsample) {
     GA_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 0 && nsample >= 0, "group_point_grad: negative dimension");
     GA_REQUIRE(b <= 65535, "group_point_grad: batch %d exceeds 65535", b);
-    if ((size_t)b * n * c == 0) return GEOADV_OK;
-    GA_REQUIRE(grad_points && (m * nsample == 0 || (grad_out && idx)), "group_point_grad: null pointer");
     GA_REQUIRE((size_t)m * nsample < ((size_t)1 << 30), "group_point_grad: m * nsample too large");
-    hipStream_t st = as_stream(stream);
-    const int entries = m * nsample;
-    if (entries == 0) {
-        GA_HIP(hipMemsetAsync(grad_points, 0, (size_t)b * n * c * sizeof(float), st));        // tf_grouping.cpp:204
-        return GEOADV_OK;
-    }
-    // segments of >= 16 groups of 64 entries, at most 64 of them per cloud
-    const int segs = std::max(1, std::min(64, entries / (64 * 16)));
-    const int seg_len = cdiv(cdiv(entries, segs), 64) * 64;
-    int passes = 1;
-    while ((n >> (6 * passes)) != 0) ++passes;              // destinations 0 .. n (n = invalid)
-    // stream-ordered scratch: two (keys, perm) buffers, the (digit, segment) table, start[b][n + 1]
-    const size_t per = (size_t)b * entries, table_ints = (size_t)b * (64 * segs + 1), start_ints = (size_t)b * (n + 1);
-    int *scratch = nullptr;
-    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), (4 * per + table_ints + start_ints) * sizeof(int), st));
+    return GEOADV_OK;
+}
+
+static int launch_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx, float *grad_points,
+                                   int *scratch, hipStream_t st) {
+    int entries, segs, seg_len, passes;
+    gpg_shape(n, m, nsample, entries, segs, seg_len, passes);
+    const size_t per = (size_t)b * entries, table_ints = (size_t)b * (64 * segs + 1);
     int *keys[2] = {scratch, scratch + per}, *perm[2] = {scratch + 2 * per, scratch + 3 * per};
     int *table = scratch + 4 * per, *start = table + table_ints;
     const dim3 grid(cdiv(segs, GPG_WAVES), b);
@@ -1405,9 +1476,46 @@ extern "C" int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, 
     }
     gpg_bounds_kernel<<<dim3(cdiv(n + 1, 256), b), 256, 0, st>>>(n, entries, kin, start);
     gpg_sum_kernel<<<dim3(cdiv(n * c, 256), b), 256, 0, st>>>(n, c, entries, grad_out, start, pin, grad_points);
-    const hipError_t err = hipGetLastError();
-    GA_HIP(hipFreeAsync(scratch, st));
-    GA_HIP(err);
+    GA_LAUNCH_CHECK();
     return GEOADV_OK;
+}
+
+extern "C" size_t geoadv_group_point_grad_workspace_bytes(int b, int n, int c, int m, int nsample) {
+    (void)c;
+    if (b <= 0 || n < 0 || m <= 0 || nsample <= 0) return 256;
+    return sizeof(int) * gpg_scratch_ints(b, n, m, nsample) + 256;
+}
+
+extern "C" int geoadv_group_point_grad_ws(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                                          float *grad_points, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = gpg_check(b, n, c, m, nsample)) return rc;
+    if ((size_t)b * n * c == 0) return GEOADV_OK;
+    GA_REQUIRE(grad_points && (m * nsample == 0 || (grad_out && idx)), "group_point_grad: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (m * nsample == 0) {
+        GA_HIP(hipMemsetAsync(grad_points, 0, (size_t)b * n * c * sizeof(float), st));        // tf_grouping.cpp:204
+        return GEOADV_OK;
+    }
+    GA_REQUIRE(workspace && workspace_bytes >= geoadv_group_point_grad_workspace_bytes(b, n, c, m, nsample),
+               "group_point_grad: workspace too small (%zu bytes, need %zu)", workspace_bytes, geoadv_group_point_grad_workspace_bytes(b, n, c, m, nsample));
+    return launch_group_point_grad(b, n, c, m, nsample, grad_out, idx, grad_points, reinterpret_cast<int *>(ws_align(workspace)), st);
+}
+
+// reference-shaped (groupPointGradLauncher has no scratch argument): stream-ordered scratch of its own
+extern "C" int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                                       float *grad_points, void *stream) {
+    if (int rc = gpg_check(b, n, c, m, nsample)) return rc;
+    if ((size_t)b * n * c == 0) return GEOADV_OK;
+    GA_REQUIRE(grad_points && (m * nsample == 0 || (grad_out && idx)), "group_point_grad: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (m * nsample == 0) {
+        GA_HIP(hipMemsetAsync(grad_points, 0, (size_t)b * n * c * sizeof(float), st));        // tf_grouping.cpp:204
+        return GEOADV_OK;
+    }
+    int *scratch = nullptr;
+    GA_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), sizeof(int) * gpg_scratch_ints(b, n, m, nsample), st));
+    const int rc = launch_group_point_grad(b, n, c, m, nsample, grad_out, idx, grad_points, scratch, st);
+    GA_HIP(hipFreeAsync(scratch, st));
+    return rc;
 }
 GA_STAMPS_GETTER(geoadv_debug_stamps_grouping)

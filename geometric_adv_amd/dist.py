@@ -55,7 +55,13 @@ def init(backend=None, single_rank_group=False, timeout_s=None):
             # a one-rank group needs no network rendezvous: a file store in a fresh temporary directory (no port to pick, so no
             # race with another process taking it between the pick and the bind)
             import tempfile
-            kw["init_method"] = "file://" + os.path.join(tempfile.mkdtemp(prefix="geoadv_pg_"), "store")
+            import atexit
+            import shutil
+            store_dir = tempfile.mkdtemp(prefix="geoadv_pg_")
+            kw["init_method"] = "file://" + os.path.join(store_dir, "store")
+            # removed when the process ends, not right after init: RCCL creates its communicator lazily and passes the unique
+            # id through this store at the first collective
+            atexit.register(shutil.rmtree, store_dir, ignore_errors=True)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 

@@ -222,40 +222,65 @@ def group_point_grad(points, idx, grad_out):
         raise ValueError("GroupPointGrad expects grad_out of shape (batch, npoint, nsample, channel)")
     gp = torch.empty_like(points)
     with torch.cuda.device(points.device):
-        _call("geoadv_group_point_grad", b, n, c, m, ns, _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(gp))
+        wb = int(_lib.lib().geoadv_group_point_grad_workspace_bytes(b, n, c, m, ns))
+        ws = torch.empty(wb, dtype=torch.uint8, device=points.device)       # caller-owned scratch (torch's caching allocator)
+        _call("geoadv_group_point_grad_ws", b, n, c, m, ns, _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(gp), _lib.ptr(ws), C.c_size_t(wb))
     return gp
 
 
-def knn_point(k, xyz1, xyz2):
+KNN_KERNELS = {"auto": 0, "all_points": 1, "grid": 2, "grid_shells": 3}     # include/geoadv.h GEOADV_KNN_*
+_knn_default = "auto"
+
+
+def _knn_kernel(kernel):
+    k = _knn_default if kernel is None else kernel
+    if k not in KNN_KERNELS:
+        raise ValueError("kernel must be one of %s" % sorted(KNN_KERNELS))
+    return KNN_KERNELS[k]
+
+
+def knn_point(k, xyz1, xyz2, kernel=None):
     """tf_grouping.py:48-75.  xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries -> val (b,m,k) squared
     distances ascending, idx (b,m,k) int32 -- fused (no (b,m,n) matrix), same order among equal
-    distances as the reference's SelectionSort."""
+    distances as the reference's SelectionSort.
+    kernel: which kernel answers THIS call -- "auto" (by size), "all_points", "grid", "grid_shells" (same results; None = the
+    default set by knn_grid_mode).  The scratch is a torch tensor (caller-owned workspace of the C ABI's _ws form)."""
     xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "knn_point")
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
     val = torch.empty((b, m, int(k)), dtype=torch.float32, device=xyz1.device)
     idx = torch.empty((b, m, int(k)), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
-        _call("geoadv_knn_point", b, n, m, int(k), _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(val), _lib.ptr(idx))
+        wb = int(_lib.lib().geoadv_knn_workspace_bytes(b, n, m, int(k)))
+        ws = torch.empty(wb, dtype=torch.uint8, device=xyz1.device)
+        _call("geoadv_knn_point_ws", _knn_kernel(kernel), b, n, m, int(k), _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(val), _lib.ptr(idx),
+              _lib.ptr(ws), C.c_size_t(wb))
     return val, idx
 
 
 def knn_grid_mode(mode):
-    """Process-wide choice of the k-NN kernel (include/geoadv.h: geoadv_knn_grid_mode): "auto" (by size), "all_points", "grid",
-    "grid_shells" (the grid search without its lane-private first pass: the wave-uniform shell walk for every query)."""
-    _lib.check(_lib.lib().geoadv_knn_grid_mode({"auto": 0, "all_points": 1, "grid": 2, "grid_shells": 3}[mode]), "knn_grid_mode")
+    """TESTS / MEASUREMENTS: the default k-NN kernel of this module's calls that pass no `kernel` ("auto" by size, "all_points",
+    "grid", "grid_shells" = the grid search without its lane-private first pass) -- and of the C ABI's reference-shaped entry
+    points (geoadv_knn_grid_mode).  Concurrent callers pass `kernel=` per call instead."""
+    global _knn_default
+    if mode not in KNN_KERNELS:
+        raise ValueError("mode must be one of %s" % sorted(KNN_KERNELS))
+    _lib.check(_lib.lib().geoadv_knn_grid_mode(KNN_KERNELS[mode]), "knn_grid_mode")
+    _knn_default = mode
 
 
-def knn_dists(pc, num_knn):
+def knn_dists(pc, num_knn, kernel=None):
     """The graph of defender/get_knn_dists_per_point.py:78-81 fused: distances (not squared) from
-    every point to its num_knn nearest neighbours, self dropped.  pc (b,n,3) -> (b,n,num_knn)."""
+    every point to its num_knn nearest neighbours, self dropped.  pc (b,n,3) -> (b,n,num_knn).  kernel: as knn_point."""
     pc = _f32(pc, "pc", 3)
     if pc.shape[2] != 3:
         raise ValueError("knn_dists only accepts 3d point sets")
     b, n, _ = pc.shape
     out = torch.empty((b, n, int(num_knn)), dtype=torch.float32, device=pc.device)
     with torch.cuda.device(pc.device):
-        _call("geoadv_knn_dists", b, n, int(num_knn), _lib.ptr(pc), _lib.ptr(out))
+        wb = int(_lib.lib().geoadv_knn_workspace_bytes(b, n, n, int(num_knn) + 1))
+        ws = torch.empty(wb, dtype=torch.uint8, device=pc.device)
+        _call("geoadv_knn_dists_ws", _knn_kernel(kernel), b, n, int(num_knn), _lib.ptr(pc), _lib.ptr(out), _lib.ptr(ws), C.c_size_t(wb))
     return out
 
 
@@ -317,19 +342,25 @@ def critical_split(point_clouds, max_val, max_idx):
 # external/structural_losses/tf_approxmatch.py
 # ---------------------------------------------------------------------------------------------
 EMD_FAST, EMD_REFERENCE = 0, 1          # include/geoadv.h: how the pair weight expf(level * d2) is evaluated
+EMD_DENSE_LEVELS = 0x100                # ... | this flag: every sweep of the call dense (no cell-grid form of the first three levels)
 
 
 def emd_sparse_levels(on):
-    """Process-wide: the sparse (cell-grid) form of the first three EMD levels' sweeps on (default) / off (include/geoadv.h)."""
+    """TESTS / MEASUREMENTS: the process default of EMD calls that pass no `dense_levels` (include/geoadv.h)."""
     _lib.check(_lib.lib().geoadv_emd_sparse_levels(int(bool(on))), "emd_sparse_levels")
 
 
-def approx_match(xyz1, xyz2, reference_weights=False):
+def _emd_mode(reference_weights, dense_levels):
+    return (EMD_REFERENCE if reference_weights else EMD_FAST) | (EMD_DENSE_LEVELS if dense_levels else 0)
+
+
+def approx_match(xyz1, xyz2, reference_weights=False, dense_levels=False):
     """tf_approxmatch.py:10-18.  xyz1 (b,n,3), xyz2 (b,m,3) -> match (b,m,n): match[b,l,k] is the
     soft assignment between xyz2 point l and xyz1 point k (the reference GPU op's layout; the CPU
     op writes the transpose into the same declared shape).  Level schedule of the CPU op.
     reference_weights: every pair weight bit for bit the CPU op's (GEOADV_EMD_REFERENCE: every plan entry within ~2 float
-    ulps of the CPU op, ~3.7x the time) instead of the fp32 fast form (typically 1e-6, rare entries 1e-4 relative)."""
+    ulps of the CPU op, ~3.7x the time) instead of the fp32 fast form (typically 1e-6, rare entries 1e-4 relative).
+    dense_levels: every sweep of THIS call dense (per call; the results differ only in the order of fp64 additions)."""
     xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "ApproxMatch")
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
@@ -337,7 +368,7 @@ def approx_match(xyz1, xyz2, reference_weights=False):
     with torch.cuda.device(xyz1.device):
         nf = _lib.lib().geoadv_approx_match_temp_floats(b, n, m)
         temp = torch.empty(int(nf), dtype=torch.float32, device=xyz1.device)
-        _call("geoadv_approx_match_mode", EMD_REFERENCE if reference_weights else EMD_FAST, b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2),
+        _call("geoadv_approx_match_mode", _emd_mode(reference_weights, dense_levels), b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2),
               _lib.ptr(match), _lib.ptr(temp))
     return match
 
@@ -357,7 +388,9 @@ def match_cost(xyz1, xyz2, match):
     xyz1, xyz2, match, b, n, m = _match_args(xyz1, xyz2, match, "MatchCost")
     cost = torch.empty((b,), dtype=torch.float32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
-        _call("geoadv_match_cost", b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(cost))
+        wf = int(_lib.lib().geoadv_match_cost_workspace_floats(b, n, m))
+        ws = torch.empty(wf, dtype=torch.float32, device=xyz1.device)
+        _call("geoadv_match_cost_ws", b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(cost), _lib.ptr(ws), C.c_size_t(wf))
     return cost
 
 
@@ -372,7 +405,7 @@ def match_cost_grad(xyz1, xyz2, match):
     return g1, g2
 
 
-def emd_cost_grad1(xyz1, xyz2, reference_weights=False):
+def emd_cost_grad1(xyz1, xyz2, reference_weights=False, dense_levels=False):
     """match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) and its gradient w.r.t. xyz1 with the plan held constant, without
     materialising the (b,m,n) plan -- the fused form the attack loop uses.  -> (cost (b,), grad1 (b,n,3))."""
     xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "ApproxMatch")
@@ -383,7 +416,7 @@ def emd_cost_grad1(xyz1, xyz2, reference_weights=False):
     with torch.cuda.device(xyz1.device):
         nf = _lib.lib().geoadv_emd_cost_grad1_temp_floats(b, n, m)
         temp = torch.empty(int(nf), dtype=torch.float32, device=xyz1.device)
-        _call("geoadv_emd_cost_grad1_mode", EMD_REFERENCE if reference_weights else EMD_FAST, b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2),
+        _call("geoadv_emd_cost_grad1_mode", _emd_mode(reference_weights, dense_levels), b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2),
               _lib.ptr(cost), _lib.ptr(g1), _lib.ptr(temp))
     return cost, g1
 

@@ -105,15 +105,24 @@ int geoadv_approx_match(int b, int n, int m, const float *xyz1, const float *xyz
  * geoadv_approx_match / geoadv_emd_cost_grad1 are the FAST mode. */
 #define GEOADV_EMD_FAST 0
 #define GEOADV_EMD_REFERENCE 1
+/* OR-ed into a `mode` argument (and into geoadv_attack_config.emd_weight_mode): every sweep of THIS call in its dense form -- the
+ * first three levels' sweeps (level = -4^8, -4^7, -4^6: weights exactly 0 beyond 0.04 / 0.08 / 0.16) otherwise walk a cell grid
+ * instead of every pair (csrc/emd.hip, "Sparse levels").  The results differ only in the order of fp64 additions. */
+#define GEOADV_EMD_DENSE_LEVELS 0x100
 int geoadv_approx_match_mode(int mode, int b, int n, int m, const float *xyz1, const float *xyz2,
                              float *match, float *temp, void *stream);
-/* The first three levels' sweeps (level = -4^8, -4^7, -4^6: weights exactly 0 beyond 0.04 / 0.08 / 0.16) walk a cell grid instead
- * of every pair (csrc/emd.hip, "Sparse levels"); on != 0 (default) / 0 = every sweep dense.  PROCESS-WIDE, for the parity tests and
- * measurements, which run both: the results differ only in the order of fp64 additions. */
+/* TEST / MEASUREMENT ONLY: the process default of calls whose mode carries no GEOADV_EMD_DENSE_LEVELS flag (on != 0, the default:
+ * sparse first levels; 0: every sweep dense).  An atomic word read at launch time -- a process that wants one behaviour for one
+ * call or handle passes the flag instead; this setter is not meant to be flipped while other threads launch. */
 int geoadv_emd_sparse_levels(int on);
-/* matchcostLauncher (tf_approxmatch.cpp:142; tf_approxmatch_g.cu:183-227): out[b]. */
+/* matchcostLauncher (tf_approxmatch.cpp:142; tf_approxmatch_g.cu:183-227): out[b].  The reference's launcher has no scratch
+ * argument: this form takes stream-ordered scratch of its own (hipMallocAsync on `stream`); geoadv_match_cost_ws is the same op on
+ * caller-owned scratch of geoadv_match_cost_workspace_floats(b,n,m) floats. */
 int geoadv_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *out, void *stream);
+size_t geoadv_match_cost_workspace_floats(int b, int n, int m);
+int geoadv_match_cost_ws(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *out,
+                         float *workspace, size_t workspace_floats, void *stream);
 /* match_cost and match_cost_grad w.r.t. xyz1 of the plan approx_match(xyz1, xyz2) WITHOUT materialising the plan: what a
  * caller that treats the plan as a constant (ApproxMatch is NoGradient, tf_approxmatch.py:19) and differentiates w.r.t.
  * xyz1 only needs -- the attack loop's Chamfer+EMD loss.  cost[b], grad1[b,n,3]; temp: scratch of
@@ -147,19 +156,36 @@ int geoadv_group_point(int b, int n, int c, int m, int nsample, const float *poi
  * tf_grouping.cpp:204) and accumulated in a fixed order (no float atomics). */
 int geoadv_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
                             float *grad_points, void *stream);
+/* ... on caller-owned scratch (geoadv_group_point_grad_workspace_bytes bytes) instead of the stream-ordered allocation the
+ * reference-shaped form above makes (its launcher prototype has no scratch argument). */
+size_t geoadv_group_point_grad_workspace_bytes(int b, int n, int c, int m, int nsample);
+int geoadv_group_point_grad_ws(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                               float *grad_points, void *workspace, size_t workspace_bytes, void *stream);
 /* knn_point(k, xyz1, xyz2) (tf_grouping.py:48-75) fused: squared distances + the k smallest per
  * query in the order SelectionSort produces (incl. its swap tie rule), without the (b,m,n)
  * matrix or the two tiled (b,m,n,3) operands.  val, idx are (b,m,k).  1 <= k <= 64. */
 int geoadv_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2,
                      float *val, int *idx, void *stream);
-/* Which kernel answers geoadv_knn_point / geoadv_knn_dists for k <= 16 -- PROCESS-WIDE, meant for the parity tests and the
- * measurements, which run both on the same inputs: 0 (default) = by size (datasets of >= 512 points: the exact grid search,
- * smaller ones: the all-points kernel), 1 = the all-points kernel only, 2 = the grid search at every size, 3 = as 2 without the
- * search's lane-private first pass (every query by the wave-uniform shell walk).  Same results. */
-int geoadv_knn_grid_mode(int mode);
 /* defender/get_knn_dists_per_point.py:78-81 fused: knn_point(k+1, pc, pc), drop the first column,
  * gather, euclidean distance.  out is (b,n,k). */
 int geoadv_knn_dists(int b, int n, int k, const float *pc, float *out, void *stream);
+/* Which kernel answers a k-NN call with k <= 16 (same results, bit for bit): */
+#define GEOADV_KNN_AUTO        0   /* by size: datasets of >= 512 points the exact grid search, smaller ones the all-points kernel */
+#define GEOADV_KNN_ALL_POINTS  1
+#define GEOADV_KNN_GRID        2   /* the grid search at every size                                                               */
+#define GEOADV_KNN_GRID_SHELLS 3   /* as GRID without the lane-private first pass (every query by the wave-uniform shell walk)     */
+/* The two ops with the kernel selected PER CALL (`kernel` = GEOADV_KNN_*) on caller-owned scratch of
+ * geoadv_knn_workspace_bytes(b,n,m,k) bytes (knn_dists: m = n and k + 1 neighbours) -- no allocation, nothing process-wide: what
+ * concurrent host threads call.  The reference-shaped forms above (tf_grouping.py:48-75 has no scratch argument) allocate
+ * stream-ordered scratch per call and follow the process default below. */
+size_t geoadv_knn_workspace_bytes(int b, int n, int m, int k);
+int geoadv_knn_point_ws(int kernel, int b, int n, int m, int k, const float *xyz1, const float *xyz2,
+                        float *val, int *idx, void *workspace, size_t workspace_bytes, void *stream);
+int geoadv_knn_dists_ws(int kernel, int b, int n, int k, const float *pc, float *out,
+                        void *workspace, size_t workspace_bytes, void *stream);
+/* TEST / MEASUREMENT ONLY: the process default (GEOADV_KNN_*) of geoadv_knn_point / geoadv_knn_dists; an atomic word read at
+ * launch time, not meant to be flipped while other threads launch -- those pass `kernel` to the _ws forms. */
+int geoadv_knn_grid_mode(int mode);
 
 /* get_outlier_pc_inlier_pc (src/adversary_utils.py:149-178) on the device, fused with the score its caller forms
  * (defender/run_defense_surface.py:187-191: the mean of the first top_k kNN distances of a point): a point is an outlier if
@@ -253,7 +279,8 @@ typedef struct geoadv_attack_config {
                                      * up to 4 clouds of 2048 points (GEOADV_SMALL_BATCH_POINTS: the ONE threshold that also switches
                                      * encoder_backward = AUTO and chamfer_kernel = AUTO) -- where the all-pairs kernel alone is as fast; 1: always the all-pairs kernel; 2: the grid search
                                      * at every size.  Same results.                                                      */
-    int   emd_weight_mode;          /* GEOADV_EMD_FAST (0, default) or GEOADV_EMD_REFERENCE for the EMD term's plan       */
+    int   emd_weight_mode;          /* GEOADV_EMD_FAST (0, default) or GEOADV_EMD_REFERENCE for the EMD term's plan,
+                                     * optionally | GEOADV_EMD_DENSE_LEVELS (this handle's EMD sweeps all dense)            */
     /* Alternative code paths with the same results, selected explicitly (never by the environment); all 0 = defaults.
      * The parity tests run every one of them against the default path.                                                */
     int   recompute_backward;       /* 1: the sparse encoder backward re-runs the forward for the critical rows instead
