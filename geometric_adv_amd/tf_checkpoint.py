@@ -11,9 +11,12 @@ MI355X image, so `restore_ae_model` here reads the two files of the bundle direc
 Restated from the published format (tensorflow/core/util/tensor_bundle/tensor_bundle.{h,cc},
 tensorflow/core/lib/io/{table,block,format}.cc, tensorflow/core/protobuf/tensor_bundle.proto at the
 pinned tensorflow-gpu==1.13.2, requirements.txt:107).  No checkpoint ships with the reference
-(download_models_and_data.sh fetches them), so this reader is **unpinned against a TF-written file**:
-the tests round-trip it against `write_checkpoint` below, which follows the same published layout
-(prefix-compressed keys with restart points, masked CRC32C block trailers and per-tensor checksums).
+(download_models_and_data.sh fetches them), so this reader is **unpinned against a TF-written file**.
+What can be pinned without TensorFlow is (tests/test_tf_checkpoint_pins.py): CRC-32C and its masking against the
+published known answers (RFC 3720 B.4 = LevelDB's crc32c_test.cc), and the reader against a two-shard bundle whose
+index BYTES are written out in the test from the published layouts (prefix-compressed keys with a restart array,
+block trailers, protobuf wire format of BundleHeaderProto / BundleEntryProto, footer, a Snappy block with literal and
+copy elements) -- not produced by `write_checkpoint` below, which the other tests round-trip.
 Both the uncompressed blocks TF's BundleWriter emits and Snappy-compressed blocks are accepted.
 """
 import os
