@@ -36,8 +36,8 @@ B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
-PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r04_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
+PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r05_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 SWEEP_BATCHES = (16, 8, 4)                 # what a rank of the strong-scaling leg runs at 2 / 4 / 8 GPUs: timed in THIS run (small_batch_sweep)
 
@@ -199,9 +199,11 @@ def pmc_encoder():
 
 
 def pmc_chamfer(alg_bytes):
-    """Counter-measured HBM-side traffic of nn_distance(recon, target) in the loop: chamfer_sym_kernel + chamfer_sym_finish_kernel,
-    (2 * FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 halves wide reads; separate --pmc passes of tools/attack_breakdown.py 32,
-    i.e. ONE leg: the pruned loop) and the profiled kernel times of the same passes.  Dropped when the kernel sources changed."""
+    """Counter-measured HBM-side traffic of nn_distance(recon, target) in the loop: chamfer_sym_kernel (column minima resolved inside
+    the workgroup, row minima out as per-slice partials) + the part of loss_cgrad_kernel's reads that merges them is NOT split out:
+    the scan kernel alone is summed here, and loss_cgrad_kernel's bytes are listed beside it.  (2 * FETCH_SIZE + WRITE_SIZE) KiB per
+    launch (gfx950 halves wide reads; separate --pmc passes of tools/attack_breakdown.py 32, i.e. ONE leg: the pruned loop) and the
+    profiled kernel times of the same passes.  Dropped when the kernel sources changed."""
     try:
         d = json.load(open(PMC_CHAMFER_FILE))
     except Exception as e:
@@ -210,18 +212,21 @@ def pmc_chamfer(alg_bytes):
     if not want or source_hashes(sorted(want)) != want:
         return {"traffic": None, "traffic_source": "%s was taken at different kernel sources: dropped" % os.path.basename(PMC_CHAMFER_FILE)}
     tot, us, per = 0.0, 0.0, {}
-    for key in ("chamfer_sym_kernel", "chamfer_sym_finish_kernel"):
+    for key, counted in (("chamfer_sym_kernel", True), ("loss_cgrad_kernel", False)):
         names = [n for n in d if n.endswith(key)]
         if not names or "FETCH_SIZE" not in d[names[0]] or "WRITE_SIZE" not in d[names[0]]:
             return {"traffic": None, "traffic_source": "%s lacks FETCH_SIZE / WRITE_SIZE for %s" % (os.path.basename(PMC_CHAMFER_FILE), key)}
         k = d[names[0]]
         b = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
         per[key] = {"bytes_per_launch": b, "avg_us_profiled": k.get("avg_us_profiled")}
-        tot += b
-        us += k.get("avg_us_profiled") or 0.0
+        if counted:
+            tot += b
+            us += k.get("avg_us_profiled") or 0.0
     return {"traffic": tot, "traffic_over_algorithmic": tot / alg_bytes, "achieved_hbm_GBps_counters": (tot / (us * 1e-6) / 1e9) if us else None,
-            "per_kernel": per, "traffic_source": "profiles/%s: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of both kernels, separate --pmc passes "
-                                                 "of tools/attack_breakdown.py 32 (the pruned loop only)" % os.path.basename(PMC_CHAMFER_FILE)}
+            "per_kernel": per, "traffic_source": "profiles/%s: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of chamfer_sym_kernel (with the paired "
+                                                 "search and the pool Jacobian riding in it), separate --pmc passes of tools/attack_breakdown.py 32 "
+                                                 "(the pruned loop only); loss_cgrad_kernel -- which folds the scan's row partials on its way in, "
+                                                 "beside its own losses and gradients -- listed, not summed" % os.path.basename(PMC_CHAMFER_FILE)}
 
 
 def surface_clouds(seed, b, n):
@@ -596,7 +601,7 @@ def config3_leg(dev, emd):
     return out
 
 
-PMC_CHAMFER_8192 = os.path.join(ROOT, "profiles", "r04_pmc_chamfer_n8192.json")
+PMC_CHAMFER_8192 = os.path.join(ROOT, "profiles", "r05_pmc_chamfer_n8192.json")
 
 
 def config4_leg(dev):
@@ -624,12 +629,12 @@ def config4_leg(dev):
             at.profile(False)
             ch_ms = br["chamfer_fwd"]
             alg = 20.0 * b * (n + n)
-            traffic, note = pmc_file_traffic(PMC_CHAMFER_8192, ("chamfer_sym_kernel", "chamfer_sym_finish_kernel"), ("chamfer_sym.hip",))
+            traffic, note = pmc_file_traffic(PMC_CHAMFER_8192, ("chamfer_sym_kernel", "chamfer_sym_merge_kernel"), ("chamfer_sym.hip",))
             pairs = 2.0 * b * n * n
             bound_ms = (pairs / 2) / 64.0 * 8 * VALU_CYC / (SIMDS * CLOCK_HZ) * 1e3     # one distance evaluation serves both directions
             out["encoder_fwd"] = {"avg_launch_ms": enc_ms, "frac_of_fp32_mfma_peak": enc_frac}
             out["kernel_ms_per_iteration"] = br
-            out["roofline_chamfer"] = {"bound": "valu issue", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel: nn_distance(recon, target) at N = 8192 "
+            out["roofline_chamfer"] = {"bound": "valu issue", "kernel": "chamfer_sym_kernel + chamfer_sym_merge_kernel: nn_distance(recon, target) at N = 8192 "
                                        "(the paired search for nn_distance(adv, x) in a launch of its own at this size)",
                                        "scan_plus_finish_class_ms": ch_ms, "achieved_Tpair_per_s": pairs / (ch_ms * 1e-3) / 1e12,
                                        "issue_bound_ms": bound_ms, "frac": bound_ms / ch_ms,
@@ -1011,10 +1016,17 @@ def main():
                      "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop,
                      "timing": "kernel begin/end stamps (hipExtLaunchKernel start/stop events) of every %s launch inside the "
                                "timed windows" % ("" if stride == 1 else {2: "2nd", 3: "3rd"}.get(stride, "%d-th" % stride))},
-        "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_sym_kernel + chamfer_sym_finish_kernel: nn_distance(recon, target), both "
-                                                         "directions from one distance evaluation per pair; nn_distance(adv, x) is answered "
-                                                         "exactly by the paired grid search, whose workgroups ride in the scan's launch",
+        "roofline_chamfer": {"bound": "valu", "kernel": "chamfer_sym_kernel: nn_distance(recon, target), both directions from one distance "
+                                                         "evaluation per pair, column minima and indices resolved inside the workgroup, row "
+                                                         "minima merged by the loss launch (no second Chamfer launch); nn_distance(adv, x) is "
+                                                         "answered exactly by the paired grid search, whose workgroups ride in the scan's launch "
+                                                         "beside the encoder's pool Jacobian",
                              "avg_class_ms": ch_avg_ms, "launches_timed": 50,
+                             "issue_bound_ms": (ch_pairs / 2) / 64.0 * 8 * VALU_CYC / (SIMDS * CLOCK_HZ) * 1e3,
+                             "frac": (ch_pairs / 2) / 64.0 * 8 * VALU_CYC / (SIMDS * CLOCK_HZ) * 1e3 / ch_avg_ms,
+                             "bound_note": "headline shape (B = 32, N = 2048): 8 unfused fp32 VALU instructions per distance (the reference's "
+                                           "rounding), every distance evaluated once for both directions, %.2f issue cycles per wave instruction, "
+                                           "%d SIMDs, %.1f GHz; the class time carries the two riders too" % (VALU_CYC, SIMDS, CLOCK_HZ / 1e9),
                              "achieved_Tpair_per_s": ch_pairs / (ch_avg_ms * 1e-3) / 1e12,
                              "algorithmic_bytes_per_launch": ch_bytes,
                              "achieved_hbm_GBps": ch_bytes / (ch_avg_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS,

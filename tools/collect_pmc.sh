@@ -3,13 +3,13 @@
 # --pmc: MI355X_MICROARCH.md / rocprofv3 PMC slots).  Usage: tools/collect_pmc.sh OUTDIR [ROUND]
 #   <ROUND>_pmc_encoder.json      bench command: SQ issue counters, MFMA busy + GRBM, FETCH_SIZE, WRITE_SIZE (hashes encoder.hip, mfma_tile.h)
 #   <ROUND>_pmc_chamfer_hbm.json  tools/attack_breakdown.py 32 (the pruned loop, ONE leg): FETCH_SIZE, WRITE_SIZE, SQ issue counters
-#                                 of chamfer_sym_kernel / chamfer_sym_finish_kernel (hashes chamfer_sym.hip, chamfer_grid.h)
+#                                 of chamfer_sym_kernel / loss_cgrad_kernel (hashes chamfer_sym.hip, chamfer_grid.h)
 #   <ROUND>_pmc_emd.json          tools/emd_attack_time.py 32: SQ issue counters
 #   <ROUND>_pmc_knn.json          tools/debug/knn_only.py (knn_dists at 256 x 2048, all-points and grid kernels): SQ counters, FETCH / WRITE
 #   <ROUND>_bench_kernel_stats.csv, <ROUND>_loop_b32_kernel_stats.csv   --kernel-trace --stats of the two commands
 set -u
 OUT=${1:-gpurun_out/pmc}
-R=${2:-r04}
+R=${2:-r05}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # the headline leg only: no secondary legs, no RCCL self-test child (a second profiled process on the GPU whose CSVs the summary
