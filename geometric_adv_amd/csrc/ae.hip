@@ -12,7 +12,8 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
                        const FusedAdam *fused = nullptr);
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
-int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
+int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream, unsigned long long *fill = nullptr,
+                       size_t fill_count = 0);
 int launch_latent_fc(const DeviceAE &A, int b, const float *z, float *d2, hipStream_t stream);
 int encoder_tiles_max(int n);
 

@@ -49,7 +49,8 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
 int encoder_mask_words();
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream);
-int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream);
+int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream, unsigned long long *fill = nullptr,
+                       size_t fill_count = 0);
 int launch_decoder_bwd(const DeviceAE &A, int b, const float *g_recon, const float *d1, const float *d2, float *partial,
                        float *dz, hipStream_t stream, const int *crit = nullptr, const float *jac = nullptr, const int *dense = nullptr,
                        float *g_enc = nullptr);
@@ -143,9 +144,16 @@ __device__ __forceinline__ void loss_premerge(const LossArgs &a, const int b, co
     const bool part3 = a.a1_all || (a.a1_need && sym_needed(a.a1_need, b));
     const size_t sl = (size_t)a.part.slices * n, o = (size_t)b * n;
     const float *p1 = a.part.rowpart_d + (size_t)b * sl, *p3 = a.part.rowpart_d + ((size_t)B + b) * sl;
+    const unsigned long long *w1 = a.part.row64 + o, *w3 = a.part.row64 + (size_t)B * n + o;      // packed form (small batches)
     for (int j = threadIdx.x; j < n; j += nthreads) {
-        const float v1 = sym_merge_min(p1 + j, a.part.slices, n);
-        const float v3 = part3 ? sym_merge_min(p3 + j, a.part.slices, n) : 0.f;
+        float v1, v3 = 0.f;
+        if (a.part.row64) {
+            v1 = __uint_as_float((unsigned)(w1[j] >> 32));
+            if (part3) v3 = __uint_as_float((unsigned)(w3[j] >> 32));
+        } else {
+            v1 = sym_merge_min(p1 + j, a.part.slices, n);
+            if (part3) v3 = sym_merge_min(p3 + j, a.part.slices, n);
+        }
         m1[j] = v1; a.r1_out[o + j] = v1;
         if (part3) { m3[j] = v3; a.a1_out[o + j] = v3; }
     }
@@ -314,9 +322,10 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
     const float g2 = gd * 2;
     const float *p = pr.p + (size_t)b * n * 3, *q = pr.q + (size_t)b * n * 3;
     const int *i1 = pr.idx1 + (size_t)b * n, *i2 = pr.idx2 + (size_t)b * n;
-    const bool part = pr.part_d && (!pr.part_need || sym_needed(pr.part_need, b));          // (uniform)
+    const bool part = (pr.part_d || pr.part_w) && (!pr.part_need || sym_needed(pr.part_need, b));          // (uniform)
     const float *pd = pr.part_d + (size_t)b * pr.part_slices * n;
     const int *pi_ = pr.part_i + (size_t)b * pr.part_slices * n;
+    const unsigned long long *pw = pr.part_w + (size_t)b * n;
     const int js = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
     const int range = (n + H - 1) / H;
     const int j_lo = h * range, j_hi = min(n, j_lo + range);
@@ -325,7 +334,13 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
     // scatter phase below) when one pass covers them (n <= 2048 on 512 threads: always, where partials exist)
     const bool pre = part && (j_hi - j_lo) <= U * CGA_THREADS;
     int mpre[U];
-    if (pre) {
+    if (pre && pr.part_w) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j_lo + threadIdx.x + u * CGA_THREADS;
+            mpre[u] = j < j_hi ? (int)(unsigned)pw[j] : 0;
+        }
+    } else if (pre) {
         int sl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -338,6 +353,8 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
             const int j = j_lo + threadIdx.x + u * CGA_THREADS;
             mpre[u] = j < j_hi ? pi_[(size_t)sl[u] * n + j] : 0;
         }
+    }
+    if (pre) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j_lo + threadIdx.x + u * CGA_THREADS;
@@ -385,7 +402,8 @@ __device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, 
                 mj[u] = 0;
                 if (j0 + u * CGA_THREADS < j_hi) {
                     float d_;
-                    sym_merge_slices(pd + j0 + u * CGA_THREADS, pi_ + j0 + u * CGA_THREADS, pr.part_slices, n, d_, mj[u]);
+                    if (pr.part_w) mj[u] = (int)(unsigned)pw[j0 + u * CGA_THREADS];
+                    else sym_merge_slices(pd + j0 + u * CGA_THREADS, pi_ + j0 + u * CGA_THREADS, pr.part_slices, n, d_, mj[u]);
                     pr.idx1_out[(size_t)b * n + j0 + u * CGA_THREADS] = mj[u];
                 }
             }
@@ -535,7 +553,9 @@ struct geoadv_attack {
     float *losses; int *jstar;
     float *best_err, *best_metrics, *best_adv, *best_recon;
     float *emd_temp, *emd_cost, *emd_g1;   // only when cfg.emd_weight > 0
-    float *sym_ws;                   // column-minimum partials of the symmetric Chamfer kernel
+    float *sym_ws;                   // row / column partials of the symmetric Chamfer kernel
+    unsigned long long *row64;       // [2][B][n] packed row minima of the symmetric scan's atomic form (small batches, chamfer_sym.h)
+    bool row64_filled;               // ... set to all ones by this forward's FC2 launch
     bool cgrad_done;                 // the cached forward's loss launch also produced the Chamfer gradients
     bool chamfer_prune;              // nn_distance(adv, x) through the paired grid search (cfg.all_pairs_source_dist = 0, the default)
     int *need_adv[2];                // [8 B] each: clouds the grid search handed back to the all-pairs kernel.  When the search
@@ -650,6 +670,14 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     // (chamfer_grid.hip) answers it for a fraction of the all-pairs cost; clouds whose pairing has become poor raise
     // their `need` flag and are redone by the all-pairs launch below (same results either way)
     const bool pruned = at->chamfer_prune && chamfer_grid_supports(n, n);
+    const bool adv_chamfer = at->cfg.loss_adv_type == GEOADV_LOSS_ADV_CHAMFER;
+    const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
+    const bool max_term = dist_chamfer && at->cfg.max_point_dist_weight > 0.f;   // the gradient needs the loss pass's arg-max first
+    const bool loss_fused = (adv_chamfer || dist_chamfer) && !max_term && n <= CG_FX_MAX_N_PLANE;   // loss_cgrad_kernel below
+    const bool merge_in_loss = loss_fused && adv_chamfer && dist_chamfer;
+    // narrow column slices (small batches): row minima folded into packed words by atomics; the FC2 launch fills them on its way
+    const bool use_row64 = merge_in_loss && at->chamfer_sym && at->row64 != nullptr;
+    SymPartials part{nullptr, nullptr, 1, B, false, use_row64 ? at->row64 : nullptr};
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st, true);
         if (int rc = launch_encoder_fwd(A, B, at->x, at->pert, (at->adv_valid && !at->adam_pending) ? nullptr : at->adv, at->fs.pmax,
@@ -684,18 +712,12 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
                                                        at->ia2, n, need_new, call, at->x_box, st)) return rc;
         } else if (int rc = launch_latent_decode(A, B, at->fs.pmax, at->fs.parg, at->fs.pcnt, at->fs.z, at->fs.crit, at->fs.zcnt,
                                                  at->fs.dense, at->fs.d1, at->fs.d2, st)) return rc;
-        if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st)) return rc;
+        if (int rc = launch_decoder_fc2(A, B, at->fs.d2, at->recon, st, use_row64 ? at->row64 : nullptr, use_row64 ? 2 * (size_t)B * n : 0)) return rc;
     }
     // The pool Jacobian of THIS forward (the next step's encoder backward, encoder_jac.h) beside the symmetric scan.  Where the
     // two-scan kernel runs instead (small batches) there is no launch long enough to hide it in, and as a launch of its own
     // (8.2 us + the 3.6 us look for tied clouds + two boundaries) it costs what the masked backward costs (11.6 us + one): those
     // batches keep the masked backward.
-    const bool adv_chamfer = at->cfg.loss_adv_type == GEOADV_LOSS_ADV_CHAMFER;
-    const bool dist_chamfer = at->cfg.loss_dist_type == GEOADV_LOSS_DIST_CHAMFER;
-    const bool max_term = dist_chamfer && at->cfg.max_point_dist_weight > 0.f;   // the gradient needs the loss pass's arg-max first
-    const bool loss_fused = (adv_chamfer || dist_chamfer) && !max_term && n <= CG_FX_MAX_N_PLANE;   // loss_cgrad_kernel below
-    const bool merge_in_loss = loss_fused && adv_chamfer && dist_chamfer;
-    SymPartials part{nullptr, nullptr, 1, B, false};
     const JacArgs jargs{n, at->masks, at->fs.crit, at->fs.z, at->fs.dense, at->jac};
     const bool jac_rides = at->jac && at->chamfer_sym;
     at->jac_valid = jac_rides;
@@ -745,7 +767,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
             ca.pr[np] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
             if (part.deferred) {
                 ca.pr[np].part_d = part.rowpart_d; ca.pr[np].part_i = part.rowpart_i; ca.pr[np].part_slices = part.slices;
-                ca.pr[np].part_need = nullptr; ca.pr[np].idx1_out = at->ir1;
+                ca.pr[np].part_need = nullptr; ca.pr[np].idx1_out = at->ir1; ca.pr[np].part_w = part.row64;
             }
             ++np;
         }
@@ -755,6 +777,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
                 const size_t off = (size_t)B * part.slices * n;
                 ca.pr[np].part_d = part.rowpart_d + off; ca.pr[np].part_i = part.rowpart_i + off; ca.pr[np].part_slices = part.slices;
                 ca.pr[np].part_need = pruned ? need_scan : nullptr; ca.pr[np].idx1_out = at->ia1;
+                ca.pr[np].part_w = part.row64 ? part.row64 + (size_t)B * n : nullptr;
             }
             ++np;
         }
@@ -922,6 +945,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     need(4 * B); need(4 * B * 4); need(4 * bn3); need(4 * bn3);
     const size_t sym_floats = chamfer_sym_workspace_floats(2, at->B, at->n, at->n);
     need(4 * sym_floats);
+    need(8 * 2 * bn);                                     // row64
     const size_t mask_words = cfg->recompute_backward ? 0 : (size_t)encoder_mask_words() * bn;   // ReLU masks of the cached forward
     need(4 * mask_words);
     const bool use_jac = mask_words != 0 && cfg->loss_adv_type == GEOADV_LOSS_ADV_CHAMFER && cfg->encoder_backward != GEOADV_ENC_BWD_MASKED;
@@ -954,6 +978,7 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->losses = F(4 * 8 * B); at->jstar = I(4 * 2 * B);
     at->best_err = F(4 * B); at->best_metrics = F(4 * B * 4); at->best_adv = F(4 * bn3); at->best_recon = F(4 * bn3);
     at->sym_ws = F(4 * sym_floats);
+    at->row64 = reinterpret_cast<unsigned long long *>(take(8 * 2 * bn));
     at->masks = mask_words ? reinterpret_cast<unsigned *>(take(4 * mask_words)) : nullptr;
     at->jac = use_jac ? F(4 * B * 128 * 3) : nullptr;
     at->jac_valid = false;
@@ -974,12 +999,15 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     // (all_pairs_source_dist 2 = the search whatever the size: the parity tests' small shapes)
     at->chamfer_prune = cfg->all_pairs_source_dist == 2 || (cfg->all_pairs_source_dist == 0 && (long)at->B * at->n >= GEOADV_SMALL_BATCH_POINTS);
     {
-        // The symmetric scan + its finish launch against the public op's plain scans in ONE launch (both directions of (recon,
-        // target), and of (adv, source) only for clouds the grid search handed back).  Since the grid search and the encoder's
-        // pool Jacobian ride in the symmetric scan's launch (round 3) it wins from B = 5 on (ms per iteration, plain /
-        // symmetric: B = 4: 0.0748 / 0.0757, 8: 0.0935 / 0.0925, 12: 0.1143 / 0.1055, 16: 0.1263 / 0.1252, 24: 0.1673 / 0.1529,
-        // 32: 0.1913 / 0.1773; later build, B = 4: 0.0749 / 0.0743, 5: 0.0909 / 0.0846, 6: 0.0916 / 0.0850); below, launches are fixed latency and the plain form has one fewer.  Same bits either way.
-        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n >= GEOADV_SMALL_BATCH_POINTS
+        // The symmetric scan against the public op's plain scans in ONE launch (both directions of (recon, target), and of (adv,
+        // source) only for clouds the grid search handed back).  Until round 4 it needed a finish launch and won from B = 5 on
+        // (ms per iteration, plain / symmetric: B = 4: 0.0749 / 0.0743, 5: 0.0909 / 0.0846, 8: 0.0935 / 0.0925, 32: 0.1913 / 0.1773).
+        // Round 5: the column minima are resolved inside the scan and the row minima reach the loss launch as per-slice partials or
+        // -- narrow slices, i.e. these small batches -- as packed words folded by 64-bit atomic minima, so the symmetric form is ONE
+        // Chamfer launch at every size and carries the encoder's pool Jacobian (no masked backward launch): plain / symmetric
+        // B = 2: 0.0675 / 0.0647, 3: 0.0736 / 0.0657, 4: 0.0743 / 0.0660, 5: 0.0917 / 0.0776, 8: 0.0933 / 0.0792, 16: 0.1262 / 0.1070
+        // (profiles/r05_small_batch_paths.jsonl).  Same bits either way.
+        at->chamfer_sym = cfg->chamfer_kernel == GEOADV_CHAMFER_AUTO ? (long)at->B * at->n >= GEOADV_SYM_MIN_POINTS
                                                                      : cfg->chamfer_kernel == GEOADV_CHAMFER_SYMMETRIC;
     }
     at->emd_temp = at->emd_cost = at->emd_g1 = nullptr;

@@ -13,11 +13,16 @@ struct ChamferPair {
 // What launch_chamfer_sym_loop leaves to the caller's next launch when asked to (`defer`): the row minima as one
 // (distance, index) partial per column slice -- [pair][cloud][slice][n] -- whose lexicographic minimum is dist1 / idx1.
 // deferred == false: dist1 / idx1 are final in the pairs' own arrays (one slice, or the merge launch ran).
+// row64 (narrow column slices, i.e. small batches: more than 8 partials per row would cost a merge launch or a heavy consumer):
+// the scan instead folds every (row, slice) into ONE packed word per row -- (distance bits << 32) | index, 64-bit unsigned atomic
+// minimum: squared distances are >= +0, so the order of the words is the lexicographic order of (distance, index) -- in
+// row64[pair][cloud][n], which must hold all ones when the scan starts (the loop's FC2 launch fills it on its way).
 struct SymPartials {
     const float *rowpart_d;
     const int *rowpart_i;
     int slices, clouds;
     bool deferred;
+    unsigned long long *row64;       // in: the caller's packed buffer (or null: never use the atomic form); out: null unless used
 };
 
 #ifdef __HIPCC__
@@ -49,6 +54,9 @@ __device__ __forceinline__ void sym_merge_slices(const float *d, const int *i, i
     od = sym_merge_pick(d, slices, stride, s);
     oi = i[(size_t)s * stride];
 }
+__device__ __forceinline__ unsigned long long sym_pack(float d, int i) {
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+}
 // the distance alone
 __device__ __forceinline__ float sym_merge_min(const float *d, int slices, size_t stride) {
     float bd = d[0];
@@ -74,6 +82,7 @@ struct CGradProblem {
     // idx1 still as the symmetric scan's (distance, index) partials per column slice (null: idx1 is final); this kernel then
     // takes their lexicographic minimum on its way in and leaves it in idx1_out.  part_need: only the clouds flagged there.
     const float *part_d; const int *part_i; int part_slices; const int *part_need; int *idx1_out;
+    const unsigned long long *part_w;      // ... or as packed (distance, index) words [B][n] (SymPartials::row64): the index is the low half
 };
 int launch_chamfer_grad(const CGradProblem *pr, int np, int B, int n, hipStream_t st);
 

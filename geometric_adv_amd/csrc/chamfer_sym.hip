@@ -45,6 +45,7 @@ struct ChamferSymArgs {
     int *rowpart_i;
     float *colpart_d;          // [pairs][clouds][rtiles][m]        column minima per row super-tile (rtiles > 1 only)
     int *colpart_i;
+    unsigned long long *row64; // [pairs][clouds][n] packed row minima folded with 64-bit atomic minima (or null: the partials above)
     const int *need[2];        // per pair: null = every cloud; else int[8 * clouds], cloud c is computed only if one of
                                // its 8 flags is set (a workgroup of the paired grid search, chamfer_grid.hip, gave up)
     GridRider rider;           // the attack loop: the paired grid search of (adv, source) as extra workgroups of the scan launch
@@ -228,6 +229,8 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
             if (rslices == 1) {
                 pr.dist1[(size_t)c * n + j] = best[r];
                 pr.idx1[(size_t)c * n + j] = f;
+            } else if (a.row64) {   // narrow slices: one packed word per row, folded at the memory side (no return value: fire and forget)
+                atomicMin(&a.row64[((size_t)pi * a.clouds + c) * n + j], sym_pack(best[r], f));
             } else {   // lexicographic (distance, index) minimum over the slices: chamfer_sym_merge_kernel or the loop's loss launch
                 const size_t o = (((size_t)pi * a.clouds + c) * rslices + (cs * a.cw + cwi)) * n + j;
                 a.rowpart_d[o] = best[r];
@@ -361,7 +364,8 @@ int launch_chamfer_sym_loop(const ChamferPair *pairs, int np, int b, int n, int 
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
                           int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider, const JacRider *jac,
                           SymPartials *defer) {
-    if (defer) { defer->slices = 1; defer->rowpart_d = nullptr; defer->rowpart_i = nullptr; defer->clouds = b; defer->deferred = false; }
+    unsigned long long *row64 = defer ? defer->row64 : nullptr;
+    if (defer) { defer->slices = 1; defer->rowpart_d = nullptr; defer->rowpart_i = nullptr; defer->clouds = b; defer->deferred = false; defer->row64 = nullptr; }
     if (b <= 0 || np <= 0) return GEOADV_OK;
     ChamferSymArgs a;
     a.need[0] = nullptr; a.need[1] = need1;
@@ -378,6 +382,8 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     a.rowpart_i = reinterpret_cast<int *>(workspace + groups * rslices * n);
     a.colpart_d = workspace + 2 * groups * rslices * n;
     a.colpart_i = reinterpret_cast<int *>(a.colpart_d + groups * s.rtiles * m);
+    // more than 8 row partials per row (narrow slices: small batches) and a caller that reads packed words: atomic form
+    a.row64 = (defer && row64 && s.rtiles == 1 && rslices > 8) ? row64 : nullptr;
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -408,6 +414,10 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     chamfer_sym_kernel<<<grid, CS_THREADS, scan_lds, stream>>>(a);
     GA_LAUNCH_CHECK();
     if (rslices == 1 && s.rtiles == 1) return GEOADV_OK;  // both sides left the scan final
+    if (a.row64) {                                         // the caller's next launch unpacks the folded words on its way in
+        defer->deferred = true; defer->slices = 0; defer->row64 = a.row64;
+        return GEOADV_OK;
+    }
     // the caller's next launch merges the row partials on its way in -- up to 8 slices: a cloud's partials are read by ONE
     // workgroup there (64 KB of distances at 8 slices, ~100 GB/s per CU); the narrow slices of small batches keep the merge launch
     if (defer && s.rtiles == 1 && rslices <= 8) {

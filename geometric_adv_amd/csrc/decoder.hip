@@ -212,7 +212,14 @@ __device__ __forceinline__ void decoder_fc2_block(const DeviceAE &A, int batch, 
     GA_STAMP(2, 7);
 }
 
-__global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch, const float *d2, float *out) {
+// fill / fill_count: words this launch also sets to all ones on its way (the symmetric Chamfer scan's packed row minima, which the
+// scan of the SAME forward folds into with 64-bit atomic minima: chamfer_sym.hip) -- no launch of their own
+__global__ __launch_bounds__(256) void decoder_fc2_kernel(DeviceAE A, int batch, const float *d2, float *out, unsigned long long *fill,
+                                                         size_t fill_count) {
+    if (fill) {
+        const size_t stride = (size_t)gridDim.x * gridDim.y * 256;
+        for (size_t e = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; e < fill_count; e += stride) fill[e] = ~0ull;
+    }
     decoder_fc2_block(A, batch, d2, out, blockIdx.x, blockIdx.y);
 }
 
@@ -313,9 +320,9 @@ int launch_latent_fc(const DeviceAE &A, int b, const float *z, float *d2, hipStr
     return GEOADV_OK;
 }
 
-int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream) {
+int launch_decoder_fc2(const DeviceAE &A, int b, const float *d2, float *recon, hipStream_t stream, unsigned long long *fill, size_t fill_count) {
     if (b <= 0) return GEOADV_OK;
-    decoder_fc2_kernel<<<dim3(A.dec2_fwd.N / 32, cdiv(b, 32)), 256, 0, stream>>>(A, b, d2, recon);
+    decoder_fc2_kernel<<<dim3(A.dec2_fwd.N / 32, cdiv(b, 32)), 256, 0, stream>>>(A, b, d2, recon, fill, fill_count);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -152,7 +152,7 @@ def attack_sharded(adv_ae, source_pc, target_latent, target_pc, target_ae_loss_r
     other slots.  Every batch's optimum is the same problem either way; only the trajectory differs.
     "Bit for bit" holds at equal Configuration: every kernel sums a cloud's numbers in an order fixed by the cloud alone
     (tests/test_gpu_attack.py::test_trajectory_of_a_cloud_does_not_depend_on_its_batch), but encoder_backward="auto"
-    picks the masked backward while batch * n_points < 10240 (GEOADV_SMALL_BATCH_POINTS, include/geoadv.h: up to 4 clouds of 2048
+    picks the masked backward while batch * n_points < 4096 (GEOADV_SYM_MIN_POINTS, include/geoadv.h: one cloud of 2048
     points) and the pool Jacobian from there on, and those two forms
     agree to rounding only: pin encoder_backward when shards of different batch size must reproduce each other exactly."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)

@@ -276,9 +276,8 @@ typedef struct geoadv_attack_config {
     float emd_weight;               /* build-defined: loss_adv += emd_weight*match_cost/N; 0 = off */
     int   all_pairs_source_dist;    /* 0 (default): nn_distance(adv, x) by the exact paired grid search, falling back per
                                      * cloud to the all-pairs kernel, except for tiny batches -- batch * n_points < 10240, i.e.
-                                     * up to 4 clouds of 2048 points (GEOADV_SMALL_BATCH_POINTS: the ONE threshold that also switches
-                                     * encoder_backward = AUTO and chamfer_kernel = AUTO) -- where the all-pairs kernel alone is as fast; 1: always the all-pairs kernel; 2: the grid search
-                                     * at every size.  Same results.                                                      */
+                                     * up to 4 clouds of 2048 points (GEOADV_SMALL_BATCH_POINTS) -- where the all-pairs kernel alone
+                                     * is as fast; 1: always the all-pairs kernel; 2: the grid search at every size.  Same results. */
     int   emd_weight_mode;          /* GEOADV_EMD_FAST (0, default) or GEOADV_EMD_REFERENCE for the EMD term's plan,
                                      * optionally | GEOADV_EMD_DENSE_LEVELS (this handle's EMD sweeps all dense)            */
     /* Alternative code paths with the same results, selected explicitly (never by the environment); all 0 = defaults.
@@ -291,10 +290,13 @@ typedef struct geoadv_attack_config {
                                      * the Jacobian (a launch of its own where nothing hosts it).  Equal to rounding.       */
     int   separate_adam;            /* 1: the Adam step is its own launch (the path loss_dist_type 'pert' always takes)
                                      * instead of riding in the next forward's point loaders                           */
-    int   chamfer_kernel;           /* GEOADV_CHAMFER_AUTO (0: by batch size), _TWO_SCAN (the public op's kernel),
+    int   chamfer_kernel;           /* GEOADV_CHAMFER_AUTO (0: by batch size, GEOADV_SYM_MIN_POINTS), _TWO_SCAN (the public op's kernel),
                                      * _SYMMETRIC (one evaluation per pair serves both directions)                      */
 } geoadv_attack_config;
-#define GEOADV_SMALL_BATCH_POINTS 10240  /* batch * n_points below this: two-scan Chamfer kernel, masked encoder backward, no grid search */
+#define GEOADV_SMALL_BATCH_POINTS 10240  /* batch * n_points below this: no paired grid search (all_pairs_source_dist = 0)                    */
+#define GEOADV_SYM_MIN_POINTS      4096  /* batch * n_points from this on: chamfer_kernel AUTO = the symmetric scan, and with it
+                                          * encoder_backward AUTO = the pool Jacobian (it rides in that scan's launch); below: the two-scan
+                                          * kernel and the masked backward                                                               */
 #define GEOADV_ENC_BWD_AUTO      0
 #define GEOADV_ENC_BWD_MASKED    1
 #define GEOADV_ENC_BWD_JACOBIAN  2

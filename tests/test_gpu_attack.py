@@ -363,9 +363,9 @@ def test_trajectory_of_a_cloud_does_not_depend_on_its_batch(n, form):
     pool Jacobian) uses 16-row tiles at every batch size, the Chamfer results are exact -- so the perturbation of a cloud after
     8 iterations is bit-identical whether it is attacked in a batch of 8, 32 or 40.  (What does change the bits: the backward
     FORM -- masked vs Jacobian agree to rounding, test_jacobian_backward_equals_masked_backward -- which `auto` picks by
-    batch size -- batch * n_points below / from GEOADV_SMALL_BATCH_POINTS = 10240 (include/geoadv.h), i.e. up to 4 / from 5 clouds
+    batch size -- batch * n_points below / from GEOADV_SYM_MIN_POINTS = 4096 (include/geoadv.h), i.e. one cloud / from two clouds
     of 2048 points; the bit-for-bit statements of dist.py / run_attack.py hold at equal
-    configuration.)"""
+    configuration.)  Batches of 2 and 4 ride along: the symmetric scan's atomic row-minimum form (narrow column slices)."""
     import torch
     from geometric_adv_amd import weights as W
     from geometric_adv_amd.autoencoder import PointNetAE
@@ -375,7 +375,7 @@ def test_trajectory_of_a_cloud_does_not_depend_on_its_batch(n, form):
     x, gt = _clouds(91, 40, n)
     p0 = (1e-3 * np.random.default_rng(3).standard_normal((40, n, 3))).astype(np.float32)
     outs = {}
-    for b in (8, 32, 40):
+    for b in (2, 4, 8, 32, 40):
         at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=8, num_iterations_thresh=3,
                                               encoder_backward=form), ae=ae)
         at.set_inputs(x[:b], gt[:b], None, 1.0)
@@ -384,6 +384,7 @@ def test_trajectory_of_a_cloud_does_not_depend_on_its_batch(n, form):
         outs[b] = at.peek()["pert"][:8].clone()
     assert outs[8].abs().max() > 0
     assert torch.equal(outs[8], outs[32]) and torch.equal(outs[8], outs[40])
+    assert torch.equal(outs[2], outs[8][:2]) and torch.equal(outs[4], outs[8][:4])
 
 
 @pytest.mark.parametrize("kernel", ["symmetric", "two_scan"])

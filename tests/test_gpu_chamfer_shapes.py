@@ -65,11 +65,13 @@ def test_paired_grid_search_on_shapes(kind, n, scale):
 
 
 @pytest.mark.parametrize("kind", ["sphere", "clusters", "duplicates", "lattice"])
-@pytest.mark.parametrize("b", [32, 4])
+@pytest.mark.parametrize("b", [32, 16, 8, 4, 2])
 @pytest.mark.parametrize("prune", ["always", False])
 def test_attack_loop_indices_on_shapes(kind, b, prune):
-    """The loop's four index arrays after a few iterations on non-uniform clouds equal ops.nn_distance on the loop's own clouds:
-    B = 32 runs the symmetric scan + finish, B = 4 the gated two-scan kernel; prune on / off = grid search / all-pairs."""
+    """The loop's four index arrays after a few iterations on non-uniform clouds equal ops.nn_distance on the loop's own clouds, and
+    its loss_ae / input_dist rows the means of ops.nn_distance's distances: B = 32 runs the symmetric scan with its row partials
+    merged by the loss launch (8 column slices), B = 16 / 8 / 4 the same scan with narrow slices and the row minima folded into
+    packed words by 64-bit atomic minima, B = 2 the gated two-scan kernel; prune on / off = grid search / all-pairs."""
     import torch
     from geometric_adv_amd import ops, weights as W
     from geometric_adv_amd.adv_ae import AdvAE, Configuration
@@ -82,9 +84,14 @@ def test_attack_loop_indices_on_shapes(kind, b, prune):
                                   chamfer_prune=prune), ae=ae)
     at.set_inputs(x, gt, ae.transform(gt), 1.0)
     at.init_pert(None, reset_optimizer=True)
-    at.run(0, 4, 2)
+    hist = torch.empty((4, 6, b), device=ae.device)
+    at.run(0, 4, 2, hist)
     p = at.peek()
-    _, i1, _, i2 = ops.nn_distance(p["recon"], _t(gt))
+    d1, i1, d2, i2 = ops.nn_distance(p["recon"], _t(gt))
     assert torch.equal(p["idx_r1"], i1) and torch.equal(p["idx_r2"], i2)
-    _, j1, _, j2 = ops.nn_distance(p["adv"], _t(x))
+    e1, j1, e2, j2 = ops.nn_distance(p["adv"], _t(x))
     assert torch.equal(p["idx_a1"], j1) and torch.equal(p["idx_a2"], j2)
+    # the metric rows of the last iteration are sums of the same distances (fp32 sums in the loop's order: compare to fp64 means)
+    h = hist[-1].cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(h[5], (d1.double().mean(1) + d2.double().mean(1)).cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(h[4], (e1.double().mean(1) + e2.double().mean(1)).cpu().numpy(), rtol=2e-6, atol=1e-12)
