@@ -60,8 +60,9 @@ def parse_args():
                     help="(internal) child mode: bring up a ONE-rank RCCL group on cuda:0, run the collectives of the N > 1 path "
                          "on device tensors, print one JSON line")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip every secondary leg (other BASELINE configs, trained victim, training step, EMD, surfaces): the "
-                         "headline, its roofline and the CPU baseline only -- what the counter passes of tools/collect_pmc.sh run")
+                    help="skip every secondary leg (other BASELINE configs, trained victim, training step, EMD, surfaces) and the "
+                         "B = 16 / 8 / 4 windows of strong_scaling.measured_ms: the headline, its roofline and the CPU baseline only -- "
+                         "what the counter passes of tools/collect_pmc.sh run")
     ap.add_argument("--only-leg", choices=["config2", "config3", "config4", "trained_victim", "training", "emd", "surfaces"],
                     help="run ONE secondary leg alone on cuda:0 and print its JSON (what `rocprofv3 --kernel-trace --stats -- python3 "
                          "bench.py --only-leg X` profiles: tools/collect_legs.sh -> profiles/r04_leg_*_kernel_stats.csv)")
@@ -503,6 +504,30 @@ def _timed_attack(at, warm, iters):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
+def _timed_attack_windows(at, warm, iters, windows=5, prime_ms=60.0):
+    """ms per iteration as the headline measures it: `warm` untimed iterations, ~prime_ms of untimed windows (clock ramp, launch
+    queue), then the MEDIAN of `windows` windows of exactly `iters` iterations, each between synchronisations."""
+    import torch
+    at.run(0, warm, 10 ** 6)
+    torch.cuda.synchronize()
+
+    def one(first):
+        t0 = time.perf_counter()
+        at.run(first, iters, 10 ** 6)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    first = one(warm)
+    done = warm + iters
+    for _ in range(min(40, int(prime_ms * 1e-3 / max(first, 1e-4)))):
+        one(done)
+        done += iters
+    w = []
+    for _ in range(windows):
+        w.append(one(done))
+        done += iters
+    return median(w) / iters * 1e3
+
+
 def _encoder_frac(at, b, n, first, iters):
     """(avg launch ms, fraction of the fp32 MFMA peak) of the encoder forward from its own begin / end stamps."""
     import torch
@@ -678,7 +703,8 @@ def trained_victim_leg(dev, steps, warmup, train_steps=320):
     src, tgt = victim_shapes(rng, B, N), victim_shapes(rng, B, N)
     out = {"victim": "this package's trainer, %d steps of batch 50 on 400 synthetic ellipsoid / box surfaces (seed 0), lr 0.001; "
                      "final epoch loss %.5f" % (train_steps // 8 * 8, float(loss)),
-           "attack": "B=32 x N=2048, chamfer/chamfer, w=1, lr 0.01, %d warm-up + %d timed iterations" % (warmup, steps)}
+           "attack": "B=32 x N=2048, chamfer/chamfer, w=1, lr 0.01, %d warm-up iterations, then the headline's protocol: ~60 ms of "
+                     "untimed windows, median of 5 windows of %d iterations" % (warmup, steps)}
     for label, prune in (("grid_search", True), ("all_pairs", False)):
         at = AdvAE("adversary", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=warmup + steps,
                                               num_iterations_thresh=10 ** 6, learning_rate=0.01, chamfer_prune=prune), device=dev, ae=ae)
@@ -690,7 +716,7 @@ def trained_victim_leg(dev, steps, warmup, train_steps=320):
                 at.run(k * (warmup + steps) // 8, (warmup + steps) // 8, 10 ** 6)
                 hb.append(at.search_state()[1])
             at.init_pert(None, reset_optimizer=True)
-        ms_it = _timed_attack(at, warmup, steps)
+        ms_it = _timed_attack_windows(at, warmup, steps)
         out[label] = {"attack_iterations_per_sec": 1e3 / ms_it, "ms_per_step": ms_it}
         if prune:
             out[label]["clouds_handed_back_of_%d_along_the_attack" % B] = hb
@@ -699,7 +725,7 @@ def trained_victim_leg(dev, steps, warmup, train_steps=320):
             out["adaptive_default"] = {"search_switched_off": not getattr(at, "_search_on", True), "clouds_handed_back_at_decision": handed}
             if not getattr(at, "_search_on", True):
                 at.init_pert(None, reset_optimizer=True)
-                ms_ad = _timed_attack(at, warmup, steps)
+                ms_ad = _timed_attack_windows(at, warmup, steps)
                 out["adaptive_default"].update({"attack_iterations_per_sec": 1e3 / ms_ad, "ms_per_step": ms_ad})
             # parity of what the search answered (or handed to the all-pairs kernel) on the moved clouds, against the oracle
             from oracle.cpu_oracle import Oracle
@@ -957,7 +983,7 @@ def main():
         strong.update({"definition": "attack iterations/s on ONE global batch of 32 clouds split contiguously over the ranks "
                                      "(SURVEY 8e); every rank runs the whole loop on its 32/N clouds, final scalars all-gathered",
                        "global_batch": B, "batch_per_gpu": bs})
-        if world == 1:
+        if world == 1 and not args.no_secondary:       # (--no-secondary: the counter passes profile the headline launches only)
             # what a rank of the 2 / 4 / 8-GPU strong-scaled run executes, TIMED HERE (not a table): B = 16 / 8 / 4 on this GPU
             sweep = small_batch_sweep(dev, weights, ae, Wm, K, gdist, backend, dog)
             ms32 = dt / K * 1e3

@@ -123,7 +123,9 @@ class AdvAE:
     def set_inputs(self, source_pc, target_pc, target_latent, dist_weight):
         B, n = self.B, self.n
         x = self._dev(source_pc, (B, n, 3)); gt = self._dev(target_pc, (B, n, 3))
-        tz = None if target_latent is None else self._dev(target_latent, (B, 128))
+        tz = None if target_latent is None else self._dev(target_latent, (B, self.ae.bneck))
+        if tz is not None and self.ae.bneck != 128:             # the kernels' width: the absent channels are zeros on both sides
+            tz = torch.cat([tz, torch.zeros((B, 128 - self.ae.bneck), dtype=torch.float32, device=self.device)], dim=1).contiguous()
         w = self._dev(np.ones(B, np.float32) * dist_weight if np.isscalar(dist_weight) else dist_weight, (B,))
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_attack_set_inputs(self._h, _lib.ptr(x), _lib.ptr(gt), _lib.ptr(tz), _lib.ptr(w),
@@ -207,6 +209,8 @@ class AdvAE:
             _lib.check(_lib.lib().geoadv_attack_peek(self._h, *[_lib.ptr(out[k]) for k in
                        ("pert", "adv", "recon", "latent", "grad", "idx_r1", "idx_r2", "idx_a1", "idx_a2")],
                        _lib.stream_handle()), "attack_peek")
+        if self.ae.bneck != 128:
+            out["latent"] = out["latent"][:, :self.ae.bneck].contiguous()
         return out
 
     def profile(self, classes, stride=1):

@@ -30,9 +30,10 @@ class PointNetAE:
         if isinstance(weights, str):
             weights = W.load(weights, ae_name)
         self.n_points = int(n_points)
-        self.bneck = 128
         self.device = torch.device(device if device is not None else "cuda:0")
-        self._canon = W.canonical(weights, self.n_points, ae_name)     # keeps the host arrays alive
+        self._canon = W.canonical(weights, self.n_points, ae_name, pad_to=W.KERNEL_BNECK)     # keeps the host arrays alive
+        self.bneck = W.bneck_of(weights, ae_name)     # the model's own bottleneck size (<= 128: narrower ones run zero-padded)
+        self._kb = W.KERNEL_BNECK
         hw = _AEWeights()
         hw.n_points = self.n_points
         hw.enc_dims[:] = W.enc_dims()
@@ -72,10 +73,10 @@ class PointNetAE:
         return t
 
     def forward(self, pc, want_recon=True):
-        """pc (b,n,3) -> (recon (b,n,3) or None, latent (b,128)) as GPU tensors."""
+        """pc (b,n,3) -> (recon (b,n,3) or None, latent (b,bneck)) as GPU tensors."""
         pc = self._as_dev(pc)
         b = pc.shape[0]
-        latent = torch.empty((b, self.bneck), dtype=torch.float32, device=self.device)
+        latent = torch.empty((b, self._kb), dtype=torch.float32, device=self.device)
         recon = torch.empty((b, self.n_points, 3), dtype=torch.float32, device=self.device) if want_recon else None
         with torch.cuda.device(self.device):
             need = _lib.lib().geoadv_ae_workspace_bytes(self._h, b)
@@ -84,7 +85,7 @@ class PointNetAE:
             st = _lib.lib().geoadv_ae_forward(self._h, b, _lib.ptr(pc), _lib.ptr(latent), _lib.ptr(recon),
                                               _lib.ptr(self._ws), _lib.stream_handle())
         _lib.check(st, "ae_forward")
-        return recon, latent
+        return recon, (latent if self.bneck == self._kb else latent[:, :self.bneck].contiguous())
 
     def max_and_argmax(self, pc):
         """(max_val (b,128), max_idx (b,128) int32) of the last encoder layer over the points of each cloud:
@@ -92,8 +93,8 @@ class PointNetAE:
         (autoencoder.py:309-319), without ever materialising the (b, n, 128) pre-symmetry tensor."""
         pc = self._as_dev(pc)
         b = pc.shape[0]
-        latent = torch.empty((b, self.bneck), dtype=torch.float32, device=self.device)
-        idx = torch.empty((b, self.bneck), dtype=torch.int32, device=self.device)
+        latent = torch.empty((b, self._kb), dtype=torch.float32, device=self.device)
+        idx = torch.empty((b, self._kb), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             need = _lib.lib().geoadv_ae_workspace_bytes(self._h, b)
             if self._ws is None or self._ws.numel() < need:
@@ -101,6 +102,8 @@ class PointNetAE:
             st = _lib.lib().geoadv_ae_critical(self._h, b, _lib.ptr(pc), _lib.ptr(latent), _lib.ptr(idx),
                                                _lib.ptr(self._ws), _lib.stream_handle())
         _lib.check(st, "ae_critical")
+        if self.bneck != self._kb:
+            latent, idx = latent[:, :self.bneck].contiguous(), idx[:, :self.bneck].contiguous()
         return latent, idx
 
     # -- the reference's method names -----------------------------------------------------
@@ -134,6 +137,8 @@ class PointNetAE:
         if z.dim() != 2 or z.shape[1] != self.bneck:
             raise ValueError("latent codes must be of shape (batch, %d); got %s" % (self.bneck, tuple(z.shape)))
         b = z.shape[0]
+        if self.bneck != self._kb:                                # the absent channels are zeros (and meet zero decoder rows)
+            z = torch.cat([z, torch.zeros((b, self._kb - self.bneck), dtype=torch.float32, device=self.device)], dim=1).contiguous()
         recon = torch.empty((b, self.n_points, 3), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             need = _lib.lib().geoadv_ae_workspace_bytes(self._h, b)

@@ -15,6 +15,9 @@ import numpy as np
 ENC_FILTERS = [64, 128, 128, 256, 128]          # src/ae_templates.py:22 with bneck_size = 128
 DEC_SIZES = [256, 256]                          # src/ae_templates.py:29 (+ [n_points * 3])
 AE_NAME = "autoencoder"
+KERNEL_BNECK = 128                              # the width the kernels are compiled for (ae.hip).  mlp_architecture(n_pc_points,
+                                                # bneck_size, ...) (src/ae_templates.py:11-39) with bneck_size < 128 runs on them with
+                                                # the missing channels as EXACT zeros (canonical(pad_to=...)); larger ones are refused
 
 
 def enc_dims(bneck=128):
@@ -36,11 +39,11 @@ def variable_names(ae_name=AE_NAME):
     return names
 
 
-def synthetic_weights(n_points, seed=7, ae_name=AE_NAME):
+def synthetic_weights(n_points, seed=7, ae_name=AE_NAME, bneck=128):
     """Seeded random-init weights of the reference architecture (dict name -> float32 array)."""
     rng = np.random.default_rng(seed)
     w = {}
-    ed, dd = enc_dims(), dec_dims(n_points)
+    ed, dd = enc_dims(bneck), dec_dims(n_points, bneck)
     for i in range(5):
         cin, cout = ed[i], ed[i + 1]
         lim = np.sqrt(6.0 / (cin + cout))
@@ -60,9 +63,9 @@ def synthetic_weights(n_points, seed=7, ae_name=AE_NAME):
     return w
 
 
-def randomized_weights(n_points, seed=3, ae_name=AE_NAME):
+def randomized_weights(n_points, seed=3, ae_name=AE_NAME, bneck=128):
     """Like synthetic_weights but with non-trivial biases / BN offsets (stress for parity tests)."""
-    w = synthetic_weights(n_points, seed=seed, ae_name=ae_name)
+    w = synthetic_weights(n_points, seed=seed, ae_name=ae_name, bneck=bneck)
     rng = np.random.default_rng(seed + 1000)
     for name in list(w):
         if name.endswith("/b") or name.endswith("/beta"):
@@ -97,9 +100,28 @@ def load(path, ae_name=AE_NAME, restore_epoch=None):
     raise FileNotFoundError("%s is neither an .npz nor a TF V2 checkpoint prefix" % path)
 
 
-def canonical(weights, n_points, ae_name=AE_NAME):
-    """Validate and reshape to what geoadv_ae_create takes: lists of contiguous float32 arrays."""
-    ed, dd = enc_dims(), dec_dims(n_points)
+def bneck_of(weights, ae_name=AE_NAME):
+    """The bottleneck size of a set of weights: output channels of the last encoder layer."""
+    name = "%s/encoder_conv_layer_4/W" % ae_name
+    if name not in weights:
+        raise KeyError("missing variable %r (restore_ae_model needs every '%s/*' variable)" % (name, ae_name))
+    return int(np.asarray(weights[name]).shape[-1])
+
+
+def canonical(weights, n_points, ae_name=AE_NAME, pad_to=None):
+    """Validate and reshape to what geoadv_ae_create takes: lists of contiguous float32 arrays, at the weights' own bottleneck
+    size (mlp_architecture's bneck_size, src/ae_templates.py:11-39; bneck_of()).
+
+    pad_to (the kernels' compiled width, KERNEL_BNECK): a smaller bottleneck is widened with channels that are EXACT zeros for
+    every input -- zero weight columns and bias, BN gamma 1 / beta 0 / mean 0 / var 1 in the last encoder layer (relu(0 * s + 0) =
+    +0), zero rows in the first decoder layer -- so every real channel, the reconstruction and every gradient are computed by the
+    same instructions on the same numbers as at width bneck.  A zero channel is never a 'tied positive maximum' (decoder.hip) and
+    never a critical point (ae_utils.py:21 drops max_val == 0)."""
+    bneck = bneck_of(weights, ae_name)
+    if pad_to is not None and bneck > pad_to:
+        raise ValueError("bneck_size %d: the kernels are built for bottlenecks of up to %d channels (src/ae_templates.py:11-39 allows any; "
+                         "the reference's own scripts use 128, autoencoder/train_ae.py:45)" % (bneck, pad_to))
+    ed, dd = enc_dims(bneck), dec_dims(n_points, bneck)
     out = {"enc_w": [], "enc_b": [], "gamma": [], "beta": [], "mean": [], "var": [], "dec_w": [], "dec_b": []}
 
     def get(name, shape):
@@ -122,4 +144,14 @@ def canonical(weights, n_points, ae_name=AE_NAME):
         p = "%s/decoder_fc_%d" % (ae_name, k)
         out["dec_w"].append(get(p + "/W", (dd[k], dd[k + 1])))
         out["dec_b"].append(get(p + "/b", (dd[k + 1],)))
+    if pad_to is not None and bneck < pad_to:
+        extra = pad_to - bneck
+        z = lambda *shape: np.zeros(shape, np.float32)
+        out["enc_w"][4] = np.ascontiguousarray(np.concatenate([out["enc_w"][4], z(ed[4], extra)], axis=1))
+        out["enc_b"][4] = np.concatenate([out["enc_b"][4], z(extra)])
+        out["gamma"][4] = np.concatenate([out["gamma"][4], np.ones(extra, np.float32)])
+        out["beta"][4] = np.concatenate([out["beta"][4], z(extra)])
+        out["mean"][4] = np.concatenate([out["mean"][4], z(extra)])
+        out["var"][4] = np.concatenate([out["var"][4], np.ones(extra, np.float32)])
+        out["dec_w"][0] = np.ascontiguousarray(np.concatenate([out["dec_w"][0], z(extra, dd[1])], axis=0))
     return out

@@ -5,7 +5,7 @@
 # Usage: tools/collect_legs.sh OUTDIR [ROUND]
 set -u
 OUT=${1:-gpurun_out/legs}
-R=${2:-r04}
+R=${2:-r05}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for leg in config2 config3 config4 trained_victim training; do
