@@ -39,7 +39,7 @@ struct ChamferSymArgs {
     int n, m, clouds, pairs;
     int rw, cw;                // row-waves x column-waves of a workgroup (rw * cw == 8)
     int rtiles;                // row super-tiles of 256 * rw rows
-    int C, cslices;            // columns per workgroup (multiple of 16), column slices = cdiv(m, C)
+    int C, S, cslices;         // columns per stage (multiple of 16), stages per workgroup, column slices = cdiv(m, C * S)
     int pair_base, q_clouds;   // q_clouds > 0: cloud c is the pair (P cloud (pair_base+c)/q_clouds, Q cloud (pair_base+c)%q_clouds)
     float *rowpart_d;          // [pairs][clouds][cslices * cw][n]  row minima per column slice (absent when there is one slice)
     int *rowpart_i;
@@ -60,6 +60,7 @@ constexpr int CS_CHUNK = 8;                   // columns per arg-min chunk
 constexpr int CS_ROUND = 16;                  // columns per transpose round
 constexpr int CS_CMAX = 256;                  // columns per workgroup at most
 constexpr int CS_CMIN = 64;
+constexpr int CS_MAX_STAGES = 4;
 constexpr int CS_TSTRIDE = 68;                // floats per column in the transpose buffer (64 lanes + pad)
 constexpr int CS_SEG = CS_WROWS + 4;          // floats per wave segment of the rows staged for the index search: 16-B aligned, staggers the banks
 
@@ -135,159 +136,180 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
         px[r] = P[3 * j]; py[r] = P[3 * j + 1]; pz[r] = P[3 * j + 2];   // so the column minima are unaffected
         best[r] = INFINITY; bestk[r] = -1;
     }
-    const int cbeg = cs * a.C, cnt = min(a.C, m - cbeg);
-    const int cntp = (cnt + CS_ROUND - 1) / CS_ROUND * CS_ROUND;
-    for (int e = threadIdx.x; e < cntp; e += CS_THREADS) {
-        float x = INFINITY, y = INFINITY, z = INFINITY;
-        if (e < cnt) { x = Q[3 * (size_t)(cbeg + e)]; y = Q[3 * (size_t)(cbeg + e) + 1]; z = Q[3 * (size_t)(cbeg + e) + 2]; }
-        sx[e] = x; sy[e] = y; sz[e] = z;
-    }
-    __syncthreads();
     float *tb = tbase + wave * (CS_ROUND * CS_TSTRIDE);
     unsigned *cq4 = colq + (size_t)rwi * CS_CMAX * 4;
-    const int nrounds = cntp / CS_ROUND;
-    const int rbeg = nrounds * cwi / a.cw, rend = nrounds * (cwi + 1) / a.cw;
-    if (rbeg < rend) {
+    float *rx = tbase, *ry = tbase + CS_WAVES * CS_SEG, *rz = tbase + 2 * CS_WAVES * CS_SEG;   // the rows, staged for the index search
+    int found[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) bestk[r] = rbeg * CS_ROUND;
-    }
-    for (int rd = rbeg; rd < rend; ++rd) {
-        const int k0 = rd * CS_ROUND;
-        float colp[CS_ROUND];
+    for (int r = 0; r < R; ++r) found[r] = INT_MAX;
+    // A workgroup walks a.S column stages of a.C columns each with the same rows in registers (large clouds: the row loads, the
+    // row partials and the launch's workgroup count shrink by S; the headline shape has S = 1).  Columns staged for stage st + 1
+    // are REQUESTED before stage st's index search, so that their global round trip hides behind it.
+    float nx = INFINITY, ny = INFINITY, nz = INFINITY;     // this thread's column of the next stage (threads < C)
+    auto request = [&](int st) {
+        nx = ny = nz = INFINITY;
+        const int k = (cs * a.S + st) * a.C + (int)threadIdx.x;
+        if (st < a.S && (int)threadIdx.x < a.C && k < m) { nx = Q[3 * (size_t)k]; ny = Q[3 * (size_t)k + 1]; nz = Q[3 * (size_t)k + 2]; }
+    };
+    request(0);
+    for (int st = 0; st < a.S; ++st) {
+        const int cbeg = (cs * a.S + st) * a.C;
+        if (cbeg >= m) break;                              // (uniform)
+        const int cnt = min(a.C, m - cbeg);
+        const int cntp = (cnt + CS_ROUND - 1) / CS_ROUND * CS_ROUND;
+        if ((int)threadIdx.x < cntp) { sx[threadIdx.x] = nx; sy[threadIdx.x] = ny; sz[threadIdx.x] = nz; }   // (padding columns: +inf)
+        __syncthreads();
+        const int nrounds = cntp / CS_ROUND;
+        const int rbeg = nrounds * cwi / a.cw, rend = nrounds * (cwi + 1) / a.cw;
+        float prev[R];
 #pragma unroll
-        for (int hf = 0; hf < CS_ROUND / CS_CHUNK; ++hf) {
-            float tx[CS_CHUNK], ty[CS_CHUNK], tz[CS_CHUNK];
+        for (int r = 0; r < R; ++r) prev[r] = best[r];
+        if (st == 0 && rbeg < rend) {
 #pragma unroll
-            for (int v = 0; v < CS_CHUNK / 4; ++v) {
-                const float4 xa = *reinterpret_cast<const float4 *>(&sx[k0 + hf * CS_CHUNK + 4 * v]);
-                const float4 ya = *reinterpret_cast<const float4 *>(&sy[k0 + hf * CS_CHUNK + 4 * v]);
-                const float4 za = *reinterpret_cast<const float4 *>(&sz[k0 + hf * CS_CHUNK + 4 * v]);
-                tx[4 * v] = xa.x; tx[4 * v + 1] = xa.y; tx[4 * v + 2] = xa.z; tx[4 * v + 3] = xa.w;
-                ty[4 * v] = ya.x; ty[4 * v + 1] = ya.y; ty[4 * v + 2] = ya.z; ty[4 * v + 3] = ya.w;
-                tz[4 * v] = za.x; tz[4 * v + 1] = za.y; tz[4 * v + 2] = za.z; tz[4 * v + 3] = za.w;
+            for (int r = 0; r < R; ++r) bestk[r] = rbeg * CS_ROUND;
+        }
+        for (int rd = rbeg; rd < rend; ++rd) {
+            const int k0 = rd * CS_ROUND;
+            float colp[CS_ROUND];
+#pragma unroll
+            for (int hf = 0; hf < CS_ROUND / CS_CHUNK; ++hf) {
+                float tx[CS_CHUNK], ty[CS_CHUNK], tz[CS_CHUNK];
+#pragma unroll
+                for (int v = 0; v < CS_CHUNK / 4; ++v) {
+                    const float4 xa = *reinterpret_cast<const float4 *>(&sx[k0 + hf * CS_CHUNK + 4 * v]);
+                    const float4 ya = *reinterpret_cast<const float4 *>(&sy[k0 + hf * CS_CHUNK + 4 * v]);
+                    const float4 za = *reinterpret_cast<const float4 *>(&sz[k0 + hf * CS_CHUNK + 4 * v]);
+                    tx[4 * v] = xa.x; tx[4 * v + 1] = xa.y; tx[4 * v + 2] = xa.z; tx[4 * v + 3] = xa.w;
+                    ty[4 * v] = ya.x; ty[4 * v + 1] = ya.y; ty[4 * v + 2] = ya.z; ty[4 * v + 3] = ya.w;
+                    tz[4 * v] = za.x; tz[4 * v + 1] = za.y; tz[4 * v + 2] = za.z; tz[4 * v + 3] = za.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float cm = INFINITY;
+#pragma unroll
+                    for (int u = 0; u < CS_CHUNK; ++u) {
+                        const float d = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]);
+                        cm = fminf(cm, d);
+                        colp[hf * CS_CHUNK + u] = r == 0 ? d : fminf(colp[hf * CS_CHUNK + u], d);
+                    }
+                    if (cm < best[r]) { best[r] = cm; bestk[r] = k0 + hf * CS_CHUNK; }
+                    // one row's eight distances die here: left alone the scheduler evaluates all 64 of the round first and
+                    // folds the minima afterwards -- 54 VGPRs of live distances at the 128-register cap, spills around the
+                    // loop (measured 32.5 -> 31.2 us).  (Fetching the next half's columns ahead on top of this spills 36
+                    // registers: 56 us.)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            // 64-lane reduction of the 16 column partials through LDS: [column][lane] -> 4 lanes per column
+#pragma unroll
+            for (int u = 0; u < CS_ROUND; ++u) tb[u * CS_TSTRIDE + lane] = colp[u];
+            __builtin_amdgcn_wave_barrier();
+            {
+                const int col = lane >> 2, quarter = lane & 3;
+                // squared distances are >= +0 (or +inf): their order as floats is their order as unsigned integers, and an
+                // integer minimum needs no canonicalising v_max in front of every value that comes back from LDS
+                const uint4 *src = reinterpret_cast<const uint4 *>(tb + col * CS_TSTRIDE + quarter * 16);
+                const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                unsigned mb = min(min(min(v0.x, v0.y), min(v0.z, v0.w)), min(min(v1.x, v1.y), min(v1.z, v1.w)));
+                mb = min(mb, min(min(min(v2.x, v2.y), min(v2.z, v2.w)), min(min(v3.x, v3.y), min(v3.z, v3.w))));
+                // lane (col, quarter) now holds the minimum over lanes 16 quarter .. 16 quarter + 15, i.e. over the rows
+                // {64 r + 16 quarter + i} of this wave: kept in LDS (consecutive lanes, consecutive words) for the index search below
+                cq4[(k0 + col) * 4 + quarter] = mb;
+            }
+            __builtin_amdgcn_wave_barrier();              // the buffer is rewritten by the next round
+        }
+        GA_STAMP(0, 1);
+        // row minima: first index attaining the minimum inside the winning chunk, for the rows whose minimum moved in THIS stage
+        // (its columns are still staged) -- branch-free: the chunk's eight columns come back as two ds_read_b128 per plane (chunks
+        // start at multiples of 8 inside the stage; columns beyond the slice are staged as +inf and can never equal a finite
+        // minimum), and the hits are taken in DESCENDING order so that the last one kept is the lowest index
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((st == 0 && rbeg < rend) || best[r] < prev[r]) {   // (first stage: also rows whose minimum stayed +inf / NaN-tainted)
+                const int kb = bestk[r];
+                const float4 xa = *reinterpret_cast<const float4 *>(&sx[kb]), xb = *reinterpret_cast<const float4 *>(&sx[kb + 4]);
+                const float4 ya = *reinterpret_cast<const float4 *>(&sy[kb]), yb = *reinterpret_cast<const float4 *>(&sy[kb + 4]);
+                const float4 za = *reinterpret_cast<const float4 *>(&sz[kb]), zb = *reinterpret_cast<const float4 *>(&sz[kb + 4]);
+                const float tx[CS_CHUNK] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                const float ty[CS_CHUNK] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+                const float tz[CS_CHUNK] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+                int f = kb;
+#pragma unroll
+                for (int u = CS_CHUNK - 1; u >= 0; --u)
+                    f = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]) == best[r] ? kb + u : f;
+                found[r] = f + cbeg;
+            }
+        }
+        request(st + 1);                                   // the next stage's columns: in flight during the index search below
+        __syncthreads();                                   // quarter minima complete; the transpose buffers are free
+        // the workgroup's rows into LDS, one padded segment per row-wave
+        if (cwi == 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float cm = INFINITY;
-#pragma unroll
-                for (int u = 0; u < CS_CHUNK; ++u) {
-                    const float d = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]);
-                    cm = fminf(cm, d);
-                    colp[hf * CS_CHUNK + u] = r == 0 ? d : fminf(colp[hf * CS_CHUNK + u], d);
-                }
-                if (cm < best[r]) { best[r] = cm; bestk[r] = k0 + hf * CS_CHUNK; }
-                // one row's eight distances die here: left alone the scheduler evaluates all 64 of the round first and
-                // folds the minima afterwards -- 54 VGPRs of live distances at the 128-register cap, spills around the
-                // loop (measured 32.5 -> 31.2 us).  (Fetching the next half's columns ahead on top of this spills 36
-                // registers: 56 us.)
-                __builtin_amdgcn_sched_barrier(0);
+                rx[rwi * CS_SEG + r * kWave + lane] = px[r];
+                ry[rwi * CS_SEG + r * kWave + lane] = py[r];
+                rz[rwi * CS_SEG + r * kWave + lane] = pz[r];
             }
         }
-        // 64-lane reduction of the 16 column partials through LDS: [column][lane] -> 4 lanes per column
-#pragma unroll
-        for (int u = 0; u < CS_ROUND; ++u) tb[u * CS_TSTRIDE + lane] = colp[u];
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        GA_STAMP(0, 2);
+        // column minima: two threads per column.  Minimum over the (wave, quarter) entries and the LOWEST wave attaining it
+        // (strict compare); several quarters of that wave attaining it (exact ties between rows 16 apart or more) are rare:
+        // those columns walk their further quarters in a loop the other lanes sit out.
         {
-            const int col = lane >> 2, quarter = lane & 3;
-            // squared distances are >= +0 (or +inf): their order as floats is their order as unsigned integers, and an
-            // integer minimum needs no canonicalising v_max in front of every value that comes back from LDS
-            const uint4 *src = reinterpret_cast<const uint4 *>(tb + col * CS_TSTRIDE + quarter * 16);
-            const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-            unsigned mb = min(min(min(v0.x, v0.y), min(v0.z, v0.w)), min(min(v1.x, v1.y), min(v1.z, v1.w)));
-            mb = min(mb, min(min(min(v2.x, v2.y), min(v2.z, v2.w)), min(min(v3.x, v3.y), min(v3.z, v3.w))));
-            // lane (col, quarter) now holds the minimum over lanes 16 quarter .. 16 quarter + 15, i.e. over the rows
-            // {64 r + 16 quarter + i} of this wave: kept in LDS (consecutive lanes, consecutive words) for the index search below
-            cq4[(k0 + col) * 4 + quarter] = mb;
+            const int col = threadIdx.x >> 1, h = threadIdx.x & 1;
+            const int cc = col < cnt ? col : 0;
+            const float4 *cq = reinterpret_cast<const float4 *>(colq);
+            float4 cpv[CS_WAVES];                                // (all eight reads in flight; absent row-waves repeat wave 0)
+#pragma unroll
+            for (int w = 0; w < CS_WAVES; ++w) cpv[w] = cq[(w < a.rw ? w : 0) * CS_CMAX + cc];
+            float4 win = cpv[0];
+            float v = fminf(fminf(win.x, win.y), fminf(win.z, win.w));
+            int bt = 0;
+#pragma unroll
+            for (int w = 1; w < CS_WAVES; ++w) {
+                const float tv = fminf(fminf(cpv[w].x, cpv[w].y), fminf(cpv[w].z, cpv[w].w));
+                if (w < a.rw && tv < v) { v = tv; bt = w; win = cpv[w]; }
+            }
+            const float qx = sx[cc], qy = sy[cc], qz = sz[cc];
+            const float *wx = rx + bt * CS_SEG, *wy = ry + bt * CS_SEG, *wz = rz + bt * CS_SEG;
+            const float qv[4] = {win.x, win.y, win.z, win.w};
+            int q1 = 3;                                           // lowest quarter attaining the minimum
+#pragma unroll
+            for (int q = 2; q >= 0; --q) q1 = qv[q] == v ? q : q1;
+            int fnd = sym_find_half(wx, wy, wz, q1, h, qx, qy, qz, v);
+            for (int q = q1 + 1; q < 4; ++q)                      // exact ties across quarters: rare
+                if (qv[q] == v) fnd = min(fnd, sym_find_half(wx, wy, wz, q, h, qx, qy, qz, v));
+            fnd = min(fnd, __builtin_amdgcn_update_dpp(INT_MAX, fnd, 0xB1, 0xf, 0xf, false));   // the pair's other half (quad_perm [1,0,3,2])
+            if (fnd == INT_MAX) fnd = 0;                          // only if v is NaN-tainted (out of contract)
+            if (col < cnt) {
+                const int k = cbeg + col;
+                const int row = (rt * a.rw + bt) * CS_WROWS + fnd;
+                if (a.rtiles == 1) {
+                    if (h == 0) pr.dist2[(size_t)c * m + k] = v; else pr.idx2[(size_t)c * m + k] = row;
+                } else {
+                    const size_t o = (((size_t)pi * a.clouds + c) * a.rtiles + rt) * m + k;
+                    if (h == 0) a.colpart_d[o] = v; else a.colpart_i[o] = row;
+                }
+            }
         }
-        __builtin_amdgcn_wave_barrier();              // the buffer is rewritten by the next round
+        __syncthreads();                                   // the stage planes, the quarter minima and the staged rows are free again
     }
-    GA_STAMP(0, 1);
-    // row minima: first index attaining the minimum inside the winning chunk -- branch-free: the chunk's eight columns come
-    // back as two ds_read_b128 per plane (chunks start at multiples of 8 inside the stage; columns beyond the slice are
-    // staged as +inf and can never equal a finite minimum), and the hits are taken in DESCENDING order so that the last one
-    // kept is the lowest index
+    // row minima of this workgroup's columns: final (one slice), a packed word folded at the memory side, or a partial per slice
     const int rslices = a.cslices * a.cw;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int f = INT_MAX;
-        if (bestk[r] >= 0) {                               // (uniform: a wave either scanned columns or did not)
-            const int kb = bestk[r];
-            const float4 xa = *reinterpret_cast<const float4 *>(&sx[kb]), xb = *reinterpret_cast<const float4 *>(&sx[kb + 4]);
-            const float4 ya = *reinterpret_cast<const float4 *>(&sy[kb]), yb = *reinterpret_cast<const float4 *>(&sy[kb + 4]);
-            const float4 za = *reinterpret_cast<const float4 *>(&sz[kb]), zb = *reinterpret_cast<const float4 *>(&sz[kb + 4]);
-            const float tx[CS_CHUNK] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            const float ty[CS_CHUNK] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
-            const float tz[CS_CHUNK] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
-            f = kb;
-#pragma unroll
-            for (int u = CS_CHUNK - 1; u >= 0; --u)
-                f = sqdist_s(tx[u], ty[u], tz[u], px[r], py[r], pz[r]) == best[r] ? kb + u : f;
-            f += cbeg;
-        }
         const int j = q0 + r * kWave + lane;
         if (j < n) {
             if (rslices == 1) {
                 pr.dist1[(size_t)c * n + j] = best[r];
-                pr.idx1[(size_t)c * n + j] = f;
+                pr.idx1[(size_t)c * n + j] = found[r];
             } else if (a.row64) {   // narrow slices: one packed word per row, folded at the memory side (no return value: fire and forget)
-                atomicMin(&a.row64[((size_t)pi * a.clouds + c) * n + j], sym_pack(best[r], f));
+                atomicMin(&a.row64[((size_t)pi * a.clouds + c) * n + j], sym_pack(best[r], found[r]));
             } else {   // lexicographic (distance, index) minimum over the slices: chamfer_sym_merge_kernel or the loop's loss launch
                 const size_t o = (((size_t)pi * a.clouds + c) * rslices + (cs * a.cw + cwi)) * n + j;
                 a.rowpart_d[o] = best[r];
-                a.rowpart_i[o] = f;
-            }
-        }
-    }
-    __syncthreads();                                       // quarter minima complete; the transpose buffers are free
-    // the workgroup's rows into LDS, one padded segment per row-wave
-    float *rx = tbase, *ry = tbase + CS_WAVES * CS_SEG, *rz = tbase + 2 * CS_WAVES * CS_SEG;
-    if (cwi == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            rx[rwi * CS_SEG + r * kWave + lane] = px[r];
-            ry[rwi * CS_SEG + r * kWave + lane] = py[r];
-            rz[rwi * CS_SEG + r * kWave + lane] = pz[r];
-        }
-    }
-    __syncthreads();
-    GA_STAMP(0, 2);
-    // column minima: two threads per column.  Minimum over the (wave, quarter) entries and the LOWEST wave attaining it
-    // (strict compare); several quarters of that wave attaining it (exact ties between rows 16 apart or more) are rare:
-    // those columns walk their further quarters in a loop the other lanes sit out.
-    {
-        const int col = threadIdx.x >> 1, h = threadIdx.x & 1;
-        const int cc = col < cnt ? col : 0;
-        const float4 *cq = reinterpret_cast<const float4 *>(colq);
-        float4 cpv[CS_WAVES];                                // (all eight reads in flight; absent row-waves repeat wave 0)
-#pragma unroll
-        for (int w = 0; w < CS_WAVES; ++w) cpv[w] = cq[(w < a.rw ? w : 0) * CS_CMAX + cc];
-        float4 win = cpv[0];
-        float v = fminf(fminf(win.x, win.y), fminf(win.z, win.w));
-        int bt = 0;
-#pragma unroll
-        for (int w = 1; w < CS_WAVES; ++w) {
-            const float tv = fminf(fminf(cpv[w].x, cpv[w].y), fminf(cpv[w].z, cpv[w].w));
-            if (w < a.rw && tv < v) { v = tv; bt = w; win = cpv[w]; }
-        }
-        const float qx = sx[cc], qy = sy[cc], qz = sz[cc];
-        const float *wx = rx + bt * CS_SEG, *wy = ry + bt * CS_SEG, *wz = rz + bt * CS_SEG;
-        const float qv[4] = {win.x, win.y, win.z, win.w};
-        int q1 = 3;                                           // lowest quarter attaining the minimum
-#pragma unroll
-        for (int q = 2; q >= 0; --q) q1 = qv[q] == v ? q : q1;
-        int found = sym_find_half(wx, wy, wz, q1, h, qx, qy, qz, v);
-        for (int q = q1 + 1; q < 4; ++q)                      // exact ties across quarters: rare
-            if (qv[q] == v) found = min(found, sym_find_half(wx, wy, wz, q, h, qx, qy, qz, v));
-        found = min(found, __builtin_amdgcn_update_dpp(INT_MAX, found, 0xB1, 0xf, 0xf, false));   // the pair's other half (quad_perm [1,0,3,2])
-        if (found == INT_MAX) found = 0;                      // only if v is NaN-tainted (out of contract)
-        if (col < cnt) {
-            const int k = cbeg + col;
-            const int row = (rt * a.rw + bt) * CS_WROWS + found;
-            if (a.rtiles == 1) {
-                if (h == 0) pr.dist2[(size_t)c * m + k] = v; else pr.idx2[(size_t)c * m + k] = row;
-            } else {
-                const size_t o = (((size_t)pi * a.clouds + c) * a.rtiles + rt) * m + k;
-                if (h == 0) a.colpart_d[o] = v; else a.colpart_i[o] = row;
+                a.rowpart_i[o] = found[r];
             }
         }
     }
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(256) void chamfer_sym_merge_kernel(ChamferSymArgs a
 
 // Launch shape of the symmetric scan: how the 8 waves of a workgroup are laid over rows and columns, and how many
 // columns a workgroup takes so that the grid fills the chip (256 / 128 / 64; `groups` = live (pair, cloud) groups).
-struct SymShape { int rw, cw, rtiles, C, cslices; };
+struct SymShape { int rw, cw, rtiles, C, S, cslices; };
 static SymShape sym_shape(long groups, int n, int m) {
     SymShape s;
     s.rw = n > 1024 ? 8 : n > 512 ? 4 : n > 256 ? 2 : 1;
@@ -330,7 +352,11 @@ static SymShape sym_shape(long groups, int n, int m) {
     s.C = CS_CMAX;
     const int cmin = std::max(CS_CMIN, 2 * CS_ROUND * s.cw);      // every column-wave keeps at least two rounds
     while (s.C > cmin && (long)s.rtiles * cdiv(m, s.C) * groups < kCUs) s.C /= 2;   // measured: slicing only pays when the grid would not even cover the CUs
-    s.cslices = cdiv(m, s.C);
+    // large launches: several column stages per workgroup (same rows in registers, next stage's columns requested a stage ahead) as
+    // long as four workgroups per CU remain
+    s.S = 1;
+    while (s.S < CS_MAX_STAGES && (long)s.rtiles * cdiv(m, s.C * s.S * 2) * groups >= 4 * kCUs) s.S *= 2;
+    s.cslices = cdiv(m, s.C * s.S);
     return s;
 }
 static size_t sym_group_floats(const SymShape &s, int n, int m) {
@@ -375,7 +401,7 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     // (a second pair gated by `need1` usually has no work at all -- the grid search answers it -- so it does not count)
     const int np_live = need1 ? 1 : np;
     const SymShape s = sym_shape((long)b * np_live, n, m);
-    a.rw = s.rw; a.cw = s.cw; a.rtiles = s.rtiles; a.C = s.C; a.cslices = s.cslices;
+    a.rw = s.rw; a.cw = s.cw; a.rtiles = s.rtiles; a.C = s.C; a.S = s.S; a.cslices = s.cslices;
     const int rslices = s.cslices * s.cw;
     const size_t groups = (size_t)np * b;
     a.rowpart_d = workspace;
