@@ -338,6 +338,7 @@ constexpr int KG_MAX_N = 4096;             // the whole sorted cloud sits in the
 struct KnnGrid {
     float lo[3], ih[3], h[3], eps[3];       // origin, 1 / cell size, cell size, slack on a face distance (rounding of the cell assignment)
     int g[3], cells;
+    int bad;                                // the cloud holds a non-finite coordinate (1 x 1 x 1 grid; the keyed search sends its queries to the redo list)
 };
 
 __device__ __forceinline__ int kg_cell1(float v, float lo, float ih, int g) {
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(KG_BUILD_THREADS) void knn_grid_build_kernel(int n,
             g.eps[a] = 8.f * 1.2e-7f * fmaxf(fabsf(l), fabsf(h));
         }
         g.cells = g.g[0] * g.g[1] * g.g[2];
+        g.bad = b != 0.f ? 1 : 0;
         info[c] = g;
     }
     __syncthreads();
@@ -593,6 +595,21 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
                                                            // whether the address is the wave's (broadcast) or the lane's own (gather)
     float *qd = kg_lds + 4 * (size_t)n4;
     constexpr int QC = kg_qcap<MODE, S>();
+    // MODE 2 = knn_point on KEYED lists: a candidate is ONE word, the bits of its squared distance with the low 12 mantissa bits
+    // replaced by its position in the sorted cloud (n <= 4096).  Distances are >= +0, so keys order like (truncated distance,
+    // position) as unsigned integers, and the whole machinery of the values-only search (one queue word, one med3 per list slot) runs
+    // on them.  When a list is finished, the <= S positions it names are re-read, their EXACT distances recomputed and sorted; every
+    // candidate the list does not name has a key >= the list's last, i.e. a true distance >= that key's truncated value T, so the
+    // k smallest are exact whenever the k-th exact distance is below T (else: the redo list, like ties; ~1 % of the queries of a
+    // uniform cloud at k = 9).  Same outputs as the (value, index) lists of MODE 0, at the values-only search's price.
+    constexpr bool KEYED = MODE == 2;
+    constexpr unsigned KMASK = 0xFFFu, KEMPTY = 0xFFFFFFFFu;
+    const float LIST_INIT = KEYED ? __uint_as_float(KEMPTY) : INFINITY;                   // an empty list slot / an open threshold
+    // a candidate as the lists hold it (its key, or its distance), and "strictly below the threshold" on that representation
+    auto cand_of = [&](const float d, const int pos) { return KEYED ? __uint_as_float((__float_as_uint(d) & ~KMASK) | (unsigned)pos) : d; };
+    auto below_thr = [&](const float cnd, const float thr) { return KEYED ? __float_as_uint(cnd) < __float_as_uint(thr) : !(cnd >= thr); };
+    // an upper bound of the true distance of a list entry (a key's truncated bits filled up; an empty slot compares false)
+    auto upper_of = [&](const float e) { return KEYED ? __uint_as_float(__float_as_uint(e) | KMASK) : e; };
     int *qi = reinterpret_cast<int *>(qd + QC * THREADS);
     int *cs_l = qi + (MODE == 0 ? QC * THREADS : 0);   // the cell offsets too: every shell of every task looks rows up in them
     const int c = blockIdx.y;
@@ -639,8 +656,50 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
         return r;
     };
     // what a lane's finished list leaves behind (a tie among the k + 1 smallest, a NaN, fewer than k finite distances: the redo list)
-    auto emit = [&](const int q, const float (&v)[S], const int (&ix)[S], const bool odd) {
-        if (MODE == 0) {
+    auto emit = [&](const int q, const float (&v)[S], const int (&ix)[S], const bool odd, const float qx, const float qy, const float qz) {
+        if (KEYED) {
+            // exact (distance, original index) of the positions the keys name, sorted by distance (insertion network; ties and the
+            // order among them do not matter: a tie inside the first k + 1 sends the query to the redo list)
+            float e[S];
+            int id[S];
+            bool again = odd;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const unsigned key = __float_as_uint(v[i]);
+                const float4 t = sp[key == KEMPTY ? 0 : (int)(key & KMASK)];
+                const float dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
+                const float d = (dx * dx + dy * dy) + dz * dz;                       // tf_grouping.py:68, left to right
+                e[i] = key == KEMPTY ? INFINITY : d;
+                id[i] = key == KEMPTY ? -1 : __float_as_int(t.w);
+                again |= d != d;
+            }
+#pragma unroll
+            for (int i = 1; i < S; ++i)
+#pragma unroll
+                for (int j = i; j > 0; --j) {
+                    const bool sw = e[j] < e[j - 1];
+                    const float lo2 = sw ? e[j] : e[j - 1], hi2 = sw ? e[j - 1] : e[j];
+                    const int loi = sw ? id[j] : id[j - 1], hii = sw ? id[j - 1] : id[j];
+                    e[j - 1] = lo2; e[j] = hi2; id[j - 1] = loi; id[j] = hii;
+                }
+            const unsigned last = __float_as_uint(v[S - 1]);                         // the list's largest key (all ones: the list is not full --
+            const float T = __uint_as_float(last & ~KMASK);                          // it then names EVERY candidate met, and nothing bounds from outside)
+            float ek = INFINITY;
+#pragma unroll
+            for (int i = 0; i < S; ++i) if (i == k - 1) ek = e[i];
+            again |= last != KEMPTY && !(ek < T);
+#pragma unroll
+            for (int i = 0; i < S; ++i) if (i == k - 1) again |= id[i] < 0;
+#pragma unroll
+            for (int i = 0; i + 1 < S; ++i)
+                if (i < k && e[i] == e[i + 1] && id[i + 1] >= 0) again = true;
+            if (again) redo[1 + atomicAdd(redo, 1)] = c * m + q;
+            else {
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+                    if (i < k) { val_out[((size_t)c * m + q) * k + i] = e[i]; idx_out[((size_t)c * m + q) * k + i] = id[i]; }
+            }
+        } else if (MODE == 0) {
             bool again = odd || ix[k - 1] < 0;
 #pragma unroll
             for (int i = 0; i + 1 < S; ++i)
@@ -669,8 +728,16 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
             const float d = has ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(qd) + jo) : INFINITY;
             int id = 0;
             if (MODE == 0) id = has ? *reinterpret_cast<const int *>(reinterpret_cast<const char *>(qi) + jo) : 0;
-            odd |= d != d;
-            if (MODE == 1) {                               // values only: sorted insertion is a median per slot, v[i] <- med3(v[i - 1], d, v[i])
+            if (!KEYED) odd |= d != d;
+            if (KEYED) {                                   // keys: the same medians on unsigned integers (v_med3_u32)
+                const unsigned x = has ? __float_as_uint(d) : KEMPTY;
+#pragma unroll
+                for (int i = S - 1; i > 0; --i) {
+                    const unsigned a_ = __float_as_uint(v[i - 1]), b_ = __float_as_uint(v[i]);
+                    v[i] = __uint_as_float(max(min(a_, x), min(max(a_, x), b_)));
+                }
+                v[0] = __uint_as_float(min(__float_as_uint(v[0]), x));
+            } else if (MODE == 1) {                        // values only: sorted insertion is a median per slot, v[i] <- med3(v[i - 1], d, v[i])
 #pragma unroll                                             // from the top down (the OLD v[i - 1]); half the instructions of a compare-exchange chain
                 for (int i = S - 1; i > 0; --i) v[i] = __builtin_amdgcn_fmed3f(v[i - 1], d, v[i]);
                 v[0] = fminf(v[0], d);                     // (a NaN only ever marks the query `odd`: its list is not used)
@@ -700,9 +767,9 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
         float v[S];
         int ix[S];
 #pragma unroll
-        for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
+        for (int i = 0; i < S; ++i) { v[i] = LIST_INIT; ix[i] = -1; }
         bool odd = false;
-        float thr = INFINITY;
+        float thr = LIST_INIT;
         unsigned qw = 4u * threadIdx.x;
         // the points [lo, hi) of the sorted cloud: wave-uniform bounds, broadcast LDS reads, four points a step (the ones past hi
         // belong to other rows: masked, or a point would enter a list twice)
@@ -718,8 +785,8 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float dx = t[u].x - qx, dy = t[u].y - qy, dz = t[u].z - qz;
-                    d[u] = (dx * dx + dy * dy) + dz * dz;                            // tf_grouping.py:68, left to right
-                    adm[u] = (p + u < hi) && !(d[u] >= thr);
+                    d[u] = cand_of((dx * dx + dy * dy) + dz * dz, p + u);            // tf_grouping.py:68, left to right
+                    adm[u] = (p + u < hi) && below_thr(d[u], thr);
                 }
                 if (__any(adm[0] | adm[1] | adm[2] | adm[3])) {
 #pragma unroll
@@ -771,13 +838,13 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
             if (y1 < gy - 1) mg = fminf(mg, ((g.lo[1] + (float)(y1 + 1) * g.h[1]) - qy) * 0.999f - g.eps[1]);
             if (z0 > 0) mg = fminf(mg, (qz - (g.lo[2] + (float)z0 * g.h[2])) * 0.999f - g.eps[2]);
             if (z1 < gz - 1) mg = fminf(mg, ((g.lo[2] + (float)(z1 + 1) * g.h[2]) - qz) * 0.999f - g.eps[2]);
-            fin = fin || (mg > 0.f && v[S - 1] < mg * mg);
+            fin = fin || (mg > 0.f && upper_of(v[S - 1]) < mg * mg);
             const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == gx - 1 && y1 == gy - 1 && z1 == gz - 1;
             KG_COUNT(1, 1); KG_COUNT(6, rows);
             if (whole || !__any(!fin)) { KG_COUNT(4, 1); KG_COUNT(7, whole ? 1 : 0); break; }
             px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
         }
-        if (live) emit(q, v, ix, odd);
+        if (live) emit(q, v, ix, odd, qx, qy, qz);
     };
 
     // ---- lane-private search (round 4, second form): every lane walks the 3 x 3 x 3 cells around ITS query -- nine runs of the
@@ -802,9 +869,9 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
         float v[S];
         int ix[S];
 #pragma unroll
-        for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
+        for (int i = 0; i < S; ++i) { v[i] = LIST_INIT; ix[i] = -1; }
         bool odd = false;
-        float thr = INFINITY;
+        float thr = LIST_INIT;
         unsigned qw = 4u * threadIdx.x;
         // Between two drains `thr` is stale, and a stale threshold admits most of what comes (the 9th of the first 16 candidates
         // lets every second one through): the queues filled 13 times a task and the drains cost twice the walk.  So a lane
@@ -829,8 +896,8 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float dx = t[u].x - qx, dy = t[u].y - qy, dz = t[u].z - qz;
-                    d[u] = (dx * dx + dy * dy) + dz * dz;                            // tf_grouping.py:68, left to right
-                    adm[u] = (p + u < hi) && !(d[u] >= thr);
+                    d[u] = cand_of((dx * dx + dy * dy) + dz * dz, p + u);            // tf_grouping.py:68, left to right
+                    adm[u] = (p + u < hi) && below_thr(d[u], thr);
                 }
                 if (__any(adm[0] | adm[1] | adm[2] | adm[3])) {
 #pragma unroll
@@ -839,10 +906,10 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
                             *reinterpret_cast<float *>(reinterpret_cast<char *>(qd) + qw) = d[u];
                             if (MODE == 0) *reinterpret_cast<int *>(reinterpret_cast<char *>(qi) + qw) = __float_as_int(t[u].w);
                             qw += 4u * THREADS;
-                            pmax = fmaxf(pmax, d[u]);
+                            pmax = KEYED ? __uint_as_float(max(__float_as_uint(pmax), __float_as_uint(d[u]))) : fmaxf(pmax, d[u]);
                             pcnt += 1;
                         }
-                    if (pcnt >= S) { thr = fminf(thr, pmax); pmax = 0.f; pcnt = 0; }
+                    if (pcnt >= S) { thr = KEYED ? __uint_as_float(min(__float_as_uint(thr), __float_as_uint(pmax))) : fminf(thr, pmax); pmax = 0.f; pcnt = 0; }
                     if (__any(qw >= 4u * (QC - 3) * THREADS)) { drain_into(v, ix, odd, thr, qw); pmax = 0.f; pcnt = 0; }
                 }
                 p += 4;
@@ -857,9 +924,9 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
         if (z0 > 0) mg = fminf(mg, (qz - (g.lo[2] + (float)z0 * g.h[2])) * 0.999f - g.eps[2]);
         if (z1 < gz - 1) mg = fminf(mg, ((g.lo[2] + (float)(z1 + 1) * g.h[2]) - qz) * 0.999f - g.eps[2]);
         const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == gx - 1 && y1 == gy - 1 && z1 == gz - 1;
-        const bool fin = whole || (mg > 0.f && v[S - 1] < mg * mg);
+        const bool fin = whole || (mg > 0.f && upper_of(v[S - 1]) < mg * mg);
         KG_COUNT(8, 1); KG_COUNT(10, __popcll(__ballot(live && !fin)));
-        if (live && fin) emit(q, v, ix, odd);
+        if (live && fin) emit(q, v, ix, odd, qx, qy, qz);
         return fin || !live;
     };
 
@@ -867,7 +934,9 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
     Query cur = load_query(task < task1 ? task : task0);
     while (task < task1) {
         const bool live = tord[blockIdx.x + task * split] * 64 + lane < m;
-        if (lane_first) {
+        if (KEYED && g.bad) {                               // a non-finite coordinate in the cloud: NaN distances must reach the reference-order
+            if (live) redo[1 + atomicAdd(redo, 1)] = c * m + cur.q;   // kernel, and a key would hide them behind the threshold
+        } else if (lane_first) {
             const bool done = lane_search(cur.q, cur.x, cur.y, cur.z, live);
             const unsigned long long nb = __ballot(!done);
             if (nb) {                                       // the lanes left over: into the workgroup's list (overflow: the redo list, exact as well)
@@ -910,9 +979,9 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
             float v[S];
             int ix[S];
 #pragma unroll
-            for (int i = 0; i < S; ++i) { v[i] = INFINITY; ix[i] = -1; }
+            for (int i = 0; i < S; ++i) { v[i] = LIST_INIT; ix[i] = -1; }
             bool odd = false;
-            float thr = INFINITY;
+            float thr = LIST_INIT;
             unsigned qw = 4u * threadIdx.x;
             const int per = (((n + THREADS / 64 - 1) / (THREADS / 64)) + 3) & ~3;
             const int lo = min(n, wave * per), hi = min(n, lo + per);
@@ -925,8 +994,8 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float dx = t[u].x - qx, dy = t[u].y - qy, dz = t[u].z - qz;
-                    d[u] = (dx * dx + dy * dy) + dz * dz;                            // tf_grouping.py:68, left to right
-                    adm[u] = (p + u < hi) && !(d[u] >= thr);
+                    d[u] = cand_of((dx * dx + dy * dy) + dz * dz, p + u);            // tf_grouping.py:68, left to right
+                    adm[u] = (p + u < hi) && below_thr(d[u], thr);
                 }
                 if (__any(adm[0] | adm[1] | adm[2] | adm[3])) {
 #pragma unroll
@@ -953,8 +1022,8 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
 #pragma unroll
                     for (int i = 0; i < S; ++i) {
                         const float d = qd[i * THREADS + w * 64 + lane];
-                        odd |= d != d;
-                        if (MODE == 1) {
+                        if (!KEYED) odd |= d != d;
+                        if (MODE != 0) {
                             unsigned x = __float_as_uint(d);
 #pragma unroll
                             for (int j = 0; j < S; ++j) {
@@ -976,7 +1045,7 @@ __global__ __launch_bounds__(THREADS, (S <= 10 ? 4 : 2)) void knn_grid_kernel(in
                         }
                     }
                 }
-                if (lv) emit(q, v, ix, odd);
+                if (lv) emit(q, v, ix, odd, qx, qy, qz);
             }
             __syncthreads();                                // the queues are free again
         }
@@ -1245,7 +1314,10 @@ static int launch_knn_fast(int kmode, int b, int n, int m, int k, const float *x
         KnnGrid *info = reinterpret_cast<KnnGrid *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b));
         int *tord = reinterpret_cast<int *>(scratch + up(redo_b) + up(sorted_b) + up(cs_b) + up(qo_b) + up(info_b));
         const int G = n < KNN_GRID_N_MID ? KNN_GRID_G_SMALL : (n < KNN_GRID_N_BIG ? KNN_GRID_G_MID : KNN_GRID_G_BIG);
-        const int lane_first = (MODE == 1 && kmode != GEOADV_KNN_GRID_SHELLS) ? 1 : 0;
+        // knn_point (MODE 0): the keyed lists (kernel MODE 2) on the lane-private walk, unless the caller asks for the shell walk alone
+        // (GEOADV_KNN_GRID_SHELLS): that one keeps the (value, index) lists, as the parity tests' second opinion
+        const bool keyed = MODE == 0 && kmode != GEOADV_KNN_GRID_SHELLS;
+        const int lane_first = ((MODE == 1 || keyed) && kmode != GEOADV_KNN_GRID_SHELLS) ? 1 : 0;
         constexpr size_t KB_LDS = (size_t)KG_MAX_N * 20;
         static DeviceOnce battr;
         if (int rc = battr.run([]() -> int {
@@ -1253,18 +1325,25 @@ static int launch_knn_fast(int kmode, int b, int n, int m, int k, const float *x
                 return GEOADV_OK;
             })) return rc;
         knn_grid_build_kernel<<<b, KG_BUILD_THREADS, KB_LDS, st>>>(n, m, G, xyz1, xyz2, sorted, cs, qo, info, tord, lane_first ? 0 : 1, redo);
+        constexpr int KMODE = MODE == 0 ? 2 : MODE;          // the keyed instantiation of this list length
         static DeviceOnce attr;
         if (int rc = attr.run([]() -> int {
                 GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<MODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)kg_lds_bytes<MODE, S>(KG_MAX_N, KG_THREADS)));
+                GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_grid_kernel<KMODE, S, KG_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kg_lds_bytes<KMODE, S>(KG_MAX_N, KG_THREADS)));
                 return GEOADV_OK;
             })) return rc;
         // workgroups per cloud: every wave should see KG_TASKS_PER_WAVE tasks or more (the counter balances them), and the launch
         // about two workgroups per CU
         const int tasks = cdiv(m, 64), waves = KG_THREADS / 64;
         const int split = std::max(1, std::min(std::max(1, tasks / (waves * KG_TASKS_PER_WAVE)), cdiv(2 * kCUs, b)));
-        knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE, S>(n, KG_THREADS, G * G * G), st>>>(n, m, k, split, sorted, cs, qo, info,
-                                                                                                                   tord, xyz2, val, idx, redo, lane_first);
+        if (keyed)
+            knn_grid_kernel<KMODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<KMODE, S>(n, KG_THREADS, G * G * G), st>>>(n, m, k, split, sorted, cs, qo,
+                                                                                                                         info, tord, xyz2, val, idx, redo, lane_first);
+        else
+            knn_grid_kernel<MODE, S, KG_THREADS><<<dim3(split, b), KG_THREADS, kg_lds_bytes<MODE, S>(n, KG_THREADS, G * G * G), st>>>(n, m, k, split, sorted, cs, qo, info,
+                                                                                                                       tord, xyz2, val, idx, redo, lane_first);
     } else {
         knn_fast_kernel<MODE, S><<<dim3(cdiv(m, KF_THREADS), b), KF_THREADS, 0, st>>>(n, m, k, xyz1, xyz2, val, idx, redo);
     }

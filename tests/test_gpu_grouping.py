@@ -344,3 +344,35 @@ def test_knn_grid_equals_all_points_randomised():
         for other in ("grid", "grid_shells"):
             for a, g in zip(out["all_points"], out[other]):
                 assert torch.equal(a.nan_to_num(nan=-1.0), g.nan_to_num(nan=-1.0)), (trial, b, n, m, k, other)
+
+
+def test_knn_point_keyed_lists_near_equal_distances(oracle):
+    """knn_point's grid search keeps ONE word per candidate (distance bits with the low 12 mantissa bits replaced by the position in
+    the sorted cloud) and recomputes the exact distances of the <= k + 1 positions a finished list names; a query whose k-th exact
+    distance is not below the truncated value of the list's last key goes to the redo list.  Clouds built to land there: thin
+    spherical shells around the queries (hundreds of neighbours within 1e-4 relative of each other), concentric shells a few
+    float ulps apart, and a uniform cloud for contrast -- values and indices as the oracle's, bit for bit, in every kernel."""
+    import torch
+    from geometric_adv_amd import ops
+    rng = np.random.default_rng(77)
+    b, n, m, k = 2, 2048, 64, 9
+    u = rng.standard_normal((b, n, 3)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=2, keepdims=True)
+    centres = (rng.random((b, 8, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    x = np.empty((b, n, 3), np.float32)
+    for j in range(8):                                          # 8 shells of 256 points, radius 0.2 * (1 +- 5e-5)
+        r = (0.2 * (1.0 + 5e-5 * rng.standard_normal((b, 256, 1)))).astype(np.float32)
+        x[:, 256 * j:256 * (j + 1)] = centres[:, j:j + 1] + r * u[:, 256 * j:256 * (j + 1)]
+    q = np.concatenate([centres, (rng.random((b, m - 8, 3), dtype=np.float32) - 0.5).astype(np.float32)], axis=1)
+    want_val, want_idx = oracle.knn_point(k, x, q)
+    for kern in ("all_points", "grid", "grid_shells"):
+        val, idx = ops.knn_point(k, _t(x), _t(q), kernel=kern)
+        assert np.array_equal(idx.cpu().numpy(), want_idx), kern
+        assert np.array_equal(val.cpu().numpy(), want_val), kern
+    # a uniform cloud at the defense's shape, every kernel against the all-points one, k = 1 .. 16
+    x = (rng.random((3, 2048, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    for k in (1, 2, 4, 8, 9, 10, 12, 16):
+        ref = ops.knn_point(k, _t(x), _t(x), kernel="all_points")
+        for kern in ("grid", "grid_shells"):
+            got = ops.knn_point(k, _t(x), _t(x), kernel=kern)
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), (k, kern)
