@@ -92,6 +92,21 @@ def test_config2_latent_attack_then_knn_defense_b256():
     h = at.last_history[0]
     assert h[-1, 0].mean() < h[0, 0].mean()                      # ||z - z_target|| went down
     assert metrics.shape == (1, b, 5) and np.isfinite(metrics).all()
+    # parity on sampled clouds of the full batch, from the GPU's own final state: source-distance indices exact (pinned oracle), the
+    # latent loss and the distance loss of the last iteration 1e-5 against the fp64 model evaluated at the GPU's perturbation
+    from oracle.attack_model import AEModel, AttackModel
+    from oracle.cpu_oracle import Oracle
+    s = {k: v.cpu().numpy() for k, v in at.peek().items()}
+    sel = [0, 77, 130, 255]
+    _, j1, _, j2 = Oracle().nn_distance(s["adv"][sel], x[sel])
+    assert np.array_equal(s["idx_a1"][sel], j1) and np.array_equal(s["idx_a2"][sel], j2)
+    am = AttackModel(AEModel(W.canonical(w, n), n, np.float64), x[sel], gt[sel], tz[sel].astype(np.float64), 150.0 * np.ones(len(sel)),
+                     loss_adv_type="latent")
+    am.pert = s["pert"][sel].astype(np.float64)
+    f = am.forward()
+    np.testing.assert_allclose(h[-1, 0][sel], f["loss_adv"], rtol=1e-5)
+    np.testing.assert_allclose(h[-1, 1][sel], f["loss_dist"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(s["latent"][sel], f["z"], atol=2e-6)
     out = defend_surface(at.ae, adv[0], x, num_knn=8, top_k=2, knn_dist_thresh=0.04)
     knn = out["knn_dists"]
     assert knn.shape == (b, n, 8) and (np.diff(knn, axis=2) >= 0).all()
