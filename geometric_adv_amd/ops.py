@@ -45,13 +45,24 @@ def _xyz_pair(xyz1, xyz2, op):
     return xyz1, xyz2
 
 
-def nn_distance(xyz1, xyz2):
+NN_SYM_MIN_PAIRS = 1 << 26      # b * n * m from which nn_distance(kernel="auto") takes the symmetric scan (measured, tools/debug/nn_op_time.py:
+                                # 32 x 2048 x 2048: 0.050 -> 0.039 ms, 256 x 2048 x 2048: 0.35 -> 0.22, 32 x 8192 x 8192: 0.62 -> 0.37; smaller
+                                # problems are host-bound either way and keep the one-launch kernel)
+
+
+def nn_distance(xyz1, xyz2, kernel="auto"):
     """tf_nndistance.py:15-26.  xyz1 (b,n,3), xyz2 (b,m,3) ->
     dist1 (b,n) squared distance from each xyz1 point to its nearest xyz2 point, idx1 (b,n) int32,
-    dist2 (b,m), idx2 (b,m).  Bit-identical to the reference CPU op; lowest index wins ties."""
+    dist2 (b,m), idx2 (b,m).  Bit-identical to the reference CPU op; lowest index wins ties.
+    kernel: "scan" = the reference-shaped entry point geoadv_nn_distance (two scans, no scratch), "symmetric" = every pair distance
+    once for both directions (nn_distance_sym: the attack loop's kernel, scratch from torch), "auto" = by size.  Same bits."""
+    if kernel not in ("auto", "scan", "symmetric"):
+        raise ValueError("kernel must be 'auto', 'scan' or 'symmetric'")
     xyz1, xyz2 = _xyz_pair(xyz1, xyz2, "NnDistance")
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
+    if n >= 1 and m >= 1 and b >= 1 and (kernel == "symmetric" or (kernel == "auto" and b * n * m >= NN_SYM_MIN_PAIRS)):
+        return nn_distance_sym(xyz1, xyz2)
     dist1 = torch.empty((b, n), dtype=torch.float32, device=xyz1.device)
     idx1 = torch.empty((b, n), dtype=torch.int32, device=xyz1.device)
     dist2 = torch.empty((b, m), dtype=torch.float32, device=xyz1.device)

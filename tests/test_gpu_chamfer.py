@@ -44,8 +44,10 @@ def test_nn_distance_grad_golden(dev, golden_nn):
         assert np.array_equal(_bits(g2.cpu().numpy()), _bits(g[f"{name}_gxyz2"])), name
 
 
+@pytest.mark.parametrize("kernel", ["scan", "auto"])
 @pytest.mark.parametrize("b,n,m", [(4, 2048, 2048), (2, 4500, 777), (3, 100, 5000), (1, 8192, 8192), (70, 33, 65)])
-def test_nn_distance_vs_oracle(dev, oracle, b, n, m):
+def test_nn_distance_vs_oracle(dev, oracle, b, n, m, kernel):
+    """(kernel "auto": the 8192 x 8192 case is large enough for the symmetric scan; "scan": always the reference-shaped entry point)"""
     from geometric_adv_amd import ops
     from conftest import cloud
     x1, x2 = cloud(100 + n, b, n), cloud(200 + m, b, m)
@@ -53,7 +55,7 @@ def test_nn_distance_vs_oracle(dev, oracle, b, n, m):
     if n == m:
         x2 = (x1 + np.float32(1e-4) * cloud(7, b, n)).astype(np.float32)
     want = oracle.nn_distance(x1, x2)
-    got = ops.nn_distance(_t(x1, dev), _t(x2, dev))
+    got = ops.nn_distance(_t(x1, dev), _t(x2, dev), kernel=kernel)
     for w, gt, what in zip(want, got, ["dist1", "idx1", "dist2", "idx2"]):
         gt = gt.cpu().numpy()
         if w.dtype == np.int32:
@@ -89,7 +91,7 @@ def test_nn_distance_random_shapes_vs_oracle(dev, oracle):
             x2[:, m // 2:] = x2[:, : m - m // 2]
         x1, x2 = x1.astype(np.float32), x2.astype(np.float32)
         want = oracle.nn_distance(x1, x2)
-        got = ops.nn_distance(_t(x1, dev), _t(x2, dev))
+        got = ops.nn_distance(_t(x1, dev), _t(x2, dev), kernel="scan")
         for w, gt, what in zip(want, got, ["dist1", "idx1", "dist2", "idx2"]):
             assert np.array_equal(_bits(gt.cpu().numpy()), _bits(w)), (trial, b, n, m, what)
 
@@ -139,7 +141,7 @@ def test_symmetric_scan_attack_shapes_vs_oracle(dev, oracle, b, n, m):
     got = ops.nn_distance_sym(_t(x1, dev), _t(x2, dev))
     for w, gt, what in zip(want, got, ["dist1", "idx1", "dist2", "idx2"]):
         assert np.array_equal(_bits(gt.cpu().numpy()[sel]), _bits(w)), what
-    ref = ops.nn_distance(_t(x1, dev), _t(x2, dev))                      # and every cloud against the public op
+    ref = ops.nn_distance(_t(x1, dev), _t(x2, dev), kernel="scan")       # and every cloud against the public op's own kernel
     for a_, b_ in zip(ref, got):
         assert np.array_equal(_bits(a_.cpu().numpy()), _bits(b_.cpu().numpy()))
 
@@ -235,7 +237,7 @@ def test_paired_grid_search_equals_default(kind, b, n):
     from geometric_adv_amd import ops
     adv, x = _paired_case(kind, b, n, 100 + n)
     adv, x = torch.as_tensor(adv).cuda(), torch.as_tensor(x).cuda()
-    ref = ops.nn_distance(adv, x)
+    ref = ops.nn_distance(adv, x, kernel="scan")
     got = ops.nn_distance_paired(adv, x)
     for a, c in zip(ref, got):
         assert torch.equal(a, c)

@@ -60,7 +60,7 @@ def test_paired_grid_search_on_shapes(kind, n, scale):
     x = make_clouds(kind, 21, 3, n)
     pert = (np.random.default_rng(22).standard_normal(x.shape) * scale).astype(np.float32)
     p, q = _t(x + pert), _t(x)
-    for g, w in zip(ops.nn_distance_paired(p, q), ops.nn_distance(p, q)):
+    for g, w in zip(ops.nn_distance_paired(p, q), ops.nn_distance(p, q, kernel="scan")):
         assert torch.equal(g, w)
 
 
@@ -87,9 +87,9 @@ def test_attack_loop_indices_on_shapes(kind, b, prune):
     hist = torch.empty((4, 6, b), device=ae.device)
     at.run(0, 4, 2, hist)
     p = at.peek()
-    d1, i1, d2, i2 = ops.nn_distance(p["recon"], _t(gt))
+    d1, i1, d2, i2 = ops.nn_distance(p["recon"], _t(gt), kernel="scan")     # the public op's own kernel, not the loop's
     assert torch.equal(p["idx_r1"], i1) and torch.equal(p["idx_r2"], i2)
-    e1, j1, e2, j2 = ops.nn_distance(p["adv"], _t(x))
+    e1, j1, e2, j2 = ops.nn_distance(p["adv"], _t(x), kernel="scan")
     assert torch.equal(p["idx_a1"], j1) and torch.equal(p["idx_a2"], j2)
     # the metric rows of the last iteration are sums of the same distances (fp32 sums in the loop's order: compare to fp64 means)
     h = hist[-1].cpu().numpy().astype(np.float64)
