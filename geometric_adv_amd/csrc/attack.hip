@@ -733,7 +733,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
                                           {at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2}};
             const GridArgs rider{at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, n, need_new, need_scan, call, at->x_box};
             JacRider jr;
-            jr.j = jargs; jr.A = A; jr.first_block = 0; jr.blocks = 0;
+            jr.j = jargs; jr.A = A; jr.first_block = 0; jr.blocks = 0; jr.raise_prio = 0;
             // the row minima leave the scan as one (distance, index) partial per column slice; when the loss launch below is the
             // fused one with both Chamfer gradients inside, it merges them on its way in (no second Chamfer launch)
             if (int rc = launch_chamfer_sym_loop(pairs, 2, B, n, n, at->sym_ws, pruned ? need_scan : nullptr, rides_scan ? &rider : nullptr,

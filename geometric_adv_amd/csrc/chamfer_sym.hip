@@ -426,7 +426,7 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
         grid += (unsigned)a.rider.blocks;
         scan_lds = std::max(scan_lds, chamfer_grid_lds_bytes(rider->n));
     }
-    a.jac.blocks = 0; a.jac.first_block = 0;
+    a.jac.blocks = 0; a.jac.first_block = 0; a.jac.raise_prio = 0;
     if (jac) {
         // LAST in the grid: every workgroup of the launch is charged the scan's 70 KB of LDS, so a CU holds two -- the search
         // and the scan from the start; the Jacobian's workgroups take the search's places as those finish (~13 us into a 30 us
@@ -434,6 +434,7 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
         a.jac = *jac;
         a.jac.first_block = (int)grid;
         a.jac.blocks = b * (128 / JAC_ROWS);
+        a.jac.raise_prio = a.jac.blocks * 2 <= kCUs ? 1 : 0;     // fewer riders than half the CUs (B <= 16): see JacRider
         grid += (unsigned)a.jac.blocks;
         scan_lds = std::max(scan_lds, JAC_LDS_BYTES);
     }

@@ -121,10 +121,15 @@ __device__ __forceinline__ void encoder_jac_block(const DeviceAE &A, const JacAr
 }
 
 // The block as extra workgroups of another kernel's launch (1-D grid, 512 threads): blocks [first_block, first_block + blocks).
-struct JacRider { JacArgs j; DeviceAE A; int first_block, blocks; };
+// raise_prio: the rider's waves above the host kernel's.  Small batches: the Jacobian's 8 * b workgroups (16.4 us each beside the
+// scan's waves, 12 alone) end the scan launch ~3 us after the scan itself (profiles/r05_timeline_b4.jsonl); at priority 1 they
+// take what they need from the few CUs they share (B = 4: 0.0673 -> 0.0666 ms, B = 8: 0.0791 -> 0.0780).  At B = 32 there is a
+// rider on EVERY CU and the scan is the long pole: raised priority costs 0.1706 -> 0.173.
+struct JacRider { JacArgs j; DeviceAE A; int first_block, blocks; int raise_prio; };
 __device__ __forceinline__ bool jac_rider_block(const JacRider &r, float *lds) {
     if (r.blocks == 0 || (int)blockIdx.x < r.first_block || (int)blockIdx.x >= r.first_block + r.blocks) return false;
     const int g = blockIdx.x - r.first_block;
+    if (r.raise_prio) __builtin_amdgcn_s_setprio(1);      // few workgroups beside a launch they would otherwise END (small batches)
     GA_STAMP(3, 0);
     encoder_jac_block<false>(r.A, r.j, lds, g % (128 / JAC_ROWS), g / (128 / JAC_ROWS));
     GA_STAMP(3, 7);
