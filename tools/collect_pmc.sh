@@ -28,6 +28,13 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY S
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/loop_$i" -- $LOOP > "$OUT/loop_$i.log" 2>&1 || { echo "loop counter pass $i FAILED (rc $?): not summarised"; rm -rf "$OUT/loop_$i"; }
 done
 python3 tools/pmc_summary.py --hash chamfer_sym.hip,chamfer_grid.h "$OUT"/loop_* > "$OUT/${R}_pmc_chamfer_hbm.json"
+# the symmetric scan ALONE (operator form, no riders): its own traffic
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/sym_$i" -- python3 tools/debug/sym_only.py > "$OUT/sym_$i.log" 2>&1 || { echo "sym counter pass $i FAILED (rc $?)"; rm -rf "$OUT/sym_$i"; }
+done
+python3 tools/pmc_summary.py --hash chamfer_sym.hip "$OUT"/sym_* > "$OUT/${R}_pmc_chamfer_sym_alone.json"
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/emd_1" -- python3 tools/emd_attack_time.py 32 > "$OUT/emd_1.log" 2>&1 || echo "emd counter pass FAILED (rc $?)"
 python3 tools/pmc_summary.py --hash emd.hip "$OUT"/emd_1 > "$OUT/${R}_pmc_emd.json"
 i=0
