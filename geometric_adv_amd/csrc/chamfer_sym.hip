@@ -417,12 +417,13 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
             return GEOADV_OK;
         })) return rc;
     unsigned grid = (unsigned)(s.rtiles * s.cslices * 8 * cdiv(b * np, 8));
-    a.rider.blocks = 0; a.rider.first_block = 0;
+    a.rider.blocks = 0; a.rider.first_block = 0; a.rider.clouds = 0;
     size_t scan_lds = CS_LDS_BYTES;
     if (rider) {
         a.rider.g = *rider;
         a.rider.first_block = 0;                           // dispatched first: its latency-bound workgroups start at once
-        a.rider.blocks = b * 2 * GR_QSPLIT;
+        a.rider.blocks = grid_rider_blocks(b);
+        a.rider.clouds = b;
         grid += (unsigned)a.rider.blocks;
         scan_lds = std::max(scan_lds, chamfer_grid_lds_bytes(rider->n));
     }
