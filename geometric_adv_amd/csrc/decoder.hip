@@ -25,10 +25,14 @@ __device__ __forceinline__ int acc_row16(int reg, int h) { return (reg & 3) + 8 
 //   crit[b][c]  = lowest point index attaining it; zcnt[b][c] = number of points attaining it
 //   dense[b]    = 1 if some channel has a positive maximum attained more than once (exact tie)
 // ------------------------------------------------------------------------------------------
-template <int THREADS>
+// PARTS > 1 (1024-thread form only): PARTS workgroups per cloud.  Each repeats the pool reduce and FC0 (the chain's short,
+// latency-bound head) and takes 256 / PARTS output columns of FC1, whose 262 KB of weights are what a cloud's ONE workgroup
+// spends most of its time streaming through its CU; part 0 alone writes z / crit / zcnt / dense / d1.  Every output's partial
+// sums and their order are unchanged: same bits.
+template <int THREADS, int PARTS = 1>
 __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles, const float *pmax, const int *parg,
                                                     const int *pcnt, float *z, int *crit, int *zcnt,
-                                                    int *dense, float *d1, float *d2, const int b) {
+                                                    int *dense, float *d1, float *d2, const int b, const int part_id = 0) {
     __shared__ float gm[8][128];
     __shared__ int ga[8][128], gk[8][128];
     __shared__ float zs[128];
@@ -85,13 +89,15 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
             m = gt ? gmv[g] : m;
         }
         zs[t] = m;
-        z[(size_t)b * 128 + t] = m;
-        crit[(size_t)b * 128 + t] = a;
-        zcnt[(size_t)b * 128 + t] = k;
+        if (part_id == 0) {
+            z[(size_t)b * 128 + t] = m;
+            crit[(size_t)b * 128 + t] = a;
+            zcnt[(size_t)b * 128 + t] = k;
+        }
         if (m > 0.f && k > 1) atomicOr(&tie, 1);
     }
     __syncthreads();
-    if (t == 0) dense[b] = tie;
+    if (t == 0 && part_id == 0) dense[b] = tie;
     GA_STAMP(0, 2);
     if (!d1) return;
     {   // FC0 + ReLU: 128 -> 256
@@ -99,14 +105,19 @@ __device__ __forceinline__ void latent_decode_block(const DeviceAE &A, int tiles
         if (t < 256) {
             const float v = fmaxf(s + A.c0[t], 0.f);
             hs[t] = v;
-            d1[(size_t)b * 256 + t] = v;
+            if (part_id == 0) d1[(size_t)b * 256 + t] = v;
         }
     }
     __syncthreads();
     GA_STAMP(0, 3);
-    {   // FC1 + ReLU: 256 -> 256
+    if (PARTS == 1) {   // FC1 + ReLU: 256 -> 256
         const float s = fc256_split4<256, THREADS>(hs, A.v1, part);
         if (t < 256) d2[(size_t)b * 256 + t] = fmaxf(s + A.c1[t], 0.f);
+    } else {            // ... this workgroup's 256 / PARTS columns of it
+        constexpr int NC = 256 / PARTS;
+        const int col0 = part_id * NC;
+        const float s = fc256_split4_cols<256, NC>(hs, A.v1, part, col0);
+        if (t < NC) d2[(size_t)b * 256 + col0 + t] = fmaxf(s + A.c1[col0 + t], 0.f);
     }
     GA_STAMP(0, 7);
 }
@@ -131,10 +142,11 @@ __global__ __launch_bounds__(LD_THREADS) void latent_fc_kernel(DeviceAE A, const
     }
 }
 
+template <int PARTS>
 __global__ __launch_bounds__(LD_THREADS) void latent_decode_kernel(DeviceAE A, int tiles, const float *pmax, const int *parg,
                                                                    const int *pcnt, float *z, int *crit, int *zcnt,
                                                                    int *dense, float *d1, float *d2) {
-    latent_decode_block<LD_THREADS>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x);
+    latent_decode_block<LD_THREADS, PARTS>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, blockIdx.x / PARTS, blockIdx.x % PARTS);
 }
 
 // The same launch with the workgroups of the attack's paired grid search nn_distance(adv, x) behind it (chamfer_grid.h):
@@ -283,7 +295,11 @@ __global__ __launch_bounds__(LD_THREADS) void decoder_bwd_tail_kernel(DeviceAE A
 int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int *parg, const int *pcnt, float *z,
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
-    latent_decode_kernel<<<b, LD_THREADS, 0, stream>>>(A, encoder_tiles(b, A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
+    // several workgroups per cloud while the launch still fits the chip once (B <= 64: four, B <= 128: two): latent_decode_block
+    const int tiles = encoder_tiles(b, A.n_points);
+    if (d1 && 4 * b <= kCUs) latent_decode_kernel<4><<<4 * b, LD_THREADS, 0, stream>>>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
+    else if (d1 && 2 * b <= kCUs) latent_decode_kernel<2><<<2 * b, LD_THREADS, 0, stream>>>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
+    else latent_decode_kernel<1><<<b, LD_THREADS, 0, stream>>>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -30,6 +30,26 @@ __device__ __forceinline__ float fc256_split4(const float *in_lds, const float *
     return ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];     // meaningful for t < 256
 }
 
+// The same product for the output columns [col0, col0 + NCOLS) only (a workgroup that shares a cloud's layer with others: every
+// column's four partial sums and their order are those of fc256_split4, so the bits do not depend on the split).  4 * NCOLS threads
+// work, one K quarter each; returns the column's sum to threads t < NCOLS (column col0 + t).
+template <int K, int NCOLS>
+__device__ __forceinline__ float fc256_split4_cols(const float *in_lds, const float *W /*[K][256]*/, float (*part)[256], const int col0) {
+    const int t = threadIdx.x, o = col0 + t % NCOLS, ks = t / NCOLS;
+    constexpr int PER = K / 4;
+    if (ks < 4) {
+        float w[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) w[k] = W[(size_t)(ks * PER + k) * 256 + o];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) s = fmaf(in_lds[ks * PER + k], w[k], s);
+        part[ks][o] = s;
+    }
+    __syncthreads();
+    return ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];     // meaningful for t < NCOLS
+}
+
 // dd2 = sum of partials, masked by d2 > 0; dd1 = dd2 @ V1^T masked by d1 > 0; dz = dd1 @ V0^T.
 // grid = clouds, 1024 threads.  TF ReluGrad masks by the layer OUTPUT being > 0.
 // (Requesting V1^T / V0^T ahead of the partial sums was measured and lost, 7.8 vs 7.2 us: a workgroup streams ~480 KB through
