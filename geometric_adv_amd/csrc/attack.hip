@@ -676,7 +676,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     const bool loss_fused = (adv_chamfer || dist_chamfer) && !max_term && n <= CG_FX_MAX_N_PLANE;   // loss_cgrad_kernel below
     const bool merge_in_loss = loss_fused && adv_chamfer && dist_chamfer;
     // narrow column slices (small batches): row minima folded into packed words by atomics; the FC2 launch fills them on its way
-    const bool use_row64 = merge_in_loss && at->chamfer_sym && at->row64 != nullptr;
+    const bool use_row64 = merge_in_loss && at->chamfer_sym && at->row64 != nullptr && chamfer_sym_packs_rows((long)B * (pruned ? 1 : 2), n, n);
     SymPartials part{nullptr, nullptr, 1, B, false, use_row64 ? at->row64 : nullptr};
     {
         ProfScope ps(at, GEOADV_PROF_ENCODER_FWD, st, true);

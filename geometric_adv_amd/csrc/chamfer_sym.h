@@ -87,6 +87,7 @@ struct CGradProblem {
 int launch_chamfer_grad(const CGradProblem *pr, int np, int B, int n, hipStream_t st);
 
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
+bool chamfer_sym_packs_rows(long live_groups, int n, int m);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
 struct GridArgs;
 struct JacRider;

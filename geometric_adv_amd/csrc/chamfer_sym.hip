@@ -372,6 +372,13 @@ size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
     return (size_t)pairs * b * per + 64;
 }
 
+// Will launch_chamfer_sym_loop fold the row minima into the caller's packed words (SymPartials::row64) at this shape?  (The caller
+// fills them with all ones beforehand only then.)  live_groups: clouds x problems that are not gated off.
+bool chamfer_sym_packs_rows(long live_groups, int n, int m) {
+    const SymShape s = sym_shape(live_groups, n, m);
+    return s.rtiles == 1 && s.cslices * s.cw > 8;
+}
+
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
                           int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider = nullptr,
