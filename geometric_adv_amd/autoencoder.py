@@ -21,12 +21,17 @@ class _AEWeights(C.Structure):
                 ("dec_w", C.c_void_p * 3), ("dec_b", C.c_void_p * 3)]
 
 
+ENCODER_ARITH = {"f32": 0, "bf16x3": 1}     # GEOADV_ENC_ARITH_*
+
+
 class PointNetAE:
     """PointNet-style encoder + FC decoder with frozen weights on one GPU."""
 
-    def __init__(self, weights, n_points, ae_name=W.AE_NAME, device=None):
+    def __init__(self, weights, n_points, ae_name=W.AE_NAME, device=None, encoder_arith=None):
         """weights: dict of TF-variable-name -> array (see weights.py), or a path to such an .npz, or a
-        TF V2 checkpoint prefix like '<ae_dir>/models.ckpt-500' (read without TensorFlow, tf_checkpoint.py)."""
+        TF V2 checkpoint prefix like '<ae_dir>/models.ckpt-500' (read without TensorFlow, tf_checkpoint.py).
+        encoder_arith: "bf16x3" (fp32 products as six bf16 piece products on the bf16 matrix pipe, include/geoadv.h) or "f32"
+        (fp32 MFMA); None = the library default.  Applies to everything that runs this model (forward, attack, defense)."""
         if isinstance(weights, str):
             weights = W.load(weights, ae_name)
         self.n_points = int(n_points)
@@ -51,7 +56,18 @@ class PointNetAE:
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_ae_create(C.byref(self._h), C.byref(hw)), "ae_create")
+        if encoder_arith is not None:
+            self.set_encoder_arith(encoder_arith)
         self._ws = None
+
+    def set_encoder_arith(self, arith):
+        """Switch the encoder kernels' arithmetic (ENCODER_ARITH); not while another thread uses this model."""
+        _lib.check(_lib.lib().geoadv_ae_set_encoder_arith(self._h, ENCODER_ARITH[arith]), "ae_set_encoder_arith")
+
+    @property
+    def encoder_arith(self):
+        code = _lib.lib().geoadv_ae_encoder_arith(self._h)
+        return next(k for k, v in ENCODER_ARITH.items() if v == code)
 
     def __del__(self):
         try:

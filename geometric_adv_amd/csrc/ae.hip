@@ -1,9 +1,11 @@
 // geoadv_ae: device-resident, MFMA-packed weights of the victim auto-encoder + plain forward
 // (AdversaryAutoEncoder.restore_ae_model / reconstruct, src/adversary_autoencoder.py:42-51,75-91).
 #include "ae.h"
+#include "encoder_x3.h"
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <atomic>
 
 namespace geoadv {
 
@@ -43,6 +45,51 @@ static void pack_fragments16(std::vector<float> &dst, size_t off, int K, int N, 
                     const int k = 16 * t + 4 * (lane >> 4) + u, n = 16 * cb + (lane & 15);
                     dst[off + (((size_t)cb * kg + t) * 64 + lane) * 4 + u] = (k < K && n < N) ? at(k, n) : 0.f;
                 }
+}
+
+// bf16 pieces of an fp32 (encoder_x3.h): round to nearest even, the remainders exact
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_value(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline void x3_pieces(float x, uint16_t (&p)[3]) {
+    p[0] = bf16_rne(x);
+    const float r1 = x - bf16_value(p[0]);
+    p[1] = bf16_rne(r1);
+    const float r2 = r1 - bf16_value(p[1]);
+    p[2] = bf16_rne(r2);
+}
+// The x3 weight image: for every sixteen-k step of the forward, 4 output-channel blocks x 3 pieces x 64 lanes x 8 k slots;
+// lane (i, h) of block ob holds W_L[x3 input channel of slot j][32 ob + i] (the same values whichever operand they become).
+static void pack_x3(uint32_t *img, const float *const W[ENC_L], const int *C) {
+    for (int L = 1; L <= 4; ++L) {
+        const int K = C[L], N = C[L + 1];
+        for (int ob = 0; ob < N / 32; ++ob)
+            for (int kb = 0; kb < K / 16; ++kb) {
+                const int step = x3_step_of(L, ob, kb);
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    uint16_t pc[8][3];
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = L == 4 ? 128 * (kb >> 3) + x3_in_channel(4, kb & 7, h, j) : x3_in_channel(L, kb, h, j);
+                        x3_pieces(W[L][(size_t)k * N + 32 * ob + i], pc[j]);
+                    }
+                    for (int q = 0; q < 3; ++q) {
+                        uint32_t *dst = img + ((size_t)(step * 4 + (ob & 3)) * 3 + q) * X3_FRAG_WORDS + lane * 4;
+                        for (int w = 0; w < 4; ++w) dst[w] = (uint32_t)pc[2 * w][q] | ((uint32_t)pc[2 * w + 1][q] << 16);
+                    }
+                }
+            }
+    }
 }
 
 struct ForwardScratch {
@@ -85,6 +132,8 @@ int run_forward(const DeviceAE &A, int b, const float *x, const float *pert, flo
 
 using namespace geoadv;
 
+static std::atomic<int> g_default_enc_arith{GEOADV_ENC_ARITH_BF16X3};
+
 extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     GA_REQUIRE(out && hw, "ae_create: null argument");
     static const int want_enc[ENC_L + 1] = {3, 64, 128, 128, 256, 128};
@@ -118,6 +167,7 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     size_t o_v0 = reserve(128 * 256), o_c0 = reserve(256), o_v1 = reserve(256 * 256), o_c1 = reserve(256);
     size_t o_v0t = reserve(256 * 128), o_v1t = reserve(256 * 256);
     size_t o_d2f = reserve((size_t)256 * n3p32), o_d2b = reserve((size_t)n3p8 * 256), o_c2 = reserve(n3);
+    size_t o_x3 = reserve(X3_IMAGE_WORDS);
 
     memcpy(&host[o_w0], hw->enc_w[0], sizeof(float) * 3 * C[1]);
     for (int i = 1; i < ENC_L; ++i) {
@@ -150,6 +200,11 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
         pack_fragments(host, o_d2b, n3, 256, n3p8, 256, [&](int k, int nn) { return V2[(size_t)nn * n3 + k]; });
     }
     memcpy(&host[o_c2], hw->dec_b[2], sizeof(float) * n3);
+    {
+        std::vector<uint32_t> img(X3_IMAGE_WORDS, 0u);
+        pack_x3(img.data(), hw->enc_w, C);
+        memcpy(&host[o_x3], img.data(), sizeof(uint32_t) * X3_IMAGE_WORDS);      // (bit patterns: the arena is only a byte container here)
+    }
 
     geoadv_ae *ae = new geoadv_ae();
     ae->arena_bytes = sizeof(float) * host.size();
@@ -184,7 +239,22 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     d.dec2_fwd = PackedLayer{base + o_d2f, 256, n3p32};
     d.dec2_bwd = PackedLayer{base + o_d2b, n3p8, 256};
     d.c2 = base + o_c2;
+    d.enc_x3 = reinterpret_cast<const unsigned *>(base + o_x3);
+    d.enc_arith = g_default_enc_arith.load();
     *out = ae;
+    return GEOADV_OK;
+}
+
+extern "C" int geoadv_ae_set_encoder_arith(geoadv_ae *ae, int arith) {
+    GA_REQUIRE(ae, "ae_set_encoder_arith: null handle");
+    GA_REQUIRE(arith == GEOADV_ENC_ARITH_F32 || arith == GEOADV_ENC_ARITH_BF16X3, "ae_set_encoder_arith: unknown arithmetic %d", arith);
+    ae->d.enc_arith = arith;
+    return GEOADV_OK;
+}
+extern "C" int geoadv_ae_encoder_arith(const geoadv_ae *ae) { return ae ? ae->d.enc_arith : -1; }
+extern "C" int geoadv_set_default_encoder_arith(int arith) {
+    GA_REQUIRE(arith == GEOADV_ENC_ARITH_F32 || arith == GEOADV_ENC_ARITH_BF16X3, "set_default_encoder_arith: unknown arithmetic %d", arith);
+    g_default_enc_arith.store(arith);
     return GEOADV_OK;
 }
 

@@ -962,7 +962,15 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
         set_error("attack_create: hipMalloc of %zu bytes failed", total);
         return GEOADV_ENOMEM;
     }
-    (void)hipMemset(at->arena, 0, total);
+    // the clear runs on the NULL stream and returns before it is done; callers' streams may be non-blocking ones (torch's are),
+    // which the null stream does not order against -- without the wait a busy GPU (another host thread's work) lets the clear
+    // land AFTER the caller's first uploads into the arena (seen as 1-3 % of two-thread runs computing on zeroed inputs)
+    if (hipMemsetAsync(at->arena, 0, total, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipFree(at->arena);
+        delete at;
+        set_error("attack_create: clearing %zu bytes failed", total);
+        return GEOADV_EHIP;
+    }
     char *p = static_cast<char *>(at->arena);
     auto take = [&](size_t bytes) { char *q = p; p += rup(bytes, 256); return q; };
     auto F = [&](size_t bytes) { return reinterpret_cast<float *>(take(bytes)); };

@@ -13,7 +13,7 @@
 
 namespace geoadv {
 
-int encoder_tiles(int b, int n);
+int encoder_tiles(const DeviceAE &A, int b);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int acc_row16(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -296,7 +296,7 @@ int launch_latent_decode(const DeviceAE &A, int b, const float *pmax, const int 
                          int *crit, int *zcnt, int *dense, float *d1, float *d2, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
     // several workgroups per cloud while the launch still fits the chip once (B <= 64: four, B <= 128: two): latent_decode_block
-    const int tiles = encoder_tiles(b, A.n_points);
+    const int tiles = encoder_tiles(A, b);
     if (d1 && 4 * b <= kCUs) latent_decode_kernel<4><<<4 * b, LD_THREADS, 0, stream>>>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
     else if (d1 && 2 * b <= kCUs) latent_decode_kernel<2><<<2 * b, LD_THREADS, 0, stream>>>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
     else latent_decode_kernel<1><<<b, LD_THREADS, 0, stream>>>(A, tiles, pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2);
@@ -321,10 +321,10 @@ int launch_latent_decode_and_grid(const DeviceAE &A, int b, const float *pmax, c
     const int blocks = b + b * 2 * GR_QSPLIT;
     if (blocks <= kCUs)     // one workgroup per CU is enough: keep the latent blocks at their 16 waves
         latent_decode_and_grid_kernel<LD_THREADS><<<blocks, LD_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
-            A, encoder_tiles(b, A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
+            A, encoder_tiles(A, b), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
     else
         latent_decode_and_grid_kernel<GR_THREADS><<<blocks, GR_THREADS, chamfer_grid_lds_bytes(n), stream>>>(
-            A, encoder_tiles(b, A.n_points), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
+            A, encoder_tiles(A, b), pmax, parg, pcnt, z, crit, zcnt, dense, d1, d2, b, G);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -23,6 +23,7 @@
 #include "ae.h"
 #include "mfma_tile.h"
 #include "encoder_jac.h"
+#include "encoder_x3.h"
 #include "decoder_tail.h"
 #include <hip/hip_ext.h>
 #include <limits.h>
@@ -438,15 +439,41 @@ __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const
     // forward recompute, bit-identical to the forward kernel (canonical accumulation order)
     fwd_layer0<ROWS, true>(pts, bufQ, 68, A, m1);
     __syncthreads();
+    const bool x3 = A.enc_arith == GEOADV_ENC_ARITH_BF16X3;          // (uniform: the arithmetic the forward used, encoder_x3.h)
+    if (x3) {
+        auto bn_relu = [&](int L, float *out, int s_out, unsigned char *mask, int width) {
+            return [=, &A](int row, int c, float a) {
+                const float v = fmaxf(fmaf(a, A.scale[L][c], A.shift[L][c]), 0.f);
+                out[row * s_out + c] = v;
+                mask[row * width + c] = v > 0.f;
+            };
+        };
+        x3_layer_lds<1, ROWS>(bufQ, 68, A.enc_x3, bn_relu(1, bufP, 132, m2, 128));
+        __syncthreads();
+        x3_layer_lds<2, ROWS>(bufP, 132, A.enc_x3, bn_relu(2, bufQ, 132, m3, 128));
+        __syncthreads();
+        x3_layer_lds<3, ROWS>(bufQ, 132, A.enc_x3, bn_relu(3, bufP, 260, m4, 256));
+        __syncthreads();
+        // layer 4 forward -> da4 into bufQ, as below
+        x3_layer_lds<4, ROWS>(bufP, 260, A.enc_x3, [&](int row, int c, float a) {
+            const float sc = A.scale[4][c];
+            const float v = fmaxf(fmaf(a, sc, A.shift[4][c]), 0.f);
+            const float zc = z[(size_t)b * 128 + c];
+            const int kc = zcnt[(size_t)b * 128 + c];
+            const float gz = (kc > 1 ? (1.0f / (float)kc) : 1.0f) * dz[(size_t)b * 128 + c];
+            bufQ[row * 132 + c] = (v == zc && v > 0.f) ? gz * sc : 0.f;
+        });
+    } else {
     fwd_layer<ROWS, 128, true>(bufQ, 68, bufP, 132, A.enc_fwd[1], A.scale[1], A.shift[1], m2, scratch);
     __syncthreads();
     fwd_layer<ROWS, 128, true>(bufP, 132, bufQ, 132, A.enc_fwd[2], A.scale[2], A.shift[2], m3, scratch);
     __syncthreads();
     fwd_layer<ROWS, 256, true>(bufQ, 132, bufP, 260, A.enc_fwd[3], A.scale[3], A.shift[3], m4, scratch);
     __syncthreads();
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {   // layer 4 forward -> da4 = dz/cnt * [h5 == z, z > 0] * scale4   into bufQ (128 wide)
+    if (!x3) {   // layer 4 forward -> da4 = dz/cnt * [h5 == z, z > 0] * scale4   into bufQ (128 wide)
         constexpr int UNITS = 4 * (ROWS / 32);
         const int col = ((wave % UNITS) % 4) * 32 + (lane & 31);
         const float sc = A.scale[4][col], sh = A.shift[4][col];
@@ -679,7 +706,10 @@ static int set_lds_attr_once() {
 #define ENC_ROWS32_BELOW 2      // 32-row tiles while 64-row ones give a CU fewer than two workgroups (measured at B = 12: 0.1235 -> 0.1135 ms per iteration; B = 8, 16: unchanged)
 #endif
 int encoder_fwd_rows(int b, int n) { return (long)b * cdiv(n, 64) < ENC_ROWS32_BELOW * kCUs ? 32 : 64; }
-int encoder_tiles(int b, int n) { return cdiv(n, encoder_fwd_rows(b, n)); }
+// pool partials per cloud of a forward launch (x3 arithmetic: 128-point workgroups whatever the batch, encoder_x3.hip)
+int encoder_tiles(const DeviceAE &A, int b) {
+    return A.enc_arith == GEOADV_ENC_ARITH_BF16X3 ? cdiv(A.n_points, 128) : cdiv(A.n_points, encoder_fwd_rows(b, A.n_points));
+}
 int encoder_tiles_max(int n) { return cdiv(n, 32); }              // what the pool-partial buffers are sized for
 
 // Words of ReLU mask per point the forward leaves for the sparse backward.
@@ -697,7 +727,7 @@ static void launch_fwd2(const DeviceAE &A, int b, const float *x, const float *p
         encoder_fwd2_kernel<MASKS, ROWS><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
 }
 
-// pmax/parg/pcnt: [b][encoder_tiles(b, n)][128]; masks: [b][n][MASK_WORDS] or null (plain forward: geoadv_ae_forward, recomputing backward)
+// pmax/parg/pcnt: [b][encoder_tiles(A, b)][128]; masks: [b][n][MASK_WORDS] or null (plain forward: geoadv_ae_forward, recomputing backward)
 // start / stop (optional): events that receive the kernel's own begin / end time stamps (geoadv_attack_profile).
 // fused (optional): a pending Adam step on pert, applied by the point loaders before they form adv = x + pert (needs pert
 // and adv_out)
@@ -711,6 +741,7 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
         GA_REQUIRE(pert && adv_out && fused->m && fused->pert == pert, "encoder_fwd: the fused Adam step needs pert and adv_out");
         fa = *fused;
     }
+    if (A.enc_arith == GEOADV_ENC_ARITH_BF16X3) return launch_encoder_fwd_x3(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);
     const bool small = encoder_fwd_rows(b, A.n_points) == 32;
     if (masks) {
         if (small) launch_fwd2<true, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);

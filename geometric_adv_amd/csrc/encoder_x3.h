@@ -1,0 +1,133 @@
+// The encoder's fp32 products on the bf16 matrix pipe ("x3" arithmetic).
+//
+// v_mfma_f32_32x32x2_f32 runs at the VALU's rate on gfx950 (1/16 of the bf16 forms), so the fp32 encoder is bounded by
+// 157 TFLOP/s.  Here every operand is written as three bf16 pieces, x = x0 + x1 + x2 with
+//     x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16((x - x0) - x1)      (round to nearest even; both subtractions are exact)
+// -- 8 + 8 + 8 significant bits, i.e. all 24 of an fp32 -- and a product a * w as the six piece products of weight >= 2^-16,
+//     a2 w0, a1 w1, a0 w2, a1 w0, a0 w1, a0 w0                          (smallest first; a1 w2, a2 w1, a2 w2 <= 2^-24 dropped)
+// each of which is EXACT in the matrix pipe's fp32 accumulator (8 x 8 bits), on v_mfma_f32_32x32x16_bf16.  Measured against
+// float64 (tools/bf16x3_probe.py, profiles/r05_bf16x3_probe.jsonl): rms error 0.48-0.52 units of 2^-24 |a|.|w| for K = 64 ...
+// 256 against 0.43-0.46 for the fp32 MFMA chain and 0.45-0.48 for a host fp32 multiply-add loop -- the error of an fp32
+// accumulation in another order, not that of a reduced-precision product (two pieces per operand: 10-20 units).
+//
+// What makes results reproducible (the recomputing backward compares its h5 with the forward's z for equality): every
+// output element is ONE chain of MFMAs -- sixteen-k blocks in ascending order, the six piece products in the order above --
+// with a fixed assignment of input channels to the instruction's k slots (x3_in_channel) and fixed operand roles per layer
+// (layers 1-3: A = weights, B = activations; layer 4: A = activations, B = weights).  A point's result does not depend on
+// which other points share its tile.
+#pragma once
+#include "ae.h"
+#include "mfma_tile.h"
+
+namespace geoadv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int X3_STEPS = 44;                  // sixteen-k steps of one 32-point unit: 4 (layer 1) + 8 (layer 2) + 2 x (8 + 8) (layers 3 + 4 by halves)
+constexpr int X3_FRAG_WORDS = 64 * 4;         // one fragment: 64 lanes x 16 bytes (8 bf16 k-slots per lane)
+constexpr int X3_STEP_WORDS = 4 * 3 * X3_FRAG_WORDS;   // 4 output-channel blocks x 3 pieces = 12 KiB
+constexpr size_t X3_IMAGE_WORDS = (size_t)X3_STEPS * X3_STEP_WORDS;
+
+// Step of the weight image that holds layer L's fragments of output-channel block ob (32 channels), sixteen-k block kb; the
+// fragment's position inside the step is (ob & 3).  Order = the order the forward consumes them in.
+__host__ __device__ constexpr int x3_step_of(int L, int ob, int kb) {
+    return L == 1 ? kb : L == 2 ? 4 + kb : L == 3 ? (ob < 4 ? 12 : 28) + kb : (kb < 8 ? 20 + kb : 36 + (kb - 8));
+}
+// Input channel held in k slot j (0..7) of lane half h (0, 1) of sixteen-k block kb.  Layer 1 reads layer 0's output, which the
+// VALU writes in natural order; layers 2-4 read an MFMA result straight from the accumulator registers, whose lane (point,
+// h) holds channels 32 c + 8 g + 4 h + u (g, u = 0..3) of channel block c: sixteen-k block kb = 2 c + (g >> 1) takes them as
+// slot j = 4 (g & 1) + u -- no lane exchange between layers.
+__host__ __device__ constexpr int x3_in_channel(int L, int kb, int h, int j) {
+    return L == 1 ? 16 * kb + 8 * h + j : 32 * (kb >> 1) + 8 * (2 * (kb & 1) + (j >> 2)) + 4 * h + (j & 3);
+}
+
+struct X3 { u32x4 p[3]; };                    // the three pieces of a lane's 8 k slots (bf16 pairs in 32-bit words)
+
+__device__ __forceinline__ unsigned x3_cvt_pk(float lo, float hi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, bf16x2));      // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+}
+// pieces of two values -> word `w` of each piece
+__device__ __forceinline__ void x3_split_pair(float a, float b, unsigned &w0, unsigned &w1, unsigned &w2) {
+    w0 = x3_cvt_pk(a, b);
+    const float ra = a - __uint_as_float(w0 << 16), rb = b - __uint_as_float(w0 & 0xffff0000u);
+    w1 = x3_cvt_pk(ra, rb);
+    const float sa = ra - __uint_as_float(w1 << 16), sb = rb - __uint_as_float(w1 & 0xffff0000u);
+    w2 = x3_cvt_pk(sa, sb);
+}
+__device__ __forceinline__ void x3_split8(const float (&v)[8], X3 &out) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned a, b, c;
+        x3_split_pair(v[2 * w], v[2 * w + 1], a, b, c);
+        out.p[0][w] = a; out.p[1][w] = b; out.p[2][w] = c;
+    }
+}
+
+// acc += a . w over the 16 k slots: the six piece products, smallest first.  ACT_IS_A: the activations are the A operand
+// (rows = points; layer 4, whose result is pooled over points in registers), else the weights are (rows = channels).
+template <bool ACT_IS_A>
+__device__ __forceinline__ void x3_mfma6(const X3 &w, const X3 &a, f32x16 &acc) {
+    constexpr int WQ[6] = {0, 1, 2, 0, 1, 0}, AQ[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const bf16x8 wf = __builtin_bit_cast(bf16x8, w.p[WQ[t]]), af = __builtin_bit_cast(bf16x8, a.p[AQ[t]]);
+        acc = ACT_IS_A ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, acc, 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc, 0, 0, 0);
+    }
+}
+
+// A lane's fragment of (step, block c, piece q) in the global weight image.
+__device__ __forceinline__ const u32x4 *x3_frag_ptr(const unsigned *img, int step, int c, int q, int lane) {
+    return reinterpret_cast<const u32x4 *>(img + ((size_t)(step * 4 + c) * 3 + q) * X3_FRAG_WORDS) + lane;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same layers for a tile of fp32 activations in LDS (the recomputing backward, encoder.hip: rare -- clouds with a
+// tied pool maximum -- and the recompute_backward A/B of the tests): the bits of the forward kernel, at no particular
+// speed.  out[row][c] for ROWS rows (a multiple of 32); units (channel block, row block) dealt to the 8 waves; weights
+// straight from the global image.  epi(row, channel, value).  Must be called by every wave; no barrier inside.
+// ------------------------------------------------------------------------------------------
+template <int L, int ROWS, class Epi>
+__device__ __forceinline__ void x3_layer_lds(const float *in, int s_in, const unsigned *img, Epi epi) {
+    constexpr int K = L == 1 ? 64 : L == 4 ? 256 : 128, NOUT = L == 3 ? 256 : 128;
+    constexpr int OB = NOUT / 32, RB = ROWS / 32, UNITS = OB * RB;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    for (int unit = wave; unit < UNITS; unit += ENC_THREADS / 64) {
+        const int ob = unit % OB, rb = unit / OB;
+        const float *row = in + (rb * 32 + p) * s_in;
+        f32x16 acc = {};
+        for (int kb = 0; kb < K / 16; ++kb) {
+            float v[8];
+            if (L == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = row[16 * kb + 8 * h + j];
+            } else {
+                // layer 4's second K half reads channels 128 .. 255: block kb - 8 of the second 128
+                const int base = (L == 4 && kb >= 8 ? 128 : 0), k7 = kb & 7;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = row[base + x3_in_channel(L, k7, h, j)];
+            }
+            X3 a;
+            x3_split8(v, a);
+            X3 w;
+            const int step = x3_step_of(L, ob, kb);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w.p[q] = *x3_frag_ptr(img, step, ob & 3, q, lane);
+            x3_mfma6<L == 4>(w, a, acc);
+        }
+        if (L == 4) {   // rows = points, column = this lane's channel
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi(rb * 32 + acc_row(r, h), ob * 32 + p, acc[r]);
+        } else {        // rows = channels, column = this lane's point
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi(rb * 32 + p, ob * 32 + acc_row(r, h), acc[r]);
+        }
+    }
+}
+
+int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg,
+                          int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const FusedAdam &fa);
+
+}  // namespace geoadv

@@ -1,0 +1,346 @@
+// Encoder forward in the x3 arithmetic (encoder_x3.h): a WAVE owns 32 points and carries them through all five layers.
+//
+// Reference semantics: src/encoders_decoders.py:37-72 with the widths of src/ae_templates.py:22 -- what encoder.hip's fp32
+// kernel computes, same outputs (per-tile pool maximum / first arg-max / tie count, ReLU masks, adv = x + pert with the fused
+// Adam step), products formed as six bf16 piece products instead of one fp32 product.
+//
+// Shape.  On the 32x32x16 MFMA with the WEIGHTS as the A operand, a lane holds, for ITS point, four runs of four consecutive
+// output channels per accumulator -- exactly the eight k slots (two runs) that lane feeds to the next layer's MFMA as the B
+// operand.  So activations never leave the registers between layers: no LDS tile, no workgroup barrier at a layer boundary,
+// no bank conflicts, and the BN + ReLU + split epilogue of one channel block runs under the next layer's first MFMAs.  Layer 4
+// takes the activations as the A operand instead (same registers), so its result has the channel on the lane and the points in
+// the registers: the max-pool is reduced in registers like the fp32 kernel's.
+// One wave per SIMD (a 512-register kernel: h3 = 96 registers of pieces, h4 half = 96, two accumulator sets); the four waves of a
+// workgroup share the only operand that streams, the weights: 12 KiB per sixteen-k step, LDS-DMA'd into a four-slot ring
+// three steps ahead (each wave fetches the fragments of "its" channel block; one raw s_barrier per step orders them) and read
+// back as 12 ds_read_b128 per 24 MFMAs.
+#include "encoder_x3.h"
+#include "encoder_jac.h"
+#include <hip/hip_ext.h>
+#include <limits.h>
+#include <type_traits>
+
+namespace geoadv {
+
+constexpr int X3_THREADS = 256;               // 4 waves, one per SIMD
+constexpr int X3_POINTS = 128;                // points per workgroup
+constexpr int X3_RING = 4, X3_AHEAD = 3;      // ring slots; steps in flight ahead of the consumer
+constexpr int X3_CONST_FLOATS = 320 + 2 * (128 + 128 + 256 + 128);   // layer 0's W / scale / shift, then (scale, shift) of layers 1-4
+constexpr int X3_SC1 = 320, X3_SC2 = X3_SC1 + 256, X3_SC3 = X3_SC2 + 256, X3_SC4 = X3_SC3 + 512;   // [scale[C] | shift[C]] per layer
+constexpr size_t X3_LDS_BYTES = (size_t)X3_RING * X3_STEP_WORDS * 4 + sizeof(float) * X3_CONST_FLOATS + (sizeof(float) + 2 * sizeof(int)) * 4 * 128;
+constexpr size_t X3_LDS_BYTES_MASKS = X3_LDS_BYTES + sizeof(unsigned) * 2 * X3_POINTS * MASK_WORDS;
+
+__device__ __forceinline__ void x3_glds16(const unsigned *gsrc, unsigned *lds_dst) {   // lds_dst: wave-uniform; lane l's 16 bytes land at + 16 l
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+// (v > 0) of a non-negative-or-minus-zero float shifted into `m` from the right: bits + 0x7fffffff carries into bit 31 exactly
+// for the bit patterns 1 .. 0x7fffffff (two instructions per value; -0 and +0 give 0)
+__device__ __forceinline__ unsigned x3_push_positive(unsigned m, float v) {
+    return __builtin_amdgcn_alignbit(m, __float_as_uint(v) + 0x7fffffffu, 31);
+}
+
+template <bool MASKS>
+__global__ __launch_bounds__(X3_THREADS, 1) void encoder_fwd3_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
+                                                                    float *pmax, int *parg, int *pcnt, unsigned *masks, FusedAdam fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_w[];
+    unsigned *ring = lds_w;                                                  // [X3_RING][12 fragments][64 lanes][4 words]
+    float *cst = reinterpret_cast<float *>(ring + X3_RING * X3_STEP_WORDS);   // X3_CONST_FLOATS
+    float *redm = cst + X3_CONST_FLOATS;                                      // [4][128]
+    int *reda = reinterpret_cast<int *>(redm + 4 * 128), *redc = reda + 4 * 128;
+    unsigned *mtile = reinterpret_cast<unsigned *>(redc + 4 * 128);          // [2][X3_POINTS][MASK_WORDS] (MASKS)
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
+    const int n0 = tile * X3_POINTS + wave * 32;                              // this wave's first point
+    const unsigned *img = A.enc_x3;
+
+    // ---- the wave's points (both lanes of a point load it; the pending Adam step is applied on the way, attack.hip adam_kernel) ----
+    float pc[3];
+    {
+        int pt = n0 + p;
+        const bool valid = pt < n;
+        pt = valid ? pt : n - 1;
+        const size_t pg = ((size_t)b * n + pt) * 3;
+        float xv[3], pp[3] = {0.f, 0.f, 0.f}, ag[3], agd[3], am[3], av[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) xv[a] = x[pg + a];
+        if (pert) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pp[a] = pert[pg + a];
+        }
+        if (fa.m) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { ag[a] = fa.g_enc[pg + a]; agd[a] = fa.g_dist[pg + a]; am[a] = fa.m[pg + a]; av[a] = fa.v[pg + a]; }
+        }
+        // constants -> LDS (one pass of the workgroup)
+        for (int e = threadIdx.x; e < X3_CONST_FLOATS; e += X3_THREADS) {
+            float v;
+            if (e < 192) v = A.w0[e];
+            else if (e < 256) v = A.scale[0][e - 192];
+            else if (e < 320) v = A.shift[0][e - 256];
+            else if (e < X3_SC2) v = e - X3_SC1 < 128 ? A.scale[1][e - X3_SC1] : A.shift[1][e - X3_SC1 - 128];
+            else if (e < X3_SC3) v = e - X3_SC2 < 128 ? A.scale[2][e - X3_SC2] : A.shift[2][e - X3_SC2 - 128];
+            else if (e < X3_SC4) v = e - X3_SC3 < 256 ? A.scale[3][e - X3_SC3] : A.shift[3][e - X3_SC3 - 256];
+            else v = e - X3_SC4 < 128 ? A.scale[4][e - X3_SC4] : A.shift[4][e - X3_SC4 - 128];
+            cst[e] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = pert ? xv[a] + pp[a] : xv[a];
+            if (fa.m) {
+                float g = ag[a];
+                g += agd[a];
+                float m = am[a], vv = av[a];
+                m += (g - m) * fa.one_minus_b1;
+                vv += (g * g - vv) * fa.one_minus_b2;
+                const float pnew = pp[a] - (m * fa.alpha) / (sqrtf(vv) + fa.eps);
+                v = xv[a] + pnew;
+                if (valid && h == 0) {
+                    fa.g_enc[pg + a] = 0.f;
+                    if (fa.grad_out) fa.grad_out[pg + a] = g;
+                    fa.m[pg + a] = m; fa.v[pg + a] = vv; fa.pert[pg + a] = pnew;
+                }
+            }
+            pc[a] = v;
+            if (adv_out && valid && h == 0) adv_out[pg + a] = v;
+        }
+    }
+    __syncthreads();                                   // constants visible; nothing of the ring is in flight yet
+
+    // ---- the weight ring ----
+    // fetch(s): this wave's three fragments (pieces of channel block `wave`) of step s, 1 KiB each, lane-linear
+    auto fetch = [&](int s) {
+        const unsigned *src = img + (size_t)s * X3_STEP_WORDS + wave * 3 * X3_FRAG_WORDS + lane * 4;
+        unsigned *dst = ring + (s % X3_RING) * X3_STEP_WORDS + wave * 3 * X3_FRAG_WORDS;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) x3_glds16(src + q * X3_FRAG_WORDS, dst + q * X3_FRAG_WORDS);
+    };
+#pragma unroll
+    for (int s = 0; s < X3_AHEAD; ++s) fetch(s);
+
+    const float4 *c4 = reinterpret_cast<const float4 *>(cst);
+    // ReLU mask words of this lane's channels, [h][point of the workgroup][MASK_WORDS] (the two lanes of a point hold
+    // complementary bits of every word: OR-ed on the way out)
+    unsigned *mrow = mtile + ((size_t)h * X3_POINTS + wave * 32 + p) * MASK_WORDS;
+
+    // ---- layer 0 (fan-in 3) on the VALU: fwd_layer0's arithmetic, 32 channels per lane = the k slots it feeds to layer 1 ----
+    X3 act1[4];
+    {
+        unsigned m01[2] = {0u, 0u};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float v[8];
+            unsigned m8 = 0;
+            const int c0 = 16 * kb + 8 * h;
+            float wx[8], wy[8], wz[8], sc[8], sh[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 a = c4[(c0 >> 2) + q], bb = c4[((64 + c0) >> 2) + q], c = c4[((128 + c0) >> 2) + q];
+                const float4 d = c4[((192 + c0) >> 2) + q], e = c4[((256 + c0) >> 2) + q];
+                wx[4 * q] = a.x; wx[4 * q + 1] = a.y; wx[4 * q + 2] = a.z; wx[4 * q + 3] = a.w;
+                wy[4 * q] = bb.x; wy[4 * q + 1] = bb.y; wy[4 * q + 2] = bb.z; wy[4 * q + 3] = bb.w;
+                wz[4 * q] = c.x; wz[4 * q + 1] = c.y; wz[4 * q + 2] = c.z; wz[4 * q + 3] = c.w;
+                sc[4 * q] = d.x; sc[4 * q + 1] = d.y; sc[4 * q + 2] = d.z; sc[4 * q + 3] = d.w;
+                sh[4 * q] = e.x; sh[4 * q + 1] = e.y; sh[4 * q + 2] = e.z; sh[4 * q + 3] = e.w;
+            }
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {
+                float a = pc[0] * wx[j];
+                a = fmaf(pc[1], wy[j], a);
+                a = fmaf(pc[2], wz[j], a);
+                v[j] = fmaxf(fmaf(a, sc[j], sh[j]), 0.f);
+                if (MASKS) m8 = x3_push_positive(m8, v[j]);          // j descending: bit j = [v[j] > 0]
+            }
+            x3_split8(v, act1[kb]);
+            if (MASKS) m01[kb >> 1] |= m8 << ((kb & 1) * 16 + 8 * h);   // channel 16 kb + 8 h + j = bit (kb & 1) * 16 + 8 h + j of word kb / 2
+        }
+        if (MASKS) { mrow[0] = m01[0]; mrow[1] = m01[1]; }
+    }
+
+    // ---- the step machinery ----
+    // Before step s's first fragment read: this wave's fetches up to step s + 1 have landed (counted vmcnt: at most the three
+    // of step s + 2 stay in flight), then the barrier -- after it EVERY wave's share of steps <= s + 1 is in LDS and every wave
+    // is done with step s - 1, whose slot the fetch of step s + 3 now overwrites.
+    X3 wcur, wnext;                                    // fragments of (step, channel block) in use / requested
+    auto frag_read = [&](X3 &d, int s, int cb) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(ring + (s % X3_RING) * X3_STEP_WORDS + cb * 3 * X3_FRAG_WORDS) + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) d.p[q] = src[q * 64];
+    };
+    auto step_sync = [&](int s) {
+        if (s + X3_AHEAD - 1 < X3_STEPS) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + X3_AHEAD < X3_STEPS) fetch(s + X3_AHEAD);
+    };
+    // one sixteen-k step: acc[cb] += w(s, cb) . a for the four channel blocks; `side` = VALU work that does not depend on
+    // this step (the epilogue of the channel block the NEXT steps consume), placed inside the step so that it can issue between
+    // the MFMAs
+    auto step = [&](auto act_is_a, int s, const X3 &a, f32x16 (&acc)[4], auto side) {
+        constexpr bool ACT_IS_A = decltype(act_is_a)::value;
+        step_sync(s);
+        if (s == 0) frag_read(wcur, 0, 0);
+        side();
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            if (cb < 3) frag_read(wnext, s, cb + 1);
+            else if (s + 1 < X3_STEPS) frag_read(wnext, s + 1, 0);   // (legal: step s + 1 landed before this step's barrier)
+            x3_mfma6<ACT_IS_A>(wcur, a, acc[cb]);
+            if (cb < 3 || s + 1 < X3_STEPS) wcur = wnext;
+        }
+    };
+    auto nothing = [] {};
+    // BN + ReLU + split of HALF a channel block of a layer result (acc: lane = point, registers = channels 32 cb + 8 g + 4 h + u;
+    // gh = 0: g = 0, 1; gh = 1: g = 2, 3): the pieces of the next layer's sixteen-k block 2 cb + gh; m16 collects the mask bits
+    auto epilogue_half = [&](const f32x16 &acc, int cb, int gh, const float *scsh /* [scale[C] | shift[C]] */, int C, int coff, X3 &dst,
+                             unsigned &m16) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(scsh + coff + 32 * cb + 4 * h);
+        const float4 *t4 = reinterpret_cast<const float4 *>(scsh + C + coff + 32 * cb + 4 * h);
+#pragma unroll
+        for (int gg = 1; gg >= 0; --gg) {
+            const int g = 2 * gh + gg;
+            const float4 sc = s4[2 * g], sh = t4[2 * g];
+            float v[4];
+            v[3] = fmaxf(fmaf(acc[4 * g + 3], sc.w, sh.w), 0.f);
+            v[2] = fmaxf(fmaf(acc[4 * g + 2], sc.z, sh.z), 0.f);
+            v[1] = fmaxf(fmaf(acc[4 * g + 1], sc.y, sh.y), 0.f);
+            v[0] = fmaxf(fmaf(acc[4 * g + 0], sc.x, sh.x), 0.f);
+            if (MASKS) {
+#pragma unroll
+                for (int u = 3; u >= 0; --u) m16 = x3_push_positive(m16, v[u]);   // within a half: bit 4 gg + u
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                unsigned a, bq, c;
+                x3_split_pair(v[2 * w], v[2 * w + 1], a, bq, c);
+                dst.p[0][2 * gg + w] = a; dst.p[1][2 * gg + w] = bq; dst.p[2][2 * gg + w] = c;
+            }
+        }
+    };
+    // mask word of a channel block from the bits of its two halves (m_lo: g = 0, 1; m_hi: g = 2, 3; bit 4 gg + u each):
+    // channel 8 g + 4 h + u = that bit of the word
+    auto mask_store = [&](int word, unsigned m_lo, unsigned m_hi) {
+        const unsigned m16 = (m_lo & 0xffu) | ((m_hi & 0xffu) << 8);
+        const unsigned spread = (m16 & 0xfu) | ((m16 & 0xf0u) << 4) | ((m16 & 0xf00u) << 8) | ((m16 & 0xf000u) << 12);
+        mrow[word] = spread << (4 * h);
+    };
+    using ActB = std::integral_constant<bool, false>;
+    using ActA = std::integral_constant<bool, true>;
+
+    // A layer boundary, software-pipelined: the epilogue of channel block cb + 1 of the finished layer (`prev`) rides in the two
+    // steps of the next layer that consume block cb's pieces.  keep: where the pieces are kept for a later pass (h3), or null.
+    auto boundary = [&](auto act_is_a, f32x16 (&prev)[4], const float *scsh, int C, int coff, int mask_off, int s0, f32x16 (&next)[4], X3 *keep) {
+        X3 cur[2], nxt[2];
+        unsigned ml = 0, mh = 0;
+        epilogue_half(prev[0], 0, 0, scsh, C, coff, cur[0], ml);
+        epilogue_half(prev[0], 0, 1, scsh, C, coff, cur[1], mh);
+        if (MASKS) mask_store(mask_off, ml, mh);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            unsigned nl = 0, nh = 0;
+            if (keep) { keep[2 * cb] = cur[0]; keep[2 * cb + 1] = cur[1]; }
+            if (cb < 3) {
+                step(act_is_a, s0 + 2 * cb, cur[0], next, [&] { epilogue_half(prev[cb + 1], cb + 1, 0, scsh, C, coff, nxt[0], nl); });
+                step(act_is_a, s0 + 2 * cb + 1, cur[1], next, [&] { epilogue_half(prev[cb + 1], cb + 1, 1, scsh, C, coff, nxt[1], nh); });
+                if (MASKS) mask_store(mask_off + cb + 1, nl, nh);
+                cur[0] = nxt[0]; cur[1] = nxt[1];
+            } else {
+                step(act_is_a, s0 + 2 * cb, cur[0], next, nothing);
+                step(act_is_a, s0 + 2 * cb + 1, cur[1], next, nothing);
+            }
+        }
+    };
+
+    // ---- layer 1: 64 -> 128 (steps 0-3) ----
+    f32x16 acc1[4] = {};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) step(ActB{}, kb, act1[kb], acc1, nothing);
+    // ---- layer 2: 128 -> 128 (steps 4-11) ----
+    f32x16 acc2[4] = {};
+    boundary(ActB{}, acc1, cst + X3_SC1, 128, 0, MASK_OFF2, 4, acc2, nullptr);
+    // ---- layers 3 + 4 by halves: h4[:, 128 half ..] feeds K half `half` of layer 4 (one chain over K = 256, ascending) ----
+    X3 act3[8];
+    f32x16 acc3[4] = {}, acc4[4] = {};
+    boundary(ActB{}, acc2, cst + X3_SC2, 128, 0, MASK_OFF3, 12, acc3, act3);           // layer 3, channels 0 .. 127 (steps 12-19)
+    boundary(ActA{}, acc3, cst + X3_SC3, 256, 0, MASK_OFF4, 20, acc4, nullptr);        // layer 4, K half 0 (steps 20-27)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc3[cb] = f32x16{};
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) step(ActB{}, 28 + kb, act3[kb], acc3, nothing);      // layer 3, channels 128 .. 255 (steps 28-35)
+    boundary(ActA{}, acc3, cst + X3_SC3, 256, 128, MASK_OFF4 + 4, 36, acc4, nullptr);  // layer 4, K half 1 (steps 36-43)
+
+    // ---- layer 4's BN + ReLU and the max-pool from the registers (lane = channel 32 cb + p, registers = points) ----
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int col = 32 * cb + p;
+        const float sc4 = cst[X3_SC4 + col], sh4 = cst[X3_SC4 + 128 + col];
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(fmaf(acc4[cb][r], sc4, sh4), 0.f);
+        if (n0 + 32 > n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (n0 + acc_row(r, h) >= n) v[r] = -2.f;             // never the maximum, never equal to it
+        }
+        float mx = -1.f;
+        int arg = INT_MAX, cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, v[r]);
+#pragma unroll
+        for (int r = 15; r >= 0; --r) {                               // rows ascend with r: the last hit kept is the lowest row
+            const bool hit = v[r] == mx;
+            arg = hit ? n0 + acc_row(r, h) : arg;
+            cnt += hit ? 1 : 0;
+        }
+        const float m2 = __shfl_xor(mx, 32);
+        const int a2 = __shfl_xor(arg, 32), k2 = __shfl_xor(cnt, 32);
+        if (m2 > mx) { mx = m2; arg = a2; cnt = k2; }
+        else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += k2; }
+        if (h == 0) { redm[wave * 128 + col] = mx; reda[wave * 128 + col] = arg; redc[wave * 128 + col] = cnt; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        float m = redm[c];
+        int a = reda[c], k = redc[c];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {                                  // waves hold ascending point ranges: the first hit stays
+            const float m2 = redm[w * 128 + c];
+            if (m2 > m) { m = m2; a = reda[w * 128 + c]; k = redc[w * 128 + c]; }
+            else if (m2 == m) { k += redc[w * 128 + c]; }
+        }
+        const size_t o = ((size_t)b * tiles + tile) * 128 + c;
+        pmax[o] = m; parg[o] = a; pcnt[o] = k;
+    }
+    if (MASKS) {   // the tile's mask rows are contiguous in HBM: the two lanes' halves OR-ed, coalesced stores
+        const int t0 = tile * X3_POINTS, live = n - t0 < X3_POINTS ? n - t0 : X3_POINTS;
+        unsigned *dst = masks + ((size_t)b * n + t0) * MASK_WORDS;
+        for (int e = threadIdx.x; e < live * MASK_WORDS; e += X3_THREADS) dst[e] = mtile[e] | mtile[X3_POINTS * MASK_WORDS + e];
+    }
+}
+
+int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg,
+                          int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const FusedAdam &fa) {
+    static DeviceOnce attr;
+    if (int rc = attr.run([]() -> int {
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES_MASKS));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES));
+            return GEOADV_OK;
+        })) return rc;
+    const dim3 grid(cdiv(A.n_points, X3_POINTS), b), block(X3_THREADS);
+    const unsigned lds = (unsigned)(masks ? X3_LDS_BYTES_MASKS : X3_LDS_BYTES);
+    if (masks) {
+        if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3_kernel<true>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+        else encoder_fwd3_kernel<true><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+    } else {
+        if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3_kernel<false>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+        else encoder_fwd3_kernel<false><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+    }
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
+}  // namespace geoadv

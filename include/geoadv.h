@@ -238,6 +238,20 @@ typedef struct geoadv_ae_weights {
 int  geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *host_weights);
 void geoadv_ae_destroy(geoadv_ae *ae);
 
+/* Arithmetic of the encoder's four wide layers (the path's dominant kernel; 180 kFLOP per point).
+ *   F32    : v_mfma_f32_32x32x2_f32 -- fp32 products, fp32 accumulate (bounded by the 157 TFLOP/s fp32 matrix peak).
+ *   BF16X3 : every operand as three bf16 pieces (8 + 8 + 8 bits = the fp32's 24), a product as its six piece products of
+ *            weight >= 2^-16, each exact in the fp32 accumulator, on v_mfma_f32_32x32x16_bf16 (csrc/encoder_x3.h).  Error
+ *            against float64 = that of an fp32 accumulation in another order (profiles/r05_bf16x3_probe.jsonl); not the
+ *            bits of F32.  Non-finite coordinates give NaN activations (inf - inf in the split) where F32 gives inf.
+ * Both reproduce themselves bit for bit (forward, recomputing backward, any batch).  The default of handles created from
+ * now on / of one handle (set before it is shared with attack handles or threads). */
+#define GEOADV_ENC_ARITH_F32    0
+#define GEOADV_ENC_ARITH_BF16X3 1
+int  geoadv_set_default_encoder_arith(int arith);
+int  geoadv_ae_set_encoder_arith(geoadv_ae *ae, int arith);
+int  geoadv_ae_encoder_arith(const geoadv_ae *ae);
+
 /* AdversaryAutoEncoder.reconstruct / AutoEncoder.transform (adversary_autoencoder.py:75-91):
  * pc[b,n,3] -> latent[b,bneck] (may be NULL) and recon[b,n,3] (may be NULL).
  * workspace: geoadv_ae_workspace_bytes(ae,b) bytes of device scratch. */

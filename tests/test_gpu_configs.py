@@ -104,7 +104,10 @@ def test_config2_latent_attack_then_knn_defense_b256():
                      loss_adv_type="latent")
     am.pert = s["pert"][sel].astype(np.float64)
     f = am.forward()
-    np.testing.assert_allclose(h[-1, 0][sel], f["loss_adv"], rtol=1e-5)
+    # the latent loss is a sum of squared DIFFERENCES of latents (|z - t| ~ 0.005 against |z| ~ 0.2): the latent's own fp32
+    # rounding (2e-7 absolute, checked two lines down at 2e-6) is amplified ~40 x in relative terms -- 2e-6 ... 1e-5 under either
+    # encoder arithmetic (tools/debug/x3_cfg2.py), so 3e-5 here; the Chamfer loss keeps the path's 1e-5
+    np.testing.assert_allclose(h[-1, 0][sel], f["loss_adv"], rtol=3e-5)
     np.testing.assert_allclose(h[-1, 1][sel], f["loss_dist"], rtol=1e-5, atol=1e-12)
     np.testing.assert_allclose(s["latent"][sel], f["z"], atol=2e-6)
     out = defend_surface(at.ae, adv[0], x, num_knn=8, top_k=2, knn_dist_thresh=0.04)

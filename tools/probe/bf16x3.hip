@@ -1,0 +1,246 @@
+// Probe (measurement tooling, NOT part of libgeoadv.so): fp32 products emulated on the bf16 matrix pipe.
+//   x = x0 + x1 + x2 (three bf16 pieces, 8 + 8 + 8 significant bits), a . b ~ the 6 piece products of weight >= 2^-16
+//   (a0b0, a0b1, a1b0, a0b2, a1b1, a2b0) on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+// Two questions, answered before anything is built on it:
+//   accuracy   -- how far from the exact product is the 6-term (and 9-term) form, next to the fp32 MFMA chain the encoder uses?
+//   throughput -- what does the loop shape of a wave-private encoder sustain (one wave per SIMD, weights re-read from LDS, the
+//                 epilogue's VALU work between the MFMAs), on random operands, launched the way the attack launches its encoder?
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+static char g_err[256] = "";
+#define PR_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// ---- piece split: truncation (bit masks; the three pieces add up to x exactly) or round-to-nearest-even casts ----
+template <bool RNE>
+__device__ __forceinline__ void split3(float x, unsigned &p0, unsigned &p1, unsigned &p2) {   // pieces as bf16 bit patterns (low 16 bits)
+    if (RNE) {
+        const __bf16 h0 = (__bf16)x;
+        const float r1 = x - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        const __bf16 h2 = (__bf16)r2;
+        p0 = __builtin_bit_cast(unsigned short, h0); p1 = __builtin_bit_cast(unsigned short, h1); p2 = __builtin_bit_cast(unsigned short, h2);
+    } else {
+        const unsigned u = __float_as_uint(x);
+        const unsigned u0 = u & 0xffff0000u;
+        const float r1 = x - __uint_as_float(u0);
+        const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(u1);
+        p0 = u0 >> 16; p1 = u1 >> 16; p2 = __float_as_uint(r2) >> 16;
+    }
+}
+
+template <bool RNE>
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&p)[3]) {
+    unsigned w[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3<RNE>(x[2 * j], a0, a1, a2);
+        split3<RNE>(x[2 * j + 1], b0, b1, b2);
+        w[0][j] = a0 | (b0 << 16); w[1][j] = a1 | (b1 << 16); w[2][j] = a2 | (b2 << 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[q] = __builtin_bit_cast(bf16x8, (u32x4){w[q][0], w[q][1], w[q][2], w[q][3]});
+}
+
+// C[tile][32][32] = A[tile][32][K] @ B[K][32]; one wave per tile.  mode 0: fp32 MFMA chain (ascending k); 1: 6 bf16 piece
+// products per 16 k (small terms first); 2: all 9; 3: 6 terms, truncation split; 4: 3 terms only (a0b0, a0b1, a1b0: "bf16x2")
+template <int MODE>
+__global__ __launch_bounds__(64) void acc_kernel(const float *A, const float *B, float *C, int K) {
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const float *a = A + (size_t)blockIdx.x * 32 * K;
+    f32x16 acc = {};
+    if (MODE == 0) {
+        for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r * K + k + h], B[(k + h) * 32 + r], acc, 0, 0, 0);
+    } else {
+        constexpr bool RNE = MODE != 3;
+        for (int k = 0; k < K; k += 16) {
+            float xa[8], xb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xa[j] = a[r * K + k + 8 * h + j]; xb[j] = B[(k + 8 * h + j) * 32 + r]; }
+            bf16x8 pa[3], pb[3];
+            split8<RNE>(xa, pa); split8<RNE>(xb, pb);
+            if (MODE == 2) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[2], pb[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[2], pb[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], pb[2], acc, 0, 0, 0);
+            }
+            if (MODE != 4) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[2], pb[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], pb[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], pb[2], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], pb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], pb[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], pb[0], acc, 0, 0, 0);
+        }
+    }
+    float *c = C + (size_t)blockIdx.x * 1024;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c[((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + r] = acc[q];
+}
+
+extern "C" const char *bf16x3_last_error(void) { return g_err; }
+
+extern "C" int bf16x3_accuracy(int mode, const float *A, const float *B, float *C, int tiles, int K, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode) {
+        case 0: acc_kernel<0><<<tiles, 64, 0, st>>>(A, B, C, K); break;
+        case 1: acc_kernel<1><<<tiles, 64, 0, st>>>(A, B, C, K); break;
+        case 2: acc_kernel<2><<<tiles, 64, 0, st>>>(A, B, C, K); break;
+        case 3: acc_kernel<3><<<tiles, 64, 0, st>>>(A, B, C, K); break;
+        case 4: acc_kernel<4><<<tiles, 64, 0, st>>>(A, B, C, K); break;
+        default: snprintf(g_err, sizeof g_err, "mode"); return 1;
+    }
+    PR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- throughput: the loop shape of a wave-private encoder -----------------------------------------------------------------
+// 256 threads = one wave per SIMD (launch bounds make it a 512-register kernel).  A wave owns 32 points; per 16-k step it reads the
+// 3 pieces of 4 channel blocks of weights from LDS (12 ds_read_b128), and issues 24 MFMAs (4 accumulators x 6 piece products)
+// against its 3 activation pieces (registers).  FILL VALU instructions per MFMA stand for the epilogue (BN, ReLU, split, pack).
+// steps: 16-k steps per wave (a 32-point unit of the encoder is 44: 4 + 8 + 16 + 16 ... x 4 channel blocks = 1056 MFMAs).
+// SRC 0: weights re-read from a 48 KiB LDS image (filled once); 1: operands stay in registers (bare MFMA rate)
+template <int FILL, int SRC>
+__global__ __launch_bounds__(256, 1) void tp_kernel(const u32x4 *wimg, float *out, int steps, int units) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 wl[];        // [4 steps][12 fragments][64 lanes]
+    const int lane = threadIdx.x & 63;
+    for (int e = threadIdx.x; e < 4 * 12 * 64; e += 256) wl[e] = wimg[e];
+    __syncthreads();
+    bf16x8 act[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) act[q] = __builtin_bit_cast(bf16x8, wimg[(q * 5 + 1) * 64 + lane]);
+    float sink = 0.f;
+    for (int u = 0; u < units; ++u) {
+        f32x16 acc[4] = {};
+        float f[8] = {1.f + lane, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+        bf16x8 w[4][3], wn[4][3];
+        auto fetch = [&](bf16x8 (&d)[4][3], int s) {
+            const u32x4 *wp = wl + (s & 3) * 12 * 64 + lane;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) d[cb][q] = __builtin_bit_cast(bf16x8, SRC == 0 ? wp[(cb * 3 + q) * 64] : wimg[((cb * 3 + q) * 64 + lane)]);
+        };
+        fetch(w, 0);
+        for (int s = 0; s < steps; ++s) {
+            fetch(wn, s + 1);                                  // the next step's weights are requested before this step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            // piece products in ascending weight; the four accumulators interleaved
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                constexpr int wa[6] = {2, 1, 0, 1, 0, 0}, xa[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cb][wa[t]], act[xa[t]], acc[cb], 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < FILL; ++v) f[(v + cb) & 7] = fmaf(f[(v + cb) & 7], 1.0001f, 0.5f);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) w[cb][q] = wn[cb][q];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sink += acc[cb][q];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) sink += f[v];
+    }
+    if (sink == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = sink;
+}
+
+// a VALU-only kernel of a chosen length, launched between the probes to give the chip the attack's duty cycle
+__global__ __launch_bounds__(256) void idle_kernel(float *out, int iters) {
+    float a = threadIdx.x, b = 1.0001f;
+    for (int i = 0; i < iters; ++i) { a = fmaf(a, b, 0.5f); b = fmaf(b, 0.99999f, 1e-6f); }
+    if (a == 12345.678f) out[threadIdx.x] = a + b;
+}
+
+// ms per tp launch (average over `reps`, HIP events around each launch), with `gap_iters` of the VALU kernel between launches
+extern "C" int bf16x3_throughput(int fill, int src, int blocks, int steps, int units, int reps, int gap_iters, float *ms_out,
+                                 float *gap_ms_out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    static u32x4 *wimg = nullptr;
+    static float *out = nullptr;
+    const size_t n = 4 * 12 * 64;
+    if (!wimg) {
+        PR_HIP(hipMalloc(&wimg, n * sizeof(u32x4)));
+        PR_HIP(hipMalloc(&out, 1 << 22));
+        uint32_t *h = (uint32_t *)malloc(n * 16);
+        uint32_t s = 12345u;
+        for (size_t i = 0; i < n * 4; ++i) {                      // random bf16 pairs of magnitude ~[0.25, 4)
+            uint32_t w = 0;
+            for (int k = 0; k < 2; ++k) {
+                s = s * 1664525u + 1013904223u;
+                const uint32_t sign = (s >> 31) << 15, exp = (125u + ((s >> 20) & 3u)) << 7, man = (s >> 8) & 0x7fu;
+                w |= (sign | exp | man) << (16 * k);
+            }
+            h[i] = w;
+        }
+        PR_HIP(hipMemcpy(wimg, h, n * 16, hipMemcpyHostToDevice));
+        free(h);
+    }
+    auto launch = [&](void) {
+        const size_t lds = n * sizeof(u32x4);
+#define TP(F, S) tp_kernel<F, S><<<blocks, 256, lds, st>>>(wimg, out, steps, units)
+        if (src == 0) { if (fill == 0) TP(0, 0); else if (fill == 2) TP(2, 0); else if (fill == 3) TP(3, 0); else if (fill == 4) TP(4, 0); else TP(6, 0); }
+        else { if (fill == 0) TP(0, 1); else TP(3, 1); }
+#undef TP
+    };
+    if (reps > 256) reps = 256;
+    static hipEvent_t ev[4][256];
+    static bool have = false;
+    if (!have) { for (int k = 0; k < 4; ++k) for (int i = 0; i < 256; ++i) PR_HIP(hipEventCreate(&ev[k][i])); have = true; }
+    for (int i = 0; i < 50; ++i) { launch(); if (gap_iters) idle_kernel<<<2048, 256, 0, st>>>(out, gap_iters); }
+    for (int i = 0; i < reps; ++i) {      // no host synchronisation inside: the stream runs the way the attack loop's does
+        PR_HIP(hipEventRecord(ev[0][i], st));
+        launch();
+        PR_HIP(hipEventRecord(ev[1][i], st));
+        if (gap_iters) {
+            PR_HIP(hipEventRecord(ev[2][i], st));
+            idle_kernel<<<2048, 256, 0, st>>>(out, gap_iters);
+            PR_HIP(hipEventRecord(ev[3][i], st));
+        }
+    }
+    PR_HIP(hipStreamSynchronize(st));
+    PR_HIP(hipGetLastError());
+    double tot = 0, gtot = 0;
+    for (int i = 0; i < reps; ++i) {
+        float ms = 0;
+        PR_HIP(hipEventElapsedTime(&ms, ev[0][i], ev[1][i])); tot += ms;
+        if (gap_iters) { PR_HIP(hipEventElapsedTime(&ms, ev[2][i], ev[3][i])); gtot += ms; }
+    }
+    *ms_out = (float)(tot / reps);
+    *gap_ms_out = (float)(gtot / reps);
+    return 0;
+}
+
+// Holds `lds_bytes` of LDS on every CU for a while (few registers, one wave): what a kernel launched meanwhile sees as a
+// non-zero LDS base.  Debug aid for kernels that address LDS through M0 (LDS-DMA).
+__global__ __launch_bounds__(64) void lds_hog_kernel(float *out, int iters) {
+    extern __shared__ float hog[];
+    hog[threadIdx.x] = threadIdx.x;
+    float a = hog[(threadIdx.x + 1) & 63];
+    for (int i = 0; i < iters; ++i) { a = fmaf(a, 1.0001f, 0.5f); __builtin_amdgcn_s_sleep(8); }
+    if (a == 12345.678f) out[threadIdx.x] = a;
+}
+extern "C" int bf16x3_lds_hog(int blocks, int lds_bytes, int iters, void *stream) {
+    static float *out = nullptr;
+    if (!out) PR_HIP(hipMalloc(&out, 4096));
+    PR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    lds_hog_kernel<<<blocks, 64, lds_bytes, (hipStream_t)stream>>>(out, iters);
+    PR_HIP(hipGetLastError());
+    return 0;
+}
