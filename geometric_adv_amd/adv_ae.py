@@ -25,7 +25,7 @@ class Configuration:
                  max_point_dist_weight=0.0, num_iterations=500, num_iterations_thresh=400,
                  learning_rate=0.01, ae_name="autoencoder", emd_weight=0.0, verbose=False, batch_slots=1,
                  chamfer_prune=True, emd_reference_weights=False, recompute_backward=False, separate_adam=False,
-                 chamfer_kernel="auto", encoder_backward="auto", emd_dense_levels=False):
+                 chamfer_kernel="auto", encoder_backward="auto", emd_dense_levels=False, encoder_arith=None):
         self.batch_size = int(batch_size)
         self.n_input = [int(n_points), 3]
         self.n_output = [int(n_points), 3]
@@ -51,6 +51,7 @@ class Configuration:
                                                  # a batch that hands most clouds back switches off FOR THAT BATCH (adapt_source_search);
                                                  # "pinned": True without that policy (timing independent of the data)
         self.emd_reference_weights = bool(emd_reference_weights)   # True: the EMD term's plan from the CPU op's expf arguments (ops.approx_match)
+        self.encoder_arith = encoder_arith                         # None (library default: "bf16x3"), "bf16x3" or "f32": autoencoder.ENCODER_ARITH; of the model this handle creates
         self.emd_dense_levels = bool(emd_dense_levels)             # True: this handle's EMD sweeps all dense (GEOADV_EMD_DENSE_LEVELS; per handle, nothing process-wide)
         # alternative code paths with the same results (geoadv_attack_config; the parity tests run each against the default)
         self.recompute_backward = bool(recompute_backward)   # encoder backward re-runs the forward instead of reading ReLU masks
@@ -90,7 +91,8 @@ class AdvAE:
         if c.loss_dist_type not in ("pert", "chamfer"):
             raise ValueError("loss_dist_type must be 'pert' or 'chamfer' (run_attack.py:50)")
         self.device = torch.device(device if device is not None else "cuda:0")
-        self.ae = ae if ae is not None else PointNetAE(c.weights, c.n_input[0], c.ae_name, self.device)
+        self.ae = ae if ae is not None else PointNetAE(c.weights, c.n_input[0], c.ae_name, self.device,
+                                                       encoder_arith=getattr(c, "encoder_arith", None))
         self.n = c.n_input[0]
         self.B = c.batch_size
         cfg = _AttackConfig(self.B, 1 if c.loss_adv_type == "latent" else 0, 1 if c.loss_dist_type == "pert" else 0,

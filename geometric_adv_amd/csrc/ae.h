@@ -29,6 +29,7 @@ struct DeviceAE {
     PackedLayer enc_bwd[ENC_L];    // [1..4] used: W_i^T : [C_{i+1}] -> [C_i]
     PackedLayer enc_bwd16[ENC_L];  // the same products packed for the 16x16x4 shape
     const unsigned *enc_x3;        // encoder layers 1-4 as bf16 piece fragments in step order (encoder_x3.h)
+    const float *enc_x3_consts;    // the x3 forward's LDS constants as one block (encoder_x3.h: X3_CONST_FLOATS)
     int enc_arith;                 // GEOADV_ENC_ARITH_*: which forward (and recompute) arithmetic the encoder kernels use
     const float *scale[ENC_L];     // BN folded: h = max(a*scale + shift, 0), a = x@W (no bias)
     const float *shift[ENC_L];     // shift = b*scale + (beta - mean*scale)

@@ -167,7 +167,7 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     size_t o_v0 = reserve(128 * 256), o_c0 = reserve(256), o_v1 = reserve(256 * 256), o_c1 = reserve(256);
     size_t o_v0t = reserve(256 * 128), o_v1t = reserve(256 * 256);
     size_t o_d2f = reserve((size_t)256 * n3p32), o_d2b = reserve((size_t)n3p8 * 256), o_c2 = reserve(n3);
-    size_t o_x3 = reserve(X3_IMAGE_WORDS);
+    size_t o_x3 = reserve(X3_IMAGE_WORDS), o_x3c = reserve(X3_CONST_FLOATS);
 
     memcpy(&host[o_w0], hw->enc_w[0], sizeof(float) * 3 * C[1]);
     for (int i = 1; i < ENC_L; ++i) {
@@ -186,6 +186,17 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
             host[o_scale[i] + c] = inv;
             host[o_shift[i] + c] = hw->enc_b[i][c] * inv + (hw->bn_beta[i][c] - hw->bn_mean[i][c] * inv);
         }
+    {   // the x3 forward's constant block (encoder_x3.h)
+        float *c = &host[o_x3c];
+        memcpy(c, hw->enc_w[0], sizeof(float) * 192);
+        memcpy(c + 192, &host[o_scale[0]], sizeof(float) * 64);
+        memcpy(c + 256, &host[o_shift[0]], sizeof(float) * 64);
+        const int off[5] = {0, X3_SC1, X3_SC2, X3_SC3, X3_SC4};
+        for (int i = 1; i < ENC_L; ++i) {
+            memcpy(c + off[i], &host[o_scale[i]], sizeof(float) * C[i + 1]);
+            memcpy(c + off[i] + C[i + 1], &host[o_shift[i]], sizeof(float) * C[i + 1]);
+        }
+    }
     memcpy(&host[o_v0], hw->dec_w[0], sizeof(float) * 128 * 256);
     memcpy(&host[o_c0], hw->dec_b[0], sizeof(float) * 256);
     memcpy(&host[o_v1], hw->dec_w[1], sizeof(float) * 256 * 256);
@@ -240,6 +251,7 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     d.dec2_bwd = PackedLayer{base + o_d2b, n3p8, 256};
     d.c2 = base + o_c2;
     d.enc_x3 = reinterpret_cast<const unsigned *>(base + o_x3);
+    d.enc_x3_consts = base + o_x3c;
     d.enc_arith = g_default_enc_arith.load();
     *out = ae;
     return GEOADV_OK;

@@ -706,9 +706,9 @@ static int set_lds_attr_once() {
 #define ENC_ROWS32_BELOW 2      // 32-row tiles while 64-row ones give a CU fewer than two workgroups (measured at B = 12: 0.1235 -> 0.1135 ms per iteration; B = 8, 16: unchanged)
 #endif
 int encoder_fwd_rows(int b, int n) { return (long)b * cdiv(n, 64) < ENC_ROWS32_BELOW * kCUs ? 32 : 64; }
-// pool partials per cloud of a forward launch (x3 arithmetic: 128-point workgroups whatever the batch, encoder_x3.hip)
+// pool partials per cloud of a forward launch
 int encoder_tiles(const DeviceAE &A, int b) {
-    return A.enc_arith == GEOADV_ENC_ARITH_BF16X3 ? cdiv(A.n_points, 128) : cdiv(A.n_points, encoder_fwd_rows(b, A.n_points));
+    return A.enc_arith == GEOADV_ENC_ARITH_BF16X3 ? cdiv(A.n_points, encoder_x3_points(b, A.n_points)) : cdiv(A.n_points, encoder_fwd_rows(b, A.n_points));
 }
 int encoder_tiles_max(int n) { return cdiv(n, 32); }              // what the pool-partial buffers are sized for
 

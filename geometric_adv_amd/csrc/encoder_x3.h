@@ -28,6 +28,10 @@ constexpr int X3_STEPS = 44;                  // sixteen-k steps of one 32-point
 constexpr int X3_FRAG_WORDS = 64 * 4;         // one fragment: 64 lanes x 16 bytes (8 bf16 k-slots per lane)
 constexpr int X3_STEP_WORDS = 4 * 3 * X3_FRAG_WORDS;   // 4 output-channel blocks x 3 pieces = 12 KiB
 constexpr size_t X3_IMAGE_WORDS = (size_t)X3_STEPS * X3_STEP_WORDS;
+// the constants the forward keeps in LDS, as one block (DeviceAE::enc_x3_consts): W0 [3][64], scale0 [64], shift0 [64], then
+// [scale | shift] of layers 1 (128 + 128), 2 (128 + 128), 3 (256 + 256), 4 (128 + 128)
+constexpr int X3_CONST_FLOATS = 320 + 2 * (128 + 128 + 256 + 128);
+constexpr int X3_SC1 = 320, X3_SC2 = X3_SC1 + 256, X3_SC3 = X3_SC2 + 256, X3_SC4 = X3_SC3 + 512;
 
 // Step of the weight image that holds layer L's fragments of output-channel block ob (32 channels), sixteen-k block kb; the
 // fragment's position inside the step is (ob & 3).  Order = the order the forward consumes them in.
@@ -127,6 +131,7 @@ __device__ __forceinline__ void x3_layer_lds(const float *in, int s_in, const un
     }
 }
 
+int encoder_x3_points(int b, int n);          // points per workgroup (= per pool partial) of the x3 forward for b clouds of n points
 int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg,
                           int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const FusedAdam &fa);
 

@@ -24,10 +24,14 @@ namespace geoadv {
 
 constexpr int X3_THREADS = 256;               // 4 waves, one per SIMD
 constexpr int X3_POINTS = 128;                // points per workgroup
-constexpr int X3_RING = 4, X3_AHEAD = 3;      // ring slots; steps in flight ahead of the consumer
-constexpr int X3_CONST_FLOATS = 320 + 2 * (128 + 128 + 256 + 128);   // layer 0's W / scale / shift, then (scale, shift) of layers 1-4
-constexpr int X3_SC1 = 320, X3_SC2 = X3_SC1 + 256, X3_SC3 = X3_SC2 + 256, X3_SC4 = X3_SC3 + 512;   // [scale[C] | shift[C]] per layer
-constexpr size_t X3_LDS_BYTES = (size_t)X3_RING * X3_STEP_WORDS * 4 + sizeof(float) * X3_CONST_FLOATS + (sizeof(float) + 2 * sizeof(int)) * 4 * 128;
+constexpr int X3_RING = 4, X3_AHEAD = 3;      // ring slots and slots in flight ahead of the consumer; a slot = X3_SLOT_STEPS steps
+constexpr int X3_SLOT_STEPS = 2;              // (one barrier per slot: per step it was 4.6 us of the B = 32 launch)
+constexpr int X3_SLOTS = X3_STEPS / X3_SLOT_STEPS, X3_SLOT_WORDS = X3_SLOT_STEPS * X3_STEP_WORDS;
+static_assert(X3_STEPS % X3_SLOT_STEPS == 0, "whole slots");
+#ifndef X3_SPLIT_HALVES
+#define X3_SPLIT_HALVES 1                     // the split form while 128-point workgroups would cover at most this many halves of the CUs
+#endif                                        // (measured, iteration ms at B = 8 / 16: split 0.0766 / 0.108, wave-private 0.0825 / 0.0935)
+constexpr size_t X3_LDS_BYTES = (size_t)X3_RING * X3_SLOT_WORDS * 4 + sizeof(float) * X3_CONST_FLOATS + (sizeof(float) + 2 * sizeof(int)) * 4 * 128;
 constexpr size_t X3_LDS_BYTES_MASKS = X3_LDS_BYTES + sizeof(unsigned) * 2 * X3_POINTS * MASK_WORDS;
 
 __device__ __forceinline__ void x3_glds16(const unsigned *gsrc, unsigned *lds_dst) {   // lds_dst: wave-uniform; lane l's 16 bytes land at + 16 l
@@ -40,12 +44,138 @@ __device__ __forceinline__ unsigned x3_push_positive(unsigned m, float v) {
     return __builtin_amdgcn_alignbit(m, __float_as_uint(v) + 0x7fffffffu, 31);
 }
 
+// The lane's point (both lanes of a point load it) with the pending Adam step applied on the way (attack.hip adam_kernel, the same
+// operations in the same order).  The stores are a step of their own (x3_store_point): where several waves load the same
+// points (the split form) they must all have loaded before one of them stores.
+struct X3Point { float v[3], g[3], m[3], vv[3], pnew[3]; size_t pg; bool valid; };
+__device__ __forceinline__ void x3_load_point(int n, int b, int pt_raw, const float *x, const float *pert, const FusedAdam &fa, X3Point &o) {
+    o.valid = pt_raw < n;
+    const int pt = o.valid ? pt_raw : n - 1;
+    o.pg = ((size_t)b * n + pt) * 3;
+    float xv[3], pp[3] = {0.f, 0.f, 0.f}, ag[3], agd[3], am[3], av[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) xv[a] = x[o.pg + a];
+    if (pert) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pp[a] = pert[o.pg + a];
+    }
+    if (fa.m) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ag[a] = fa.g_enc[o.pg + a]; agd[a] = fa.g_dist[o.pg + a]; am[a] = fa.m[o.pg + a]; av[a] = fa.v[o.pg + a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float v = pert ? xv[a] + pp[a] : xv[a];
+        if (fa.m) {
+            float g = ag[a];
+            g += agd[a];
+            float m = am[a], vv = av[a];
+            m += (g - m) * fa.one_minus_b1;
+            vv += (g * g - vv) * fa.one_minus_b2;
+            const float pnew = pp[a] - (m * fa.alpha) / (sqrtf(vv) + fa.eps);
+            v = xv[a] + pnew;
+            o.g[a] = g; o.m[a] = m; o.vv[a] = vv; o.pnew[a] = pnew;
+        }
+        o.v[a] = v;
+    }
+}
+__device__ __forceinline__ void x3_store_point(const X3Point &o, float *adv_out, const FusedAdam &fa) {
+    if (!o.valid) return;                              // (padding lanes repeat the cloud's last point and must not store)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (fa.m) {
+            fa.g_enc[o.pg + a] = 0.f;
+            if (fa.grad_out) fa.grad_out[o.pg + a] = o.g[a];
+            fa.m[o.pg + a] = o.m[a]; fa.v[o.pg + a] = o.vv[a]; fa.pert[o.pg + a] = o.pnew[a];
+        }
+        if (adv_out) adv_out[o.pg + a] = o.v[a];
+    }
+}
+
+// layer 0's constants and the (scale, shift) pairs of layers 1-4 -> LDS: a straight copy of the block ae.hip packs in this
+// order (X3_CONST_FLOATS floats; two 16-byte loads per thread, all in flight at once -- gathering them from the seven arrays
+// cost seven dependent round trips, 1.5 us of every workgroup's prologue)
+__device__ __forceinline__ void x3_stage_constants(const DeviceAE &A, float *cst, int threads) {
+    const float4 *src = reinterpret_cast<const float4 *>(A.enc_x3_consts);
+    float4 *dst = reinterpret_cast<float4 *>(cst);
+    for (int e = threadIdx.x; e < X3_CONST_FLOATS / 4; e += threads) dst[e] = src[e];
+}
+
+// Layer 0 (fan-in 3) on the VALU: fwd_layer0's arithmetic (encoder.hip), 32 channels per lane = the k slots it feeds to layer 1.
+// m01: this lane's bits of mask words 0 and 1 (channel 16 kb + 8 h + j = bit (kb & 1) * 16 + 8 h + j of word kb / 2).
+template <bool MASKS>
+__device__ __forceinline__ void x3_layer0(const float *cst, const float (&pc)[3], int h, X3 (&act1)[4], unsigned (&m01)[2]) {
+    const float4 *c4 = reinterpret_cast<const float4 *>(cst);
+    m01[0] = m01[1] = 0u;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        float v[8];
+        unsigned m8 = 0;
+        const int c0 = 16 * kb + 8 * h;
+        float wx[8], wy[8], wz[8], sc[8], sh[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 a = c4[(c0 >> 2) + q], bb = c4[((64 + c0) >> 2) + q], c = c4[((128 + c0) >> 2) + q];
+            const float4 d = c4[((192 + c0) >> 2) + q], e = c4[((256 + c0) >> 2) + q];
+            wx[4 * q] = a.x; wx[4 * q + 1] = a.y; wx[4 * q + 2] = a.z; wx[4 * q + 3] = a.w;
+            wy[4 * q] = bb.x; wy[4 * q + 1] = bb.y; wy[4 * q + 2] = bb.z; wy[4 * q + 3] = bb.w;
+            wz[4 * q] = c.x; wz[4 * q + 1] = c.y; wz[4 * q + 2] = c.z; wz[4 * q + 3] = c.w;
+            sc[4 * q] = d.x; sc[4 * q + 1] = d.y; sc[4 * q + 2] = d.z; sc[4 * q + 3] = d.w;
+            sh[4 * q] = e.x; sh[4 * q + 1] = e.y; sh[4 * q + 2] = e.z; sh[4 * q + 3] = e.w;
+        }
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            float a = pc[0] * wx[j];
+            a = fmaf(pc[1], wy[j], a);
+            a = fmaf(pc[2], wz[j], a);
+            v[j] = fmaxf(fmaf(a, sc[j], sh[j]), 0.f);
+            if (MASKS) m8 = x3_push_positive(m8, v[j]);          // j descending: bit j = [v[j] > 0]
+        }
+        x3_split8(v, act1[kb]);
+        if (MASKS) m01[kb >> 1] |= m8 << ((kb & 1) * 16 + 8 * h);
+    }
+}
+
+// BN + ReLU + split of HALF a channel block of a layer result (acc: lane = point, registers = channels 32 cb + 8 g + 4 h + u;
+// gh = 0: g = 0, 1; gh = 1: g = 2, 3): the pieces of the next layer's sixteen-k block 2 cb + gh; m16 collects the mask bits.
+// sc, sh: the layer's scale / shift at channel 32 cb + 4 h (LDS).
+template <bool MASKS>
+__device__ __forceinline__ void x3_epilogue_half(const f32x16 &acc, const float *sc_p, const float *sh_p, int gh, X3 &dst, unsigned &m16) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(sc_p), *t4 = reinterpret_cast<const float4 *>(sh_p);
+#pragma unroll
+    for (int gg = 1; gg >= 0; --gg) {
+        const int g = 2 * gh + gg;
+        const float4 sc = s4[2 * g], sh = t4[2 * g];
+        float v[4];
+        v[3] = fmaxf(fmaf(acc[4 * g + 3], sc.w, sh.w), 0.f);
+        v[2] = fmaxf(fmaf(acc[4 * g + 2], sc.z, sh.z), 0.f);
+        v[1] = fmaxf(fmaf(acc[4 * g + 1], sc.y, sh.y), 0.f);
+        v[0] = fmaxf(fmaf(acc[4 * g + 0], sc.x, sh.x), 0.f);
+        if (MASKS) {
+#pragma unroll
+            for (int u = 3; u >= 0; --u) m16 = x3_push_positive(m16, v[u]);   // within a half: bit 4 gg + u
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            unsigned a, bq, c;
+            x3_split_pair(v[2 * w], v[2 * w + 1], a, bq, c);
+            dst.p[0][2 * gg + w] = a; dst.p[1][2 * gg + w] = bq; dst.p[2][2 * gg + w] = c;
+        }
+    }
+}
+// this lane's bits of a channel block's mask word from the bits of the two halves (bit 4 gg + u each): channel 8 g + 4 h + u
+__device__ __forceinline__ unsigned x3_mask_bits(unsigned m_lo, unsigned m_hi, int h) {
+    const unsigned m16 = (m_lo & 0xffu) | ((m_hi & 0xffu) << 8);
+    const unsigned spread = (m16 & 0xfu) | ((m16 & 0xf0u) << 4) | ((m16 & 0xf00u) << 8) | ((m16 & 0xf000u) << 12);
+    return spread << (4 * h);
+}
+
 template <bool MASKS>
 __global__ __launch_bounds__(X3_THREADS, 1) void encoder_fwd3_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
                                                                     float *pmax, int *parg, int *pcnt, unsigned *masks, FusedAdam fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_w[];
-    unsigned *ring = lds_w;                                                  // [X3_RING][12 fragments][64 lanes][4 words]
-    float *cst = reinterpret_cast<float *>(ring + X3_RING * X3_STEP_WORDS);   // X3_CONST_FLOATS
+    unsigned *ring = lds_w;                                                  // [X3_RING][X3_SLOT_STEPS][12 fragments][64 lanes][4 words]
+    float *cst = reinterpret_cast<float *>(ring + X3_RING * X3_SLOT_WORDS);   // X3_CONST_FLOATS
     float *redm = cst + X3_CONST_FLOATS;                                      // [4][128]
     int *reda = reinterpret_cast<int *>(redm + 4 * 128), *redc = reda + 4 * 128;
     unsigned *mtile = reinterpret_cast<unsigned *>(redc + 4 * 128);          // [2][X3_POINTS][MASK_WORDS] (MASKS)
@@ -56,221 +186,138 @@ __global__ __launch_bounds__(X3_THREADS, 1) void encoder_fwd3_kernel(DeviceAE A,
     const int n0 = tile * X3_POINTS + wave * 32;                              // this wave's first point
     const unsigned *img = A.enc_x3;
 
-    // ---- the wave's points (both lanes of a point load it; the pending Adam step is applied on the way, attack.hip adam_kernel) ----
+    // ---- the wave's points ----
     float pc[3];
     {
-        int pt = n0 + p;
-        const bool valid = pt < n;
-        pt = valid ? pt : n - 1;
-        const size_t pg = ((size_t)b * n + pt) * 3;
-        float xv[3], pp[3] = {0.f, 0.f, 0.f}, ag[3], agd[3], am[3], av[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) xv[a] = x[pg + a];
-        if (pert) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) pp[a] = pert[pg + a];
-        }
-        if (fa.m) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { ag[a] = fa.g_enc[pg + a]; agd[a] = fa.g_dist[pg + a]; am[a] = fa.m[pg + a]; av[a] = fa.v[pg + a]; }
-        }
-        // constants -> LDS (one pass of the workgroup)
-        for (int e = threadIdx.x; e < X3_CONST_FLOATS; e += X3_THREADS) {
-            float v;
-            if (e < 192) v = A.w0[e];
-            else if (e < 256) v = A.scale[0][e - 192];
-            else if (e < 320) v = A.shift[0][e - 256];
-            else if (e < X3_SC2) v = e - X3_SC1 < 128 ? A.scale[1][e - X3_SC1] : A.shift[1][e - X3_SC1 - 128];
-            else if (e < X3_SC3) v = e - X3_SC2 < 128 ? A.scale[2][e - X3_SC2] : A.shift[2][e - X3_SC2 - 128];
-            else if (e < X3_SC4) v = e - X3_SC3 < 256 ? A.scale[3][e - X3_SC3] : A.shift[3][e - X3_SC3 - 256];
-            else v = e - X3_SC4 < 128 ? A.scale[4][e - X3_SC4] : A.shift[4][e - X3_SC4 - 128];
-            cst[e] = v;
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float v = pert ? xv[a] + pp[a] : xv[a];
-            if (fa.m) {
-                float g = ag[a];
-                g += agd[a];
-                float m = am[a], vv = av[a];
-                m += (g - m) * fa.one_minus_b1;
-                vv += (g * g - vv) * fa.one_minus_b2;
-                const float pnew = pp[a] - (m * fa.alpha) / (sqrtf(vv) + fa.eps);
-                v = xv[a] + pnew;
-                if (valid && h == 0) {
-                    fa.g_enc[pg + a] = 0.f;
-                    if (fa.grad_out) fa.grad_out[pg + a] = g;
-                    fa.m[pg + a] = m; fa.v[pg + a] = vv; fa.pert[pg + a] = pnew;
-                }
-            }
-            pc[a] = v;
-            if (adv_out && valid && h == 0) adv_out[pg + a] = v;
-        }
+        X3Point pt;
+        x3_load_point(n, b, n0 + p, x, pert, fa, pt);
+        if (h == 0) x3_store_point(pt, adv_out, fa);      // (the two lanes of a point belong to one wave: both have loaded)
+        pc[0] = pt.v[0]; pc[1] = pt.v[1]; pc[2] = pt.v[2];
     }
+    x3_stage_constants(A, cst, X3_THREADS);
     __syncthreads();                                   // constants visible; nothing of the ring is in flight yet
 
     // ---- the weight ring ----
-    // fetch(s): this wave's three fragments (pieces of channel block `wave`) of step s, 1 KiB each, lane-linear
-    auto fetch = [&](int s) {
-        const unsigned *src = img + (size_t)s * X3_STEP_WORDS + wave * 3 * X3_FRAG_WORDS + lane * 4;
-        unsigned *dst = ring + (s % X3_RING) * X3_STEP_WORDS + wave * 3 * X3_FRAG_WORDS;
+    // fetch(t): this wave's fragments (the three pieces of channel block `wave`, 1 KiB each, lane-linear) of the steps of slot t
+    auto fetch = [&](int t) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) x3_glds16(src + q * X3_FRAG_WORDS, dst + q * X3_FRAG_WORDS);
+        for (int u = 0; u < X3_SLOT_STEPS; ++u) {
+            const int s = t * X3_SLOT_STEPS + u;
+            const unsigned *src = img + (size_t)s * X3_STEP_WORDS + wave * 3 * X3_FRAG_WORDS + lane * 4;
+            unsigned *dst = ring + (t % X3_RING) * X3_SLOT_WORDS + u * X3_STEP_WORDS + wave * 3 * X3_FRAG_WORDS;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) x3_glds16(src + q * X3_FRAG_WORDS, dst + q * X3_FRAG_WORDS);
+        }
     };
 #pragma unroll
-    for (int s = 0; s < X3_AHEAD; ++s) fetch(s);
+    for (int t = 0; t < X3_AHEAD; ++t) fetch(t);
 
-    const float4 *c4 = reinterpret_cast<const float4 *>(cst);
     // ReLU mask words of this lane's channels, [h][point of the workgroup][MASK_WORDS] (the two lanes of a point hold
     // complementary bits of every word: OR-ed on the way out)
     unsigned *mrow = mtile + ((size_t)h * X3_POINTS + wave * 32 + p) * MASK_WORDS;
 
-    // ---- layer 0 (fan-in 3) on the VALU: fwd_layer0's arithmetic, 32 channels per lane = the k slots it feeds to layer 1 ----
+    // ---- layer 0 ----
     X3 act1[4];
     {
-        unsigned m01[2] = {0u, 0u};
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            float v[8];
-            unsigned m8 = 0;
-            const int c0 = 16 * kb + 8 * h;
-            float wx[8], wy[8], wz[8], sc[8], sh[8];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float4 a = c4[(c0 >> 2) + q], bb = c4[((64 + c0) >> 2) + q], c = c4[((128 + c0) >> 2) + q];
-                const float4 d = c4[((192 + c0) >> 2) + q], e = c4[((256 + c0) >> 2) + q];
-                wx[4 * q] = a.x; wx[4 * q + 1] = a.y; wx[4 * q + 2] = a.z; wx[4 * q + 3] = a.w;
-                wy[4 * q] = bb.x; wy[4 * q + 1] = bb.y; wy[4 * q + 2] = bb.z; wy[4 * q + 3] = bb.w;
-                wz[4 * q] = c.x; wz[4 * q + 1] = c.y; wz[4 * q + 2] = c.z; wz[4 * q + 3] = c.w;
-                sc[4 * q] = d.x; sc[4 * q + 1] = d.y; sc[4 * q + 2] = d.z; sc[4 * q + 3] = d.w;
-                sh[4 * q] = e.x; sh[4 * q + 1] = e.y; sh[4 * q + 2] = e.z; sh[4 * q + 3] = e.w;
-            }
-#pragma unroll
-            for (int j = 7; j >= 0; --j) {
-                float a = pc[0] * wx[j];
-                a = fmaf(pc[1], wy[j], a);
-                a = fmaf(pc[2], wz[j], a);
-                v[j] = fmaxf(fmaf(a, sc[j], sh[j]), 0.f);
-                if (MASKS) m8 = x3_push_positive(m8, v[j]);          // j descending: bit j = [v[j] > 0]
-            }
-            x3_split8(v, act1[kb]);
-            if (MASKS) m01[kb >> 1] |= m8 << ((kb & 1) * 16 + 8 * h);   // channel 16 kb + 8 h + j = bit (kb & 1) * 16 + 8 h + j of word kb / 2
-        }
+        unsigned m01[2];
+        x3_layer0<MASKS>(cst, pc, h, act1, m01);
         if (MASKS) { mrow[0] = m01[0]; mrow[1] = m01[1]; }
     }
 
     // ---- the step machinery ----
-    // Before step s's first fragment read: this wave's fetches up to step s + 1 have landed (counted vmcnt: at most the three
-    // of step s + 2 stay in flight), then the barrier -- after it EVERY wave's share of steps <= s + 1 is in LDS and every wave
-    // is done with step s - 1, whose slot the fetch of step s + 3 now overwrites.
+    // Before the first fragment read of slot t (steps 2 t, 2 t + 1): this wave's fetches up to slot t + 1 have landed (counted
+    // vmcnt: at most the six of slot t + 2 stay in flight), then the barrier -- after it EVERY wave's share of slots <= t + 1 is in
+    // LDS and every wave is done with slot t - 1, which the fetch of slot t + 3 now overwrites.
     X3 wcur, wnext;                                    // fragments of (step, channel block) in use / requested
     auto frag_read = [&](X3 &d, int s, int cb) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(ring + (s % X3_RING) * X3_STEP_WORDS + cb * 3 * X3_FRAG_WORDS) + lane;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(ring + ((s / X3_SLOT_STEPS) % X3_RING) * X3_SLOT_WORDS + (s % X3_SLOT_STEPS) * X3_STEP_WORDS +
+                                                           cb * 3 * X3_FRAG_WORDS) + lane;
 #pragma unroll
         for (int q = 0; q < 3; ++q) d.p[q] = src[q * 64];
     };
-    auto step_sync = [&](int s) {
-        if (s + X3_AHEAD - 1 < X3_STEPS) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    auto slot_sync = [&](int t) {
+        if (t + X3_AHEAD - 1 < X3_SLOTS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * X3_SLOT_STEPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + X3_AHEAD < X3_STEPS) fetch(s + X3_AHEAD);
+        if (t + X3_AHEAD < X3_SLOTS) fetch(t + X3_AHEAD);
     };
-    // one sixteen-k step: acc[cb] += w(s, cb) . a for the four channel blocks; `side` = VALU work that does not depend on
-    // this step (the epilogue of the channel block the NEXT steps consume), placed inside the step so that it can issue between
-    // the MFMAs
-    auto step = [&](auto act_is_a, int s, const X3 &a, f32x16 (&acc)[4], auto side) {
+    // one sixteen-k step: acc[cb] += w(s, cb) . a for the four channel blocks.  `side`: VALU work that does not depend on this
+    // step (the epilogue of the channel block the NEXT steps consume), placed inside the step so that it can issue between the
+    // MFMAs; `after0`: work on acc[0] once its chain is complete (a layer's last step: the first half-epilogues of the boundary
+    // ride under the other three blocks' MFMAs instead of standing alone)
+    auto step = [&](auto act_is_a, int s, const X3 &a, f32x16 (&acc)[4], auto side, auto after0) {
         constexpr bool ACT_IS_A = decltype(act_is_a)::value;
-        step_sync(s);
+        if (s % X3_SLOT_STEPS == 0) slot_sync(s / X3_SLOT_STEPS);
         if (s == 0) frag_read(wcur, 0, 0);
         side();
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             if (cb < 3) frag_read(wnext, s, cb + 1);
-            else if (s + 1 < X3_STEPS) frag_read(wnext, s + 1, 0);   // (legal: step s + 1 landed before this step's barrier)
+            else if (s + 1 < X3_STEPS) frag_read(wnext, s + 1, 0);   // (legal: the slot of step s + 1 landed before this slot's barrier)
             x3_mfma6<ACT_IS_A>(wcur, a, acc[cb]);
+            if (cb == 0) after0();
             if (cb < 3 || s + 1 < X3_STEPS) wcur = wnext;
         }
     };
     auto nothing = [] {};
-    // BN + ReLU + split of HALF a channel block of a layer result (acc: lane = point, registers = channels 32 cb + 8 g + 4 h + u;
-    // gh = 0: g = 0, 1; gh = 1: g = 2, 3): the pieces of the next layer's sixteen-k block 2 cb + gh; m16 collects the mask bits
     auto epilogue_half = [&](const f32x16 &acc, int cb, int gh, const float *scsh /* [scale[C] | shift[C]] */, int C, int coff, X3 &dst,
                              unsigned &m16) {
-        const float4 *s4 = reinterpret_cast<const float4 *>(scsh + coff + 32 * cb + 4 * h);
-        const float4 *t4 = reinterpret_cast<const float4 *>(scsh + C + coff + 32 * cb + 4 * h);
-#pragma unroll
-        for (int gg = 1; gg >= 0; --gg) {
-            const int g = 2 * gh + gg;
-            const float4 sc = s4[2 * g], sh = t4[2 * g];
-            float v[4];
-            v[3] = fmaxf(fmaf(acc[4 * g + 3], sc.w, sh.w), 0.f);
-            v[2] = fmaxf(fmaf(acc[4 * g + 2], sc.z, sh.z), 0.f);
-            v[1] = fmaxf(fmaf(acc[4 * g + 1], sc.y, sh.y), 0.f);
-            v[0] = fmaxf(fmaf(acc[4 * g + 0], sc.x, sh.x), 0.f);
-            if (MASKS) {
-#pragma unroll
-                for (int u = 3; u >= 0; --u) m16 = x3_push_positive(m16, v[u]);   // within a half: bit 4 gg + u
-            }
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                unsigned a, bq, c;
-                x3_split_pair(v[2 * w], v[2 * w + 1], a, bq, c);
-                dst.p[0][2 * gg + w] = a; dst.p[1][2 * gg + w] = bq; dst.p[2][2 * gg + w] = c;
-            }
-        }
+        x3_epilogue_half<MASKS>(acc, scsh + coff + 32 * cb + 4 * h, scsh + C + coff + 32 * cb + 4 * h, gh, dst, m16);
     };
-    // mask word of a channel block from the bits of its two halves (m_lo: g = 0, 1; m_hi: g = 2, 3; bit 4 gg + u each):
-    // channel 8 g + 4 h + u = that bit of the word
-    auto mask_store = [&](int word, unsigned m_lo, unsigned m_hi) {
-        const unsigned m16 = (m_lo & 0xffu) | ((m_hi & 0xffu) << 8);
-        const unsigned spread = (m16 & 0xfu) | ((m16 & 0xf0u) << 4) | ((m16 & 0xf00u) << 8) | ((m16 & 0xf000u) << 12);
-        mrow[word] = spread << (4 * h);
-    };
+    auto mask_store = [&](int word, unsigned m_lo, unsigned m_hi) { mrow[word] = x3_mask_bits(m_lo, m_hi, h); };
     using ActB = std::integral_constant<bool, false>;
     using ActA = std::integral_constant<bool, true>;
 
+    // The pieces of channel block 0 of a finished layer, made under that layer's last step (step's `after0`).
+    X3 first[2];
+    auto first_epilogue = [&](f32x16 (&accs)[4], const float *scsh, int C, int coff, int mask_word) {
+        return [&, scsh, C, coff, mask_word] {
+            unsigned ml = 0, mh = 0;
+            epilogue_half(accs[0], 0, 0, scsh, C, coff, first[0], ml);
+            epilogue_half(accs[0], 0, 1, scsh, C, coff, first[1], mh);
+            if (MASKS) mask_store(mask_word, ml, mh);
+        };
+    };
     // A layer boundary, software-pipelined: the epilogue of channel block cb + 1 of the finished layer (`prev`) rides in the two
-    // steps of the next layer that consume block cb's pieces.  keep: where the pieces are kept for a later pass (h3), or null.
-    auto boundary = [&](auto act_is_a, f32x16 (&prev)[4], const float *scsh, int C, int coff, int mask_off, int s0, f32x16 (&next)[4], X3 *keep) {
-        X3 cur[2], nxt[2];
-        unsigned ml = 0, mh = 0;
-        epilogue_half(prev[0], 0, 0, scsh, C, coff, cur[0], ml);
-        epilogue_half(prev[0], 0, 1, scsh, C, coff, cur[1], mh);
-        if (MASKS) mask_store(mask_off, ml, mh);
+    // steps of the next layer that consume block cb's pieces (block 0's are in `first`).  keep: where the pieces are kept for a
+    // later pass (h3), or null.  last_after0: the next boundary's first_epilogue, or nothing.
+    auto boundary = [&](auto act_is_a, f32x16 (&prev)[4], const float *scsh, int C, int coff, int mask_off, int s0, f32x16 (&next)[4], X3 *keep,
+                        auto last_after0) {
+        X3 cur[2] = {first[0], first[1]}, nxt[2];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             unsigned nl = 0, nh = 0;
             if (keep) { keep[2 * cb] = cur[0]; keep[2 * cb + 1] = cur[1]; }
             if (cb < 3) {
-                step(act_is_a, s0 + 2 * cb, cur[0], next, [&] { epilogue_half(prev[cb + 1], cb + 1, 0, scsh, C, coff, nxt[0], nl); });
-                step(act_is_a, s0 + 2 * cb + 1, cur[1], next, [&] { epilogue_half(prev[cb + 1], cb + 1, 1, scsh, C, coff, nxt[1], nh); });
+                step(act_is_a, s0 + 2 * cb, cur[0], next, [&] { epilogue_half(prev[cb + 1], cb + 1, 0, scsh, C, coff, nxt[0], nl); }, nothing);
+                step(act_is_a, s0 + 2 * cb + 1, cur[1], next, [&] { epilogue_half(prev[cb + 1], cb + 1, 1, scsh, C, coff, nxt[1], nh); }, nothing);
                 if (MASKS) mask_store(mask_off + cb + 1, nl, nh);
                 cur[0] = nxt[0]; cur[1] = nxt[1];
             } else {
-                step(act_is_a, s0 + 2 * cb, cur[0], next, nothing);
-                step(act_is_a, s0 + 2 * cb + 1, cur[1], next, nothing);
+                step(act_is_a, s0 + 2 * cb, cur[0], next, nothing, nothing);
+                step(act_is_a, s0 + 2 * cb + 1, cur[1], next, nothing, last_after0);
             }
         }
     };
 
     // ---- layer 1: 64 -> 128 (steps 0-3) ----
-    f32x16 acc1[4] = {};
+    f32x16 acc1[4] = {}, acc2[4] = {}, acc3[4] = {}, acc4[4] = {};
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) step(ActB{}, kb, act1[kb], acc1, nothing);
+    for (int kb = 0; kb < 3; ++kb) step(ActB{}, kb, act1[kb], acc1, nothing, nothing);
+    step(ActB{}, 3, act1[3], acc1, nothing, first_epilogue(acc1, cst + X3_SC1, 128, 0, MASK_OFF2));
     // ---- layer 2: 128 -> 128 (steps 4-11) ----
-    f32x16 acc2[4] = {};
-    boundary(ActB{}, acc1, cst + X3_SC1, 128, 0, MASK_OFF2, 4, acc2, nullptr);
+    boundary(ActB{}, acc1, cst + X3_SC1, 128, 0, MASK_OFF2, 4, acc2, nullptr, first_epilogue(acc2, cst + X3_SC2, 128, 0, MASK_OFF3));
     // ---- layers 3 + 4 by halves: h4[:, 128 half ..] feeds K half `half` of layer 4 (one chain over K = 256, ascending) ----
     X3 act3[8];
-    f32x16 acc3[4] = {}, acc4[4] = {};
-    boundary(ActB{}, acc2, cst + X3_SC2, 128, 0, MASK_OFF3, 12, acc3, act3);           // layer 3, channels 0 .. 127 (steps 12-19)
-    boundary(ActA{}, acc3, cst + X3_SC3, 256, 0, MASK_OFF4, 20, acc4, nullptr);        // layer 4, K half 0 (steps 20-27)
+    boundary(ActB{}, acc2, cst + X3_SC2, 128, 0, MASK_OFF3, 12, acc3, act3, first_epilogue(acc3, cst + X3_SC3, 256, 0, MASK_OFF4));   // layer 3, channels 0 .. 127 (steps 12-19)
+    boundary(ActA{}, acc3, cst + X3_SC3, 256, 0, MASK_OFF4, 20, acc4, nullptr, nothing);                                             // layer 4, K half 0 (steps 20-27)
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc3[cb] = f32x16{};
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) step(ActB{}, 28 + kb, act3[kb], acc3, nothing);      // layer 3, channels 128 .. 255 (steps 28-35)
-    boundary(ActA{}, acc3, cst + X3_SC3, 256, 128, MASK_OFF4 + 4, 36, acc4, nullptr);  // layer 4, K half 1 (steps 36-43)
+    for (int kb = 0; kb < 7; ++kb) step(ActB{}, 28 + kb, act3[kb], acc3, nothing, nothing);                                          // layer 3, channels 128 .. 255 (steps 28-35)
+    step(ActB{}, 35, act3[7], acc3, nothing, first_epilogue(acc3, cst + X3_SC3, 256, 128, MASK_OFF4 + 4));
+    boundary(ActA{}, acc3, cst + X3_SC3, 256, 128, MASK_OFF4 + 4, 36, acc4, nullptr, nothing);                                       // layer 4, K half 1 (steps 36-43)
 
     // ---- layer 4's BN + ReLU and the max-pool from the registers (lane = channel 32 cb + p, registers = points) ----
 #pragma unroll
@@ -322,15 +369,198 @@ __global__ __launch_bounds__(X3_THREADS, 1) void encoder_fwd3_kernel(DeviceAE A,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same forward for launches that would leave CUs idle (few clouds): the four waves of a workgroup share ONE 32-point
+// unit, wave w computing output-channel block w of every layer -- a quarter of the MFMAs per wave, four times the workgroups.
+// A layer's pieces are exchanged through LDS in exactly the fragment form every wave reads them in (all four waves hold
+// the same points, so the B operand of lane (point, h) is the same bytes in each): 6 ds_write_b128 + a barrier + 24
+// ds_read_b128 per layer and wave.  A wave uses only the weight fragments of its own channel block -- nothing to share, so
+// they come straight into registers, X3S_AHEAD steps ahead (a step is 6 MFMAs here, ~100 ns, against an L2 round trip of
+// ~1 us: the LDS ring's three steps of run-ahead left this form waiting for weights, 15.7 us per workgroup on an idle chip).
+// Same chain per output element, same bits (tests/test_gpu_encoder_x3.py).
+// ------------------------------------------------------------------------------------------
+constexpr int X3S_AHEAD = 10;                                                 // steps of weights in flight: 120 registers
+constexpr int X3S_XBUF_WORDS = 8 * 3 * X3_FRAG_WORDS;                        // one layer's pieces: 8 sixteen-k blocks x 3 x 1 KiB
+constexpr size_t X3S_LDS_BYTES = 2 * X3S_XBUF_WORDS * 4 + sizeof(float) * (X3_CONST_FLOATS + 32 * 3);
+constexpr size_t X3S_LDS_BYTES_MASKS = X3S_LDS_BYTES + sizeof(unsigned) * 32 * MASK_WORDS;
+
+template <bool MASKS>
+__global__ __launch_bounds__(X3_THREADS, 1) void encoder_fwd3s_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
+                                                                     float *pmax, int *parg, int *pcnt, unsigned *masks, FusedAdam fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_w[];
+    unsigned *xbuf = lds_w;                                                  // [2][8][3][64 lanes][4 words]
+    float *cst = reinterpret_cast<float *>(xbuf + 2 * X3S_XBUF_WORDS);
+    float *pcs = cst + X3_CONST_FLOATS;                                      // [32][3] the unit's points
+    unsigned *mtile = reinterpret_cast<unsigned *>(pcs + 32 * 3);            // [32 points][MASK_WORDS] (MASKS)
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
+    const int n0 = tile * 32;
+    GA_STAMP(1, 0);
+    // this wave's fragments of step s: 3 KiB at a fixed stride -- buffer loads with the step as an immediate offset
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(A.enc_x3) + wave * 3 * X3_FRAG_WORDS, 0, 0x7fffffff, 0x00020000);
+    const unsigned lb = (unsigned)lane * 16u;
+    X3 wr[X3S_AHEAD];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wr[s % X3S_AHEAD].p[q] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, lb, (s * X3_STEP_WORDS + q * X3_FRAG_WORDS) * 4, 0);
+    };
+    // the unit's points: wave 0 loads them (and applies / stores the pending Adam step), the others take them from LDS; the small
+    // loads go first (loads return in order: behind thirty weight fragments they would wait for all of those)
+    if (wave == 0) {
+        X3Point pt;
+        x3_load_point(n, b, n0 + p, x, pert, fa, pt);
+        if (h == 0) {
+            x3_store_point(pt, adv_out, fa);
+            pcs[p * 3] = pt.v[0]; pcs[p * 3 + 1] = pt.v[1]; pcs[p * 3 + 2] = pt.v[2];
+        }
+    }
+    x3_stage_constants(A, cst, X3_THREADS);
+#pragma unroll
+    for (int s = 0; s < X3S_AHEAD; ++s) fetch(s);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a raw barrier: __syncthreads()'s fence would drain the weight loads)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float pc[3] = {pcs[p * 3], pcs[p * 3 + 1], pcs[p * 3 + 2]};
+    GA_STAMP(1, 1);
+
+    X3 act1[4];
+    {
+        unsigned m01[2];
+        x3_layer0<MASKS>(cst, pc, h, act1, m01);
+        if (MASKS && wave == 0) {
+            m01[0] |= __shfl_xor(m01[0], 32); m01[1] |= __shfl_xor(m01[1], 32);
+            if (h == 0) { mtile[p * MASK_WORDS] = m01[0]; mtile[p * MASK_WORDS + 1] = m01[1]; }
+        }
+    }
+    auto step = [&](auto act_is_a, int s, const X3 &a, f32x16 &acc) {
+        constexpr bool ACT_IS_A = decltype(act_is_a)::value;
+        x3_mfma6<ACT_IS_A>(wr[s % X3S_AHEAD], a, acc);
+        if (s + X3S_AHEAD < X3_STEPS) fetch(s + X3S_AHEAD);
+    };
+    // epilogue of this wave's channel block -> the pieces of sixteen-k blocks 2 w, 2 w + 1 into exchange buffer `buf`, then all eight back
+    auto exchange = [&](const f32x16 &acc, const float *scsh, int C, int coff, int mask_word, int buf, X3 (&out)[8]) {
+        X3 lo, hi;
+        unsigned ml = 0, mh = 0;
+        x3_epilogue_half<MASKS>(acc, scsh + coff + 32 * wave + 4 * h, scsh + C + coff + 32 * wave + 4 * h, 0, lo, ml);
+        x3_epilogue_half<MASKS>(acc, scsh + coff + 32 * wave + 4 * h, scsh + C + coff + 32 * wave + 4 * h, 1, hi, mh);
+        u32x4 *xb = reinterpret_cast<u32x4 *>(xbuf + buf * X3S_XBUF_WORDS) + lane;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { xb[((2 * wave) * 3 + q) * 64] = lo.p[q]; xb[((2 * wave + 1) * 3 + q) * 64] = hi.p[q]; }
+        if (MASKS) {
+            unsigned m = x3_mask_bits(ml, mh, h);
+            m |= __shfl_xor(m, 32);
+            if (h == 0) mtile[p * MASK_WORDS + mask_word + wave] = m;
+        }
+        // a raw barrier: __syncthreads() would drain the weight loads in flight (its fence waits for vmcnt(0))
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) out[kb].p[q] = xb[(kb * 3 + q) * 64];
+    };
+    using ActB = std::integral_constant<bool, false>;
+    using ActA = std::integral_constant<bool, true>;
+
+    X3 act2[8], act3[8], act4[8];
+    {
+        f32x16 acc = {};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) step(ActB{}, kb, act1[kb], acc);
+        GA_STAMP(1, 2);
+        exchange(acc, cst + X3_SC1, 128, 0, MASK_OFF2, 0, act2);
+        GA_STAMP(1, 3);
+    }
+    {
+        f32x16 acc = {};
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) step(ActB{}, 4 + kb, act2[kb], acc);
+        GA_STAMP(1, 4);
+        exchange(acc, cst + X3_SC2, 128, 0, MASK_OFF3, 1, act3);
+        GA_STAMP(1, 5);
+    }
+    f32x16 acc4 = {};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 acc = {};
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) step(ActB{}, (half ? 28 : 12) + kb, act3[kb], acc);
+        exchange(acc, cst + X3_SC3, 256, 128 * half, MASK_OFF4 + 4 * half, half, act4);
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) step(ActA{}, (half ? 36 : 20) + kb, act4[kb], acc4);
+    }
+    GA_STAMP(1, 6);
+    {   // BN + ReLU and the pool of this wave's 32 channels over the unit's 32 points
+        const int col = 32 * wave + p;
+        const float sc4 = cst[X3_SC4 + col], sh4 = cst[X3_SC4 + 128 + col];
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(fmaf(acc4[r], sc4, sh4), 0.f);
+        if (n0 + 32 > n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (n0 + acc_row(r, h) >= n) v[r] = -2.f;
+        }
+        float mx = -1.f;
+        int arg = INT_MAX, cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, v[r]);
+#pragma unroll
+        for (int r = 15; r >= 0; --r) {
+            const bool hit = v[r] == mx;
+            arg = hit ? n0 + acc_row(r, h) : arg;
+            cnt += hit ? 1 : 0;
+        }
+        const float m2 = __shfl_xor(mx, 32);
+        const int a2 = __shfl_xor(arg, 32), k2 = __shfl_xor(cnt, 32);
+        if (m2 > mx) { mx = m2; arg = a2; cnt = k2; }
+        else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += k2; }
+        if (h == 0) {
+            const size_t o = ((size_t)b * tiles + tile) * 128 + col;
+            pmax[o] = mx; parg[o] = arg; pcnt[o] = cnt;
+        }
+    }
+    if (MASKS) {
+        __syncthreads();
+        const int live = n - n0 < 32 ? n - n0 : 32;
+        unsigned *dst = masks + ((size_t)b * n + n0) * MASK_WORDS;
+        for (int e = threadIdx.x; e < live * MASK_WORDS; e += X3_THREADS) dst[e] = mtile[e];
+    }
+    GA_STAMP(1, 7);
+}
+
+// Points per workgroup of the x3 forward for a batch of b clouds: 32 (the split form) while 128-point workgroups would leave
+// half of the CUs without one.
+int encoder_x3_points(int b, int n) { return (long)b * cdiv(n, X3_POINTS) * 2 <= (long)X3_SPLIT_HALVES * kCUs ? 32 : X3_POINTS; }
+
 int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg,
                           int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const FusedAdam &fa) {
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES_MASKS));
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES_MASKS));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES));
             return GEOADV_OK;
         })) return rc;
-    const dim3 grid(cdiv(A.n_points, X3_POINTS), b), block(X3_THREADS);
+    const dim3 block(X3_THREADS);
+    if (encoder_x3_points(b, A.n_points) == 32) {
+        const dim3 grid(cdiv(A.n_points, 32), b);
+        const unsigned lds = (unsigned)(masks ? X3S_LDS_BYTES_MASKS : X3S_LDS_BYTES);
+        if (masks) {
+            if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3s_kernel<true>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+            else encoder_fwd3s_kernel<true><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+        } else {
+            if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3s_kernel<false>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+            else encoder_fwd3s_kernel<false><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+        }
+        GA_LAUNCH_CHECK();
+        return GEOADV_OK;
+    }
+    const dim3 grid(cdiv(A.n_points, X3_POINTS), b);
     const unsigned lds = (unsigned)(masks ? X3_LDS_BYTES_MASKS : X3_LDS_BYTES);
     if (masks) {
         if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3_kernel<true>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
@@ -344,3 +574,4 @@ int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float 
 }
 
 }  // namespace geoadv
+GA_STAMPS_GETTER(geoadv_debug_stamps_encoder_x3)

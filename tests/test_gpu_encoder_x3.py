@@ -1,0 +1,108 @@
+"""GPU: the encoder's two arithmetics (include/geoadv.h GEOADV_ENC_ARITH_*).
+
+bf16x3 (the default) forms every fp32 product as six bf16 piece products on the bf16 matrix pipe; f32 is the fp32 MFMA.
+Both are checked against the float64 model of the reference encoder (oracle/attack_model.py, src/encoders_decoders.py:37-72)
+at the same tolerance, against each other, and each against itself across batch sizes / kernel forms (bit for bit)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ARITHS = ("bf16x3", "f32")
+
+
+def _models(n, seed=3):
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    w = W.randomized_weights(n, seed=seed)
+    return w, {a: PointNetAE(w, n, encoder_arith=a) for a in ARITHS}
+
+
+@pytest.mark.parametrize("n,b", [(2048, 3), (2048, 40), (1000, 5), (100, 2), (33, 4), (1, 2)])
+def test_latent_of_both_arithmetics_against_the_float64_model(n, b):
+    from geometric_adv_amd import weights as W
+    from oracle.attack_model import AEModel
+    from conftest import cloud
+    w, aes = _models(n)
+    pc = cloud(11 + n, b, n)
+    ref = AEModel(W.canonical(w, n), n, np.float64)
+    z64 = ref.encode(pc.astype(np.float64))
+    got = {}
+    for a, ae in aes.items():
+        assert ae.encoder_arith == a
+        got[a] = ae.forward(pc, want_recon=False)[1].cpu().numpy()
+    scale = np.abs(z64).max()
+    for a in ARITHS:
+        np.testing.assert_allclose(got[a] / scale, z64 / scale, atol=2e-6, err_msg=a)
+    np.testing.assert_allclose(got["bf16x3"], got["f32"], atol=2e-6 * np.abs(got["f32"]).max())
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_a_clouds_latent_and_critical_points_do_not_depend_on_the_batch(arith):
+    """The forward picks its workgroup shape by batch size (bf16x3: four waves sharing a 32-point unit for few clouds, a wave per
+    32 points otherwise; f32: 32- or 64-row tiles): the same chain per output element in every form, so the same bits."""
+    import torch
+    from conftest import cloud
+    for n in (2048, 777):
+        w, aes = _models(n, seed=5)
+        ae = aes[arith]
+        pc = cloud(21, 48, n)
+        z_all, i_all = ae.max_and_argmax(pc)
+        for b in (1, 2, 7, 16, 17, 33):
+            z, i = ae.max_and_argmax(pc[:b])
+            assert torch.equal(torch.as_tensor(z), torch.as_tensor(z_all)[:b]), (n, b)
+            assert torch.equal(torch.as_tensor(i), torch.as_tensor(i_all)[:b]), (n, b)
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_attack_trajectory_against_the_float64_model_under_each_arithmetic(arith):
+    """Ten iterations of the output-space attack: the per-iteration losses against the float64 model driven with the GPU's own
+    perturbation (1e-5, the path's tolerance), under either arithmetic; small batch (split form) and large."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from oracle.attack_model import AEModel, AttackModel
+    from conftest import cloud
+    n = 1024
+    w = W.synthetic_weights(n, seed=2)
+    for b in (3, 40):
+        x, gt = cloud(41, b, n), cloud(42, b, n)
+        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=10, num_iterations_thresh=5,
+                                              encoder_arith=arith))
+        assert at.ae.encoder_arith == arith
+        at.set_inputs(x, gt, None, 1.0)
+        at.init_pert(None, reset_optimizer=True)
+        hist = torch.empty((10, 6, b), device=at.device)
+        at.run(0, 10, 1, hist)
+        s = {k: v.cpu().numpy() for k, v in at.peek().items()}
+        sel = [0, b - 1]
+        am = AttackModel(AEModel(W.canonical(w, n), n, np.float64), x[sel], gt[sel], None, np.ones(len(sel)))
+        am.pert = s["pert"][sel].astype(np.float64)
+        f = am.forward()
+        np.testing.assert_allclose(s["latent"][sel], f["z"], atol=2e-6)
+        np.testing.assert_allclose(s["recon"][sel], f["recon"], atol=2e-6)
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("backward", ["auto", "masked", "jacobian"])
+def test_attack_state_agrees_between_a_two_cloud_and_a_forty_cloud_batch(arith, backward):
+    """Three iterations on the same clouds (same initial perturbation) in a batch of 2 (bf16x3: the split form) and of 40: every
+    piece of state bit for bit -- the ReLU masks, tie counts and arg-max rows feed the backward, so they are covered through it."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from conftest import cloud
+    n = 2048
+    w = W.synthetic_weights(n, seed=4)
+    x, gt = cloud(51, 40, n), cloud(52, 40, n)
+    p0 = (1e-3 * np.random.default_rng(3).standard_normal((40, n, 3))).astype(np.float32)      # (init_pert(None) draws by shape)
+    peeks = {}
+    for b in (2, 40):
+        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=3, num_iterations_thresh=1,
+                                              encoder_arith=arith, encoder_backward=backward))
+        at.set_inputs(x[:b], gt[:b], None, 1.0)
+        at.init_pert(p0[:b], reset_optimizer=True)
+        at.run(0, 3, 1, torch.empty((3, 6, b), device=at.device))
+        peeks[b] = {k: v.cpu().numpy() for k, v in at.peek().items()}
+    for k in ("latent", "recon", "adv", "pert", "grad", "idx_r1", "idx_r2", "idx_a1", "idx_a2"):
+        assert np.array_equal(peeks[2][k], peeks[40][k][:2]), k

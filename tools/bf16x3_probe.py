@@ -80,9 +80,24 @@ def throughput():
                           "note": "512 workgroups x 4 waves x 2 units x 44 steps x 24 MFMAs = the B = 32 encoder's MFMA count (2 rounds on 256 CUs)"}), flush=True)
 
 
+def chains():
+    """Dependent against independent consecutive MFMAs, on a quarter of the chip (no clock give-back) and on all of it."""
+    st = torch.cuda.current_stream().cuda_stream
+    for blocks in (64, 256, 512):
+        for fill, name in ((0, "four accumulators interleaved"), (100, "six products of an accumulator back to back"), (101, "one accumulator"),
+                           (102, "six back to back + 3 VALU per MFMA")):
+            ms, gms = C.c_float(0), C.c_float(0)
+            check(lib.bf16x3_throughput(fill, 0, blocks, 44, 2, 100, 0, C.byref(ms), C.byref(gms), C.c_void_p(st)))
+            rounds = max(1, blocks // 256)
+            print(json.dumps({"probe": "chains", "order": name, "workgroups": blocks, "ms": round(ms.value, 5),
+                              "cycles_per_mfma_at_2p4GHz": round(ms.value * 1e-3 * 2.4e9 / (2 * 44 * 24 * rounds), 2)}), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "accuracy"):
         accuracy()
     if what in ("all", "throughput"):
         throughput()
+    if what in ("all", "chains"):
+        chains()

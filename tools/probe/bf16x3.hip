@@ -109,7 +109,9 @@ extern "C" int bf16x3_accuracy(int mode, const float *A, const float *B, float *
 // against its 3 activation pieces (registers).  FILL VALU instructions per MFMA stand for the epilogue (BN, ReLU, split, pack).
 // steps: 16-k steps per wave (a 32-point unit of the encoder is 44: 4 + 8 + 16 + 16 ... x 4 channel blocks = 1056 MFMAs).
 // SRC 0: weights re-read from a 48 KiB LDS image (filled once); 1: operands stay in registers (bare MFMA rate)
-template <int FILL, int SRC>
+// ORDER 0: the four accumulators interleaved (consecutive MFMAs independent); 1: the six products of an accumulator back to back
+// (consecutive MFMAs dependent, four chains per step); 2: everything on ONE accumulator (a single dependent chain)
+template <int FILL, int SRC, int ORDER = 0>
 __global__ __launch_bounds__(256, 1) void tp_kernel(const u32x4 *wimg, float *out, int steps, int units) {
     extern __shared__ __attribute__((aligned(16))) u32x4 wl[];        // [4 steps][12 fragments][64 lanes]
     const int lane = threadIdx.x & 63;
@@ -134,17 +136,28 @@ __global__ __launch_bounds__(256, 1) void tp_kernel(const u32x4 *wimg, float *ou
         for (int s = 0; s < steps; ++s) {
             fetch(wn, s + 1);                                  // the next step's weights are requested before this step's MFMAs
             __builtin_amdgcn_sched_barrier(0);
-            // piece products in ascending weight; the four accumulators interleaved
+            // piece products in ascending weight
+            constexpr int wa[6] = {2, 1, 0, 1, 0, 0}, xa[6] = {0, 1, 2, 0, 1, 0};
+            if (ORDER == 0) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                constexpr int wa[6] = {2, 1, 0, 1, 0, 0}, xa[6] = {0, 1, 2, 0, 1, 0};
+                for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cb][wa[t]], act[xa[t]], acc[cb], 0, 0, 0);
+                    for (int cb = 0; cb < 4; ++cb) {
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cb][wa[t]], act[xa[t]], acc[cb], 0, 0, 0);
 #pragma unroll
-                    for (int v = 0; v < FILL; ++v) f[(v + cb) & 7] = fmaf(f[(v + cb) & 7], 1.0001f, 0.5f);
-                }
+                        for (int v = 0; v < FILL; ++v) f[(v + cb) & 7] = fmaf(f[(v + cb) & 7], 1.0001f, 0.5f);
+                    }
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        acc[ORDER == 2 ? 0 : cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cb][wa[t]], act[xa[t]], acc[ORDER == 2 ? 0 : cb], 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < FILL; ++v) f[(v + cb) & 7] = fmaf(f[(v + cb) & 7], 1.0001f, 0.5f);
+                    }
             }
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
@@ -195,7 +208,8 @@ extern "C" int bf16x3_throughput(int fill, int src, int blocks, int steps, int u
     auto launch = [&](void) {
         const size_t lds = n * sizeof(u32x4);
 #define TP(F, S) tp_kernel<F, S><<<blocks, 256, lds, st>>>(wimg, out, steps, units)
-        if (src == 0) { if (fill == 0) TP(0, 0); else if (fill == 2) TP(2, 0); else if (fill == 3) TP(3, 0); else if (fill == 4) TP(4, 0); else TP(6, 0); }
+        if (fill >= 100) { if (fill == 100) tp_kernel<0, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else if (fill == 101) tp_kernel<0, 0, 2><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else tp_kernel<3, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); }
+        else if (src == 0) { if (fill == 0) TP(0, 0); else if (fill == 2) TP(2, 0); else if (fill == 3) TP(3, 0); else if (fill == 4) TP(4, 0); else TP(6, 0); }
         else { if (fill == 0) TP(0, 1); else TP(3, 1); }
 #undef TP
     };
