@@ -35,6 +35,9 @@ sys.path.insert(0, ROOT)
 B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_MFMA_BF16_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 32 cycles / SIMD at 2.4 GHz)
+X3_PRODUCTS = 6                           # bf16 piece products per fp32 product of the encoder's default arithmetic (csrc/encoder_x3.h)
+PEAK_ENCODER_X3_TFLOPS = PEAK_MFMA_BF16_TFLOPS / X3_PRODUCTS     # algorithmic fp32 TFLOP/s the bf16 pipe can deliver in that form
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
 PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r05_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
@@ -190,7 +193,7 @@ def pmc_encoder():
     if not want or source_hashes(sorted(want)) != want:
         return None, None, "%s was taken at different kernel sources: dropped" % os.path.basename(PMC_FILE)
     names = [n for n in d if "encoder_fwd" in n]
-    names.sort(key=lambda n: ("<true, 64>" not in n, n))      # the loop's instantiation at B = 32: masks on, 64-row tiles
+    names.sort(key=lambda n: ("encoder_fwd3_kernel<true>" not in n, "<true, 64>" not in n, n))      # the loop's instantiation at B = 32: masks on
     k = d[names[0]]
     traffic = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
     util = None
@@ -529,7 +532,8 @@ def _timed_attack_windows(at, warm, iters, windows=5, prime_ms=60.0):
 
 
 def _encoder_frac(at, b, n, first, iters):
-    """(avg launch ms, fraction of the fp32 MFMA peak) of the encoder forward from its own begin / end stamps."""
+    """(avg launch ms, algorithmic fp32 FLOP/s as a fraction of the fp32 MFMA peak -- above 1 is possible: the default arithmetic
+    runs on the bf16 pipe, PEAK_ENCODER_X3_TFLOPS = 2.65 x that peak) of the encoder forward from its own begin / end stamps."""
     import torch
     at.profile(["encoder_fwd"], stride=max(1, iters // 32))
     at.run(first, iters, 10 ** 6)
@@ -967,6 +971,15 @@ def main():
     dt_ap = median(dts_ap)
     del leg_ap
 
+    # ---- the same loop with the encoder's products as fp32 MFMAs (GEOADV_ENC_ARITH_F32): what the default arithmetic buys ----
+    dt_f32 = None
+    if not args.no_secondary:                   # (--no-secondary: the counter passes profile the headline launches only)
+        ae_f32 = PointNetAE(weights, N, device=dev, encoder_arith="f32")
+        leg_f32 = Leg(dev, weights, ae_f32, x, gt, Wm, K, dog=dog)
+        dts_f32 = leg_f32.windows(min(R, 3), gdist, backend, dev)
+        dt_f32 = median(dts_f32)
+        del leg_f32, ae_f32
+
     # ---- strong scaling: ONE global batch of 32 (rank 0's seeds), 32 / world clouds per rank ----
     strong = None
     if B % world == 0:
@@ -1023,12 +1036,20 @@ def main():
         "value": world * K / dt, "unit": "attack-iterations/sec", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "encoder_arith": "bf16x3 (fp32 operands as three bf16 pieces, six piece products per multiply, fp32 accumulate; include/geoadv.h "
+                         "GEOADV_ENC_ARITH_BF16X3) -- everything else plain fp32",
         "timing": "median of %d windows of exactly %d steps, each bracketed by barrier + synchronize, max over ranks; ~0.1 s of "
                   "untimed priming windows first (clock ramp)" % (R, K),
         "windows_ms": [round(t * 1e3, 3) for t in dts],
         "value_all_pairs": world * K / dt_ap,
         "value_all_pairs_note": "nn_distance(adv, x) by the all-pairs kernel for every cloud (Configuration.chamfer_prune=False): what a "
                                 "victim whose adversarial points leave their grid cells gets; same results bit for bit",
+        "value_encoder_f32": (world * K / dt_f32) if dt_f32 else None,
+        "value_encoder_f32_note": "the same loop with the encoder's products as fp32 MFMAs (encoder_arith='f32', v_mfma_f32_32x32x2_f32: "
+                                  "the round-4 kernel).  `value` runs the default: every fp32 operand as three bf16 pieces, a product as its six "
+                                  "piece products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the error of an fp32 "
+                                  "accumulation in another order (profiles/r05_bf16x3_probe.jsonl: rms 0.48-0.52 against 0.43-0.46 units of "
+                                  "2^-24 |a|.|w|), same parity tolerances (tests/test_gpu_encoder_x3.py)",
         "config": {"workload": "BASELINE configs[1]: B=32 random clouds x N=2048, output-space attack (chamfer/chamfer, "
                                "dist_weight 1.0, lr 0.01), one batch per GPU", "batch_per_gpu": B, "n_points": N,
                    "global_batch": B * world, "parallelism": "batches sharded, dp%d, no data-path collective" % world,
@@ -1036,8 +1057,17 @@ def main():
                    "rccl_version": group_info["rccl_version"],
                    "thresh_fraction": 0.8},
         "strong_scaling": strong,
-        "roofline": {"bound": "mfma", "kernel": "encoder_fwd2_kernel<true, 64>", "achieved": enc_tflops, "peak": PEAK_MFMA_F32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": enc_tflops / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+        "roofline": {"bound": "mfma", "kernel": "encoder_fwd3_kernel<true>", "achieved": enc_tflops, "peak": PEAK_ENCODER_X3_TFLOPS,
+                     "unit": "TFLOP/s", "frac": enc_tflops / PEAK_ENCODER_X3_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                     "peak_note": "algorithmic fp32 FLOP (SURVEY 8d: 2 x 90304 per point) against the dense bf16 MFMA peak (%.0f TFLOP/s) / %d: "
+                                  "the kernel issues six bf16 piece products per fp32 product.  Against the fp32 MFMA peak the round-4 kernel "
+                                  "was priced on (%.1f) the same launch is frac_of_fp32_mfma_peak" % (PEAK_MFMA_BF16_TFLOPS, X3_PRODUCTS, PEAK_MFMA_F32_TFLOPS),
+                     "issued_bf16_tflops": X3_PRODUCTS * enc_tflops, "frac_of_fp32_mfma_peak": enc_tflops / PEAK_MFMA_F32_TFLOPS,
+                     "sustained_note": "a bare stream of the same MFMAs (operands in registers, weights re-read from LDS, 3 VALU per MFMA, all "
+                                       "256 CUs, random operands) sustains 1.37 PFLOP/s bf16 on this part -- 55 % of the spec peak: the chip "
+                                       "lowers its clock under bf16 matrix load (profiles/r05_bf16x3_probe.jsonl; MI355X_MICROARCH.md, DVFS "
+                                       "give-back) -- so this kernel's MFMA floor is ~48 us of its launch",
+                     "frac_of_sustained_bf16_stream": X3_PRODUCTS * enc_tflops / 1367.6,
                      "mfma_pipe_utilisation_pmc": mfma_util,
                      "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop,
                      "timing": "kernel begin/end stamps (hipExtLaunchKernel start/stop events) of every %s launch inside the "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's counter evidence (run on the GPU box through gpurun; counters in separate passes, --kernel-trace only beside
 # --pmc: MI355X_MICROARCH.md / rocprofv3 PMC slots).  Usage: tools/collect_pmc.sh OUTDIR [ROUND]
-#   <ROUND>_pmc_encoder.json      bench command: SQ issue counters, MFMA busy + GRBM, FETCH_SIZE, WRITE_SIZE (hashes encoder.hip, mfma_tile.h)
+#   <ROUND>_pmc_encoder.json      bench command: SQ issue counters, MFMA busy + GRBM, FETCH_SIZE, WRITE_SIZE (hashes encoder.hip, encoder_x3.hip, encoder_x3.h, mfma_tile.h)
 #   <ROUND>_pmc_chamfer_hbm.json  tools/attack_breakdown.py 32 (the pruned loop, ONE leg): FETCH_SIZE, WRITE_SIZE, SQ issue counters
 #                                 of chamfer_sym_kernel / loss_cgrad_kernel (hashes chamfer_sym.hip, chamfer_grid.h)
 #   <ROUND>_pmc_emd.json          tools/emd_attack_time.py 32: SQ issue counters
@@ -44,7 +44,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_WAIT_AN
 done
 python3 tools/pmc_summary.py --hash grouping.hip "$OUT"/knn_* > "$OUT/${R}_pmc_knn.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- $BENCH > "$OUT/bench_stats.log" 2>&1
-cp "$(grep -l encoder_fwd2 "$OUT"/bench_stats/*/*_kernel_stats.csv | head -1)" "$OUT/${R}_bench_kernel_stats.csv" 2>/dev/null   # (the RCCL self-test child writes a file of its own)
+cp "$(grep -l encoder_fwd "$OUT"/bench_stats/*/*_kernel_stats.csv | head -1)" "$OUT/${R}_bench_kernel_stats.csv" 2>/dev/null   # (the RCCL self-test child writes a file of its own)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/loop_stats" -- $LOOP > "$OUT/loop_stats.log" 2>&1
-cp "$(grep -l encoder_fwd2 "$OUT"/loop_stats/*/*_kernel_stats.csv | head -1)" "$OUT/${R}_loop_b32_kernel_stats.csv" 2>/dev/null
+cp "$(grep -l encoder_fwd "$OUT"/loop_stats/*/*_kernel_stats.csv | head -1)" "$OUT/${R}_loop_b32_kernel_stats.csv" 2>/dev/null
 tail -2 "$OUT/bench_stats.log"

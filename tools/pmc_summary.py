@@ -7,7 +7,7 @@ import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geometric_adv_amd", "csrc")
-HASHED = ("encoder.hip", "mfma_tile.h")      # bench.py drops counters taken at other sources of the dominant kernel
+HASHED = ("encoder.hip", "encoder_x3.hip", "encoder_x3.h", "mfma_tile.h")      # bench.py drops counters taken at other sources of the dominant kernel
                                              # (--hash a,b,c selects other files: the Chamfer summary hashes its own)
 
 
