@@ -93,6 +93,17 @@ def chains():
                               "cycles_per_mfma_at_2p4GHz": round(ms.value * 1e-3 * 2.4e9 / (2 * 44 * 24 * rounds), 2)}), flush=True)
 
 
+def shapes():
+    """32x32x16 against 16x16x32 for the same work (MFMA count doubles, each half the size), whole chip."""
+    st = torch.cuda.current_stream().cuda_stream
+    for blocks in (256, 512):
+        for fill, name in ((0, "32x32x16"), (3, "32x32x16 + 3 VALU per MFMA"), (200, "16x16x32"), (201, "16x16x32 + 1.5 VALU per MFMA")):
+            ms, gms = C.c_float(0), C.c_float(0)
+            check(lib.bf16x3_throughput(fill, 0, blocks, 44, 2, 100, 0, C.byref(ms), C.byref(gms), C.c_void_p(st)))
+            flops = blocks * 4 * 2 * 44 * 24 * 32 * 32 * 16 * 2
+            print(json.dumps({"probe": "shapes", "shape": name, "workgroups": blocks, "ms": round(ms.value, 5), "bf16_tflops": round(flops / ms.value / 1e9, 1)}), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "accuracy"):
@@ -101,3 +112,5 @@ if __name__ == "__main__":
         throughput()
     if what in ("all", "chains"):
         chains()
+    if what in ("all", "shapes"):
+        shapes()

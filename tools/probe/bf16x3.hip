@@ -174,6 +174,55 @@ __global__ __launch_bounds__(256, 1) void tp_kernel(const u32x4 *wimg, float *ou
     if (sink == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = sink;
 }
 
+// The same work on v_mfma_f32_16x16x32_bf16 (MI355X_MICROARCH.md reports that shape at 1.12-1.15 x the FLOP/s of 32x32x16 where the
+// chip lowers its clock under load): per 32-k double step 8 channel tiles x 2 point tiles x 6 piece products = 96 MFMAs of half
+// the size, 24 weight fragments from LDS (the same bytes as two 16-k steps of the other shape), 16 accumulators of 4 registers.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int FILL>
+__global__ __launch_bounds__(256, 1) void tp16_kernel(const u32x4 *wimg, float *out, int dsteps, int units) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 wl[];        // [2 double steps][24 fragments][64 lanes]
+    const int lane = threadIdx.x & 63;
+    for (int e = threadIdx.x; e < 4 * 12 * 64; e += 256) wl[e] = wimg[e];
+    __syncthreads();
+    bf16x8 act[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) act[t][q] = __builtin_bit_cast(bf16x8, wimg[((q * 5 + 1 + t) % 48) * 64 + lane]);
+    float sink = 0.f;
+    for (int u = 0; u < units; ++u) {
+        f32x4v acc[8][2] = {};
+        float f[8] = {1.f + lane, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+        for (int s = 0; s < dsteps; ++s) {
+            const u32x4 *wp = wl + (s & 1) * 24 * 64 + lane;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                bf16x8 w[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) w[q] = __builtin_bit_cast(bf16x8, wp[(ct * 3 + q) * 64]);
+                constexpr int wa[6] = {2, 1, 0, 1, 0, 0}, xa[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[wa[t]], act[pt][xa[t]], acc[ct][pt], 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < FILL; ++v) if ((t * 2 + pt + v) % 2 == 0) f[(v + ct) & 7] = fmaf(f[(v + ct) & 7], 1.0001f, 0.5f);
+                    }
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sink += acc[ct][pt][q];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) sink += f[v];
+    }
+    if (sink == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = sink;
+}
+
 // a VALU-only kernel of a chosen length, launched between the probes to give the chip the attack's duty cycle
 __global__ __launch_bounds__(256) void idle_kernel(float *out, int iters) {
     float a = threadIdx.x, b = 1.0001f;
@@ -208,7 +257,8 @@ extern "C" int bf16x3_throughput(int fill, int src, int blocks, int steps, int u
     auto launch = [&](void) {
         const size_t lds = n * sizeof(u32x4);
 #define TP(F, S) tp_kernel<F, S><<<blocks, 256, lds, st>>>(wimg, out, steps, units)
-        if (fill >= 100) { if (fill == 100) tp_kernel<0, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else if (fill == 101) tp_kernel<0, 0, 2><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else tp_kernel<3, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); }
+        if (fill >= 200) { if (fill == 200) tp16_kernel<0><<<blocks, 256, lds, st>>>(wimg, out, steps / 2, units); else tp16_kernel<3><<<blocks, 256, lds, st>>>(wimg, out, steps / 2, units); }
+        else if (fill >= 100) { if (fill == 100) tp_kernel<0, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else if (fill == 101) tp_kernel<0, 0, 2><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else tp_kernel<3, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); }
         else if (src == 0) { if (fill == 0) TP(0, 0); else if (fill == 2) TP(2, 0); else if (fill == 3) TP(3, 0); else if (fill == 4) TP(4, 0); else TP(6, 0); }
         else { if (fill == 0) TP(0, 1); else TP(3, 1); }
 #undef TP
