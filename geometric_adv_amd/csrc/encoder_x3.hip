@@ -34,8 +34,16 @@ static_assert(X3_STEPS % X3_SLOT_STEPS == 0, "whole slots");
 constexpr size_t X3_LDS_BYTES = (size_t)X3_RING * X3_SLOT_WORDS * 4 + sizeof(float) * X3_CONST_FLOATS + (sizeof(float) + 2 * sizeof(int)) * 4 * 128;
 constexpr size_t X3_LDS_BYTES_MASKS = X3_LDS_BYTES + sizeof(unsigned) * 2 * X3_POINTS * MASK_WORDS;
 
-__device__ __forceinline__ void x3_glds16(const unsigned *gsrc, unsigned *lds_dst) {   // lds_dst: wave-uniform; lane l's 16 bytes land at + 16 l
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+// LDS-DMA of 16 bytes per lane: lane l's bytes land at lds_dst + 16 l (lds_dst wave-uniform).  Inline assembly, not
+// __builtin_amdgcn_global_load_lds: with the builtin the compiler knows the LDS is being written and puts an s_waitcnt vmcnt(0)
+// in front of the next ds_read that might alias -- every LDS read of this kernel -- which drains the ring at every slot; here the
+// counted vmcnt + barrier of slot_sync is the only ordering, as intended.  (M0 is compiler-reserved: saved and restored in the
+// same statement.)
+__device__ __forceinline__ void x3_glds16(const unsigned *gsrc, unsigned *lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(lds_dst));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
 // (v > 0) of a non-negative-or-minus-zero float shifted into `m` from the right: bits + 0x7fffffff carries into bit 31 exactly
