@@ -387,13 +387,16 @@ __global__ __launch_bounds__(X3_THREADS, 1) void encoder_fwd3_kernel(DeviceAE A,
 // ~1 us: the LDS ring's three steps of run-ahead left this form waiting for weights, 15.7 us per workgroup on an idle chip).
 // Same chain per output element, same bits (tests/test_gpu_encoder_x3.py).
 // ------------------------------------------------------------------------------------------
-constexpr int X3S_AHEAD = 10;                                                 // steps of weights in flight: 120 registers
+// Two instantiations: <10 steps of weights in flight (120 registers), one workgroup per CU> while the launch has at most one
+// workgroup per CU anyway (B <= 4 at N = 2048), <6 steps (72 registers: 236 in all), two workgroups per CU> beyond -- the second
+// workgroup's exchanges and prologue run under the first one's MFMAs (B = 8: 0.0761 -> 0.0691 ms per iteration; B = 4 with the
+// shallower run-ahead: 0.0634 -> 0.0641).
 constexpr int X3S_XBUF_WORDS = 8 * 3 * X3_FRAG_WORDS;                        // one layer's pieces: 8 sixteen-k blocks x 3 x 1 KiB
 constexpr size_t X3S_LDS_BYTES = 2 * X3S_XBUF_WORDS * 4 + sizeof(float) * (X3_CONST_FLOATS + 32 * 3);
 constexpr size_t X3S_LDS_BYTES_MASKS = X3S_LDS_BYTES + sizeof(unsigned) * 32 * MASK_WORDS;
 
-template <bool MASKS>
-__global__ __launch_bounds__(X3_THREADS, 1) void encoder_fwd3s_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
+template <bool MASKS, int X3S_AHEAD, int WG_PER_CU>
+__global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
                                                                      float *pmax, int *parg, int *pcnt, unsigned *masks, FusedAdam fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_w[];
     unsigned *xbuf = lds_w;                                                  // [2][8][3][64 lanes][4 words]
@@ -550,21 +553,25 @@ int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float 
     if (int rc = attr.run([]() -> int {
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES_MASKS));
             GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES));
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES_MASKS));
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<true, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES_MASKS));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<false, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<true, 6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES_MASKS));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<false, 6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES));
             return GEOADV_OK;
         })) return rc;
     const dim3 block(X3_THREADS);
     if (encoder_x3_points(b, A.n_points) == 32) {
         const dim3 grid(cdiv(A.n_points, 32), b);
         const unsigned lds = (unsigned)(masks ? X3S_LDS_BYTES_MASKS : X3S_LDS_BYTES);
-        if (masks) {
-            if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3s_kernel<true>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
-            else encoder_fwd3s_kernel<true><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
-        } else {
-            if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3s_kernel<false>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
-            else encoder_fwd3s_kernel<false><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
-        }
+        const bool two = (long)grid.x * b > kCUs;          // more workgroups than CUs: two per CU
+#define X3S_LAUNCH(M, AH, W)                                                                                                                     \
+        do {                                                                                                                                      \
+            if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3s_kernel<M, AH, W>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa); \
+            else encoder_fwd3s_kernel<M, AH, W><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);      \
+        } while (0)
+        if (masks) { if (two) X3S_LAUNCH(true, 6, 2); else X3S_LAUNCH(true, 10, 1); }
+        else { if (two) X3S_LAUNCH(false, 6, 2); else X3S_LAUNCH(false, 10, 1); }
+#undef X3S_LAUNCH
         GA_LAUNCH_CHECK();
         return GEOADV_OK;
     }
