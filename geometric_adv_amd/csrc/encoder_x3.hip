@@ -10,10 +10,10 @@
 // no bank conflicts, and the BN + ReLU + split epilogue of one channel block runs under the next layer's first MFMAs.  Layer 4
 // takes the activations as the A operand instead (same registers), so its result has the channel on the lane and the points in
 // the registers: the max-pool is reduced in registers like the fp32 kernel's.
-// One wave per SIMD (a 512-register kernel: h3 = 96 registers of pieces, h4 half = 96, two accumulator sets); the four waves of a
-// workgroup share the only operand that streams, the weights: 12 KiB per sixteen-k step, LDS-DMA'd into a four-slot ring
-// three steps ahead (each wave fetches the fragments of "its" channel block; one raw s_barrier per step orders them) and read
-// back as 12 ds_read_b128 per 24 MFMAs.
+// Two waves per SIMD, each a 256-register wave (h3 = 96 registers of pieces, two accumulator sets of 64, the epilogue's staging);
+// the four waves of a workgroup share the only operand that streams, the weights: 12 KiB per sixteen-k step, LDS-DMA'd into a
+// four-slot ring three steps ahead (each wave fetches the fragments of "its" channel block; one raw s_barrier per step orders
+// them) and read back as 12 ds_read_b128 per 24 MFMAs; two workgroups share a CU, one's stalls under the other's MFMAs.
 #include "encoder_x3.h"
 #include "encoder_jac.h"
 #include <hip/hip_ext.h>
@@ -25,7 +25,13 @@ namespace geoadv {
 constexpr int X3_THREADS = 256;               // 4 waves, one per SIMD
 constexpr int X3_POINTS = 128;                // points per workgroup
 constexpr int X3_RING = 4, X3_AHEAD = 3;      // ring slots and slots in flight ahead of the consumer; a slot = X3_SLOT_STEPS steps
-constexpr int X3_SLOT_STEPS = 2;              // (one barrier per slot: per step it was 4.6 us of the B = 32 launch)
+// TWO workgroups per CU (two waves per SIMD): one's prologue, barriers and the epilogue instructions that found no shadow run
+// under the other's MFMAs -- 0.1432 -> 0.135 ms per iteration at B = 32.  What it takes: 256 registers per wave (the compiler gets
+// there from 288 with 4 spilled) and 80 KB of LDS per workgroup, i.e. ring slots of ONE step (with two steps per slot and one
+// workgroup per CU: 0.1432; one step per slot, one workgroup: 0.142 -- the barrier per step costs nothing since the ring's
+// LDS-DMA comes from inline assembly).
+constexpr int X3_SLOT_STEPS = 1;              // steps per ring slot = per barrier
+constexpr int X3_BIG_WG_PER_CU = 2;
 constexpr int X3_SLOTS = X3_STEPS / X3_SLOT_STEPS, X3_SLOT_WORDS = X3_SLOT_STEPS * X3_STEP_WORDS;
 static_assert(X3_STEPS % X3_SLOT_STEPS == 0, "whole slots");
 #ifndef X3_SPLIT_HALVES
@@ -33,6 +39,7 @@ static_assert(X3_STEPS % X3_SLOT_STEPS == 0, "whole slots");
 #endif                                        // (measured, iteration ms at B = 8 / 16: split 0.0766 / 0.108, wave-private 0.0825 / 0.0935)
 constexpr size_t X3_LDS_BYTES = (size_t)X3_RING * X3_SLOT_WORDS * 4 + sizeof(float) * X3_CONST_FLOATS + (sizeof(float) + 2 * sizeof(int)) * 4 * 128;
 constexpr size_t X3_LDS_BYTES_MASKS = X3_LDS_BYTES + sizeof(unsigned) * 2 * X3_POINTS * MASK_WORDS;
+static_assert(X3_BIG_WG_PER_CU * X3_LDS_BYTES_MASKS <= 160 * 1024, "the workgroups of a CU share its 160 KB of LDS");
 
 // LDS-DMA of 16 bytes per lane: lane l's bytes land at lds_dst + 16 l (lds_dst wave-uniform).  Inline assembly, not
 // __builtin_amdgcn_global_load_lds: with the builtin the compiler knows the LDS is being written and puts an s_waitcnt vmcnt(0)
@@ -179,7 +186,7 @@ __device__ __forceinline__ unsigned x3_mask_bits(unsigned m_lo, unsigned m_hi, i
 }
 
 template <bool MASKS>
-__global__ __launch_bounds__(X3_THREADS, 1) void encoder_fwd3_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
+__global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
                                                                     float *pmax, int *parg, int *pcnt, unsigned *masks, FusedAdam fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_w[];
     unsigned *ring = lds_w;                                                  // [X3_RING][X3_SLOT_STEPS][12 fragments][64 lanes][4 words]
