@@ -200,6 +200,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
     const int n0 = tile * X3_POINTS + wave * 32;                              // this wave's first point
     const unsigned *img = A.enc_x3;
+    GA_STAMP(0, 0);
 
     // ---- the wave's points ----
     float pc[3];
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     }
     x3_stage_constants(A, cst, X3_THREADS);
     __syncthreads();                                   // constants visible; nothing of the ring is in flight yet
+    GA_STAMP(0, 1);
 
     // ---- the weight ring ----
     // fetch(t): this wave's fragments (the three pieces of channel block `wave`, 1 KiB each, lane-linear) of the steps of slot t
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
         if (MASKS) { mrow[0] = m01[0]; mrow[1] = m01[1]; }
     }
 
+    GA_STAMP(0, 2);
     // ---- the step machinery ----
     // Before the first fragment read of slot t (steps 2 t, 2 t + 1): this wave's fetches up to slot t + 1 have landed (counted
     // vmcnt: at most the six of slot t + 2 stay in flight), then the barrier -- after it EVERY wave's share of slots <= t + 1 is in
@@ -321,12 +324,15 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
 #pragma unroll
     for (int kb = 0; kb < 3; ++kb) step(ActB{}, kb, act1[kb], acc1, nothing, nothing);
     step(ActB{}, 3, act1[3], acc1, nothing, first_epilogue(acc1, cst + X3_SC1, 128, 0, MASK_OFF2));
+    GA_STAMP(0, 3);
     // ---- layer 2: 128 -> 128 (steps 4-11) ----
     boundary(ActB{}, acc1, cst + X3_SC1, 128, 0, MASK_OFF2, 4, acc2, nullptr, first_epilogue(acc2, cst + X3_SC2, 128, 0, MASK_OFF3));
+    GA_STAMP(0, 4);
     // ---- layers 3 + 4 by halves: h4[:, 128 half ..] feeds K half `half` of layer 4 (one chain over K = 256, ascending) ----
     X3 act3[8];
     boundary(ActB{}, acc2, cst + X3_SC2, 128, 0, MASK_OFF3, 12, acc3, act3, first_epilogue(acc3, cst + X3_SC3, 256, 0, MASK_OFF4));   // layer 3, channels 0 .. 127 (steps 12-19)
     boundary(ActA{}, acc3, cst + X3_SC3, 256, 0, MASK_OFF4, 20, acc4, nullptr, nothing);                                             // layer 4, K half 0 (steps 20-27)
+    GA_STAMP(0, 5);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc3[cb] = f32x16{};
 #pragma unroll
@@ -334,6 +340,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     step(ActB{}, 35, act3[7], acc3, nothing, first_epilogue(acc3, cst + X3_SC3, 256, 128, MASK_OFF4 + 4));
     boundary(ActA{}, acc3, cst + X3_SC3, 256, 128, MASK_OFF4 + 4, 36, acc4, nullptr, nothing);                                       // layer 4, K half 1 (steps 36-43)
 
+    GA_STAMP(0, 6);
     // ---- layer 4's BN + ReLU and the max-pool from the registers (lane = channel 32 cb + p, registers = points) ----
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
@@ -382,6 +389,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
         unsigned *dst = masks + ((size_t)b * n + t0) * MASK_WORDS;
         for (int e = threadIdx.x; e < live * MASK_WORDS; e += X3_THREADS) dst[e] = mtile[e] | mtile[X3_POINTS * MASK_WORDS + e];
     }
+    GA_STAMP(0, 7);
 }
 
 // ------------------------------------------------------------------------------------------
