@@ -106,3 +106,25 @@ def test_attack_state_agrees_between_a_two_cloud_and_a_forty_cloud_batch(arith, 
         peeks[b] = {k: v.cpu().numpy() for k, v in at.peek().items()}
     for k in ("latent", "recon", "adv", "pert", "grad", "idx_r1", "idx_r2", "idx_a1", "idx_a2"):
         assert np.array_equal(peeks[2][k], peeks[40][k][:2]), k
+
+
+def test_arithmetic_selection_api():
+    """geoadv_ae_set_encoder_arith / geoadv_ae_encoder_arith / geoadv_set_default_encoder_arith: round trip, refusal of unknown
+    values, and a switched model reproducing the other arithmetic's model bit for bit."""
+    import torch
+    from geometric_adv_amd import _lib
+    from conftest import cloud
+    n = 512
+    w, aes = _models(n, seed=9)
+    pc = cloud(61, 4, n)
+    z = {a: aes[a].forward(pc, want_recon=False)[1].clone() for a in ARITHS}
+    a = aes["f32"]
+    a.set_encoder_arith("bf16x3")
+    assert a.encoder_arith == "bf16x3" and torch.equal(a.forward(pc, want_recon=False)[1], z["bf16x3"])
+    a.set_encoder_arith("f32")
+    assert a.encoder_arith == "f32" and torch.equal(a.forward(pc, want_recon=False)[1], z["f32"])
+    lib = _lib.lib()
+    assert lib.geoadv_ae_set_encoder_arith(a.handle, 7) != 0 and a.encoder_arith == "f32"
+    assert lib.geoadv_set_default_encoder_arith(7) != 0
+    with pytest.raises(KeyError):
+        a.set_encoder_arith("fp16")
