@@ -349,9 +349,15 @@ static SymShape sym_shape(long groups, int n, int m) {
     s.rw = n > 1024 ? 8 : n > 512 ? 4 : n > 256 ? 2 : 1;
     s.cw = CS_WAVES / s.rw;
     s.rtiles = cdiv(n, CS_WROWS * s.rw);
-    s.C = CS_CMAX;
     const int cmin = std::max(CS_CMIN, 2 * CS_ROUND * s.cw);      // every column-wave keeps at least two rounds
-    while (s.C > cmin && (long)s.rtiles * cdiv(m, s.C) * groups < kCUs) s.C /= 2;   // measured: slicing only pays when the grid would not even cover the CUs
+    // columns per workgroup: halved while the grid does not cover the CUs (measured: slicing only pays then) -- but not below 128
+    // columns into a grid that no longer fits ONE workgroup per CU: 10 ... 14 clouds got 320 ... 448 workgroups of 64 columns, a
+    // second layer on a quarter of the CUs of a VALU-bound kernel (scan 28.4 us at B = 10 and 12 against 24.0 at B = 16; with 128
+    // columns 0.0917 -> 0.0877, 0.0971 -> 0.0894, 0.0976 -> 0.0915 ms per iteration at B = 10 / 12 / 14).  Wider slices than that
+    // keep the old rule: 320 workgroups of 128 columns beat 160 of 256 (B = 20: 0.1178 against 0.1268).
+    s.C = CS_CMAX;
+    while (s.C > cmin && (long)s.rtiles * cdiv(m, s.C) * groups < kCUs &&
+           (s.C > 128 || (long)s.rtiles * cdiv(m, s.C / 2) * groups <= kCUs)) s.C /= 2;
     // large launches: several column stages per workgroup (same rows in registers, next stage's columns requested a stage ahead) as
     // long as four workgroups per CU remain
     s.S = 1;
