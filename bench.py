@@ -363,7 +363,16 @@ def cpu_baseline(weights, x, gt, iters, gpu_clouds=None):
         pass
     gemm_s = (dt - ch) / iters
     flop = 3 * ENC_FLOP_PER_POINT * B * N + 3 * 2.0 * B * (98304 + 768 * N)      # 2 forwards + 1 backward-to-input
-    return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"value": iters / dt, "unit": "attack-iterations/sec", "cores": threads, "host_cores": os.cpu_count(), "usable_cores": usable,
+            "cores_note": "threads of the network's GEMMs = the FASTEST of {8, 16, 32, 64, torch default} <= host cores on one encoder "
+                          "forward + backward, measured in this run (not an affinity or cgroup limit: usable_cores says what the process "
+                          "may use; [65536 x <=256] x [<=256 x <=256] GEMMs stop scaling long before 256 cores -- 128 threads ran 8 x "
+                          "slower than 8 on the round-2 box); the Chamfer part is single-threaded like the reference op",
+            "kind": "port",
             "chamfer_kind": "reference (oracle/_ref: the reference's nnsearch compiled from its own source)" if ref_chamfer else "port",
             "parity": parity, "cpu_model": cpu_model,
             "sample": "%d iterations of config 2 (B=32, N=2048) after 1 warm-up, reference schedule (2 forwards + 1 backward per "
@@ -430,11 +439,13 @@ def emd_leg(dev):
         sparse_pw = 2 * 27 / 16.0 ** 3 + 3 * 27 / 12.0 ** 3 + 3 * 27 / 6.0 ** 3
         bound_reduced_ms = b * N * N / 64.0 * ((21.4 - 8 + sparse_pw) * cyc_pw + cyc_pair - 21.4 * cyc_pw) / (1024 * 2.4e9) * 1e3
         out["B%d" % b] = {"approx_match_ms": t_match, "levels_cost_grad1_fused_ms": t_fused, "issue_bound_ms": bound_ms,
-                          "frac": bound_ms / t_match, "issue_bound_reduced_work_ms": bound_reduced_ms, "frac_reduced_work": bound_reduced_ms / t_match,
+                          "frac": bound_reduced_ms / t_match, "issue_bound_reduced_work_ms": bound_reduced_ms, "frac_reduced_work": bound_reduced_ms / t_match,
+                          "equivalent_dense_frac": bound_ms / t_match,
                           "achieved_Tpair_weights_per_s_sweeps_only": 21.4 * b * N * N / (t_match * 1e-3) / 1e12}
-    out.update({"bound": "valu issue", "frac_note": "`frac`: the dense algorithm's pair-weights (what the op computes the result of) over the time; "
-                "`frac_reduced_work`: only the pair-weights the sparse first levels still evaluate (csrc/emd.hip, Sparse levels) -- the sparse "
-                "sweeps trade 8 dense pair-weights per pair for 0.44 at 4-10 x the cost each", "cycles_per_64_pairs": cyc_pair, "cycles_per_64_sweep_pair_weights": cyc_pw,
+    out.update({"bound": "valu issue", "frac_note": "`frac` (= `frac_reduced_work`): issue time of the pair-weights the op actually evaluates -- the sparse "
+                "first levels (csrc/emd.hip) skip exact zeros: 8 dense pair-weights per pair become 0.44 at 4-10 x the cost each -- over the "
+                "measured time: the roofline fraction.  `equivalent_dense_frac`: the DENSE algorithm's pair-weights over the same time, an "
+                "equivalent rate (it counts skipped work), not a roofline fraction", "cycles_per_64_pairs": cyc_pair, "cycles_per_64_sweep_pair_weights": cyc_pw,
                 "hbm_note": "approx_match writes the 4 B N M plan once (537 MB at B = 32: ~0.1 ms at 5 TB/s); the fused form writes nothing",
                 "round1_approx_match_ms_B32": 4.61, "round3_approx_match_ms_B32": 1.22})
     return out
@@ -595,10 +606,15 @@ def config2_leg(dev):
            "defend_surface_ms": t_def, "defend_surface_numpy_in_out_ms": t_def_np,
            "roofline_knn": {"bound": "valu issue", "kernel": "knn_grid_build_kernel + knn_grid_kernel<1, 9, 512> (exact grid search: lane-private 27-cell walk, leftovers by a cooperative all-points scan) + knn_redo_kernel for tied / non-finite queries",
                             "pairs_per_launch": pairs, "achieved_Tpair_per_s": pairs / (t_knn * 1e-3) / 1e12,
-                            "issue_bound_ms": bound_ms, "frac": bound_ms / t_knn,
+                            "issue_bound_ms": bound_ms, "equivalent_all_pairs_frac": bound_ms / t_knn,
+                            "pairs_evaluated_per_query": KNN_CANDIDATES_PER_QUERY,
+                            "frac": bound_ms * (KNN_CANDIDATES_PER_QUERY / N) / t_knn,
                             "bound_note": "distance only: 8 fp32 VALU instructions per pair (3 sub, 3 mul, 2 add -- unfused, the reference's "
-                                          "rounding) at %.2f issue cycles per wave instruction, %d SIMDs, %.1f GHz; the compare and the "
-                                          "top-k bookkeeping are overhead against this bound" % (VALU_CYC, SIMDS, CLOCK_HZ / 1e9),
+                                          "rounding) at %.2f issue cycles per wave instruction, %d SIMDs, %.1f GHz.  `frac`: the distance "
+                                          "evaluations the grid search PERFORMS (~%d candidates per query on uniform clouds: its own 27 cells, "
+                                          "tools/debug/knn_diag.py) against that bound -- the search is bound by its walk and list bookkeeping, "
+                                          "not by distance arithmetic; `equivalent_all_pairs_frac`: all b*n*n pairs over the same time, an "
+                                          "equivalent rate, not a roofline fraction" % (VALU_CYC, SIMDS, CLOCK_HZ / 1e9, KNN_CANDIDATES_PER_QUERY),
                             "algorithmic_bytes_per_launch": 12.0 * b * N + 4.0 * b * N * 8}}
     del at
     return out
@@ -625,11 +641,34 @@ def config3_leg(dev, emd):
            "emd_levels_cost_grad1_fused_ms": e.get("levels_cost_grad1_fused_ms"),
            "emd_share_of_iteration": (e.get("levels_cost_grad1_fused_ms") / ms_it) if e.get("levels_cost_grad1_fused_ms") else None,
            "roofline_emd": {"bound": "valu issue", "approx_match_ms": e.get("approx_match_ms"), "issue_bound_ms": e.get("issue_bound_ms"),
-                            "frac": e.get("frac"), "see": "secondary.roofline_emd"}}
+                            "frac": e.get("frac"), "equivalent_dense_frac": e.get("equivalent_dense_frac"), "see": "secondary.roofline_emd"}}
     del at
+    out["full_size_ms_per_iteration"] = _full_size_ms(dev, 1024, N, 1.0)
+    out["full_size_note"] = "configs[3] WHOLE on this GPU: B=1024 x N=2048, Chamfer + approx-EMD/N, 3 timed iterations after 2"
     return out
 
 
+def _full_size_ms(dev, b, n, emd_weight, warm=2, iters=3):
+    """ms per attack iteration of a whole multi-GPU config of BASELINE.json on THIS GPU (the N = 1 point a measured 8-GPU figure
+    would be divided by; parity of the same run: tests/test_gpu_configs.py::test_config*_full_size_*)."""
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    w = W.synthetic_weights(n, seed=7)
+    ae = PointNetAE(w, n, device=dev)
+    x, gt = clouds(1006, b, n), clouds(2006, b, n)
+    kw = {"emd_weight": emd_weight} if emd_weight else {}
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=warm + iters + 1,
+                                          num_iterations_thresh=10 ** 6, **kw), device=dev, ae=ae)
+    at.set_inputs(x, gt, ae.transform(gt), 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    ms = _timed_attack(at, warm, iters)
+    at.status()
+    del at, ae
+    return ms
+
+
+KNN_CANDIDATES_PER_QUERY = 110      # measured by tools/debug/knn_diag.py on uniform clouds of 2048 points (DESIGN 4, knn row)
 PMC_CHAMFER_8192 = os.path.join(ROOT, "profiles", "r05_pmc_chamfer_n8192.json")
 
 
@@ -671,6 +710,8 @@ def config4_leg(dev):
                                        "algorithmic_bytes_per_launch": alg, "traffic": traffic, "traffic_source": note,
                                        "traffic_over_algorithmic": (traffic / alg) if traffic else None}
         del at
+    out["full_size_ms_per_iteration"] = _full_size_ms(dev, 256, n, 0.0)
+    out["full_size_note"] = "configs[4] WHOLE on this GPU: B=256 x N=8192, output-space attack, 3 timed iterations after 2"
     return out
 
 
@@ -890,6 +931,17 @@ def calibration(dev):
     return out
 
 
+def sustained_bf16_tflops():
+    """TFLOP/s a bare stream of the encoder's MFMAs sustained in the recorded probe (tools/bf16x3_probe.py throughput, weights
+    from LDS, 2-3 VALU per MFMA), or None when the record is missing: a number of ANOTHER box and clock state, reported as such."""
+    try:
+        rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r05_bf16x3_probe.jsonl"))]
+        v = [r["bf16_tflops"] for r in rows if r.get("probe") == "throughput" and r.get("weights_from") == "lds" and r.get("valu_per_mfma") in (2, 3)]
+        return sum(v) / len(v) if v else None
+    except Exception:
+        return None
+
+
 def median(v):
     s = sorted(v)
     return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
@@ -972,13 +1024,17 @@ def main():
     del leg_ap
 
     # ---- the same loop with the encoder's products as fp32 MFMAs (GEOADV_ENC_ARITH_F32): what the default arithmetic buys ----
-    dt_f32 = None
+    dt_f32 = dt_f32ap = None
     if not args.no_secondary:                   # (--no-secondary: the counter passes profile the headline launches only)
         ae_f32 = PointNetAE(weights, N, device=dev, encoder_arith="f32")
         leg_f32 = Leg(dev, weights, ae_f32, x, gt, Wm, K, dog=dog)
         dts_f32 = leg_f32.windows(min(R, 3), gdist, backend, dev)
         dt_f32 = median(dts_f32)
-        del leg_f32, ae_f32
+        del leg_f32
+        # ---- neither shortcut: fp32 MFMA encoder AND all-pairs nn_distance(adv, x) ----
+        leg_f32ap = Leg(dev, weights, ae_f32, x, gt, Wm, K, prune=False, dog=dog)
+        dt_f32ap = median(leg_f32ap.windows(min(R, 3), gdist, backend, dev))
+        del leg_f32ap, ae_f32
 
     # ---- strong scaling: ONE global batch of 32 (rank 0's seeds), 32 / world clouds per rank ----
     strong = None
@@ -1035,7 +1091,7 @@ def main():
         "metric": "attack-iterations/sec (B=32, N=2048) at 1/2/4/8 GPUs; Chamfer rel-err vs ref",
         "value": world * K / dt, "unit": "attack-iterations/sec", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (encoder products: bf16x3)", "data": "synthetic",
         "encoder_arith": "bf16x3 (fp32 operands as three bf16 pieces, six piece products per multiply, fp32 accumulate; include/geoadv.h "
                          "GEOADV_ENC_ARITH_BF16X3) -- everything else plain fp32",
         "timing": "median of %d windows of exactly %d steps, each bracketed by barrier + synchronize, max over ranks; ~0.1 s of "
@@ -1067,7 +1123,7 @@ def main():
                                        "256 CUs, random operands) sustains 1.37 PFLOP/s bf16 on this part -- 55 % of the spec peak: the chip "
                                        "lowers its clock under bf16 matrix load (profiles/r05_bf16x3_probe.jsonl; MI355X_MICROARCH.md, DVFS "
                                        "give-back) -- so this kernel's MFMA floor is ~48 us of its launch",
-                     "frac_of_sustained_bf16_stream": X3_PRODUCTS * enc_tflops / 1367.6,
+                     "frac_of_sustained_bf16_stream": (X3_PRODUCTS * enc_tflops / sustained_bf16_tflops()) if sustained_bf16_tflops() else None,
                      "mfma_pipe_utilisation_pmc": mfma_util,
                      "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop,
                      "timing": "kernel begin/end stamps (hipExtLaunchKernel start/stop events) of every %s launch inside the "
@@ -1114,6 +1170,26 @@ def main():
         out["cpu_baseline"] = cpu_baseline(weights, x, gt, args.cpu_iters,
                                            gpu_clouds=(recon_best[:4].contiguous(), torch.as_tensor(gt[:4]).to(dev)))
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    # The qualifiers of the headline, repeated (short) under `config` and `roofline`: the driver's record keeps only
+    # metric ... config, roofline and cpu_baseline of this line (VERDICT r05 task 2).
+    rc = out["roofline_chamfer"]
+    sec = out.get("secondary") or {}
+    tv = sec.get("trained_victim") or {}
+    r1 = lambda v: None if v is None else round(float(v), 1)
+    out["config"]["qualifiers"] = {
+        "value_all_pairs": r1(out["value_all_pairs"]), "value_encoder_f32": r1(out["value_encoder_f32"]),
+        "value_f32_all_pairs": r1((world * K / dt_f32ap) if dt_f32ap else None),
+        "trained_victim_its": {k: r1(tv[k]["attack_iterations_per_sec"]) for k in ("grid_search", "all_pairs", "adaptive_default")
+                               if isinstance(tv.get(k), dict) and "attack_iterations_per_sec" in tv[k]} or None,
+        "strong_measured_ms": ({k: round(v, 4) for k, v in strong["measured_ms"].items()} if strong and "measured_ms" in strong else None),
+        "full_size_ms": {k: (sec.get("configs", {}).get(k) or {}).get("full_size_ms_per_iteration")
+                         for k in ("config3_chamfer_emd_b128", "config4_n8192_b32")} if sec else None,
+        "note": "all_pairs: nn_distance(adv, x) without the data-dependent grid search; encoder_f32: fp32 MFMAs instead of bf16x3; "
+                "f32_all_pairs: neither; strong_measured_ms: ms per iteration of THIS GPU at B = 32/G; full_size_ms: configs[3] "
+                "(B=1024) and configs[4] (B=256 x 8192) whole on one GPU"}
+    out["roofline"]["chamfer"] = {"kernel": "chamfer scan of nn_distance(recon, target)", "frac": round(rc["frac"], 4),
+                                  "avg_class_ms": round(rc["avg_class_ms"], 5), "issue_bound_ms": round(rc["issue_bound_ms"], 5),
+                                  "traffic_over_algorithmic": rc.get("traffic_over_algorithmic")}
     print(json.dumps(out))
 
 

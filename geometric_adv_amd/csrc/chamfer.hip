@@ -221,6 +221,32 @@ __global__ void chamfer_fill_empty_kernel(float *dist, int *idx, size_t count) {
     if (i < count) { dist[i] = 0.f; idx[i] = 0; }
 }
 
+// Non-finite inputs, the reference's rule (tf_nndistance.cpp:31-40): candidate 0 is ALWAYS taken (`k==0 || d<best`) and nothing
+// compares below a NaN, so a query whose distance to candidate 0 is NaN keeps (NaN, 0); a NaN distance to a later candidate never
+// wins.  The scans fold with fminf / integer minima, which already skip NaNs and keep the lowest index of an infinite minimum --
+// what is left is the first case, patched here on the finished outputs of the OPERATOR entry points (one thread per query of
+// either direction; the attack loop's internal launches skip it: a NaN there is a diverged attack whose losses are NaN either way).
+__global__ __launch_bounds__(256) void nn_nonfinite_fix_kernel(int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                                                               int *idx1, float *dist2, int *idx2) {
+    const int c = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    const float *P = xyz1 + (size_t)c * n * 3, *Q = xyz2 + (size_t)c * m * 3;
+    if (e < n) {
+        const float d0 = sqdist(Q[0], Q[1], Q[2], P[3 * (size_t)e], P[3 * (size_t)e + 1], P[3 * (size_t)e + 2]);
+        if (d0 != d0) { dist1[(size_t)c * n + e] = d0; idx1[(size_t)c * n + e] = 0; }
+    }
+    if (e < m) {
+        const float d0 = sqdist(P[0], P[1], P[2], Q[3 * (size_t)e], Q[3 * (size_t)e + 1], Q[3 * (size_t)e + 2]);
+        if (d0 != d0) { dist2[(size_t)c * m + e] = d0; idx2[(size_t)c * m + e] = 0; }
+    }
+}
+int launch_nn_nonfinite_fix(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1, int *idx1, float *dist2,
+                            int *idx2, hipStream_t stream) {
+    if (b <= 0 || n <= 0 || m <= 0) return GEOADV_OK;
+    nn_nonfinite_fix_kernel<<<dim3(cdiv(std::max(n, m), 256), b), 256, 0, stream>>>(n, m, xyz1, xyz2, dist1, idx1, dist2, idx2);
+    GA_LAUNCH_CHECK();
+    return GEOADV_OK;
+}
+
 int launch_chamfer_scans(const ChamferScan *scans, int nscan, int b, hipStream_t stream) {
     if (b <= 0) return GEOADV_OK;
     ChamferArgs args;
@@ -342,7 +368,8 @@ extern "C" int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const 
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE((n == 0 || (xyz1 && dist1 && idx1)) && (m == 0 || (xyz2 && dist2 && idx2)), "nn_distance: null pointer");
     ChamferScan scans[2] = {{xyz1, xyz2, dist1, idx1, n, m}, {xyz2, xyz1, dist2, idx2, m, n}};
-    return launch_chamfer_scans(scans, 2, b, as_stream(stream));
+    if (int rc = launch_chamfer_scans(scans, 2, b, as_stream(stream))) return rc;
+    return launch_nn_nonfinite_fix(b, n, xyz1, m, xyz2, dist1, idx1, dist2, idx2, as_stream(stream));
 }
 
 extern "C" int geoadv_nn_distance_grad(int b, int n, const float *xyz1, int m, const float *xyz2,

@@ -21,6 +21,7 @@
 // `need` flag and leaves -- the caller's all-pairs kernel then computes that cloud -- and looks again only every
 // GR_RETRY-th call.  Worst case: the all-pairs price plus one sort every 16 calls.
 #include "chamfer_grid.h"
+#include "chamfer_sym.h"
 
 namespace geoadv {
 
@@ -91,5 +92,6 @@ extern "C" int geoadv_nn_distance_paired(int b, int n, const float *xyz1, const 
                geoadv::GR_MAX_N_BIG);
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && dist1 && idx1 && dist2 && idx2, "nn_distance_paired: null pointer");
-    return geoadv::launch_chamfer_grid(xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, nullptr, 0, nullptr, geoadv::as_stream(stream));
+    if (int rc = geoadv::launch_chamfer_grid(xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, nullptr, 0, nullptr, geoadv::as_stream(stream))) return rc;
+    return geoadv::launch_nn_nonfinite_fix(b, n, xyz1, n, xyz2, dist1, idx1, dist2, idx2, geoadv::as_stream(stream));
 }

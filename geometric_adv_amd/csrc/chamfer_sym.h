@@ -86,6 +86,10 @@ struct CGradProblem {
 };
 int launch_chamfer_grad(const CGradProblem *pr, int np, int B, int n, hipStream_t st);
 
+// the reference's rule for a NaN distance to candidate 0, applied to finished nn_distance outputs (chamfer.hip)
+int launch_nn_nonfinite_fix(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1, int *idx1, float *dist2,
+                            int *idx2, hipStream_t stream);
+
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m);
 bool chamfer_sym_packs_rows(long live_groups, int n, int m);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);

@@ -359,9 +359,11 @@ static SymShape sym_shape(long groups, int n, int m) {
     while (s.C > cmin && (long)s.rtiles * cdiv(m, s.C) * groups < kCUs &&
            (s.C > 128 || (long)s.rtiles * cdiv(m, s.C / 2) * groups <= kCUs)) s.C /= 2;
     // large launches: several column stages per workgroup (same rows in registers, next stage's columns requested a stage ahead) as
-    // long as four workgroups per CU remain
+    // long as four workgroups per CU remain.  Only where ONE column-wave walks the slice: with cw > 1 every stage is re-split over
+    // the column-waves, a wave's partial then covers columns that are not one ascending range, and the merge's tie rule (lowest
+    // slice = lowest index, chamfer_sym.h) would no longer hold (tests/test_gpu_chamfer_shapes.py duplicates cases).
     s.S = 1;
-    while (s.S < CS_MAX_STAGES && (long)s.rtiles * cdiv(m, s.C * s.S * 2) * groups >= 4 * kCUs) s.S *= 2;
+    while (s.cw == 1 && s.S < CS_MAX_STAGES && (long)s.rtiles * cdiv(m, s.C * s.S * 2) * groups >= 4 * kCUs) s.S *= 2;
     s.cslices = cdiv(m, s.C * s.S);
     return s;
 }
@@ -533,18 +535,22 @@ extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *
 }
 
 // nn_distance through the symmetric scan as an operator: same outputs as geoadv_nn_distance, bit for bit.
+// The operator launches with exactly b live groups, so its scratch is the partials of THAT shape (the bound over every possible
+// live-group count, chamfer_sym_workspace_floats, is what an attack handle needs: its need flags change the count from call to call).
+static size_t nn_sym_floats(int b, int n, int m) { return (size_t)b * sym_group_floats(sym_shape((long)b, n, m), n, m) + 64; }
 extern "C" size_t geoadv_nn_distance_sym_workspace_floats(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 64;
-    return chamfer_sym_workspace_floats(1, b, n, m);
+    return nn_sym_floats(b, n, m);
 }
 extern "C" int geoadv_nn_distance_sym(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1, int *idx1,
                                       float *dist2, int *idx2, float *workspace, size_t workspace_floats, void *stream) {
     GA_REQUIRE(b >= 0 && n >= 1 && m >= 1, "nn_distance_sym: bad dimensions (b=%d n=%d m=%d)", b, n, m);
     if (b == 0) return GEOADV_OK;
     GA_REQUIRE(xyz1 && xyz2 && dist1 && idx1 && dist2 && idx2 && workspace, "nn_distance_sym: null pointer");
-    GA_REQUIRE(workspace_floats >= chamfer_sym_workspace_floats(1, b, n, m), "nn_distance_sym: workspace too small (%zu floats, need %zu)",
-               workspace_floats, chamfer_sym_workspace_floats(1, b, n, m));
+    GA_REQUIRE(workspace_floats >= nn_sym_floats(b, n, m), "nn_distance_sym: workspace too small (%zu floats, need %zu)",
+               workspace_floats, nn_sym_floats(b, n, m));
     const ChamferPair pr{xyz1, xyz2, dist1, idx1, dist2, idx2};
-    return launch_chamfer_sym(&pr, 1, b, n, m, workspace, as_stream(stream));
+    if (int rc = launch_chamfer_sym(&pr, 1, b, n, m, workspace, as_stream(stream))) return rc;
+    return launch_nn_nonfinite_fix(b, n, xyz1, m, xyz2, dist1, idx1, dist2, idx2, as_stream(stream));
 }
 GA_STAMPS_GETTER(geoadv_debug_stamps_chamfer_sym)

@@ -44,7 +44,11 @@ const char *geoadv_last_error(void);
  * distance / index of the nearest xyz2 point for every xyz1 point; dist2/idx2 the converse.
  * Results are bit-identical to the reference CPU op (tf_nndistance.cpp:21-43): unfused fp32
  * arithmetic, lowest index on ties.  n == 0 or m == 0 is accepted (m == 0 gives dist 0 / idx 0,
- * like the CPU loop). */
+ * like the CPU loop).  Non-finite coordinates follow the CPU loop too (`k==0 || d<best`, :33): a
+ * query whose distance to candidate 0 is NaN returns (NaN, 0), a NaN distance to a later
+ * candidate never wins, an infinite minimum returns its lowest index (the payload of a returned
+ * NaN is not specified).  The same holds for geoadv_nn_distance_sym and geoadv_nn_distance_paired
+ * (tests/golden/nn_distance_nonfinite.npz). */
 int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
                        float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
 

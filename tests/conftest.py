@@ -38,6 +38,11 @@ def golden_nn():
 
 
 @pytest.fixture(scope="session")
+def golden_nn_nonfinite():
+    return np.load(os.path.join(GOLDEN, "nn_distance_nonfinite.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_emd():
     return np.load(os.path.join(GOLDEN, "approxmatch.npz"))
 

@@ -241,3 +241,28 @@ def test_paired_grid_search_equals_default(kind, b, n):
     got = ops.nn_distance_paired(adv, x)
     for a, c in zip(ref, got):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("kernel", ["scan", "symmetric", "paired"])
+def test_nn_distance_nonfinite_golden(dev, golden_nn_nonfinite, kernel):
+    """NaN / +-inf coordinates: the reference's own outputs (oracle/make_golden_nonfinite.py; tf_nndistance.cpp:31-40 --
+    candidate 0 always taken, a NaN never wins later) from all three operator kernels: indices exact, distances equal with
+    NaN == NaN.  (The paired search needs n == m.)"""
+    from geometric_adv_amd import ops
+    g = golden_nn_nonfinite
+    ran = 0
+    for name in g["cases"]:
+        x1, x2 = g[f"{name}_xyz1"], g[f"{name}_xyz2"]
+        if kernel == "paired":
+            if x1.shape[1] != x2.shape[1]:
+                continue
+            got = ops.nn_distance_paired(_t(x1, dev), _t(x2, dev))
+        else:
+            got = ops.nn_distance(_t(x1, dev), _t(x2, dev), kernel=kernel)
+        d1, i1, d2, i2 = [t.cpu().numpy() for t in got]
+        assert np.array_equal(i1, g[f"{name}_idx1"]), name
+        assert np.array_equal(i2, g[f"{name}_idx2"]), name
+        assert np.array_equal(d1, g[f"{name}_dist1"], equal_nan=True), name
+        assert np.array_equal(d2, g[f"{name}_dist2"], equal_nan=True), name
+        ran += 1
+    assert ran >= 5

@@ -95,3 +95,18 @@ def test_attack_loop_indices_on_shapes(kind, b, prune):
     h = hist[-1].cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(h[5], (d1.double().mean(1) + d2.double().mean(1)).cpu().numpy(), rtol=2e-6)
     np.testing.assert_allclose(h[4], (e1.double().mean(1) + e2.double().mean(1)).cpu().numpy(), rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("kernel", ["symmetric", "auto"])
+@pytest.mark.parametrize("b,n,m", [(64, 1024, 8192), (1024, 256, 2048), (512, 1024, 1024), (128, 512, 4096), (40, 2048, 8192)])
+def test_symmetric_scan_tie_rule_at_large_launches(oracle, kernel, b, n, m):
+    """Launch shapes large enough for several column stages per workgroup and, below 1025 rows, several column-waves (ADVICE
+    r05: a stage re-split over the column-waves broke 'lowest index wins'): duplicated points give exact ties in every
+    direction; sampled clouds against the pinned oracle, indices and distance bits."""
+    from geometric_adv_amd import ops
+    a, c = make_clouds("duplicates", 41, b, n), make_clouds("duplicates", 42, b, m)
+    got = [t.cpu().numpy() for t in ops.nn_distance(_t(a), _t(c), kernel=kernel)]
+    pick = np.unique(np.r_[0, 1, b // 2, b - 1, np.random.default_rng(43).integers(0, b, 4)])
+    want = oracle.nn_distance(a[pick], c[pick])
+    for g, w in zip(got, want):
+        assert np.array_equal(g[pick], w)

@@ -319,6 +319,79 @@ def test_config4_full_batch_b32_n8192_indices(oracle):
     np.testing.assert_allclose(h[4][sel], a1.mean(1, dtype=np.float64) + a2.mean(1, dtype=np.float64), rtol=1e-5)
 
 
+def _full_size_checks(oracle, at, x, gt, sel, hist, emd):
+    """Sampled clouds of a full-size run against the pinned oracle on the GPU's own clouds: the four index arrays exact, the
+    Chamfer metric rows within 1e-5 of fp64 means of the oracle's distances; status OK, every metric finite."""
+    at.status()
+    s = at.peek()
+    h = hist.cpu().numpy()[-1]
+    assert np.isfinite(hist.cpu().numpy()).all()
+    recon, adv = s["recon"][sel].cpu().numpy(), s["adv"][sel].cpu().numpy()
+    r1, i1, r2, i2 = oracle.nn_distance(recon, gt[sel])
+    assert np.array_equal(s["idx_r1"][sel].cpu().numpy(), i1) and np.array_equal(s["idx_r2"][sel].cpu().numpy(), i2)
+    a1, j1, a2, j2 = oracle.nn_distance(adv, x[sel])
+    assert np.array_equal(s["idx_a1"][sel].cpu().numpy(), j1) and np.array_equal(s["idx_a2"][sel].cpu().numpy(), j2)
+    cham = r1.mean(1, dtype=np.float64) + r2.mean(1, dtype=np.float64)
+    dist = a1.mean(1, dtype=np.float64) + a2.mean(1, dtype=np.float64)
+    np.testing.assert_allclose(h[4][sel], dist, rtol=1e-5)        # input_dist (adv_ae.py:132)
+    np.testing.assert_allclose(h[5][sel], cham, rtol=1e-5)        # loss_ae (adv_ae.py:121)
+    if not emd:
+        np.testing.assert_allclose(h[0][sel], cham, rtol=1e-5)    # loss_adv = loss_ae for the Chamfer attack
+    return s, h, cham
+
+
+def test_config3_full_size_b1024_on_one_gpu(oracle):
+    """configs[3] WHOLE on one GPU (B = 1024 x N = 2048, loss_adv = Chamfer + approx-EMD / N; b*n*m = 2^32 pair weights per level
+    -- past every 32-bit product): two iterations.  4 sampled clouds' indices against the pinned oracle, the input-distance row
+    within 1e-5, the adversarial-loss row = Chamfer (oracle) + match_cost / N of the GPU's own plan on those clouds (the plan
+    held to the CPU op in test_gpu_emd.py), transport-plan properties on one 32-cloud slice, attack_status OK."""
+    import torch
+    from geometric_adv_amd import ops, weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from conftest import cloud
+    b, n = 1024, 2048
+    w = W.synthetic_weights(n, seed=7)
+    ae = PointNetAE(w, n)
+    x, gt = cloud(1013, b, n), cloud(2013, b, n)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=3, num_iterations_thresh=1,
+                                          emd_weight=1.0), ae=ae)
+    at.set_inputs(x, gt, None, 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    hist = torch.empty((2, 6, b), device=ae.device)
+    at.run(0, 2, 1, hist)
+    sel = [0, 333, 800, 1023]
+    s, h, cham = _full_size_checks(oracle, at, x, gt, sel, hist, emd=True)
+    gtd = torch.as_tensor(gt).to(ae.device)
+    sl = slice(992, 1024)                                     # the LAST slice: its offsets are the largest of the batch
+    match = ops.approx_match(s["recon"][sl], gtd[sl])
+    assert (match >= 0).all()
+    assert match.sum(2).max() <= 1.0 + 1e-4 and match.sum(1).max() <= 1.0 + 1e-4
+    total = match.sum((1, 2))
+    assert (total > 0.98 * n).all() and (total <= n * (1 + 1e-5)).all()
+    cost = ops.match_cost(s["recon"][sl], gtd[sl], match).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(h[0][1023], cham[3] + cost[31] / n, rtol=2e-5)      # loss_adv = Chamfer + EMD cost / N
+
+
+def test_config4_full_size_b256_n8192_on_one_gpu(oracle):
+    """configs[4] WHOLE on one GPU (B = 256 x N = 8192, output-space attack; b*n*m = 2^34 pair distances per nn_distance): two
+    iterations, 4 sampled clouds' four index arrays against the pinned oracle on the GPU's own clouds, both Chamfer metric
+    rows within 1e-5, attack_status OK."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from conftest import cloud
+    b, n = 256, 8192
+    w = W.synthetic_weights(n, seed=7)
+    x, gt = cloud(1014, b, n), cloud(2014, b, n)
+    at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=3, num_iterations_thresh=1))
+    at.set_inputs(x, gt, None, 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    hist = torch.empty((2, 6, b), device=at.device)
+    at.run(0, 2, 1, hist)
+    _full_size_checks(oracle, at, x, gt, [0, 100, 201, 255], hist, emd=False)
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2 ...` from a bare shell (no torchrun, WORLD_SIZE unset): the parent spawns the two ranks before
     touching the GPU and relays rank 0's line.  The box has one GPU, so GEOADV_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 with

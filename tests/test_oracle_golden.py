@@ -15,6 +15,23 @@ def test_nn_distance_matches_reference_bit_exact(oracle, golden_nn):
         assert np.array_equal(d2.view(np.uint32), g[f"{name}_dist2"].view(np.uint32)), name
 
 
+def test_nn_distance_nonfinite_inputs_match_reference(oracle, golden_nn_nonfinite):
+    """NaN / +-inf coordinates (oracle/make_golden_nonfinite.py; tf_nndistance.cpp:31-40: candidate 0 is always taken, a NaN
+    distance never wins later): indices exact, distances equal with NaN == NaN (the payload of a NaN is not pinned)."""
+    g = golden_nn_nonfinite
+    for name in g["cases"]:
+        with np.errstate(all="ignore"):
+            d1, i1, d2, i2 = oracle.nn_distance(g[f"{name}_xyz1"], g[f"{name}_xyz2"])
+        assert np.array_equal(i1, g[f"{name}_idx1"]), name
+        assert np.array_equal(i2, g[f"{name}_idx2"]), name
+        assert np.array_equal(d1, g[f"{name}_dist1"], equal_nan=True), name
+        assert np.array_equal(d2, g[f"{name}_dist2"], equal_nan=True), name
+    # the cases are not vacuous: NaN results at index 0, infinite results, and finite results beside them
+    d = np.concatenate([g[f"{n}_dist1"].ravel() for n in g["cases"]])
+    assert np.isnan(d).any() and np.isinf(d).any() and np.isfinite(d).any()
+    assert not g["nan_first_s_idx1"].any() and np.isnan(g["nan_first_s_dist1"]).all()
+
+
 def test_nn_distance_ties_pick_lowest_index(golden_nn):
     g = golden_nn
     # duplicated targets sit at indices 40.. (copies of 0..23): never selected
