@@ -1,5 +1,6 @@
 // Device-side description of the victim auto-encoder (internal to libgeoadv.so).
 #pragma once
+#include <atomic>
 #include "common.h"
 
 namespace geoadv {
@@ -55,6 +56,7 @@ struct FusedAdam {
 
 struct geoadv_ae {
     geoadv::DeviceAE d;
+    mutable std::atomic<int> attack_refs{0};   // live attack handles on this model (they cache a forward in d.enc_arith's layout)
     void *arena;       // one device allocation holding everything above
     size_t arena_bytes;
 };

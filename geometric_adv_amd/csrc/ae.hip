@@ -1,6 +1,7 @@
 // geoadv_ae: device-resident, MFMA-packed weights of the victim auto-encoder + plain forward
 // (AdversaryAutoEncoder.restore_ae_model / reconstruct, src/adversary_autoencoder.py:42-51,75-91).
 #include "ae.h"
+#include <cmath>
 #include "encoder_x3.h"
 #include <math.h>
 #include <string.h>
@@ -63,6 +64,11 @@ static inline float bf16_value(uint16_t h) {
 }
 static inline void x3_pieces(float x, uint16_t (&p)[3]) {
     p[0] = bf16_rne(x);
+    if (std::isfinite(x) && !std::isfinite(bf16_value(p[0]))) {   // |x| within half a bf16 ulp of FLT_MAX: rounding up would be an
+        uint32_t u;                                               // infinity and the remainders NaN -- truncate the first piece
+        memcpy(&u, &x, 4);                                        // instead (the remainders stay exact, the three still carry x)
+        p[0] = (uint16_t)(u >> 16);
+    }
     const float r1 = x - bf16_value(p[0]);
     p[1] = bf16_rne(r1);
     const float r2 = r1 - bf16_value(p[1]);
@@ -260,6 +266,11 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
 extern "C" int geoadv_ae_set_encoder_arith(geoadv_ae *ae, int arith) {
     GA_REQUIRE(ae, "ae_set_encoder_arith: null handle");
     GA_REQUIRE(arith == GEOADV_ENC_ARITH_F32 || arith == GEOADV_ENC_ARITH_BF16X3, "ae_set_encoder_arith: unknown arithmetic %d", arith);
+    // an attack handle caches a forward (pool partials, masks) in the tile layout of the arithmetic it ran under and recomputes in
+    // it: switching under a live handle would make the two disagree -- refused, not silently accepted
+    GA_REQUIRE(arith == ae->d.enc_arith || ae->attack_refs.load() == 0,
+               "ae_set_encoder_arith: %d attack handle(s) hold a forward of this model in its present arithmetic; destroy them first "
+               "(or choose the arithmetic when the model is created)", ae->attack_refs.load());
     ae->d.enc_arith = arith;
     return GEOADV_OK;
 }

@@ -557,6 +557,7 @@ struct geoadv_attack {
     unsigned long long *row64;       // [2][B][n] packed row minima of the symmetric scan's atomic form (small batches, chamfer_sym.h)
     bool row64_filled;               // ... set to all ones by this forward's FC2 launch
     bool cgrad_done;                 // the cached forward's loss launch also produced the Chamfer gradients
+    bool counted = false;            // this handle is counted in ae->attack_refs (geoadv_ae_set_encoder_arith refuses a switch under it)
     bool chamfer_prune;              // nn_distance(adv, x) through the paired grid search (cfg.all_pairs_source_dist = 0, the default)
     int *need_adv[2];                // [8 B] each: clouds the grid search handed back to the all-pairs kernel.  When the search
                                      // shares the all-pairs launch, call k reads [k & 1] (the verdicts of call k - 1) and
@@ -1038,12 +1039,15 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N));
             return GEOADV_OK;
         })) { geoadv_attack_destroy(at); return rc; }
+    ae->attack_refs.fetch_add(1);
+    at->counted = true;
     *out = at;
     return GEOADV_OK;
 }
 
 extern "C" void geoadv_attack_destroy(geoadv_attack *at) {
     if (!at) return;
+    if (at->counted) at->ae->attack_refs.fetch_sub(1);
     for (auto e : at->ev) (void)hipEventDestroy(e);
     (void)hipFree(at->arena);
     delete at;

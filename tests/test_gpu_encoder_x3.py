@@ -128,3 +128,13 @@ def test_arithmetic_selection_api():
     assert lib.geoadv_set_default_encoder_arith(7) != 0
     with pytest.raises(KeyError):
         a.set_encoder_arith("fp16")
+    # a live attack handle caches a forward in the model's arithmetic: a switch under it is refused, the same value accepted
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    at = AdvAE("a", Configuration(batch_size=2, n_points=n, weights=w, num_iterations=2, num_iterations_thresh=1), ae=a)
+    assert lib.geoadv_ae_set_encoder_arith(a.handle, 1) != 0 and a.encoder_arith == "f32"
+    assert lib.geoadv_ae_set_encoder_arith(a.handle, 0) == 0
+    del at
+    import gc
+    gc.collect()
+    a.set_encoder_arith("bf16x3")
+    assert a.encoder_arith == "bf16x3"

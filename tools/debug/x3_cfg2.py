@@ -13,8 +13,8 @@ x, gt = cloud(31, b, n), cloud(32, b, n)
 for arith in ("f32", "bf16x3"):
     conf = Configuration(batch_size=b, n_points=n, weights=w, loss_adv_type="latent", loss_dist_type="chamfer",
                          dist_weight_list=[150.0], num_iterations=30, num_iterations_thresh=25)
-    at = AdvAE("adversary", conf)
-    at.ae.set_encoder_arith(arith)
+    from geometric_adv_amd.autoencoder import PointNetAE
+    at = AdvAE("adversary", conf, ae=PointNetAE(w, n, encoder_arith=arith))
     tz = at.ae.transform(gt)
     ref = at.ae.get_loss_per_pc(gt)
     metrics, adv, recon = at.attack(x, tz, gt, ref, conf)

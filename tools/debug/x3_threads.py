@@ -15,9 +15,9 @@ emd = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 def attack(dense, out, stream=None, arith=None):
     ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
     with ctx:
+        from geometric_adv_amd.autoencoder import PointNetAE
         at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=6, num_iterations_thresh=1,
-                                              emd_weight=emd, emd_dense_levels=dense))
-        at.ae.set_encoder_arith(arith)
+                                              emd_weight=emd, emd_dense_levels=dense), ae=PointNetAE(w, n, encoder_arith=arith))
         at.set_inputs(xs, gs, None, 1.0)
         at.init_pert(None, reset_optimizer=True)
         hist = torch.empty((6, 6, b), device=dev)
