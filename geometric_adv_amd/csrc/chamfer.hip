@@ -222,27 +222,42 @@ __global__ void chamfer_fill_empty_kernel(float *dist, int *idx, size_t count) {
 }
 
 // Non-finite inputs, the reference's rule (tf_nndistance.cpp:31-40): candidate 0 is ALWAYS taken (`k==0 || d<best`) and nothing
-// compares below a NaN, so a query whose distance to candidate 0 is NaN keeps (NaN, 0); a NaN distance to a later candidate never
-// wins.  The scans fold with fminf / integer minima, which already skip NaNs and keep the lowest index of an infinite minimum --
-// what is left is the first case, patched here on the finished outputs of the OPERATOR entry points (one thread per query of
-// either direction; the attack loop's internal launches skip it: a NaN there is a diverged attack whose losses are NaN either way).
-__global__ __launch_bounds__(256) void nn_nonfinite_fix_kernel(int n, int m, const float *xyz1, const float *xyz2, float *dist1,
-                                                               int *idx1, float *dist2, int *idx2) {
-    const int c = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+// compares below a NaN, so a query whose distance to candidate 0 is NaN keeps (NaN, 0), a NaN distance to a later candidate never
+// wins, and an infinite minimum keeps its lowest index.  The fast kernels are written for finite clouds (fminf / integer minima
+// skip NaNs, the grid search sorts points into cells): the OPERATOR entry points therefore finish with this launch -- one
+// workgroup per cloud looks for a non-finite coordinate in either cloud (one pass over 12 (n + m) bytes) and, only if there is
+// one, recomputes both directions of that cloud with the reference's own loop, a thread per query.  (The attack loop's internal
+// launches skip it: a non-finite cloud there is a diverged attack whose losses are NaN either way.)
+__global__ __launch_bounds__(1024) void nn_nonfinite_redo_kernel(int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                                                                 int *idx1, float *dist2, int *idx2) {
+    const int c = blockIdx.x, t = threadIdx.x;
     const float *P = xyz1 + (size_t)c * n * 3, *Q = xyz2 + (size_t)c * m * 3;
-    if (e < n) {
-        const float d0 = sqdist(Q[0], Q[1], Q[2], P[3 * (size_t)e], P[3 * (size_t)e + 1], P[3 * (size_t)e + 2]);
-        if (d0 != d0) { dist1[(size_t)c * n + e] = d0; idx1[(size_t)c * n + e] = 0; }
-    }
-    if (e < m) {
-        const float d0 = sqdist(P[0], P[1], P[2], Q[3 * (size_t)e], Q[3 * (size_t)e + 1], Q[3 * (size_t)e + 2]);
-        if (d0 != d0) { dist2[(size_t)c * m + e] = d0; idx2[(size_t)c * m + e] = 0; }
+    int bad = 0;
+    for (int i = t; i < 3 * n; i += 1024) bad |= !(fabsf(P[i]) <= 3.402823466e38f);
+    for (int i = t; i < 3 * m; i += 1024) bad |= !(fabsf(Q[i]) <= 3.402823466e38f);
+    if (!__syncthreads_or(bad)) return;
+    for (int dir = 0; dir < 2; ++dir) {
+        const float *A = dir ? Q : P, *T = dir ? P : Q;
+        const int na = dir ? m : n, nt = dir ? n : m;
+        float *dist = (dir ? dist2 : dist1) + (size_t)c * na;
+        int *idx = (dir ? idx2 : idx1) + (size_t)c * na;
+        for (int j = t; j < na; j += 1024) {
+            const float x = A[3 * (size_t)j], y = A[3 * (size_t)j + 1], z = A[3 * (size_t)j + 2];
+            float best = sqdist(T[0], T[1], T[2], x, y, z);
+            int bi = 0;
+            for (int k = 1; k < nt; ++k) {
+                const float d = sqdist(T[3 * (size_t)k], T[3 * (size_t)k + 1], T[3 * (size_t)k + 2], x, y, z);
+                if (d < best) { best = d; bi = k; }
+            }
+            dist[j] = best;
+            idx[j] = bi;
+        }
     }
 }
 int launch_nn_nonfinite_fix(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1, int *idx1, float *dist2,
                             int *idx2, hipStream_t stream) {
     if (b <= 0 || n <= 0 || m <= 0) return GEOADV_OK;
-    nn_nonfinite_fix_kernel<<<dim3(cdiv(std::max(n, m), 256), b), 256, 0, stream>>>(n, m, xyz1, xyz2, dist1, idx1, dist2, idx2);
+    nn_nonfinite_redo_kernel<<<b, 1024, 0, stream>>>(n, m, xyz1, xyz2, dist1, idx1, dist2, idx2);
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
 }

@@ -26,6 +26,7 @@
 #include "chamfer_grid.h"
 #include "encoder_jac.h"
 #include "chamfer_sym.h"
+#include "chamfer_mx.h"
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -316,6 +317,59 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     GA_STAMP(0, 7);
 }
 
+// The matrix-pipe-screened form of the same scan (chamfer_mx.h): same grid mapping, same riders, same three ways out for the row
+// minima (final / packed word folded by a 64-bit atomic minimum / one partial per column slice) and two for the column minima.
+template <int NCT>
+__global__ __launch_bounds__(MX_THREADS, 2) void chamfer_mx_kernel(ChamferSymArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];
+    if (grid_rider_block<GR_MAX_N>(a.rider)) return;
+    if (jac_rider_block(a.jac, stage)) return;
+    GA_STAMP(0, 0);
+    const int lin = blockIdx.x - a.rider.blocks;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int per = a.rtiles * a.cslices;
+    const int group = (slot / per) * 8 + xcd, sub = slot % per;
+    if (group >= a.clouds * a.pairs) return;
+    const int rt = sub % a.rtiles, cs = sub / a.rtiles;
+    const int pi = group / a.clouds, c = group % a.clouds;
+    if (!sym_needed(a.need[pi], c)) return;
+    const ChamferPair pr = a.pr[pi];
+    const int n = a.n, m = a.m;
+    const int cp = a.q_clouds > 0 ? (a.pair_base + c) / a.q_clouds : c;
+    const int cq = a.q_clouds > 0 ? (a.pair_base + c) % a.q_clouds : c;
+    MxView v;
+    v.P = pr.p + (size_t)cp * n * 3; v.Q = pr.q + (size_t)cq * m * 3;
+    v.n = n; v.m = m; v.rt = rt; v.cs = cs; v.C = a.C; v.S = a.S;
+    const int rslices = a.cslices;
+    auto out_row = [&](int j, float d, int i) {
+        if (rslices == 1) { pr.dist1[(size_t)c * n + j] = d; pr.idx1[(size_t)c * n + j] = i; }
+        else if (a.row64) atomicMin(&a.row64[((size_t)pi * a.clouds + c) * n + j], sym_pack(d, i));
+        else {
+            const size_t o = (((size_t)pi * a.clouds + c) * rslices + cs) * n + j;
+            a.rowpart_d[o] = d; a.rowpart_i[o] = i;
+        }
+    };
+    auto out_col = [&](int k, float d, int i) {
+        if (a.rtiles == 1) { pr.dist2[(size_t)c * m + k] = d; pr.idx2[(size_t)c * m + k] = i; }
+        else {
+            const size_t o = (((size_t)pi * a.clouds + c) * a.rtiles + rt) * m + k;
+            a.colpart_d[o] = d; a.colpart_i[o] = i;
+        }
+    };
+#ifdef GA_STAMPS
+    unsigned long long clk0_, clk1_;                               // diagnostic build: the shader clock over the scan (s_memtime counts core cycles)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0_)::"memory");
+#endif
+    mx_scan_block<NCT>(v, reinterpret_cast<unsigned *>(stage), out_row, out_col);
+#ifdef GA_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1_)::"memory");
+    if (threadIdx.x == 0 && blockIdx.x < GA_STAMP_BLOCKS) ga_stamps[(2 * GA_STAMP_BLOCKS + blockIdx.x) * 8 + 1] = clk1_ - clk0_;
+    GA_STAMP(0, 6);
+    __syncthreads();                                               // (diagnostic build: stamp 7 = the workgroup's last wave)
+#endif
+    GA_STAMP(0, 7);
+}
+
 // The operator form's second launch: lexicographic (distance, index) minimum over the row partials of the column slices
 // and, for clouds of several row super-tiles, over the column partials.  grid = (cdiv(max(n, m), 256), clouds * pairs).
 __global__ __launch_bounds__(256) void chamfer_sym_merge_kernel(ChamferSymArgs a) {
@@ -343,9 +397,35 @@ __global__ __launch_bounds__(256) void chamfer_sym_merge_kernel(ChamferSymArgs a
 
 // Launch shape of the symmetric scan: how the 8 waves of a workgroup are laid over rows and columns, and how many
 // columns a workgroup takes so that the grid fills the chip (256 / 128 / 64; `groups` = live (pair, cloud) groups).
-struct SymShape { int rw, cw, rtiles, C, S, cslices; };
-static SymShape sym_shape(long groups, int n, int m) {
+struct SymShape { int rw, cw, rtiles, C, S, cslices; bool mx; };
+// GEOADV_CHAMFER_MX=0: the unscreened scan everywhere (A/B runs; read once)
+static bool mx_enabled() {
+    static const bool on = [] { const char *e = getenv("GEOADV_CHAMFER_MX"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// loop: the attack loop's launch (riders may share it).  The screened kernel holds ONE workgroup per CU (256 registers a wave,
+// 100 KB of LDS): the loop's riders -- latency-bound workgroups that hide under the unscreened scan at two workgroups per CU --
+// would queue behind it, and its own serial phases (operands, column finish, uncertified queries: ~9 of ~24 us per 2048 x 256
+// tile) are only amortised when a CU gets several tiles.  Measured (tools/debug/mx_check.py, us per call): 32 x 2048^2 36.6
+// against 40.6 unscreened, 64 x 2048^2 59.9 / 65.2, 32 x 8192^2 327 / 406; 16 x 2048^2 (128-column slices) 29.2 / 27.0.  So:
+// operators from one 256-column tile per CU on, the loop from four.
+static SymShape sym_shape(long groups, int n, int m, bool loop) {
     SymShape s;
+    s.mx = false;
+    if (mx_enabled() && n > 1024 && (long)cdiv(n, MX_ROWS) * cdiv(m, MX_CMAX) * groups >= (loop ? 4 : 1) * (long)kCUs) {
+        // the matrix-pipe-screened kernel (chamfer_mx.h): eight row-waves always, a slice of 256 / 128 / 64 columns per stage so that
+        // the grid covers the chip (same rule as below), several stages per workgroup while two workgroups per CU remain (one is
+        // resident at a time: 256 registers a wave)
+        s.mx = true; s.rw = MX_WAVES; s.cw = 1;
+        s.rtiles = cdiv(n, MX_ROWS);
+        s.C = MX_CMAX;
+        while (s.C > 64 && (long)s.rtiles * cdiv(m, s.C) * groups < kCUs &&
+               (s.C > 128 || (long)s.rtiles * cdiv(m, s.C / 2) * groups <= kCUs)) s.C /= 2;
+        s.S = 1;
+        while (s.S < MX_MAX_STAGES && (long)s.rtiles * cdiv(m, s.C * s.S * 2) * groups >= 2 * kCUs) s.S *= 2;
+        s.cslices = cdiv(m, s.C * s.S);
+        return s;
+    }
     s.rw = n > 1024 ? 8 : n > 512 ? 4 : n > 256 ? 2 : 1;
     s.cw = CS_WAVES / s.rw;
     s.rtiles = cdiv(n, CS_WROWS * s.rw);
@@ -375,22 +455,24 @@ static size_t sym_group_floats(const SymShape &s, int n, int m) {
 // any number of live groups <= pairs * b (fewer live groups = narrower slices = more row partials per group).
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
     size_t per = 0;
-    for (long g = 1; g <= (long)pairs * b; g *= 2) per = std::max(per, sym_group_floats(sym_shape(g, n, m), n, m));
-    per = std::max(per, sym_group_floats(sym_shape((long)pairs * b, n, m), n, m));
+    for (int loop = 0; loop < 2; ++loop) {
+        for (long g = 1; g <= (long)pairs * b; g *= 2) per = std::max(per, sym_group_floats(sym_shape(g, n, m, loop != 0), n, m));
+        per = std::max(per, sym_group_floats(sym_shape((long)pairs * b, n, m, loop != 0), n, m));
+    }
     return (size_t)pairs * b * per + 64;
 }
 
 // Will launch_chamfer_sym_loop fold the row minima into the caller's packed words (SymPartials::row64) at this shape?  (The caller
 // fills them with all ones beforehand only then.)  live_groups: clouds x problems that are not gated off.
 bool chamfer_sym_packs_rows(long live_groups, int n, int m) {
-    const SymShape s = sym_shape(live_groups, n, m);
+    const SymShape s = sym_shape(live_groups, n, m, true);
     return s.rtiles == 1 && s.cslices * s.cw > 8;
 }
 
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
                           int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider = nullptr,
-                          const JacRider *jac = nullptr, SymPartials *defer = nullptr);
+                          const JacRider *jac = nullptr, SymPartials *defer = nullptr, bool loop = false);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream) {
     return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, nullptr, stream);
 }
@@ -399,12 +481,12 @@ int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, fl
 // Jacobian's 8 * b workgroups as well (jac->first_block / blocks are set here); defer (or null): see SymPartials
 int launch_chamfer_sym_loop(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
                             const GridArgs *rider, const JacRider *jac, SymPartials *defer, hipStream_t stream) {
-    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider, jac, defer);
+    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider, jac, defer, true);
 }
 
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
                           int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider, const JacRider *jac,
-                          SymPartials *defer) {
+                          SymPartials *defer, bool loop) {
     unsigned long long *row64 = defer ? defer->row64 : nullptr;
     if (defer) { defer->slices = 1; defer->rowpart_d = nullptr; defer->rowpart_i = nullptr; defer->clouds = b; defer->deferred = false; defer->row64 = nullptr; }
     if (b <= 0 || np <= 0) return GEOADV_OK;
@@ -415,7 +497,7 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     a.n = n; a.m = m; a.clouds = b; a.pairs = np;
     // (a second pair gated by `need1` usually has no work at all -- the grid search answers it -- so it does not count)
     const int np_live = need1 ? 1 : np;
-    const SymShape s = sym_shape((long)b * np_live, n, m);
+    const SymShape s = sym_shape((long)b * np_live, n, m, loop);
     a.rw = s.rw; a.cw = s.cw; a.rtiles = s.rtiles; a.C = s.C; a.S = s.S; a.cslices = s.cslices;
     const int rslices = s.cslices * s.cw;
     const size_t groups = (size_t)np * b;
@@ -427,13 +509,16 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     a.row64 = (defer && row64 && s.rtiles == 1 && rslices > 8) ? row64 : nullptr;
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)std::max(std::max(CS_LDS_BYTES, chamfer_grid_lds_bytes(GR_MAX_N)), JAC_LDS_BYTES)));
+            const int need = (int)std::max(std::max(std::max(CS_LDS_BYTES, MX_LDS_BYTES), chamfer_grid_lds_bytes(GR_MAX_N)), JAC_LDS_BYTES);
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_sym_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, need));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_mx_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, need));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_mx_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, need));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_mx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, need));
             return GEOADV_OK;
         })) return rc;
     unsigned grid = (unsigned)(s.rtiles * s.cslices * 8 * cdiv(b * np, 8));
     a.rider.blocks = 0; a.rider.first_block = 0; a.rider.clouds = 0;
-    size_t scan_lds = CS_LDS_BYTES;
+    size_t scan_lds = s.mx ? MX_LDS_BYTES : CS_LDS_BYTES;
     if (rider) {
         a.rider.g = *rider;
         a.rider.first_block = 0;                           // dispatched first: its latency-bound workgroups start at once
@@ -454,7 +539,10 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
         grid += (unsigned)a.jac.blocks;
         scan_lds = std::max(scan_lds, JAC_LDS_BYTES);
     }
-    chamfer_sym_kernel<<<grid, CS_THREADS, scan_lds, stream>>>(a);
+    if (!s.mx) chamfer_sym_kernel<<<grid, CS_THREADS, scan_lds, stream>>>(a);
+    else if (s.C == 256) chamfer_mx_kernel<8><<<grid, MX_THREADS, scan_lds, stream>>>(a);
+    else if (s.C == 128) chamfer_mx_kernel<4><<<grid, MX_THREADS, scan_lds, stream>>>(a);
+    else chamfer_mx_kernel<2><<<grid, MX_THREADS, scan_lds, stream>>>(a);
     GA_LAUNCH_CHECK();
     if (rslices == 1 && s.rtiles == 1) return GEOADV_OK;  // both sides left the scan final
     if (a.row64) {                                         // the caller's next launch unpacks the folded words on its way in
@@ -497,7 +585,7 @@ using namespace geoadv;
 // Scratch of geoadv_chamfer_matrix for `cnt` pairs processed together, in floats: the four nn_distance outputs of every pair +
 // the symmetric scan's partials at the launch shape `cnt` groups get (fewer groups = narrower column slices = more row partials each).
 static size_t matrix_floats(size_t cnt, int n, int m) {
-    return cnt * 2 * ((size_t)n + m) + cnt * sym_group_floats(sym_shape((long)cnt, n, m), n, m) + 64;
+    return cnt * 2 * ((size_t)n + m) + cnt * sym_group_floats(sym_shape((long)cnt, n, m, false), n, m) + 64;
 }
 
 extern "C" size_t geoadv_chamfer_matrix_workspace_floats(int na, int nb, int n, int m) {
@@ -537,7 +625,11 @@ extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *
 // nn_distance through the symmetric scan as an operator: same outputs as geoadv_nn_distance, bit for bit.
 // The operator launches with exactly b live groups, so its scratch is the partials of THAT shape (the bound over every possible
 // live-group count, chamfer_sym_workspace_floats, is what an attack handle needs: its need flags change the count from call to call).
-static size_t nn_sym_floats(int b, int n, int m) { return (size_t)b * sym_group_floats(sym_shape((long)b, n, m), n, m) + 64; }
+static size_t nn_sym_floats(int b, int n, int m) { return (size_t)b * sym_group_floats(sym_shape((long)b, n, m, false), n, m) + 64; }
+// 1 if geoadv_nn_distance_sym answers this shape with the matrix-pipe-screened kernel (chamfer_mx.h), 0 if with the unscreened scan
+extern "C" int geoadv_nn_distance_sym_is_screened(int b, int n, int m) {
+    return (b > 0 && n > 0 && m > 0 && sym_shape((long)b, n, m, false).mx) ? 1 : 0;
+}
 extern "C" size_t geoadv_nn_distance_sym_workspace_floats(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 64;
     return nn_sym_floats(b, n, m);

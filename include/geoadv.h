@@ -47,8 +47,9 @@ const char *geoadv_last_error(void);
  * like the CPU loop).  Non-finite coordinates follow the CPU loop too (`k==0 || d<best`, :33): a
  * query whose distance to candidate 0 is NaN returns (NaN, 0), a NaN distance to a later
  * candidate never wins, an infinite minimum returns its lowest index (the payload of a returned
- * NaN is not specified).  The same holds for geoadv_nn_distance_sym and geoadv_nn_distance_paired
- * (tests/golden/nn_distance_nonfinite.npz). */
+ * NaN is not specified): a cloud pair with a non-finite coordinate is recomputed by that loop, a
+ * thread per query, in a closing launch of the operator.  The same holds for geoadv_nn_distance_sym
+ * and geoadv_nn_distance_paired (tests/golden/nn_distance_nonfinite.npz). */
 int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
                        float *dist1, int *idx1, float *dist2, int *idx2, void *stream);
 
@@ -57,6 +58,10 @@ int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2
  * geoadv_nn_distance_sym_workspace_floats(b,n,m) floats of caller-owned scratch (row minima per column slice; the caller
  * allocates, as with the temp tensor of tf_approxmatch.cpp:164-170). */
 size_t geoadv_nn_distance_sym_workspace_floats(int b, int n, int m);
+/* 1 if this shape is answered by the matrix-pipe-screened form of the scan (csrc/chamfer_mx.h: approximate distances from one fp16
+ * MFMA per 32 x 32 pairs select, with a rigorous error bound, the few pairs that are then evaluated with the reference's
+ * arithmetic -- same bits out), 0 if by the unscreened scan; GEOADV_CHAMFER_MX=0 in the environment forces the latter. */
+int geoadv_nn_distance_sym_is_screened(int b, int n, int m);
 int geoadv_nn_distance_sym(int b, int n, const float *xyz1, int m, const float *xyz2,
                            float *dist1, int *idx1, float *dist2, int *idx2,
                            float *workspace, size_t workspace_floats, void *stream);

@@ -1,0 +1,107 @@
+"""GPU: the matrix-pipe-screened form of the symmetric Chamfer scan (csrc/chamfer_mx.h).  Approximate distances from fp16 MFMAs only
+SELECT, under a rigorous error bound, the pairs that are then evaluated with the reference's arithmetic (tf_nndistance.cpp:21-43),
+so its outputs must be the reference's bits like every other nn_distance kernel: here against the two-scan kernel (itself pinned to
+the reference's golden vectors) on whole batches and against the pinned C oracle on sampled clouds, on shapes that reach the
+screened kernel (asserted), cloud kinds with exact ties everywhere, clouds far from the origin / tiny / huge (the bound is
+computed from the data), collapsed and non-finite clouds (every pair evaluated exactly)."""
+import numpy as np
+import pytest
+
+from test_gpu_chamfer_shapes import make_clouds, KINDS
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(36, 2048, 2048), (3, 8192, 8192), (10, 2049, 5000), (300, 1500, 300), (260, 1100, 257), (50, 4096, 700)]
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _screened(b, n, m):
+    from geometric_adv_amd import _lib
+    return _lib.lib().geoadv_nn_distance_sym_is_screened(b, n, m) == 1
+
+
+def _same(got, want):
+    import torch
+    for g, w in zip(got, want):
+        if g.dtype.is_floating_point:
+            assert torch.equal(g.view(torch.int32), w.view(torch.int32)) or torch.equal(torch.nan_to_num(g, nan=-1.0), torch.nan_to_num(w, nan=-1.0))
+        else:
+            assert torch.equal(g, w)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("b,n,m", SHAPES)
+def test_screened_scan_equals_two_scan_kernel_and_oracle(oracle, kind, b, n, m):
+    from geometric_adv_amd import ops
+    assert _screened(b, n, m)
+    a, c = make_clouds(kind, 61, b, n), make_clouds(kind, 62, b, m)
+    if kind in ("duplicates", "lattice") and n == m:
+        c = c.copy(); c[:, : n // 2] = a[:, : n // 2]                 # exact zero distances across the two clouds
+    got = ops.nn_distance(_t(a), _t(c), kernel="symmetric")
+    _same(got, ops.nn_distance(_t(a), _t(c), kernel="scan"))
+    pick = [0, b - 1]
+    want = oracle.nn_distance(a[pick], c[pick])
+    for g, w in zip(got, want):
+        assert np.array_equal(g[pick].cpu().numpy(), w)
+
+
+@pytest.mark.parametrize("what", ["far", "far_negative", "tiny", "huge", "anisotropic", "columns_far_from_rows", "paired", "identical_clouds"])
+def test_screened_scan_bound_follows_the_data(what):
+    """The error bound, the scale and the centre come from each workgroup's own rows and columns: translated, rescaled and
+    flattened clouds, a target far from the source, and the attack's own regime (adv = x + a small perturbation; adv == x)."""
+    from geometric_adv_amd import ops
+    b, n = 36, 2048
+    assert _screened(b, n, n)
+    a, c = make_clouds("sphere", 71, b, n), make_clouds("uniform", 72, b, n)
+    f = np.float32
+    if what == "far":
+        a, c = a + f(100.0), c + f(100.0)
+    elif what == "far_negative":
+        a, c = a - f(1e4), c - f(1e4)
+    elif what == "tiny":
+        a, c = a * f(1e-6), c * f(1e-6)
+    elif what == "huge":
+        a, c = a * f(1e6), c * f(1e6)
+    elif what == "anisotropic":
+        s = np.array([1.0, 1e-3, 50.0], np.float32)
+        a, c = a * s, c * s
+    elif what == "columns_far_from_rows":
+        c = c * f(0.01) + f(7.0)
+    elif what == "paired":
+        c = a.copy()
+        a = (a + f(1e-4) * np.random.default_rng(3).standard_normal(a.shape).astype(np.float32)).astype(np.float32)
+    elif what == "identical_clouds":
+        c = a.copy()
+    a, c = a.astype(np.float32), c.astype(np.float32)
+    _same(ops.nn_distance(_t(a), _t(c), kernel="symmetric"), ops.nn_distance(_t(a), _t(c), kernel="scan"))
+
+
+@pytest.mark.parametrize("what", ["collapsed", "collapsed_rows", "nan", "inf", "overflowing"])
+def test_screened_scan_degenerate_and_nonfinite_clouds(what):
+    """A cloud collapsed to a point, and NaN / inf / squares-overflow coordinates in some clouds of the batch: no screen is possible
+    there (every pair is evaluated exactly); the other clouds of the same launch are unaffected."""
+    from geometric_adv_amd import ops
+    b, n = 36, 2048
+    a, c = make_clouds("uniform", 81, b, n), make_clouds("uniform", 82, b, n)
+    rng = np.random.default_rng(5)
+    if what == "collapsed":
+        a[3] = a[3, :1]; c[3] = a[3, :1]
+        a[7] = np.float32(0.25); c[7] = np.float32(0.25)
+    elif what == "collapsed_rows":
+        a[5] = a[5, 17:18]
+    elif what == "nan":
+        a[2, rng.integers(1, n, 5), rng.integers(0, 3, 5)] = np.nan
+        c[2, rng.integers(1, n, 5), rng.integers(0, 3, 5)] = np.nan
+        c[9, 0, 1] = np.nan
+    elif what == "inf":
+        a[4, rng.integers(0, n, 3), 0] = np.inf
+        c[4, rng.integers(0, n, 3), 0] = np.inf
+        c[11, 100, 2] = -np.inf
+    elif what == "overflowing":
+        a[6] *= np.float32(1e25); c[6] *= np.float32(1e25)        # squared distances overflow to inf in the reference's arithmetic
+    with np.errstate(all="ignore"):
+        _same(ops.nn_distance(_t(a), _t(c), kernel="symmetric"), ops.nn_distance(_t(a), _t(c), kernel="scan"))
