@@ -84,7 +84,7 @@ __device__ __forceinline__ unsigned mx_med3(unsigned a, unsigned b, unsigned c) 
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ unsigned mx_dpp_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ unsigned mx_dpp_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float mx_dpp_xor1f(float v) { return __uint_as_float(mx_dpp_xor1(__float_as_uint(v))); }
 
 __device__ __forceinline__ float mx_sqdist(float tx, float ty, float tz, float qx, float qy, float qz) {
@@ -357,11 +357,17 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
                 const int ch = (int)(M1 & MX_ROW_IDMASK);
                 float bd = INFINITY;
                 int bi = INT_MAX;
+                {
+                    float dd[NCT / 2];
 #pragma unroll
-                for (int c2 = 0; c2 < NCT; c2 += 2) {
-                    const int k = sbeg + (c2 + half) * 32 + ch;
-                    const float4 q = colv[k];
-                    mx_take(mx_sqdist(q.x, q.y, q.z, tp.x, tp.y, tp.z), k, bd, bi);
+                    for (int c2 = 0; c2 < NCT / 2; ++c2) {
+                        const float4 q = colv[sbeg + (2 * c2 + half) * 32 + ch];
+                        dd[c2] = mx_sqdist(q.x, q.y, q.z, tp.x, tp.y, tp.z);
+                        bd = fminf(bd, dd[c2]);                    // (NaN distances skipped; all NaN or inf: bd stays inf)
+                    }
+#pragma unroll
+                    for (int c2 = NCT / 2 - 1; c2 >= 0; --c2)      // descending: the last hit kept is the lowest column
+                        bi = dd[c2] == bd ? sbeg + (2 * c2 + half) * 32 + ch : bi;
                 }
                 {
                     const float od = mx_dpp_xor1f(bd);

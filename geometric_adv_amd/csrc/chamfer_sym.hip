@@ -27,6 +27,7 @@
 #include "encoder_jac.h"
 #include "chamfer_sym.h"
 #include "chamfer_mx.h"
+#include <atomic>
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -398,21 +399,22 @@ __global__ __launch_bounds__(256) void chamfer_sym_merge_kernel(ChamferSymArgs a
 // Launch shape of the symmetric scan: how the 8 waves of a workgroup are laid over rows and columns, and how many
 // columns a workgroup takes so that the grid fills the chip (256 / 128 / 64; `groups` = live (pair, cloud) groups).
 struct SymShape { int rw, cw, rtiles, C, S, cslices; bool mx; };
-// GEOADV_CHAMFER_MX=0: the unscreened scan everywhere (A/B runs; read once)
-static bool mx_enabled() {
-    static const bool on = [] { const char *e = getenv("GEOADV_CHAMFER_MX"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// process-wide switch (geoadv_set_chamfer_screen): 0 = the unscreened scan everywhere -- the parity tests' second opinion and the
+// A/B tools.  Scratch sizes never depend on it (they cover both kernels), so it may change between calls.
+static std::atomic<int> g_mx_on{1};
+static bool mx_enabled() { return g_mx_on.load() != 0; }
 // loop: the attack loop's launch (riders may share it).  The screened kernel holds ONE workgroup per CU (256 registers a wave,
 // 100 KB of LDS): the loop's riders -- latency-bound workgroups that hide under the unscreened scan at two workgroups per CU --
 // would queue behind it, and its own serial phases (operands, column finish, uncertified queries: ~9 of ~24 us per 2048 x 256
-// tile) are only amortised when a CU gets several tiles.  Measured (tools/debug/mx_check.py, us per call): 32 x 2048^2 36.6
-// against 40.6 unscreened, 64 x 2048^2 59.9 / 65.2, 32 x 8192^2 327 / 406; 16 x 2048^2 (128-column slices) 29.2 / 27.0.  So:
-// operators from one 256-column tile per CU on, the loop from four.
-static SymShape sym_shape(long groups, int n, int m, bool loop) {
+// tile) are only amortised when a CU gets several tiles.  Measured (tools/debug/mx_check.py, us per operator call, alternating in
+// one process): 32 x 2048^2 33.8 against 37.0 unscreened, 64 x 2048^2 55.8 / 60.6, 128 x 2048^2 93.2 / 106.8, 32 x 8192^2
+// 317 / 385; with 128-column slices (16 x 2048^2) 29.2 / 27.0; inside the B = 32 all-pairs loop with the Jacobian rider behind it
+// (two tiles per CU, tools/debug/mx_loop_ab.py) 159.1 us per iteration against 150.1.  So: operators from one 256-column tile
+// per CU on, the loop from four.
+static SymShape sym_shape(long groups, int n, int m, bool loop, bool screen) {
     SymShape s;
     s.mx = false;
-    if (mx_enabled() && n > 1024 && (long)cdiv(n, MX_ROWS) * cdiv(m, MX_CMAX) * groups >= (loop ? 4 : 1) * (long)kCUs) {
+    if (screen && n > 1024 && (long)cdiv(n, MX_ROWS) * cdiv(m, MX_CMAX) * groups >= (loop ? 4 : 1) * (long)kCUs) {
         // the matrix-pipe-screened kernel (chamfer_mx.h): eight row-waves always, a slice of 256 / 128 / 64 columns per stage so that
         // the grid covers the chip (same rule as below), several stages per workgroup while two workgroups per CU remain (one is
         // resident at a time: 256 registers a wave)
@@ -455,9 +457,9 @@ static size_t sym_group_floats(const SymShape &s, int n, int m) {
 // any number of live groups <= pairs * b (fewer live groups = narrower slices = more row partials per group).
 size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
     size_t per = 0;
-    for (int loop = 0; loop < 2; ++loop) {
-        for (long g = 1; g <= (long)pairs * b; g *= 2) per = std::max(per, sym_group_floats(sym_shape(g, n, m, loop != 0), n, m));
-        per = std::max(per, sym_group_floats(sym_shape((long)pairs * b, n, m, loop != 0), n, m));
+    for (int v = 0; v < 4; ++v) {                            // (either launch rule, screened or not: the switch may change later)
+        for (long g = 1; g <= (long)pairs * b; g *= 2) per = std::max(per, sym_group_floats(sym_shape(g, n, m, (v & 1) != 0, (v & 2) != 0), n, m));
+        per = std::max(per, sym_group_floats(sym_shape((long)pairs * b, n, m, (v & 1) != 0, (v & 2) != 0), n, m));
     }
     return (size_t)pairs * b * per + 64;
 }
@@ -465,7 +467,7 @@ size_t chamfer_sym_workspace_floats(int pairs, int b, int n, int m) {
 // Will launch_chamfer_sym_loop fold the row minima into the caller's packed words (SymPartials::row64) at this shape?  (The caller
 // fills them with all ones beforehand only then.)  live_groups: clouds x problems that are not gated off.
 bool chamfer_sym_packs_rows(long live_groups, int n, int m) {
-    const SymShape s = sym_shape(live_groups, n, m, true);
+    const SymShape s = sym_shape(live_groups, n, m, true, mx_enabled());
     return s.rtiles == 1 && s.cslices * s.cw > 8;
 }
 
@@ -497,7 +499,7 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     a.n = n; a.m = m; a.clouds = b; a.pairs = np;
     // (a second pair gated by `need1` usually has no work at all -- the grid search answers it -- so it does not count)
     const int np_live = need1 ? 1 : np;
-    const SymShape s = sym_shape((long)b * np_live, n, m, loop);
+    const SymShape s = sym_shape((long)b * np_live, n, m, loop, mx_enabled());
     a.rw = s.rw; a.cw = s.cw; a.rtiles = s.rtiles; a.C = s.C; a.S = s.S; a.cslices = s.cslices;
     const int rslices = s.cslices * s.cw;
     const size_t groups = (size_t)np * b;
@@ -585,7 +587,8 @@ using namespace geoadv;
 // Scratch of geoadv_chamfer_matrix for `cnt` pairs processed together, in floats: the four nn_distance outputs of every pair +
 // the symmetric scan's partials at the launch shape `cnt` groups get (fewer groups = narrower column slices = more row partials each).
 static size_t matrix_floats(size_t cnt, int n, int m) {
-    return cnt * 2 * ((size_t)n + m) + cnt * sym_group_floats(sym_shape((long)cnt, n, m, false), n, m) + 64;
+    return cnt * 2 * ((size_t)n + m) + cnt * std::max(sym_group_floats(sym_shape((long)cnt, n, m, false, false), n, m),
+                                                      sym_group_floats(sym_shape((long)cnt, n, m, false, true), n, m)) + 64;
 }
 
 extern "C" size_t geoadv_chamfer_matrix_workspace_floats(int na, int nb, int n, int m) {
@@ -625,10 +628,13 @@ extern "C" int geoadv_chamfer_matrix(int na, int nb, int n, int m, const float *
 // nn_distance through the symmetric scan as an operator: same outputs as geoadv_nn_distance, bit for bit.
 // The operator launches with exactly b live groups, so its scratch is the partials of THAT shape (the bound over every possible
 // live-group count, chamfer_sym_workspace_floats, is what an attack handle needs: its need flags change the count from call to call).
-static size_t nn_sym_floats(int b, int n, int m) { return (size_t)b * sym_group_floats(sym_shape((long)b, n, m, false), n, m) + 64; }
+static size_t nn_sym_floats(int b, int n, int m) {
+    return (size_t)b * std::max(sym_group_floats(sym_shape((long)b, n, m, false, false), n, m), sym_group_floats(sym_shape((long)b, n, m, false, true), n, m)) + 64;
+}
+extern "C" int geoadv_set_chamfer_screen(int on) { return g_mx_on.exchange(on ? 1 : 0); }
 // 1 if geoadv_nn_distance_sym answers this shape with the matrix-pipe-screened kernel (chamfer_mx.h), 0 if with the unscreened scan
 extern "C" int geoadv_nn_distance_sym_is_screened(int b, int n, int m) {
-    return (b > 0 && n > 0 && m > 0 && sym_shape((long)b, n, m, false).mx) ? 1 : 0;
+    return (b > 0 && n > 0 && m > 0 && sym_shape((long)b, n, m, false, mx_enabled()).mx) ? 1 : 0;
 }
 extern "C" size_t geoadv_nn_distance_sym_workspace_floats(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 64;

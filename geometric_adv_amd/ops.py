@@ -74,6 +74,12 @@ def nn_distance(xyz1, xyz2, kernel="auto"):
     return dist1, idx1, dist2, idx2
 
 
+def chamfer_screen(on):
+    """Process-wide switch of the matrix-pipe-screened symmetric scan (csrc/chamfer_mx.h; default on): False = the unscreened scan
+    everywhere.  Same results either way, bit for bit; returns the previous setting."""
+    return bool(_lib.lib().geoadv_set_chamfer_screen(1 if on else 0))
+
+
 def nn_distance_sym(xyz1, xyz2):
     """nn_distance with every pair distance evaluated ONCE for both directions (the attack loop's kernel): identical outputs,
     bit for bit; both clouds need at least one point."""

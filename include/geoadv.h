@@ -60,8 +60,10 @@ int geoadv_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2
 size_t geoadv_nn_distance_sym_workspace_floats(int b, int n, int m);
 /* 1 if this shape is answered by the matrix-pipe-screened form of the scan (csrc/chamfer_mx.h: approximate distances from one fp16
  * MFMA per 32 x 32 pairs select, with a rigorous error bound, the few pairs that are then evaluated with the reference's
- * arithmetic -- same bits out), 0 if by the unscreened scan; GEOADV_CHAMFER_MX=0 in the environment forces the latter. */
+ * arithmetic -- same bits out), 0 if by the unscreened scan.  geoadv_set_chamfer_screen(0) turns the screened kernel off for the
+ * whole process (operators, scorer, attack and training loops; returns the previous setting): the tests' second opinion. */
 int geoadv_nn_distance_sym_is_screened(int b, int n, int m);
+int geoadv_set_chamfer_screen(int on);
 int geoadv_nn_distance_sym(int b, int n, const float *xyz1, int m, const float *xyz2,
                            float *dist1, int *idx1, float *dist2, int *idx2,
                            float *workspace, size_t workspace_floats, void *stream);

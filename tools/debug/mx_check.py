@@ -1,5 +1,5 @@
 """The matrix-pipe-screened symmetric scan (csrc/chamfer_mx.h) against the two-scan kernel, bit for bit, on many shapes and cloud
-kinds, and its time against the unscreened scan (GEOADV_CHAMFER_MX=0 in a child process).   python tools/debug/mx_check.py [time]"""
+kinds, and its time against the unscreened scan (ops.chamfer_screen).   python tools/debug/mx_check.py [time]"""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -10,24 +10,28 @@ from geometric_adv_amd import ops
 
 
 def timing():
+    """us per call (kernel + the operators' closing launch + torch's allocations), screened and unscreened ALTERNATING on the same
+    tensors: minimum of five windows each."""
     out = {}
-    for b, n, m in ((32, 2048, 2048), (64, 2048, 2048), (8, 2048, 2048), (32, 8192, 8192), (4, 2048, 2048), (16, 2048, 2048)):
+    for b, n, m in ((32, 2048, 2048), (64, 2048, 2048), (128, 2048, 2048), (8, 2048, 2048), (32, 8192, 8192), (16, 2048, 2048), (50, 2048, 2048)):
         x = torch.rand((b, n, 3), device="cuda") - 0.5
         y = torch.rand((b, m, 3), device="cuda") - 0.5
-        for _ in range(5):
-            ops.nn_distance_sym(x, y)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 40 if n <= 2048 else 10
-        best = 1e9
-        for _ in range(3):
-            e0.record()
-            for _ in range(reps):
+        best = {True: 1e9, False: 1e9}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for w in range(6):
+            for on in (True, False):
+                ops.chamfer_screen(on)
                 ops.nn_distance_sym(x, y)
-            e1.record(); torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) / reps)
-        out["%dx%dx%d" % (b, n, m)] = round(best * 1e3, 1)
-    print(json.dumps({"mx": os.environ.get("GEOADV_CHAMFER_MX", "1"), "us_per_call_incl_torch_alloc": out}))
+                e0.record()
+                for _ in range(reps):
+                    ops.nn_distance_sym(x, y)
+                e1.record(); torch.cuda.synchronize()
+                if w:
+                    best[on] = min(best[on], e0.elapsed_time(e1) / reps)
+        out["%dx%dx%d" % (b, n, m)] = {"screened": round(best[True] * 1e3, 1), "unscreened": round(best[False] * 1e3, 1)}
+    ops.chamfer_screen(True)
+    print(json.dumps({"us_per_call_incl_torch_alloc": out}))
 
 
 def check():
@@ -69,12 +73,6 @@ def check():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "time":
-        timing()
-    else:
-        bad = check()
-        sys.stdout.flush()
-        for mx in ("1", "0"):
-            env = dict(os.environ, GEOADV_CHAMFER_MX=mx)
-            subprocess.run([sys.executable, os.path.abspath(__file__), "time"], env=env)
-        sys.exit(1 if bad else 0)
+    bad = check() if "notest" not in sys.argv else 0
+    timing()
+    sys.exit(1 if bad else 0)
