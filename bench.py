@@ -40,7 +40,7 @@ X3_PRODUCTS = 6                           # bf16 piece products per fp32 product
 PEAK_ENCODER_X3_TFLOPS = PEAK_MFMA_BF16_TFLOPS / X3_PRODUCTS     # algorithmic fp32 TFLOP/s the bf16 pipe can deliver in that form
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
-PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r05_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
+PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r06_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 SWEEP_BATCHES = (16, 8, 4)                 # what a rank of the strong-scaling leg runs at 2 / 4 / 8 GPUs: timed in THIS run (small_batch_sweep)
 
@@ -669,7 +669,9 @@ def _full_size_ms(dev, b, n, emd_weight, warm=2, iters=3):
 
 
 KNN_CANDIDATES_PER_QUERY = 110      # measured by tools/debug/knn_diag.py on uniform clouds of 2048 points (knn row)
-PMC_CHAMFER_8192 = os.path.join(ROOT, "profiles", "r05_pmc_chamfer_n8192.json")
+PMC_CHAMFER_8192 = os.path.join(ROOT, "profiles", "r06_pmc_chamfer_n8192.json")
+MX_MFMA_CYC, MX_MIN_CYC, MX_MIN_PER_PAIR = 32.0, 4.75, 1.19     # screened scan: one 32x32x16 fp16 MFMA (8 passes) per 1024 pairs; min-class VALU
+                                                                  # instructions (4.75 issue cycles, profiles/r01_probe_valu_v2.json) per pair: 0.5 row + 0.69 column
 
 
 def config4_leg(dev):
@@ -697,16 +699,28 @@ def config4_leg(dev):
             at.profile(False)
             ch_ms = br["chamfer_fwd"]
             alg = 20.0 * b * (n + n)
-            traffic, note = pmc_file_traffic(PMC_CHAMFER_8192, ("chamfer_sym_kernel", "chamfer_sym_merge_kernel"), ("chamfer_sym.hip",))
+            from geometric_adv_amd import _lib
+            screened = _lib.lib().geoadv_nn_distance_sym_is_screened(b // 4, n, n) == 1     # (the loop's rule, four tiles per CU = the operator's rule at a quarter of the batch)
+            traffic, note = pmc_file_traffic(PMC_CHAMFER_8192, ("chamfer_mx_kernel<8>" if screened else "chamfer_sym_kernel", "chamfer_sym_merge_kernel"),
+                                             ("chamfer_sym.hip", "chamfer_mx.h"))
             pairs = 2.0 * b * n * n
             bound_ms = (pairs / 2) / 64.0 * 8 * VALU_CYC / (SIMDS * CLOCK_HZ) * 1e3     # one distance evaluation serves both directions
+            # the screened kernel's own issue bound: per 64 pairs 1/16 of an MFMA and 1.19 min-class VALU instructions
+            bound_mx_ms = (pairs / 2) / 64.0 * (MX_MFMA_CYC / 16.0 + MX_MIN_PER_PAIR * MX_MIN_CYC) / (SIMDS * CLOCK_HZ) * 1e3
             out["encoder_fwd"] = {"avg_launch_ms": enc_ms, "frac_of_fp32_mfma_peak": enc_frac}
             out["kernel_ms_per_iteration"] = br
-            out["roofline_chamfer"] = {"bound": "valu issue", "kernel": "chamfer_sym_kernel + chamfer_sym_merge_kernel: nn_distance(recon, target) at N = 8192 "
-                                       "(the paired search for nn_distance(adv, x) in a launch of its own at this size)",
+            out["roofline_chamfer"] = {"bound": "valu issue", "kernel": ("chamfer_mx_kernel<8> (matrix-pipe-screened scan, csrc/chamfer_mx.h)" if screened else "chamfer_sym_kernel") +
+                                       " + chamfer_sym_merge_kernel: nn_distance(recon, target) at N = 8192 (the paired search for nn_distance(adv, x) in a "
+                                       "launch of its own at this size)", "screened": screened,
                                        "scan_plus_finish_class_ms": ch_ms, "achieved_Tpair_per_s": pairs / (ch_ms * 1e-3) / 1e12,
-                                       "issue_bound_ms": bound_ms, "frac": bound_ms / ch_ms,
-                                       "bound_note": "8 fp32 VALU instructions per distance, every distance evaluated once for both directions",
+                                       "issue_bound_ms": bound_mx_ms if screened else bound_ms, "frac": (bound_mx_ms if screened else bound_ms) / ch_ms,
+                                       "unscreened_issue_bound_ms": bound_ms, "equivalent_unscreened_frac": bound_ms / ch_ms,
+                                       "bound_note": "screened: approximate distances from one fp16 MFMA per 32 x 32 pairs (32 pipe cycles) and 1.19 min-class "
+                                                     "VALU instructions per pair (4.75 issue cycles each) -- the work this kernel does on EVERY pair; the exact "
+                                                     "evaluations of the selected ~3 % are overhead against it.  `equivalent_unscreened_frac`: the unscreened "
+                                                     "scan's bound (8 fp32 VALU instructions per distance, once for both directions) over the same time: an "
+                                                     "equivalent rate, not a roofline fraction" if screened else
+                                                     "8 fp32 VALU instructions per distance, every distance evaluated once for both directions",
                                        "algorithmic_bytes_per_launch": alg, "traffic": traffic, "traffic_source": note,
                                        "traffic_over_algorithmic": (traffic / alg) if traffic else None}
         del at

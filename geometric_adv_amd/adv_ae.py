@@ -25,7 +25,7 @@ class Configuration:
                  max_point_dist_weight=0.0, num_iterations=500, num_iterations_thresh=400,
                  learning_rate=0.01, ae_name="autoencoder", emd_weight=0.0, verbose=False, batch_slots=1,
                  chamfer_prune=True, emd_reference_weights=False, recompute_backward=False, separate_adam=False,
-                 chamfer_kernel="auto", encoder_backward="auto", emd_dense_levels=False, encoder_arith=None):
+                 chamfer_kernel="auto", encoder_backward="auto", emd_dense_levels=False, encoder_arith=None, loss_in_scan=True):
         self.batch_size = int(batch_size)
         self.n_input = [int(n_points), 3]
         self.n_output = [int(n_points), 3]
@@ -62,6 +62,7 @@ class Configuration:
         if encoder_backward not in ENCODER_BACKWARDS:
             raise ValueError("encoder_backward must be one of %s" % sorted(ENCODER_BACKWARDS))
         self.encoder_backward = encoder_backward             # "auto", "masked" (back-propagate dz) or "jacobian" (pool Jacobian)
+        self.loss_in_scan = bool(loss_in_scan)               # False: the loss + gradient pass always as a launch of its own
 
 
 CHAMFER_KERNELS = {"auto": 0, "two_scan": 1, "symmetric": 2}
@@ -73,7 +74,7 @@ class _AttackConfig(C.Structure):
                 ("max_point_pert_weight", C.c_float), ("max_point_dist_weight", C.c_float),
                 ("learning_rate", C.c_float), ("emd_weight", C.c_float), ("all_pairs_source_dist", C.c_int),
                 ("emd_weight_mode", C.c_int), ("recompute_backward", C.c_int), ("encoder_backward", C.c_int),
-                ("separate_adam", C.c_int), ("chamfer_kernel", C.c_int)]
+                ("separate_adam", C.c_int), ("chamfer_kernel", C.c_int), ("loss_in_scan", C.c_int)]
 
 
 PROF_NAMES = ["encoder_fwd", "decoder_fwd", "chamfer_fwd", "loss_grad", "decoder_bwd", "encoder_bwd", "adam"]
@@ -100,7 +101,7 @@ class AdvAE:
                             {True: 0, "pinned": 0, False: 1, "always": 2}[getattr(c, "chamfer_prune", True)], (1 if getattr(c, "emd_reference_weights", False) else 0) | (0x100 if getattr(c, "emd_dense_levels", False) else 0),
                             1 if getattr(c, "recompute_backward", False) else 0, ENCODER_BACKWARDS[getattr(c, "encoder_backward", "auto")],
                             1 if getattr(c, "separate_adam", False) else 0,
-                            CHAMFER_KERNELS[getattr(c, "chamfer_kernel", "auto")])
+                            CHAMFER_KERNELS[getattr(c, "chamfer_kernel", "auto")], 0 if getattr(c, "loss_in_scan", True) else 1)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_attack_create(C.byref(self._h), self.ae.handle, C.byref(cfg)), "attack_create")

@@ -13,6 +13,8 @@
 #include "chamfer_grid.h"
 #include "encoder_jac.h"
 #include "decoder_tail.h"
+#define LC_STAMP(K, I) GA_STAMP(K, I)
+#include "loss_cgrad.h"
 #include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
@@ -59,196 +61,6 @@ int launch_encoder_bwd(const DeviceAE &A, int b, const float *adv, const int *cr
                        const int *zcnt, const float *dz, const int *dense_flag, float *g_enc, const unsigned *masks,
                        hipStream_t stream);
 
-// ------------------------------------------------------------------------------------------
-// Per-cloud losses + metrics history + keep-best.  grid = clouds, 256 threads.
-// ------------------------------------------------------------------------------------------
-struct LossArgs {
-    int n;                         // points per cloud (n_input == n_output)
-    int loss_adv_type, loss_dist_type;
-    float mp_pert_w, mp_dist_w;
-    const float *r1, *r2, *a1, *a2;   // [B][n] squared NN distances (recon->gt, gt->recon, adv->x, x->adv)
-    const float *pert;                // [B][n][3]
-    const float *z, *tz;              // [B][128]
-    const float *w;                   // [B] dist_weight
-    const float *emd_cost;            // [B] match_cost(recon, gt) or null
-    float emd_weight;                 // loss_adv += emd_weight * emd_cost / n  (build-defined)
-    float *losses;                    // [8][B]: loss_adv, loss_dist, loss_pert, loss_max|max_dist, input_dist, loss_ae, loss_max(pert), max_dist
-    int *jstar;                       // [B] argmax_j a1 (first), [B] argmax_n |pert_n|^2 (first)
-    float *dz_latent;                 // [B][128] d loss_adv / d z in latent mode (else untouched)
-    float *hist;                      // [6][B] slot of this iteration or null
-    int keep;                         // 1: take part in the keep-best update
-    float *best_err;                  // [B]
-    float *best_metrics;              // [B][4]
-    const float *adv, *recon;         // [B][n][3]
-    float *best_adv, *best_recon;     // [B][n][3]
-    // the symmetric scan's row minima still in one partial per column slice (chamfer_sym.h; slices <= 1: r1 / a1 are final):
-    // r1 of every cloud, a1 of the clouds the all-pairs kernel computed (a1_all, or their `a1_need` flags).  This block forms
-    // the minima on its way in and leaves them in r1 / a1 (mutable here for that reason).
-    SymPartials part;
-    const int *a1_need; int a1_all;
-    float *r1_out, *a1_out;
-};
-
-// One pass for everything: 5 sums and 2 (max, lowest index) pairs per thread, reduced across the
-// wave with shuffles and across the 4 waves through LDS -- two barriers instead of ~60.
-struct CloudRed { float s1, s2, s3, s4, sp, ma, mp; int ja, jp; };
-
-__device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-}
-
-__device__ __forceinline__ CloudRed block_reduce(CloudRed r, float (*shf)[8], int (*shi)[2]) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        r.s1 += __shfl_xor(r.s1, off); r.s2 += __shfl_xor(r.s2, off); r.s3 += __shfl_xor(r.s3, off);
-        r.s4 += __shfl_xor(r.s4, off); r.sp += __shfl_xor(r.sp, off);
-        argmax_merge(r.ma, r.ja, __shfl_xor(r.ma, off), __shfl_xor(r.ja, off));
-        argmax_merge(r.mp, r.jp, __shfl_xor(r.mp, off), __shfl_xor(r.jp, off));
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        shf[wave][0] = r.s1; shf[wave][1] = r.s2; shf[wave][2] = r.s3; shf[wave][3] = r.s4; shf[wave][4] = r.sp;
-        shf[wave][5] = r.ma; shf[wave][6] = r.mp; shi[wave][0] = r.ja; shi[wave][1] = r.jp;
-    }
-    __syncthreads();
-    CloudRed t;
-    t.s1 = ((shf[0][0] + shf[1][0]) + shf[2][0]) + shf[3][0];
-    t.s2 = ((shf[0][1] + shf[1][1]) + shf[2][1]) + shf[3][1];
-    t.s3 = ((shf[0][2] + shf[1][2]) + shf[2][2]) + shf[3][2];
-    t.s4 = ((shf[0][3] + shf[1][3]) + shf[2][3]) + shf[3][3];
-    t.sp = ((shf[0][4] + shf[1][4]) + shf[2][4]) + shf[3][4];
-    t.ma = shf[0][5]; t.ja = shi[0][0]; t.mp = shf[0][6]; t.jp = shi[0][1];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        argmax_merge(t.ma, t.ja, shf[w][5], shi[w][0]);
-        argmax_merge(t.mp, t.jp, shf[w][6], shi[w][1]);
-    }
-    return t;
-}
-
-__device__ __forceinline__ float wave4_sum128(float v, float *sh2) {   // sum over threads 0..127 (others pass 0)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0) sh2[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh2[0] + sh2[1];
-}
-
-constexpr int LOSS_PRE_MAX_N = 2048;           // deferred row partials exist for clouds of one row super-tile only (chamfer_sym.hip)
-
-// The symmetric scan's row partials of cloud b folded by ALL threads of the workgroup (nthreads; one pass at n = 2048 on 512)
-// into LDS -- m1 = r1, m3 = a1 (only where the all-pairs kernel computed it) -- and left in r1 / a1 for later readers; the
-// caller puts a workgroup barrier between this and loss_metrics_body, which then sums them in its own fixed order.
-__device__ __forceinline__ void loss_premerge(const LossArgs &a, const int b, const int B, const int nthreads, float *m1, float *m3) {
-    const int n = a.n;
-    const bool part3 = a.a1_all || (a.a1_need && sym_needed(a.a1_need, b));
-    const size_t sl = (size_t)a.part.slices * n, o = (size_t)b * n;
-    const float *p1 = a.part.rowpart_d + (size_t)b * sl, *p3 = a.part.rowpart_d + ((size_t)B + b) * sl;
-    const unsigned long long *w1 = a.part.row64 + o, *w3 = a.part.row64 + (size_t)B * n + o;      // packed form (small batches)
-    for (int j = threadIdx.x; j < n; j += nthreads) {
-        float v1, v3 = 0.f;
-        if (a.part.row64) {
-            v1 = __uint_as_float((unsigned)(w1[j] >> 32));
-            if (part3) v3 = __uint_as_float((unsigned)(w3[j] >> 32));
-        } else {
-            v1 = sym_merge_min(p1 + j, a.part.slices, n);
-            if (part3) v3 = sym_merge_min(p3 + j, a.part.slices, n);
-        }
-        m1[j] = v1; a.r1_out[o + j] = v1;
-        if (part3) { m3[j] = v3; a.a1_out[o + j] = v3; }
-    }
-}
-
-// cloud b of B; executed by threads 0..255 of the workgroup (whole waves beyond that may have exited).  m1 / m3: loss_premerge's
-// LDS arrays when a.part.deferred (else unused)
-__device__ __forceinline__ void loss_metrics_body(const LossArgs &a, const int b, const int B, const float *m1 = nullptr, const float *m3 = nullptr) {
-    __shared__ float shf[4][8];
-    __shared__ int shi[4][2];
-    __shared__ float sh2[4];
-    __shared__ int take;
-    const int t = threadIdx.x, n = a.n;
-    const size_t o = (size_t)b * n;
-    CloudRed r;
-    r.s1 = r.s2 = r.s3 = r.s4 = r.sp = 0.f;
-    r.ma = r.mp = -1.f;
-    r.ja = r.jp = INT_MAX;
-    const bool part1 = a.part.deferred;                                                  // (uniform)
-    const bool part3 = part1 && (a.a1_all || (a.a1_need && sym_needed(a.a1_need, b)));
-    constexpr int U = 4;                                  // points per thread and pass: all 7 * U loads requested first
-    for (int j0 = t; j0 < n; j0 += U * 256) {             // (same order of accumulation as one point per pass)
-        float v1[U], v2[U], v3[U], v4[U], vx[U], vy[U], vz[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * 256 < n ? j0 + u * 256 : t;
-            v1[u] = part1 ? m1[j] : a.r1[o + j];
-            v3[u] = part3 ? m3[j] : a.a1[o + j];
-            v2[u] = a.r2[o + j]; v4[u] = a.a2[o + j];
-            vx[u] = a.pert[(o + j) * 3]; vy[u] = a.pert[(o + j) * 3 + 1]; vz[u] = a.pert[(o + j) * 3 + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * 256;
-            if (j >= n) continue;
-            r.s1 += v1[u]; r.s2 += v2[u];
-            const float d = v3[u];
-            r.s3 += d; r.s4 += v4[u];
-            if (d > r.ma) { r.ma = d; r.ja = j; }
-            const float p2 = (vx[u] * vx[u] + vy[u] * vy[u]) + vz[u] * vz[u];
-            r.sp += p2;
-            if (p2 > r.mp) { r.mp = p2; r.jp = j; }
-        }
-    }
-    r = block_reduce(r, shf, shi);
-    float ma = r.ma, mp = r.mp;
-    const int ja = r.ja, jp = r.jp;
-    const float inv_n = 1.0f / (float)n;
-    const float loss_ae = r.s1 * inv_n + r.s2 * inv_n;                                 // adv_ae.py:121
-    const float input_dist = r.s3 * inv_n + r.s4 * inv_n;                              // adv_ae.py:132, max :133
-    const float pert_sq = r.sp;                                                        // adversary.py:41-44
-    const float loss_pert = sqrtf(pert_sq), loss_max = sqrtf(mp);                      // adversary.py:47,50
-    float loss_adv = loss_ae;
-    if (a.emd_cost) loss_adv = loss_ae + a.emd_weight * (a.emd_cost[b] * inv_n);
-    if (a.loss_adv_type == GEOADV_LOSS_ADV_LATENT) {                                   // adv_ae.py:107-116
-        float d = 0.f;
-        if (t < 128) { d = a.z[(size_t)b * 128 + t] - a.tz[(size_t)b * 128 + t]; }
-        const float nsq = wave4_sum128(d * d, sh2);
-        loss_adv = sqrtf(nsq);
-        if (t < 128) a.dz_latent[(size_t)b * 128 + t] = d / loss_adv;
-    }
-    float loss_dist;
-    if (a.loss_dist_type == GEOADV_LOSS_DIST_PERT)
-        loss_dist = a.mp_pert_w > 0.f ? loss_pert + a.mp_pert_w * loss_max : loss_pert;   // adv_ae.py:93-97
-    else
-        loss_dist = a.mp_dist_w > 0.f ? input_dist + a.mp_dist_w * ma : input_dist;       // adv_ae.py:98-102
-    const float fourth = a.loss_dist_type == GEOADV_LOSS_DIST_PERT ? loss_max : ma;       // adv_ae.py:204-207
-    if (t == 0) {
-        a.losses[0 * B + b] = loss_adv; a.losses[1 * B + b] = loss_dist; a.losses[2 * B + b] = loss_pert;
-        a.losses[3 * B + b] = fourth;   a.losses[4 * B + b] = input_dist; a.losses[5 * B + b] = loss_ae;
-        a.losses[6 * B + b] = loss_max; a.losses[7 * B + b] = ma;
-        a.jstar[b] = ja; a.jstar[B + b] = jp;
-        if (a.hist) {
-            a.hist[0 * B + b] = loss_adv; a.hist[1 * B + b] = loss_dist; a.hist[2 * B + b] = loss_pert;
-            a.hist[3 * B + b] = fourth;   a.hist[4 * B + b] = input_dist; a.hist[5 * B + b] = loss_ae;
-        }
-        int tk = 0;
-        if (a.keep && loss_ae < a.best_err[b]) {                                          // adv_ae.py:239 (strict)
-            tk = 1;
-            a.best_err[b] = loss_ae;
-            a.best_metrics[b * 4 + 0] = loss_adv; a.best_metrics[b * 4 + 1] = loss_dist;
-            a.best_metrics[b * 4 + 2] = input_dist; a.best_metrics[b * 4 + 3] = loss_ae;   // nre = this / ref, at read-out
-        }
-        take = tk;
-    }
-    __syncthreads();
-    if (take) {
-        const size_t base = o * 3;
-        for (int e = t; e < 3 * n; e += 256) {
-            a.best_adv[base + e] = a.adv[base + e];
-            a.best_recon[base + e] = a.recon[base + e];
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void loss_metrics_kernel(LossArgs a) { loss_metrics_body(a, blockIdx.x, gridDim.x); }
 
 // chamfer_dist = reduce_mean(dist1, axis=1) + reduce_mean(dist2, axis=1) (get_dists_per_point.py:75, prepare_indices_for_attack.py:114)
@@ -277,9 +89,6 @@ __global__ __launch_bounds__(256) void chamfer_per_pc_kernel(int n, int m, const
 // accumulation as chamfer.hip (tf_nndistance.cpp:130-163): own term, then scatter terms in
 // ascending index.  grid = (clouds, problems).
 // ------------------------------------------------------------------------------------------
-struct CGradArgs { CGradProblem pr[2]; int n, P; };
-constexpr int CGA_THREADS = 512;
-
 __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     const CGradProblem pr = a.pr[blockIdx.y];
@@ -297,164 +106,19 @@ __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_kernel(CGradA
     chamfer_grad_side<true, CGA_THREADS>(s, lds, a.P);
 }
 
-// Fast variant for the loop (n*24 B of LDS must fit): instead of sorting, every scatter term is
-// added to its target point as a 64-bit FIXED-POINT number (2^-44 resolution) with LDS integer
-// atomics.  Integer addition commutes, so the result is independent of the arrival order --
-// deterministic run to run like the sorted form -- and the sum is exact to 6e-14 absolute (tighter
-// than the CPU op's sequential fp32 sum, from which it differs by normal fp32 rounding only).
-// The bit-exact-vs-CPU sorted form stays behind the public NnDistanceGrad op (chamfer.hip).
-constexpr double CG_FX = 17592186044416.0;          // 2^44
-constexpr int CG_FX_MAX_N = 5000;                   // 3 * 8 B * n <= 120 KB: one workgroup holds the accumulators of a whole cloud
-constexpr int CG_FX_MAX_N_PLANE = 15000;            // larger clouds: H = 2 or 3 workgroups per (cloud, problem), each owning a
-                                                    // contiguous range of the receiving points (config 4: n = 8192, H = 2)
-inline int cgrad_fx_parts(int n) { return (n + CG_FX_MAX_N - 1) / CG_FX_MAX_N; }
-inline int cgrad_fx_range(int n) { return (n + cgrad_fx_parts(n) - 1) / cgrad_fx_parts(n); }
-inline size_t cgrad_fx_lds_bytes(int n) { return sizeof(unsigned long long) * 3 * (size_t)cgrad_fx_range(n); }
-
-// part h of H: this workgroup owns the receiving points [j_lo, j_hi); it scans ALL scatter sources and keeps those that land there
-__device__ __forceinline__ void cgrad_fx_body(const CGradArgs &a, const int pi, const int b, const int h, const int H) {
-    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
-    unsigned long long *acc = reinterpret_cast<unsigned long long *>(lds);     // [n][3]
-    const CGradProblem pr = a.pr[pi];
-    const int n = a.n;
-    const float wb = pr.w ? pr.w[b] : 1.0f;
-    const float gd = wb * (1.0f / (float)n);
-    const float g2 = gd * 2;
-    const float *p = pr.p + (size_t)b * n * 3, *q = pr.q + (size_t)b * n * 3;
-    const int *i1 = pr.idx1 + (size_t)b * n, *i2 = pr.idx2 + (size_t)b * n;
-    const bool part = (pr.part_d || pr.part_w) && (!pr.part_need || sym_needed(pr.part_need, b));          // (uniform)
-    const float *pd = pr.part_d + (size_t)b * pr.part_slices * n;
-    const int *pi_ = pr.part_i + (size_t)b * pr.part_slices * n;
-    const unsigned long long *pw = pr.part_w + (size_t)b * n;
-    const int js = (pr.jstar && pr.extra_w > 0.f) ? pr.jstar[b] : -1;
-    const int range = (n + H - 1) / H;
-    const int j_lo = h * range, j_hi = min(n, j_lo + range);
-    constexpr int U = 4;
-    // row partials of the symmetric scan: this workgroup's own points' matches are folded FIRST (their loads run beside the
-    // scatter phase below) when one pass covers them (n <= 2048 on 512 threads: always, where partials exist)
-    const bool pre = part && (j_hi - j_lo) <= U * CGA_THREADS;
-    int mpre[U];
-    if (pre && pr.part_w) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j_lo + threadIdx.x + u * CGA_THREADS;
-            mpre[u] = j < j_hi ? (int)(unsigned)pw[j] : 0;
-        }
-    } else if (pre) {
-        int sl[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j_lo + threadIdx.x + u * CGA_THREADS;
-            sl[u] = 0;
-            if (j < j_hi) (void)sym_merge_pick(pd + j, pr.part_slices, n, sl[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j_lo + threadIdx.x + u * CGA_THREADS;
-            mpre[u] = j < j_hi ? pi_[(size_t)sl[u] * n + j] : 0;
-        }
-    }
-    if (pre) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j_lo + threadIdx.x + u * CGA_THREADS;
-            if (j < j_hi) pr.idx1_out[(size_t)b * n + j] = mpre[u];
-        }
-    }
-    for (int e = threadIdx.x; e < 3 * (j_hi - j_lo); e += CGA_THREADS) acc[e] = 0ull;
-    __syncthreads();
-    GA_STAMP(1, 1);
-    // Four points per thread and pass, index loads first, then all the dependent gathers: the launch is latency-bound
-    // (one workgroup per cloud, problem and part), and a loop of "load index, gather, add" pays two global round trips per point.
-    for (int k0 = threadIdx.x; k0 < n; k0 += U * CGA_THREADS) {
-        int jj[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) jj[u] = k0 + u * CGA_THREADS < n ? i2[k0 + u * CGA_THREADS] : -1;   // other point k matched our point j
-        float qv[U][3], pv[U][3];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool mine = jj[u] >= j_lo && jj[u] < j_hi;
-            const int k = mine ? k0 + u * CGA_THREADS : 0, j = mine ? jj[u] : 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { qv[u][c] = q[3 * k + c]; pv[u][c] = p[3 * j + c]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (jj[u] < j_lo || jj[u] >= j_hi) continue;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float t = g2 * (qv[u][c] - pv[u][c]);
-                const long long f = __double2ll_rn((double)t * CG_FX);
-                atomicAdd(&acc[3 * (jj[u] - j_lo) + c], (unsigned long long)f);
-            }
-        }
-    }
-    __syncthreads();
-    GA_STAMP(1, 2);
-    for (int j0 = j_lo + threadIdx.x; j0 < j_hi; j0 += U * CGA_THREADS) {
-        int mj[U];
-        if (pre) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) mj[u] = mpre[u];
-        } else if (part) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                mj[u] = 0;
-                if (j0 + u * CGA_THREADS < j_hi) {
-                    float d_;
-                    if (pr.part_w) mj[u] = (int)(unsigned)pw[j0 + u * CGA_THREADS];
-                    else sym_merge_slices(pd + j0 + u * CGA_THREADS, pi_ + j0 + u * CGA_THREADS, pr.part_slices, n, d_, mj[u]);
-                    pr.idx1_out[(size_t)b * n + j0 + u * CGA_THREADS] = mj[u];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) mj[u] = j0 + u * CGA_THREADS < j_hi ? i1[j0 + u * CGA_THREADS] : 0;
-        }
-        float qv[U][3], pv[U][3];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * CGA_THREADS < j_hi ? j0 + u * CGA_THREADS : j_lo;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { pv[u][c] = p[3 * j + c]; qv[u][c] = q[3 * mj[u] + c]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * CGA_THREADS;
-            if (j >= j_hi) continue;
-            const float gown = (j == js ? gd + wb * pr.extra_w : gd) * 2;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float own = gown * (pv[u][c] - qv[u][c]);
-                const float sc = (float)((double)(long long)acc[3 * (j - j_lo) + c] * (1.0 / CG_FX));
-                pr.g[((size_t)b * n + j) * 3 + c] = own - sc;
-            }
-        }
-    }
-}
-
 // grid = (clouds, problems * H)
 __global__ __launch_bounds__(CGA_THREADS) void chamfer_grad_attack_fx_kernel(CGradArgs a, int H) {
-    cgrad_fx_body(a, blockIdx.y / H, blockIdx.x, blockIdx.y % H, H);
+    extern __shared__ __attribute__((aligned(16))) unsigned fx_lds[];
+    cgrad_fx_body(a, blockIdx.y / H, blockIdx.x, blockIdx.y % H, H, fx_lds);
 }
 
 // The per-cloud losses and the Chamfer gradients read the same NN results and do not depend on each other (unless the
 // max-distance term is on: it needs the arg-max the loss pass finds), so one launch does both: grid = (clouds,
 // 1 + problems * H); row 0 = losses / metrics / keep-best (its four upper waves leave at once), rows 1.. = gradients.
 __global__ __launch_bounds__(CGA_THREADS) void loss_cgrad_kernel(LossArgs la, CGradArgs ca, int H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lc_lds[];
     GA_STAMP(0, 0);
-    if (blockIdx.y == 0) {
-        __shared__ float m1[LOSS_PRE_MAX_N], m3[LOSS_PRE_MAX_N];
-        if (la.part.deferred) {                            // (uniform) all eight waves fold the row partials, four sum them
-            loss_premerge(la, blockIdx.x, gridDim.x, CGA_THREADS, m1, m3);
-            __syncthreads();
-        }
-        if (threadIdx.x < 256) loss_metrics_body(la, blockIdx.x, gridDim.x, m1, m3);
-    } else {
-        GA_STAMP(1, 0);
-        cgrad_fx_body(ca, (blockIdx.y - 1) / H, blockIdx.x, (blockIdx.y - 1) % H, H);
-        GA_STAMP(1, 7);
-    }
+    loss_cgrad_block(la, ca, H, blockIdx.x, gridDim.x, blockIdx.y, lc_lds);
     GA_STAMP(0, 7);
 }
 
@@ -534,6 +198,16 @@ __global__ void best_metrics_kernel(int B, const float *best_metrics, const floa
     out[b * 5 + 4] = best_err[b];                                // adv_ae.py:249
 }
 
+// Workgroup i of a launch runs on XCD i % 8 (each XCD has its own L2): what the loss riders' same-XCD hand-off relies on.
+// Recorded, not assumed: 64 workgroups store the XCC id they ran on.
+__global__ void xcd_probe_kernel(unsigned *out) {
+    if (threadIdx.x == 0) {
+        unsigned v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        out[blockIdx.x] = v & 0xf;
+    }
+}
+
 }  // namespace geoadv
 
 using namespace geoadv;
@@ -570,6 +244,10 @@ struct geoadv_attack {
     bool jac_valid;                  // ... computed for the cached forward
     unsigned *tail_ready;            // [B] + 1 word: hand-off flags of the merged tail + dense launch, the spin-timeout word
     unsigned tail_epoch;             // (host) steps launched so far: the flag value of the current one
+    unsigned *loss_done;             // [B] arrival counters of the loss riders in the symmetric scan's launch (loss_cgrad.h), never reset
+    unsigned loss_target;            // (host) arrivals a cloud's counter has seen after the launches so far
+    bool host_loss;                  // loss + gradient workgroups ride in the scan's launch (cfg.loss_in_scan, and the device deals
+                                     // workgroup i to XCD i % 8: checked once at creation)
     int cus;                         // compute units of THIS device (hipDeviceAttributeMultiprocessorCount at create): the merged tail +
                                      // dense launch spins on in-launch flags and needs all its workgroups resident at once
     bool chamfer_sym;
@@ -727,6 +405,44 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         if (int rc = launch_encoder_jac(A, B, jargs, st)) return rc;
         at->jac_valid = true;
     }
+    // arguments of the loss / metrics / keep-best pass and of the two Chamfer gradients, for row minima that arrive as `p` says
+    auto fill_loss = [&](const SymPartials &p, LossArgs &la, CGradArgs &ca, int &np) {
+        la.n = n; la.loss_adv_type = at->cfg.loss_adv_type; la.loss_dist_type = at->cfg.loss_dist_type;
+        la.mp_pert_w = at->cfg.max_point_pert_weight; la.mp_dist_w = at->cfg.max_point_dist_weight;
+        la.r1 = at->r1; la.r2 = at->r2; la.a1 = at->a1; la.a2 = at->a2; la.pert = at->pert;
+        la.z = at->fs.z; la.tz = at->tz; la.w = at->w; la.losses = at->losses; la.jstar = at->jstar;
+        la.emd_cost = at->emd_temp ? at->emd_cost : nullptr; la.emd_weight = at->cfg.emd_weight;
+        la.dz_latent = at->dz; la.hist = hist_slot; la.keep = keep; la.best_err = at->best_err;
+        la.best_metrics = at->best_metrics; la.adv = at->adv; la.recon = at->recon;
+        la.best_adv = at->best_adv; la.best_recon = at->best_recon;
+        la.part = p; la.a1_need = pruned ? need_scan : nullptr; la.a1_all = pruned ? 0 : 1; la.r1_out = at->r1; la.a1_out = at->a1;
+        // the Chamfer gradients the next step starts with ride in the same launch (see loss_cgrad_kernel)
+        np = 0;
+        if (adv_chamfer) {
+            ca.pr[np] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
+            if (p.deferred) {
+                ca.pr[np].part_d = p.rowpart_d; ca.pr[np].part_i = p.rowpart_i; ca.pr[np].part_slices = p.slices;
+                ca.pr[np].part_need = nullptr; ca.pr[np].idx1_out = at->ir1; ca.pr[np].part_w = p.row64;
+            }
+            ++np;
+        }
+        if (dist_chamfer) {
+            ca.pr[np] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, 0.f};
+            if (p.deferred) {                             // pair 1's partials follow pair 0's B clouds
+                const size_t off = (size_t)B * p.slices * n;
+                ca.pr[np].part_d = p.rowpart_d + off; ca.pr[np].part_i = p.rowpart_i + off; ca.pr[np].part_slices = p.slices;
+                ca.pr[np].part_need = pruned ? need_scan : nullptr; ca.pr[np].idx1_out = at->ia1;
+                ca.pr[np].part_w = p.row64 ? p.row64 + (size_t)B * n : nullptr;
+            }
+            ++np;
+        }
+        ca.n = n; ca.P = 0;
+    };
+    struct LossCtx { void (*fill)(void *, const SymPartials &, LossArgs &, CGradArgs &, int &); void *self; };
+    LossCtx lctx{[](void *f, const SymPartials &p, LossArgs &la, CGradArgs &ca, int &np) { (*static_cast<decltype(fill_loss) *>(f))(p, la, ca, np); }, &fill_loss};
+    LossRider lr;
+    lr.blocks = 0; lr.patch = nullptr; lr.ctx = nullptr;
+    bool want_host = false, hosted = false;
     {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
         if (at->chamfer_sym) {   // one distance evaluation per pair serves both directions
@@ -735,10 +451,25 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
             const GridArgs rider{at->adv, at->x, at->a1, at->ia1, at->a2, at->ia2, n, need_new, need_scan, call, at->x_box};
             JacRider jr;
             jr.j = jargs; jr.A = A; jr.first_block = 0; jr.blocks = 0; jr.raise_prio = 0;
+            // The loss + gradient workgroups as the last riders of this launch (loss_cgrad.h) where it can host them: they wait for
+            // their cloud's workgroups through a counter instead of a kernel boundary.  (Not with the EMD term: its launch lies between.)
+            if (at->host_loss && merge_in_loss && !at->emd_temp) {
+                lr.H = cgrad_fx_parts(n); lr.rows = 1 + 2 * lr.H; lr.done = at->loss_done; lr.target = at->loss_target;
+                lr.spin_timeout = reinterpret_cast<int *>(at->tail_ready + B);
+                lr.ctx = &lctx;
+                lr.patch = [](LossRider &r, const SymPartials &p, void *c) {
+                    LossCtx &x = *static_cast<LossCtx *>(c);
+                    int np_ = 0;
+                    x.fill(x.self, p, r.la, r.ca, np_);
+                };
+                want_host = true;
+            }
             // the row minima leave the scan as one (distance, index) partial per column slice; when the loss launch below is the
             // fused one with both Chamfer gradients inside, it merges them on its way in (no second Chamfer launch)
             if (int rc = launch_chamfer_sym_loop(pairs, 2, B, n, n, at->sym_ws, pruned ? need_scan : nullptr, rides_scan ? &rider : nullptr,
-                                                 jac_rides ? &jr : nullptr, merge_in_loss ? &part : nullptr, st)) return rc;
+                                                 jac_rides ? &jr : nullptr, merge_in_loss ? &part : nullptr, st, want_host ? &lr : nullptr)) return rc;
+            hosted = want_host && lr.blocks > 0;
+            if (hosted) { at->loss_target = lr.target; at->cgrad_done = true; }
         } else {
             ChamferScan all[4] = {sc_recon[0], sc_recon[1], sc_adv[0], sc_adv[1]};
             if (pruned) all[2].need = all[3].need = need_scan;         // only the clouds the grid search handed back
@@ -749,44 +480,16 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);   // needs only its cost and d cost / d recon, so the plan itself is never stored
         if (int rc = geoadv_emd_cost_grad1_mode(at->cfg.emd_weight_mode, B, n, n, at->recon, at->gt, at->emd_cost, at->emd_g1, at->emd_temp, st)) return rc;
     }
-    {
+    if (!hosted) {
         ProfScope ps(at, GEOADV_PROF_LOSS_GRAD, st);
         LossArgs la;
-        la.n = n; la.loss_adv_type = at->cfg.loss_adv_type; la.loss_dist_type = at->cfg.loss_dist_type;
-        la.mp_pert_w = at->cfg.max_point_pert_weight; la.mp_dist_w = at->cfg.max_point_dist_weight;
-        la.r1 = at->r1; la.r2 = at->r2; la.a1 = at->a1; la.a2 = at->a2; la.pert = at->pert;
-        la.z = at->fs.z; la.tz = at->tz; la.w = at->w; la.losses = at->losses; la.jstar = at->jstar;
-        la.emd_cost = at->emd_temp ? at->emd_cost : nullptr; la.emd_weight = at->cfg.emd_weight;
-        la.dz_latent = at->dz; la.hist = hist_slot; la.keep = keep; la.best_err = at->best_err;
-        la.best_metrics = at->best_metrics; la.adv = at->adv; la.recon = at->recon;
-        la.best_adv = at->best_adv; la.best_recon = at->best_recon;
-        la.part = part; la.a1_need = pruned ? need_scan : nullptr; la.a1_all = pruned ? 0 : 1; la.r1_out = at->r1; la.a1_out = at->a1;
-        // the Chamfer gradients the next step starts with ride in the same launch (see loss_cgrad_kernel)
         CGradArgs ca;
         int np = 0;
-        if (adv_chamfer) {
-            ca.pr[np] = CGradProblem{at->recon, at->gt, at->ir1, at->ir2, at->g_recon, nullptr, nullptr, 0.f};
-            if (part.deferred) {
-                ca.pr[np].part_d = part.rowpart_d; ca.pr[np].part_i = part.rowpart_i; ca.pr[np].part_slices = part.slices;
-                ca.pr[np].part_need = nullptr; ca.pr[np].idx1_out = at->ir1; ca.pr[np].part_w = part.row64;
-            }
-            ++np;
-        }
-        if (dist_chamfer) {
-            ca.pr[np] = CGradProblem{at->adv, at->x, at->ia1, at->ia2, at->g_dist, at->w, at->jstar, 0.f};
-            if (part.deferred) {                          // pair 1's partials follow pair 0's B clouds
-                const size_t off = (size_t)B * part.slices * n;
-                ca.pr[np].part_d = part.rowpart_d + off; ca.pr[np].part_i = part.rowpart_i + off; ca.pr[np].part_slices = part.slices;
-                ca.pr[np].part_need = pruned ? need_scan : nullptr; ca.pr[np].idx1_out = at->ia1;
-                ca.pr[np].part_w = part.row64 ? part.row64 + (size_t)B * n : nullptr;
-            }
-            ++np;
-        }
+        fill_loss(part, la, ca, np);
         at->cgrad_done = false;
         if (loss_fused) {
-            ca.n = n; ca.P = 0;
             const int H = cgrad_fx_parts(n);
-            loss_cgrad_kernel<<<dim3(B, 1 + np * H), CGA_THREADS, cgrad_fx_lds_bytes(n), st>>>(la, ca, H);
+            loss_cgrad_kernel<<<dim3(B, 1 + np * H), CGA_THREADS, loss_cgrad_lds_bytes(n), st>>>(la, ca, H);
             at->cgrad_done = true;
         } else {
             loss_metrics_kernel<<<B, 256, 0, st>>>(la);
@@ -993,6 +696,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
     at->jac_valid = false;
     at->tail_ready = reinterpret_cast<unsigned *>(take(4 * (B + 1)));      // (the arena is zeroed above)
     at->tail_epoch = 0;
+    at->loss_done = reinterpret_cast<unsigned *>(take(4 * (size_t)B));
+    at->loss_target = 0;
     {
         int dev = 0, cus = 0;                               // unknown => 0: always the two plain launches
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) at->cus = cus;
@@ -1039,6 +744,19 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 24 * CG_FX_MAX_N));
             return GEOADV_OK;
         })) { geoadv_attack_destroy(at); return rc; }
+    at->host_loss = false;
+    if (cfg->loss_in_scan == 0 && at->chamfer_sym) {           // does this device deal workgroup i to XCD i % 8?
+        unsigned *d = reinterpret_cast<unsigned *>(at->sym_ws), h[64];
+        xcd_probe_kernel<<<64, 64>>>(d);
+        if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            bool ok = true;
+            for (int i = 8; i < 64; ++i) ok = ok && h[i] == h[i & 7];
+            for (int i = 0; i < 8; ++i)
+                for (int j = 0; j < i; ++j) ok = ok && h[i] != h[j];
+            at->host_loss = ok;
+        }
+        (void)hipGetLastError();
+    }
     ae->attack_refs.fetch_add(1);
     at->counted = true;
     *out = at;

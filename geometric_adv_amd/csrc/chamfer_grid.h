@@ -305,7 +305,7 @@ __device__ __forceinline__ void grid_nn_block(const GridArgs &a, const int cloud
 // so block g of the rider serves cloud (g / 64) * 8 + g % 8 and its (direction, slice) unit (g / 8) % 8: the eight workgroups of a
 // cloud have equal g % 8, i.e. ONE XCD, whose L2 then fetches the cloud's 49 KB once (dealt cloud-major, all eight XCDs fetched every
 // cloud: 12.6 of the scan launch's 16.7 MB of counted reads at B = 32).  blocks = 64 * ceil(clouds / 8); units of absent clouds leave.
-struct GridRider { GridArgs g; int first_block, blocks, clouds; };
+struct GridRider { GridArgs g; int first_block, blocks, clouds; unsigned *done; };   // done: null, or per-cloud arrival counters (loss_cgrad.h: LossRider)
 inline int grid_rider_blocks(int clouds) { return 8 * 2 * GR_QSPLIT * ((clouds + 7) / 8); }
 template <int MAXN>
 __device__ __forceinline__ bool grid_rider_block(const GridRider &r) {   // true: this workgroup belonged to the rider and is done
@@ -319,6 +319,11 @@ __device__ __forceinline__ bool grid_rider_block(const GridRider &r) {   // true
             GA_STAMP(1, 0);
             grid_nn_block<MAXN>(r.g, cloud, unit / GR_QSPLIT, unit % GR_QSPLIT);
             GA_STAMP(1, 7);
+            if (r.done) {                                  // (the search leaves its block uniformly: every thread arrives here)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(r.done + cloud, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     return true;

@@ -95,7 +95,12 @@ bool chamfer_sym_packs_rows(long live_groups, int n, int m);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream);
 struct GridArgs;
 struct JacRider;
+struct LossRider;
+// loss (or null): the loop's loss + gradient workgroups as the LAST riders of the launch (loss_cgrad.h; first_block / blocks /
+// target are set here).  Returns with loss->blocks == 0 when the launch could not host them (the caller then launches them itself).
 int launch_chamfer_sym_loop(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
-                            const GridArgs *rider, const JacRider *jac, SymPartials *defer, hipStream_t stream);
+                            const GridArgs *rider, const JacRider *jac, SymPartials *defer, hipStream_t stream, LossRider *loss = nullptr);
+// can the symmetric scan's launch of this shape host the loss riders?  (the unscreened kernel, one row super-tile, whole groups of 8 clouds)
+bool chamfer_sym_hosts_loss(long live_groups, int b, int n, int m);
 
 }  // namespace geoadv

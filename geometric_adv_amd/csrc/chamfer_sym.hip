@@ -27,6 +27,7 @@
 #include "encoder_jac.h"
 #include "chamfer_sym.h"
 #include "chamfer_mx.h"
+#include "loss_cgrad.h"
 #include <atomic>
 #include <limits.h>
 #include <math.h>
@@ -52,6 +53,7 @@ struct ChamferSymArgs {
                                // its 8 flags is set (a workgroup of the paired grid search, chamfer_grid.hip, gave up)
     GridRider rider;           // the attack loop: the paired grid search of (adv, source) as extra workgroups of the scan launch
     JacRider jac;              // ... and the encoder's pool Jacobian (encoder_jac.h): needed by the NEXT step's backward only
+    LossRider loss;            // ... and the loop's loss + gradient workgroups (loss_cgrad.h), which wait for their cloud's scan and search
 };
 
 constexpr int CS_THREADS = 512;               // 8 waves
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     extern __shared__ __attribute__((aligned(16))) float stage[];
     if (grid_rider_block<GR_MAX_N>(a.rider)) return;
     if (jac_rider_block(a.jac, stage)) return;
+    if (loss_rider_block(a.loss, reinterpret_cast<unsigned *>(stage))) return;
     GA_STAMP(0, 0);
     const int lin = blockIdx.x - a.rider.blocks;           // (the search's workgroups come first); XCD-aware mapping, see chamfer_scan_kernel
     const int xcd = lin & 7, slot = lin >> 3;
@@ -112,7 +115,10 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
     if (group >= a.clouds * a.pairs) return;
     const int rt = sub % a.rtiles, cs = sub / a.rtiles;    // row super-tile, column slice
     const int pi = group / a.clouds, c = group % a.clouds;
-    if (!sym_needed(a.need[pi], c)) return;
+    if (!sym_needed(a.need[pi], c)) {                      // (a gated-off cloud still counts in: the loss riders expect every workgroup)
+        if (a.loss.blocks) loss_rider_arrive(a.loss.done, c);
+        return;
+    }
     const ChamferPair pr = a.pr[pi];
     const int n = a.n, m = a.m;
     const int cp = a.q_clouds > 0 ? (a.pair_base + c) / a.q_clouds : c;
@@ -315,6 +321,7 @@ __global__ __launch_bounds__(CS_THREADS, 4) void chamfer_sym_kernel(ChamferSymAr
             }
         }
     }
+    if (a.loss.blocks) loss_rider_arrive(a.loss.done, c);
     GA_STAMP(0, 7);
 }
 
@@ -474,7 +481,7 @@ bool chamfer_sym_packs_rows(long live_groups, int n, int m) {
 // pairs: up to 2 problems with identical (n, m).  Requires n >= 1, m >= 1.
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
                           int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider = nullptr,
-                          const JacRider *jac = nullptr, SymPartials *defer = nullptr, bool loop = false);
+                          const JacRider *jac = nullptr, SymPartials *defer = nullptr, bool loop = false, LossRider *loss = nullptr);
 int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, hipStream_t stream) {
     return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, nullptr, stream);
 }
@@ -482,13 +489,18 @@ int launch_chamfer_sym(const ChamferPair *pairs, int np, int b, int n, int m, fl
 // rider (rider->n <= GR_MAX_N): the paired grid search as 8 * b extra workgroups of the scan launch; jac (or null): the pool
 // Jacobian's 8 * b workgroups as well (jac->first_block / blocks are set here); defer (or null): see SymPartials
 int launch_chamfer_sym_loop(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, const int *need1,
-                            const GridArgs *rider, const JacRider *jac, SymPartials *defer, hipStream_t stream) {
-    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider, jac, defer, true);
+                            const GridArgs *rider, const JacRider *jac, SymPartials *defer, hipStream_t stream, LossRider *loss) {
+    return launch_chamfer_sym_ex(pairs, np, b, n, m, workspace, 0, 0, need1, stream, rider, jac, defer, true, loss);
+}
+bool chamfer_sym_hosts_loss(long live_groups, int b, int n, int m) {
+    const SymShape s = sym_shape(live_groups, n, m, true, mx_enabled());
+    return !s.mx && s.rtiles == 1 && b % 8 == 0 && (long)s.rtiles * s.cslices * live_groups > kCUs;
 }
 
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
                           int q_clouds, const int *need1, hipStream_t stream, const GridArgs *rider, const JacRider *jac,
-                          SymPartials *defer, bool loop) {
+                          SymPartials *defer, bool loop, LossRider *loss) {
+    if (loss) loss->blocks = 0;
     unsigned long long *row64 = defer ? defer->row64 : nullptr;
     if (defer) { defer->slices = 1; defer->rowpart_d = nullptr; defer->rowpart_i = nullptr; defer->clouds = b; defer->deferred = false; defer->row64 = nullptr; }
     if (b <= 0 || np <= 0) return GEOADV_OK;
@@ -519,13 +531,21 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
             return GEOADV_OK;
         })) return rc;
     unsigned grid = (unsigned)(s.rtiles * s.cslices * 8 * cdiv(b * np, 8));
-    a.rider.blocks = 0; a.rider.first_block = 0; a.rider.clouds = 0;
+    a.rider.blocks = 0; a.rider.first_block = 0; a.rider.clouds = 0; a.rider.done = nullptr;
+    a.loss.blocks = 0; a.loss.first_block = 0; a.loss.done = nullptr;
     size_t scan_lds = s.mx ? MX_LDS_BYTES : CS_LDS_BYTES;
+    // ... which pays when the scan's workgroups come in SEVERAL rounds: the riders of a cloud whose eight slices ran in an earlier round
+    // work under the later rounds (B = 64: 229.4 -> 216.9 us per iteration).  With one round every cloud's slowest slice ends with the
+    // launch, the riders start where a launch of their own would, and the producers' drained stores + the extra residents cost more
+    // than the boundary returns (B = 32: 129.7 -> 134.1, B = 16: 88.3 -> 94.1; tools/debug/loss_in_scan_ab.py, timeline in DESIGN 6)
+    const bool host_loss = loss && !s.mx && s.rtiles == 1 && b % 8 == 0 && q_clouds == 0 &&
+                           (long)s.rtiles * s.cslices * b * np_live > kCUs;
     if (rider) {
         a.rider.g = *rider;
         a.rider.first_block = 0;                           // dispatched first: its latency-bound workgroups start at once
         a.rider.blocks = grid_rider_blocks(b);
         a.rider.clouds = b;
+        if (host_loss) a.rider.done = loss->done;
         grid += (unsigned)a.rider.blocks;
         scan_lds = std::max(scan_lds, chamfer_grid_lds_bytes(rider->n));
     }
@@ -541,6 +561,25 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
         grid += (unsigned)a.jac.blocks;
         scan_lds = std::max(scan_lds, JAC_LDS_BYTES);
     }
+    // how the row minima will leave this launch (what `defer` reports below), known before the launch: the loss riders read them
+    SymPartials plan{nullptr, nullptr, 1, b, false, nullptr};
+    bool merge_launch = false;
+    if (rslices == 1 && s.rtiles == 1) {}                               // final in dist1 / idx1
+    else if (a.row64) { plan.deferred = true; plan.slices = 0; plan.row64 = a.row64; }
+    else if (defer && s.rtiles == 1 && rslices <= 8) { plan.deferred = true; plan.slices = rslices; plan.rowpart_d = a.rowpart_d; plan.rowpart_i = a.rowpart_i; }
+    else merge_launch = true;
+    if (host_loss && !merge_launch) {
+        // behind everything else: a cloud's riders can only start once its scan and search workgroups are done.  Every workgroup
+        // of the scan (np problems, gated off or not) and of the search counts itself into done[cloud] once per call.
+        loss->first_block = (int)grid;
+        loss->blocks = loss_rider_blocks(b, loss->rows);
+        loss->clouds = b;
+        loss->target += (unsigned)(np * s.rtiles * s.cslices + (rider ? 2 * GR_QSPLIT : 0));
+        if (loss->patch) loss->patch(*loss, plan, loss->ctx);
+        a.loss = *loss;
+        grid += (unsigned)a.loss.blocks;
+        scan_lds = std::max(scan_lds, loss_cgrad_lds_bytes(n));
+    } else if (a.rider.done) a.rider.done = nullptr;
     if (!s.mx) chamfer_sym_kernel<<<grid, CS_THREADS, scan_lds, stream>>>(a);
     else if (s.C == 256) chamfer_mx_kernel<8><<<grid, MX_THREADS, scan_lds, stream>>>(a);
     else if (s.C == 128) chamfer_mx_kernel<4><<<grid, MX_THREADS, scan_lds, stream>>>(a);

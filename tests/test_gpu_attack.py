@@ -580,3 +580,37 @@ def test_roctx_markers_and_kernel_timing_leave_results_alone(setup):
             at.profile(False); at.markers(False)
         outs.append(at.peek()["pert"].clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("b,prune", [(64, True), (64, False), (40, True)])
+def test_loss_riders_in_the_scan_launch_equal_their_own_launch(b, prune):
+    """Configuration.loss_in_scan: from two rounds of scan workgroups on, the loss / keep-best / Chamfer-gradient workgroups ride as
+    the last workgroups of the symmetric scan's launch and wait for their cloud's scan and search workgroups through a per-cloud
+    counter (csrc/loss_cgrad.h).  Same bodies, same order of every sum: 60 iterations (keep-best from iteration 20 on) must agree
+    with the launch of their own bit for bit -- metrics history, perturbation, indices, gradient, best clouds."""
+    import torch
+    from geometric_adv_amd import weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from conftest import cloud
+    n = 2048
+    w = W.synthetic_weights(n, seed=7)
+    ae = PointNetAE(w, n)
+    x, gt = cloud(501, b, n), cloud(502, b, n)
+    out = {}
+    for on in (True, False):
+        at = AdvAE("a", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=60, num_iterations_thresh=20, chamfer_prune=prune,
+                                      loss_in_scan=on), ae=ae)
+        at.set_inputs(x, gt, ae.transform(gt), 1.0)
+        at.init_pert(None, reset_optimizer=True)
+        h = torch.empty((60, 6, b), device=ae.device)
+        at.run(0, 60, 20, h)
+        at.status()
+        best = at.get_best(ae.get_loss_per_pc(gt))
+        out[on] = (h.clone(), {k: v.clone() for k, v in at.peek().items()}, [t.clone() for t in best])
+        del at
+    assert torch.equal(out[True][0], out[False][0])
+    for k in out[True][1]:
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+    for a_, b_ in zip(out[True][2], out[False][2]):
+        assert torch.equal(a_, b_)

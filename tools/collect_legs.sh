@@ -5,7 +5,7 @@
 # Usage: tools/collect_legs.sh OUTDIR [ROUND]
 set -u
 OUT=${1:-gpurun_out/legs}
-R=${2:-r05}
+R=${2:-r06}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for leg in config2 config3 config4 trained_victim training; do
@@ -23,5 +23,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY S
   rc=$?
   [ $rc -ne 0 ] && echo "n8192 pmc pass $i failed (rc $rc)"
 done
-python3 tools/pmc_summary.py --hash chamfer_sym.hip,chamfer_grid.h "$OUT"/n8192_* > "$OUT/${R}_pmc_chamfer_n8192.json"
+python3 tools/pmc_summary.py --hash chamfer_sym.hip,chamfer_mx.h,chamfer_grid.h "$OUT"/n8192_* > "$OUT/${R}_pmc_chamfer_n8192.json"
 ls -la "$OUT"/*.csv "$OUT"/*.json

@@ -9,7 +9,7 @@
 #   <ROUND>_bench_kernel_stats.csv, <ROUND>_loop_b32_kernel_stats.csv   --kernel-trace --stats of the two commands
 set -u
 OUT=${1:-gpurun_out/pmc}
-R=${2:-r05}
+R=${2:-r06}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # the headline leg only: no secondary legs, no RCCL self-test child (a second profiled process on the GPU whose CSVs the summary
@@ -27,14 +27,17 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY S
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/loop_$i" -- $LOOP > "$OUT/loop_$i.log" 2>&1 || { echo "loop counter pass $i FAILED (rc $?): not summarised"; rm -rf "$OUT/loop_$i"; }
 done
-python3 tools/pmc_summary.py --hash chamfer_sym.hip,chamfer_grid.h "$OUT"/loop_* > "$OUT/${R}_pmc_chamfer_hbm.json"
-# the symmetric scan ALONE (operator form, no riders): its own traffic
-i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
-  i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/sym_$i" -- python3 tools/debug/sym_only.py > "$OUT/sym_$i.log" 2>&1 || { echo "sym counter pass $i FAILED (rc $?)"; rm -rf "$OUT/sym_$i"; }
+python3 tools/pmc_summary.py --hash chamfer_sym.hip,chamfer_mx.h,chamfer_grid.h "$OUT"/loop_* > "$OUT/${R}_pmc_chamfer_hbm.json"
+# the symmetric scan ALONE (operator form, no riders): the unscreened kernel at the loop's shape, the screened one at 2048 and 8192
+for what in "sym unscreened 2048 chamfer_sym_alone" "mx screened 2048 chamfer_mx_alone" "mx8k screened 8192 chamfer_mx_n8192_alone"; do
+  set -- $what
+  i=0
+  for cs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $cs --kernel-trace --output-format csv -d "$OUT/$1_$i" -- python3 tools/debug/sym_only.py $2 $3 > "$OUT/$1_$i.log" 2>&1 || { echo "$1 counter pass $i FAILED (rc $?)"; rm -rf "$OUT/$1_$i"; }
+  done
+  python3 tools/pmc_summary.py --hash chamfer_sym.hip,chamfer_mx.h "$OUT"/$1_[0-9] > "$OUT/${R}_pmc_$4.json"
 done
-python3 tools/pmc_summary.py --hash chamfer_sym.hip "$OUT"/sym_* > "$OUT/${R}_pmc_chamfer_sym_alone.json"
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/emd_1" -- python3 tools/emd_attack_time.py 32 > "$OUT/emd_1.log" 2>&1 || echo "emd counter pass FAILED (rc $?)"
 python3 tools/pmc_summary.py --hash emd.hip "$OUT"/emd_1 > "$OUT/${R}_pmc_emd.json"
 i=0

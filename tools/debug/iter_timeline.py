@@ -20,7 +20,7 @@ NB = 1024
 names = {"decoder": {0: "latent_decode", 1: "grid_search blocks (in latent_decode)", 2: "decoder_fc2", 3: "decoder_fc2_bwd", 4: "decoder_bwd_tail"},
          "encoder": {0: "encoder_fwd", 1: "encoder_bwd blocks (masked / dense)", 2: "encoder_jac", 4: "decoder_bwd_tail blocks (in tail+dense)"}, "chamfer": {0: "chamfer_scan"},
          "encoder_x3": {0: "encoder_fwd3 (x3: constants | layer 0 | layer 1 | layer 2 | layers 3a + 4a | layers 3b + 4b | pool + masks)", 1: "encoder_fwd3s (x3 split form)"},
-         "chamfer_sym": {0: "chamfer_sym", 1: "grid_search blocks (in chamfer_sym)", 2: "chamfer_sym_finish", 3: "pool Jacobian blocks (in chamfer_sym)"}, "attack": {0: "loss_cgrad (all blocks)", 1: "loss_cgrad: gradient blocks"}}
+         "chamfer_sym": {0: "chamfer_sym", 1: "grid_search blocks (in chamfer_sym)", 2: "chamfer_sym_finish", 3: "pool Jacobian blocks (in chamfer_sym)", 4: "loss + gradient riders (in chamfer_sym): entry | released | end"}, "attack": {0: "loss_cgrad (all blocks)", 1: "loss_cgrad: gradient blocks"}}
 rows = []
 for tu, slots in names.items():
     buf = (C.c_ulonglong * (8 * NB * 8))()

@@ -1,0 +1,19 @@
+import os, sys, json, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from geometric_adv_amd import weights as W
+from geometric_adv_amd.adv_ae import AdvAE, Configuration
+from geometric_adv_amd.autoencoder import PointNetAE
+N = 2048; B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+w = W.synthetic_weights(N, seed=7); ae = PointNetAE(w, N)
+rng = np.random.default_rng(B)
+x = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5); gt = rng.random((B, N, 3), dtype=np.float32) - np.float32(0.5)
+for on in (True, False, True, False):
+    at = AdvAE("a", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=3000, num_iterations_thresh=10**6, loss_in_scan=on), ae=ae)
+    at.set_inputs(x, gt, ae.transform(gt), 1.0); at.init_pert(None, reset_optimizer=True)
+    at.run(0, 200, 10**6); torch.cuda.synchronize()
+    at.profile(True); at.run(200, 100, 10**6); torch.cuda.synchronize()
+    br = {k: round(ms / max(c, 1) * 1e3, 2) for k, (c, ms) in at.profile_read().items()}
+    at.profile(False)
+    print(json.dumps({"riding": on, "us": br, "sum": round(sum(br.values()), 1)}))
+    del at
