@@ -62,7 +62,9 @@ class Configuration:
         if encoder_backward not in ENCODER_BACKWARDS:
             raise ValueError("encoder_backward must be one of %s" % sorted(ENCODER_BACKWARDS))
         self.encoder_backward = encoder_backward             # "auto", "masked" (back-propagate dz) or "jacobian" (pool Jacobian)
-        self.loss_in_scan = bool(loss_in_scan)               # False: the loss + gradient pass always as a launch of its own
+        if loss_in_scan not in (True, False, "always"):
+            raise ValueError("loss_in_scan must be True (where it pays), False or 'always'")
+        self.loss_in_scan = loss_in_scan                     # False: the loss + gradient pass always as a launch of its own; "always": riding wherever possible
 
 
 CHAMFER_KERNELS = {"auto": 0, "two_scan": 1, "symmetric": 2}
@@ -101,7 +103,7 @@ class AdvAE:
                             {True: 0, "pinned": 0, False: 1, "always": 2}[getattr(c, "chamfer_prune", True)], (1 if getattr(c, "emd_reference_weights", False) else 0) | (0x100 if getattr(c, "emd_dense_levels", False) else 0),
                             1 if getattr(c, "recompute_backward", False) else 0, ENCODER_BACKWARDS[getattr(c, "encoder_backward", "auto")],
                             1 if getattr(c, "separate_adam", False) else 0,
-                            CHAMFER_KERNELS[getattr(c, "chamfer_kernel", "auto")], 0 if getattr(c, "loss_in_scan", True) else 1)
+                            CHAMFER_KERNELS[getattr(c, "chamfer_kernel", "auto")], {True: 0, False: 1, "always": 2}[getattr(c, "loss_in_scan", True)])
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_attack_create(C.byref(self._h), self.ae.handle, C.byref(cfg)), "attack_create")

@@ -246,6 +246,7 @@ struct geoadv_attack {
     unsigned tail_epoch;             // (host) steps launched so far: the flag value of the current one
     unsigned *loss_done;             // [B] arrival counters of the loss riders in the symmetric scan's launch (loss_cgrad.h), never reset
     unsigned loss_target;            // (host) arrivals a cloud's counter has seen after the launches so far
+    bool host_loss_force;            // cfg.loss_in_scan == 2: wherever the launch can host them, not only where it pays
     bool host_loss;                  // loss + gradient workgroups ride in the scan's launch (cfg.loss_in_scan, and the device deals
                                      // workgroup i to XCD i % 8: checked once at creation)
     int cus;                         // compute units of THIS device (hipDeviceAttributeMultiprocessorCount at create): the merged tail +
@@ -441,7 +442,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
     struct LossCtx { void (*fill)(void *, const SymPartials &, LossArgs &, CGradArgs &, int &); void *self; };
     LossCtx lctx{[](void *f, const SymPartials &p, LossArgs &la, CGradArgs &ca, int &np) { (*static_cast<decltype(fill_loss) *>(f))(p, la, ca, np); }, &fill_loss};
     LossRider lr;
-    lr.blocks = 0; lr.patch = nullptr; lr.ctx = nullptr;
+    lr.blocks = 0; lr.patch = nullptr; lr.ctx = nullptr; lr.force = false;
     bool want_host = false, hosted = false;
     {
         ProfScope ps(at, GEOADV_PROF_CHAMFER_FWD, st);
@@ -456,7 +457,7 @@ int do_forward(geoadv_attack *at, float *hist_slot, int keep, hipStream_t st) {
             if (at->host_loss && merge_in_loss && !at->emd_temp) {
                 lr.H = cgrad_fx_parts(n); lr.rows = 1 + 2 * lr.H; lr.done = at->loss_done; lr.target = at->loss_target;
                 lr.spin_timeout = reinterpret_cast<int *>(at->tail_ready + B);
-                lr.ctx = &lctx;
+                lr.ctx = &lctx; lr.force = at->host_loss_force;
                 lr.patch = [](LossRider &r, const SymPartials &p, void *c) {
                     LossCtx &x = *static_cast<LossCtx *>(c);
                     int np_ = 0;
@@ -745,7 +746,8 @@ extern "C" int geoadv_attack_create(geoadv_attack **out, const geoadv_ae *ae, co
             return GEOADV_OK;
         })) { geoadv_attack_destroy(at); return rc; }
     at->host_loss = false;
-    if (cfg->loss_in_scan == 0 && at->chamfer_sym) {           // does this device deal workgroup i to XCD i % 8?
+    at->host_loss_force = cfg->loss_in_scan == 2;
+    if (cfg->loss_in_scan != 1 && at->chamfer_sym) {           // does this device deal workgroup i to XCD i % 8?
         unsigned *d = reinterpret_cast<unsigned *>(at->sym_ws), h[64];
         xcd_probe_kernel<<<64, 64>>>(d);
         if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {

@@ -494,7 +494,7 @@ int launch_chamfer_sym_loop(const ChamferPair *pairs, int np, int b, int n, int 
 }
 bool chamfer_sym_hosts_loss(long live_groups, int b, int n, int m) {
     const SymShape s = sym_shape(live_groups, n, m, true, mx_enabled());
-    return !s.mx && s.rtiles == 1 && b % 8 == 0 && (long)s.rtiles * s.cslices * live_groups > kCUs;
+    return !s.mx && s.rtiles == 1 && b % 8 == 0;
 }
 
 int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m, float *workspace, int pair_base,
@@ -534,12 +534,15 @@ int launch_chamfer_sym_ex(const ChamferPair *pairs, int np, int b, int n, int m,
     a.rider.blocks = 0; a.rider.first_block = 0; a.rider.clouds = 0; a.rider.done = nullptr;
     a.loss.blocks = 0; a.loss.first_block = 0; a.loss.done = nullptr;
     size_t scan_lds = s.mx ? MX_LDS_BYTES : CS_LDS_BYTES;
-    // ... which pays when the scan's workgroups come in SEVERAL rounds: the riders of a cloud whose eight slices ran in an earlier round
-    // work under the later rounds (B = 64: 229.4 -> 216.9 us per iteration).  With one round every cloud's slowest slice ends with the
-    // launch, the riders start where a launch of their own would, and the producers' drained stores + the extra residents cost more
-    // than the boundary returns (B = 32: 129.7 -> 134.1, B = 16: 88.3 -> 94.1; tools/debug/loss_in_scan_ab.py, timeline in DESIGN 6)
+    // ... which pays in a narrow band only (tools/debug/loss_in_scan_ab.py, us per iteration riding / own launch, trajectories
+    // bit-identical everywhere): with the search's workgroups in the launch and two or more scan workgroups per CU, the riders of
+    // clouds whose slices ran first work under the later ones -- B = 64: 229.2 / 241.0, B = 96: 318.5 / 325.4 (B = 128: 428.2 /
+    // 427.2).  With one scan workgroup per CU every cloud's slowest slice ends with the launch: the riders start where a launch of
+    // their own would, and the producers' drained stores + the extra residents cost more than the boundary returns (B = 32: 134.1
+    // / 129.7, B = 16: 94.1 / 88.3; timeline in DESIGN 6); without the search (all-pairs) the scan's own workgroups hold every
+    // slot to the end (B = 32 ... 128: +- 0.6).
     const bool host_loss = loss && !s.mx && s.rtiles == 1 && b % 8 == 0 && q_clouds == 0 &&
-                           (long)s.rtiles * s.cslices * b * np_live > kCUs;
+                           (loss->force || (rider != nullptr && (long)s.rtiles * s.cslices * b * np_live >= 2 * (long)kCUs));
     if (rider) {
         a.rider.g = *rider;
         a.rider.first_block = 0;                           // dispatched first: its latency-bound workgroups start at once

@@ -376,6 +376,7 @@ struct LossRider {
     // only once it has chosen its launch shape; it hands that to the caller's `patch`, which completes la / ca before the launch
     void (*patch)(LossRider &, const SymPartials &, void *);
     void *ctx;
+    bool force;                // host them wherever the launch CAN (the parity tests; the default hosts them where it pays)
 };
 inline int loss_rider_blocks(int clouds, int rows) { return 8 * ((clouds + 7) / 8) * rows; }
 __device__ __forceinline__ bool loss_rider_block(const LossRider &r, unsigned *dyn) {

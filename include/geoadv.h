@@ -318,11 +318,12 @@ typedef struct geoadv_attack_config {
     int   chamfer_kernel;           /* GEOADV_CHAMFER_AUTO (0: by batch size, GEOADV_SYM_MIN_POINTS), _TWO_SCAN (the public op's kernel),
                                      * _SYMMETRIC (one evaluation per pair serves both directions)                      */
     int   loss_in_scan;             /* 0 (default): the loss / metrics / keep-best and Chamfer-gradient workgroups ride as the last
-                                     * workgroups of the symmetric scan's launch where that pays and it can host them (the scan's
-                                     * workgroups come in several rounds: batch > 32 at 2048 points; both losses Chamfer, no EMD
+                                     * workgroups of the symmetric scan's launch where that pays and it can host them (the paired
+                                     * search in the launch and two scan workgroups per CU: batch >= 64 at 2048 points; both losses Chamfer, no EMD
                                      * term, batch a multiple of 8, one row super-tile, and a device that deals workgroup i to XCD
                                      * i % 8: checked once per handle) -- they wait for their cloud's workgroups through a counter
-                                     * instead of a kernel boundary; 1: always a launch of their own.  Same results, bit for bit. */
+                                     * instead of a kernel boundary; 1: always a launch of their own; 2: riding wherever the launch CAN
+                                     * host them, paying or not (the parity tests).  Same results, bit for bit. */
 } geoadv_attack_config;
 #define GEOADV_SMALL_BATCH_POINTS 10240  /* batch * n_points below this: no paired grid search (all_pairs_source_dist = 0)                    */
 #define GEOADV_SYM_MIN_POINTS      4096  /* batch * n_points from this on: chamfer_kernel AUTO = the symmetric scan, and with it

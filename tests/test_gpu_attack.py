@@ -582,7 +582,7 @@ def test_roctx_markers_and_kernel_timing_leave_results_alone(setup):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("b,prune", [(64, True), (64, False), (40, True)])
+@pytest.mark.parametrize("b,prune", [(64, True), (64, False), (40, True), (32, True), (8, False), (16, "always")])
 def test_loss_riders_in_the_scan_launch_equal_their_own_launch(b, prune):
     """Configuration.loss_in_scan: from two rounds of scan workgroups on, the loss / keep-best / Chamfer-gradient workgroups ride as
     the last workgroups of the symmetric scan's launch and wait for their cloud's scan and search workgroups through a per-cloud
@@ -600,7 +600,7 @@ def test_loss_riders_in_the_scan_launch_equal_their_own_launch(b, prune):
     out = {}
     for on in (True, False):
         at = AdvAE("a", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=60, num_iterations_thresh=20, chamfer_prune=prune,
-                                      loss_in_scan=on), ae=ae)
+                                      loss_in_scan="always" if on else False), ae=ae)
         at.set_inputs(x, gt, ae.transform(gt), 1.0)
         at.init_pert(None, reset_optimizer=True)
         h = torch.empty((60, 6, b), device=ae.device)

@@ -16,7 +16,7 @@ for B in [int(a) for a in sys.argv[1:]] or [32, 16, 8, 64]:
         hs, ats = {}, {}
         for on in (True, False):
             at = AdvAE("a", Configuration(batch_size=B, n_points=N, weights=w, num_iterations=3000, num_iterations_thresh=50, chamfer_prune=prune,
-                                          loss_in_scan=on), ae=ae)
+                                          loss_in_scan="always" if on else False), ae=ae)
             at.set_inputs(x, gt, ae.transform(gt), 1.0); at.init_pert(None, reset_optimizer=True)
             h = torch.empty((120, 6, B), device=ae.device)
             at.run(0, 120, 50, h); at.status()
