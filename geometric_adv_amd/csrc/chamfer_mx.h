@@ -56,7 +56,7 @@ constexpr int MX_RT = 8;                      // row tiles of 32 per wave
 constexpr int MX_WROWS = 32 * MX_RT;          // 256 rows per wave
 constexpr int MX_ROWS = MX_WAVES * MX_WROWS;  // 2048 rows per workgroup (row super-tile)
 constexpr int MX_CMAX = 256;                  // columns per stage at most
-constexpr int MX_MAX_STAGES = 4;
+constexpr int MX_MAX_STAGES = 8;
 constexpr int MX_TSTRIDE = 68;                // dwords per accumulator register in the transpose buffer (64 lanes + pad)
 constexpr int MX_BSTRIDE = 12;                // dwords per column in the B exchange buffer (8 used: 48-byte stride, conflict-free b128 reads)
 constexpr unsigned MX_ROW_IDMASK = 31u;       // row direction: 32 chunks (the lanes of a half wave)
@@ -74,6 +74,7 @@ constexpr size_t MX_LDS_DWORDS = MX_OFF_RED + 192;
 constexpr size_t MX_LDS_BYTES = 4 * MX_LDS_DWORDS;
 static_assert(MX_OFF_B % 4 == 0 && MX_OFF_ROWS % 4 == 0 && MX_OFF_T % 4 == 0, "16-byte aligned regions");
 static_assert(2 * MX_CMAX <= 16 * MX_TSTRIDE, "a wave's column keys fit its transpose buffer");
+static_assert((MX_CMAX * MX_MAX_STAGES) % MX_THREADS == 0, "whole columns per thread in the prologue");
 
 // (plain C, not inline assembly: these read MFMA results, and the wait states between a matrix instruction and a VALU read of
 // its result are inserted by the compiler only for instructions it knows -- the first build, with v_min3_u32 from an asm
@@ -150,9 +151,10 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
         j = j < n ? j : n - 1;
         px[r] = v.P[3 * (size_t)j]; py[r] = v.P[3 * (size_t)j + 1]; pz[r] = v.P[3 * (size_t)j + 2];
     }
-    float qx[2], qy[2], qz[2];                                     // this thread's columns t and t + 512 of the workgroup's S * C
+    constexpr int QU = MX_CMAX * MX_MAX_STAGES / MX_THREADS;       // columns per thread at most: t, t + 512, ... of the workgroup's S * C
+    float qx[QU], qy[QU], qz[QU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < QU; ++u) {
         int k = t + u * MX_THREADS;
         k = k < ncols ? k : ncols - 1;                             // (clamped for the box; staged as +inf below)
         qx[u] = v.Q[3 * (size_t)(cbase + k)]; qy[u] = v.Q[3 * (size_t)(cbase + k) + 1]; qz[u] = v.Q[3 * (size_t)(cbase + k) + 2];
@@ -166,9 +168,12 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
             lo[1] = fminf(lo[1], py[r]); hi[1] = fmaxf(hi[1], py[r]);
             lo[2] = fminf(lo[2], pz[r]); hi[2] = fmaxf(hi[2], pz[r]);
         }
-        lo[3] = fminf(lo[3], qx[1]); hi[3] = fmaxf(hi[3], qx[1]);
-        lo[4] = fminf(lo[4], qy[1]); hi[4] = fmaxf(hi[4], qy[1]);
-        lo[5] = fminf(lo[5], qz[1]); hi[5] = fmaxf(hi[5], qz[1]);
+#pragma unroll
+        for (int u = 1; u < QU; ++u) {
+            lo[3] = fminf(lo[3], qx[u]); hi[3] = fmaxf(hi[3], qx[u]);
+            lo[4] = fminf(lo[4], qy[u]); hi[4] = fmaxf(hi[4], qy[u]);
+            lo[5] = fminf(lo[5], qz[u]); hi[5] = fmaxf(hi[5], qz[u]);
+        }
 #pragma unroll
         for (int c = 0; c < 6; ++c) { lo[c] = mx_wave_min(lo[c]); hi[c] = mx_wave_max(hi[c]); }
         if (lane == 0) {
@@ -185,7 +190,7 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
         }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < QU; ++u) {
         const int k = t + u * MX_THREADS;
         if (k < S * C) colv[k] = k < ncols ? make_float4(qx[u], qy[u], qz[u], 0.f) : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
     }
@@ -237,7 +242,7 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
     build_b(0);
     float rn2 = 0.f, cn2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < QU; ++u) {
         const float cx = qx[u] - cen[0], cy = qy[u] - cen[1], cz = qz[u] - cen[2];
         cn2 = fmaxf(cn2, (cx * cx + cy * cy) + cz * cz);
     }
@@ -283,8 +288,7 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
     for (int st = 0; st < S; ++st) {
         const int sbeg = st * C;                                   // first column of the stage inside the workgroup
         if (sbeg >= ncols) break;                                  // (uniform)
-        if (st > 0) { build_b(sbeg); __syncthreads(); }
-        mx_f16x8 Bf[NCT];
+        mx_f16x8 Bf[NCT];                                         // (a later stage's exchange was filled at the end of the one before)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) Bf[ct] = *reinterpret_cast<const mx_f16x8 *>(bex + (size_t)(ct * 32 + mrow) * MX_BSTRIDE + 4 * g);
         const bool more = st + 1 < S && sbeg + C < ncols;          // another stage follows
@@ -528,7 +532,10 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
                 if (lane == 0) out_col(cbase + k, bd, min(v.rt * MX_ROWS + bi, n - 1));
             }
         }
-        if (more) __syncthreads();                                 // the B exchange, the column keys and the transpose buffers are free again
+        if (more) {
+            build_b(sbeg + C);                                     // the next stage's operands (the exchange was read out at this stage's start)
+            __syncthreads();                                       // ... and the column keys and the transpose buffers are free again
+        }
     }
     // rows of several stages leave now: their running minimum is complete (each entry was written by the lane that reads it, or by
     // a lane of the same wave: program order)

@@ -11,7 +11,8 @@ from test_gpu_chamfer_shapes import make_clouds, KINDS
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(36, 2048, 2048), (3, 8192, 8192), (10, 2049, 5000), (300, 1500, 300), (260, 1100, 257), (50, 4096, 700)]
+SHAPES = [(36, 2048, 2048), (3, 8192, 8192), (10, 2049, 5000), (300, 1500, 300), (260, 1100, 257), (50, 4096, 700),
+          (24, 2048, 16384), (16, 8192, 8192), (200, 2048, 2048)]      # (the last three: 8, 8 and 4 column stages per workgroup)
 
 
 def _t(a):

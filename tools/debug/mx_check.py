@@ -39,7 +39,7 @@ def check():
     bad = 0
     cases = []
     for kind in ("uniform", "sphere", "clusters", "duplicates", "lattice"):
-        for b, n, m in ((2, 2048, 2048), (3, 1500, 777), (1, 8192, 8192), (2, 1025, 4100), (5, 2049, 300), (33, 2048, 2048), (2, 4097, 31), (1, 3000, 1)):
+        for b, n, m in ((2, 2048, 2048), (3, 1500, 777), (1, 8192, 8192), (2, 1025, 4100), (5, 2049, 300), (33, 2048, 2048), (2, 4097, 31), (1, 3000, 1), (16, 8192, 8192), (24, 2048, 16384)):
             cases.append((kind, b, n, m, 0.0))
     cases += [("uniform", 4, 2048, 2048, 100.0), ("sphere", 2, 2048, 2048, -1e4), ("uniform", 2, 2048, 2048, 1e-6)]
     for kind, b, n, m, shift in cases:
