@@ -39,7 +39,7 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA
 X3_PRODUCTS = 6                           # bf16 piece products per fp32 product of the encoder's default arithmetic (csrc/encoder_x3.h)
 PEAK_ENCODER_X3_TFLOPS = PEAK_MFMA_BF16_TFLOPS / X3_PRODUCTS     # algorithmic fp32 TFLOP/s the bf16 pipe can deliver in that form
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
 PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r06_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
 CSRC = os.path.join(ROOT, "geometric_adv_amd", "csrc")
 SWEEP_BATCHES = (16, 8, 4)                 # what a rank of the strong-scaling leg runs at 2 / 4 / 8 GPUs: timed in THIS run (small_batch_sweep)
