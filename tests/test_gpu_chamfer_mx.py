@@ -12,7 +12,8 @@ from test_gpu_chamfer_shapes import make_clouds, KINDS
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(36, 2048, 2048), (3, 8192, 8192), (10, 2049, 5000), (300, 1500, 300), (260, 1100, 257), (50, 4096, 700),
-          (24, 2048, 16384), (16, 8192, 8192), (200, 2048, 2048)]      # (the last three: 8, 8 and 4 column stages per workgroup)
+          (24, 2048, 16384), (16, 8192, 8192), (200, 2048, 2048),      # (these three: 8, 8 and 4 column stages per workgroup)
+          (700, 2048, 1), (600, 1100, 33), (300, 1025, 255), (40, 6145, 513)]   # one column; ragged tiles on both sides
 
 
 def _t(a):
