@@ -107,3 +107,24 @@ def test_screened_scan_degenerate_and_nonfinite_clouds(what):
         a[6] *= np.float32(1e25); c[6] *= np.float32(1e25)        # squared distances overflow to inf in the reference's arithmetic
     with np.errstate(all="ignore"):
         _same(ops.nn_distance(_t(a), _t(c), kernel="symmetric"), ops.nn_distance(_t(a), _t(c), kernel="scan"))
+
+
+def test_scorer_matrix_through_the_screened_scan():
+    """geoadv_chamfer_matrix pairs cloud i of A with cloud j of B inside the launch (no tiled copies); at 2048 points and a few
+    hundred pairs its scan is the screened kernel.  Every entry must be the bits the UNSCREENED scan gives (process-wide switch off),
+    and a sampled row equal to means of the two-scan kernel's distances (1e-6: the order of the fp32 sums differs)."""
+    import torch
+    from geometric_adv_amd import ops
+    na, nb, n = 9, 40, 2048
+    a, b = _t(make_clouds("sphere", 91, na, n)), _t(make_clouds("uniform", 92, nb, n))
+    assert _screened(na * nb, n, n)
+    got = ops.chamfer_dist_matrix(a, b)
+    assert ops.chamfer_screen(False) is True
+    try:
+        ref = ops.chamfer_dist_matrix(a, b)
+    finally:
+        ops.chamfer_screen(True)
+    assert torch.equal(got, ref)
+    d1, _, d2, _ = ops.nn_distance(a[4:5].expand(nb, n, 3).contiguous(), b, kernel="scan")
+    want = (d1.double().mean(1) + d2.double().mean(1)).cpu().numpy()
+    np.testing.assert_allclose(got[4].cpu().numpy(), want, rtol=1e-6)
