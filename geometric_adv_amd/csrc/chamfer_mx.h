@@ -70,7 +70,10 @@ constexpr size_t MX_OFF_ROWS = MX_OFF_B + (size_t)MX_CMAX * MX_BSTRIDE;
 constexpr size_t MX_OFF_T = MX_OFF_ROWS + 4 * (size_t)MX_ROWS;
 constexpr size_t MX_OFF_BEST = MX_OFF_T + (size_t)MX_WAVES * 16 * MX_TSTRIDE;
 constexpr size_t MX_OFF_RED = MX_OFF_BEST + 2 * (size_t)MX_ROWS;
-constexpr size_t MX_LDS_DWORDS = MX_OFF_RED + 192;
+constexpr int MX_ICAP = 160;                  // uncertified rows a wave can list (more: every row of the wave is redone at the end)
+constexpr int MX_CCAP = 32;                   // ... and deferred columns (more: answered on the spot)
+constexpr size_t MX_OFF_ITEMS = MX_OFF_RED + 192;
+constexpr size_t MX_LDS_DWORDS = MX_OFF_ITEMS + (size_t)MX_WAVES * (MX_ICAP + MX_CCAP);
 constexpr size_t MX_LDS_BYTES = 4 * MX_LDS_DWORDS;
 static_assert(MX_OFF_B % 4 == 0 && MX_OFF_ROWS % 4 == 0 && MX_OFF_T % 4 == 0, "16-byte aligned regions");
 static_assert(2 * MX_CMAX <= 16 * MX_TSTRIDE, "a wave's column keys fit its transpose buffer");
@@ -135,6 +138,7 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
     unsigned *tbase = lds + MX_OFF_T;
     unsigned *rbest = lds + MX_OFF_BEST;       // [2048][2]: distance bits, index (several stages only)
     float *red = reinterpret_cast<float *>(lds + MX_OFF_RED);
+    unsigned *ritems = lds + MX_OFF_ITEMS + (size_t)(threadIdx.x >> 6) * (MX_ICAP + MX_CCAP), *citems = ritems + MX_ICAP;   // this wave's lists
 
     const int n = v.n, m = v.m, C = v.C, S = v.S;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -284,6 +288,10 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
     const int rowin = 8 * (rowsub_r >> 2) + 4 * rowsub_h + (rowsub_r & 3);             // row inside a tile served by this lane pair
     // queries that could not be certified: answered after the scan by whole waves (wave-uniform masks: bit = the lane that served it)
 
+    // Queries that cannot be certified are LISTED (stage, row / column inside the workgroup) and answered after the last stage by
+    // whole groups of lanes: answered stage by stage they cost a round of LDS latency on one wave while seven waited at the
+    // stage's barrier -- 10-12 % of the kernel at 5 rows per workgroup and stage.
+    int nritems = 0, ncitems = 0, stages_done = 0;                 // (wave-uniform)
 #pragma unroll 1
     for (int st = 0; st < S; ++st) {
         const int sbeg = st * C;                                   // first column of the stage inside the workgroup
@@ -297,8 +305,6 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
         unsigned cm1[NCT], cm2[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) { cm1[ct] = MX_KEY_MAX; cm2[ct] = MX_KEY_MAX; }
-        unsigned long long row_amb[MX_RT];
-        unsigned long long col_amb;
         const mx_f32x16 zero = {0.f};
         // the products of a stage as one software pipeline: step q = (row tile q / NP, column tile pair q % NP); the matrix
         // instructions of step q + 1 are issued before step q's minima (two accumulator sets)
@@ -356,7 +362,16 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
                 const unsigned o1 = mx_dpp_xor1(m1), o2 = mx_dpp_xor1(m2);       // the pair's other half: smallest two of the four
                 const unsigned M1 = min(m1, o1), M2 = min(max(m1, o1), min(m2, o2));
                 const bool amb = M2 <= thr_bits(M1, MX_ROW_IDMASK);
-                row_amb[r] = __ballot(amb && half == 0);
+                const int jrow = wave * MX_WROWS + r * 32 + rowin; // row inside the workgroup
+                {
+                    const unsigned long long am = __ballot(amb && half == 0);
+                    if (amb && half == 0) {
+                        const int slot = nritems + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                        if (slot < MX_ICAP) ritems[slot] = ((unsigned)st << 11) | (unsigned)jrow;
+                        if (S > 1 && st == 0) { rbest[2 * jrow] = 0x7f800000u; rbest[2 * jrow + 1] = 0x7fffffffu; }   // (later stages merge into it)
+                    }
+                    nritems += __builtin_popcountll(am);
+                }
                 // the chunk of M1: its NCT columns, split over the pair
                 const int ch = (int)(M1 & MX_ROW_IDMASK);
                 float bd = INFINITY;
@@ -379,8 +394,7 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
                     mx_take(od, oi, bd, bi);
                 }
                 if (bi == INT_MAX) bi = sbeg;                      // every distance inf / NaN: any valid index (uncertified anyway)
-                const int jrow = wave * MX_WROWS + r * 32 + rowin; // row inside the workgroup
-                if (half == 0 && !amb) {                           // (an uncertified row is answered by its item below)
+                if (half == 0 && !amb) {                           // (an uncertified row is answered from the list, after the last stage)
                     if (S > 1) {
                         if (st > 0) {                              // earlier stages hold lower indices: they keep ties
                             const float pd = __uint_as_float(rbest[2 * jrow]);
@@ -445,96 +459,97 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
             }
             if (bi == INT_MAX) bi = 0;
             const bool live = hf == 0 && col < C && k < ncols;
-            col_amb = __ballot(defer && live);
             if (!defer && live) out_col(cbase + k, bd, min(v.rt * MX_ROWS + bi, n - 1));
+            {
+                const unsigned long long cm = __ballot(defer && live);
+                if (defer && live) {
+                    const int slot = ncitems + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                    if (slot < MX_CCAP) citems[slot] = (unsigned)k;
+                }
+                ncitems += __builtin_popcountll(cm);
+            }
         }
+        stages_done = st + 1;
         GA_STAMP(0, 5);
-#ifdef GA_STAMPS
-        {   // diagnostic build: uncertified rows / deferred columns of the workgroup into stamp slot 1
-            int nr = 0;
-            for (int r = 0; r < MX_RT; ++r) nr += __builtin_popcountll(row_amb[r]);
-            const unsigned blk_ = blockIdx.x;
-            if (lane == 0 && blk_ < GA_STAMP_BLOCKS) {
-                atomicAdd(&ga_stamps[(1 * GA_STAMP_BLOCKS + blk_) * 8 + 1], (unsigned long long)nr);
-                atomicAdd(&ga_stamps[(1 * GA_STAMP_BLOCKS + blk_) * 8 + 2], (unsigned long long)__builtin_popcountll(col_amb));
-                atomicAdd(&ga_stamps[(1 * GA_STAMP_BLOCKS + blk_) * 8 + 3], 1ull);
-            }
-        }
-#endif
-        // ---- the uncertified queries of the stage, with the reference's arithmetic on every pair.  Rows: FOUR at a time, one per
-        // 16-lane row of the wave (C / 16 columns a lane, all requested before the first is used; four DPP steps fold a row of lanes)
-        {
-            const int grp = lane >> 4, sub = lane & 15;
-#pragma unroll 1
-            for (int r = 0; r < MX_RT; ++r) {
-                unsigned long long mask = row_amb[r];
-                while (mask) {
-                    int l[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        l[u] = mask ? __builtin_ctzll(mask) : -1;
-                        mask = mask ? (mask & (mask - 1)) : 0ull;
-                    }
-                    const int mine = grp == 0 ? l[0] : grp == 1 ? l[1] : grp == 2 ? l[2] : l[3];
-                    const int lr = mine >> 2, lh = (mine >> 1) & 1;
-                    const int jrow = wave * MX_WROWS + r * 32 + 8 * (lr >> 2) + 4 * lh + (lr & 3);
-                    const bool live = mine >= 0 && v.rt * MX_ROWS + jrow < n;
-                    const float4 tp = rowv[live ? jrow : 0];
-                    float bd = INFINITY;
-                    int bi = INT_MAX;
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        float4 q[NCT];
-#pragma unroll
-                        for (int u = 0; u < NCT; ++u) q[u] = colv[sbeg + (h2 * NCT + u) * 16 + sub];
-#pragma unroll
-                        for (int u = 0; u < NCT; ++u) mx_take(mx_sqdist(q[u].x, q[u].y, q[u].z, tp.x, tp.y, tp.z), sbeg + (h2 * NCT + u) * 16 + sub, bd, bi);
-                    }
-#define MX_LEX(CTRL)                                                                                      \
-                    {                                                                                     \
-                        const float d2_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), CTRL, 0xf, 0xf, false)); \
-                        const int k2_ = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);        \
-                        mx_take(d2_, k2_, bd, bi);                                                        \
-                    }
-                    MX_LEX(0xB1) MX_LEX(0x4E) MX_LEX(0x141) MX_LEX(0x140)
-#undef MX_LEX
-                    if (bi == INT_MAX) bi = sbeg;
-                    if (live && sub == 0) {
-                        if (S > 1) {
-                            if (st > 0) {
-                                const float pd = __uint_as_float(rbest[2 * jrow]);
-                                if (!(bd < pd)) { bd = pd; bi = (int)rbest[2 * jrow + 1]; }
-                            }
-                            rbest[2 * jrow] = __float_as_uint(bd); rbest[2 * jrow + 1] = (unsigned)bi;
-                        } else out_row(v.rt * MX_ROWS + jrow, bd, cbase + bi);
-                    }
-                }
-            }
-            // columns whose candidates may be incomplete: a whole wave over all 2048 rows, eight requests ahead
-            unsigned long long mask = col_amb;
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const int k = sbeg + wave * 32 + (l >> 1);
-                const float4 tq = colv[k];
-                float bd = INFINITY;
-                int bi = INT_MAX;
-#pragma unroll 1
-                for (int j0 = 0; j0 < MX_ROWS; j0 += 8 * 64) {
-                    float4 p[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) p[u] = rowv[j0 + u * 64 + lane];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) mx_take(mx_sqdist(p[u].x, p[u].y, p[u].z, tq.x, tq.y, tq.z), j0 + u * 64 + lane, bd, bi);
-                }
-                wave_lexmin(bd, bi);
-                if (bi == INT_MAX) bi = 0;
-                if (lane == 0) out_col(cbase + k, bd, min(v.rt * MX_ROWS + bi, n - 1));
-            }
-        }
         if (more) {
             build_b(sbeg + C);                                     // the next stage's operands (the exchange was read out at this stage's start)
             __syncthreads();                                       // ... and the column keys and the transpose buffers are free again
+        }
+    }
+    // ---- the listed queries, with the reference's arithmetic on every pair of theirs.  Rows: FOUR at a time, one per 16-lane row of
+    // the wave over the C columns of the item's stage (all requested before the first is used; four DPP steps fold a row of lanes).
+    // A wave whose list overflowed (degenerate data: everything uncertified) redoes every row of its own at every stage.
+    {
+        const int grp = lane >> 4, sub = lane & 15;
+        const bool rover = nritems > MX_ICAP;
+#ifdef MX_EXP_NO_ITEMS
+        const int count = 0;
+#else
+        const int count = rover ? MX_WROWS * stages_done : nritems;
+#endif
+#ifdef GA_STAMPS
+        if (lane == 0 && blockIdx.x < GA_STAMP_BLOCKS) {           // diagnostic build: listed rows / columns of the workgroup into stamp slot 1
+            atomicAdd(&ga_stamps[(1 * GA_STAMP_BLOCKS + blockIdx.x) * 8 + 1], (unsigned long long)nritems);
+            atomicAdd(&ga_stamps[(1 * GA_STAMP_BLOCKS + blockIdx.x) * 8 + 2], (unsigned long long)ncitems);
+            atomicAdd(&ga_stamps[(1 * GA_STAMP_BLOCKS + blockIdx.x) * 8 + 3], 1ull);
+        }
+#endif
+#pragma unroll 1
+        for (int base = 0; base < count; base += 4) {
+            const int e = base + grp;
+            const bool have = e < count;
+            const unsigned item = !have ? 0u : rover ? (((unsigned)(e / MX_WROWS) << 11) | (unsigned)(wave * MX_WROWS + e % MX_WROWS)) : ritems[e];
+            const int ist = (int)(item >> 11), jrow = (int)(item & 2047u), isb = ist * C;
+            const bool live = have && v.rt * MX_ROWS + jrow < n;
+            const float4 tp = rowv[jrow];
+            float bd = INFINITY;
+            int bi = INT_MAX;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                float4 q[NCT];
+#pragma unroll
+                for (int u = 0; u < NCT; ++u) q[u] = colv[isb + (h2 * NCT + u) * 16 + sub];
+#pragma unroll
+                for (int u = 0; u < NCT; ++u) mx_take(mx_sqdist(q[u].x, q[u].y, q[u].z, tp.x, tp.y, tp.z), isb + (h2 * NCT + u) * 16 + sub, bd, bi);
+            }
+#define MX_LEX(CTRL)                                                                                      \
+            {                                                                                             \
+                const float d2_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), CTRL, 0xf, 0xf, false)); \
+                const int k2_ = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);                \
+                mx_take(d2_, k2_, bd, bi);                                                                \
+            }
+            MX_LEX(0xB1) MX_LEX(0x4E) MX_LEX(0x141) MX_LEX(0x140)
+#undef MX_LEX
+            if (bi == INT_MAX) bi = isb;
+            if (live && sub == 0) {
+                if (S > 1) {                                       // lexicographic: the other stages' entries may be there already
+                    mx_take(__uint_as_float(rbest[2 * jrow]), (int)rbest[2 * jrow + 1], bd, bi);
+                    rbest[2 * jrow] = __float_as_uint(bd); rbest[2 * jrow + 1] = (unsigned)bi;
+                } else out_row(v.rt * MX_ROWS + jrow, bd, cbase + bi);
+            }
+        }
+        // columns whose candidates may be incomplete: a whole wave over all 2048 rows, eight requests ahead.  (A wave whose list
+        // overflowed redoes every column of its own: 32 per stage.)
+        const bool cover = ncitems > MX_CCAP;
+        const int ccount = cover ? 32 * stages_done : ncitems;
+#pragma unroll 1
+        for (int e = 0; e < ccount; ++e) {
+            const int k = cover ? (e / 32) * C + wave * 32 + e % 32 : (int)citems[e];
+            if (k >= ncols || (cover && wave * 32 + e % 32 >= C)) continue;
+            const float4 tq = colv[k];
+            float bd = INFINITY;
+            int bi = INT_MAX;
+#pragma unroll 1
+            for (int j0 = 0; j0 < MX_ROWS; j0 += 8 * 64) {
+                float4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = rowv[j0 + u * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mx_take(mx_sqdist(p[u].x, p[u].y, p[u].z, tq.x, tq.y, tq.z), j0 + u * 64 + lane, bd, bi);
+            }
+            wave_lexmin(bd, bi);
+            if (bi == INT_MAX) bi = 0;
+            if (lane == 0) out_col(cbase + k, bd, min(v.rt * MX_ROWS + bi, n - 1));
         }
     }
     // rows of several stages leave now: their running minimum is complete (each entry was written by the lane that reads it, or by
