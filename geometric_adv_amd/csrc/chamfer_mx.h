@@ -136,7 +136,11 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
     unsigned *bex = lds + MX_OFF_B;
     float4 *rowv = reinterpret_cast<float4 *>(lds + MX_OFF_ROWS);       // [2048]   padding: +inf
     unsigned *tbase = lds + MX_OFF_T;
-    unsigned *rbest = lds + MX_OFF_BEST;       // [2048][2]: distance bits, index (several stages only)
+    // [2048] running row minima over the stages as ONE word each, (distance bits << 32) | index: squared distances are >= +0 (or
+    // +inf), so the order of the words is the lexicographic order of (distance, index) -- a listed row may be answered for two
+    // stages in the same batch below, by two groups of lanes at once: ds_min_u64, not read-merge-write (several stages only)
+    unsigned long long *rbest = reinterpret_cast<unsigned long long *>(lds + MX_OFF_BEST);
+    auto rb_pack = [](float d, int i) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i; };
     float *red = reinterpret_cast<float *>(lds + MX_OFF_RED);
     unsigned *ritems = lds + MX_OFF_ITEMS + (size_t)(threadIdx.x >> 6) * (MX_ICAP + MX_CCAP), *citems = ritems + MX_ICAP;   // this wave's lists
 
@@ -368,7 +372,7 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
                     if (amb && half == 0) {
                         const int slot = nritems + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
                         if (slot < MX_ICAP) ritems[slot] = ((unsigned)st << 11) | (unsigned)jrow;
-                        if (S > 1 && st == 0) { rbest[2 * jrow] = 0x7f800000u; rbest[2 * jrow + 1] = 0x7fffffffu; }   // (later stages merge into it)
+                        if (S > 1 && st == 0) rbest[jrow] = 0x7f8000007fffffffull;   // (+inf, no index: later stages and the list fold into it)
                     }
                     nritems += __builtin_popcountll(am);
                 }
@@ -396,11 +400,8 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
                 if (bi == INT_MAX) bi = sbeg;                      // every distance inf / NaN: any valid index (uncertified anyway)
                 if (half == 0 && !amb) {                           // (an uncertified row is answered from the list, after the last stage)
                     if (S > 1) {
-                        if (st > 0) {                              // earlier stages hold lower indices: they keep ties
-                            const float pd = __uint_as_float(rbest[2 * jrow]);
-                            if (!(bd < pd)) { bd = pd; bi = (int)rbest[2 * jrow + 1]; }
-                        }
-                        rbest[2 * jrow] = __float_as_uint(bd); rbest[2 * jrow + 1] = (unsigned)bi;
+                        const unsigned long long nw = rb_pack(bd, bi);
+                        rbest[jrow] = st > 0 ? min(rbest[jrow], nw) : nw;   // (this lane alone touches the row during the stages)
                     } else if (v.rt * MX_ROWS + jrow < n) out_row(v.rt * MX_ROWS + jrow, bd, cbase + bi);
                 }
             }
@@ -522,10 +523,8 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
 #undef MX_LEX
             if (bi == INT_MAX) bi = isb;
             if (live && sub == 0) {
-                if (S > 1) {                                       // lexicographic: the other stages' entries may be there already
-                    mx_take(__uint_as_float(rbest[2 * jrow]), (int)rbest[2 * jrow + 1], bd, bi);
-                    rbest[2 * jrow] = __float_as_uint(bd); rbest[2 * jrow + 1] = (unsigned)bi;
-                } else out_row(v.rt * MX_ROWS + jrow, bd, cbase + bi);
+                if (S > 1) atomicMin(&rbest[jrow], rb_pack(bd, bi));    // (another group of this batch may hold the same row's other stage)
+                else out_row(v.rt * MX_ROWS + jrow, bd, cbase + bi);
             }
         }
         // columns whose candidates may be incomplete: a whole wave over all 2048 rows, eight requests ahead.  (A wave whose list
@@ -559,7 +558,7 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
         for (int r = 0; r < MX_RT; ++r) {
             const int jrow = wave * MX_WROWS + r * 32 + rowin;
             if (half == 0 && v.rt * MX_ROWS + jrow < n)
-                out_row(v.rt * MX_ROWS + jrow, __uint_as_float(rbest[2 * jrow]), cbase + (int)rbest[2 * jrow + 1]);
+                out_row(v.rt * MX_ROWS + jrow, __uint_as_float((unsigned)(rbest[jrow] >> 32)), cbase + (int)(unsigned)rbest[jrow]);
         }
     }
 }
