@@ -414,9 +414,9 @@ static bool mx_enabled() { return g_mx_on.load() != 0; }
 // 100 KB of LDS): the loop's riders -- latency-bound workgroups that hide under the unscreened scan at two workgroups per CU --
 // would queue behind it, and its own serial phases (operands, column finish, uncertified queries: ~9 of ~24 us per 2048 x 256
 // tile) are only amortised when a CU gets several tiles.  Measured (tools/debug/mx_check.py, us per operator call, alternating in
-// one process): 32 x 2048^2 33.8 against 37.0 unscreened, 64 x 2048^2 55.8 / 60.6, 128 x 2048^2 93.2 / 106.8, 32 x 8192^2
-// 317 / 385; with 128-column slices (16 x 2048^2) 29.2 / 27.0; inside the B = 32 all-pairs loop with the Jacobian rider behind it
-// (two tiles per CU, tools/debug/mx_loop_ab.py) 159.1 us per iteration against 150.1.  So: operators from one 256-column tile
+// one process): 32 x 2048^2 33.5 against 37.8 unscreened, 64 x 2048^2 55.0 / 60.7, 128 x 2048^2 87.0 / 108.2, 32 x 8192^2
+// 272 / 383; with 128-column slices (16 x 2048^2) 29.2 / 27.0; inside the B = 32 all-pairs loop with the Jacobian rider behind it
+// (two tiles per CU, tools/debug/mx_loop_ab.py) 156.7 us per iteration against 151.4.  So: operators from one 256-column tile
 // per CU on, the loop from four.
 static SymShape sym_shape(long groups, int n, int m, bool loop, bool screen) {
     SymShape s;
