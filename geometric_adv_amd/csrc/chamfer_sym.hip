@@ -331,7 +331,7 @@ template <int NCT>
 __global__ __launch_bounds__(MX_THREADS, 2) void chamfer_mx_kernel(ChamferSymArgs a) {
     extern __shared__ __attribute__((aligned(16))) float stage[];
     if (grid_rider_block<GR_MAX_N>(a.rider)) return;
-    if (jac_rider_block(a.jac, stage)) return;
+    if (jac_rider_block<true>(a.jac, stage)) return;       // (this kernel's register budget admits the Jacobian's faster form)
     GA_STAMP(0, 0);
     const int lin = blockIdx.x - a.rider.blocks;
     const int xcd = lin & 7, slot = lin >> 3;
@@ -430,8 +430,20 @@ static SymShape sym_shape(long groups, int n, int m, bool loop, bool screen) {
         s.C = MX_CMAX;
         while (s.C > 64 && (long)s.rtiles * cdiv(m, s.C) * groups < kCUs &&
                (s.C > 128 || (long)s.rtiles * cdiv(m, s.C / 2) * groups <= kCUs)) s.C /= 2;
+        // column stages per workgroup: ONE workgroup is resident per CU, so the launch takes rounds(S) x (operands + S x stage) with
+        // rounds = ceil(workgroups / CUs) -- ~6 + 18 S us per workgroup at 256-column stages.  More stages amortise the
+        // operands and save whole rounds (512 tiles: two rounds of one stage 48, one round of two stages 42; 1600 tiles: 168 / 156 /
+        // 150 at 2 / 4 / 8), as long as the last round is not mostly idle -- which the same product prices.
         s.S = 1;
-        while (s.S < MX_MAX_STAGES && (long)s.rtiles * cdiv(m, s.C * s.S * 2) * groups >= 2 * kCUs) s.S *= 2;
+        {
+            const int ctiles = cdiv(m, s.C);
+            long best = -1;
+            for (int S = 1; S <= MX_MAX_STAGES && S <= std::max(1, ctiles); S *= 2) {
+                const long wgs = (long)s.rtiles * cdiv(ctiles, S) * groups;
+                const long cost = ((wgs + kCUs - 1) / kCUs) * (6 + 18L * S);
+                if (best < 0 || cost < best) { best = cost; s.S = S; }
+            }
+        }
         s.cslices = cdiv(m, s.C * s.S);
         return s;
     }

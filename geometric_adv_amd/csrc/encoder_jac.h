@@ -126,12 +126,14 @@ __device__ __forceinline__ void encoder_jac_block(const DeviceAE &A, const JacAr
 // take what they need from the few CUs they share (B = 4: 0.0673 -> 0.0666 ms, B = 8: 0.0791 -> 0.0780).  At B = 32 there is a
 // rider on EVERY CU and the scan is the long pole: raised priority costs 0.1706 -> 0.173.
 struct JacRider { JacArgs j; DeviceAE A; int first_block, blocks; int raise_prio; };
+// AHEAD: the form with the weights requested a layer ahead (145 registers: only a host kernel with that budget -- the screened scan)
+template <bool AHEAD = false>
 __device__ __forceinline__ bool jac_rider_block(const JacRider &r, float *lds) {
     if (r.blocks == 0 || (int)blockIdx.x < r.first_block || (int)blockIdx.x >= r.first_block + r.blocks) return false;
     const int g = blockIdx.x - r.first_block;
     if (r.raise_prio) __builtin_amdgcn_s_setprio(1);      // few workgroups beside a launch they would otherwise END (small batches)
     GA_STAMP(3, 0);
-    encoder_jac_block<false>(r.A, r.j, lds, g % (128 / JAC_ROWS), g / (128 / JAC_ROWS));
+    encoder_jac_block<AHEAD>(r.A, r.j, lds, g % (128 / JAC_ROWS), g / (128 / JAC_ROWS));
     GA_STAMP(3, 7);
     return true;
 }
