@@ -30,3 +30,21 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, "libgeoadv.so lacks: %s" % missing
     assert lib.geoadv_version() >= 1
+
+
+def _struct_fields(name):
+    """(C type, field) pairs of `typedef struct <name> { ... } <name>;` in include/geoadv.h, comments stripped."""
+    text = open(os.path.join(ROOT, "include", "geoadv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), text, flags=re.S).group(1)
+    return [(t, f) for t, f in re.findall(r"\b(int|float)\s+([a-z0-9_]+)\s*;", body)]
+
+
+def test_python_mirror_of_the_attack_config_matches_the_header():
+    """The ctypes structure adv_ae.py passes to geoadv_attack_create has the header's fields, in order, with the header's types:
+    a field added on one side only would shift every later one silently."""
+    from geometric_adv_amd.adv_ae import _AttackConfig
+    want = _struct_fields("geoadv_attack_config")
+    got = [({ctypes.c_int: "int", ctypes.c_float: "float"}[t], f) for f, t in _AttackConfig._fields_]
+    assert got == want
+    assert want[-1] == ("int", "loss_in_scan")
