@@ -48,3 +48,10 @@ def test_python_mirror_of_the_attack_config_matches_the_header():
     got = [({ctypes.c_int: "int", ctypes.c_float: "float"}[t], f) for f, t in _AttackConfig._fields_]
     assert got == want
     assert want[-1] == ("int", "loss_in_scan")
+
+
+def test_python_mirror_of_the_train_config_matches_the_header():
+    from geometric_adv_amd.trainer import _TrainConfig
+    want = _struct_fields("geoadv_train_config")
+    got = [({ctypes.c_int: "int", ctypes.c_float: "float"}[t], f) for f, t in _TrainConfig._fields_]
+    assert got == want
