@@ -78,6 +78,7 @@ constexpr size_t MX_LDS_BYTES = 4 * MX_LDS_DWORDS;
 static_assert(MX_OFF_B % 4 == 0 && MX_OFF_ROWS % 4 == 0 && MX_OFF_T % 4 == 0, "16-byte aligned regions");
 static_assert(2 * MX_CMAX <= 16 * MX_TSTRIDE, "a wave's column keys fit its transpose buffer");
 static_assert((MX_CMAX * MX_MAX_STAGES) % MX_THREADS == 0, "whole columns per thread in the prologue");
+static_assert(MX_LDS_BYTES + 2048 <= 160 * 1024, "one workgroup's dynamic LDS (+ the host kernel's static words) fits a CU");
 
 // (plain C, not inline assembly: these read MFMA results, and the wait states between a matrix instruction and a VALU read of
 // its result are inserted by the compiler only for instructions it knows -- the first build, with v_min3_u32 from an asm
