@@ -70,9 +70,10 @@ def parse_args():
                     help="run ONE secondary leg alone on cuda:0 and print its JSON (what `rocprofv3 --kernel-trace --stats -- python3 "
                          "bench.py --only-leg X` profiles: tools/collect_legs.sh -> profiles/r04_leg_*_kernel_stats.csv)")
     ap.add_argument("--no-rccl-selftest", action="store_true", help="do not start the one-rank RCCL child at N = 1")
-    ap.add_argument("--slots", type=int, default=0,
-                    help="also measure S concurrent batch slots (secondary.batch_slots; off by default: its overlapping "
-                         "launches would distort the per-kernel averages of a rocprofv3 run of this command)")
+    ap.add_argument("--slots", type=int, default=-1,
+                    help="also measure S concurrent batch slots (secondary.batch_slots).  Default: 2 and 3 slots, unless the run is "
+                         "being profiled (a ROCPROF* / ROCP_* variable in the environment: overlapping launches would distort the "
+                         "per-kernel averages of a rocprofv3 run of this command); 0: never")
     return ap.parse_args()
 
 
@@ -1177,8 +1178,13 @@ def main():
                             "trained_victim": trained_victim_leg(dev, min(K, 200), Wm),
                             "ae_training_step": training_leg(dev), "roofline_emd": emd,
                             "surface_clouds": surfaces_leg(dev, weights, ae, min(K, 200), Wm)}
-        if args.slots > 1:
-            out["secondary"]["batch_slots"] = slots_leg(dev, weights, ae, args.slots)
+        profiled = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
+        slot_counts = [args.slots] if args.slots > 1 else ([2, 3] if args.slots < 0 and not profiled else [])
+        if slot_counts:
+            out["secondary"]["batch_slots"] = {str(c): slots_leg(dev, weights, ae, c) for c in slot_counts}
+            out["secondary"]["batch_slots"]["note"] = ("Configuration.batch_slots: that many INDEPENDENT B = 32 batches of an attack set in flight on this GPU "
+                                                       "(own handle, stream and host thread each): one batch's dependent launches and their boundaries run under "
+                                                       "another's kernels.  Aggregate iterations/s over the slots; `value` stays one batch at a time")
     if world == 1 and not args.no_cpu_baseline:
         _, adv_best, recon_best = at.get_best(leg.ref)
         out["cpu_baseline"] = cpu_baseline(weights, x, gt, args.cpu_iters,
@@ -1196,10 +1202,12 @@ def main():
         "trained_victim_its": {k: r1(tv[k]["attack_iterations_per_sec"]) for k in ("grid_search", "all_pairs", "adaptive_default")
                                if isinstance(tv.get(k), dict) and "attack_iterations_per_sec" in tv[k]} or None,
         "strong_measured_ms": ({k: round(v, 4) for k, v in strong["measured_ms"].items()} if strong and "measured_ms" in strong else None),
+        "batch_slots_its": {k: r1(v["attack_iterations_per_sec_all_slots"]) for k, v in (sec.get("batch_slots") or {}).items() if isinstance(v, dict)} or None,
         "full_size_ms": {k: (sec.get("configs", {}).get(k) or {}).get("full_size_ms_per_iteration")
                          for k in ("config3_chamfer_emd_b128", "config4_n8192_b32")} if sec else None,
         "note": "all_pairs: nn_distance(adv, x) without the data-dependent grid search; encoder_f32: fp32 MFMAs instead of bf16x3; "
-                "f32_all_pairs: neither; strong_measured_ms: ms per iteration of THIS GPU at B = 32/G; full_size_ms: configs[3] "
+                "f32_all_pairs: neither; strong_measured_ms: ms per iteration of THIS GPU at B = 32/G; batch_slots_its: aggregate it/s with "
+                "2 / 3 independent B = 32 batches in flight (not the headline's one batch at a time); full_size_ms: configs[3] "
                 "(B=1024) and configs[4] (B=256 x 8192) whole on one GPU"}
     out["roofline"]["chamfer"] = {"kernel": "chamfer scan of nn_distance(recon, target)", "frac": round(rc["frac"], 4),
                                   "avg_class_ms": round(rc["avg_class_ms"], 5), "issue_bound_ms": round(rc["issue_bound_ms"], 5),
