@@ -128,3 +128,39 @@ def test_scorer_matrix_through_the_screened_scan():
     d1, _, d2, _ = ops.nn_distance(a[4:5].expand(nb, n, 3).contiguous(), b, kernel="scan")
     want = (d1.double().mean(1) + d2.double().mean(1)).cpu().numpy()
     np.testing.assert_allclose(got[4].cpu().numpy(), want, rtol=1e-6)
+
+
+def test_attack_loop_at_n8192_is_the_same_with_and_without_the_screen():
+    """configs[4]'s per-GPU loop (B = 32 x 8192: the loop takes the screened scan there) against the same loop with the process-wide
+    switch off, and with the switch flipped in the middle of a run (scratch sizes cover both kernels): metrics history, perturbation
+    and all four index arrays bit for bit."""
+    import torch
+    from geometric_adv_amd import ops, weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from conftest import cloud
+    b, n = 32, 8192
+    w = W.synthetic_weights(n, seed=7)
+    ae = PointNetAE(w, n)
+    x, gt = cloud(701, b, n), cloud(702, b, n)
+    out = {}
+    try:
+        for mode in ("on", "off", "flip"):
+            ops.chamfer_screen(mode != "off")
+            at = AdvAE("a", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=6, num_iterations_thresh=2), ae=ae)
+            at.set_inputs(x, gt, ae.transform(gt), 1.0)
+            at.init_pert(None, reset_optimizer=True)
+            h = torch.empty((6, 6, b), device=ae.device)
+            at.run(0, 3, 2, h[:3])
+            if mode == "flip":
+                ops.chamfer_screen(False)
+            at.run(3, 3, 2, h[3:])
+            at.status()
+            out[mode] = (h.clone(), {k: v.clone() for k, v in at.peek().items()})
+            del at
+    finally:
+        ops.chamfer_screen(True)
+    for mode in ("off", "flip"):
+        assert torch.equal(out["on"][0], out[mode][0]), mode
+        for k in out["on"][1]:
+            assert torch.equal(out["on"][1][k], out[mode][1][k]), (mode, k)
