@@ -36,8 +36,9 @@ B, N = 32, 2048
 ENC_FLOP_PER_POINT = 2 * 90304            # 2 * (3*64 + 64*128 + 128*128 + 128*256 + 256*128)  
 PEAK_MFMA_F32_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_MFMA_BF16_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 32 cycles / SIMD at 2.4 GHz)
-X3_PRODUCTS = 6                           # bf16 piece products per fp32 product of the encoder's default arithmetic (csrc/encoder_x3.h)
-PEAK_ENCODER_X3_TFLOPS = PEAK_MFMA_BF16_TFLOPS / X3_PRODUCTS     # algorithmic fp32 TFLOP/s the bf16 pipe can deliver in that form
+X3_PRODUCTS = 3                           # fp16 piece products per fp32 product of the encoder's default arithmetic, f16x2 (csrc/encoder_x3.h;
+                                          # the dense fp16 and bf16 MFMA peaks are the same figure); bf16x3 takes 6
+PEAK_ENCODER_X3_TFLOPS = PEAK_MFMA_BF16_TFLOPS / X3_PRODUCTS     # algorithmic fp32 TFLOP/s the fp16 pipe can deliver in that form
 PEAK_HBM_GBS = 8000.0
 PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_encoder.json")     # tools/pmc_summary.py output + source hashes
 PMC_CHAMFER_FILE = os.path.join(ROOT, "profiles", "r06_pmc_chamfer_hbm.json")   # the same for the Chamfer kernels of the plain B = 32 loop
@@ -194,7 +195,7 @@ def pmc_encoder():
     if not want or source_hashes(sorted(want)) != want:
         return None, None, "%s was taken at different kernel sources: dropped" % os.path.basename(PMC_FILE)
     names = [n for n in d if "encoder_fwd" in n]
-    names.sort(key=lambda n: ("encoder_fwd3_kernel<true>" not in n, "<true, 64>" not in n, n))      # the loop's instantiation at B = 32: masks on
+    names.sort(key=lambda n: ("encoder_fwd3_kernel<2, true>" not in n, "encoder_fwd3_kernel<3, true>" not in n, "<true, 64>" not in n, n))      # the loop's instantiation at B = 32: masks on
     k = d[names[0]]
     traffic = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
     util = None
@@ -947,11 +948,12 @@ def calibration(dev):
 
 
 def sustained_bf16_tflops():
-    """TFLOP/s a bare stream of the encoder's MFMAs sustained in the recorded probe (tools/bf16x3_probe.py throughput, weights
-    from LDS, 2-3 VALU per MFMA), or None when the record is missing: a number of ANOTHER box and clock state, reported as such."""
+    """TFLOP/s a bare stream of the encoder's MFMAs (the f16x2 loop shape) sustained in the recorded probe (tools/bf16x3_probe.py
+    f16x2, weights from LDS, 3 VALU per MFMA), or None when the record is missing: a number of ANOTHER box and clock state,
+    reported as such."""
     try:
-        rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r05_bf16x3_probe.jsonl"))]
-        v = [r["bf16_tflops"] for r in rows if r.get("probe") == "throughput" and r.get("weights_from") == "lds" and r.get("valu_per_mfma") in (2, 3)]
+        rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r06_f16x2_probe.jsonl"))]
+        v = [r["f16_tflops"] for r in rows if r.get("probe") == "throughput_f16x2" and r.get("valu_per_mfma") == 3 and not r.get("gap_kernel_ms")]
         return sum(v) / len(v) if v else None
     except Exception:
         return None
@@ -1038,9 +1040,14 @@ def main():
     dt_ap = median(dts_ap)
     del leg_ap
 
-    # ---- the same loop with the encoder's products as fp32 MFMAs (GEOADV_ENC_ARITH_F32): what the default arithmetic buys ----
-    dt_f32 = dt_f32ap = None
+    # ---- the same loop with the encoder's products as fp32 MFMAs (GEOADV_ENC_ARITH_F32) / as six bf16 piece products
+    # (GEOADV_ENC_ARITH_BF16X3, round 5's default): what the default arithmetic buys ----
+    dt_f32 = dt_f32ap = dt_x3 = None
     if not args.no_secondary:                   # (--no-secondary: the counter passes profile the headline launches only)
+        ae_x3 = PointNetAE(weights, N, device=dev, encoder_arith="bf16x3")
+        leg_x3 = Leg(dev, weights, ae_x3, x, gt, Wm, K, dog=dog)
+        dt_x3 = median(leg_x3.windows(min(R, 3), gdist, backend, dev))
+        del leg_x3, ae_x3
         ae_f32 = PointNetAE(weights, N, device=dev, encoder_arith="f32")
         leg_f32 = Leg(dev, weights, ae_f32, x, gt, Wm, K, dog=dog)
         dts_f32 = leg_f32.windows(min(R, 3), gdist, backend, dev)
@@ -1106,9 +1113,9 @@ def main():
         "metric": "attack-iterations/sec (B=32, N=2048) at 1/2/4/8 GPUs; Chamfer rel-err vs ref",
         "value": world * K / dt, "unit": "attack-iterations/sec", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (encoder products: bf16x3)", "data": "synthetic",
-        "encoder_arith": "bf16x3 (fp32 operands as three bf16 pieces, six piece products per multiply, fp32 accumulate; include/geoadv.h "
-                         "GEOADV_ENC_ARITH_BF16X3) -- everything else plain fp32",
+        "dtype": "f32 (encoder products: f16x2)", "data": "synthetic",
+        "encoder_arith": "f16x2 (fp32 operands, scaled by powers of two, as two fp16 pieces; three piece products per multiply, fp32 "
+                         "accumulate; range-guarded; include/geoadv.h GEOADV_ENC_ARITH_F16X2) -- everything else plain fp32",
         "timing": "median of %d windows of exactly %d steps, each bracketed by barrier + synchronize, max over ranks; ~0.1 s of "
                   "untimed priming windows first (clock ramp)" % (R, K),
         "windows_ms": [round(t * 1e3, 3) for t in dts],
@@ -1117,10 +1124,13 @@ def main():
                                 "victim whose adversarial points leave their grid cells gets; same results bit for bit",
         "value_encoder_f32": (world * K / dt_f32) if dt_f32 else None,
         "value_encoder_f32_note": "the same loop with the encoder's products as fp32 MFMAs (encoder_arith='f32', v_mfma_f32_32x32x2_f32: "
-                                  "the round-4 kernel).  `value` runs the default: every fp32 operand as three bf16 pieces, a product as its six "
-                                  "piece products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the error of an fp32 "
-                                  "accumulation in another order (profiles/r05_bf16x3_probe.jsonl: rms 0.48-0.52 against 0.43-0.46 units of "
-                                  "2^-24 |a|.|w|), same parity tolerances (tests/test_gpu_encoder_x3.py)",
+                                  "the round-4 kernel).  `value` runs the default: every fp32 operand as two fp16 pieces of its power-of-two-"
+                                  "scaled value, a product as its three piece products of weight >= 2^-11 on v_mfma_f32_32x32x16_f16, fp32 "
+                                  "accumulate -- the error of an fp32 accumulation in another order (profiles/r06_f16x2_probe.jsonl: rms "
+                                  "0.44-0.52 against 0.43-0.46 units of 2^-24 |a|.|w|), same parity tolerances (tests/test_gpu_encoder_x3.py)",
+        "value_encoder_bf16x3": (world * K / dt_x3) if dt_x3 else None,
+        "value_encoder_bf16x3_note": "the same loop with round 5's default arithmetic (three bf16 pieces, six piece products): the fallback of a "
+                                     "model whose activations leave f16x2's range (>= 1023.5; guarded, never silent)",
         "config": {"workload": "BASELINE configs[1]: B=32 random clouds x N=2048, output-space attack (chamfer/chamfer, "
                                "dist_weight 1.0, lr 0.01), one batch per GPU", "batch_per_gpu": B, "n_points": N,
                    "global_batch": B * world, "parallelism": "batches sharded, dp%d, no data-path collective" % world,
@@ -1128,17 +1138,17 @@ def main():
                    "rccl_version": group_info["rccl_version"],
                    "thresh_fraction": 0.8},
         "strong_scaling": strong,
-        "roofline": {"bound": "mfma", "kernel": "encoder_fwd3_kernel<true>", "achieved": enc_tflops, "peak": PEAK_ENCODER_X3_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": "encoder_fwd3_kernel<2, true>", "achieved": enc_tflops, "peak": PEAK_ENCODER_X3_TFLOPS,
                      "unit": "TFLOP/s", "frac": enc_tflops / PEAK_ENCODER_X3_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
-                     "peak_note": "algorithmic fp32 FLOP (SURVEY 8d: 2 x 90304 per point) against the dense bf16 MFMA peak (%.0f TFLOP/s) / %d: "
-                                  "the kernel issues six bf16 piece products per fp32 product.  Against the fp32 MFMA peak the round-4 kernel "
+                     "peak_note": "algorithmic fp32 FLOP (SURVEY 8d: 2 x 90304 per point) against the dense fp16 MFMA peak (%.0f TFLOP/s) / %d: "
+                                  "the kernel issues three fp16 piece products per fp32 product.  Against the fp32 MFMA peak the round-4 kernel "
                                   "was priced on (%.1f) the same launch is frac_of_fp32_mfma_peak" % (PEAK_MFMA_BF16_TFLOPS, X3_PRODUCTS, PEAK_MFMA_F32_TFLOPS),
-                     "issued_bf16_tflops": X3_PRODUCTS * enc_tflops, "frac_of_fp32_mfma_peak": enc_tflops / PEAK_MFMA_F32_TFLOPS,
-                     "sustained_note": "a bare stream of the same MFMAs (operands in registers, weights re-read from LDS, 3 VALU per MFMA, all "
-                                       "256 CUs, random operands) sustains 1.37 PFLOP/s bf16 on this part -- 55 % of the spec peak: the chip "
-                                       "lowers its clock under bf16 matrix load (profiles/r05_bf16x3_probe.jsonl; MI355X_MICROARCH.md, DVFS "
-                                       "give-back) -- so this kernel's MFMA floor is ~48 us of its launch",
-                     "frac_of_sustained_bf16_stream": (X3_PRODUCTS * enc_tflops / sustained_bf16_tflops()) if sustained_bf16_tflops() else None,
+                     "issued_f16_tflops": X3_PRODUCTS * enc_tflops, "frac_of_fp32_mfma_peak": enc_tflops / PEAK_MFMA_F32_TFLOPS,
+                     "sustained_note": "a bare stream of the same MFMAs in the kernel's loop shape (operands in registers, weight pieces re-read "
+                                       "from LDS, 3 VALU per MFMA, all 256 CUs, random operands) is what frac_of_sustained_f16_stream compares "
+                                       "with (profiles/r06_f16x2_probe.jsonl, another box): the chip lowers its clock under matrix load "
+                                       "(MI355X_MICROARCH.md, DVFS give-back; the bf16 stream of round 5 sustained 1.37 PFLOP/s = 55 % of the spec peak)",
+                     "frac_of_sustained_f16_stream": (X3_PRODUCTS * enc_tflops / sustained_bf16_tflops()) if sustained_bf16_tflops() else None,
                      "mfma_pipe_utilisation_pmc": mfma_util,
                      "avg_launch_ms": enc_avg_ms, "launches_timed": enc_n, "algorithmic_flop_per_launch": enc_flop,
                      "timing": "kernel begin/end stamps (hipExtLaunchKernel start/stop events) of every %s launch inside the "
@@ -1198,6 +1208,7 @@ def main():
     r1 = lambda v: None if v is None else round(float(v), 1)
     out["config"]["qualifiers"] = {
         "value_all_pairs": r1(out["value_all_pairs"]), "value_encoder_f32": r1(out["value_encoder_f32"]),
+        "value_encoder_bf16x3": r1(out["value_encoder_bf16x3"]),
         "value_f32_all_pairs": r1((world * K / dt_f32ap) if dt_f32ap else None),
         "trained_victim_its": {k: r1(tv[k]["attack_iterations_per_sec"]) for k in ("grid_search", "all_pairs", "adaptive_default")
                                if isinstance(tv.get(k), dict) and "attack_iterations_per_sec" in tv[k]} or None,
@@ -1205,7 +1216,8 @@ def main():
         "batch_slots_its": {k: r1(v["attack_iterations_per_sec_all_slots"]) for k, v in (sec.get("batch_slots") or {}).items() if isinstance(v, dict)} or None,
         "full_size_ms": {k: (sec.get("configs", {}).get(k) or {}).get("full_size_ms_per_iteration")
                          for k in ("config3_chamfer_emd_b128", "config4_n8192_b32")} if sec else None,
-        "note": "all_pairs: nn_distance(adv, x) without the data-dependent grid search; encoder_f32: fp32 MFMAs instead of bf16x3; "
+        "note": "all_pairs: nn_distance(adv, x) without the data-dependent grid search; encoder_f32 / encoder_bf16x3: fp32 MFMAs / six bf16 "
+                "piece products instead of f16x2's three fp16 ones; "
                 "f32_all_pairs: neither; strong_measured_ms: ms per iteration of THIS GPU at B = 32/G; batch_slots_its: aggregate it/s with "
                 "2 / 3 independent B = 32 batches in flight (not the headline's one batch at a time); full_size_ms: configs[3] "
                 "(B=1024) and configs[4] (B=256 x 8192) whole on one GPU"}

@@ -21,7 +21,7 @@ class _AEWeights(C.Structure):
                 ("dec_w", C.c_void_p * 3), ("dec_b", C.c_void_p * 3)]
 
 
-ENCODER_ARITH = {"f32": 0, "bf16x3": 1}     # GEOADV_ENC_ARITH_*
+ENCODER_ARITH = {"f32": 0, "bf16x3": 1, "f16x2": 2}     # GEOADV_ENC_ARITH_*
 
 
 class PointNetAE:
@@ -30,8 +30,10 @@ class PointNetAE:
     def __init__(self, weights, n_points, ae_name=W.AE_NAME, device=None, encoder_arith=None):
         """weights: dict of TF-variable-name -> array (see weights.py), or a path to such an .npz, or a
         TF V2 checkpoint prefix like '<ae_dir>/models.ckpt-500' (read without TensorFlow, tf_checkpoint.py).
-        encoder_arith: "bf16x3" (fp32 products as six bf16 piece products on the bf16 matrix pipe, include/geoadv.h) or "f32"
-        (fp32 MFMA); None = the library default.  Applies to everything that runs this model (forward, attack, defense)."""
+        encoder_arith: "f16x2" (fp32 products as three fp16 piece products of power-of-two-scaled operands on the fp16 matrix pipe,
+        range-guarded: include/geoadv.h), "bf16x3" (six bf16 piece products) or "f32" (fp32 MFMA); None = the library default
+        ("f16x2" for every model whose constants scale exactly).  Applies to everything that runs this model (forward, attack,
+        defense)."""
         if isinstance(weights, str):
             weights = W.load(weights, ae_name)
         self.n_points = int(n_points)
@@ -68,6 +70,12 @@ class PointNetAE:
     def encoder_arith(self):
         code = _lib.lib().geoadv_ae_encoder_arith(self._h)
         return next(k for k, v in ENCODER_ARITH.items() if v == code)
+
+    def status(self):
+        """Synchronises and raises if an "f16x2" forward of this model met an activation outside its range since the last call
+        (geoadv_ae_status: the clouds concerned got +inf latents).  The numpy-returning methods call it."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geoadv_ae_status(self._h, _lib.stream_handle()), "ae_status")
 
     def __del__(self):
         try:
@@ -130,11 +138,13 @@ class PointNetAE:
         if compute_loss:
             gt = self._as_dev(X if GT is None else GT)
             loss = float(self.loss_per_pc_tensor(recon, gt).mean().item())
+        self.status()
         return recon.cpu().numpy(), loss
 
     def transform(self, X):
         """Latent codes (autoencoder.py: transform / get_latent_vectors) as numpy."""
         _, z = self.forward(X, want_recon=False)
+        self.status()
         return z.cpu().numpy()
 
     get_latent_vectors = transform

@@ -31,6 +31,10 @@ struct DeviceAE {
     PackedLayer enc_bwd16[ENC_L];  // the same products packed for the 16x16x4 shape
     const unsigned *enc_x3;        // encoder layers 1-4 as bf16 piece fragments in step order (encoder_x3.h)
     const float *enc_x3_consts;    // the x3 forward's LDS constants as one block (encoder_x3.h: X3_CONST_FLOATS)
+    const unsigned *enc_h2;        // the same as fp16 piece fragments of the SCALED weights (encoder_x3.h, f16x2); null if the model's
+    const float *enc_h2_consts;    // weights / BN constants do not scale exactly (then the arithmetic is refused); its LDS constants
+    float h2_unscale[ENC_L];       // [1..4]: 1 / (H2_ACT_SCALE S_w(L)), the power of two that takes an f16x2 accumulator back
+    int *range_flag;               // device int, sticky: an f16x2 forward saw an activation beyond the fp16 range (geoadv_ae_status)
     int enc_arith;                 // GEOADV_ENC_ARITH_*: which forward (and recompute) arithmetic the encoder kernels use
     const float *scale[ENC_L];     // BN folded: h = max(a*scale + shift, 0), a = x@W (no bias)
     const float *shift[ENC_L];     // shift = b*scale + (beta - mean*scale)
@@ -53,6 +57,8 @@ struct FusedAdam {
 };
 
 }  // namespace geoadv
+
+namespace geoadv { int ae_range_check(const geoadv_ae *ae, hipStream_t stream, const char *who); }
 
 struct geoadv_ae {
     geoadv::DeviceAE d;

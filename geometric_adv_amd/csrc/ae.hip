@@ -98,6 +98,48 @@ static void pack_x3(uint32_t *img, const float *const W[ENC_L], const int *C) {
     }
 }
 
+// fp16 pieces of an (already scaled) fp32 (encoder_x3.h, f16x2): round to nearest even, the remainder exact
+static inline void h2_pieces(float x, uint16_t (&p)[2]) {
+    const _Float16 h0 = (_Float16)x;
+    const _Float16 h1 = (_Float16)(x - (float)h0);
+    memcpy(&p[0], &h0, 2);
+    memcpy(&p[1], &h1, 2);
+}
+// The power of two that brings a layer's largest |weight| into [2^13, 2^14); 0 if a weight is not finite.
+static float h2_weight_scale(const float *W, size_t count) {
+    float mx = 0.f;
+    for (size_t i = 0; i < count; ++i) {
+        if (!std::isfinite(W[i])) return 0.f;
+        mx = std::max(mx, std::fabs(W[i]));
+    }
+    if (mx == 0.f) return 1.f;
+    int e;
+    (void)frexpf(mx, &e);                       // mx in [2^(e-1), 2^e)
+    return ldexpf(1.f, 14 - e);
+}
+// The f16x2 weight image: pack_x3's layout with two fp16 pieces of S_w(L) W_L per fragment position.
+static void pack_h2(uint32_t *img, const float *const W[ENC_L], const int *C, const float *sw) {
+    for (int L = 1; L <= 4; ++L) {
+        const int K = C[L], N = C[L + 1];
+        for (int ob = 0; ob < N / 32; ++ob)
+            for (int kb = 0; kb < K / 16; ++kb) {
+                const int step = x3_step_of(L, ob, kb);
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    uint16_t pc[8][2];
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = L == 4 ? 128 * (kb >> 3) + x3_in_channel(4, kb & 7, h, j) : x3_in_channel(L, kb, h, j);
+                        h2_pieces(W[L][(size_t)k * N + 32 * ob + i] * sw[L], pc[j]);
+                    }
+                    for (int q = 0; q < 2; ++q) {
+                        uint32_t *dst = img + ((size_t)(step * 4 + (ob & 3)) * 2 + q) * X3_FRAG_WORDS + lane * 4;
+                        for (int w = 0; w < 4; ++w) dst[w] = (uint32_t)pc[2 * w][q] | ((uint32_t)pc[2 * w + 1][q] << 16);
+                    }
+                }
+            }
+    }
+}
+
 struct ForwardScratch {
     float *pmax; int *parg; int *pcnt;   // [b][tiles][128]
     float *z; int *crit; int *zcnt;      // [b][128]
@@ -138,7 +180,9 @@ int run_forward(const DeviceAE &A, int b, const float *x, const float *pert, flo
 
 using namespace geoadv;
 
-static std::atomic<int> g_default_enc_arith{GEOADV_ENC_ARITH_BF16X3};
+// -1: f16x2 where the model's constants scale exactly (every sane model), bf16x3 otherwise
+static std::atomic<int> g_default_enc_arith{-1};
+static bool known_arith(int a) { return a == GEOADV_ENC_ARITH_F32 || a == GEOADV_ENC_ARITH_BF16X3 || a == GEOADV_ENC_ARITH_F16X2; }
 
 extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     GA_REQUIRE(out && hw, "ae_create: null argument");
@@ -174,6 +218,7 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     size_t o_v0t = reserve(256 * 128), o_v1t = reserve(256 * 256);
     size_t o_d2f = reserve((size_t)256 * n3p32), o_d2b = reserve((size_t)n3p8 * 256), o_c2 = reserve(n3);
     size_t o_x3 = reserve(X3_IMAGE_WORDS), o_x3c = reserve(X3_CONST_FLOATS);
+    size_t o_h2 = reserve(H2_IMAGE_WORDS), o_h2c = reserve(X3_CONST_FLOATS), o_flag = reserve(1);
 
     memcpy(&host[o_w0], hw->enc_w[0], sizeof(float) * 3 * C[1]);
     for (int i = 1; i < ENC_L; ++i) {
@@ -202,6 +247,36 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
             memcpy(c + off[i], &host[o_scale[i]], sizeof(float) * C[i + 1]);
             memcpy(c + off[i] + C[i + 1], &host[o_shift[i]], sizeof(float) * C[i + 1]);
         }
+    }
+    // the f16x2 forward's image and constants: weights scaled by S_w(L), the scales folded into the epilogue's constants
+    // (encoder_x3.h).  Every folded constant must be the exact power-of-two multiple (no under- / overflow): else no f16x2.
+    float sw[ENC_L] = {1.f, 1.f, 1.f, 1.f, 1.f}, h2_unscale[ENC_L] = {1.f, 1.f, 1.f, 1.f, 1.f};
+    bool h2_ok = true;
+    {
+        for (int L = 1; L < ENC_L; ++L) {
+            sw[L] = h2_weight_scale(hw->enc_w[L], (size_t)C[L] * C[L + 1]);
+            if (sw[L] == 0.f) { h2_ok = false; sw[L] = 1.f; }
+            h2_unscale[L] = 1.f / (H2_ACT_SCALE * sw[L]);
+        }
+        float *c = &host[o_h2c];
+        const float *x3c = &host[o_x3c];
+        auto fold = [&](float v, float factor) {            // v * factor, factor a power of two: exact unless it leaves the normal range
+            const float r = v * factor;
+            if (!std::isfinite(r) || r / factor != v) h2_ok = false;
+            return r;
+        };
+        memcpy(c, x3c, sizeof(float) * 192);
+        for (int k = 0; k < 64; ++k) { c[192 + k] = fold(x3c[192 + k], H2_ACT_SCALE); c[256 + k] = fold(x3c[256 + k], H2_ACT_SCALE); }
+        const int off[5] = {0, X3_SC1, X3_SC2, X3_SC3, X3_SC4};
+        for (int L = 1; L < ENC_L; ++L)
+            for (int k = 0; k < C[L + 1]; ++k) {
+                // layers 1-3 hand a scaled activation on; layer 4's result is the (unscaled) latent candidate
+                c[off[L] + k] = fold(x3c[off[L] + k], L < 4 ? 1.f / sw[L] : h2_unscale[L]);
+                c[off[L] + C[L + 1] + k] = L < 4 ? fold(x3c[off[L] + C[L + 1] + k], H2_ACT_SCALE) : x3c[off[L] + C[L + 1] + k];
+            }
+        std::vector<uint32_t> img(H2_IMAGE_WORDS, 0u);
+        if (h2_ok) pack_h2(img.data(), hw->enc_w, C, sw);
+        memcpy(&host[o_h2], img.data(), sizeof(uint32_t) * H2_IMAGE_WORDS);
     }
     memcpy(&host[o_v0], hw->dec_w[0], sizeof(float) * 128 * 256);
     memcpy(&host[o_c0], hw->dec_b[0], sizeof(float) * 256);
@@ -258,14 +333,25 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     d.c2 = base + o_c2;
     d.enc_x3 = reinterpret_cast<const unsigned *>(base + o_x3);
     d.enc_x3_consts = base + o_x3c;
-    d.enc_arith = g_default_enc_arith.load();
+    d.enc_h2 = h2_ok ? reinterpret_cast<const unsigned *>(base + o_h2) : nullptr;
+    d.enc_h2_consts = h2_ok ? base + o_h2c : nullptr;
+    memcpy(d.h2_unscale, h2_unscale, sizeof(h2_unscale));
+    d.range_flag = reinterpret_cast<int *>(static_cast<float *>(ae->arena) + o_flag);     // (uploaded as 0)
+    {
+        const int want = g_default_enc_arith.load();
+        d.enc_arith = want < 0 ? (h2_ok ? GEOADV_ENC_ARITH_F16X2 : GEOADV_ENC_ARITH_BF16X3)
+                               : (want == GEOADV_ENC_ARITH_F16X2 && !h2_ok ? GEOADV_ENC_ARITH_BF16X3 : want);
+    }
     *out = ae;
     return GEOADV_OK;
 }
 
 extern "C" int geoadv_ae_set_encoder_arith(geoadv_ae *ae, int arith) {
     GA_REQUIRE(ae, "ae_set_encoder_arith: null handle");
-    GA_REQUIRE(arith == GEOADV_ENC_ARITH_F32 || arith == GEOADV_ENC_ARITH_BF16X3, "ae_set_encoder_arith: unknown arithmetic %d", arith);
+    GA_REQUIRE(known_arith(arith), "ae_set_encoder_arith: unknown arithmetic %d", arith);
+    GA_REQUIRE(arith != GEOADV_ENC_ARITH_F16X2 || ae->d.enc_h2,
+               "ae_set_encoder_arith: this model's weights / batch-norm constants do not scale into the fp16 range exactly "
+               "(non-finite, or a constant that would leave the normal fp32 range): f16x2 is not available for it");
     // an attack handle caches a forward (pool partials, masks) in the tile layout of the arithmetic it ran under and recomputes in
     // it: switching under a live handle would make the two disagree -- refused, not silently accepted
     GA_REQUIRE(arith == ae->d.enc_arith || ae->attack_refs.load() == 0,
@@ -275,8 +361,24 @@ extern "C" int geoadv_ae_set_encoder_arith(geoadv_ae *ae, int arith) {
     return GEOADV_OK;
 }
 extern "C" int geoadv_ae_encoder_arith(const geoadv_ae *ae) { return ae ? ae->d.enc_arith : -1; }
+
+// The f16x2 range guard's verdict (encoder_x3.h): synchronises, reads and clears the model's flag.
+int geoadv::ae_range_check(const geoadv_ae *ae, hipStream_t stream, const char *who) {
+    GA_HIP(hipStreamSynchronize(stream));
+    int flag = 0;
+    GA_HIP(hipMemcpy(&flag, ae->d.range_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (!flag) return GEOADV_OK;
+    GA_HIP(hipMemset(ae->d.range_flag, 0, sizeof(int)));
+    set_error("%s: an encoder forward in the f16x2 arithmetic met an activation of 1023.5 or more (outside the fp16 range of its "
+              "scaled operands): the latents of the clouds concerned were set to +inf.  Use GEOADV_ENC_ARITH_BF16X3 for this model", who);
+    return GEOADV_ERANGE;
+}
+extern "C" int geoadv_ae_status(const geoadv_ae *ae, void *stream) {
+    GA_REQUIRE(ae, "ae_status: null handle");
+    return ae_range_check(ae, static_cast<hipStream_t>(stream), "ae_status");
+}
 extern "C" int geoadv_set_default_encoder_arith(int arith) {
-    GA_REQUIRE(arith == GEOADV_ENC_ARITH_F32 || arith == GEOADV_ENC_ARITH_BF16X3, "set_default_encoder_arith: unknown arithmetic %d", arith);
+    GA_REQUIRE(arith == GEOADV_ENC_ARITH_AUTO || known_arith(arith), "set_default_encoder_arith: unknown arithmetic %d", arith);
     g_default_enc_arith.store(arith);
     return GEOADV_OK;
 }

@@ -868,7 +868,7 @@ extern "C" int geoadv_attack_status(geoadv_attack *at, void *stream) {
                   "the results of this run are invalid");
         return GEOADV_EHIP;
     }
-    return GEOADV_OK;
+    return ae_range_check(at->ae, st, "attack_status");        // the victim's f16x2 range guard (encoder_x3.h)
 }
 
 extern "C" int geoadv_attack_peek(geoadv_attack *at, float *pert, float *adv, float *recon, float *latent, float *grad,

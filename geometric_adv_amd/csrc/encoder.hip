@@ -439,7 +439,7 @@ __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const
     // forward recompute, bit-identical to the forward kernel (canonical accumulation order)
     fwd_layer0<ROWS, true>(pts, bufQ, 68, A, m1);
     __syncthreads();
-    const bool x3 = A.enc_arith == GEOADV_ENC_ARITH_BF16X3;          // (uniform: the arithmetic the forward used, encoder_x3.h)
+    const bool x3 = A.enc_arith != GEOADV_ENC_ARITH_F32;             // (uniform: the arithmetic the forward used, encoder_x3.h)
     if (x3) {
         auto bn_relu = [&](int L, float *out, int s_out, unsigned char *mask, int width) {
             return [=, &A](int row, int c, float a) {
@@ -448,21 +448,32 @@ __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const
                 mask[row * width + c] = v > 0.f;
             };
         };
-        x3_layer_lds<1, ROWS>(bufQ, 68, A.enc_x3, bn_relu(1, bufP, 132, m2, 128));
-        __syncthreads();
-        x3_layer_lds<2, ROWS>(bufP, 132, A.enc_x3, bn_relu(2, bufQ, 132, m3, 128));
-        __syncthreads();
-        x3_layer_lds<3, ROWS>(bufQ, 132, A.enc_x3, bn_relu(3, bufP, 260, m4, 256));
-        __syncthreads();
         // layer 4 forward -> da4 into bufQ, as below
-        x3_layer_lds<4, ROWS>(bufP, 260, A.enc_x3, [&](int row, int c, float a) {
+        auto pool_grad = [&](int row, int c, float a) {
             const float sc = A.scale[4][c];
             const float v = fmaxf(fmaf(a, sc, A.shift[4][c]), 0.f);
             const float zc = z[(size_t)b * 128 + c];
             const int kc = zcnt[(size_t)b * 128 + c];
             const float gz = (kc > 1 ? (1.0f / (float)kc) : 1.0f) * dz[(size_t)b * 128 + c];
             bufQ[row * 132 + c] = (v == zc && v > 0.f) ? gz * sc : 0.f;
-        });
+        };
+        if (A.enc_arith == GEOADV_ENC_ARITH_F16X2) {
+            xp_layer_lds<2, 1, ROWS>(bufQ, 68, A.enc_h2, A.h2_unscale[1], bn_relu(1, bufP, 132, m2, 128));
+            __syncthreads();
+            xp_layer_lds<2, 2, ROWS>(bufP, 132, A.enc_h2, A.h2_unscale[2], bn_relu(2, bufQ, 132, m3, 128));
+            __syncthreads();
+            xp_layer_lds<2, 3, ROWS>(bufQ, 132, A.enc_h2, A.h2_unscale[3], bn_relu(3, bufP, 260, m4, 256));
+            __syncthreads();
+            xp_layer_lds<2, 4, ROWS>(bufP, 260, A.enc_h2, A.h2_unscale[4], pool_grad);
+        } else {
+            xp_layer_lds<3, 1, ROWS>(bufQ, 68, A.enc_x3, 1.f, bn_relu(1, bufP, 132, m2, 128));
+            __syncthreads();
+            xp_layer_lds<3, 2, ROWS>(bufP, 132, A.enc_x3, 1.f, bn_relu(2, bufQ, 132, m3, 128));
+            __syncthreads();
+            xp_layer_lds<3, 3, ROWS>(bufQ, 132, A.enc_x3, 1.f, bn_relu(3, bufP, 260, m4, 256));
+            __syncthreads();
+            xp_layer_lds<3, 4, ROWS>(bufP, 260, A.enc_x3, 1.f, pool_grad);
+        }
     } else {
     fwd_layer<ROWS, 128, true>(bufQ, 68, bufP, 132, A.enc_fwd[1], A.scale[1], A.shift[1], m2, scratch);
     __syncthreads();
@@ -708,7 +719,7 @@ static int set_lds_attr_once() {
 int encoder_fwd_rows(int b, int n) { return (long)b * cdiv(n, 64) < ENC_ROWS32_BELOW * kCUs ? 32 : 64; }
 // pool partials per cloud of a forward launch
 int encoder_tiles(const DeviceAE &A, int b) {
-    return A.enc_arith == GEOADV_ENC_ARITH_BF16X3 ? cdiv(A.n_points, encoder_x3_points(b, A.n_points)) : cdiv(A.n_points, encoder_fwd_rows(b, A.n_points));
+    return A.enc_arith != GEOADV_ENC_ARITH_F32 ? cdiv(A.n_points, encoder_x3_points(b, A.n_points)) : cdiv(A.n_points, encoder_fwd_rows(b, A.n_points));
 }
 int encoder_tiles_max(int n) { return cdiv(n, 32); }              // what the pool-partial buffers are sized for
 
@@ -741,7 +752,7 @@ int launch_encoder_fwd(const DeviceAE &A, int b, const float *x, const float *pe
         GA_REQUIRE(pert && adv_out && fused->m && fused->pert == pert, "encoder_fwd: the fused Adam step needs pert and adv_out");
         fa = *fused;
     }
-    if (A.enc_arith == GEOADV_ENC_ARITH_BF16X3) return launch_encoder_fwd_x3(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);
+    if (A.enc_arith != GEOADV_ENC_ARITH_F32) return launch_encoder_fwd_x3(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);
     const bool small = encoder_fwd_rows(b, A.n_points) == 32;
     if (masks) {
         if (small) launch_fwd2<true, 32>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);

@@ -32,14 +32,17 @@ constexpr int X3_RING = 4, X3_AHEAD = 3;      // ring slots and slots in flight 
 // LDS-DMA comes from inline assembly).
 constexpr int X3_SLOT_STEPS = 1;              // steps per ring slot = per barrier
 constexpr int X3_BIG_WG_PER_CU = 2;
-constexpr int X3_SLOTS = X3_STEPS / X3_SLOT_STEPS, X3_SLOT_WORDS = X3_SLOT_STEPS * X3_STEP_WORDS;
+constexpr int X3_SLOTS = X3_STEPS / X3_SLOT_STEPS;
+__host__ __device__ constexpr int xp_slot_words(int np) { return X3_SLOT_STEPS * xp_step_words(np); }
 static_assert(X3_STEPS % X3_SLOT_STEPS == 0, "whole slots");
 #ifndef X3_SPLIT_HALVES
 #define X3_SPLIT_HALVES 1                     // the split form while 128-point workgroups would cover at most this many halves of the CUs
 #endif                                        // (measured, iteration ms at B = 8 / 16: split 0.0766 / 0.108, wave-private 0.0825 / 0.0935)
-constexpr size_t X3_LDS_BYTES = (size_t)X3_RING * X3_SLOT_WORDS * 4 + sizeof(float) * X3_CONST_FLOATS + (sizeof(float) + 2 * sizeof(int)) * 4 * 128;
-constexpr size_t X3_LDS_BYTES_MASKS = X3_LDS_BYTES + sizeof(unsigned) * 2 * X3_POINTS * MASK_WORDS;
-static_assert(X3_BIG_WG_PER_CU * X3_LDS_BYTES_MASKS <= 160 * 1024, "the workgroups of a CU share its 160 KB of LDS");
+constexpr size_t x3_lds_bytes(int np, bool masks) {
+    return (size_t)X3_RING * xp_slot_words(np) * 4 + sizeof(float) * X3_CONST_FLOATS + (sizeof(float) + 2 * sizeof(int)) * 4 * 128 +
+           (masks ? sizeof(unsigned) * 2 * X3_POINTS * MASK_WORDS : 0);
+}
+static_assert(X3_BIG_WG_PER_CU * x3_lds_bytes(3, true) <= 160 * 1024, "the workgroups of a CU share its 160 KB of LDS");
 
 // LDS-DMA of 16 bytes per lane: lane l's bytes land at lds_dst + 16 l (lds_dst wave-uniform).  Inline assembly, not
 // __builtin_amdgcn_global_load_lds: with the builtin the compiler knows the LDS is being written and puts an s_waitcnt vmcnt(0)
@@ -110,16 +113,17 @@ __device__ __forceinline__ void x3_store_point(const X3Point &o, float *adv_out,
 // layer 0's constants and the (scale, shift) pairs of layers 1-4 -> LDS: a straight copy of the block ae.hip packs in this
 // order (X3_CONST_FLOATS floats; two 16-byte loads per thread, all in flight at once -- gathering them from the seven arrays
 // cost seven dependent round trips, 1.5 us of every workgroup's prologue)
-__device__ __forceinline__ void x3_stage_constants(const DeviceAE &A, float *cst, int threads) {
-    const float4 *src = reinterpret_cast<const float4 *>(A.enc_x3_consts);
+__device__ __forceinline__ void x3_stage_constants(const float *consts, float *cst, int threads) {
+    const float4 *src = reinterpret_cast<const float4 *>(consts);
     float4 *dst = reinterpret_cast<float4 *>(cst);
     for (int e = threadIdx.x; e < X3_CONST_FLOATS / 4; e += threads) dst[e] = src[e];
 }
 
 // Layer 0 (fan-in 3) on the VALU: fwd_layer0's arithmetic (encoder.hip), 32 channels per lane = the k slots it feeds to layer 1.
 // m01: this lane's bits of mask words 0 and 1 (channel 16 kb + 8 h + j = bit (kb & 1) * 16 + 8 h + j of word kb / 2).
-template <bool MASKS>
-__device__ __forceinline__ void x3_layer0(const float *cst, const float (&pc)[3], int h, X3 (&act1)[4], unsigned (&m01)[2]) {
+// (f16x2: scale0 / shift0 arrive multiplied by H2_ACT_SCALE, v is the scaled activation; gmax: the range guard's running maximum)
+template <int NP, bool MASKS>
+__device__ __forceinline__ void x3_layer0(const float *cst, const float (&pc)[3], int h, XP<NP> (&act1)[4], unsigned (&m01)[2], float &gmax) {
     const float4 *c4 = reinterpret_cast<const float4 *>(cst);
     m01[0] = m01[1] = 0u;
 #pragma unroll
@@ -146,7 +150,7 @@ __device__ __forceinline__ void x3_layer0(const float *cst, const float (&pc)[3]
             v[j] = fmaxf(fmaf(a, sc[j], sh[j]), 0.f);
             if (MASKS) m8 = x3_push_positive(m8, v[j]);          // j descending: bit j = [v[j] > 0]
         }
-        x3_split8(v, act1[kb]);
+        xp_split8(v, act1[kb], gmax);
         if (MASKS) m01[kb >> 1] |= m8 << ((kb & 1) * 16 + 8 * h);
     }
 }
@@ -154,8 +158,8 @@ __device__ __forceinline__ void x3_layer0(const float *cst, const float (&pc)[3]
 // BN + ReLU + split of HALF a channel block of a layer result (acc: lane = point, registers = channels 32 cb + 8 g + 4 h + u;
 // gh = 0: g = 0, 1; gh = 1: g = 2, 3): the pieces of the next layer's sixteen-k block 2 cb + gh; m16 collects the mask bits.
 // sc, sh: the layer's scale / shift at channel 32 cb + 4 h (LDS).
-template <bool MASKS>
-__device__ __forceinline__ void x3_epilogue_half(const f32x16 &acc, const float *sc_p, const float *sh_p, int gh, X3 &dst, unsigned &m16) {
+template <int NP, bool MASKS>
+__device__ __forceinline__ void x3_epilogue_half(const f32x16 &acc, const float *sc_p, const float *sh_p, int gh, XP<NP> &dst, unsigned &m16, float &gmax) {
     const float4 *s4 = reinterpret_cast<const float4 *>(sc_p), *t4 = reinterpret_cast<const float4 *>(sh_p);
 #pragma unroll
     for (int gg = 1; gg >= 0; --gg) {
@@ -171,11 +175,7 @@ __device__ __forceinline__ void x3_epilogue_half(const f32x16 &acc, const float 
             for (int u = 3; u >= 0; --u) m16 = x3_push_positive(m16, v[u]);   // within a half: bit 4 gg + u
         }
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            unsigned a, bq, c;
-            x3_split_pair(v[2 * w], v[2 * w + 1], a, bq, c);
-            dst.p[0][2 * gg + w] = a; dst.p[1][2 * gg + w] = bq; dst.p[2][2 * gg + w] = c;
-        }
+        for (int w = 0; w < 2; ++w) xp_split_pair(v[2 * w], v[2 * w + 1], dst, 2 * gg + w, gmax);
     }
 }
 // this lane's bits of a channel block's mask word from the bits of the two halves (bit 4 gg + u each): channel 8 g + 4 h + u
@@ -185,12 +185,15 @@ __device__ __forceinline__ unsigned x3_mask_bits(unsigned m_lo, unsigned m_hi, i
     return spread << (4 * h);
 }
 
-template <bool MASKS>
+template <int NP, bool MASKS>
 __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
                                                                     float *pmax, int *parg, int *pcnt, unsigned *masks, FusedAdam fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_w[];
-    unsigned *ring = lds_w;                                                  // [X3_RING][X3_SLOT_STEPS][12 fragments][64 lanes][4 words]
-    float *cst = reinterpret_cast<float *>(ring + X3_RING * X3_SLOT_WORDS);   // X3_CONST_FLOATS
+    using XPN = XP<NP>;
+    using NPc = std::integral_constant<int, NP>;
+    constexpr int STEP_WORDS = xp_step_words(NP), SLOT_WORDS = xp_slot_words(NP);
+    unsigned *ring = lds_w;                                                  // [X3_RING][X3_SLOT_STEPS][4 NP fragments][64 lanes][4 words]
+    float *cst = reinterpret_cast<float *>(ring + X3_RING * SLOT_WORDS);      // X3_CONST_FLOATS
     float *redm = cst + X3_CONST_FLOATS;                                      // [4][128]
     int *reda = reinterpret_cast<int *>(redm + 4 * 128), *redc = reda + 4 * 128;
     unsigned *mtile = reinterpret_cast<unsigned *>(redc + 4 * 128);          // [2][X3_POINTS][MASK_WORDS] (MASKS)
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     const int p = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
     const int n0 = tile * X3_POINTS + wave * 32;                              // this wave's first point
-    const unsigned *img = A.enc_x3;
+    const unsigned *img = xp_image(A, NPc{});
+    float gmax = 0.f;                                                         // f16x2: largest scaled activation this lane split
     GA_STAMP(0, 0);
 
     // ---- the wave's points ----
@@ -210,20 +214,20 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
         if (h == 0) x3_store_point(pt, adv_out, fa);      // (the two lanes of a point belong to one wave: both have loaded)
         pc[0] = pt.v[0]; pc[1] = pt.v[1]; pc[2] = pt.v[2];
     }
-    x3_stage_constants(A, cst, X3_THREADS);
+    x3_stage_constants(xp_consts(A, NPc{}), cst, X3_THREADS);
     __syncthreads();                                   // constants visible; nothing of the ring is in flight yet
     GA_STAMP(0, 1);
 
     // ---- the weight ring ----
-    // fetch(t): this wave's fragments (the three pieces of channel block `wave`, 1 KiB each, lane-linear) of the steps of slot t
+    // fetch(t): this wave's fragments (the NP pieces of channel block `wave`, 1 KiB each, lane-linear) of the steps of slot t
     auto fetch = [&](int t) {
 #pragma unroll
         for (int u = 0; u < X3_SLOT_STEPS; ++u) {
             const int s = t * X3_SLOT_STEPS + u;
-            const unsigned *src = img + (size_t)s * X3_STEP_WORDS + wave * 3 * X3_FRAG_WORDS + lane * 4;
-            unsigned *dst = ring + (t % X3_RING) * X3_SLOT_WORDS + u * X3_STEP_WORDS + wave * 3 * X3_FRAG_WORDS;
+            const unsigned *src = img + (size_t)s * STEP_WORDS + wave * NP * X3_FRAG_WORDS + lane * 4;
+            unsigned *dst = ring + (t % X3_RING) * SLOT_WORDS + u * STEP_WORDS + wave * NP * X3_FRAG_WORDS;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) x3_glds16(src + q * X3_FRAG_WORDS, dst + q * X3_FRAG_WORDS);
+            for (int q = 0; q < NP; ++q) x3_glds16(src + q * X3_FRAG_WORDS, dst + q * X3_FRAG_WORDS);
         }
     };
 #pragma unroll
@@ -234,27 +238,27 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     unsigned *mrow = mtile + ((size_t)h * X3_POINTS + wave * 32 + p) * MASK_WORDS;
 
     // ---- layer 0 ----
-    X3 act1[4];
+    XPN act1[4];
     {
         unsigned m01[2];
-        x3_layer0<MASKS>(cst, pc, h, act1, m01);
+        x3_layer0<NP, MASKS>(cst, pc, h, act1, m01, gmax);
         if (MASKS) { mrow[0] = m01[0]; mrow[1] = m01[1]; }
     }
 
     GA_STAMP(0, 2);
     // ---- the step machinery ----
     // Before the first fragment read of slot t (steps 2 t, 2 t + 1): this wave's fetches up to slot t + 1 have landed (counted
-    // vmcnt: at most the six of slot t + 2 stay in flight), then the barrier -- after it EVERY wave's share of slots <= t + 1 is in
+    // vmcnt: at most the 2 NP of slot t + 2 stay in flight), then the barrier -- after it EVERY wave's share of slots <= t + 1 is in
     // LDS and every wave is done with slot t - 1, which the fetch of slot t + 3 now overwrites.
-    X3 wcur, wnext;                                    // fragments of (step, channel block) in use / requested
-    auto frag_read = [&](X3 &d, int s, int cb) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(ring + ((s / X3_SLOT_STEPS) % X3_RING) * X3_SLOT_WORDS + (s % X3_SLOT_STEPS) * X3_STEP_WORDS +
-                                                           cb * 3 * X3_FRAG_WORDS) + lane;
+    XPN wcur, wnext;                                   // fragments of (step, channel block) in use / requested
+    auto frag_read = [&](XPN &d, int s, int cb) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(ring + ((s / X3_SLOT_STEPS) % X3_RING) * SLOT_WORDS + (s % X3_SLOT_STEPS) * STEP_WORDS +
+                                                           cb * NP * X3_FRAG_WORDS) + lane;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) d.p[q] = src[q * 64];
+        for (int q = 0; q < NP; ++q) d.p[q] = src[q * 64];
     };
     auto slot_sync = [&](int t) {
-        if (t + X3_AHEAD - 1 < X3_SLOTS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * X3_SLOT_STEPS) : "memory");
+        if (t + X3_AHEAD - 1 < X3_SLOTS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP * X3_SLOT_STEPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     // step (the epilogue of the channel block the NEXT steps consume), placed inside the step so that it can issue between the
     // MFMAs; `after0`: work on acc[0] once its chain is complete (a layer's last step: the first half-epilogues of the boundary
     // ride under the other three blocks' MFMAs instead of standing alone)
-    auto step = [&](auto act_is_a, int s, const X3 &a, f32x16 (&acc)[4], auto side, auto after0) {
+    auto step = [&](auto act_is_a, int s, const XPN &a, f32x16 (&acc)[4], auto side, auto after0) {
         constexpr bool ACT_IS_A = decltype(act_is_a)::value;
         if (s % X3_SLOT_STEPS == 0) slot_sync(s / X3_SLOT_STEPS);
         if (s == 0) frag_read(wcur, 0, 0);
@@ -273,22 +277,22 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
         for (int cb = 0; cb < 4; ++cb) {
             if (cb < 3) frag_read(wnext, s, cb + 1);
             else if (s + 1 < X3_STEPS) frag_read(wnext, s + 1, 0);   // (legal: the slot of step s + 1 landed before this slot's barrier)
-            x3_mfma6<ACT_IS_A>(wcur, a, acc[cb]);
+            xp_mfma<ACT_IS_A>(wcur, a, acc[cb]);
             if (cb == 0) after0();
             if (cb < 3 || s + 1 < X3_STEPS) wcur = wnext;
         }
     };
     auto nothing = [] {};
-    auto epilogue_half = [&](const f32x16 &acc, int cb, int gh, const float *scsh /* [scale[C] | shift[C]] */, int C, int coff, X3 &dst,
+    auto epilogue_half = [&](const f32x16 &acc, int cb, int gh, const float *scsh /* [scale[C] | shift[C]] */, int C, int coff, XPN &dst,
                              unsigned &m16) {
-        x3_epilogue_half<MASKS>(acc, scsh + coff + 32 * cb + 4 * h, scsh + C + coff + 32 * cb + 4 * h, gh, dst, m16);
+        x3_epilogue_half<NP, MASKS>(acc, scsh + coff + 32 * cb + 4 * h, scsh + C + coff + 32 * cb + 4 * h, gh, dst, m16, gmax);
     };
     auto mask_store = [&](int word, unsigned m_lo, unsigned m_hi) { mrow[word] = x3_mask_bits(m_lo, m_hi, h); };
     using ActB = std::integral_constant<bool, false>;
     using ActA = std::integral_constant<bool, true>;
 
     // The pieces of channel block 0 of a finished layer, made under that layer's last step (step's `after0`).
-    X3 first[2];
+    XPN first[2];
     auto first_epilogue = [&](f32x16 (&accs)[4], const float *scsh, int C, int coff, int mask_word) {
         return [&, scsh, C, coff, mask_word] {
             unsigned ml = 0, mh = 0;
@@ -300,9 +304,9 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     // A layer boundary, software-pipelined: the epilogue of channel block cb + 1 of the finished layer (`prev`) rides in the two
     // steps of the next layer that consume block cb's pieces (block 0's are in `first`).  keep: where the pieces are kept for a
     // later pass (h3), or null.  last_after0: the next boundary's first_epilogue, or nothing.
-    auto boundary = [&](auto act_is_a, f32x16 (&prev)[4], const float *scsh, int C, int coff, int mask_off, int s0, f32x16 (&next)[4], X3 *keep,
+    auto boundary = [&](auto act_is_a, f32x16 (&prev)[4], const float *scsh, int C, int coff, int mask_off, int s0, f32x16 (&next)[4], XPN *keep,
                         auto last_after0) {
-        X3 cur[2] = {first[0], first[1]}, nxt[2];
+        XPN cur[2] = {first[0], first[1]}, nxt[2];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
             unsigned nl = 0, nh = 0;
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     boundary(ActB{}, acc1, cst + X3_SC1, 128, 0, MASK_OFF2, 4, acc2, nullptr, first_epilogue(acc2, cst + X3_SC2, 128, 0, MASK_OFF3));
     GA_STAMP(0, 4);
     // ---- layers 3 + 4 by halves: h4[:, 128 half ..] feeds K half `half` of layer 4 (one chain over K = 256, ascending) ----
-    X3 act3[8];
+    XPN act3[8];
     boundary(ActB{}, acc2, cst + X3_SC2, 128, 0, MASK_OFF3, 12, acc3, act3, first_epilogue(acc3, cst + X3_SC3, 256, 0, MASK_OFF4));   // layer 3, channels 0 .. 127 (steps 12-19)
     boundary(ActA{}, acc3, cst + X3_SC3, 256, 0, MASK_OFF4, 20, acc4, nullptr, nothing);                                             // layer 4, K half 0 (steps 20-27)
     GA_STAMP(0, 5);
@@ -341,6 +345,10 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
     boundary(ActA{}, acc3, cst + X3_SC3, 256, 128, MASK_OFF4 + 4, 36, acc4, nullptr, nothing);                                       // layer 4, K half 1 (steps 36-43)
 
     GA_STAMP(0, 6);
+    // f16x2's range guard: a wave that split a scaled activation beyond the fp16 range gives +inf as its pool maxima (the latent,
+    // the reconstruction and every loss of that cloud become inf / NaN) and raises the model's flag -- never a silent wrong number
+    const bool tripped = NP == 2 && __builtin_amdgcn_ballot_w64(gmax > H2_ACT_LIMIT) != 0;
+    if (tripped && lane == 0) atomicOr(A.range_flag, 1);
     // ---- layer 4's BN + ReLU and the max-pool from the registers (lane = channel 32 cb + p, registers = points) ----
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
@@ -368,6 +376,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
         const int a2 = __shfl_xor(arg, 32), k2 = __shfl_xor(cnt, 32);
         if (m2 > mx) { mx = m2; arg = a2; cnt = k2; }
         else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += k2; }
+        if (tripped) { mx = INFINITY; arg = n0 < n ? n0 : n - 1; cnt = 1; }
         if (h == 0) { redm[wave * 128 + col] = mx; reda[wave * 128 + col] = arg; redc[wave * 128 + col] = cnt; }
     }
     __syncthreads();
@@ -406,16 +415,20 @@ __global__ __launch_bounds__(X3_THREADS, X3_BIG_WG_PER_CU) void encoder_fwd3_ker
 // workgroup per CU anyway (B <= 4 at N = 2048), <6 steps (72 registers: 236 in all), two workgroups per CU> beyond -- the second
 // workgroup's exchanges and prologue run under the first one's MFMAs (B = 8: 0.0761 -> 0.0691 ms per iteration; B = 4 with the
 // shallower run-ahead: 0.0634 -> 0.0641).
-constexpr int X3S_XBUF_WORDS = 8 * 3 * X3_FRAG_WORDS;                        // one layer's pieces: 8 sixteen-k blocks x 3 x 1 KiB
-constexpr size_t X3S_LDS_BYTES = 2 * X3S_XBUF_WORDS * 4 + sizeof(float) * (X3_CONST_FLOATS + 32 * 3);
-constexpr size_t X3S_LDS_BYTES_MASKS = X3S_LDS_BYTES + sizeof(unsigned) * 32 * MASK_WORDS;
+__host__ __device__ constexpr int x3s_xbuf_words(int np) { return 8 * np * X3_FRAG_WORDS; }   // one layer's pieces: 8 sixteen-k blocks x NP x 1 KiB
+constexpr size_t x3s_lds_bytes(int np, bool masks) {
+    return 2 * x3s_xbuf_words(np) * 4 + sizeof(float) * (X3_CONST_FLOATS + 32 * 3) + (masks ? sizeof(unsigned) * 32 * MASK_WORDS : 0);
+}
 
-template <bool MASKS, int X3S_AHEAD, int WG_PER_CU>
+template <int NP, bool MASKS, int X3S_AHEAD, int WG_PER_CU>
 __global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(DeviceAE A, int n, const float *x, const float *pert, float *adv_out,
                                                                      float *pmax, int *parg, int *pcnt, unsigned *masks, FusedAdam fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_w[];
-    unsigned *xbuf = lds_w;                                                  // [2][8][3][64 lanes][4 words]
-    float *cst = reinterpret_cast<float *>(xbuf + 2 * X3S_XBUF_WORDS);
+    using XPN = XP<NP>;
+    using NPc = std::integral_constant<int, NP>;
+    constexpr int STEP_WORDS = xp_step_words(NP), XBUF_WORDS = x3s_xbuf_words(NP);
+    unsigned *xbuf = lds_w;                                                  // [2][8][NP][64 lanes][4 words]
+    float *cst = reinterpret_cast<float *>(xbuf + 2 * XBUF_WORDS);
     float *pcs = cst + X3_CONST_FLOATS;                                      // [32][3] the unit's points
     unsigned *mtile = reinterpret_cast<unsigned *>(pcs + 32 * 3);            // [32 points][MASK_WORDS] (MASKS)
 
@@ -424,13 +437,14 @@ __global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(De
     const int tile = blockIdx.x, b = blockIdx.y, tiles = gridDim.x;
     const int n0 = tile * 32;
     GA_STAMP(1, 0);
-    // this wave's fragments of step s: 3 KiB at a fixed stride -- buffer loads with the step as an immediate offset
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(A.enc_x3) + wave * 3 * X3_FRAG_WORDS, 0, 0x7fffffff, 0x00020000);
+    // this wave's fragments of step s: NP KiB at a fixed stride -- buffer loads with the step as an immediate offset
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(xp_image(A, NPc{})) + wave * NP * X3_FRAG_WORDS, 0, 0x7fffffff, 0x00020000);
     const unsigned lb = (unsigned)lane * 16u;
-    X3 wr[X3S_AHEAD];
+    float gmax = 0.f;
+    XPN wr[X3S_AHEAD];
     auto fetch = [&](int s) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) wr[s % X3S_AHEAD].p[q] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, lb, (s * X3_STEP_WORDS + q * X3_FRAG_WORDS) * 4, 0);
+        for (int q = 0; q < NP; ++q) wr[s % X3S_AHEAD].p[q] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, lb, (s * STEP_WORDS + q * X3_FRAG_WORDS) * 4, 0);
     };
     // the unit's points: wave 0 loads them (and applies / stores the pending Adam step), the others take them from LDS; the small
     // loads go first (loads return in order: behind thirty weight fragments they would wait for all of those)
@@ -442,7 +456,7 @@ __global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(De
             pcs[p * 3] = pt.v[0]; pcs[p * 3 + 1] = pt.v[1]; pcs[p * 3 + 2] = pt.v[2];
         }
     }
-    x3_stage_constants(A, cst, X3_THREADS);
+    x3_stage_constants(xp_consts(A, NPc{}), cst, X3_THREADS);
 #pragma unroll
     for (int s = 0; s < X3S_AHEAD; ++s) fetch(s);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a raw barrier: __syncthreads()'s fence would drain the weight loads)
@@ -451,29 +465,29 @@ __global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(De
     float pc[3] = {pcs[p * 3], pcs[p * 3 + 1], pcs[p * 3 + 2]};
     GA_STAMP(1, 1);
 
-    X3 act1[4];
+    XPN act1[4];
     {
         unsigned m01[2];
-        x3_layer0<MASKS>(cst, pc, h, act1, m01);
+        x3_layer0<NP, MASKS>(cst, pc, h, act1, m01, gmax);
         if (MASKS && wave == 0) {
             m01[0] |= __shfl_xor(m01[0], 32); m01[1] |= __shfl_xor(m01[1], 32);
             if (h == 0) { mtile[p * MASK_WORDS] = m01[0]; mtile[p * MASK_WORDS + 1] = m01[1]; }
         }
     }
-    auto step = [&](auto act_is_a, int s, const X3 &a, f32x16 &acc) {
+    auto step = [&](auto act_is_a, int s, const XPN &a, f32x16 &acc) {
         constexpr bool ACT_IS_A = decltype(act_is_a)::value;
-        x3_mfma6<ACT_IS_A>(wr[s % X3S_AHEAD], a, acc);
+        xp_mfma<ACT_IS_A>(wr[s % X3S_AHEAD], a, acc);
         if (s + X3S_AHEAD < X3_STEPS) fetch(s + X3S_AHEAD);
     };
     // epilogue of this wave's channel block -> the pieces of sixteen-k blocks 2 w, 2 w + 1 into exchange buffer `buf`, then all eight back
-    auto exchange = [&](const f32x16 &acc, const float *scsh, int C, int coff, int mask_word, int buf, X3 (&out)[8]) {
-        X3 lo, hi;
+    auto exchange = [&](const f32x16 &acc, const float *scsh, int C, int coff, int mask_word, int buf, XPN (&out)[8]) {
+        XPN lo, hi;
         unsigned ml = 0, mh = 0;
-        x3_epilogue_half<MASKS>(acc, scsh + coff + 32 * wave + 4 * h, scsh + C + coff + 32 * wave + 4 * h, 0, lo, ml);
-        x3_epilogue_half<MASKS>(acc, scsh + coff + 32 * wave + 4 * h, scsh + C + coff + 32 * wave + 4 * h, 1, hi, mh);
-        u32x4 *xb = reinterpret_cast<u32x4 *>(xbuf + buf * X3S_XBUF_WORDS) + lane;
+        x3_epilogue_half<NP, MASKS>(acc, scsh + coff + 32 * wave + 4 * h, scsh + C + coff + 32 * wave + 4 * h, 0, lo, ml, gmax);
+        x3_epilogue_half<NP, MASKS>(acc, scsh + coff + 32 * wave + 4 * h, scsh + C + coff + 32 * wave + 4 * h, 1, hi, mh, gmax);
+        u32x4 *xb = reinterpret_cast<u32x4 *>(xbuf + buf * XBUF_WORDS) + lane;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { xb[((2 * wave) * 3 + q) * 64] = lo.p[q]; xb[((2 * wave + 1) * 3 + q) * 64] = hi.p[q]; }
+        for (int q = 0; q < NP; ++q) { xb[((2 * wave) * NP + q) * 64] = lo.p[q]; xb[((2 * wave + 1) * NP + q) * 64] = hi.p[q]; }
         if (MASKS) {
             unsigned m = x3_mask_bits(ml, mh, h);
             m |= __shfl_xor(m, 32);
@@ -486,12 +500,12 @@ __global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(De
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) out[kb].p[q] = xb[(kb * 3 + q) * 64];
+            for (int q = 0; q < NP; ++q) out[kb].p[q] = xb[(kb * NP + q) * 64];
     };
     using ActB = std::integral_constant<bool, false>;
     using ActA = std::integral_constant<bool, true>;
 
-    X3 act2[8], act3[8], act4[8];
+    XPN act2[8], act3[8], act4[8];
     {
         f32x16 acc = {};
 #pragma unroll
@@ -519,6 +533,8 @@ __global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(De
         for (int kb = 0; kb < 8; ++kb) step(ActA{}, (half ? 36 : 20) + kb, act4[kb], acc4);
     }
     GA_STAMP(1, 6);
+    const bool tripped = NP == 2 && __builtin_amdgcn_ballot_w64(gmax > H2_ACT_LIMIT) != 0;   // (the range guard, as above: this wave's channels)
+    if (tripped && lane == 0) atomicOr(A.range_flag, 1);
     {   // BN + ReLU and the pool of this wave's 32 channels over the unit's 32 points
         const int col = 32 * wave + p;
         const float sc4 = cst[X3_SC4 + col], sh4 = cst[X3_SC4 + 128 + col];
@@ -544,6 +560,7 @@ __global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(De
         const int a2 = __shfl_xor(arg, 32), k2 = __shfl_xor(cnt, 32);
         if (m2 > mx) { mx = m2; arg = a2; cnt = k2; }
         else if (m2 == mx) { arg = a2 < arg ? a2 : arg; cnt += k2; }
+        if (tripped) { mx = INFINITY; arg = n0 < n ? n0 : n - 1; cnt = 1; }
         if (h == 0) {
             const size_t o = ((size_t)b * tiles + tile) * 128 + col;
             pmax[o] = mx; parg[o] = arg; pcnt[o] = cnt;
@@ -562,27 +579,28 @@ __global__ __launch_bounds__(X3_THREADS, WG_PER_CU) void encoder_fwd3s_kernel(De
 // half of the CUs without one.
 int encoder_x3_points(int b, int n) { return (long)b * cdiv(n, X3_POINTS) * 2 <= (long)X3_SPLIT_HALVES * kCUs ? 32 : X3_POINTS; }
 
-int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg,
-                          int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const FusedAdam &fa) {
+template <int NP>
+static int launch_encoder_fwd_xp(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg,
+                                 int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const FusedAdam &fa) {
     static DeviceOnce attr;
     if (int rc = attr.run([]() -> int {
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES_MASKS));
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES));
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<true, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES_MASKS));
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<false, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES));
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<true, 6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES_MASKS));
-            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<false, 6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3S_LDS_BYTES));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes(NP, true)));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3_kernel<NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes(NP, false)));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<NP, true, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3s_lds_bytes(NP, true)));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<NP, false, 10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3s_lds_bytes(NP, false)));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<NP, true, 6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3s_lds_bytes(NP, true)));
+            GA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(encoder_fwd3s_kernel<NP, false, 6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3s_lds_bytes(NP, false)));
             return GEOADV_OK;
         })) return rc;
     const dim3 block(X3_THREADS);
     if (encoder_x3_points(b, A.n_points) == 32) {
         const dim3 grid(cdiv(A.n_points, 32), b);
-        const unsigned lds = (unsigned)(masks ? X3S_LDS_BYTES_MASKS : X3S_LDS_BYTES);
+        const unsigned lds = (unsigned)x3s_lds_bytes(NP, masks != nullptr);
         const bool two = (long)grid.x * b > kCUs;          // more workgroups than CUs: two per CU
 #define X3S_LAUNCH(M, AH, W)                                                                                                                     \
         do {                                                                                                                                      \
-            if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3s_kernel<M, AH, W>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa); \
-            else encoder_fwd3s_kernel<M, AH, W><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);      \
+            if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3s_kernel<NP, M, AH, W>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa); \
+            else encoder_fwd3s_kernel<NP, M, AH, W><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);  \
         } while (0)
         if (masks) { if (two) X3S_LAUNCH(true, 6, 2); else X3S_LAUNCH(true, 10, 1); }
         else { if (two) X3S_LAUNCH(false, 6, 2); else X3S_LAUNCH(false, 10, 1); }
@@ -591,16 +609,23 @@ int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float 
         return GEOADV_OK;
     }
     const dim3 grid(cdiv(A.n_points, X3_POINTS), b);
-    const unsigned lds = (unsigned)(masks ? X3_LDS_BYTES_MASKS : X3_LDS_BYTES);
+    const unsigned lds = (unsigned)x3_lds_bytes(NP, masks != nullptr);
     if (masks) {
-        if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3_kernel<true>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
-        else encoder_fwd3_kernel<true><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+        if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3_kernel<NP, true>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+        else encoder_fwd3_kernel<NP, true><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
     } else {
-        if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3_kernel<false>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
-        else encoder_fwd3_kernel<false><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+        if (start && stop) hipExtLaunchKernelGGL((encoder_fwd3_kernel<NP, false>), grid, block, lds, stream, start, stop, 0, A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
+        else encoder_fwd3_kernel<NP, false><<<grid, block, lds, stream>>>(A, A.n_points, x, pert, adv_out, pmax, parg, pcnt, masks, fa);
     }
     GA_LAUNCH_CHECK();
     return GEOADV_OK;
+}
+
+// the forward in the model's piece arithmetic (bf16x3 or f16x2: DeviceAE::enc_arith)
+int launch_encoder_fwd_x3(const DeviceAE &A, int b, const float *x, const float *pert, float *adv_out, float *pmax, int *parg,
+                          int *pcnt, unsigned *masks, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const FusedAdam &fa) {
+    if (A.enc_arith == GEOADV_ENC_ARITH_F16X2) return launch_encoder_fwd_xp<2>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);
+    return launch_encoder_fwd_xp<3>(A, b, x, pert, adv_out, pmax, parg, pcnt, masks, stream, start, stop, fa);
 }
 
 }  // namespace geoadv

@@ -31,6 +31,7 @@ extern "C" {
 #define GEOADV_EINVAL  1   /* bad shape / argument                      */
 #define GEOADV_EHIP    2   /* a HIP runtime call or kernel launch failed */
 #define GEOADV_ENOMEM  3
+#define GEOADV_ERANGE  4   /* a value left the range an arithmetic was set up for (geoadv_ae_status) */
 
 int         geoadv_version(void);                /* 1000*major + minor */
 const char *geoadv_last_error(void);
@@ -255,13 +256,29 @@ void geoadv_ae_destroy(geoadv_ae *ae);
  *            weight >= 2^-16, each exact in the fp32 accumulator, on v_mfma_f32_32x32x16_bf16 (csrc/encoder_x3.h).  Error
  *            against float64 = that of an fp32 accumulation in another order (profiles/r05_bf16x3_probe.jsonl); not the
  *            bits of F32.  Non-finite coordinates give NaN activations (inf - inf in the split) where F32 gives inf.
- * Both reproduce themselves bit for bit (forward, recomputing backward, any batch).  The default of handles created from
- * now on / of one handle (set before it is shared with attack handles or threads). */
+ *   F16X2  : every operand as TWO fp16 pieces (11 + 11 bits; remainder < 2^-23) of power-of-two-scaled values, a product as its
+ *            three piece products of weight >= 2^-11, each exact in the fp32 accumulator, on v_mfma_f32_32x32x16_f16: half of
+ *            BF16X3's matrix instructions, the same error against float64 (profiles/r06_f16x2_probe.jsonl: 0.44-0.52 units of
+ *            2^-24 |a|.|w| rms, the fp32 chain's).  Activations are carried times 2^6, a layer's weights times the power of two
+ *            that puts the largest in [2^13, 2^14); RANGE: an activation of 1023.5 or more does not fit -- the kernels check
+ *            every activation they split, and a cloud that has one gets +inf latents (so that nothing downstream looks sane)
+ *            and raises the model's sticky flag: geoadv_ae_status / geoadv_attack_status then return GEOADV_ERANGE.  Batch-
+ *            normalised ReLU activations are O(1-10); a model that trips the guard runs under BF16X3.  Not available (set
+ *            refuses, the default falls back to BF16X3) for a model with a non-finite weight or a folded constant outside the
+ *            normal fp32 range.
+ * All reproduce themselves bit for bit (forward, recomputing backward, any batch).  The default of handles created from
+ * now on (AUTO, the initial setting: F16X2 where available, else BF16X3) / of one handle (set before it is shared with attack
+ * handles or threads). */
+#define GEOADV_ENC_ARITH_AUTO  (-1)
 #define GEOADV_ENC_ARITH_F32    0
 #define GEOADV_ENC_ARITH_BF16X3 1
+#define GEOADV_ENC_ARITH_F16X2  2
 int  geoadv_set_default_encoder_arith(int arith);
 int  geoadv_ae_set_encoder_arith(geoadv_ae *ae, int arith);
 int  geoadv_ae_encoder_arith(const geoadv_ae *ae);
+/* Synchronises `stream`; GEOADV_ERANGE (message in geoadv_last_error; the flag is cleared) if an F16X2 forward of this model since
+ * the last call met an activation outside its range, else GEOADV_OK.  Callers that synchronise anyway (to read results) call it. */
+int  geoadv_ae_status(const geoadv_ae *ae, void *stream);
 
 /* AdversaryAutoEncoder.reconstruct / AutoEncoder.transform (adversary_autoencoder.py:75-91):
  * pc[b,n,3] -> latent[b,bneck] (may be NULL) and recon[b,n,3] (may be NULL).
@@ -375,7 +392,8 @@ int geoadv_attack_set_source_search(geoadv_attack *at, int on);
 /* Health of the run since the last set_inputs / init_pert: synchronises the stream and returns GEOADV_EHIP (message in
  * geoadv_last_error) if an in-launch hand-off of the loop ever gave up waiting -- the bounded spin of the dense encoder backward
  * on its cloud's decoder-tail flag; never observed, but a run after it would have used a stale gradient.  geoadv_attack_get_best
- * additionally NaN-fills the metrics of such a run.  Callers that synchronise anyway (to download results) call this first. */
+ * additionally NaN-fills the metrics of such a run.  Also GEOADV_ERANGE if the victim's F16X2 range guard tripped (geoadv_ae_status).
+ * Callers that synchronise anyway (to download results) call this first. */
 int geoadv_attack_status(geoadv_attack *at, void *stream);
 
 /* Introspection for tests: copies of the current device state (any pointer may be NULL).

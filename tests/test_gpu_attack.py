@@ -329,8 +329,11 @@ def test_emd_combined_loss_step(setup, reference_weights):
 def test_masked_backward_equals_recomputing_backward(setup, n):
     """The sparse encoder backward reads the ReLU masks the forward left behind (16-row tiles on the 16x16x4 MFMA shape); with
     Configuration(recompute_backward=True) it re-runs the forward for the critical rows instead (32-row tiles, 32x32x2).  The same products in
-    two summation orders: the first iteration's gradient agrees to 2e-6 of its largest component, and the perturbation
-    after 6 Adam steps to 1e-4 of its size (also for a ragged point count, whose last tile is partly empty)."""
+    two summation orders: from ONE state -- the perturbation of the masked run after 0 ... 5 Adam steps -- the two gradients agree to
+    2e-6 of their largest component (also for a ragged point count, whose last tile is partly empty), and the perturbations after
+    that step to 1e-3 of their size.  (Two six-step TRAJECTORIES are not compared: they differ by ~1e-5 after a step, and one
+    nearest-neighbour or critical-point switch that only one of them sees by iteration 5 is a 1e-3 difference under any of the
+    encoder arithmetics -- tools/debug/recompute_spread.py.)"""
     import torch
     from geometric_adv_amd import weights as W
     from geometric_adv_amd.autoencoder import PointNetAE
@@ -339,21 +342,30 @@ def test_masked_backward_equals_recomputing_backward(setup, n):
     ae = PointNetAE(w, n)
     b = 3
     x, gt = _clouds(71, b, n)
-    grads, outs = [], []
-    for recompute in (False, True):
-        at = AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=6, num_iterations_thresh=3,
-                                              recompute_backward=recompute), ae=ae)
-        at.set_inputs(x, gt, None, 1.0)
-        at.init_pert(None, reset_optimizer=True)
-        at.run(0, 1, 3)
-        grads.append(at.peek()["grad"].clone())
-        at.run(1, 5, 3)
-        outs.append(at.peek()["pert"].clone())
-    sc = grads[1].abs().amax((1, 2), keepdim=True)
-    assert (sc > 0).all()
-    torch.testing.assert_close(grads[0] / sc, grads[1] / sc, rtol=0, atol=2e-6)
-    assert outs[0].abs().max() > 0
-    torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-4 * outs[1].abs().max().item())
+    make = lambda recompute: AdvAE("adversary", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=6, num_iterations_thresh=3,
+                                                              recompute_backward=recompute), ae=ae)
+    lead = make(False)
+    lead.set_inputs(x, gt, None, 1.0)
+    lead.init_pert(None, reset_optimizer=True)
+    for it in range(6):
+        state = lead.peek()["pert"].cpu().numpy()
+        grads, outs = [], []
+        for recompute in (False, True):
+            at = make(recompute)
+            at.set_inputs(x, gt, None, 1.0)
+            at.init_pert(state, reset_optimizer=True)
+            at.run(0, 1, 3)
+            pk = at.peek()
+            grads.append(pk["grad"].clone())
+            outs.append(pk["pert"].clone())
+        sc = grads[1].abs().amax((1, 2), keepdim=True)
+        assert (sc > 0).all()
+        torch.testing.assert_close(grads[0] / sc, grads[1] / sc, rtol=0, atol=2e-6)
+        # (the step itself is Adam's first, lr * g / (|g| + eps'): a component whose gradient is ~0 moves by anything up to lr
+        # on a 1e-6 difference, so the perturbations are held to 1e-3 of their size only)
+        assert outs[0].abs().max() > 0
+        torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-3 * outs[1].abs().max().item())
+        lead.run(it, 1, 3)
 
 
 @pytest.mark.parametrize("n,form", [(2048, "auto"), (256, "masked"), (256, "jacobian")])

@@ -48,7 +48,19 @@ def test_forward_latent_decode_and_attack_step_at_other_bottlenecks(oracle, bnec
         at.run(0, 1, 1, hist)
         got = at.peek()["grad"].cpu().numpy()
         sc = np.abs(g).reshape(b, -1).max(1)[:, None, None]
-        np.testing.assert_allclose(got / sc, g / sc, atol=2e-4, err_msg=adv_type)
+        # a critical point the fp32 pool picks differently from the fp64 model's is legitimate where the two candidates are within
+        # fp32 rounding of each other (1e-6 relative): the gradient of that channel then lands on the other row -- those rows are
+        # left out of the comparison (under f16x2 one channel of cloud 3 at bneck = 64: 0.187058724 against 0.187058745)
+        adv64 = (x + p0).astype(np.float64)
+        h5 = model.encode(adv64, keep=True)[1][-1]
+        arg64, crit = h5.argmax(axis=1), ae.max_and_argmax((x + p0).astype(np.float32))[1].cpu().numpy()
+        keep = np.ones((b, n), dtype=bool)
+        for bb, c in np.argwhere((crit != arg64) & (h5.max(axis=1) > 0)):
+            top = h5[bb, arg64[bb, c], c]
+            assert top - h5[bb, crit[bb, c], c] <= 1e-6 * top, (bb, c)
+            keep[bb, crit[bb, c]] = keep[bb, arg64[bb, c]] = False
+        assert keep.sum() >= b * n - 8
+        np.testing.assert_allclose((got / sc)[keep], (g / sc)[keep], atol=2e-4, err_msg=adv_type)
 
 
 def test_wider_bottlenecks_are_refused_with_the_reason():

@@ -1,14 +1,15 @@
-"""GPU: the encoder's two arithmetics (include/geoadv.h GEOADV_ENC_ARITH_*).
+"""GPU: the encoder's three arithmetics (include/geoadv.h GEOADV_ENC_ARITH_*).
 
-bf16x3 (the default) forms every fp32 product as six bf16 piece products on the bf16 matrix pipe; f32 is the fp32 MFMA.
-Both are checked against the float64 model of the reference encoder (oracle/attack_model.py, src/encoders_decoders.py:37-72)
-at the same tolerance, against each other, and each against itself across batch sizes / kernel forms (bit for bit)."""
+f16x2 (the default) forms every fp32 product as three fp16 piece products of power-of-two-scaled operands on the fp16 matrix
+pipe, bf16x3 as six bf16 piece products; f32 is the fp32 MFMA.  All are checked against the float64 model of the reference
+encoder (oracle/attack_model.py, src/encoders_decoders.py:37-72) at the same tolerance, against each other, and each against
+itself across batch sizes / kernel forms (bit for bit); f16x2's range guard is driven to trip."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-ARITHS = ("bf16x3", "f32")
+ARITHS = ("f16x2", "bf16x3", "f32")
 
 
 def _models(n, seed=3):
@@ -35,6 +36,7 @@ def test_latent_of_both_arithmetics_against_the_float64_model(n, b):
     for a in ARITHS:
         np.testing.assert_allclose(got[a] / scale, z64 / scale, atol=2e-6, err_msg=a)
     np.testing.assert_allclose(got["bf16x3"], got["f32"], atol=2e-6 * np.abs(got["f32"]).max())
+    np.testing.assert_allclose(got["f16x2"], got["f32"], atol=2e-6 * np.abs(got["f32"]).max())
 
 
 @pytest.mark.parametrize("arith", ARITHS)
@@ -121,9 +123,13 @@ def test_arithmetic_selection_api():
     a = aes["f32"]
     a.set_encoder_arith("bf16x3")
     assert a.encoder_arith == "bf16x3" and torch.equal(a.forward(pc, want_recon=False)[1], z["bf16x3"])
+    a.set_encoder_arith("f16x2")
+    assert a.encoder_arith == "f16x2" and torch.equal(a.forward(pc, want_recon=False)[1], z["f16x2"])
     a.set_encoder_arith("f32")
     assert a.encoder_arith == "f32" and torch.equal(a.forward(pc, want_recon=False)[1], z["f32"])
     lib = _lib.lib()
+    from geometric_adv_amd.autoencoder import PointNetAE
+    assert PointNetAE(w, n).encoder_arith == "f16x2"                   # the library default (AUTO) on a sane model
     assert lib.geoadv_ae_set_encoder_arith(a.handle, 7) != 0 and a.encoder_arith == "f32"
     assert lib.geoadv_set_default_encoder_arith(7) != 0
     with pytest.raises(KeyError):
@@ -138,3 +144,71 @@ def test_arithmetic_selection_api():
     gc.collect()
     a.set_encoder_arith("bf16x3")
     assert a.encoder_arith == "bf16x3"
+
+
+def _scaled_model(n, factor, seed=9):
+    """randomized weights with layer 0's batch-norm gamma / beta multiplied by `factor` and layer 1's weights divided by it:
+    layer 0's activations grow by the factor, everything behind them stays what it was."""
+    from geometric_adv_amd import weights as W
+    w = dict(W.randomized_weights(n, seed=seed))
+    for k in ("autoencoder/encoder_conv_layer_0_bnorm/gamma", "autoencoder/encoder_conv_layer_0_bnorm/beta"):
+        w[k] = (np.asarray(w[k], dtype=np.float64) * factor).astype(np.float32)
+    k = "autoencoder/encoder_conv_layer_1/W"
+    w[k] = (np.asarray(w[k], dtype=np.float64) / factor).astype(np.float32)
+    return w
+
+
+@pytest.mark.parametrize("b", [2, 40])
+def test_f16x2_range_guard_trips_loudly_and_only_when_it_must(b):
+    """Layer 0's activations scaled up: while the largest stays under 1023.5 f16x2 still agrees with the float64 model; beyond
+    it the forward gives +inf latents for the clouds concerned (never a plausible number), geoadv_ae_status reports
+    GEOADV_ERANGE once (the flag is cleared), transform() raises, and bf16x3 runs the same model."""
+    import torch
+    from geometric_adv_amd import _lib, weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from oracle.attack_model import AEModel
+    from conftest import cloud
+    n = 2048
+    pc = cloud(71, b, n)
+    base = AEModel(W.canonical(W.randomized_weights(n, seed=9), n), n, np.float64)
+    h1 = np.maximum((pc.astype(np.float64) @ base.W[0] + base.b[0]) * base.scale[0] + base.offset[0], 0)
+    top = float(h1.max())
+    lib = _lib.lib()
+    # just inside the range
+    f_in = 900.0 / top
+    w_in = _scaled_model(n, f_in)
+    ae = PointNetAE(w_in, n, encoder_arith="f16x2")
+    z = ae.forward(pc, want_recon=False)[1].cpu().numpy()
+    assert lib.geoadv_ae_status(ae.handle, _lib.stream_handle()) == 0
+    z64 = AEModel(W.canonical(w_in, n), n, np.float64).encode(pc.astype(np.float64))
+    np.testing.assert_allclose(z / np.abs(z64).max(), z64 / np.abs(z64).max(), atol=2e-6)
+    # beyond it
+    f_out = 1100.0 / top
+    w_out = _scaled_model(n, f_out)
+    ae = PointNetAE(w_out, n, encoder_arith="f16x2")
+    z = ae.forward(pc, want_recon=False)[1].cpu().numpy()
+    assert np.isinf(z).any() and not np.isnan(z).any()
+    assert lib.geoadv_ae_status(ae.handle, _lib.stream_handle()) == 4          # GEOADV_ERANGE
+    assert b"f16x2" in lib.geoadv_last_error()
+    assert lib.geoadv_ae_status(ae.handle, _lib.stream_handle()) == 0          # reported once
+    with pytest.raises(RuntimeError):
+        ae.transform(pc)
+    ae3 = PointNetAE(w_out, n, encoder_arith="bf16x3")
+    z3 = ae3.transform(pc)
+    z64 = AEModel(W.canonical(w_out, n), n, np.float64).encode(pc.astype(np.float64))
+    np.testing.assert_allclose(z3 / np.abs(z64).max(), z64 / np.abs(z64).max(), atol=2e-6)
+
+
+def test_f16x2_is_refused_for_a_model_that_does_not_scale():
+    """A non-finite encoder weight: the library default falls back to bf16x3 and an explicit f16x2 is refused with a message."""
+    from geometric_adv_amd import _lib, weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    n = 256
+    w = dict(W.randomized_weights(n, seed=2))
+    k = "autoencoder/encoder_conv_layer_2/W"
+    a = np.array(w[k], dtype=np.float32); a[0, 0, 3, 5] = np.inf
+    w[k] = a
+    ae = PointNetAE(w, n)
+    assert ae.encoder_arith == "bf16x3"
+    assert _lib.lib().geoadv_ae_set_encoder_arith(ae.handle, 2) != 0
+    assert b"f16x2" in _lib.lib().geoadv_last_error()

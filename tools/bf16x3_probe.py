@@ -38,7 +38,7 @@ def check(rc):
 def accuracy():
     dev = "cuda"
     g = torch.Generator().manual_seed(5)
-    names = {0: "f32_mfma_chain", 1: "bf16x3_6term_rne", 2: "bf16x3_9term_rne", 3: "bf16x3_6term_trunc", 4: "bf16x2_3term_rne"}
+    names = {0: "f32_mfma_chain", 1: "bf16x3_6term_rne", 2: "bf16x3_9term_rne", 3: "bf16x3_6term_trunc", 4: "bf16x2_3term_rne", 5: "f16x2_3term", 6: "f16x2_4term", 7: "f16x2_3term_subnormal_second_pieces"}
     for K in (64, 128, 256):
         tiles = 512
         A = torch.randn(tiles, 32, K, generator=g).clamp_min(0).contiguous()
@@ -104,6 +104,21 @@ def shapes():
             print(json.dumps({"probe": "shapes", "shape": name, "workgroups": blocks, "ms": round(ms.value, 5), "bf16_tflops": round(flops / ms.value / 1e9, 1)}), flush=True)
 
 
+def throughput_h2():
+    """The f16x2 encoder's loop shape (tp_h2_kernel): 12 MFMAs and 8 fragment reads per step; random fp16 operands."""
+    st = torch.cuda.current_stream().cuda_stream
+    for (fill, gap) in ((300, 0), (303, 0), (306, 0), (303, 40000)):
+        ms, gms = C.c_float(0), C.c_float(0)
+        check(lib.bf16x3_throughput(fill, 0, 512, 44, 2, 200, gap, C.byref(ms), C.byref(gms), C.c_void_p(st)))
+        mfmas = 512 * 4 * 2 * 44 * 12
+        flops = mfmas * 32 * 32 * 16 * 2
+        print(json.dumps({"probe": "throughput_f16x2", "valu_per_mfma": fill - 300, "weights_from": "lds", "gap_kernel_ms": round(gms.value, 4),
+                          "ms": round(ms.value, 5), "f16_tflops": round(flops / ms.value / 1e9, 1),
+                          "cycles_per_mfma_at_2p4GHz": round(ms.value * 1e-3 * 2.4e9 / (2 * 44 * 12) / 2, 2),
+                          "emulated_f32_tflops": round(flops / 3 / ms.value / 1e9, 1),
+                          "note": "512 workgroups x 4 waves x 2 units x 44 steps x 12 MFMAs = the B = 32 encoder's MFMA count in the f16x2 arithmetic"}), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "accuracy"):
@@ -114,3 +129,5 @@ if __name__ == "__main__":
         chains()
     if what in ("all", "shapes"):
         shapes()
+    if what in ("all", "f16x2"):
+        throughput_h2()

@@ -52,6 +52,18 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&p)[3]) {
 
 // C[tile][32][32] = A[tile][32][K] @ B[K][32]; one wave per tile.  mode 0: fp32 MFMA chain (ascending k); 1: 6 bf16 piece
 // products per 16 k (small terms first); 2: all 9; 3: 6 terms, truncation split; 4: 3 terms only (a0b0, a0b1, a1b0: "bf16x2")
+// modes 5 / 6: two fp16 pieces per operand (11 + 11 significant bits) of operands scaled by powers of two (activations 2^8,
+// weights 2^15: the second pieces stay normal fp16 numbers), 3 products (a0b0, a0b1, a1b0) / all 4, on v_mfma_f32_32x32x16_f16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8h(const float (&x)[8], float scale, f16x8 (&p)[2]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = x[j] * scale;
+        const _Float16 h0 = (_Float16)v;
+        const _Float16 h1 = (_Float16)(v - (float)h0);
+        p[0][j] = h0; p[1][j] = h1;
+    }
+}
 template <int MODE>
 __global__ __launch_bounds__(64) void acc_kernel(const float *A, const float *B, float *C, int K) {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
@@ -59,6 +71,20 @@ __global__ __launch_bounds__(64) void acc_kernel(const float *A, const float *B,
     f32x16 acc = {};
     if (MODE == 0) {
         for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r * K + k + h], B[(k + h) * 32 + r], acc, 0, 0, 0);
+    } else if (MODE >= 5) {
+        for (int k = 0; k < K; k += 16) {
+            float xa[8], xb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xa[j] = a[r * K + k + 8 * h + j]; xb[j] = B[(k + 8 * h + j) * 32 + r]; }
+            f16x8 pa[2], pb[2];
+            split8h(xa, MODE == 7 ? 1.f / 64.f : 256.f, pa); split8h(xb, 32768.f, pb);
+            if (MODE == 6) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[1], pb[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[1], pb[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[0], pb[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[0], pb[0], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] *= MODE == 7 ? 64.f / 32768.f : 1.f / (256.f * 32768.f);
     } else {
         constexpr bool RNE = MODE != 3;
         for (int k = 0; k < K; k += 16) {
@@ -97,6 +123,9 @@ extern "C" int bf16x3_accuracy(int mode, const float *A, const float *B, float *
         case 2: acc_kernel<2><<<tiles, 64, 0, st>>>(A, B, C, K); break;
         case 3: acc_kernel<3><<<tiles, 64, 0, st>>>(A, B, C, K); break;
         case 4: acc_kernel<4><<<tiles, 64, 0, st>>>(A, B, C, K); break;
+        case 5: acc_kernel<5><<<tiles, 64, 0, st>>>(A, B, C, K); break;
+        case 6: acc_kernel<6><<<tiles, 64, 0, st>>>(A, B, C, K); break;
+        case 7: acc_kernel<7><<<tiles, 64, 0, st>>>(A, B, C, K); break;   // activations scaled DOWN: their second pieces are fp16 subnormals
         default: snprintf(g_err, sizeof g_err, "mode"); return 1;
     }
     PR_HIP(hipGetLastError());
@@ -223,6 +252,58 @@ __global__ __launch_bounds__(256, 1) void tp16_kernel(const u32x4 *wimg, float *
     if (sink == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = sink;
 }
 
+// The f16x2 encoder's loop shape: per 16-k step 2 pieces of 4 channel blocks from LDS (8 ds_read_b128) and 12 MFMAs (4 accumulators
+// x 3 piece products) on v_mfma_f32_32x32x16_f16 against 2 activation pieces; otherwise tp_kernel.
+template <int FILL>
+__global__ __launch_bounds__(256, 1) void tp_h2_kernel(const u32x4 *wimg, float *out, int steps, int units) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 wl[];        // [4 steps][12 fragments][64 lanes] (8 of the 12 read)
+    const int lane = threadIdx.x & 63;
+    for (int e = threadIdx.x; e < 4 * 12 * 64; e += 256) wl[e] = wimg[e];
+    __syncthreads();
+    f16x8 act[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) act[q] = __builtin_bit_cast(f16x8, wimg[(q * 5 + 1) * 64 + lane]);
+    float sink = 0.f;
+    for (int u = 0; u < units; ++u) {
+        f32x16 acc[4] = {};
+        float f[8] = {1.f + lane, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+        f16x8 w[4][2], wn[4][2];
+        auto fetch = [&](f16x8 (&d)[4][2], int s) {
+            const u32x4 *wp = wl + (s & 3) * 12 * 64 + lane;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) d[cb][q] = __builtin_bit_cast(f16x8, wp[(cb * 2 + q) * 64]);
+        };
+        fetch(w, 0);
+        for (int s = 0; s < steps; ++s) {
+            fetch(wn, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int wa[3] = {0, 1, 0}, xa[3] = {1, 0, 0};
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cb][wa[t]], act[xa[t]], acc[cb], 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < FILL; ++v) f[(v + cb) & 7] = fmaf(f[(v + cb) & 7], 1.0001f, 0.5f);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) w[cb][q] = wn[cb][q];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sink += acc[cb][q];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) sink += f[v];
+    }
+    if (sink == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = sink;
+}
+
 // a VALU-only kernel of a chosen length, launched between the probes to give the chip the attack's duty cycle
 __global__ __launch_bounds__(256) void idle_kernel(float *out, int iters) {
     float a = threadIdx.x, b = 1.0001f;
@@ -242,7 +323,7 @@ extern "C" int bf16x3_throughput(int fill, int src, int blocks, int steps, int u
         PR_HIP(hipMalloc(&out, 1 << 22));
         uint32_t *h = (uint32_t *)malloc(n * 16);
         uint32_t s = 12345u;
-        for (size_t i = 0; i < n * 4; ++i) {                      // random bf16 pairs of magnitude ~[0.25, 4)
+        for (size_t i = 0; i < n * 4; ++i) {                      // random bf16 pairs of magnitude ~[0.25, 4) (as fp16: normal numbers ~2^-15 .. 2^-11)
             uint32_t w = 0;
             for (int k = 0; k < 2; ++k) {
                 s = s * 1664525u + 1013904223u;
@@ -257,7 +338,8 @@ extern "C" int bf16x3_throughput(int fill, int src, int blocks, int steps, int u
     auto launch = [&](void) {
         const size_t lds = n * sizeof(u32x4);
 #define TP(F, S) tp_kernel<F, S><<<blocks, 256, lds, st>>>(wimg, out, steps, units)
-        if (fill >= 200) { if (fill == 200) tp16_kernel<0><<<blocks, 256, lds, st>>>(wimg, out, steps / 2, units); else tp16_kernel<3><<<blocks, 256, lds, st>>>(wimg, out, steps / 2, units); }
+        if (fill >= 300) { if (fill == 300) tp_h2_kernel<0><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else if (fill == 303) tp_h2_kernel<3><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else tp_h2_kernel<6><<<blocks, 256, lds, st>>>(wimg, out, steps, units); }
+        else if (fill >= 200) { if (fill == 200) tp16_kernel<0><<<blocks, 256, lds, st>>>(wimg, out, steps / 2, units); else tp16_kernel<3><<<blocks, 256, lds, st>>>(wimg, out, steps / 2, units); }
         else if (fill >= 100) { if (fill == 100) tp_kernel<0, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else if (fill == 101) tp_kernel<0, 0, 2><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else tp_kernel<3, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); }
         else if (src == 0) { if (fill == 0) TP(0, 0); else if (fill == 2) TP(2, 0); else if (fill == 3) TP(3, 0); else if (fill == 4) TP(4, 0); else TP(6, 0); }
         else { if (fill == 0) TP(0, 1); else TP(3, 1); }
