@@ -5,7 +5,7 @@ import numpy as np, torch
 from geometric_adv_amd import weights as W, _lib
 from geometric_adv_amd.autoencoder import PointNetAE
 B, n = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 2048
-ae = PointNetAE(W.randomized_weights(n, seed=3), n)
+ae = PointNetAE(W.randomized_weights(n, seed=3), n, encoder_arith=os.environ.get("ARITH"))     # None: the library default
 pc = torch.rand(B, n, 3, device="cuda") - 0.5
 for _ in range(20):
     ae.forward(pc, want_recon=False)
