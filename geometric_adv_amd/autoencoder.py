@@ -187,6 +187,7 @@ class PointNetAE:
         """autoencoder.py:296-307: reconstructions of (N,K,3) clouds, fed `batch_size` at a time like the reference (the result
         does not depend on the chunking: every cloud is reconstructed on its own)."""
         out = [self.forward(pclouds[s:s + batch_size])[0].cpu().numpy() for s in range(0, len(pclouds), batch_size)]
+        self.status()
         return np.vstack(out)
 
     def get_loss(self, X, GT=None):
@@ -194,6 +195,7 @@ class PointNetAE:
         nn_distance(reconstruct(X), GT or X) over the whole batch, a python float."""
         recon, _ = self.forward(X)
         d1, _, d2, _ = ops.nn_distance(recon, self._as_dev(X if GT is None else GT))
+        self.status()
         return float((d1.mean() + d2.mean()).item())
 
     def gradient_of_input_wrt_loss(self, in_points, gt_points=None):
@@ -224,4 +226,5 @@ class PointNetAE:
         """autoencoder.py:150-168: per-cloud Chamfer reconstruction error as numpy."""
         recon, _ = self.forward(feed_data)
         gt = self._as_dev(feed_data if orig_data is None else orig_data)
+        self.status()
         return self.loss_per_pc_tensor(recon, gt).cpu().numpy()

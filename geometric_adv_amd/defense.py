@@ -98,9 +98,13 @@ def _to_numpy(d):
 
 def defend_surface(ae, adversarial_pc, source_pc, num_knn=8, top_k=2, knn_dist_thresh=0.04):
     """defend_surface_device for numpy callers (one download per result array at the end)."""
-    return _to_numpy(defend_surface_device(ae, adversarial_pc, source_pc, num_knn, top_k, knn_dist_thresh))
+    out = defend_surface_device(ae, adversarial_pc, source_pc, num_knn, top_k, knn_dist_thresh)
+    ae.status()                                  # (the f16x2 encoder's range guard: raises instead of returning +inf-born numbers)
+    return _to_numpy(out)
 
 
 def defend_critical(ae, adversarial_pc, source_pc):
     """defend_critical_device for numpy callers."""
-    return _to_numpy(defend_critical_device(ae, adversarial_pc, source_pc))
+    out = defend_critical_device(ae, adversarial_pc, source_pc)
+    ae.status()
+    return _to_numpy(out)

@@ -191,8 +191,22 @@ def test_f16x2_range_guard_trips_loudly_and_only_when_it_must(b):
     assert lib.geoadv_ae_status(ae.handle, _lib.stream_handle()) == 4          # GEOADV_ERANGE
     assert b"f16x2" in lib.geoadv_last_error()
     assert lib.geoadv_ae_status(ae.handle, _lib.stream_handle()) == 0          # reported once
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="f16x2"):
         ae.transform(pc)
+    # the attack on such a model: status() (which attack() calls before it returns anything) raises, defend_* raise
+    from geometric_adv_amd._lib import GeoAdvError
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd import defense
+    at = AdvAE("a", Configuration(batch_size=b, n_points=n, weights=w_out, num_iterations=2, num_iterations_thresh=1), ae=ae)
+    at.set_inputs(pc, cloud(72, b, n), None, 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    at.run(0, 2, 1, torch.empty((2, 6, b), device=ae.device))
+    with pytest.raises(GeoAdvError, match="f16x2"):
+        at.status()
+    at.status()                                                         # (cleared)
+    with pytest.raises(GeoAdvError, match="f16x2"):
+        defense.defend_critical(ae, pc, pc)
+    del at
     ae3 = PointNetAE(w_out, n, encoder_arith="bf16x3")
     z3 = ae3.transform(pc)
     z64 = AEModel(W.canonical(w_out, n), n, np.float64).encode(pc.astype(np.float64))
