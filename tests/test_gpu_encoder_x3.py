@@ -226,3 +226,49 @@ def test_f16x2_is_refused_for_a_model_that_does_not_scale():
     assert ae.encoder_arith == "bf16x3"
     assert _lib.lib().geoadv_ae_set_encoder_arith(ae.handle, 2) != 0
     assert b"f16x2" in _lib.lib().geoadv_last_error()
+
+
+def test_arithmetics_on_a_trained_victim_and_its_adversarial_clouds():
+    """A victim trained with the repo's trainer (batch statistics folded into moving averages, activations no longer those of the
+    random initialisation): latents of clean and of attacked clouds under every arithmetic against the float64 model at the
+    path's 2e-6, the range guard quiet, and the largest activation the float64 model sees two orders of magnitude inside f16x2's
+    range."""
+    import torch
+    from geometric_adv_amd import _lib, weights as W
+    from geometric_adv_amd.adv_ae import AdvAE, Configuration
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from geometric_adv_amd.trainer import PointNetAETrainer, initial_weights
+    from oracle.attack_model import AEModel
+    n, b = 512, 8
+    rng = np.random.default_rng(0)
+
+    def shapes(count):
+        u = rng.standard_normal((count, n, 3)).astype(np.float32)
+        u /= np.linalg.norm(u, axis=2, keepdims=True)
+        scale = rng.uniform(0.15, 0.45, size=(count, 1, 3)).astype(np.float32)
+        return (u * scale).astype(np.float32)
+
+    data = shapes(64)
+    tr = PointNetAETrainer(initial_weights(n, seed=2), n, batch_size=b, learning_rate=0.002)
+    for _ in range(12):
+        tr._single_epoch_train(data)
+    w = tr.export_weights()
+    del tr
+    model = AEModel(W.canonical(w, n), n, np.float64)
+    src, tgt = shapes(b), shapes(b)
+    ae = PointNetAE(w, n)
+    assert ae.encoder_arith == "f16x2"
+    at = AdvAE("a", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=40, num_iterations_thresh=20, learning_rate=0.01), ae=ae)
+    at.set_inputs(src, tgt, ae.transform(tgt), 1.0)
+    at.init_pert(None, reset_optimizer=True)
+    at.run(0, 40, 20, torch.empty((40, 6, b), device=ae.device))
+    at.status()
+    adv = at.peek()["adv"].cpu().numpy()
+    for pcs in (src, adv):
+        z64, hs = model.encode(pcs.astype(np.float64), keep=True)
+        assert max(float(h.max()) for h in hs) < 10.0                   # (1023.5 is the guard)
+        sc = np.abs(z64).max()
+        for arith in ARITHS:
+            a = PointNetAE(w, n, encoder_arith=arith)
+            np.testing.assert_allclose(a.transform(pcs) / sc, z64 / sc, atol=2e-6, err_msg=arith)
+            assert _lib.lib().geoadv_ae_status(a.handle, _lib.stream_handle()) == 0
