@@ -7,7 +7,7 @@ from geometric_adv_amd.autoencoder import PointNetAE
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 n = 2048
-ae = PointNetAE(W.randomized_weights(n, seed=3), n, encoder_arith=os.environ.get("ARITH", "bf16x3"))
+ae = PointNetAE(W.randomized_weights(n, seed=3), n, encoder_arith=os.environ.get("ARITH"))     # None: the library default (f16x2)
 pc = torch.rand(B, n, 3, device="cuda") - 0.5
 for _ in range(reps):
     ae.transform_tensor(pc) if hasattr(ae, "transform_tensor") else ae.forward(pc, want_recon=False)
