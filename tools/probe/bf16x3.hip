@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256, 1) void tp16_kernel(const u32x4 *wimg, float *
 
 // The f16x2 encoder's loop shape: per 16-k step 2 pieces of 4 channel blocks from LDS (8 ds_read_b128) and 12 MFMAs (4 accumulators
 // x 3 piece products) on v_mfma_f32_32x32x16_f16 against 2 activation pieces; otherwise tp_kernel.
-template <int FILL>
-__global__ __launch_bounds__(256, 1) void tp_h2_kernel(const u32x4 *wimg, float *out, int steps, int units) {
+template <int FILL, int WG_PER_CU = 1, int ORDER = 1>
+__global__ __launch_bounds__(256, WG_PER_CU) void tp_h2_kernel(const u32x4 *wimg, float *out, int steps, int units) {
     extern __shared__ __attribute__((aligned(16))) u32x4 wl[];        // [4 steps][12 fragments][64 lanes] (8 of the 12 read)
     const int lane = threadIdx.x & 63;
     for (int e = threadIdx.x; e < 4 * 12 * 64; e += 256) wl[e] = wimg[e];
@@ -280,14 +280,25 @@ __global__ __launch_bounds__(256, 1) void tp_h2_kernel(const u32x4 *wimg, float 
             fetch(wn, s + 1);
             __builtin_amdgcn_sched_barrier(0);
             constexpr int wa[3] = {0, 1, 0}, xa[3] = {1, 0, 0};
+            if (ORDER == 1) {                   // the kernel's order: the three products of an accumulator back to back
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+                for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cb][wa[t]], act[xa[t]], acc[cb], 0, 0, 0);
+                    for (int t = 0; t < 3; ++t) {
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cb][wa[t]], act[xa[t]], acc[cb], 0, 0, 0);
 #pragma unroll
-                    for (int v = 0; v < FILL; ++v) f[(v + cb) & 7] = fmaf(f[(v + cb) & 7], 1.0001f, 0.5f);
-                }
+                        for (int v = 0; v < FILL; ++v) f[(v + cb) & 7] = fmaf(f[(v + cb) & 7], 1.0001f, 0.5f);
+                    }
+            } else {                            // the four accumulators interleaved: consecutive MFMAs independent
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cb][wa[t]], act[xa[t]], acc[cb], 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < FILL; ++v) f[(v + cb) & 7] = fmaf(f[(v + cb) & 7], 1.0001f, 0.5f);
+                    }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
@@ -338,7 +349,14 @@ extern "C" int bf16x3_throughput(int fill, int src, int blocks, int steps, int u
     auto launch = [&](void) {
         const size_t lds = n * sizeof(u32x4);
 #define TP(F, S) tp_kernel<F, S><<<blocks, 256, lds, st>>>(wimg, out, steps, units)
-        if (fill >= 300) { if (fill == 300) tp_h2_kernel<0><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else if (fill == 303) tp_h2_kernel<3><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else tp_h2_kernel<6><<<blocks, 256, lds, st>>>(wimg, out, steps, units); }
+        if (fill >= 310) {              // 31x: two workgroups per CU (two waves per SIMD); 32x: one, accumulators interleaved; 33x: two, interleaved
+            if (fill == 310) tp_h2_kernel<0, 2><<<blocks, 256, lds, st>>>(wimg, out, steps, units);
+            else if (fill == 313) tp_h2_kernel<3, 2><<<blocks, 256, lds, st>>>(wimg, out, steps, units);
+            else if (fill == 320) tp_h2_kernel<0, 1, 0><<<blocks, 256, lds, st>>>(wimg, out, steps, units);
+            else if (fill == 330) tp_h2_kernel<0, 2, 0><<<blocks, 256, lds, st>>>(wimg, out, steps, units);
+            else tp_h2_kernel<3, 2, 0><<<blocks, 256, lds, st>>>(wimg, out, steps, units);
+        }
+        else if (fill >= 300) { if (fill == 300) tp_h2_kernel<0><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else if (fill == 303) tp_h2_kernel<3><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else tp_h2_kernel<6><<<blocks, 256, lds, st>>>(wimg, out, steps, units); }
         else if (fill >= 200) { if (fill == 200) tp16_kernel<0><<<blocks, 256, lds, st>>>(wimg, out, steps / 2, units); else tp16_kernel<3><<<blocks, 256, lds, st>>>(wimg, out, steps / 2, units); }
         else if (fill >= 100) { if (fill == 100) tp_kernel<0, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else if (fill == 101) tp_kernel<0, 0, 2><<<blocks, 256, lds, st>>>(wimg, out, steps, units); else tp_kernel<3, 0, 1><<<blocks, 256, lds, st>>>(wimg, out, steps, units); }
         else if (src == 0) { if (fill == 0) TP(0, 0); else if (fill == 2) TP(2, 0); else if (fill == 3) TP(3, 0); else if (fill == 4) TP(4, 0); else TP(6, 0); }
