@@ -272,3 +272,33 @@ def test_arithmetics_on_a_trained_victim_and_its_adversarial_clouds():
             a = PointNetAE(w, n, encoder_arith=arith)
             np.testing.assert_allclose(a.transform(pcs) / sc, z64 / sc, atol=2e-6, err_msg=arith)
             assert _lib.lib().geoadv_ae_status(a.handle, _lib.stream_handle()) == 0
+
+
+@pytest.mark.parametrize("log2_factor", [-40, 30])
+def test_f16x2_weight_scaling_follows_the_layer(log2_factor):
+    """One layer's weights and bias multiplied by 2^k with its batch-norm mean multiplied and its gamma divided likewise (var is
+    left alone, so the float64 model is rebuilt from the modified weights): the per-layer power of two that f16x2 scales
+    the weights by follows, and the latent stays within the path's 2e-6 of the float64 model."""
+    from geometric_adv_amd import _lib, weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from oracle.attack_model import AEModel
+    from conftest import cloud
+    n, b = 1024, 5
+    f = np.float64(2.0) ** log2_factor
+    w = dict(W.randomized_weights(n, seed=13))
+    for layer in (2, 4):
+        pre = "autoencoder/encoder_conv_layer_%d" % layer
+        var = np.asarray(w[pre + "_bnorm/moving_variance"], dtype=np.float64)
+        w[pre + "/W"] = (np.asarray(w[pre + "/W"], dtype=np.float64) * f).astype(np.float32)
+        w[pre + "/b"] = (np.asarray(w[pre + "/b"], dtype=np.float64) * f).astype(np.float32)
+        w[pre + "_bnorm/moving_mean"] = (np.asarray(w[pre + "_bnorm/moving_mean"], dtype=np.float64) * f).astype(np.float32)
+        w[pre + "_bnorm/moving_variance"] = (var * f * f).astype(np.float32)          # inv = gamma / sqrt(var f^2 + 1e-5)
+    pc = cloud(81, b, n)
+    ae = PointNetAE(w, n)
+    assert ae.encoder_arith == "f16x2"
+    z = ae.transform(pc)
+    z64 = AEModel(W.canonical(w, n), n, np.float64).encode(pc.astype(np.float64))
+    sc = np.abs(z64).max()
+    assert sc > 0 and np.isfinite(z).all()
+    np.testing.assert_allclose(z / sc, z64 / sc, atol=2e-6)
+    assert _lib.lib().geoadv_ae_status(ae.handle, _lib.stream_handle()) == 0
