@@ -832,7 +832,7 @@ class Leg:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         self.at.run(self.W, self.K, self.thresh)                        # no host sync inside
-        metrics, _, _ = self.at.get_best(self.ref)
+        metrics, _, _ = self.at.get_best(self.ref, clouds=False)      # the final loss scalars (the clouds stay where they are)
         self.gathered = gdist.all_gather_examples(metrics[None] if backend == "nccl" else metrics[None].cpu(), axis=1)   # final loss scalars only
         torch.cuda.synchronize()
         gdist.barrier()

@@ -166,12 +166,14 @@ class AdvAE:
             _lib.check(_lib.lib().geoadv_attack_run(self._h, int(first_iteration), int(iterations), int(thresh),
                                                     _lib.ptr(history), _lib.stream_handle()), "attack_run")
 
-    def get_best(self, target_ae_loss_ref):
+    def get_best(self, target_ae_loss_ref, clouds=True):
+        """(metrics [B, 5], best adversarial clouds, their reconstructions) as GPU tensors; clouds=False: the metrics only (the
+        two cloud arrays are None and not copied -- geoadv_attack_get_best takes null pointers for them)."""
         B, n = self.B, self.n
         ref = self._dev(target_ae_loss_ref, (B,))
         metrics = torch.empty((B, 5), dtype=torch.float32, device=self.device)
-        adv = torch.empty((B, n, 3), dtype=torch.float32, device=self.device)
-        recon = torch.empty((B, n, 3), dtype=torch.float32, device=self.device)
+        adv = torch.empty((B, n, 3), dtype=torch.float32, device=self.device) if clouds else None
+        recon = torch.empty((B, n, 3), dtype=torch.float32, device=self.device) if clouds else None
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().geoadv_attack_get_best(self._h, _lib.ptr(ref), _lib.ptr(metrics), _lib.ptr(adv),
                                                          _lib.ptr(recon), _lib.stream_handle()), "attack_get_best")
