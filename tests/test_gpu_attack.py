@@ -188,6 +188,8 @@ def test_keep_best_bookkeeping(setup):
         s = at.peek()
         snaps.append((s["adv"].clone(), s["recon"].clone()))
     metrics, adv, recon = at.get_best(ref)
+    m_only, no_adv, no_recon = at.get_best(ref, clouds=False)           # the metrics alone (what bench.py's timed window fetches)
+    assert no_adv is None and no_recon is None and torch.equal(m_only, metrics)
     h = hist.cpu().numpy()
     metrics = metrics.cpu().numpy()
     for j in range(b):
