@@ -33,7 +33,8 @@ struct DeviceAE {
     const float *enc_x3_consts;    // the x3 forward's LDS constants as one block (encoder_x3.h: X3_CONST_FLOATS)
     const unsigned *enc_h2;        // the same as fp16 piece fragments of the SCALED weights (encoder_x3.h, f16x2); null if the model's
     const float *enc_h2_consts;    // weights / BN constants do not scale exactly (then the arithmetic is refused); its LDS constants
-    float h2_unscale[ENC_L];       // [1..4]: 1 / (H2_ACT_SCALE S_w(L)), the power of two that takes an f16x2 accumulator back
+    float h2_act_scale[ENC_L];     // [0..3]: s_j, the power of two layer j's activations are carried times (2^6 x the layer's batch-norm magnitude)
+    float h2_unscale[ENC_L];       // [1..4]: 1 / (s_{L-1} S_w(L)), the power of two that takes an f16x2 accumulator of layer L back
     int *range_flag;               // device int, sticky: an f16x2 forward saw an activation beyond the fp16 range (geoadv_ae_status)
     int enc_arith;                 // GEOADV_ENC_ARITH_*: which forward (and recompute) arithmetic the encoder kernels use
     const float *scale[ENC_L];     // BN folded: h = max(a*scale + shift, 0), a = x@W (no bias)

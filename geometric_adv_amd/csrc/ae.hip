@@ -248,15 +248,28 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
             memcpy(c + off[i] + C[i + 1], &host[o_shift[i]], sizeof(float) * C[i + 1]);
         }
     }
-    // the f16x2 forward's image and constants: weights scaled by S_w(L), the scales folded into the epilogue's constants
-    // (encoder_x3.h).  Every folded constant must be the exact power-of-two multiple (no under- / overflow): else no f16x2.
-    float sw[ENC_L] = {1.f, 1.f, 1.f, 1.f, 1.f}, h2_unscale[ENC_L] = {1.f, 1.f, 1.f, 1.f, 1.f};
+    // the f16x2 forward's image and constants (encoder_x3.h): weights scaled by S_w(L), the activations a layer hands on by s_j
+    // (below), all of it folded into the epilogue's constants.  Every folded constant must be the exact power-of-two multiple
+    // (no under- / overflow): else no f16x2 for this model.
+    float sw[ENC_L] = {1.f, 1.f, 1.f, 1.f, 1.f}, h2_unscale[ENC_L] = {1.f, 1.f, 1.f, 1.f, 1.f}, act_scale[ENC_L] = {1.f, 1.f, 1.f, 1.f, 1.f};
     bool h2_ok = true;
     {
+        // s_j, the power of two layer j's activations are carried times (j = 0..3): 2^6 for a layer whose batch norm has gamma^2 +
+        // beta^2 = 1 on average -- relu(gamma z + beta) with z ~ N(0, 1) is what a layer trained on such data puts out --, moved with
+        // that magnitude otherwise, so that the fp16 window [2^-9, 1023.5] / 2^6 x t_j sits where the model's own constants say its
+        // activations are (a layer with gamma = 2^-12 would otherwise work on second pieces that are all fp16 subnormals:
+        // tools/debug/h2_low_side.py).  gamma = 1, beta = 0 gives exactly 2^6.
+        for (int j = 0; j < ENC_L - 1; ++j) {
+            double q = 0.0;
+            for (int c = 0; c < C[j + 1]; ++c) q += (double)hw->bn_gamma[j][c] * hw->bn_gamma[j][c] + (double)hw->bn_beta[j][c] * hw->bn_beta[j][c];
+            const double t = std::sqrt(q / C[j + 1]);
+            const int e = (std::isfinite(t) && t > 0.0) ? std::max(-60, std::min(60, (int)std::lround(std::log2(t)))) : 0;   // t ~ 2^e
+            act_scale[j] = ldexpf(1.f, 6 - e);
+        }
         for (int L = 1; L < ENC_L; ++L) {
             sw[L] = h2_weight_scale(hw->enc_w[L], (size_t)C[L] * C[L + 1]);
             if (sw[L] == 0.f) { h2_ok = false; sw[L] = 1.f; }
-            h2_unscale[L] = 1.f / (H2_ACT_SCALE * sw[L]);
+            h2_unscale[L] = 1.f / (act_scale[L - 1] * sw[L]);
         }
         float *c = &host[o_h2c];
         const float *x3c = &host[o_x3c];
@@ -266,13 +279,13 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
             return r;
         };
         memcpy(c, x3c, sizeof(float) * 192);
-        for (int k = 0; k < 64; ++k) { c[192 + k] = fold(x3c[192 + k], H2_ACT_SCALE); c[256 + k] = fold(x3c[256 + k], H2_ACT_SCALE); }
+        for (int k = 0; k < 64; ++k) { c[192 + k] = fold(x3c[192 + k], act_scale[0]); c[256 + k] = fold(x3c[256 + k], act_scale[0]); }
         const int off[5] = {0, X3_SC1, X3_SC2, X3_SC3, X3_SC4};
         for (int L = 1; L < ENC_L; ++L)
             for (int k = 0; k < C[L + 1]; ++k) {
-                // layers 1-3 hand a scaled activation on; layer 4's result is the (unscaled) latent candidate
-                c[off[L] + k] = fold(x3c[off[L] + k], L < 4 ? 1.f / sw[L] : h2_unscale[L]);
-                c[off[L] + C[L + 1] + k] = L < 4 ? fold(x3c[off[L] + C[L + 1] + k], H2_ACT_SCALE) : x3c[off[L] + C[L + 1] + k];
+                // layers 1-3 hand a scaled activation on (s_L a); layer 4's result is the (unscaled) latent candidate
+                c[off[L] + k] = fold(fold(x3c[off[L] + k], h2_unscale[L]), L < 4 ? act_scale[L] : 1.f);
+                c[off[L] + C[L + 1] + k] = L < 4 ? fold(x3c[off[L] + C[L + 1] + k], act_scale[L]) : x3c[off[L] + C[L + 1] + k];
             }
         std::vector<uint32_t> img(H2_IMAGE_WORDS, 0u);
         if (h2_ok) pack_h2(img.data(), hw->enc_w, C, sw);
@@ -336,6 +349,7 @@ extern "C" int geoadv_ae_create(geoadv_ae **out, const geoadv_ae_weights *hw) {
     d.enc_h2 = h2_ok ? reinterpret_cast<const unsigned *>(base + o_h2) : nullptr;
     d.enc_h2_consts = h2_ok ? base + o_h2c : nullptr;
     memcpy(d.h2_unscale, h2_unscale, sizeof(h2_unscale));
+    memcpy(d.h2_act_scale, act_scale, sizeof(act_scale));
     d.range_flag = reinterpret_cast<int *>(static_cast<float *>(ae->arena) + o_flag);     // (uploaded as 0)
     {
         const int want = g_default_enc_arith.load();
@@ -369,8 +383,10 @@ int geoadv::ae_range_check(const geoadv_ae *ae, hipStream_t stream, const char *
     GA_HIP(hipMemcpy(&flag, ae->d.range_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (!flag) return GEOADV_OK;
     GA_HIP(hipMemset(ae->d.range_flag, 0, sizeof(int)));
-    set_error("%s: an encoder forward in the f16x2 arithmetic met an activation of 1023.5 or more (outside the fp16 range of its "
-              "scaled operands): the latents of the clouds concerned were set to +inf.  Use GEOADV_ENC_ARITH_BF16X3 for this model", who);
+    set_error("%s: an encoder forward in the f16x2 arithmetic met an activation outside the fp16 range of its scaled operands (1023.5 x "
+              "the magnitude its layer's batch-norm constants announce; layer scales 2^%d 2^%d 2^%d 2^%d): the latents of the clouds "
+              "concerned were set to +inf.  Use GEOADV_ENC_ARITH_BF16X3 for this model", who, ilogbf(ae->d.h2_act_scale[0]),
+              ilogbf(ae->d.h2_act_scale[1]), ilogbf(ae->d.h2_act_scale[2]), ilogbf(ae->d.h2_act_scale[3]));
     return GEOADV_ERANGE;
 }
 extern "C" int geoadv_ae_status(const geoadv_ae *ae, void *stream) {

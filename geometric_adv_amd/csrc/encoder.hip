@@ -458,21 +458,21 @@ __device__ __forceinline__ void encoder_bwd_tile(const DeviceAE &A, int n, const
             bufQ[row * 132 + c] = (v == zc && v > 0.f) ? gz * sc : 0.f;
         };
         if (A.enc_arith == GEOADV_ENC_ARITH_F16X2) {
-            xp_layer_lds<2, 1, ROWS>(bufQ, 68, A.enc_h2, A.h2_unscale[1], bn_relu(1, bufP, 132, m2, 128));
+            xp_layer_lds<2, 1, ROWS>(bufQ, 68, A.enc_h2, A.h2_act_scale[0], A.h2_unscale[1], bn_relu(1, bufP, 132, m2, 128));
             __syncthreads();
-            xp_layer_lds<2, 2, ROWS>(bufP, 132, A.enc_h2, A.h2_unscale[2], bn_relu(2, bufQ, 132, m3, 128));
+            xp_layer_lds<2, 2, ROWS>(bufP, 132, A.enc_h2, A.h2_act_scale[1], A.h2_unscale[2], bn_relu(2, bufQ, 132, m3, 128));
             __syncthreads();
-            xp_layer_lds<2, 3, ROWS>(bufQ, 132, A.enc_h2, A.h2_unscale[3], bn_relu(3, bufP, 260, m4, 256));
+            xp_layer_lds<2, 3, ROWS>(bufQ, 132, A.enc_h2, A.h2_act_scale[2], A.h2_unscale[3], bn_relu(3, bufP, 260, m4, 256));
             __syncthreads();
-            xp_layer_lds<2, 4, ROWS>(bufP, 260, A.enc_h2, A.h2_unscale[4], pool_grad);
+            xp_layer_lds<2, 4, ROWS>(bufP, 260, A.enc_h2, A.h2_act_scale[3], A.h2_unscale[4], pool_grad);
         } else {
-            xp_layer_lds<3, 1, ROWS>(bufQ, 68, A.enc_x3, 1.f, bn_relu(1, bufP, 132, m2, 128));
+            xp_layer_lds<3, 1, ROWS>(bufQ, 68, A.enc_x3, 1.f, 1.f, bn_relu(1, bufP, 132, m2, 128));
             __syncthreads();
-            xp_layer_lds<3, 2, ROWS>(bufP, 132, A.enc_x3, 1.f, bn_relu(2, bufQ, 132, m3, 128));
+            xp_layer_lds<3, 2, ROWS>(bufP, 132, A.enc_x3, 1.f, 1.f, bn_relu(2, bufQ, 132, m3, 128));
             __syncthreads();
-            xp_layer_lds<3, 3, ROWS>(bufQ, 132, A.enc_x3, 1.f, bn_relu(3, bufP, 260, m4, 256));
+            xp_layer_lds<3, 3, ROWS>(bufQ, 132, A.enc_x3, 1.f, 1.f, bn_relu(3, bufP, 260, m4, 256));
             __syncthreads();
-            xp_layer_lds<3, 4, ROWS>(bufP, 260, A.enc_x3, 1.f, pool_grad);
+            xp_layer_lds<3, 4, ROWS>(bufP, 260, A.enc_x3, 1.f, 1.f, pool_grad);
         }
     } else {
     fwd_layer<ROWS, 128, true>(bufQ, 68, bufP, 132, A.enc_fwd[1], A.scale[1], A.shift[1], m2, scratch);

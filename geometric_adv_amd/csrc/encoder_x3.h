@@ -19,12 +19,14 @@
 // The f16x2 arithmetic (round 6) is the same construction with TWO fp16 pieces per operand -- 11 + 11 significant bits, the
 // remainder below 2^-23 |x| -- and the three piece products of weight >= 2^-11 (a1 w0, a0 w1, a0 w0; a1 w1 <= 2^-22 dropped), each
 // exact in the fp32 accumulator (11 x 11 bits), on v_mfma_f32_32x32x16_f16: HALF the matrix instructions.  fp16 has five exponent
-// bits, so the operands are scaled by powers of two (exact): activations by 2^6 (H2_ACT_SCALE: the second piece of every
-// activation >= 2^-9 is a normal fp16 number; smaller ones keep an ABSOLUTE error <= 2^-31, the pipe honours fp16 subnormals),
-// a layer's weights so that the largest magnitude lies in [2^13, 2^14).  The scales ride in the constants of the epilogue
-// (scale' = scale / S_w, shift' = 2^6 shift: the next layer's scaled activation comes out of the same fma, bit for bit 2^6 times
-// the unscaled one).  Measured against float64 (tools/bf16x3_probe.py modes 5-7, profiles/r06_f16x2_probe.jsonl): rms error
-// 0.44-0.52 units of 2^-24 |a|.|w| -- the fp32 chain's.  RANGE: a scaled activation above 65504 (an activation >= 1023.5) would
+// bits, so the operands are scaled by powers of two (exact): layer j's activations by s_j = 2^6 / (the power of two nearest to
+// the rms of sqrt(gamma^2 + beta^2) over the layer's batch-norm channels -- what relu(gamma z + beta) puts out; 2^6 exactly for
+// gamma = 1, beta = 0: ae.hip) -- the second piece of every scaled activation >= 2^-3 is a normal fp16 number, smaller ones
+// keep an ABSOLUTE error <= 2^-25 / s_j, the pipe honours fp16 subnormals --, a layer's weights so that the largest magnitude
+// lies in [2^13, 2^14).  The scales ride in the constants of the epilogue (scale' = scale s_L / (s_{L-1} S_w), shift' = s_L
+// shift: the next layer's scaled activation comes out of the same fma, bit for bit s_L times the unscaled one).  Measured against float64 (tools/bf16x3_probe.py modes 5-7, profiles/r06_f16x2_probe.jsonl): rms error
+// 0.44-0.52 units of 2^-24 |a|.|w| -- the fp32 chain's.  RANGE: a scaled activation above 65504 (an activation >= 1023.5 x its
+// layer's batch-norm magnitude) would
 // round to an fp16 infinity; every epilogue keeps a running maximum (one v_max3_f32 per two values) and a workgroup that sees
 // one poisons its pool partial with +inf and raises DeviceAE::range_flag (geoadv_ae_status: GEOADV_ERANGE) -- never silent.
 #pragma once
@@ -46,7 +48,6 @@ __host__ __device__ constexpr int xp_step_words(int np) { return 4 * np * X3_FRA
 __host__ __device__ constexpr size_t xp_image_words(int np) { return (size_t)X3_STEPS * xp_step_words(np); }
 constexpr int X3_STEP_WORDS = xp_step_words(3);
 constexpr size_t X3_IMAGE_WORDS = xp_image_words(3), H2_IMAGE_WORDS = xp_image_words(2);
-constexpr float H2_ACT_SCALE = 64.f;          // 2^6: activations as the f16x2 forward carries them
 constexpr float H2_ACT_LIMIT = 65504.f;       // largest finite fp16: a scaled activation above it trips the range guard
 // the constants the forward keeps in LDS, as one block (DeviceAE::enc_x3_consts): W0 [3][64], scale0 [64], shift0 [64], then
 // [scale | shift] of layers 1 (128 + 128), 2 (128 + 128), 3 (256 + 256), 4 (128 + 128)
@@ -151,10 +152,10 @@ __device__ __forceinline__ const u32x4 *xp_frag_ptr(const unsigned *img, int ste
 // speed.  out[row][c] for ROWS rows (a multiple of 32); units (channel block, row block) dealt to the 8 waves; weights
 // straight from the global image.  epi(row, channel, value).  Must be called by every wave; no barrier inside.
 // ------------------------------------------------------------------------------------------
-// NP = 2: the rows are scaled by H2_ACT_SCALE on the way into the split and the result by `unscale` = 1 / (H2_ACT_SCALE S_w(L))
-// on the way out (powers of two: what the forward's folded constants do, bit for bit); NP = 3: unscale = 1.
+// NP = 2: the rows are scaled by `in_scale` = s_{L-1} on the way into the split and the result by `unscale` = 1 / (s_{L-1} S_w(L))
+// on the way out (powers of two: what the forward's folded constants do, bit for bit); NP = 3: both 1.
 template <int NP, int L, int ROWS, class Epi>
-__device__ __forceinline__ void xp_layer_lds(const float *in, int s_in, const unsigned *img, float unscale, Epi epi) {
+__device__ __forceinline__ void xp_layer_lds(const float *in, int s_in, const unsigned *img, float in_scale, float unscale, Epi epi) {
     constexpr int K = L == 1 ? 64 : L == 4 ? 256 : 128, NOUT = L == 3 ? 256 : 128;
     constexpr int OB = NOUT / 32, RB = ROWS / 32, UNITS = OB * RB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
@@ -175,7 +176,7 @@ __device__ __forceinline__ void xp_layer_lds(const float *in, int s_in, const un
             }
             if (NP == 2) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= H2_ACT_SCALE;
+                for (int j = 0; j < 8; ++j) v[j] *= in_scale;
             }
             XP<NP> a;
             float gmax = 0.f;                  // (the forward that made these activations already checked their range)

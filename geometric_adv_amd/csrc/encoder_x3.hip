@@ -121,7 +121,7 @@ __device__ __forceinline__ void x3_stage_constants(const float *consts, float *c
 
 // Layer 0 (fan-in 3) on the VALU: fwd_layer0's arithmetic (encoder.hip), 32 channels per lane = the k slots it feeds to layer 1.
 // m01: this lane's bits of mask words 0 and 1 (channel 16 kb + 8 h + j = bit (kb & 1) * 16 + 8 h + j of word kb / 2).
-// (f16x2: scale0 / shift0 arrive multiplied by H2_ACT_SCALE, v is the scaled activation; gmax: the range guard's running maximum)
+// (f16x2: scale0 / shift0 arrive multiplied by s_0, v is the scaled activation; gmax: the range guard's running maximum)
 template <int NP, bool MASKS>
 __device__ __forceinline__ void x3_layer0(const float *cst, const float (&pc)[3], int h, XP<NP> (&act1)[4], unsigned (&m01)[2], float &gmax) {
     const float4 *c4 = reinterpret_cast<const float4 *>(cst);

@@ -259,13 +259,15 @@ void geoadv_ae_destroy(geoadv_ae *ae);
  *   F16X2  : every operand as TWO fp16 pieces (11 + 11 bits; remainder < 2^-23) of power-of-two-scaled values, a product as its
  *            three piece products of weight >= 2^-11, each exact in the fp32 accumulator, on v_mfma_f32_32x32x16_f16: half of
  *            BF16X3's matrix instructions, the same error against float64 (profiles/r06_f16x2_probe.jsonl: 0.44-0.52 units of
- *            2^-24 |a|.|w| rms, the fp32 chain's).  Activations are carried times 2^6, a layer's weights times the power of two
- *            that puts the largest in [2^13, 2^14); RANGE: an activation of 1023.5 or more does not fit -- the kernels check
- *            every activation they split, and a cloud that has one gets +inf latents (so that nothing downstream looks sane)
- *            and raises the model's sticky flag: geoadv_ae_status / geoadv_attack_status then return GEOADV_ERANGE.  Batch-
- *            normalised ReLU activations are O(1-10); a model that trips the guard runs under BF16X3.  Not available (set
- *            refuses, the default falls back to BF16X3) for a model with a non-finite weight or a folded constant outside the
- *            normal fp32 range.
+ *            2^-24 |a|.|w| rms, the fp32 chain's).  A layer's activations are carried times a power of two s_j -- 2^6 for a
+ *            layer whose batch norm has gamma^2 + beta^2 = 1 on average, moved with that magnitude otherwise (what
+ *            relu(gamma z + beta) puts out) --, its weights times the power of two that puts the largest in [2^13, 2^14);
+ *            RANGE: an activation of 1023.5 x that magnitude or more does not fit (clouds far outside what the victim's
+ *            batch norms were made for) -- the kernels check every activation they split, and a cloud that has one gets
+ *            +inf latents (so that nothing downstream looks sane) and raises the model's sticky flag: geoadv_ae_status /
+ *            geoadv_attack_status then return GEOADV_ERANGE.  Such clouds run under BF16X3.  Not available (set refuses, the
+ *            default falls back to BF16X3) for a model with a non-finite weight or a folded constant outside the normal fp32
+ *            range.
  * All reproduce themselves bit for bit (forward, recomputing backward, any batch).  The default of handles created from
  * now on (AUTO, the initial setting: F16X2 where available, else BF16X3) / of one handle (set before it is shared with attack
  * handles or threads). */

@@ -146,71 +146,110 @@ def test_arithmetic_selection_api():
     assert a.encoder_arith == "bf16x3"
 
 
-def _scaled_model(n, factor, seed=9):
-    """randomized weights with layer 0's batch-norm gamma / beta multiplied by `factor` and layer 1's weights divided by it:
-    layer 0's activations grow by the factor, everything behind them stays what it was."""
-    from geometric_adv_amd import weights as W
-    w = dict(W.randomized_weights(n, seed=seed))
-    for k in ("autoencoder/encoder_conv_layer_0_bnorm/gamma", "autoencoder/encoder_conv_layer_0_bnorm/beta"):
-        w[k] = (np.asarray(w[k], dtype=np.float64) * factor).astype(np.float32)
-    k = "autoencoder/encoder_conv_layer_1/W"
-    w[k] = (np.asarray(w[k], dtype=np.float64) / factor).astype(np.float32)
-    return w
+def _f16x2_limits(canon):
+    """Largest activation each of layers 0..3 may hand on under f16x2: 65504 / s_j with s_j = 2^6 / (the power of two nearest to the
+    rms of sqrt(gamma^2 + beta^2) over the layer's channels) -- the rule of geoadv_ae_create (csrc/ae.hip), restated."""
+    lim = []
+    for g, be in zip(canon["gamma"][:4], canon["beta"][:4]):
+        t = np.sqrt(np.mean(np.asarray(g, np.float64) ** 2 + np.asarray(be, np.float64) ** 2))
+        lim.append(65504.0 / 2.0 ** (6 - int(np.round(np.log2(t)))))
+    return lim
+
+
+def _input_scale_for(model, limits, pc, target):
+    """The factor on the input coordinates at which the largest activation / limit ratio over layers 0..3 equals `target` (bisection on
+    the float64 model; far from the unit cube the activations grow with the factor)."""
+    def ratio(f):
+        hs = model.encode(pc.astype(np.float64) * f, keep=True)[1]
+        return max(float(h.max()) / l for h, l in zip(hs[:4], limits))
+    lo, hi = 1.0, 1e7
+    assert ratio(lo) < target < ratio(hi)
+    for _ in range(40):
+        mid = np.sqrt(lo * hi)
+        lo, hi = (mid, hi) if ratio(mid) < target else (lo, mid)
+    return float(lo)
 
 
 @pytest.mark.parametrize("b", [2, 40])
 def test_f16x2_range_guard_trips_loudly_and_only_when_it_must(b):
-    """Layer 0's activations scaled up: while the largest stays under 1023.5 f16x2 still agrees with the float64 model; beyond
-    it the forward gives +inf latents for the clouds concerned (never a plausible number), geoadv_ae_status reports
-    GEOADV_ERANGE once (the flag is cleared), transform() raises, and bf16x3 runs the same model."""
+    """Clouds far outside the unit cube the victim's batch norms were made for: while every layer's largest activation stays under
+    its limit (1023.5 x the magnitude the layer's gamma / beta announce) f16x2 still agrees with the float64 model; beyond it the
+    forward gives +inf latents for the clouds concerned (never a plausible number), geoadv_ae_status reports GEOADV_ERANGE once
+    (the flag is cleared), transform() / the attack's status / the defenses raise, and bf16x3 runs the same clouds."""
     import torch
     from geometric_adv_amd import _lib, weights as W
     from geometric_adv_amd.autoencoder import PointNetAE
     from oracle.attack_model import AEModel
     from conftest import cloud
     n = 2048
-    pc = cloud(71, b, n)
-    base = AEModel(W.canonical(W.randomized_weights(n, seed=9), n), n, np.float64)
-    h1 = np.maximum((pc.astype(np.float64) @ base.W[0] + base.b[0]) * base.scale[0] + base.offset[0], 0)
-    top = float(h1.max())
+    w = W.randomized_weights(n, seed=9)
+    canon = W.canonical(w, n)
+    model = AEModel(canon, n, np.float64)
+    limits = _f16x2_limits(canon)
+    one = cloud(71, 1, n)                                               # every cloud of the batch = the same points in another order:
+    rng = np.random.default_rng(5)                                      # the same activations, so one bisection on one cloud serves all
+    pc = np.concatenate([one[:, rng.permutation(n)] for _ in range(b)])
     lib = _lib.lib()
+    ae = PointNetAE(w, n, encoder_arith="f16x2")
     # just inside the range
-    f_in = 900.0 / top
-    w_in = _scaled_model(n, f_in)
-    ae = PointNetAE(w_in, n, encoder_arith="f16x2")
-    z = ae.forward(pc, want_recon=False)[1].cpu().numpy()
+    pc_in = (pc * np.float32(_input_scale_for(model, limits, one, 0.85))).astype(np.float32)
+    z = ae.forward(pc_in, want_recon=False)[1].cpu().numpy()
     assert lib.geoadv_ae_status(ae.handle, _lib.stream_handle()) == 0
-    z64 = AEModel(W.canonical(w_in, n), n, np.float64).encode(pc.astype(np.float64))
+    z64 = model.encode(pc_in.astype(np.float64))
     np.testing.assert_allclose(z / np.abs(z64).max(), z64 / np.abs(z64).max(), atol=2e-6)
     # beyond it
-    f_out = 1100.0 / top
-    w_out = _scaled_model(n, f_out)
-    ae = PointNetAE(w_out, n, encoder_arith="f16x2")
-    z = ae.forward(pc, want_recon=False)[1].cpu().numpy()
+    pc_out = (pc * np.float32(_input_scale_for(model, limits, one, 1.1))).astype(np.float32)
+    z = ae.forward(pc_out, want_recon=False)[1].cpu().numpy()
     assert np.isinf(z).any() and not np.isnan(z).any()
     assert lib.geoadv_ae_status(ae.handle, _lib.stream_handle()) == 4          # GEOADV_ERANGE
     assert b"f16x2" in lib.geoadv_last_error()
     assert lib.geoadv_ae_status(ae.handle, _lib.stream_handle()) == 0          # reported once
     with pytest.raises(RuntimeError, match="f16x2"):
-        ae.transform(pc)
-    # the attack on such a model: status() (which attack() calls before it returns anything) raises, defend_* raise
+        ae.transform(pc_out)
+    # the attack on such clouds: status() (which attack() calls before it returns anything) raises, defend_* raise
     from geometric_adv_amd._lib import GeoAdvError
     from geometric_adv_amd.adv_ae import AdvAE, Configuration
     from geometric_adv_amd import defense
-    at = AdvAE("a", Configuration(batch_size=b, n_points=n, weights=w_out, num_iterations=2, num_iterations_thresh=1), ae=ae)
-    at.set_inputs(pc, cloud(72, b, n), None, 1.0)
+    at = AdvAE("a", Configuration(batch_size=b, n_points=n, weights=w, num_iterations=2, num_iterations_thresh=1), ae=ae)
+    at.set_inputs(pc_out, pc_out[::-1].copy(), None, 1.0)
     at.init_pert(None, reset_optimizer=True)
     at.run(0, 2, 1, torch.empty((2, 6, b), device=ae.device))
     with pytest.raises(GeoAdvError, match="f16x2"):
         at.status()
     at.status()                                                         # (cleared)
     with pytest.raises(GeoAdvError, match="f16x2"):
-        defense.defend_critical(ae, pc, pc)
+        defense.defend_critical(ae, pc_out, pc_out)
     del at
-    ae3 = PointNetAE(w_out, n, encoder_arith="bf16x3")
-    z3 = ae3.transform(pc)
-    z64 = AEModel(W.canonical(w_out, n), n, np.float64).encode(pc.astype(np.float64))
+    ae3 = PointNetAE(w, n, encoder_arith="bf16x3")
+    z3 = ae3.transform(pc_out)
+    z64 = model.encode(pc_out.astype(np.float64))
     np.testing.assert_allclose(z3 / np.abs(z64).max(), z64 / np.abs(z64).max(), atol=2e-6)
+
+
+@pytest.mark.parametrize("log2_gamma", [-20, -8, 8])
+def test_f16x2_activation_scale_follows_the_batch_norm(log2_gamma):
+    """Layer 0's gamma and beta multiplied by 2^k and layer 1's weights divided by it: layer 0's activations are 2^k times what
+    they were, everything behind them is unchanged -- and so is f16x2's accuracy, because the power of two a layer's activations are
+    carried times follows the layer's own batch-norm constants (with the fixed 2^6 of the first build the latent was 6e-4 off at
+    k = -20: tools/debug/h2_low_side.py)."""
+    from geometric_adv_amd import _lib, weights as W
+    from geometric_adv_amd.autoencoder import PointNetAE
+    from oracle.attack_model import AEModel
+    from conftest import cloud
+    n, b = 1024, 6
+    f = np.float64(2.0) ** log2_gamma
+    w = dict(W.randomized_weights(n, seed=9))
+    for k in ("autoencoder/encoder_conv_layer_0_bnorm/gamma", "autoencoder/encoder_conv_layer_0_bnorm/beta"):
+        w[k] = (np.asarray(w[k], dtype=np.float64) * f).astype(np.float32)
+    k = "autoencoder/encoder_conv_layer_1/W"
+    w[k] = (np.asarray(w[k], dtype=np.float64) / f).astype(np.float32)
+    pc = cloud(73, b, n)
+    ae = PointNetAE(w, n)
+    assert ae.encoder_arith == "f16x2"
+    z = ae.transform(pc)
+    z64 = AEModel(W.canonical(w, n), n, np.float64).encode(pc.astype(np.float64))
+    np.testing.assert_allclose(z / np.abs(z64).max(), z64 / np.abs(z64).max(), atol=2e-6)
+    assert _lib.lib().geoadv_ae_status(ae.handle, _lib.stream_handle()) == 0
 
 
 def test_f16x2_is_refused_for_a_model_that_does_not_scale():
