@@ -555,10 +555,15 @@ __device__ __forceinline__ void mx_scan_block(const MxView &v, unsigned *lds, Ou
     // rows of several stages leave now: their running minimum is complete (each entry was written by the lane that reads it, or by
     // a lane of the same wave: program order)
     if (S > 1) {
+        // (the lane's row inside its wave's tiles, derived afresh: kept alive across the stage loop it was the one register the
+        // NCT = 8 instantiation spilled -- and a kernel with a scratch segment costs microseconds to launch)
+        int t2 = threadIdx.x;
+        asm volatile("" : "+v"(t2));
+        const int sr2 = (t2 & 63) >> 2, rowin2 = 8 * (sr2 >> 2) + 4 * ((t2 >> 1) & 1) + (sr2 & 3), wrow2 = (t2 >> 6) * MX_WROWS + rowin2;
 #pragma unroll
         for (int r = 0; r < MX_RT; ++r) {
-            const int jrow = wave * MX_WROWS + r * 32 + rowin;
-            if (half == 0 && v.rt * MX_ROWS + jrow < n)
+            const int jrow = wrow2 + r * 32;
+            if ((t2 & 1) == 0 && v.rt * MX_ROWS + jrow < n)
                 out_row(v.rt * MX_ROWS + jrow, __uint_as_float((unsigned)(rbest[jrow] >> 32)), cbase + (int)(unsigned)rbest[jrow]);
         }
     }

@@ -349,20 +349,31 @@ __global__ __launch_bounds__(MX_THREADS, 2) void chamfer_mx_kernel(ChamferSymArg
     v.P = pr.p + (size_t)cp * n * 3; v.Q = pr.q + (size_t)cq * m * 3;
     v.n = n; v.m = m; v.rt = rt; v.cs = cs; v.C = a.C; v.S = a.S;
     const int rslices = a.cslices;
+    // The results leave through buffer stores: a uniform base (this workgroup's row of the output or of the partials: scalar
+    // registers) and a 32-bit lane offset.  As plain pointer stores the four per-lane 64-bit addresses were hoisted out of the
+    // stage loop and, at 256 registers, spilled -- the only scratch segment among the loop's kernels.
+    float *row_d = rslices == 1 ? pr.dist1 + (size_t)c * n : a.rowpart_d + (((size_t)pi * a.clouds + c) * rslices + cs) * n;
+    int *row_i = rslices == 1 ? pr.idx1 + (size_t)c * n : a.rowpart_i + (((size_t)pi * a.clouds + c) * rslices + cs) * n;
+    float *col_d = a.rtiles == 1 ? pr.dist2 + (size_t)c * m : a.colpart_d + (((size_t)pi * a.clouds + c) * a.rtiles + rt) * m;
+    int *col_i = a.rtiles == 1 ? pr.idx2 + (size_t)c * m : a.colpart_i + (((size_t)pi * a.clouds + c) * a.rtiles + rt) * m;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(row_d, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(row_i, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cd = __builtin_amdgcn_make_buffer_rsrc(col_d, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ci = __builtin_amdgcn_make_buffer_rsrc(col_i, 0, 0x7fffffff, 0x00020000);
+    const bool row_atomic = rslices != 1 && a.row64 != nullptr;
+    // (j / k made opaque where they are used: the byte offsets are loop-invariant per lane and would be hoisted -- and spilled -- too)
     auto out_row = [&](int j, float d, int i) {
-        if (rslices == 1) { pr.dist1[(size_t)c * n + j] = d; pr.idx1[(size_t)c * n + j] = i; }
-        else if (a.row64) atomicMin(&a.row64[((size_t)pi * a.clouds + c) * n + j], sym_pack(d, i));
+        asm volatile("" : "+v"(j));
+        if (row_atomic) atomicMin(&a.row64[((size_t)pi * a.clouds + c) * n + j], sym_pack(d, i));
         else {
-            const size_t o = (((size_t)pi * a.clouds + c) * rslices + cs) * n + j;
-            a.rowpart_d[o] = d; a.rowpart_i[o] = i;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), rd, (unsigned)j * 4u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, ri, (unsigned)j * 4u, 0, 0);
         }
     };
     auto out_col = [&](int k, float d, int i) {
-        if (a.rtiles == 1) { pr.dist2[(size_t)c * m + k] = d; pr.idx2[(size_t)c * m + k] = i; }
-        else {
-            const size_t o = (((size_t)pi * a.clouds + c) * a.rtiles + rt) * m + k;
-            a.colpart_d[o] = d; a.colpart_i[o] = i;
-        }
+        asm volatile("" : "+v"(k));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), cd, (unsigned)k * 4u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, ci, (unsigned)k * 4u, 0, 0);
     };
 #ifdef GA_STAMPS
     unsigned long long clk0_, clk1_;                               // diagnostic build: the shader clock over the scan (s_memtime counts core cycles)
